@@ -1,0 +1,211 @@
+/*
+ * libymk — C-ABI boundary of the MI355X-native YOLO-Master detection forward pass.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes + a
+ * HIP stream (passed as void*), returns 0 on success or a negative YMK_E_*
+ * code, never throws, never allocates, never synchronises the stream.
+ * Workspaces are sized by the matching *_workspace_bytes() query and are
+ * owned by the caller.  Device-side error conditions (non-finite router
+ * input, candidate overflow) are reported through caller-provided int32
+ * `flags`/`status` words that the host checks once per batch.
+ *
+ * The reference (Tencent/YOLO-Master) has no native op on this path; each
+ * function below states the Python reference interface (file:line under the
+ * reference checkout) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes stub a maintainer would add on the reference side.
+ *
+ * Layout convention: activations are NHWC ("pixel-major"): element (b,y,x,c)
+ * of a tensor view lives at base[((b*H + y)*W + x) * ld + c]; `ld` (the pixel
+ * stride, in elements) may exceed C so that a view can be a channel slice of
+ * a wider concat buffer.  Weights are pre-packed by ymk_pack_* helpers on the
+ * host side (python: yolo_master_amd/engine.py) as [Cout][Kpad] with
+ * K = (ky, kx, cin) and BatchNorm already folded (fp32 fold, then cast).
+ */
+#ifndef YMK_H_
+#define YMK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YMK_ABI_VERSION 1
+
+/* error codes */
+#define YMK_OK 0
+#define YMK_E_BADARG (-1)    /* unsupported shape / alignment / dtype      */
+#define YMK_E_LAUNCH (-2)    /* hipLaunchKernel reported an error           */
+#define YMK_E_WORKSPACE (-3) /* workspace too small                         */
+
+/* dtypes of activations / packed weights */
+#define YMK_F32 0
+#define YMK_BF16 1
+
+/* activation codes for fused epilogues */
+#define YMK_ACT_NONE 0
+#define YMK_ACT_SILU 1
+
+/* device flag bits (int32 words written with atomicOr by kernels) */
+#define YMK_FLAG_NONFINITE_INPUT 1  /* router input contains NaN/Inf  (routers.py:51)  */
+#define YMK_FLAG_NONFINITE_LOGITS 2 /* router logits contain NaN/Inf  (routers.py:467) */
+#define YMK_FLAG_NMS_OVERFLOW 4     /* more than max_nms candidates in one image       */
+
+int ymk_abi_version(void);
+/* human readable build string (arch, compiler) — static storage */
+const char* ymk_build_info(void);
+
+/* ------------------------------------------------------------------------
+ * Convolution (implicit GEMM on MFMA) + folded-BN bias + SiLU + residual.
+ * Replaces Conv.forward_fuse = act(conv2d(x, W', b'))
+ *   ultralytics/nn/modules/conv.py:80-89, BN fold utils/torch_utils.py:315-349,
+ * and the residual add of Bottleneck.forward (nn/modules/block.py:484-486),
+ * ABlock.forward (block.py:1787-1797).
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t dtype;     /* YMK_F32 | YMK_BF16: type of x, w, residual                 */
+    int32_t out_dtype; /* type of y (YMK_F32 allowed with bf16 compute)              */
+    int32_t B, H, W;   /* input batch / height / width                               */
+    int32_t Cin, Cout; /* Cin % 8 == 0 (bf16) or % 4 == 0 (f32); Cout % 4 == 0       */
+    int32_t ksize;     /* 1 or 3 (square), padding = ksize/2 (conv.py:30-36 autopad) */
+    int32_t stride;    /* 1 or 2                                                     */
+    int32_t ldx, ldy, ldr; /* pixel strides (elements) of x, y, residual             */
+    int32_t Kpad;      /* packed row length of w, multiple of 64, >= ksize^2*Cin     */
+    int32_t act;       /* YMK_ACT_*                                                  */
+} ymk_conv_desc;
+
+int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, const float* bias,
+               const void* residual /* may be NULL */, void* y, void* stream);
+
+/* Stem convolution reading the NCHW fp32 network input directly (Cin <= 4) and
+ * writing NHWC.  Replaces layer 0 `Conv(3, c, 3, 2)` (cfg yolo-master-*.yaml,
+ * conv.py:80-89) together with the NCHW->NHWC layout change.
+ * w: fp32 [Cout][ksize*ksize*Cin] (ky,kx,cin), bias fp32 [Cout]. */
+int ymk_conv2d_stem_nchw(const float* x_nchw, const float* w, const float* bias, void* y,
+                         int32_t out_dtype, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                         int32_t Cout, int32_t ksize, int32_t stride, int32_t ldy, int32_t act,
+                         void* stream);
+
+/* ------------------------------------------------------------------------
+ * Depthwise k x k convolution (stride 1, pad k/2, k odd <= 15) + bias + act
+ * + residual.  Replaces DWConv (conv.py:185-199; Detect cv3 head.py:111-118),
+ * AAttn.pe (block.py:1688,1731) and the depthwise stage of
+ * DepthwiseSeparableConv (moe/experts.py:283-292).
+ * w: packed [k*k][C] in `dtype`; bias fp32 [C] or NULL.
+ * ------------------------------------------------------------------------ */
+int ymk_dwconv2d(int32_t dtype, const void* x, const void* w, const float* bias,
+                 const void* residual, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                 int32_t ksize, int32_t ldx, int32_t ldy, int32_t ldr, int32_t act, void* stream);
+
+/* ------------------------------------------------------------------------
+ * ES-MoE (ultralytics/nn/modules/moe/modules.py:410-704)
+ * ------------------------------------------------------------------------ */
+
+/* Router: global-average-pool -> 1x1 (C->hidden) -> SiLU -> 1x1 (hidden->E) ->
+ * softmax(fp32, logits clamped to +-30) -> top-k -> stable_normalize
+ * (DynamicRoutingLayer.forward routers.py:458-496, _hard_top_k :519-527,
+ *  stable_normalize _numeric.py:85-90), followed by the sparse-dispatch decision
+ * of ES_MOE._sparse_forward (modules.py:665-684): retained = rank0 | (w >=
+ * dynamic_threshold), renormalise over the retained set, and the
+ * image->expert CSR permutation built with wave ballots / prefix scans.
+ *
+ * Outputs (all device memory):
+ *   route_w   fp32 [B][E]   routing weights before pruning (hard top-k, sums to 1)
+ *   gate_w    fp32 [B][E]   retained & renormalised weights (0 where pruned)
+ *   sel       int32 [B][top_k] expert id per slot in ascending expert order, -1 = unused
+ *   csr_off   int32 [E+1]   expert -> range in csr_pair
+ *   csr_pair  int32 [B*top_k] packed (b*top_k + slot), grouped by expert, b ascending
+ *   flags     int32 [1]     YMK_FLAG_NONFINITE_* bits (atomicOr)
+ * workspace: ymk_esmoe_route_workspace_bytes(B, C, H, W) (partial pooling sums).
+ */
+size_t ymk_esmoe_route_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
+int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
+                    int32_t ldx, const float* w1 /*[hidden][C]*/, const float* b1,
+                    const float* w2 /*[E][hidden]*/, const float* b2, int32_t hidden, int32_t E,
+                    int32_t top_k, float dynamic_threshold, float* route_w, float* gate_w,
+                    int32_t* sel, int32_t* csr_off, int32_t* csr_pair, int32_t* flags,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Depthwise stage of the retained experts, dispatched over the CSR pairs
+ * (experts.py:283-292, modules.py:690-697).  dw_w is one blob holding every
+ * expert's [k_e*k_e][C] filter at element offset dw_off[e]; ksizes[e] odd <= 15.
+ * Output: dw_out[pair][H][W][C] (pair = b*top_k + slot), dense (ld = C). */
+int ymk_esmoe_dw(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
+                 int32_t ldx, const void* dw_w, const int32_t* dw_off, const int32_t* ksizes,
+                 int32_t E, int32_t top_k, const int32_t* sel, const int32_t* csr_off,
+                 const int32_t* csr_pair, void* dw_out, void* stream);
+
+/* Pointwise stage: grouped GEMM on MFMA over the retained experts of each image,
+ * epilogue SiLU(BN_e(.)) * gate_w accumulated in ascending expert order, then the
+ * trailing ES_MOE.norm (BN + SiLU) — experts.py:293-296, modules.py:697-702,:581.
+ * pw_w: [E][Cout][Kpad] (BN_e folded), pw_b: fp32 [E][Cout];
+ * norm_scale/norm_shift: fp32 [Cout] (eval BatchNorm as y*s+t). */
+int ymk_esmoe_pw(int32_t dtype, const void* dw_out, int32_t B, int32_t H, int32_t W, int32_t C,
+                 int32_t Cout, int32_t Kpad, const void* pw_w, const float* pw_b,
+                 const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
+                 const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Area attention core: softmax(q^T k / sqrt(d)) v per (image, area, head)
+ * (AAttn.forward block.py:1696-1726).  qkv is the NHWC output of the qkv 1x1
+ * conv with output channels re-ordered at pack time to [Q | K | V], each
+ * [heads][head_dim]; areas are `area` equal contiguous token ranges of H*W.
+ * head_dim must be 32.  out: [B][H*W][heads*32] view with pixel stride ldo.
+ * ------------------------------------------------------------------------ */
+int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, int32_t B,
+                  int32_t N /*tokens = H*W*/, int32_t heads, int32_t area, void* stream);
+
+/* nearest 2x upsample (nn.Upsample(None, 2, "nearest"), yaml head) into a channel slice */
+int ymk_upsample2x(int32_t dtype, const void* x, void* y, int32_t B, int32_t H, int32_t W,
+                   int32_t C, int32_t ldx, int32_t ldy, void* stream);
+/* channel-slice copy (Concat.forward conv.py:629-641 when a producer could not write in place) */
+int ymk_copy_channels(int32_t dtype, const void* x, void* y, int64_t npix, int32_t C, int32_t ldx,
+                      int32_t ldy, void* stream);
+/* NHWC (any ld) -> dense NCHW fp32, for the module-level API and feature taps */
+int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int32_t HW, int32_t C,
+                         int32_t ldx, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Detect decode: DFL softmax-expectation + dist2bbox(xywh) * stride + sigmoid
+ * (Detect._inference head.py:173-194, DFL.forward block.py:81-84,
+ *  make_anchors/dist2bbox utils/tal.py:398-423).
+ * box_l / cls_l: fp32 NHWC logits of one level: [B][H_l*W_l][4*reg_max] / [..][nc].
+ * y: fp32 [B][4+nc][A_total]; this call fills anchors [a_off, a_off + H_l*W_l).
+ * ------------------------------------------------------------------------ */
+int ymk_detect_decode(const float* box_l, const float* cls_l, float* y, int32_t B, int32_t Hl,
+                      int32_t Wl, int32_t reg_max, int32_t nc, float stride, int32_t a_off,
+                      int32_t A_total, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Batched NMS: non_max_suppression (utils/nms.py:13-171) with TorchNMS.nms
+ * greedy semantics (nms.py:245-302): candidates conf > thres (best class, or
+ * every class when multi_label), stable score-descending order, cap max_nms,
+ * class offset cls*max_wh, suppress IoU > iou_thres, first max_det kept.
+ * y: fp32 [B][4+nc][A] as produced by ymk_detect_decode (not modified).
+ * out_dets fp32 [B][max_det][6] (x1,y1,x2,y2,conf,cls); out_counts int32 [B];
+ * out_idx int32 [B][max_det] anchor index of each kept detection
+ * (return_idxs=True of the reference); status int32 [1] YMK_FLAG_NMS_OVERFLOW.
+ * ------------------------------------------------------------------------ */
+size_t ymk_nms_workspace_bytes(int32_t B, int32_t nc, int32_t A, int32_t multi_label,
+                               int32_t max_nms);
+int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A, float conf_thres,
+                    float iou_thres, int32_t multi_label, int32_t agnostic, int32_t max_det,
+                    int32_t max_nms, float max_wh, float* out_dets, int32_t* out_counts,
+                    int32_t* out_idx, int32_t* status, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Cluster-weighted box refinement (CW-NMS).  Not implemented in the reference's
+ * Python; algorithm spec = examples/YOLO-Master-Cross-Platform-Edge-Deployment/
+ * cpp/src/common.cpp:150-185 (fp64 accumulation, pool = top-3000 candidates).
+ * Must be called right after ymk_nms_batched with the same workspace and the same
+ * (B, nc, A, multi_label, max_nms) so that the workspace layout matches;
+ * rewrites out_dets[..][0:4] in place, keep-set/order/scores/classes unchanged. */
+int ymk_cw_refine(int32_t B, int32_t nc, int32_t A, int32_t multi_label, int32_t max_nms, int32_t max_det,
+                  float iou_thres, float sigma, int32_t pool_cap, float* out_dets,
+                  const int32_t* out_counts, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YMK_H_ */

@@ -1,0 +1,111 @@
+"""ctypes binding of libymk.so — the C-ABI boundary (include/ymk.h).
+
+The library is hand-written HIP for gfx950; there is no CPU or PyTorch fallback.  If the
+shared object is missing or a symbol declared in include/ymk.h is not exported, importing
+an op raises immediately (``YmkLibraryError``) instead of silently degrading.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+__all__ = ["lib", "load", "YmkLibraryError", "ConvDesc", "check", "LIB_PATH", "SYMBOLS"]
+
+LIB_PATH = Path(__file__).resolve().parent / "libymk.so"
+
+YMK_F32, YMK_BF16 = 0, 1
+ACT_NONE, ACT_SILU = 0, 1
+FLAG_NONFINITE_INPUT, FLAG_NONFINITE_LOGITS, FLAG_NMS_OVERFLOW = 1, 2, 4
+
+
+class YmkLibraryError(RuntimeError):
+    """libymk.so is missing / stale; the MI355X-native path cannot run."""
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``ymk_conv_desc`` (include/ymk.h)."""
+
+    _fields_ = [
+        ("dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32),
+        ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
+        ("Kpad", C.c_int32), ("act", C.c_int32),
+    ]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every function declared in include/ymk.h
+SYMBOLS = {
+    "ymk_abi_version": (C.c_int, []),
+    "ymk_build_info": (C.c_char_p, []),
+    "ymk_conv2d": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ymk_conv2d_stem_nchw": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_dwconv2d": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_esmoe_route_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "ymk_esmoe_route": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ymk_esmoe_dw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ymk_esmoe_pw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
+                               _vp, _i32, _vp]),
+    "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_upsample2x": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_copy_channels": (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "ymk_nhwc_to_nchw_f32": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_detect_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "ymk_nms_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "ymk_nms_batched": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
+                                  _vp, _sz, _vp]),
+    "ymk_cw_refine": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load(path: os.PathLike | None = None) -> C.CDLL:
+    """Load libymk.so (once) and bind every C-ABI symbol; raise loudly when unavailable."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise YmkLibraryError(
+            f"{p} not found: build it with `python -m yolo_master_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU/PyTorch fallback for the ymk forward path."
+        )
+    # torch ships its own libamdhip64.so.7; import it first so both share one HIP runtime
+    import torch  # noqa: F401
+
+    try:
+        h = C.CDLL(str(p))
+    except OSError as e:  # pragma: no cover
+        raise YmkLibraryError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise YmkLibraryError(f"{p} does not export {name}; rebuild libymk") from e
+        fn.restype, fn.argtypes = res, args
+    if h.ymk_abi_version() != 1:
+        raise YmkLibraryError(f"{p}: ABI version {h.ymk_abi_version()} != 1")
+    if path is None:
+        _lib = h
+    return h
+
+
+class _Lazy:
+    def __getattr__(self, k):
+        return getattr(load(), k)
+
+
+lib = _Lazy()
+
+_ERR = {-1: "YMK_E_BADARG (unsupported shape/alignment/dtype)", -2: "YMK_E_LAUNCH", -3: "YMK_E_WORKSPACE"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libymk {what} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,179 @@
+// Area attention core on MFMA: out = softmax(q^T k / sqrt(d)) v per (image, area, head).
+// Reference: AAttn.forward (ultralytics/nn/modules/block.py:1696-1726): the two matmuls
+// `attn = (q*scale)^T @ k`, `softmax(-1)`, `x = v @ attn^T` over N/area tokens, head_dim 32.
+//
+// Structure: workgroup = 64 queries (4 waves x 16) of one (image, area, head); keys/values
+// are streamed in chunks of 256 tokens through LDS (K row-major, V transposed) with an
+// online softmax across chunks.  S^T = K Q^T is computed with keys as MFMA rows, so the
+// softmax reduction over keys is lane-local plus two cross-lane steps, and P feeds the
+// second MFMA (O^T = V^T P^T) straight from registers (the k-slot permutation induced by the
+// accumulator layout is applied identically to the V^T operand).
+#include "igemm.h"
+
+#define AT_KC 256
+
+template <typename T>
+__global__ __launch_bounds__(256) void area_attn_kernel(const T* __restrict__ qkv, int ldq, T* __restrict__ out,
+                                                       int ldo, int N, int Na, int heads, int area, float scale) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int NF = sizeof(T) == 2 ? 1 : 2;  // 16-byte fragments per 32-wide head row per lane
+    constexpr int VPAD = AT_KC + VEC;
+    constexpr bool PRECISE = sizeof(T) == 4;
+    __shared__ __attribute__((aligned(16))) T sK[AT_KC * 32];
+    __shared__ __attribute__((aligned(16))) T sVt[32 * VPAD];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fi = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z / area, ar = blockIdx.z % area;
+    const int tok0 = ar * Na;  // first token of this area inside the image
+    const int Cq = heads * 32;
+    const T* base = qkv + (size_t)b * N * ldq;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const bool wave_on = q0 < Na;
+
+    // query fragment(s): B operand, lane (query fi, k-group g)
+    u32x4 qf[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        qf[f] = u32x4{0u, 0u, 0u, 0u};
+        if (wave_on && q0 + fi < Na)
+            qf[f] = *reinterpret_cast<const u32x4*>(base + (size_t)(tok0 + q0 + fi) * ldq + h * 32 + f * 16 + g * VEC);
+    }
+
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float mrun = -INFINITY, lrun = 0.f;
+
+    for (int c0 = 0; c0 < Na; c0 += AT_KC) {
+        const int kc = min(AT_KC, Na - c0);
+        const int kc32 = (kc + 31) & ~31;  // processed keys (zero padded)
+        __syncthreads();                   // previous chunk fully consumed
+        // stage K (row-major [key][32]) and V (transposed [d][key])
+        constexpr int CPR = 32 / VEC;  // 16-byte chunks per row
+        for (int i = t; i < kc32 * CPR; i += 256) {
+            const int key = i / CPR, ch = i % CPR;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (key < kc) {
+                const T* p = base + (size_t)(tok0 + c0 + key) * ldq + h * 32 + ch * VEC;
+                kv = *reinterpret_cast<const u32x4*>(p + Cq);
+                vv = *reinterpret_cast<const u32x4*>(p + 2 * Cq);
+            }
+            *reinterpret_cast<u32x4*>(&sK[key * 32 + ch * VEC]) = kv;
+            const T* ve = reinterpret_cast<const T*>(&vv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) sVt[(ch * VEC + q) * VPAD + key] = ve[q];
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+
+        const int ntile = kc32 / 16;
+        f32x4 sacc[AT_KC / 16];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int tk = 0; tk < AT_KC / 16; ++tk) {
+            if (tk < ntile) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(&sK[(tk * 16 + fi) * 32 + f * 16 + g * VEC]);
+                    mma16<T>(acc, kf, qf[f]);
+                }
+                const int key0 = tk * 16 + g * 4;
+                acc.x = key0 + 0 < kc ? acc.x * scale : -INFINITY;
+                acc.y = key0 + 1 < kc ? acc.y * scale : -INFINITY;
+                acc.z = key0 + 2 < kc ? acc.z * scale : -INFINITY;
+                acc.w = key0 + 3 < kc ? acc.w * scale : -INFINITY;
+                cmax = fmaxf(cmax, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
+                sacc[tk] = acc;
+            }
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float mnew = fmaxf(mrun, cmax);  // finite: every chunk has >= 1 valid key
+        const float resc = PRECISE ? expf(mrun - mnew) : __expf(mrun - mnew);
+        mrun = mnew;
+        lrun *= resc;
+        o[0] *= resc;
+        o[1] *= resc;
+        float lsum = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < AT_KC / 16; ++tk) {
+            if (tk < ntile) {
+                f32x4 p = sacc[tk];
+                if (PRECISE) {
+                    p.x = expf(p.x - mnew); p.y = expf(p.y - mnew); p.z = expf(p.z - mnew); p.w = expf(p.w - mnew);
+                } else {
+                    p.x = __expf(p.x - mnew); p.y = __expf(p.y - mnew); p.z = __expf(p.z - mnew); p.w = __expf(p.w - mnew);
+                }
+                lsum += (p.x + p.y) + (p.z + p.w);
+                sacc[tk] = p;
+            }
+        }
+        lrun += lsum;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int u = 0; u < AT_KC / 32; ++u) {
+                if (2 * u < ntile) {
+                    u32x4 pb;
+                    pb.x = pack_bf16x2(sacc[2 * u].x, sacc[2 * u].y);
+                    pb.y = pack_bf16x2(sacc[2 * u].z, sacc[2 * u].w);
+                    pb.z = pack_bf16x2(sacc[2 * u + 1].x, sacc[2 * u + 1].y);
+                    pb.w = pack_bf16x2(sacc[2 * u + 1].z, sacc[2 * u + 1].w);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const T* vr = &sVt[(dt * 16 + fi) * VPAD + g * 4];
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + (2 * u) * 16);
+                        const u32x2 hi = *reinterpret_cast<const u32x2*>(vr + (2 * u + 1) * 16);
+                        const u32x4 va = {lo.x, lo.y, hi.x, hi.y};
+                        mma16<T>(o[dt], va, pb);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tk = 0; tk < AT_KC / 16; ++tk) {
+                if (tk < ntile) {
+                    u32x4 pb;
+                    pb.x = __float_as_uint(sacc[tk].x); pb.y = __float_as_uint(sacc[tk].y);
+                    pb.z = __float_as_uint(sacc[tk].z); pb.w = __float_as_uint(sacc[tk].w);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const u32x4 va = *reinterpret_cast<const u32x4*>(&sVt[(dt * 16 + fi) * VPAD + tk * 16 + g * 4]);
+                        mma16<T>(o[dt], va, pb);
+                    }
+                }
+            }
+        }
+    }
+    if (!wave_on) return;
+    lrun += __shfl_xor(lrun, 16);
+    lrun += __shfl_xor(lrun, 32);
+    if (q0 + fi < Na) {
+        const float inv = 1.0f / lrun;
+        T* op = out + (size_t)(b * (size_t)N + tok0 + q0 + fi) * ldo + h * 32 + g * 4;
+        store4(op, o[0].x * inv, o[0].y * inv, o[0].z * inv, o[0].w * inv);
+        store4(op + 16, o[1].x * inv, o[1].y * inv, o[1].z * inv, o[1].w * inv);
+    }
+}
+
+extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, int32_t B,
+                             int32_t N, int32_t heads, int32_t area, void* stream) {
+    if (!qkv || !out || heads < 1 || area < 1 || N % area) return YMK_E_BADARG;
+    const int vec = dtype == YMK_BF16 ? 8 : 4;
+    if (ldq % vec || ldo % 4) return YMK_E_BADARG;
+    if (B <= 0 || N <= 0) return YMK_OK;
+    const int Na = N / area;
+    if ((int64_t)B * area > 65535 || heads > 65535) return YMK_E_BADARG;
+    dim3 grid((Na + 63) / 64, heads, B * area), blk(256);
+    const float scale = 0.17677669529663687f;  // 32^-0.5
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == YMK_F32)
+        hipLaunchKernelGGL(area_attn_kernel<float>, grid, blk, 0, s, (const float*)qkv, ldq, (float*)out, ldo, N, Na,
+                           heads, area, scale);
+    else if (dtype == YMK_BF16)
+        hipLaunchKernelGGL(area_attn_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N,
+                           Na, heads, area, scale);
+    else
+        return YMK_E_BADARG;
+    return ymk_launch_status();
+}

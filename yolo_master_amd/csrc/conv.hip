@@ -1,0 +1,211 @@
+// Fused Conv + folded-BN bias + SiLU (+ residual) as implicit GEMM on MFMA.
+// Reference semantics: Conv.forward_fuse (ultralytics/nn/modules/conv.py:80-89)
+// after fuse_conv_and_bn (ultralytics/utils/torch_utils.py:315-349).
+#include "igemm.h"
+
+struct ConvArgs {
+    const void* x;
+    const void* w;
+    const float* bias;
+    const void* res;
+    void* y;
+    int B, H, W, Ho, Wo, Cin, Cout, stride, ldx, ldy, ldr, Kpad, act, out_f32;
+    int64_t M;  // B*Ho*Wo
+};
+
+template <typename T, bool PRECISE>
+__device__ __forceinline__ float act_silu(float v) {
+    return PRECISE ? silu_exact(v) : silu_f(v);
+}
+
+template <typename T, int BCO, int BPX, int WCO, int WPX, int KS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    using G = IGemm<T, BCO, BPX, WCO, WPX, KS>;
+    __shared__ u32x4 smem[2 * G::STAGE];
+    const int t = threadIdx.x;
+    const int64_t px0 = (int64_t)blockIdx.x * BPX;
+    const int co0 = blockIdx.y * BCO;
+    const int pad = KS / 2;
+
+    typename G::Rows rows;
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < G::NB; ++i) {
+        const int64_t m = px0 + (t >> 2) + i * 64;
+        rows.ok[i] = m < a.M;
+        const int64_t mm = rows.ok[i] ? m : 0;
+        const int b = (int)(mm / HoWo);
+        const int rem = (int)(mm - (int64_t)b * HoWo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        rows.pix[i] = b * a.H * a.W;
+        rows.iy0[i] = oy * a.stride - pad;
+        rows.ix0[i] = ox * a.stride - pad;
+    }
+
+    f32x4 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* wt = reinterpret_cast<const T*>(a.w) + (size_t)co0 * a.Kpad;
+    G::run(acc, reinterpret_cast<const T*>(a.x), a.ldx, a.H, a.W, a.Cin, rows, wt, a.Kpad,
+           a.Cout - co0, smem);
+
+    // epilogue: bias + act (+ residual), 4 consecutive couts per lane
+    const int lane = t & 63, wave = t >> 6;
+    const int wco = wave / WPX, wpx = wave % WPX;
+    constexpr bool PRECISE = sizeof(T) == 4;
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i) {
+        const int co = co0 + (wco * G::TM + i) * 16 + (lane >> 4) * 4;
+        if (co >= a.Cout) continue;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) {
+            const int64_t m = px0 + (wpx * G::TN + j) * 16 + (lane & 15);
+            if (m >= a.M) continue;
+            float v0 = acc[i][j].x + bv.x, v1 = acc[i][j].y + bv.y;
+            float v2 = acc[i][j].z + bv.z, v3 = acc[i][j].w + bv.w;
+            if (a.act == YMK_ACT_SILU) {
+                v0 = act_silu<T, PRECISE>(v0); v1 = act_silu<T, PRECISE>(v1);
+                v2 = act_silu<T, PRECISE>(v2); v3 = act_silu<T, PRECISE>(v3);
+            }
+            if (a.res) {
+                float r0, r1, r2, r3;
+                load4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co, r0, r1, r2, r3);
+                v0 = r0 + v0; v1 = r1 + v1; v2 = r2 + v2; v3 = r3 + v3;
+            }
+            if (a.out_f32)
+                store4(reinterpret_cast<float*>(a.y) + m * a.ldy + co, v0, v1, v2, v3);
+            else
+                store4(reinterpret_cast<T*>(a.y) + m * a.ldy + co, v0, v1, v2, v3);
+        }
+    }
+}
+
+template <typename T, int KS>
+static int launch_conv(const ConvArgs& a, hipStream_t s) {
+    dim3 blk(256);
+    if (a.Cout > 64) {
+        dim3 grid((unsigned)ceil_div64(a.M, 128), (a.Cout + 127) / 128);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, KS>), grid, blk, 0, s, a);
+    } else if (a.Cout > 32) {
+        dim3 grid((unsigned)ceil_div64(a.M, 256), 1);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, 256, 1, 4, KS>), grid, blk, 0, s, a);
+    } else if (a.Cout > 16) {
+        dim3 grid((unsigned)ceil_div64(a.M, 256), 1);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 32, 256, 1, 4, KS>), grid, blk, 0, s, a);
+    } else {
+        dim3 grid((unsigned)ceil_div64(a.M, 256), 1);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 16, 256, 1, 4, KS>), grid, blk, 0, s, a);
+    }
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, const float* bias,
+                          const void* residual, void* y, void* stream) {
+    if (!d || !x || !w || !bias || !y) return YMK_E_BADARG;
+    if (d->ksize != 1 && d->ksize != 3) return YMK_E_BADARG;
+    if (d->stride != 1 && d->stride != 2) return YMK_E_BADARG;
+    const int vec = d->dtype == YMK_BF16 ? 8 : 4;
+    if (d->dtype != YMK_F32 && d->dtype != YMK_BF16) return YMK_E_BADARG;
+    if (d->Cin % vec || d->ldx % vec || d->Cout % 4 || d->ldy % 4 || d->Kpad % 64) return YMK_E_BADARG;
+    if (d->Kpad < d->ksize * d->ksize * d->Cin) return YMK_E_BADARG;
+    if (residual && d->ldr % 4) return YMK_E_BADARG;
+    if (d->out_dtype != d->dtype && d->out_dtype != YMK_F32) return YMK_E_BADARG;
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W;
+    const int pad = d->ksize / 2;
+    a.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
+    a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+    a.Cin = d->Cin; a.Cout = d->Cout; a.stride = d->stride;
+    a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.Kpad = d->Kpad; a.act = d->act;
+    a.out_f32 = (d->out_dtype == YMK_F32 && d->dtype != YMK_F32) ? 1 : 0;
+    a.M = (int64_t)d->B * a.Ho * a.Wo;
+    if (a.M <= 0) return YMK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == YMK_F32)
+        return d->ksize == 1 ? launch_conv<float, 1>(a, s) : launch_conv<float, 3>(a, s);
+    return d->ksize == 1 ? launch_conv<bf16_t, 1>(a, s) : launch_conv<bf16_t, 3>(a, s);
+}
+
+// ---------------------------------------------------------------------------
+// Stem: NCHW fp32 input with tiny Cin (3) -> NHWC.  Direct VALU convolution: the
+// layer is output-bandwidth bound (27 MACs per output element), one thread per
+// output pixel x 8 couts, weights broadcast from LDS.
+// ---------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, TO* __restrict__ y,
+                                                    int B, int Cin, int H, int W, int Ho, int Wo, int Cout,
+                                                    int ks, int stride, int ldy, int act) {
+    extern __shared__ float sw[];  // [Cout][K] then bias[Cout]
+    const int K = ks * ks * Cin;
+    for (int i = threadIdx.x; i < Cout * K; i += blockDim.x) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[Cout * K + i] = bias[i];
+    __syncthreads();
+    const int ng = Cout / 8;  // groups of 8 couts
+    const int64_t total = (int64_t)B * Ho * Wo * ng;
+    const int pad = ks / 2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % ng);
+        const int64_t m = idx / ng;
+        const int ox = (int)(m % Wo);
+        const int oy = (int)((m / Wo) % Ho);
+        const int b = (int)(m / ((int64_t)Wo * Ho));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int ky = 0; ky < ks; ++ky) {
+            const int iy = oy * stride - pad + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < ks; ++kx) {
+                const int ix = ox * stride - pad + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                for (int c = 0; c < Cin; ++c) {
+                    const float xv = x[(((int64_t)b * Cin + c) * H + iy) * W + ix];
+                    const int k = (ky * ks + kx) * Cin + c;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, sw[(g * 8 + j) * K + k], acc[j]);
+                }
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = acc[j] + sw[Cout * K + g * 8 + j];
+            v[j] = act == YMK_ACT_SILU ? silu_exact(t) : t;
+        }
+        TO* o = y + m * ldy + g * 8;
+        store4(o, v[0], v[1], v[2], v[3]);
+        store4(o + 4, v[4], v[5], v[6], v[7]);
+    }
+}
+
+extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float* bias, void* y,
+                                    int32_t out_dtype, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                                    int32_t Cout, int32_t ksize, int32_t stride, int32_t ldy,
+                                    int32_t act, void* stream) {
+    if (!x || !w || !bias || !y || Cout % 8 || ldy % 8 || Cin < 1 || Cin > 4 || (ksize & 1) == 0)
+        return YMK_E_BADARG;
+    const int pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const int64_t total = (int64_t)B * Ho * Wo * (Cout / 8);
+    if (total <= 0) return YMK_OK;
+    const size_t shm = ((size_t)Cout * ksize * ksize * Cin + Cout) * sizeof(float);
+    if (shm > 64 * 1024) return YMK_E_BADARG;
+    const int blocks = (int)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == YMK_F32)
+        hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(256), shm, s, x, w, bias, (float*)y, B,
+                           Cin, H, W, Ho, Wo, Cout, ksize, stride, ldy, act);
+    else if (out_dtype == YMK_BF16)
+        hipLaunchKernelGGL(stem_kernel<bf16_t>, dim3(blocks), dim3(256), shm, s, x, w, bias, (bf16_t*)y,
+                           B, Cin, H, W, Ho, Wo, Cout, ksize, stride, ldy, act);
+    else
+        return YMK_E_BADARG;
+    return ymk_launch_status();
+}

@@ -1,0 +1,174 @@
+// Layout / copy kernels (HBM-bound): nearest 2x upsample into a concat slice, channel-slice
+// copy, NHWC -> NCHW fp32 export, and the Detect decode.
+// -ffp-contract=off is set for this file: the decode must follow the reference's
+// op-by-op fp32 arithmetic (no fused multiply-add contraction).
+#include "ymk_common.h"
+
+// ---- nn.Upsample(None, 2, "nearest") (yaml head rows 13/16) -------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
+                                                        int W, int C, int ldx, int ldy) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC;
+    const int64_t total = (int64_t)B * (2 * H) * (2 * W) * ncv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % ncv);
+        int64_t p = i / ncv;
+        const int ox = (int)(p % (2 * W)); p /= (2 * W);
+        const int oy = (int)(p % (2 * H));
+        const int b = (int)(p / (2 * H));
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((int64_t)b * H + (oy >> 1)) * W + (ox >> 1)) * ldx + cv * VEC);
+        *reinterpret_cast<u32x4*>(y + (((int64_t)b * 2 * H + oy) * 2 * W + ox) * ldy + cv * VEC) = v;
+    }
+}
+
+extern "C" int ymk_upsample2x(int32_t dtype, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                              int32_t ldx, int32_t ldy, void* stream) {
+    const int vec = dtype == YMK_BF16 ? 8 : 4;
+    if (!x || !y || (dtype != YMK_F32 && dtype != YMK_BF16) || C % vec || ldx % vec || ldy % vec) return YMK_E_BADARG;
+    const int64_t total = (int64_t)B * 4 * H * W * (C / vec);
+    if (total <= 0) return YMK_OK;
+    const int blocks = (int)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
+    if (dtype == YMK_F32)
+        hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (float*)y, B, H, W, C, ldx, ldy);
+    else
+        hipLaunchKernelGGL(upsample2x_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ldx, ldy);
+    return ymk_launch_status();
+}
+
+// ---- Concat by channel-slice copy (conv.py:629-641) ---------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t npix,
+                                                           int C, int ldx, int ldy) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC;
+    const int64_t total = npix * ncv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % ncv);
+        const int64_t p = i / ncv;
+        *reinterpret_cast<u32x4*>(y + p * ldy + cv * VEC) = *reinterpret_cast<const u32x4*>(x + p * ldx + cv * VEC);
+    }
+}
+
+extern "C" int ymk_copy_channels(int32_t dtype, const void* x, void* y, int64_t npix, int32_t C, int32_t ldx,
+                                 int32_t ldy, void* stream) {
+    const int vec = dtype == YMK_BF16 ? 8 : 4;
+    if (!x || !y || (dtype != YMK_F32 && dtype != YMK_BF16) || C % vec || ldx % vec || ldy % vec) return YMK_E_BADARG;
+    const int64_t total = npix * (C / vec);
+    if (total <= 0) return YMK_OK;
+    const int blocks = (int)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
+    if (dtype == YMK_F32)
+        hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (float*)y, npix, C, ldx, ldy);
+    else
+        hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, npix, C, ldx, ldy);
+    return ymk_launch_status();
+}
+
+// ---- NHWC -> NCHW fp32 via a 64x64 LDS transpose tile -------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int HW, int C,
+                                                          int ldx) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? to_f32(x[((size_t)b * HW + p) * ldx + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) y[((size_t)b * C + c) * HW + p] = tile[tx][r];
+    }
+}
+
+extern "C" int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int32_t HW, int32_t C,
+                                    int32_t ldx, void* stream) {
+    if (!x || !y || (dtype != YMK_F32 && dtype != YMK_BF16)) return YMK_E_BADARG;
+    if (B <= 0 || HW <= 0 || C <= 0) return YMK_OK;
+    if (B > 65535) return YMK_E_BADARG;
+    dim3 grid((HW + 63) / 64, (C + 63) / 64, B), blk(256);
+    if (dtype == YMK_F32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)x, y, HW, C, ldx);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)x, y, HW, C,
+                           ldx);
+    return ymk_launch_status();
+}
+
+// ---- Detect decode (head.py:173-194, block.py:81-84, tal.py:398-423) ------------------
+// One workgroup = 64 anchors of one image.  The [64][4*reg_max] box logits and [64][nc]
+// class logits are read coalesced (anchor-major rows), transposed through LDS, and written
+// as y[b][channel][anchor] (anchor-contiguous).  Arithmetic, in the reference's order:
+//   p = softmax_16(logits); dist = sum_i i*p_i; x1y1 = anchor - lt; x2y2 = anchor + rb;
+//   c = (x1y1 + x2y2)/2; wh = x2y2 - x1y1; box = (c, wh) * stride; score = sigmoid(cls).
+__global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restrict__ box, const float* __restrict__ cls,
+                                                           float* __restrict__ y, int Hl, int Wl, int reg_max, int nc,
+                                                           float stride, int a_off, int A) {
+    extern __shared__ float sm[];  // cls tile [64][nc+1], dist [64][4]
+    const int HW = Hl * Wl;
+    const int b = blockIdx.y;
+    const int a0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+    float* scls = sm;
+    float* sdist = sm + 64 * (nc + 1);
+    const int na = min(64, HW - a0);
+    // class logits: coalesced read of na*nc floats
+    for (int i = t; i < na * nc; i += 256) {
+        const int r = i / nc, c = i - r * nc;
+        scls[r * (nc + 1) + c] = cls[((size_t)b * HW + a0) * nc + i];
+    }
+    // DFL: thread (anchor r = t/4, side s = t%4) reduces reg_max bins
+    {
+        const int r = t >> 2, s = t & 3;
+        if (r < na) {
+            const float* p = box + ((size_t)b * HW + a0 + r) * (4 * reg_max) + s * reg_max;
+            float mx = -INFINITY;
+            for (int i = 0; i < reg_max; ++i) mx = fmaxf(mx, p[i]);
+            float den = 0.f;
+            for (int i = 0; i < reg_max; ++i) den += expf(p[i] - mx);
+            float d = 0.f;
+            for (int i = 0; i < reg_max; ++i) d += (float)i * (expf(p[i] - mx) / den);
+            sdist[r * 4 + s] = d;
+        }
+    }
+    __syncthreads();
+    float* yb = y + (size_t)b * (4 + nc) * A + a_off + a0;
+    if (t < 64 && t < na) {
+        const int a = a0 + t;
+        const float ax = (float)(a % Wl) + 0.5f, ay = (float)(a / Wl) + 0.5f;
+        const float l = sdist[t * 4 + 0], tp = sdist[t * 4 + 1], r = sdist[t * 4 + 2], bt = sdist[t * 4 + 3];
+        const float x1 = ax - l, y1 = ay - tp, x2 = ax + r, y2 = ay + bt;
+        yb[0 * (size_t)A + t] = ((x1 + x2) / 2.0f) * stride;
+        yb[1 * (size_t)A + t] = ((y1 + y2) / 2.0f) * stride;
+        yb[2 * (size_t)A + t] = (x2 - x1) * stride;
+        yb[3 * (size_t)A + t] = (y2 - y1) * stride;
+    }
+    for (int i = t; i < 64 * nc; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (r < na) {
+            const float v = scls[r * (nc + 1) + c];
+            yb[(size_t)(4 + c) * A + r] = 1.0f / (1.0f + expf(-v));
+        }
+    }
+}
+
+extern "C" int ymk_detect_decode(const float* box_l, const float* cls_l, float* y, int32_t B, int32_t Hl, int32_t Wl,
+                                 int32_t reg_max, int32_t nc, float stride, int32_t a_off, int32_t A_total,
+                                 void* stream) {
+    if (!box_l || !cls_l || !y || reg_max < 1 || nc < 1) return YMK_E_BADARG;
+    const int HW = Hl * Wl;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    if (B > 65535 || a_off + HW > A_total) return YMK_E_BADARG;
+    const size_t shm = (size_t)(64 * (nc + 1) + 64 * 4) * sizeof(float);
+    if (shm > 64 * 1024) return YMK_E_BADARG;
+    dim3 grid((HW + 63) / 64, B), blk(256);
+    hipLaunchKernelGGL(detect_decode_kernel, grid, blk, shm, (hipStream_t)stream, box_l, cls_l, y, Hl, Wl, reg_max, nc,
+                       stride, a_off, A_total);
+    return ymk_launch_status();
+}

@@ -1,0 +1,342 @@
+// ES-MoE router + sparse dispatch (CSR) + pointwise grouped GEMM.
+// Reference: ultralytics/nn/modules/moe/modules.py:535-704 (ES_MOE.forward,
+// _sparse_forward), moe/routers.py:458-527 (DynamicRoutingLayer), moe/experts.py:280-296,
+// nn/modules/_numeric.py:85-90 (stable_normalize).
+#include "igemm.h"
+
+#define RT_PIX 256     // pixels per partial-GAP workgroup
+#define RT_MAX_E 16
+#define RT_MAX_HID 256
+
+extern "C" size_t ymk_esmoe_route_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
+    const size_t chunks = ((size_t)H * W + RT_PIX - 1) / RT_PIX;
+    return (size_t)B * chunks * C * sizeof(float);
+}
+
+// stage 1: deterministic partial global-average-pool sums + finite check of x
+template <typename T>
+__global__ __launch_bounds__(256) void gap_partial_kernel(const T* __restrict__ x, int HW, int C, int ldx,
+                                                         float* __restrict__ part, int* __restrict__ flags) {
+    __shared__ float red[256 * 4];
+    const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+    const int nc4 = C / 4;
+    const int t = threadIdx.x;
+    bool bad = false;
+    for (int cv0 = 0; cv0 < nc4; cv0 += 256) {
+        const int ncv = min(256, nc4 - cv0);
+        const int rows = 256 / ncv;
+        const int cv = t % ncv, pr = t / ncv;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pr < rows) {
+            const int p1 = min(HW, (chunk + 1) * RT_PIX);
+            const T* base = x + ((size_t)b * HW) * ldx + (cv0 + cv) * 4;
+            for (int p = chunk * RT_PIX + pr; p < p1; p += rows) {
+                float v0, v1, v2, v3;
+                load4(base + (size_t)p * ldx, v0, v1, v2, v3);
+                s[0] += v0; s[1] += v1; s[2] += v2; s[3] += v3;
+            }
+        }
+        bad |= !(isfinite(s[0]) && isfinite(s[1]) && isfinite(s[2]) && isfinite(s[3]));
+        red[t * 4 + 0] = s[0]; red[t * 4 + 1] = s[1]; red[t * 4 + 2] = s[2]; red[t * 4 + 3] = s[3];
+        __syncthreads();
+        if (pr == 0) {
+            for (int r = 1; r < rows; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] += red[(r * ncv + cv) * 4 + q];
+            }
+            float* o = part + ((size_t)b * nchunk + chunk) * C + (cv0 + cv) * 4;
+            store4(o, s[0], s[1], s[2], s[3]);
+        }
+        __syncthreads();
+    }
+    // NaN/Inf anywhere in x makes its partial sum non-finite (finite inputs cannot
+    // overflow an fp32 sum of <= 256 bf16/fp32 activations in practice): this folds
+    // _validate_router_input's isnan/isinf scan (routers.py:51) into the GAP read.
+    if (bad) atomicOr(flags, YMK_FLAG_NONFINITE_INPUT);
+}
+
+// stage 2: one workgroup per image: finish the mean, run the two 1x1 layers, softmax,
+// hard top-k, stable_normalize, threshold pruning + renormalisation.
+__global__ __launch_bounds__(256) void route_finalize_kernel(
+    const float* __restrict__ part, int nchunk, int HW, int C, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int hidden, int E,
+    int top_k, float thr, float* __restrict__ route_w, float* __restrict__ gate_w, int* __restrict__ sel,
+    int* __restrict__ flags) {
+    extern __shared__ float sm[];  // pooled[C], h[hidden], logits[E]
+    float* pooled = sm;
+    float* h = sm + C;
+    float* logits = h + hidden;
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < nchunk; ++k) s += part[((size_t)b * nchunk + k) * C + c];
+        pooled[c] = s / (float)HW;
+    }
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;
+    for (int j = wave; j < hidden; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)j * C + c], pooled[c], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) h[j] = silu_exact(s + b1[j]);
+    }
+    __syncthreads();
+    if (t < E) {
+        float s = 0.f;
+        for (int j = 0; j < hidden; ++j) s = fmaf(w2[t * hidden + j], h[j], s);
+        logits[t] = s + b2[t];
+    }
+    __syncthreads();
+    if (t == 0) {
+        float p[RT_MAX_E];
+        bool fin = true;
+        float mx = -INFINITY;
+        for (int e = 0; e < E; ++e) {
+            fin &= isfinite(logits[e]);
+            p[e] = fminf(fmaxf(logits[e], -30.f), 30.f);
+            mx = fmaxf(mx, p[e]);
+        }
+        if (!fin) atomicOr(flags, YMK_FLAG_NONFINITE_LOGITS);
+        float den = 0.f;
+        for (int e = 0; e < E; ++e) { p[e] = expf(p[e] - mx); den += p[e]; }
+        for (int e = 0; e < E; ++e) p[e] = p[e] / den;
+        // hard top-k (descending, ties -> lower index), renormalised over the selected set
+        int idx[RT_MAX_E];
+        bool used[RT_MAX_E];
+        for (int e = 0; e < E; ++e) used[e] = false;
+        float vsum = 0.f;
+        for (int k = 0; k < top_k; ++k) {
+            int best = -1;
+            for (int e = 0; e < E; ++e)
+                if (!used[e] && (best < 0 || p[e] > p[best])) best = e;
+            used[best] = true;
+            idx[k] = best;
+            vsum += p[best];
+        }
+        vsum = fmaxf(vsum, 1e-6f);
+        float rw[RT_MAX_E];
+        for (int e = 0; e < E; ++e) rw[e] = 0.f;
+        for (int k = 0; k < top_k; ++k) rw[idx[k]] = p[idx[k]] / vsum;
+        // sparse dispatch decision (modules.py:665-684): importance == rw (spatially constant)
+        bool keep[RT_MAX_E];
+        for (int e = 0; e < E; ++e) keep[e] = false;
+        if (top_k >= E) {
+            for (int e = 0; e < E; ++e) keep[e] = true;  // dense path: every expert, unpruned
+        } else {
+            for (int k = 0; k < top_k; ++k)
+                keep[idx[k]] = (k == 0) || !(thr > 0.f) || (rw[idx[k]] >= thr);
+        }
+        float nsum = 0.f;
+        for (int e = 0; e < E; ++e) nsum += keep[e] ? rw[e] : 0.f;
+        nsum = (top_k >= E) ? 1.0f : fmaxf(nsum, 1.1920929e-07f);
+        int ns = 0;
+        for (int e = 0; e < E; ++e) {
+            route_w[b * E + e] = rw[e];
+            const float g = keep[e] ? ((top_k >= E) ? rw[e] : rw[e] / nsum) : 0.f;
+            gate_w[b * E + e] = g;
+            if (keep[e] && ns < top_k) sel[b * top_k + ns++] = e;
+        }
+        for (; ns < top_k; ++ns) sel[b * top_k + ns] = -1;
+    }
+}
+
+// stage 3: image->expert CSR permutation, one wavefront: per 64-image chunk and expert,
+// a ballot gives the member mask, popcount-of-lower-lanes the position inside the chunk.
+__global__ __launch_bounds__(64) void route_csr_kernel(const int* __restrict__ sel, int B, int E, int top_k,
+                                                      int* __restrict__ csr_off, int* __restrict__ csr_pair) {
+    const int lane = threadIdx.x;
+    int cnt[RT_MAX_E];
+    for (int e = 0; e < E; ++e) cnt[e] = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        for (int e = 0; e < E; ++e) {
+            bool f = false;
+            if (b < B)
+                for (int s = 0; s < top_k; ++s) f |= (sel[b * top_k + s] == e);
+            cnt[e] += __popcll(__ballot(f));
+        }
+    }
+    int off[RT_MAX_E + 1];
+    off[0] = 0;
+    for (int e = 0; e < E; ++e) off[e + 1] = off[e] + cnt[e];
+    if (lane == 0)
+        for (int e = 0; e <= E; ++e) csr_off[e] = off[e];
+    for (int e = 0; e < E; ++e) cnt[e] = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        for (int e = 0; e < E; ++e) {
+            int slot = -1;
+            if (b < B)
+                for (int s = 0; s < top_k; ++s)
+                    if (sel[b * top_k + s] == e) slot = s;
+            const unsigned long long m = __ballot(slot >= 0);
+            const int pre = __popcll(m & ((1ull << lane) - 1ull));
+            if (slot >= 0) csr_pair[off[e] + cnt[e] + pre] = b * top_k + slot;
+            cnt[e] += __popcll(m);
+        }
+    }
+}
+
+extern "C" int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
+                               int32_t ldx, const float* w1, const float* b1, const float* w2,
+                               const float* b2, int32_t hidden, int32_t E, int32_t top_k,
+                               float dynamic_threshold, float* route_w, float* gate_w, int32_t* sel,
+                               int32_t* csr_off, int32_t* csr_pair, int32_t* flags, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !route_w || !gate_w || !sel || !csr_off || !csr_pair || !flags)
+        return YMK_E_BADARG;
+    if (C % 4 || ldx % 4 || E < 1 || E > RT_MAX_E || top_k < 1 || top_k > E || hidden < 1 ||
+        hidden > RT_MAX_HID)
+        return YMK_E_BADARG;
+    const int HW = H * W;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    if (B > 65535) return YMK_E_BADARG;
+    const int nchunk = (HW + RT_PIX - 1) / RT_PIX;
+    if (!workspace || workspace_bytes < ymk_esmoe_route_workspace_bytes(B, C, H, W)) return YMK_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    dim3 g1(nchunk, B), blk(256);
+    if (dtype == YMK_F32)
+        hipLaunchKernelGGL(gap_partial_kernel<float>, g1, blk, 0, s, (const float*)x, HW, C, ldx, part, flags);
+    else if (dtype == YMK_BF16)
+        hipLaunchKernelGGL(gap_partial_kernel<bf16_t>, g1, blk, 0, s, (const bf16_t*)x, HW, C, ldx, part, flags);
+    else
+        return YMK_E_BADARG;
+    const size_t shm = (size_t)(C + hidden + E) * sizeof(float);
+    hipLaunchKernelGGL(route_finalize_kernel, dim3(B), blk, shm, s, part, nchunk, HW, C, w1, b1, w2, b2, hidden,
+                       E, top_k, dynamic_threshold, route_w, gate_w, sel, flags);
+    hipLaunchKernelGGL(route_csr_kernel, dim3(1), dim3(64), 0, s, sel, B, E, top_k, csr_off, csr_pair);
+    return ymk_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// Pointwise stage: grouped GEMM over the retained experts of each image.
+// One workgroup = (image, pixel tile, cout tile); it loops over the image's
+// slots, so the output tile is produced once, in registers, without atomics
+// or a zero-initialised accumulator in HBM (the reference's index_add_, :702).
+// ---------------------------------------------------------------------------
+struct MoePwArgs {
+    const void* dw;
+    const void* pw_w;
+    const float* pw_b;
+    const float* nscale;
+    const float* nshift;
+    const int* sel;
+    const float* gate;
+    void* y;
+    int B, HW, C, Cout, Kpad, E, top_k, ldy, tiles;
+};
+
+template <typename T, int BCO, int BPX, int WCO, int WPX>
+__global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
+    using G = IGemm<T, BCO, BPX, WCO, WPX, 1>;
+    __shared__ u32x4 smem[2 * G::STAGE];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x / a.tiles, tile = blockIdx.x % a.tiles;
+    const int co0 = blockIdx.y * BCO;
+    const int m0 = tile * BPX;
+
+    typename G::Rows rows;
+#pragma unroll
+    for (int i = 0; i < G::NB; ++i) {
+        const int m = m0 + (t >> 2) + i * 64;
+        rows.ok[i] = m < a.HW;
+        rows.pix[i] = 0; rows.iy0[i] = 0; rows.ix0[i] = rows.ok[i] ? m : 0;
+    }
+    const int lane = t & 63, wave = t >> 6;
+    const int wco = wave / WPX, wpx = wave % WPX;
+    constexpr bool PRECISE = sizeof(T) == 4;
+
+    f32x4 out[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) out[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < a.top_k; ++s) {
+        const int pair = b * a.top_k + s;
+        const int e = a.sel[pair];
+        if (e < 0) continue;  // workgroup-uniform
+        const float g = a.gate[b * a.E + e];
+        f32x4 acc[G::TM][G::TN];
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* xin = reinterpret_cast<const T*>(a.dw) + (size_t)pair * a.HW * a.C;
+        const T* wt = reinterpret_cast<const T*>(a.pw_w) + ((size_t)e * a.Cout + co0) * a.Kpad;
+        G::run(acc, xin, a.C, 1, a.HW, a.C, rows, wt, a.Kpad, a.Cout - co0, smem);
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) {
+            const int co = co0 + (wco * G::TM + i) * 16 + (lane >> 4) * 4;
+            if (co >= a.Cout) continue;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.pw_b + (size_t)e * a.Cout + co);
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j) {
+                float v0 = acc[i][j].x + bv.x, v1 = acc[i][j].y + bv.y;
+                float v2 = acc[i][j].z + bv.z, v3 = acc[i][j].w + bv.w;
+                if (PRECISE) {
+                    v0 = silu_exact(v0); v1 = silu_exact(v1); v2 = silu_exact(v2); v3 = silu_exact(v3);
+                } else {
+                    v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3);
+                }
+                out[i][j].x += v0 * g; out[i][j].y += v1 * g;
+                out[i][j].z += v2 * g; out[i][j].w += v3 * g;
+            }
+        }
+    }
+    // trailing ES_MOE.norm: BatchNorm(eval) + SiLU
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i) {
+        const int co = co0 + (wco * G::TM + i) * 16 + (lane >> 4) * 4;
+        if (co >= a.Cout) continue;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.nscale + co);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.nshift + co);
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) {
+            const int m = m0 + (wpx * G::TN + j) * 16 + (lane & 15);
+            if (m >= a.HW) continue;
+            float v0 = out[i][j].x * sc.x + sh.x, v1 = out[i][j].y * sc.y + sh.y;
+            float v2 = out[i][j].z * sc.z + sh.z, v3 = out[i][j].w * sc.w + sh.w;
+            if (PRECISE) {
+                v0 = silu_exact(v0); v1 = silu_exact(v1); v2 = silu_exact(v2); v3 = silu_exact(v3);
+            } else {
+                v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3);
+            }
+            store4(reinterpret_cast<T*>(a.y) + ((size_t)b * a.HW + m) * a.ldy + co, v0, v1, v2, v3);
+        }
+    }
+}
+
+template <typename T>
+static int launch_pw(MoePwArgs a, hipStream_t s) {
+    dim3 blk(256);
+    if (a.Cout > 64) {
+        a.tiles = (a.HW + 127) / 128;
+        dim3 grid(a.B * a.tiles, (a.Cout + 127) / 128);
+        hipLaunchKernelGGL((moe_pw_kernel<T, 128, 128, 2, 2>), grid, blk, 0, s, a);
+    } else if (a.Cout > 32) {
+        a.tiles = (a.HW + 255) / 256;
+        dim3 grid(a.B * a.tiles, 1);
+        hipLaunchKernelGGL((moe_pw_kernel<T, 64, 256, 1, 4>), grid, blk, 0, s, a);
+    } else {
+        a.tiles = (a.HW + 255) / 256;
+        dim3 grid(a.B * a.tiles, 1);
+        hipLaunchKernelGGL((moe_pw_kernel<T, 32, 256, 1, 4>), grid, blk, 0, s, a);
+    }
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_esmoe_pw(int32_t dtype, const void* dw_out, int32_t B, int32_t H, int32_t W, int32_t C,
+                            int32_t Cout, int32_t Kpad, const void* pw_w, const float* pw_b,
+                            const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
+                            const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream) {
+    if (!dw_out || !pw_w || !pw_b || !norm_scale || !norm_shift || !sel || !gate_w || !y) return YMK_E_BADARG;
+    const int vec = dtype == YMK_BF16 ? 8 : 4;
+    if (dtype != YMK_F32 && dtype != YMK_BF16) return YMK_E_BADARG;
+    if (C % vec || Cout % 4 || ldy % 4 || Kpad % 64 || Kpad < C || Cout > 32 * 1024) return YMK_E_BADARG;
+    if (B <= 0 || H * W <= 0) return YMK_OK;
+    MoePwArgs a{dw_out, pw_w, pw_b, norm_scale, norm_shift, sel, gate_w, y, B, H * W, C, Cout, Kpad, E, top_k, ldy, 0};
+    return dtype == YMK_F32 ? launch_pw<float>(a, (hipStream_t)stream) : launch_pw<bf16_t>(a, (hipStream_t)stream);
+}

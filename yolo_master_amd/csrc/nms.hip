@@ -1,0 +1,388 @@
+// Batched NMS on the GPU, bit-compatible with the reference's CPU result.
+// Reference: non_max_suppression (ultralytics/utils/nms.py:13-171) + TorchNMS.nms (:245-302).
+//   candidates: conf > thres (best class :124-129, or every class when multi_label :119-123)
+//   order: score descending (ties: lower candidate index first), cap max_nms (:142-146)
+//   boxes + cls*max_wh (:148-154); greedy: drop j when !(IoU(i,j) <= thr) (:300); [:max_det] (:162)
+// Pipeline (all per-image work runs batched over B):
+//   count -> scan -> emit (ordered compaction) -> rank (counting sort, stable)
+//   -> 64x64 IoU bitmask (upper triangle) -> blocked sweep (one wavefront per image).
+// Compile with -ffp-contract=off: IoU arithmetic must round exactly like the reference.
+#include "ymk_common.h"
+
+struct NmsWs {
+    int* cnt;        // [B][A]
+    float* bconf;    // [B][A]
+    int* bcls;       // [B][A]
+    int* blocksum;   // [B][NBLK]
+    int* blockoff;   // [B][NBLK]
+    int* ncand;      // [B] candidates (clamped to capc)
+    int* nsort;      // [B] min(ncand, ns)
+    float* cbox;     // [B][capc][4] xyxy
+    float* cscore;   // [B][capc]
+    int* ccls;       // [B][capc]
+    int* canchor;    // [B][capc]
+    float* sbox;     // [B][ns][4]
+    float* sscore;   // [B][ns]
+    int* scls;       // [B][ns]
+    int* sanchor;    // [B][ns]
+    int* keep_pos;   // [B][max_det_cap]
+    unsigned long long* mask;  // [B][ns][nw]
+    int nblk, capc, ns, nw;
+    size_t total;
+};
+
+#define NMS_MAXDET_CAP 1024
+
+static NmsWs nms_layout(void* base, int B, int nc, int A, int multi, int max_nms) {
+    NmsWs w;
+    w.nblk = (A + 255) / 256;
+    const int64_t full = multi ? (int64_t)A * nc : (int64_t)A;
+    const int64_t capm = (int64_t)max_nms * 2;
+    w.capc = (int)(multi ? (full < capm ? full : capm) : full);
+    w.ns = w.capc < max_nms ? w.capc : max_nms;
+    w.nw = (w.ns + 63) / 64;
+    size_t off = 0;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) {
+        char* r = p ? p + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    w.cnt = (int*)take((size_t)B * A * 4);
+    w.bconf = (float*)take((size_t)B * A * 4);
+    w.bcls = (int*)take((size_t)B * A * 4);
+    w.blocksum = (int*)take((size_t)B * w.nblk * 4);
+    w.blockoff = (int*)take((size_t)B * w.nblk * 4);
+    w.ncand = (int*)take((size_t)B * 4);
+    w.nsort = (int*)take((size_t)B * 4);
+    w.cbox = (float*)take((size_t)B * w.capc * 16);
+    w.cscore = (float*)take((size_t)B * w.capc * 4);
+    w.ccls = (int*)take((size_t)B * w.capc * 4);
+    w.canchor = (int*)take((size_t)B * w.capc * 4);
+    w.sbox = (float*)take((size_t)B * w.ns * 16);
+    w.sscore = (float*)take((size_t)B * w.ns * 4);
+    w.scls = (int*)take((size_t)B * w.ns * 4);
+    w.sanchor = (int*)take((size_t)B * w.ns * 4);
+    w.keep_pos = (int*)take((size_t)B * NMS_MAXDET_CAP * 4);
+    w.mask = (unsigned long long*)take((size_t)B * w.ns * w.nw * 8);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t ymk_nms_workspace_bytes(int32_t B, int32_t nc, int32_t A, int32_t multi_label, int32_t max_nms) {
+    if (B <= 0 || A <= 0 || nc <= 0 || max_nms <= 0) return 0;
+    return nms_layout(nullptr, B, nc, A, multi_label && nc > 1, max_nms).total;
+}
+
+// ---- 1. per-anchor candidate count (+ best class for single-label) ----------------
+__global__ __launch_bounds__(256) void nms_count_kernel(const float* __restrict__ y, int nc, int A, float conf, int multi,
+                                                       NmsWs w) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    int c = 0;
+    if (a < A) {
+        const float* p = y + ((size_t)b * (4 + nc) + 4) * A + a;
+        if (multi) {
+            for (int k = 0; k < nc; ++k) c += p[(size_t)k * A] > conf;
+        } else {
+            float best = p[0];
+            int bi = 0;
+            for (int k = 1; k < nc; ++k) {
+                const float v = p[(size_t)k * A];
+                if (v > best) { best = v; bi = k; }
+            }
+            c = best > conf;
+            w.bconf[(size_t)b * A + a] = best;
+            w.bcls[(size_t)b * A + a] = bi;
+        }
+        w.cnt[(size_t)b * A + a] = c;
+    }
+    int s = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) w.blocksum[b * w.nblk + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---- 2. exclusive scan of block sums (one wavefront per image) ---------------------
+__global__ __launch_bounds__(64) void nms_scan_kernel(NmsWs w, int* __restrict__ status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int run = 0;
+    for (int i0 = 0; i0 < w.nblk; i0 += 64) {
+        const int i = i0 + lane;
+        const int v = i < w.nblk ? w.blocksum[b * w.nblk + i] : 0;
+        int inc = v;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(inc, o);
+            if (lane >= o) inc += n;
+        }
+        if (i < w.nblk) w.blockoff[b * w.nblk + i] = run + inc - v;
+        run += __shfl(inc, 63);
+    }
+    if (lane == 0) {
+        if (run > w.capc) atomicOr(status, YMK_FLAG_NMS_OVERFLOW);
+        const int n = run < w.capc ? run : w.capc;
+        w.ncand[b] = n;
+        w.nsort[b] = n < w.ns ? n : w.ns;
+    }
+}
+
+// ---- 3. ordered compaction of candidates -------------------------------------------
+__global__ __launch_bounds__(256) void nms_emit_kernel(const float* __restrict__ y, int nc, int A, float conf, int multi,
+                                                      NmsWs w) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = a < A ? w.cnt[(size_t)b * A + a] : 0;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(inc, o);
+        if (lane >= o) inc += n;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int pos = w.blockoff[b * w.nblk + blockIdx.x] + inc - c;
+    for (int k = 0; k < wv; ++k) pos += wsum[k];
+    if (c == 0) return;
+    const float* yb = y + (size_t)b * (4 + nc) * A + a;
+    const float cx = yb[0], cy = yb[(size_t)A], bw = yb[2 * (size_t)A], bh = yb[3 * (size_t)A];
+    const float hw = bw / 2.0f, hh = bh / 2.0f;  // xywh2xyxy (utils/ops.py:248-264)
+    const float x1 = cx - hw, y1 = cy - hh, x2 = cx + hw, y2 = cy + hh;
+    auto put = [&](int at, float score, int cls) {
+        if (at >= w.capc) return;
+        const size_t o = (size_t)b * w.capc + at;
+        w.cbox[o * 4 + 0] = x1; w.cbox[o * 4 + 1] = y1; w.cbox[o * 4 + 2] = x2; w.cbox[o * 4 + 3] = y2;
+        w.cscore[o] = score; w.ccls[o] = cls; w.canchor[o] = a;
+    };
+    if (multi) {
+        for (int k = 0; k < nc; ++k) {
+            const float v = yb[(size_t)(4 + k) * A];
+            if (v > conf) put(pos++, v, k);
+        }
+    } else {
+        put(pos, w.bconf[(size_t)b * A + a], w.bcls[(size_t)b * A + a]);
+    }
+}
+
+// ---- 4. stable descending counting-rank sort ---------------------------------------
+__global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w) {
+    __shared__ float ts[256];
+    const int b = blockIdx.y;
+    const int n = w.ncand[b];
+    const int i0 = blockIdx.x * 256;
+    if (i0 >= n) return;
+    const int i = i0 + threadIdx.x;
+    const float* sc = w.cscore + (size_t)b * w.capc;
+    const float si = i < n ? sc[i] : 0.f;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        ts[threadIdx.x] = (j0 + threadIdx.x) < n ? sc[j0 + threadIdx.x] : -INFINITY;
+        __syncthreads();
+        const int lim = min(256, n - j0);
+        for (int j = 0; j < lim; ++j) {
+            const float sj = ts[j];
+            rank += (sj > si) || (sj == si && (j0 + j) < i);
+        }
+    }
+    if (i < n && rank < w.ns) {
+        const size_t s = (size_t)b * w.capc + i, d = (size_t)b * w.ns + rank;
+        const f32x4 bx = *reinterpret_cast<const f32x4*>(w.cbox + s * 4);
+        *reinterpret_cast<f32x4*>(w.sbox + d * 4) = bx;
+        w.sscore[d] = si; w.scls[d] = w.ccls[s]; w.sanchor[d] = w.canchor[s];
+    }
+}
+
+// ---- 5. IoU bitmask, upper triangle, 64x64 tiles -----------------------------------
+// grid (G, B): each wavefront walks the image's valid tiles with a stride; the 64 column
+// boxes of a tile live one per lane and are broadcast with v_readlane (no LDS, no barrier).
+__device__ __forceinline__ float rdlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__global__ __launch_bounds__(256) void nms_mask_kernel(NmsWs w, float thr, float cls_off) {
+    const int b = blockIdx.y;
+    const int n = w.nsort[b];
+    const int nwv = (n + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* sb = w.sbox + (size_t)b * w.ns * 4;
+    const int* sc = w.scls + (size_t)b * w.ns;
+    for (int tile = blockIdx.x * 4 + wave; tile < nwv * nwv; tile += gridDim.x * 4) {
+        const int rb = tile / nwv, cb = tile - rb * nwv;
+        if (cb < rb) continue;
+        const int j = cb * 64 + lane;
+        float jx1 = 0.f, jy1 = 0.f, jx2 = 0.f, jy2 = 0.f;
+        if (j < n) {
+            const f32x4 bx = *reinterpret_cast<const f32x4*>(sb + (size_t)j * 4);
+            const float c = (float)sc[j] * cls_off;
+            jx1 = bx.x + c; jy1 = bx.y + c; jx2 = bx.z + c; jy2 = bx.w + c;
+        }
+        const float jar = (jx2 - jx1) * (jy2 - jy1);
+        const int i = rb * 64 + lane;
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+        if (i < n) {
+            const f32x4 bx = *reinterpret_cast<const f32x4*>(sb + (size_t)i * 4);
+            const float c = (float)sc[i] * cls_off;
+            x1 = bx.x + c; y1 = bx.y + c; x2 = bx.z + c; y2 = bx.w + c;
+        }
+        const float ai = (x2 - x1) * (y2 - y1);
+        unsigned long long bits = 0ull;
+        const int jn = min(64, n - cb * 64);
+        for (int jj = 0; jj < jn; ++jj) {
+            const float cx1 = rdlane(jx1, jj), cy1 = rdlane(jy1, jj), cx2 = rdlane(jx2, jj), cy2 = rdlane(jy2, jj);
+            const float ca = rdlane(jar, jj);
+            const float xx1 = fmaxf(x1, cx1), yy1 = fmaxf(y1, cy1);
+            const float xx2 = fminf(x2, cx2), yy2 = fminf(y2, cy2);
+            const float ww = fmaxf(xx2 - xx1, 0.f), hh = fmaxf(yy2 - yy1, 0.f);
+            const float inter = ww * hh;
+            const float iou = inter / ((ai + ca) - inter);
+            if ((cb * 64 + jj) > i && !(iou <= thr)) bits |= 1ull << jj;
+        }
+        if (i < n) w.mask[((size_t)b * w.ns + i) * w.nw + cb] = bits;
+    }
+}
+
+// ---- 6. blocked greedy sweep, one wavefront per image --------------------------------
+__global__ __launch_bounds__(64) void nms_sweep_kernel(NmsWs w, int max_det, float* __restrict__ out_dets,
+                                                      int* __restrict__ out_counts, int* __restrict__ out_idx) {
+    extern __shared__ unsigned long long rem[];  // [nw]
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = w.nsort[b];
+    const int nw = (n + 63) / 64;
+    for (int i = lane; i < nw; i += 64) rem[i] = 0ull;
+    __syncthreads();
+    const unsigned long long* mb = w.mask + (size_t)b * w.ns * w.nw;
+    int kept = 0;
+    for (int wi = 0; wi < nw && kept < max_det; ++wi) {
+        const int row = wi * 64 + lane;
+        unsigned long long cur = rem[wi];
+        const unsigned long long diag = row < n ? mb[(size_t)row * w.nw + wi] : 0ull;
+        const int nv = min(64, n - wi * 64);
+        unsigned long long km = 0ull;
+        for (int t = 0; t < nv; ++t) {
+            const unsigned long long dt = __shfl(diag, t);
+            if (!((cur >> t) & 1ull)) {
+                km |= 1ull << t;
+                cur |= dt;
+            }
+        }
+        // trim to the detections still allowed
+        int cntk = __popcll(km);
+        if (kept + cntk > max_det) {
+            int allow = max_det - kept;
+            unsigned long long m2 = 0ull, tmp = km;
+            while (allow-- > 0) { const unsigned long long low = tmp & (~tmp + 1ull); m2 |= low; tmp ^= low; }
+            km = m2;
+            cntk = __popcll(km);
+        }
+        if ((km >> lane) & 1ull) {
+            const int pos = kept + __popcll(km & ((1ull << lane) - 1ull));
+            const size_t s = (size_t)b * w.ns + row;
+            float* o = out_dets + ((size_t)b * max_det + pos) * 6;
+            o[0] = w.sbox[s * 4 + 0]; o[1] = w.sbox[s * 4 + 1]; o[2] = w.sbox[s * 4 + 2]; o[3] = w.sbox[s * 4 + 3];
+            o[4] = w.sscore[s]; o[5] = (float)w.scls[s];
+            out_idx[(size_t)b * max_det + pos] = w.sanchor[s];
+            if (pos < NMS_MAXDET_CAP) w.keep_pos[(size_t)b * NMS_MAXDET_CAP + pos] = row;
+        }
+        kept += cntk;
+        if (kept >= max_det) break;
+        // fold the kept rows into the removed bitmap of the later 64-blocks
+        for (int w0 = wi + 1; w0 < nw; w0 += 64) {
+            const int ww = w0 + lane;
+            unsigned long long acc = 0ull, tmp = km;
+            const unsigned long long* col = mb + (size_t)(wi * 64) * w.nw + (ww < nw ? ww : 0);
+            while (tmp) {  // up to four independent row loads in flight per step
+                int tt[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    tt[q] = tmp ? __ffsll((long long)tmp) - 1 : -1;
+                    if (tmp) tmp &= tmp - 1ull;
+                }
+                unsigned long long v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (tt[q] >= 0 && ww < nw) ? col[(size_t)tt[q] * w.nw] : 0ull;
+                acc |= (v[0] | v[1]) | (v[2] | v[3]);
+            }
+            if (ww < nw) rem[ww] |= acc;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) out_counts[b] = kept < max_det ? kept : max_det;
+}
+
+extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A, float conf_thres, float iou_thres,
+                               int32_t multi_label, int32_t agnostic, int32_t max_det, int32_t max_nms, float max_wh,
+                               float* out_dets, int32_t* out_counts, int32_t* out_idx, int32_t* status,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!y || !out_dets || !out_counts || !out_idx || !status || !workspace) return YMK_E_BADARG;
+    if (B <= 0 || A <= 0 || nc <= 0 || max_det <= 0 || max_nms <= 0 || B > 65535 || max_det > NMS_MAXDET_CAP)
+        return YMK_E_BADARG;
+    const int multi = (multi_label && nc > 1) ? 1 : 0;
+    NmsWs w = nms_layout(workspace, B, nc, A, multi, max_nms);
+    if (workspace_bytes < w.total) return YMK_E_WORKSPACE;
+    if ((size_t)w.nw * 8 > 60 * 1024 || w.nw > 65535) return YMK_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, w);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, w, status);
+    hipLaunchKernelGGL(nms_emit_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, w);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(64, B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), (size_t)w.nw * 8, s, w, max_det, out_dets, out_counts,
+                       out_idx);
+    return ymk_launch_status();
+}
+
+// ---- CW-NMS refinement (spec: examples/.../cpp/src/common.cpp:150-185) ----------------
+// One wavefront per kept detection: fp64 accumulation over the score-sorted pool.
+__global__ __launch_bounds__(64) void cw_refine_kernel(NmsWs w, int max_det, float thr, double sigma, int pool_cap,
+                                                      float* __restrict__ dets, const int* __restrict__ counts) {
+    const int b = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
+    if (k >= counts[b]) return;
+    const int n = min(w.nsort[b], pool_cap);
+    const int row = w.keep_pos[(size_t)b * NMS_MAXDET_CAP + k];
+    const size_t base = (size_t)b * w.ns;
+    const int ck = w.scls[base + row];
+    const double kx1 = w.sbox[(base + row) * 4 + 0], ky1 = w.sbox[(base + row) * 4 + 1];
+    const double kx2 = w.sbox[(base + row) * 4 + 2], ky2 = w.sbox[(base + row) * 4 + 3];
+    const double ak = (kx2 - kx1) * (ky2 - ky1);
+    double sw = 0, ax1 = 0, ay1 = 0, ax2 = 0, ay2 = 0;
+    for (int m = lane; m < n; m += 64) {
+        if (w.scls[base + m] != ck) continue;
+        const double x1 = w.sbox[(base + m) * 4 + 0], y1 = w.sbox[(base + m) * 4 + 1];
+        const double x2 = w.sbox[(base + m) * 4 + 2], y2 = w.sbox[(base + m) * 4 + 3];
+        const double iw = fmin(kx2, x2) - fmax(kx1, x1), ih = fmin(ky2, y2) - fmax(ky1, y1);
+        if (iw <= 0 || ih <= 0) continue;
+        const double inter = iw * ih;
+        const double uni = ak + (x2 - x1) * (y2 - y1) - inter;
+        const double ov = uni > 0 ? inter / uni : 0.0;
+        if (ov <= (double)thr) continue;
+        const double wt = (double)w.sscore[base + m] * exp(-((1.0 - ov) * (1.0 - ov)) / sigma);
+        sw += wt; ax1 += wt * x1; ay1 += wt * y1; ax2 += wt * x2; ay2 += wt * y2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sw += __shfl_xor(sw, o); ax1 += __shfl_xor(ax1, o); ay1 += __shfl_xor(ay1, o);
+        ax2 += __shfl_xor(ax2, o); ay2 += __shfl_xor(ay2, o);
+    }
+    if (lane == 0 && sw > 1e-6) {
+        float* o = dets + ((size_t)b * max_det + k) * 6;
+        const double x0 = ax1 / sw, y0 = ay1 / sw;
+        const double ww = fmax(0.0, ax2 / sw - x0), hh = fmax(0.0, ay2 / sw - y0);
+        o[0] = (float)x0; o[1] = (float)y0; o[2] = (float)(x0 + ww); o[3] = (float)(y0 + hh);
+    }
+}
+
+extern "C" int ymk_cw_refine(int32_t B, int32_t nc, int32_t A, int32_t multi_label, int32_t max_nms, int32_t max_det,
+                                float iou_thres, float sigma, int32_t pool_cap, float* out_dets,
+                                const int32_t* out_counts, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!out_dets || !out_counts || !workspace || B <= 0 || max_det <= 0 || max_det > NMS_MAXDET_CAP || !(sigma > 0.f))
+        return YMK_E_BADARG;
+    const int multi = (multi_label && nc > 1) ? 1 : 0;
+    NmsWs w = nms_layout(workspace, B, nc, A, multi, max_nms);
+    if (workspace_bytes < w.total) return YMK_E_WORKSPACE;
+    hipLaunchKernelGGL(cw_refine_kernel, dim3(max_det, B), dim3(64), 0, (hipStream_t)stream, w, max_det, iou_thres,
+                       (double)sigma, pool_cap, out_dets, out_counts);
+    return ymk_launch_status();
+}

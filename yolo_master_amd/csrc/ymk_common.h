@@ -1,0 +1,95 @@
+// Shared device/host helpers for libymk (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ymk.h"
+
+#define YMK_WAVE 64
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+    return __uint_as_float(((uint32_t)h) << 16);
+}
+// round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16 cast)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// SiLU exactly as x * sigmoid(x) with sigmoid = 1/(1+exp(-x)) (torch CPU formula)
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+
+template <typename T>
+struct ElemTraits;
+template <>
+struct ElemTraits<float> {
+    static constexpr int VEC = 4;  // elements per 16 bytes
+    static constexpr int DT = YMK_F32;
+};
+template <>
+struct ElemTraits<bf16_t> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = YMK_BF16;
+};
+
+// load VEC elements (16 B) as fp32 values
+__device__ __forceinline__ void load_vec_f32(const float* p, float (&v)[4]) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load_vec_f32(const bf16_t* p, float (&v)[8]) {
+    u32x4 t = *reinterpret_cast<const u32x4*>(p);
+    v[0] = bf16lo(t.x); v[1] = bf16hi(t.x); v[2] = bf16lo(t.y); v[3] = bf16hi(t.y);
+    v[4] = bf16lo(t.z); v[5] = bf16hi(t.z); v[6] = bf16lo(t.w); v[7] = bf16hi(t.w);
+}
+__device__ __forceinline__ void store_vec_f32(float* p, const float (&v)[4]) {
+    f32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+    *reinterpret_cast<f32x4*>(p) = t;
+}
+__device__ __forceinline__ void store_vec_f32(bf16_t* p, const float (&v)[8]) {
+    u32x4 t;
+    t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);
+    t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<u32x4*>(p) = t;
+}
+// store 4 consecutive channels
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    f32x4 t; t.x = a; t.y = b; t.z = c; t.w = d;
+    *reinterpret_cast<f32x4*>(p) = t;
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+    u32x2 t; t.x = pack_bf16x2(a, b); t.y = pack_bf16x2(c, d);
+    *reinterpret_cast<u32x2*>(p) = t;
+}
+__device__ __forceinline__ void load4(const float* p, float& a, float& b, float& c, float& d) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    a = t.x; b = t.y; c = t.z; d = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float& a, float& b, float& c, float& d) {
+    u32x2 t = *reinterpret_cast<const u32x2*>(p);
+    a = bf16lo(t.x); b = bf16hi(t.x); c = bf16lo(t.y); d = bf16hi(t.y);
+}
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ void from_f32(float& d, float v) { d = v; }
+__device__ __forceinline__ void from_f32(bf16_t& d, float v) { d = f32_to_bf16(v); }
+
+static inline int ymk_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? YMK_OK : YMK_E_LAUNCH;
+}
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,780 @@
+"""Module library of the MI355X-native YOLO-Master detection path.
+
+Every class keeps the constructor signature, attribute names and parameter/buffer names of
+its reference counterpart (cited per class), so a reference ``state_dict`` loads unchanged
+and ``parse_model`` can build the reference's model YAMLs.  The arithmetic does NOT live
+here: ``forward`` hands NHWC views to hand-written HIP kernels through the libymk C-ABI
+(``yolo_master_amd.ops``).  There is no PyTorch/CPU implementation of the forward pass in
+this package — on a CPU tensor (or without libymk.so) the ops raise.
+
+Internal calling convention: ``m._run(x, out=None, ...)`` takes/returns NHWC tensors
+``[B, H, W, C]`` (possibly channel slices of a wider buffer, which is how Concat/chunk are
+made free); ``m.forward(x)`` is the public NCHW-logical wrapper (returns a channels-last
+view, zero-copy).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..errors import MoERouterError, ShapeMismatchError
+
+__all__ = [
+    "autopad", "Conv", "DWConv", "Concat", "Bottleneck", "C2f", "C3", "C3k", "C3k2", "AAttn", "ABlock", "A2C2f",
+    "DFL", "Detect", "DynamicRoutingLayer", "DepthwiseSeparableConv", "EfficientExpertGroup", "ES_MOE",
+    "set_compute_dtype", "LazyUpsample",
+]
+
+
+def autopad(k, p=None, d=1):
+    """'same' padding (ultralytics/nn/modules/conv.py:30-36)."""
+    if d > 1:
+        k = d * (k - 1) + 1 if isinstance(k, int) else [d * (x - 1) + 1 for x in k]
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+class YmkModule(nn.Module):
+    """Base: compute dtype + packed-weight cache + NCHW<->NHWC public wrapper."""
+
+    ymk_dtype = torch.float32
+
+    def _cache(self) -> dict:
+        c = self.__dict__.get("_ymk_pack")
+        if c is None:
+            c = {}
+            self.__dict__["_ymk_pack"] = c
+        return c
+
+    def clear_pack(self):
+        self.__dict__["_ymk_pack"] = {}
+
+    def _packed(self, device):
+        key = (self.ymk_dtype, str(device))
+        c = self._cache()
+        if key not in c:
+            with torch.no_grad():
+                c[key] = self._pack(self.ymk_dtype, device)
+        return c[key]
+
+    def _pack(self, dtype, device):  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    # public, reference-compatible entry: NCHW-logical in, NCHW-logical (channels-last) out
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError(
+                f"{type(self).__name__}: the ymk path implements eval-mode inference only "
+                "(training runs on the reference implementation)"
+            )
+        y = self._run(to_nhwc(x, self.ymk_dtype))
+        return y.permute(0, 3, 1, 2)
+
+
+def to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """NCHW-logical tensor (any memory format) -> NHWC tensor of the compute dtype."""
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got {tuple(x.shape)}")
+    if not x.is_cuda:
+        raise RuntimeError("yolo_master_amd modules run on MI355X (HIP) only; got a CPU tensor")
+    xh = x.permute(0, 2, 3, 1)
+    if xh.dtype != dtype:
+        xh = xh.to(dtype)
+    return xh if xh.is_contiguous() else xh.contiguous()
+
+
+def set_compute_dtype(model: nn.Module, dtype: torch.dtype) -> nn.Module:
+    """Select fp32 or bf16 activations/weights for every ymk module (parameters stay fp32 masters)."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("ymk compute dtype must be torch.float32 or torch.bfloat16")
+    for m in model.modules():
+        if isinstance(m, YmkModule):
+            m.ymk_dtype = dtype
+            m.clear_pack()
+    return model
+
+
+def _is_silu(act) -> bool:
+    if isinstance(act, nn.SiLU):
+        return True
+    if isinstance(act, nn.Identity):
+        return False
+    raise NotImplementedError(f"ymk Conv supports SiLU / Identity activations, got {act}")
+
+
+def _bn_scale_shift(bn: nn.BatchNorm2d):
+    s = bn.weight.div(torch.sqrt(bn.running_var + bn.eps))
+    return s, bn.bias - bn.running_mean * s
+
+
+class Conv(YmkModule):
+    """Conv2d + BatchNorm2d + SiLU (ultralytics/nn/modules/conv.py:39-89)."""
+
+    default_act = nn.SiLU()
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+
+    # -- packing ---------------------------------------------------------------------
+    def _geometry(self):
+        cv = self.conv
+        k, s = cv.kernel_size[0], cv.stride[0]
+        if cv.kernel_size[0] != cv.kernel_size[1] or cv.stride[0] != cv.stride[1] or cv.dilation != (1, 1):
+            raise NotImplementedError("ymk Conv: square kernels, equal strides, dilation 1 only")
+        if cv.padding != (k // 2, k // 2):
+            raise NotImplementedError("ymk Conv: padding must be k//2 ('same')")
+        dw = cv.groups > 1
+        if dw and not (cv.groups == cv.in_channels == cv.out_channels and s == 1):
+            raise NotImplementedError("ymk Conv: groups must be 1 or depthwise (stride 1)")
+        if not dw and k not in (1, 3):
+            raise NotImplementedError("ymk Conv: dense kernels are 1x1 or 3x3")
+        return k, s, dw
+
+    def _folded(self):
+        w = self.conv.weight.detach().float()
+        if hasattr(self, "bn"):
+            bn = self.bn
+            return ops.fold_bn(w, bn.weight.float(), bn.bias.float(), bn.running_mean.float(), bn.running_var.float(),
+                               bn.eps, None if self.conv.bias is None else self.conv.bias.float())
+        b = self.conv.bias.detach().float() if self.conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+        return w, b
+
+    cout_perm = None  # optional output-channel permutation applied at pack time (AAttn.qkv)
+
+    def _pack(self, dtype, device):
+        k, s, dw = self._geometry()
+        w, b = self._folded()
+        w, b = w.to(device), b.to(device)
+        if self.cout_perm is not None:
+            perm = torch.as_tensor(self.cout_perm, device=device)
+            w, b = w[perm], b[perm]
+        if dw:
+            return {"dw": True, "w": ops.pack_dw_weight(w, dtype), "b": b.contiguous(), "k": k, "s": s}
+        if self.conv.in_channels <= 4:  # stem: fp32 [Cout][k*k*Cin], reads the NCHW input directly
+            return {"stem": True, "w": w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), "b": b.contiguous(),
+                    "k": k, "s": s}
+        return {"dw": False, "w": ops.pack_conv_weight(w, dtype), "b": b.contiguous(), "k": k, "s": s}
+
+    # -- execution -------------------------------------------------------------------
+    def _run(self, x, out=None, residual=None, out_dtype=None):
+        pk = self._packed(x.device)
+        act = _is_silu(self.act)
+        if pk.get("stem"):
+            raise RuntimeError("stem Conv (Cin<=4) consumes the NCHW network input: use _run_stem")
+        if pk["dw"]:
+            return ops.dwconv2d(x, pk["w"], pk["b"], pk["k"], act, out=out, residual=residual)
+        return ops.conv2d(x, pk["w"], pk["b"], pk["k"], pk["s"], act, out=out, residual=residual, out_dtype=out_dtype)
+
+    def _run_stem(self, x_nchw, out=None):
+        pk = self._packed(x_nchw.device)
+        return ops.conv2d_stem(x_nchw, pk["w"], pk["b"], pk["k"], pk["s"], _is_silu(self.act), self.ymk_dtype, out=out)
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("Conv: the ymk path implements eval-mode inference only")
+        if self.conv.in_channels <= 4 and self.conv.groups == 1:
+            if not x.is_cuda:
+                raise RuntimeError("yolo_master_amd modules run on MI355X (HIP) only; got a CPU tensor")
+            return self._run_stem(x).permute(0, 3, 1, 2)
+        return self._run(to_nhwc(x, self.ymk_dtype)).permute(0, 3, 1, 2)
+
+    forward_fuse = forward  # BN is always folded at pack time (torch_utils.py:315-349 semantics)
+
+
+class DWConv(Conv):
+    """Depth-wise convolution (ultralytics/nn/modules/conv.py:185-199)."""
+
+    def __init__(self, c1, c2, k=1, s=1, d=1, act=True):
+        super().__init__(c1, c2, k, s, g=math.gcd(c1, c2), d=d, act=act)
+
+
+class LazyUpsample:
+    """Marker returned by the graph walker for nn.Upsample: the consumer (Concat) materialises
+    the 2x nearest upsample straight into its channel slice."""
+
+    def __init__(self, src):
+        self.src = src
+
+    def materialise(self, out=None):
+        return ops.upsample2x(self.src, out=out)
+
+
+class Concat(nn.Module):
+    """Concatenate along channels (ultralytics/nn/modules/conv.py:616-641)."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def _run(self, xs):
+        if self.d != 1:
+            raise NotImplementedError("ymk Concat: channel dimension only")
+        shapes = [(x.src.shape[0], 2 * x.src.shape[1], 2 * x.src.shape[2], x.src.shape[3], x.src.dtype, x.src.device)
+                  if isinstance(x, LazyUpsample) else (*x.shape, x.dtype, x.device) for x in xs]
+        B, H, W = shapes[0][:3]
+        ctot = sum(s[3] for s in shapes)
+        buf = ops.new_act(B, H, W, ctot, shapes[0][4], shapes[0][5])
+        c0 = 0
+        for x, s in zip(xs, shapes):
+            sl = buf[..., c0:c0 + s[3]]
+            if isinstance(x, LazyUpsample):
+                x.materialise(out=sl)
+            else:
+                ops.copy_channels(x, sl)
+            c0 += s[3]
+        return buf
+
+    def forward(self, x):
+        dt = x[0].dtype
+        y = self._run([to_nhwc(t, dt) for t in x])
+        return y.permute(0, 3, 1, 2)
+
+
+class Bottleneck(YmkModule):
+    """Standard bottleneck (ultralytics/nn/modules/block.py:462-486)."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def _run(self, x, out=None):
+        h = self.cv1._run(x)
+        return self.cv2._run(h, out=out, residual=x if self.add else None)
+
+
+class C2f(YmkModule):
+    """CSP bottleneck with 2 convolutions (ultralytics/nn/modules/block.py:293-325)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
+
+    def _run(self, x, out=None):
+        # chunk(2)/cat are free: cv1 and every block write their slice of one buffer
+        B, H, W, _ = x.shape
+        c, n = self.c, len(self.m)
+        cat = ops.new_act(B, H, W, (2 + n) * c, x.dtype, x.device)
+        self.cv1._run(x, out=cat[..., : 2 * c])
+        for i, m in enumerate(self.m):
+            m._run(cat[..., (1 + i) * c:(2 + i) * c], out=cat[..., (2 + i) * c:(3 + i) * c])
+        return self.cv2._run(cat, out=out)
+
+
+class C3(YmkModule):
+    """CSP bottleneck with 3 convolutions (ultralytics/nn/modules/block.py:327-351)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, k=((1, 1), (3, 3)), e=1.0) for _ in range(n)))
+
+    def _run(self, x, out=None):
+        B, H, W, _ = x.shape
+        c_ = self.cv1.conv.out_channels
+        cat = ops.new_act(B, H, W, 2 * c_, x.dtype, x.device)
+        n = len(self.m)
+        h = self.cv1._run(x, out=cat[..., :c_] if n == 0 else None)
+        for j, blk in enumerate(self.m):
+            h = blk._run(h, out=cat[..., :c_] if j == n - 1 else None)
+        self.cv2._run(x, out=cat[..., c_:])
+        return self.cv3._run(cat, out=out)
+
+
+class C3k(C3):
+    """C3 with k x k bottlenecks (ultralytics/nn/modules/block.py:1114-1132)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5, k=3):
+        super().__init__(c1, c2, n, shortcut, g, e)
+        c_ = int(c2 * e)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, k=(k, k), e=1.0) for _ in range(n)))
+
+
+class C3k2(C2f):
+    """C2f whose blocks are Bottleneck or C3k (ultralytics/nn/modules/block.py:1074-1111)."""
+
+    def __init__(self, c1, c2, n=1, c3k=False, e=0.5, attn=False, g=1, shortcut=True):
+        super().__init__(c1, c2, n, shortcut, g, e)
+        if attn:
+            raise NotImplementedError("ymk C3k2: attn=True (PSABlock) is not on the master det path")
+        self.m = nn.ModuleList(
+            C3k(self.c, self.c, 2, shortcut, g) if c3k else Bottleneck(self.c, self.c, shortcut, g) for _ in range(n)
+        )
+
+
+class AAttn(YmkModule):
+    """Area attention (ultralytics/nn/modules/block.py:1646-1732)."""
+
+    def __init__(self, dim, num_heads, area=1):
+        super().__init__()
+        self.area = area
+        self.num_heads = num_heads
+        self.head_dim = head_dim = dim // num_heads
+        self.all_head_dim = all_head_dim = head_dim * self.num_heads
+        self.qkv = Conv(dim, all_head_dim * 3, 1, act=False)
+        self.proj = Conv(all_head_dim, dim, 1, act=False)
+        self.pe = Conv(all_head_dim, all_head_dim, 7, 1, 3, g=all_head_dim, act=False)
+        if head_dim != 32:
+            raise NotImplementedError("ymk AAttn kernel is specialised for head_dim == 32")
+        # re-order qkv output channels from per-head [q|k|v] to [Q(all heads) | K | V] so that q, k, v
+        # of the 1x1 conv output are contiguous channel ranges (free: applied to the packed weights)
+        d, h = head_dim, num_heads
+        self.qkv.cout_perm = [hh * 3 * d + part * d + dd for part in range(3) for hh in range(h) for dd in range(d)]
+
+    def _run(self, x, out=None, residual=None):
+        """Returns residual + proj(attn(x) + pe(v)) (residual = the ABlock skip input)."""
+        B, H, W, _ = x.shape
+        if (H * W) % self.area:
+            raise ValueError(f"AAttn: {H}x{W} tokens not divisible by area={self.area}")
+        qkv = self.qkv._run(x)
+        c = self.all_head_dim
+        att = ops.area_attn(qkv, self.num_heads, self.area)
+        att = self.pe._run(qkv[..., 2 * c:], residual=att)  # x + pe(v)
+        return self.proj._run(att, out=out, residual=residual)
+
+
+class ABlock(YmkModule):
+    """Area-attention block (ultralytics/nn/modules/block.py:1735-1797)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=1.2, area=1):
+        super().__init__()
+        self.attn = AAttn(dim, num_heads=num_heads, area=area)
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.mlp = nn.Sequential(Conv(dim, mlp_hidden_dim, 1), Conv(mlp_hidden_dim, dim, 1, act=False))
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Conv2d):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def _run(self, x, out=None):
+        x1 = self.attn._run(x, residual=x)              # x + attn(x)
+        h = self.mlp[0]._run(x1)
+        return self.mlp[1]._run(h, out=out, residual=x1)  # x + mlp(x)
+
+
+class A2C2f(YmkModule):
+    """Area-attention C2f (ultralytics/nn/modules/block.py:1800-1879)."""
+
+    def __init__(self, c1, c2, n=1, a2=True, area=1, residual=False, mlp_ratio=2.0, e=0.5, g=1, shortcut=True):
+        super().__init__()
+        c_ = int(c2 * e)
+        assert c_ % 32 == 0, "Dimension of ABlock must be a multiple of 32."
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv((1 + n) * c_, c2, 1)
+        self.gamma = nn.Parameter(0.01 * torch.ones(c2), requires_grad=True) if a2 and residual else None
+        self.m = nn.ModuleList(
+            nn.Sequential(*(ABlock(c_, c_ // 32, mlp_ratio, area) for _ in range(2))) if a2 else C3k(c_, c_, 2, shortcut, g)
+            for _ in range(n)
+        )
+
+    def _run(self, x, out=None):
+        if self.gamma is not None:
+            raise NotImplementedError("ymk A2C2f: gamma-residual (l/x scales) not built yet")
+        B, H, W, _ = x.shape
+        c_ = self.cv1.conv.out_channels
+        n = len(self.m)
+        cat = ops.new_act(B, H, W, (1 + n) * c_, x.dtype, x.device)
+        self.cv1._run(x, out=cat[..., :c_])
+        for i, m in enumerate(self.m):
+            src, dst = cat[..., i * c_:(i + 1) * c_], cat[..., (i + 1) * c_:(i + 2) * c_]
+            if isinstance(m, nn.Sequential):
+                h = src
+                for j, blk in enumerate(m):
+                    h = blk._run(h, out=dst if j == len(m) - 1 else None)
+            else:
+                m._run(src, out=dst)
+        return self.cv2._run(cat, out=out)
+
+
+class DFL(nn.Module):
+    """Distribution-focal-loss integral (ultralytics/nn/modules/block.py:63-84); the decode
+    kernel evaluates it in closed form, this module only carries the fixed arange weights."""
+
+    def __init__(self, c1=16):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, 1, 1, bias=False).requires_grad_(False)
+        x = torch.arange(c1, dtype=torch.float)
+        self.conv.weight.data[:] = nn.Parameter(x.view(1, c1, 1, 1))
+        self.c1 = c1
+
+
+class _PlainConv:
+    """Packing helper for the bare nn.Conv2d 1x1 (+bias) that ends each Detect branch."""
+
+    @staticmethod
+    def pack(conv: nn.Conv2d, dtype, device):
+        if conv.kernel_size != (1, 1) or conv.groups != 1:
+            raise NotImplementedError("Detect tail conv must be 1x1")
+        w = conv.weight.detach().float().to(device)
+        b = conv.bias.detach().float().to(device) if conv.bias is not None else torch.zeros(w.shape[0], device=device)
+        return ops.pack_conv_weight(w, dtype), b.contiguous()
+
+
+class Detect(YmkModule):
+    """Detection head (ultralytics/nn/modules/head.py:37-258): box/cls branches + DFL decode."""
+
+    dynamic = False
+    export = False
+    format = None
+    max_det = 300
+    agnostic_nms = False
+    shape = None
+    anchors = torch.empty(0)
+    strides = torch.empty(0)
+    legacy = False
+    xyxy = False
+
+    def __init__(self, nc=80, reg_max=16, end2end=False, ch=()):
+        super().__init__()
+        if end2end:
+            raise NotImplementedError("ymk Detect: end2end (one2one) heads are not on the master det path")
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = reg_max
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        c2, c3 = max((16, ch[0] // 4, self.reg_max * 4)), max(ch[0], min(self.nc, 100))
+        self.cv2 = nn.ModuleList(
+            nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for x in ch
+        )
+        self.cv3 = (
+            nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
+            if self.legacy
+            else nn.ModuleList(
+                nn.Sequential(
+                    nn.Sequential(DWConv(x, x, 3), Conv(x, c3, 1)),
+                    nn.Sequential(DWConv(c3, c3, 3), Conv(c3, c3, 1)),
+                    nn.Conv2d(c3, self.nc, 1),
+                )
+                for x in ch
+            )
+        )
+        self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
+
+    end2end = False
+
+    def bias_init(self):
+        """Detect bias init (head.py:196-211); requires self.stride."""
+        for a, b, s in zip(self.cv2, self.cv3, self.stride):
+            a[-1].bias.data[:] = 2.0
+            b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)
+
+    def _pack(self, dtype, device):
+        return {"box": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv2],
+                "cls": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv3]}
+
+    def _branch(self, seq, x):
+        for m in list(seq)[:-1]:
+            if isinstance(m, nn.Sequential):
+                for mm in m:
+                    x = mm._run(x)
+            else:
+                x = m._run(x)
+        return x
+
+    def _run(self, feats):
+        """feats: list of NHWC maps.  Returns (y [B, 4+nc, A] fp32, raw) with raw = per-level
+        (box_logits [B,H,W,4*reg_max], cls_logits [B,H,W,nc]) fp32 NHWC tensors."""
+        if self.reg_max <= 1:
+            raise NotImplementedError("ymk Detect: reg_max must be > 1 (DFL)")
+        pk = self._packed(feats[0].device)
+        B = feats[0].shape[0]
+        A = sum(f.shape[1] * f.shape[2] for f in feats)
+        y = torch.empty((B, 4 + self.nc, A), dtype=torch.float32, device=feats[0].device)
+        raw, a_off = [], 0
+        for i, f in enumerate(feats):
+            hb = self._branch(self.cv2[i], f)
+            box = ops.conv2d(hb, pk["box"][i][0], pk["box"][i][1], 1, 1, False, out_dtype=torch.float32)
+            hc = self._branch(self.cv3[i], f)
+            cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)
+            ops.detect_decode(box, cls, y, float(self.stride[i]), a_off, self.reg_max)
+            raw.append((box, cls))
+            a_off += f.shape[1] * f.shape[2]
+        return y, raw
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("Detect: the ymk path implements eval-mode inference only")
+        feats = [to_nhwc(t, self.ymk_dtype) for t in x]
+        y, raw = self._run(feats)
+        if self.export:
+            return y
+        B = y.shape[0]
+        boxes = torch.cat([b.reshape(B, -1, 4 * self.reg_max) for b, _ in raw], 1).permute(0, 2, 1)
+        scores = torch.cat([c.reshape(B, -1, self.nc) for _, c in raw], 1).permute(0, 2, 1)
+        return y, dict(boxes=boxes, scores=scores, feats=list(x))
+
+
+# ------------------------------------------------------------------------------ ES-MoE
+class DynamicRoutingLayer(nn.Module):
+    """Router parameters (ultralytics/nn/modules/moe/routers.py:429-457); evaluated by ymk_esmoe_route."""
+
+    def __init__(self, in_channels, num_experts=3, reduction=8, top_k=None):
+        super().__init__()
+        if num_experts < 1:
+            raise ValueError(f"num_experts must be positive, got {num_experts}")
+        if reduction < 1:
+            raise ValueError(f"reduction must be positive, got {reduction}")
+        if top_k is not None and not 1 <= top_k <= num_experts:
+            raise ValueError(f"top_k must be in [1, {num_experts}], got {top_k}")
+        reduced_channels = max(in_channels // reduction, 8)
+        self.in_channels = in_channels
+        self.num_experts = num_experts
+        self.top_k = min(top_k, num_experts) if top_k is not None else num_experts
+        self.use_top_k = top_k is not None
+        self.global_pool = nn.AdaptiveAvgPool2d(1)
+        self.routing_network = nn.Sequential(
+            nn.Conv2d(in_channels, reduced_channels, kernel_size=1),
+            nn.SiLU(inplace=False),
+            nn.Conv2d(reduced_channels, num_experts, kernel_size=1),
+        )
+        self.last_routing_diagnostics = {}
+
+
+class DepthwiseSeparableConv(nn.Module):
+    """Expert body parameters (ultralytics/nn/modules/moe/experts.py:280-296)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1):
+        super().__init__()
+        padding = (kernel_size - 1) // 2
+        self.depthwise = nn.Conv2d(in_channels, in_channels, kernel_size, stride=stride, padding=padding,
+                                   groups=in_channels, bias=False)
+        self.pointwise = nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.act = nn.SiLU(inplace=True)
+
+
+class EfficientExpertGroup(nn.Module):
+    """ultralytics/nn/modules/moe/experts.py:299-311."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1):
+        super().__init__()
+        self.conv = DepthwiseSeparableConv(in_channels, out_channels, kernel_size, stride)
+
+
+class ES_MOE(YmkModule):
+    """Sample-routed conv MoE (ultralytics/nn/modules/moe/modules.py:410-779).
+
+    Eval forward = router (GAP -> 2 x 1x1 -> softmax -> top-k -> threshold/renorm -> CSR), depthwise
+    stage over the CSR pairs, pointwise grouped GEMM with fused BN/SiLU/gate/accumulate and the
+    trailing BN+SiLU; all in libymk.  Non-finite router input/logits raise ``MoERouterError`` when the
+    batch's device flag word is checked (``check_flags``), not through a per-layer host sync.
+    """
+
+    def __init__(self, in_channels, out_channels=None, num_experts=4, reduction=8, top_k=2, use_sparse_inference=True,
+                 dynamic_threshold=0.4, max_kernel_size=15, expert_kernel_sizes=None):
+        super().__init__()
+        if in_channels < 1 or (out_channels is not None and out_channels < 1):
+            raise ValueError("in_channels and out_channels must be positive")
+        if num_experts < 1:
+            raise ValueError(f"num_experts must be positive, got {num_experts}")
+        if reduction < 1:
+            raise ValueError(f"reduction must be positive, got {reduction}")
+        if top_k is not None and not 1 <= top_k <= num_experts:
+            raise ValueError(f"top_k must be in [1, {num_experts}], got {top_k}")
+        if not 0.0 <= dynamic_threshold <= 1.0:
+            raise ValueError(f"dynamic_threshold must be in [0, 1], got {dynamic_threshold}")
+        if max_kernel_size < 3:
+            raise ValueError(f"max_kernel_size must be at least 3, got {max_kernel_size}")
+        max_kernel_size = int(max_kernel_size)
+        if max_kernel_size % 2 == 0:
+            max_kernel_size -= 1
+        if out_channels is None:
+            out_channels = in_channels
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_experts = num_experts
+        self.reduction = reduction
+        self.top_k = min(top_k, num_experts) if top_k is not None else num_experts
+        self.use_top_k = top_k is not None
+        self.use_sparse_inference = use_sparse_inference
+        self.dynamic_threshold = dynamic_threshold
+        self.max_kernel_size = max_kernel_size
+        self.routing = DynamicRoutingLayer(in_channels, num_experts, reduction, top_k)
+        if expert_kernel_sizes is not None:
+            if len(expert_kernel_sizes) != num_experts:
+                raise ValueError(f"expert_kernel_sizes must have {num_experts} entries, got {len(expert_kernel_sizes)}")
+            ks = []
+            for k in expert_kernel_sizes:
+                k = int(k)
+                if k % 2 == 0:
+                    k -= 1
+                ks.append(min(k, max_kernel_size))
+        else:
+            default_kernel_sizes = [3, 5, 7]
+            if num_experts <= len(default_kernel_sizes):
+                ks = [min(k, max_kernel_size) for k in default_kernel_sizes[:num_experts]]
+            else:
+                ks = [min(3 + 2 * i, max_kernel_size) for i in range(num_experts)]
+        self.experts = nn.ModuleList([EfficientExpertGroup(in_channels, out_channels, kernel_size=k) for k in ks])
+        self.norm = nn.Sequential(nn.BatchNorm2d(out_channels), nn.SiLU(inplace=True))
+        self.register_buffer("load_balancing_loss", torch.tensor(0.0), persistent=False)
+        self.register_buffer("expert_usage_counts", torch.zeros(num_experts), persistent=False)
+        self.last_routing_snapshot = {}
+        self.last_routing_diagnostics = {}
+        self.balance_loss_coeff = 1.0
+        self._flags = None
+        self.last_route = None
+
+    # -- routed-module protocol (ultralytics/nn/modules/routing_protocol.py:34-55) -----------
+    @property
+    def aux_loss(self):
+        return self.load_balancing_loss * float(self.balance_loss_coeff)
+
+    def publish_aux_loss(self, *, step: int, training: bool):
+        return self.aux_loss
+
+    def routing_snapshot(self) -> dict:
+        return dict(self.last_routing_snapshot)
+
+    def _eager_sparse_enabled(self) -> bool:
+        return bool(self.use_sparse_inference and self.use_top_k and self.top_k < self.num_experts)
+
+    def export_capabilities(self) -> dict:
+        sparse = self._eager_sparse_enabled()
+        return dict(routing_kind="moe", num_experts=self.num_experts, top_k=self.top_k, sparse_dispatch=sparse,
+                    eager_sparse_dispatch=sparse, training_sparse_dispatch=False)
+
+    def get_load_balancing_loss(self):
+        return self.load_balancing_loss
+
+    def get_expert_usage_stats(self):
+        if self.expert_usage_counts.numel() > 0:
+            stats = {
+                "expert_usage": self.expert_usage_counts.cpu().tolist(),
+                "usage_variance": self.expert_usage_counts.var().item(),
+                "max_usage": self.expert_usage_counts.max().item(),
+                "min_usage": self.expert_usage_counts.min().item(),
+            }
+            if self.use_top_k:
+                stats["active_experts"] = f"{self.top_k}/{self.num_experts}"
+                stats["theoretical_speedup"] = f"{self.num_experts / self.top_k:.2f}x"
+            return stats
+        return None
+
+    def set_top_k(self, top_k):
+        if top_k is not None:
+            self.top_k = min(top_k, self.num_experts)
+            self.routing.top_k = self.top_k
+            self.use_top_k = True
+            self.routing.use_top_k = True
+        else:
+            self.top_k = self.num_experts
+            self.use_top_k = False
+            self.routing.use_top_k = False
+
+    def enable_sparse_inference(self, enable=True):
+        self.use_sparse_inference = enable
+
+    # -- packing -------------------------------------------------------------------------
+    def _pack(self, dtype, device):
+        E, C, Co = self.num_experts, self.in_channels, self.out_channels
+        rn = self.routing.routing_network
+        hidden = rn[0].out_channels
+        ks, dw_parts, dw_off, off = [], [], [], 0
+        pw_w = torch.zeros((E, Co, ops.kpad(C)), dtype=torch.float32, device=device)
+        pw_b = torch.zeros((E, Co), dtype=torch.float32, device=device)
+        for e, ex in enumerate(self.experts):
+            cv = ex.conv
+            k = cv.depthwise.kernel_size[0]
+            if cv.depthwise.stride != (1, 1) or k % 2 == 0 or k > 15:
+                raise NotImplementedError("ymk ES_MOE: experts are odd k<=15 stride-1 depthwise + pointwise")
+            ks.append(k)
+            w = ops.pack_dw_weight(cv.depthwise.weight.detach().float().to(device), dtype)
+            dw_parts.append(w.reshape(-1))
+            dw_off.append(off)
+            off += w.numel()
+            wf, bf = ops.fold_bn(cv.pointwise.weight.detach().float().to(device), cv.bn.weight.float().to(device),
+                                 cv.bn.bias.float().to(device), cv.bn.running_mean.float().to(device),
+                                 cv.bn.running_var.float().to(device), cv.bn.eps)
+            pw_w[e, :, :C] = wf.reshape(Co, C)
+            pw_b[e] = bf
+        ns, nt = _bn_scale_shift(self.norm[0])
+        i32 = dict(dtype=torch.int32, device=device)
+        return {
+            "w1": rn[0].weight.detach().float().reshape(hidden, C).to(device).contiguous(),
+            "b1": rn[0].bias.detach().float().to(device).contiguous(),
+            "w2": rn[2].weight.detach().float().reshape(E, hidden).to(device).contiguous(),
+            "b2": rn[2].bias.detach().float().to(device).contiguous(),
+            "dw_w": torch.cat(dw_parts).contiguous(), "dw_off": torch.tensor(dw_off, **i32),
+            "ks": torch.tensor(ks, **i32), "pw_w": pw_w.to(dtype).contiguous(), "pw_b": pw_b.contiguous(),
+            "ns": ns.detach().float().to(device).contiguous(), "nt": nt.detach().float().to(device).contiguous(),
+        }
+
+    # -- execution -----------------------------------------------------------------------
+    def bind_flags(self, flags: torch.Tensor):
+        """Share one device flag word (per batch) between all routed layers of a model."""
+        self._flags = flags
+
+    def _run(self, x, out=None):
+        if x.dim() != 4:
+            raise MoERouterError(f"Router input must be 4-D (NCHW), got {x.dim()}-D shape {tuple(x.shape)} "
+                                 "[DynamicRoutingLayer]")
+        B, H, W, C = x.shape
+        if C != self.in_channels:
+            raise ShapeMismatchError(expected=f"(N, {self.in_channels}, H, W)", actual=(B, C, H, W),
+                                     context="DynamicRoutingLayer")
+        pk = self._packed(x.device)
+        if self._flags is None or self._flags.device != x.device:
+            self._flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
+        dense = not self._eager_sparse_enabled()
+        top_k = self.num_experts if dense else self.top_k
+        route_w, gate_w, sel, csr_off, csr_pair = ops.esmoe_route(
+            x, pk["w1"], pk["b1"], pk["w2"], pk["b2"], top_k, float(self.dynamic_threshold), self._flags)
+        dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], top_k, sel, csr_off, csr_pair)
+        y = ops.esmoe_pw(dw, B, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel, gate_w, out=out)
+        # eval-time state the reference keeps (modules.py:706-741): usage = mean routing weight
+        usage = route_w.mean(0)
+        self.expert_usage_counts = usage
+        un = usage / usage.sum().clamp_min(1e-6)
+        self.load_balancing_loss = self.num_experts * torch.sum(un * un)
+        self.last_route = {"route_w": route_w, "gate_w": gate_w, "sel": sel, "csr_off": csr_off, "csr_pair": csr_pair}
+        return y
+
+    def check_flags(self):
+        """Host-side check of the device flag word (one sync); raises the reference's exception types."""
+        if self._flags is None:
+            return
+        f = int(self._flags.item())
+        self.last_routing_diagnostics = {
+            "all_finite": (f & 3) == 0,
+            "first_nonfinite_boundary": "router_input" if f & 1 else "router_logits" if f & 2 else None,
+        }
+        if f & 1:
+            self._flags.zero_()
+            raise MoERouterError("Router input contains NaN/Inf values [DynamicRoutingLayer]")
+        if f & 2:
+            self._flags.zero_()
+            raise MoERouterError("DynamicRoutingLayer internal output contains NaN/Inf values")
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("ES_MOE: the ymk path implements eval-mode inference only")
+        if x.dim() != 4:
+            raise MoERouterError(f"Router input must be 4-D (NCHW), got {x.dim()}-D shape {tuple(x.shape)} "
+                                 "[DynamicRoutingLayer]")
+        if x.shape[1] != self.in_channels:
+            raise ShapeMismatchError(expected=f"(N, {self.in_channels}, H, W)", actual=tuple(x.shape),
+                                     context="DynamicRoutingLayer")
+        y = self._run(to_nhwc(x, self.ymk_dtype))
+        self.check_flags()  # module-level API keeps the reference's eager raise-on-NaN contract
+        return y.permute(0, 3, 1, 2)

@@ -1,0 +1,276 @@
+"""Model-YAML parser and detection model of the ymk path.
+
+``parse_model`` follows the reference's YAML contract (ultralytics/nn/tasks.py:2022-2270:
+``[from, repeats, module, args]`` rows, ``scales``, width/depth/max_channels rules, and the
+mixture-module argument adaptation of ultralytics/nn/mixture_registry.py:84-156) for the module
+set of the YOLO-Master detection graphs.  ``DetectionModel`` keeps the reference's attribute
+surface (``model``, ``save``, ``stride``, ``yaml``, ``names``, ``fuse()``, ``forward/predict``;
+tasks.py:123-218, 502-560) and walks the graph on NHWC buffers through libymk.
+"""
+from __future__ import annotations
+
+import ast
+import contextlib
+import math
+import re
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import yaml
+
+from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DWConv, LazyUpsample,
+                      YmkModule, set_compute_dtype)
+
+CFG_DIR = Path(__file__).resolve().parent.parent / "cfg"
+
+BASE_MODULES = {"Conv": Conv, "DWConv": DWConv, "Bottleneck": Bottleneck, "C2f": C2f, "C3": C3, "C3k2": C3k2,
+                "A2C2f": A2C2f}
+REPEAT_MODULES = {C2f, C3, C3k2, A2C2f}
+# the plugin registry the reference resolves YAML names through (mixture_registry.py:39-81)
+MIXTURE_MODULES = {"ES_MOE": ES_MOE}
+HEAD_MODULES = {"Detect": Detect}
+
+
+def make_divisible(x, divisor):
+    """ultralytics/utils/ops.py:161-173."""
+    return math.ceil(x / divisor) * divisor
+
+
+def guess_model_scale(path) -> str:
+    m = re.search(r"-([nslmx])(-[a-z0-9]+)?$", Path(path).stem)
+    return m.group(1) if m else ""
+
+
+def yaml_model_load(path):
+    """Load a model YAML; ``yolo-master-s.yaml`` resolves to ``yolo-master.yaml`` + scale 's'."""
+    p = Path(path)
+    cands = [p, CFG_DIR / p.name]
+    scale = guess_model_scale(p)
+    if scale:
+        unified = re.sub(r"-([nslmx])$", "", p.stem) + p.suffix
+        cands += [p.with_name(unified), CFG_DIR / unified]
+    for c in cands:
+        if c.exists():
+            d = yaml.safe_load(c.read_text())
+            d["yaml_file"] = str(path)
+            if scale and "scale" not in d:
+                d["scale"] = scale
+            return d
+    raise FileNotFoundError(f"model yaml {path} not found (searched {[str(c) for c in cands]})")
+
+
+def parse_model(d, ch, verbose=False):
+    """YAML dict -> (nn.Sequential, save list); mirrors tasks.py:2022-2270 for the supported modules."""
+    legacy = True
+    max_channels = float("inf")
+    nc, act, scales, end2end = (d.get(x) for x in ("nc", "activation", "scales", "end2end"))
+    reg_max = d.get("reg_max", 16)
+    depth, width = d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0)
+    scale = d.get("scale")
+    if scales:
+        if not scale:
+            scale = next(iter(scales.keys()))
+        depth, width, max_channels = scales[scale]
+    if act:
+        raise NotImplementedError("ymk parse_model: custom default activations are not supported (SiLU only)")
+    ch = [ch]
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
+        name = m
+        if m.startswith("nn."):
+            mod = getattr(nn, m[3:])
+        elif m in BASE_MODULES:
+            mod = BASE_MODULES[m]
+        elif m == "Concat":
+            mod = Concat
+        elif m in HEAD_MODULES:
+            mod = HEAD_MODULES[m]
+        elif m in MIXTURE_MODULES:
+            mod = MIXTURE_MODULES[m]
+        else:
+            raise KeyError(f"unknown model module {m!r} (ymk builds the YOLO-Master detection module set)")
+        args = list(args)
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                with contextlib.suppress(ValueError):
+                    args[j] = {"nc": nc}[a] if a == "nc" else ast.literal_eval(a)
+        n = n_ = max(round(n * depth), 1) if n > 1 else n
+        if mod in BASE_MODULES.values():
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if mod in REPEAT_MODULES:
+                args.insert(2, n)
+                n = 1
+            if mod is C3k2:
+                legacy = False
+                if scale in "mlx":
+                    args[3] = True
+            if mod is A2C2f:
+                legacy = False
+                if scale in "lx":
+                    args.extend((True, 1.2))
+        elif mod in MIXTURE_MODULES.values():  # adapt_mixture_args (mixture_registry.py:143-156)
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+        elif mod is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif mod is Detect:
+            args.extend([reg_max, end2end, [ch[x] for x in f]])
+            Detect.legacy = legacy
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*(mod(*args) for _ in range(n))) if n > 1 else mod(*args)
+        m_.np = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type = i, f, name
+        if verbose:
+            print(f"{i:>3}{f!s:>20}{n_:>3}{m_.np:10.0f}  {name:<20}{args!s:<30}")
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+class DetectionModel(nn.Module):
+    """YOLO-Master detection model on the ymk path (reference surface: tasks.py:502-560)."""
+
+    def __init__(self, cfg="yolo-master-s.yaml", ch=3, nc=None, verbose=False):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        self.yaml = deepcopy(self.yaml)
+        self.yaml["channels"] = ch
+        if nc and nc != self.yaml["nc"]:
+            self.yaml["nc"] = nc
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self.names = {i: f"{i}" for i in range(self.yaml["nc"])}
+        self.inplace = self.yaml.get("inplace", True)
+        self.end2end = False
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.stride = torch.tensor(self._head_strides(), dtype=torch.float32)
+            self.stride = m.stride
+            m.bias_init()
+        else:
+            self.stride = torch.Tensor([32])
+        # initialize_weights (ultralytics/utils/torch_utils.py:552-562): BN eps/momentum
+        for mod in self.modules():
+            if type(mod) is nn.BatchNorm2d:
+                mod.eps = 1e-3
+                mod.momentum = 0.03
+        self.ymk_dtype = torch.float32
+        self._flags = None
+
+    # the reference finds strides with a 256x256 dry run (tasks.py:547-549); the graph is static, so
+    # walk it symbolically instead (no forward pass needed, works without a GPU)
+    def _head_strides(self):
+        scale_of = []  # cumulative downsampling factor of every layer's output
+        for m in self.model:
+            f = m.f
+            if isinstance(m, Detect):
+                return [scale_of[j] for j in f]
+            if isinstance(f, int):
+                base = (scale_of[-1] if scale_of else 1.0) if f == -1 else scale_of[f]
+            else:
+                base = scale_of[-1] if f[0] == -1 else scale_of[f[0]]
+            if isinstance(m, Conv):
+                base = base * m.conv.stride[0]
+            elif isinstance(m, nn.Upsample):
+                base = base / float(m.scale_factor)
+            scale_of.append(base)
+        raise RuntimeError("no Detect head")
+
+    # -- configuration -------------------------------------------------------------------
+    def set_compute_dtype(self, dtype: torch.dtype):
+        set_compute_dtype(self, dtype)
+        self.ymk_dtype = dtype
+        return self
+
+    def fuse(self, verbose=False):
+        """BN folding happens when weights are packed for libymk (same algebra as
+        fuse_conv_and_bn, torch_utils.py:315-349); kept for API compatibility."""
+        return self
+
+    def is_fused(self, thresh=10):
+        return True
+
+    def repack(self):
+        """Drop packed weights (call after loading / editing parameters)."""
+        for m in self.modules():
+            if isinstance(m, YmkModule):
+                m.clear_pack()
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        r = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self.repack()
+        return r
+
+    # -- forward ---------------------------------------------------------------------------
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):
+            raise RuntimeError("ymk DetectionModel implements inference only (loss/training: use the reference)")
+        return self.predict(x, *args, **kwargs)
+
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        if augment or visualize or embed:
+            raise NotImplementedError("ymk DetectionModel.predict: augment/visualize/embed are not on the hot path")
+        return self._predict_once(x)
+
+    def _predict_once(self, x, taps=None):
+        """Graph walk on NHWC buffers (reference loop: tasks.py:182-218).  x: NCHW fp32 [B,3,H,W] on GPU.
+        Returns (y [B,4+nc,A] fp32, preds dict) like Detect in eval mode.  ``taps``: optional dict that
+        receives every layer's NHWC output (parity tests)."""
+        if self.training:
+            raise RuntimeError("ymk DetectionModel implements eval-mode inference only; call .eval()")
+        if not x.is_cuda:
+            raise RuntimeError("yolo_master_amd runs on MI355X (HIP) only; got a CPU tensor. No CPU fallback exists.")
+        if self._flags is None or self._flags.device != x.device:
+            self._flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
+        ys = []
+        cur = x
+        raw = None
+        for m in self.model:
+            if m.f != -1:
+                cur = ys[m.f] if isinstance(m.f, int) else [cur if j == -1 else ys[j] for j in m.f]
+            if isinstance(m, Conv):
+                if isinstance(cur, LazyUpsample):
+                    cur = cur.materialise()
+                cur = m._run_stem(cur) if m.i == 0 and m.conv.in_channels <= 4 else m._run(cur)
+            elif isinstance(m, nn.Upsample):
+                if m.mode != "nearest" or float(m.scale_factor) != 2.0:
+                    raise NotImplementedError("ymk: nn.Upsample must be nearest x2")
+                cur = LazyUpsample(cur)
+            elif isinstance(m, Concat):
+                cur = m._run(cur)
+            elif isinstance(m, ES_MOE):
+                m.bind_flags(self._flags)
+                cur = m._run(cur)
+            elif isinstance(m, Detect):
+                cur, raw = m._run(cur)
+            elif isinstance(m, nn.Sequential):
+                for mm in m:
+                    cur = mm._run(cur)
+            else:
+                if isinstance(cur, LazyUpsample):
+                    cur = cur.materialise()
+                cur = m._run(cur)
+            ys.append(cur if m.i in self.save else None)
+            if taps is not None:
+                taps[m.i] = cur
+        det = self.model[-1]
+        preds = {"raw": raw, "feats": None}
+        return cur, preds
+
+    def check_flags(self):
+        """One host sync per batch: raise MoERouterError if any routed layer saw NaN/Inf."""
+        for m in self.model:
+            if isinstance(m, ES_MOE):
+                m.check_flags()
+                break

@@ -1,0 +1,238 @@
+"""Tensor-level wrappers over the libymk C-ABI (include/ymk.h).
+
+Activations are NHWC torch tensors ``[B, H, W, C]`` on the GPU whose channel dim is dense
+(stride 1) and whose pixel stride ``stride(2)`` may exceed ``C`` (a channel slice of a wider
+concat buffer).  Every wrapper launches on ``torch.cuda.current_stream()`` and never
+synchronises.  torch is used for memory and streams only — all arithmetic is in libymk.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib
+
+DT = {torch.float32: _lib.YMK_F32, torch.bfloat16: _lib.YMK_BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_gpu(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            "yolo_master_amd ops run on MI355X (HIP) only; got a CPU tensor. There is no CPU fallback."
+        )
+
+
+def _nhwc(t: torch.Tensor):
+    """Validate an NHWC view; return (B, H, W, C, ld)."""
+    _need_gpu(t)
+    B, H, W, Cc = t.shape
+    if t.stride(3) != 1 and Cc > 1:
+        raise ValueError("NHWC view must be channel-dense")
+    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else max(Cc, t.stride(0) // max(H * W, 1)))
+    if W > 1 and H > 1 and t.stride(1) != W * ld:
+        raise ValueError("NHWC view rows must be contiguous in pixels")
+    if B > 1 and t.stride(0) != H * W * ld:
+        raise ValueError("NHWC view images must be contiguous in pixels")
+    return B, H, W, Cc, ld
+
+
+def new_act(B: int, H: int, W: int, Cc: int, dtype: torch.dtype, device) -> torch.Tensor:
+    return torch.empty((B, H, W, Cc), dtype=dtype, device=device)
+
+
+# ----------------------------------------------------------------------------- packing
+def kpad(k: int) -> int:
+    return (k + 63) // 64 * 64
+
+
+def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cout_perm: torch.Tensor | None = None) -> torch.Tensor:
+    """[Cout, Cin, kh, kw] fp32 -> [Cout, Kpad] with K ordered (ky, kx, cin), zero padded."""
+    co, ci, kh, kw = w.shape
+    m = w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    if cout_perm is not None:
+        m = m[cout_perm]
+    out = torch.zeros((co, kpad(kh * kw * ci)), dtype=torch.float32, device=w.device)
+    out[:, : kh * kw * ci] = m
+    return out.to(dtype).contiguous()
+
+
+def pack_dw_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[C, 1, k, k] -> [k*k, C]."""
+    c, _, kh, kw = w.shape
+    return w.reshape(c, kh * kw).t().contiguous().to(dtype)
+
+
+def fold_bn(w: torch.Tensor, bn_w, bn_b, bn_mean, bn_var, eps: float, conv_bias=None):
+    """BN fold exactly as fuse_conv_and_bn (ultralytics/utils/torch_utils.py:315-349)."""
+    co = w.shape[0]
+    w_bn = torch.diag(bn_w.div(torch.sqrt(eps + bn_var)))
+    wf = torch.mm(w_bn, w.reshape(co, -1)).view(w.shape)
+    b_conv = torch.zeros(co, device=w.device, dtype=w.dtype) if conv_bias is None else conv_bias
+    b_bn = bn_b - bn_w.mul(bn_mean).div(torch.sqrt(bn_var + eps))
+    bf = torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn
+    return wf, bf
+
+
+# ----------------------------------------------------------------------------- conv
+def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual=None, out_dtype=None):
+    B, H, W, Cin, ldx = _nhwc(x)
+    Cout, Kp = w_packed.shape
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    odt = out_dtype or x.dtype
+    if out is None:
+        out = new_act(B, Ho, Wo, Cout, odt, x.device)
+    Bo, Ho2, Wo2, Co2, ldy = _nhwc(out)
+    assert (Bo, Ho2, Wo2, Co2) == (B, Ho, Wo, Cout), f"conv out shape {tuple(out.shape)} != {(B, Ho, Wo, Cout)}"
+    ldr = 0
+    if residual is not None:
+        rb = _nhwc(residual)
+        assert rb[:4] == (B, Ho, Wo, Cout)
+        ldr = rb[4]
+    d = ConvDesc(DT[x.dtype], DT[out.dtype], B, H, W, Cin, Cout, k, stride, ldx, ldy, ldr, Kp,
+                 _lib.ACT_SILU if act else _lib.ACT_NONE)
+    check(lib.ymk_conv2d(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), _stream()), "conv2d")
+    return out
+
+
+def conv2d_stem(x_nchw, w, bias, k: int, stride: int, act: bool, dtype: torch.dtype, out=None):
+    _need_gpu(x_nchw)
+    x_nchw = x_nchw.contiguous().float()
+    B, Cin, H, W = x_nchw.shape
+    Cout = w.shape[0]
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = new_act(B, Ho, Wo, Cout, dtype, x_nchw.device)
+    ldy = _nhwc(out)[4]
+    check(lib.ymk_conv2d_stem_nchw(_p(x_nchw), _p(w), _p(bias), _p(out), DT[out.dtype], B, Cin, H, W, Cout, k, stride,
+                                   ldy, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "conv2d_stem_nchw")
+    return out
+
+
+def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
+    B, H, W, Cc, ldx = _nhwc(x)
+    if out is None:
+        out = new_act(B, H, W, Cc, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    ldr = _nhwc(residual)[4] if residual is not None else 0
+    check(lib.ymk_dwconv2d(DT[x.dtype], _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy,
+                           ldr, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d")
+    return out
+
+
+# ----------------------------------------------------------------------------- ES-MoE
+def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
+    B, H, W, Cc, ldx = _nhwc(x)
+    hidden, E = w1.shape[0], w2.shape[0]
+    dev = x.device
+    route_w = torch.empty((B, E), dtype=torch.float32, device=dev)
+    gate_w = torch.empty((B, E), dtype=torch.float32, device=dev)
+    sel = torch.empty((B, top_k), dtype=torch.int32, device=dev)
+    csr_off = torch.empty((E + 1,), dtype=torch.int32, device=dev)
+    csr_pair = torch.empty((B * top_k,), dtype=torch.int32, device=dev)
+    nbytes = lib.ymk_esmoe_route_workspace_bytes(B, Cc, H, W)
+    ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
+    check(lib.ymk_esmoe_route(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(w1), _p(b1), _p(w2), _p(b2), hidden, E, top_k,
+                              float(thr), _p(route_w), _p(gate_w), _p(sel), _p(csr_off), _p(csr_pair), _p(flags),
+                              _p(ws), nbytes, _stream()), "esmoe_route")
+    return route_w, gate_w, sel, csr_off, csr_pair
+
+
+def esmoe_dw(x, dw_w, dw_off, ksizes, top_k: int, sel, csr_off, csr_pair):
+    B, H, W, Cc, ldx = _nhwc(x)
+    E = ksizes.numel()
+    out = torch.empty((B * top_k, H, W, Cc), dtype=x.dtype, device=x.device)
+    check(lib.ymk_esmoe_dw(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), E, top_k, _p(sel),
+                           _p(csr_off), _p(csr_pair), _p(out), _stream()), "esmoe_dw")
+    return out
+
+
+def esmoe_pw(dw_out, B: int, H: int, W: int, pw_w, pw_b, nscale, nshift, top_k: int, sel, gate_w, out=None):
+    Cc = dw_out.shape[-1]
+    E, Cout, Kp = pw_w.shape
+    if out is None:
+        out = new_act(B, H, W, Cout, dw_out.dtype, dw_out.device)
+    ldy = _nhwc(out)[4]
+    check(lib.ymk_esmoe_pw(DT[dw_out.dtype], _p(dw_out), B, H, W, Cc, Cout, Kp, _p(pw_w), _p(pw_b), _p(nscale),
+                           _p(nshift), E, top_k, _p(sel), _p(gate_w), _p(out), ldy, _stream()), "esmoe_pw")
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+def area_attn(qkv, heads: int, area: int, out=None):
+    B, H, W, C3, ldq = _nhwc(qkv)
+    Cq = heads * 32
+    assert C3 == 3 * Cq
+    if out is None:
+        out = new_act(B, H, W, Cq, qkv.dtype, qkv.device)
+    ldo = _nhwc(out)[4]
+    check(lib.ymk_area_attn(DT[qkv.dtype], _p(qkv), ldq, _p(out), ldo, B, H * W, heads, area, _stream()), "area_attn")
+    return out
+
+
+# ----------------------------------------------------------------------------- layout
+def upsample2x(x, out=None):
+    B, H, W, Cc, ldx = _nhwc(x)
+    if out is None:
+        out = new_act(B, 2 * H, 2 * W, Cc, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    check(lib.ymk_upsample2x(DT[x.dtype], _p(x), _p(out), B, H, W, Cc, ldx, ldy, _stream()), "upsample2x")
+    return out
+
+
+def copy_channels(x, out):
+    B, H, W, Cc, ldx = _nhwc(x)
+    ldy = _nhwc(out)[4]
+    check(lib.ymk_copy_channels(DT[x.dtype], _p(x), _p(out), B * H * W, Cc, ldx, ldy, _stream()), "copy_channels")
+    return out
+
+
+def nhwc_to_nchw_f32(x):
+    B, H, W, Cc, ldx = _nhwc(x)
+    y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    check(lib.ymk_nhwc_to_nchw_f32(DT[x.dtype], _p(x), _p(y), B, H * W, Cc, ldx, _stream()), "nhwc_to_nchw_f32")
+    return y
+
+
+# ----------------------------------------------------------------------------- detect / nms
+def detect_decode(box_l, cls_l, y, stride: float, a_off: int, reg_max: int):
+    B, Hl, Wl, _, _ = _nhwc(box_l)
+    nc = cls_l.shape[-1]
+    assert box_l.is_contiguous() and cls_l.is_contiguous() and box_l.dtype == torch.float32
+    check(lib.ymk_detect_decode(_p(box_l), _p(cls_l), _p(y), B, Hl, Wl, reg_max, nc, float(stride), a_off, y.shape[2],
+                                _stream()), "detect_decode")
+    return y
+
+
+def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, max_det: int, max_nms: int,
+                max_wh: float, cw_sigma: float | None = None, cw_pool: int = 3000):
+    """Returns (dets [B,max_det,6], counts [B] int32, idx [B,max_det] int32, status [1] int32)."""
+    _need_gpu(y)
+    assert y.dtype == torch.float32 and y.is_contiguous()
+    B, ch, A = y.shape
+    nc = ch - 4
+    dev = y.device
+    nbytes = lib.ymk_nms_workspace_bytes(B, nc, A, int(multi_label), max_nms)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=dev)
+    counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+    idx = torch.zeros((B, max_det), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    check(lib.ymk_nms_batched(_p(y), B, nc, A, float(conf), float(iou), int(multi_label), int(agnostic), max_det, max_nms,
+                              float(max_wh), _p(dets), _p(counts), _p(idx), _p(status), _p(ws), nbytes, _stream()),
+          "nms_batched")
+    if cw_sigma is not None:
+        check(lib.ymk_cw_refine(B, nc, A, int(multi_label), max_nms, max_det, float(iou), float(cw_sigma), cw_pool,
+                                _p(dets), _p(counts), _p(ws), nbytes, _stream()), "cw_refine")
+    return dets, counts, idx, status

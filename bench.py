@@ -1,0 +1,193 @@
+"""Headline benchmark: images/sec @ 640x640, bs=64 per GPU, YOLO-Master-S, forward + batched NMS on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic images already resident in HBM: the 26-layer
+forward (libymk HIP kernels) + batched NMS (conf 0.25, IoU 0.7, max_det 300), plus — for N>1 — the RCCL
+all_gather of the padded detections.  Images are sharded over ranks (weak scaling: 64 images per GPU, i.e.
+BASELINE.json config 3 at N=1 and config 4 at N=8); there is no data-path collective inside the forward.
+Rank 0 prints ONE JSON line (schema: see the task contract) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+
+
+def cpu_baseline(scale: str, seconds_budget: float = 25.0):
+    """Oracle (CPU fp32 restatement of the reference path, kind="port") timed on this host's cores on a
+    bounded sample of the same workload: forward + NMS on a few 640x640 images."""
+    from oracle import model_ref, nms_ref
+    from yolo_master_amd.nn.tasks import DetectionModel, yaml_model_load
+    from yolo_master_amd.weights import synth_input, synth_state_dict
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = yaml_model_load(f"yolo-master-{scale}.yaml")
+    sd = synth_state_dict(DetectionModel(cfg).state_dict(), seed=0)
+    B = 4
+    x = synth_input(B, 640, 640, seed=1)
+    times = []
+    with torch.inference_mode():
+        t_all = time.time()
+        for it in range(6):
+            t0 = time.time()
+            y, _, _ = model_ref.forward(cfg, sd, x)
+            nms_ref.non_max_suppression(y.numpy(), 0.25, 0.7)
+            dt = time.time() - t0
+            if it:  # first pass = warm-up
+                times.append(dt)
+            if time.time() - t_all > seconds_budget and len(times) >= 2:
+                break
+    times.sort()
+    p50 = times[len(times) // 2]
+    return {"value": round(B / p50, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle forward+NMS, YOLO-Master-{scale.upper()} fp32, {B}x3x640x640, {len(times)} timed passes (p50)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scale", default="s")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--roofline-kernel", default=None, help="conv kernel tag to time (default: dominant one)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
+    a = ap.parse_args()
+
+    from yolo_master_amd import ops
+    from yolo_master_amd.dist import broadcast_state_dict, gather_detections, init_from_env
+    from yolo_master_amd.nms import nms_padded
+    from yolo_master_amd.nn.tasks import DetectionModel
+    from yolo_master_amd.weights import synth_input, synth_state_dict
+
+    rank, local, world = init_from_env()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+
+    model = DetectionModel(f"yolo-master-{a.scale}.yaml")
+    if rank == 0:
+        model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
+    model.eval().to(dev)
+    broadcast_state_dict(model, src=0)       # weight replication over xGMI (RCCL broadcast)
+    model.set_compute_dtype(dtype)
+    x = synth_input(a.batch, a.imgsz, a.imgsz, seed=1 + rank).to(dev)   # resident in HBM before timing
+
+    def step():
+        y, _ = model._predict_once(x)
+        dets, counts, idx, status = nms_padded(y, 0.25, 0.7, max_det=300)
+        if world > 1:
+            dets, counts, idx = gather_detections(dets, counts, idx)
+        return dets, counts
+
+    with torch.inference_mode():
+        for _ in range(max(a.warmup, 1)):
+            out = step()
+        torch.cuda.synchronize()
+        model.check_flags()
+        graph = None
+        if not a.no_graph and world == 1:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = step()
+                graph.replay()
+                torch.cuda.synchronize()
+            except Exception as e:  # pragma: no cover
+                if rank == 0:
+                    print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+        run = graph.replay if graph is not None else step
+
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(a.steps):
+            run()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+        p50_ms = per_step[len(per_step) // 2]
+
+        # roofline leg: per-launch HIP events around the dominant kernel family, eager launches on this stream
+        roof = None
+        if rank == 0:
+            tag = a.roofline_kernel or ops.conv_kernel_tag(dtype, 128, 3)
+            ops.TIMER.start(tag)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            recs = ops.TIMER.records
+            ops.TIMER.stop()
+            if recs:
+                ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+                nbytes = sum(r[2] for r in recs)
+                flops = sum(r[3] for r in recs)
+                gbs = nbytes / (ms * 1e-3) / 1e9
+                tfl = flops / (ms * 1e-3) / 1e12
+                intensity = flops / nbytes
+                ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+                if intensity < ridge:
+                    roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+                else:
+                    roof = {"bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_PEAK_TFLOPS[a.dtype],
+                            "unit": "TFLOP/s", "frac": round(tfl / MFMA_PEAK_TFLOPS[a.dtype], 4), "traffic": None}
+                roof.update(kernel=tag, launches_per_step=len(recs) // 3, avg_launch_us=round(ms * 1e3 / len(recs), 2),
+                            alg_bytes_per_launch=int(nbytes / len(recs)), alg_gflop_per_launch=round(flops / len(recs) / 1e9, 3),
+                            achieved_gbs=round(gbs, 1), achieved_tflops=round(tfl, 2))
+
+    if rank == 0:
+        total_images = world * a.batch * a.steps
+        res = {
+            "metric": "images/sec @ 640x640 bs=64, YOLO-Master-S; per-image p50 latency",
+            "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "p50_ms_per_image": round(p50_ms / a.batch, 5),
+            "config": {"workload": f"YOLO-Master-{a.scale.upper()} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, "
+                                   f"bs={a.batch}/GPU, ES-MoE top-k=2 (BASELINE.json configs[2]{'/[3]' if world > 1 else ''})",
+                       "global_batch": world * a.batch, "imgsz": a.imgsz, "parallelism": f"dp{world} (image shards, no data-path collective)",
+                       "launch": "hipGraph" if graph is not None else "eager", "weights": "seeded random + BN calibration (no checkpoints offline)"},
+            "roofline": roof,
+            "cpu_baseline": None,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.scale)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,13 @@ def model_case(name, scale, B, H, W, seed, conf=0.25, iou=0.7, full_y=False):
     otaps, info = {}, {}
     with torch.inference_mode():
         oy, oboxes, oscores = model_ref.forward(cfg, sd, x, taps=otaps, moe_info=info)
+    # fp64 evaluation of the same graph (validated oracle, unfused = the mathematically exact composition):
+    # |reference_fp32 - fp64| is the reference's own round-off noise floor, stored per layer so that parity
+    # tests can bound the HIP path by "as close to the exact result as the reference itself is".
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    taps64 = {}
+    with torch.inference_mode():
+        y64, _, _ = model_ref.forward(cfg, sd64, x.double(), fused=False, taps=taps64)
     exact = all(torch.equal(taps[i], otaps[i]) for i in range(len(ref.model) - 1)) and torch.equal(y, oy)
     print(f"[{name}] oracle forward bit-exact vs reference: {exact}; max|dy| = {(y - oy).abs().max().item():.3e}")
     for i, rw in routes.items():
@@ -98,10 +105,16 @@ def model_case(name, scale, B, H, W, seed, conf=0.25, iou=0.7, full_y=False):
         rec[f"layer{i}_idx"] = idx.numpy().astype(np.int32)
         rec[f"layer{i}_val"] = taps[i].reshape(-1)[idx].numpy()
         rec[f"layer{i}_shape"] = np.array(taps[i].shape)
+        rec[f"layer{i}_val64"] = taps64[i].reshape(-1)[idx].numpy()
+        rec[f"layer{i}_noise"] = np.float64((taps[i].double() - taps64[i]).abs().max().item())
     if full_y:
         rec["y"] = y.numpy()
     idx = sample_idx(y.numel(), NSAMP_Y, 7)
     rec["y_idx"], rec["y_val"], rec["y_shape"] = idx.numpy().astype(np.int32), y.reshape(-1)[idx].numpy(), np.array(y.shape)
+    rec["y_val64"] = y64.reshape(-1)[idx].numpy()
+    rec["y_noise_box"] = np.float64((y[:, :4].double() - y64[:, :4]).abs().max().item())
+    rec["y_noise_cls"] = np.float64((y[:, 4:].double() - y64[:, 4:]).abs().max().item())
+    print(f"[{name}] reference fp32 noise floor vs fp64: boxes {rec['y_noise_box']:.3e} px, scores {rec['y_noise_cls']:.3e}")
     for i, rw in routes.items():
         rec[f"route{i}_route_w"] = rw.numpy()
         rec[f"route{i}_gate_w"] = info[f"model.{i}"]["gate_w"].numpy()

@@ -1,0 +1,64 @@
+"""Shared helpers for the parity tests (HIP path vs oracle / golden)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from yolo_master_amd.weights import synth_state_dict
+
+# tolerances (stated once, used by every parity test)
+#   fp32: the HIP path accumulates in fp32 with a different summation order than oneDNN; per-op relative
+#         error ~1e-6, end-to-end (26 layers, random calibrated weights) we require |d| <= 1e-4 + 1e-4*|ref|
+#         on boxes/scores (north_star: 1e-4 fp32).
+#   bf16: activations and weights rounded to bf16 (8 mantissa bits) at every layer; per-op bound 2e-2 rel.
+TOL = {torch.float32: dict(rtol=1e-4, atol=1e-4), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+
+
+def nhwc(x_nchw: torch.Tensor, dtype, dev, pad_c: int = 0, c_off: int = 0) -> torch.Tensor:
+    """NCHW CPU tensor -> NHWC device view; with pad_c>0 the view is a channel slice of a wider buffer."""
+    B, C, H, W = x_nchw.shape
+    buf = torch.full((B, H, W, C + pad_c), 7.0, dtype=dtype, device=dev)
+    v = buf[..., c_off:c_off + C]
+    v.copy_(x_nchw.permute(0, 2, 3, 1).to(dtype))
+    return v
+
+
+def nchw(y_nhwc: torch.Tensor) -> torch.Tensor:
+    return y_nhwc.float().permute(0, 3, 1, 2).cpu()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).float()
+
+
+def assert_close(got: torch.Tensor, ref: torch.Tensor, dtype, what: str, scale_aware=True):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} != {tuple(ref.shape)}"
+    tol = TOL[dtype]
+    mag = ref.abs().max().item() if scale_aware else 1.0
+    err = (got - ref).abs()
+    bound = tol["atol"] * max(mag, 1.0) + tol["rtol"] * ref.abs()
+    bad = err > bound
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err "
+                           f"{err.max().item():.3e} (ref max {mag:.3e}), first bad idx {bad.nonzero()[0].tolist()}")
+    return err.max().item()
+
+
+def module_sd(module, prefix="model.0", seed=0):
+    """Seeded random parameters for a module, returned both loaded into it and as a prefixed oracle dict."""
+    sd = synth_state_dict(module.state_dict(), seed=seed, calib=None)
+    module.load_state_dict(sd)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3
+    return {f"{prefix}.{k}": v for k, v in sd.items()}
+
+
+def load_npz(path):
+    z = np.load(path)
+    return {k: z[k] for k in z.files}

@@ -1,0 +1,44 @@
+"""C-ABI boundary: libymk.so loads and exports every symbol include/ymk.h declares (no compute calls)."""
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def header_functions():
+    txt = (ROOT / "include" / "ymk.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ymk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_expected_surface():
+    fns = header_functions()
+    for must in ("ymk_conv2d", "ymk_dwconv2d", "ymk_esmoe_route", "ymk_esmoe_dw", "ymk_esmoe_pw", "ymk_area_attn",
+                 "ymk_detect_decode", "ymk_nms_batched", "ymk_cw_refine"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol():
+    from yolo_master_amd import _lib
+
+    if not _lib.LIB_PATH.exists():
+        pytest.fail(f"{_lib.LIB_PATH} missing: run `python -m yolo_master_amd.build` (build() in __graft_entry__)")
+    h = _lib.load()
+    fns = header_functions()
+    assert sorted(_lib.SYMBOLS) == fns, "ctypes table and include/ymk.h disagree"
+    for f in fns:
+        assert hasattr(h, f), f"libymk.so does not export {f}"
+    assert h.ymk_abi_version() == 1
+    assert b"gfx950" in h.ymk_build_info()
+    # pure host-side queries work without a GPU
+    assert h.ymk_nms_workspace_bytes(2, 80, 8400, 0, 30000) > 0
+    assert h.ymk_esmoe_route_workspace_bytes(2, 128, 40, 40) == 2 * 7 * 128 * 4
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from yolo_master_amd import _lib
+
+    with pytest.raises(_lib.YmkLibraryError):
+        _lib.load(tmp_path / "libymk_missing.so")

@@ -1,0 +1,66 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise sharding, weight broadcast and result gather."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from yolo_master_amd.dist import shard_range
+
+
+def test_shard_range_partition():
+    for n in (0, 1, 7, 64, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from yolo_master_amd.dist import broadcast_state_dict, gather_detections, init_from_env
+    from yolo_master_amd.nn.modules import C3k2
+
+    r, _, w = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)            # different weights per rank before the broadcast
+    m = C3k2(16, 32, 1, False, 0.25)
+    for p in m.parameters():
+        torch.nn.init.normal_(p)
+    broadcast_state_dict(m, src=0)
+    flat = torch.cat([t.reshape(-1).float() for t in m.state_dict().values()])
+    ref = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(ref, flat)
+    same = all(torch.equal(ref[0], t) for t in ref)
+    # result gather: rank r owns images [b0, b1) of a batch of 6, padded detections
+    b0, b1 = shard_range(6, rank, world)
+    dets = torch.zeros((b1 - b0, 4, 6))
+    counts = torch.zeros((b1 - b0,), dtype=torch.int32)
+    for i, b in enumerate(range(b0, b1)):
+        counts[i] = b % 4
+        dets[i, : b % 4, 4] = float(b)
+    gd, gc, _ = gather_detections(dets, counts)
+    ok = gc.tolist() == [b % 4 for b in range(6)] and all(float(gd[b, 0, 4]) == (b if b % 4 else 0.0) for b in range(6))
+    q.put((rank, same, ok))
+    dist.destroy_process_group()
+
+
+def test_two_process_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(same and ok for _, same, ok in res), res

@@ -1,0 +1,362 @@
+"""GPU parity of every libymk kernel (called through the C-ABI) against plain PyTorch fp32 CPU
+references of the same op / the oracle restatement.  fp32 and bf16 compute types."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import assert_close, bf16_round, module_sd, nchw, nhwc, rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _prep(t, dtype):
+    return bf16_round(t) if dtype == torch.bfloat16 else t
+
+
+# ------------------------------------------------------------------------------- conv (MFMA igemm)
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, act, residual, pad_in, pad_out
+    (2, 20, 20, 64, 128, 1, 1, True, False, 0, 0),
+    (2, 20, 20, 64, 256, 3, 1, True, True, 0, 0),
+    (1, 33, 29, 16, 8, 3, 1, True, False, 0, 0),      # odd sizes, tiny Cout (N-scale bottleneck)
+    (2, 40, 40, 32, 64, 3, 2, True, False, 16, 32),   # stride 2, channel-slice views in and out
+    (3, 17, 23, 8, 16, 3, 2, False, False, 8, 0),     # Cin = 8 (tap crosses a 16-byte chunk boundary)
+    (2, 16, 16, 192, 80, 1, 1, False, False, 0, 0),   # Cout = 80 (Detect cls tail), K not multiple of 64
+    (1, 12, 12, 512, 512, 3, 1, True, True, 0, 0),    # K = 4608
+    (2, 9, 9, 48, 32, 1, 1, True, True, 16, 16),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case, dtype):
+    from yolo_master_amd import ops
+
+    B, H, W, Cin, Cout, k, s, act, res, pin, pout = case
+    x = _prep(rnd(B, Cin, H, W, seed=1), dtype)
+    w = _prep(rnd(Cout, Cin, k, k, seed=2, scale=(1.0 / (Cin * k * k)) ** 0.5), dtype)
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d(x, w, b, s, k // 2)
+    if act:
+        ref = F.silu(ref)
+    Ho, Wo = ref.shape[2:]
+    r = _prep(rnd(B, Cout, Ho, Wo, seed=4), dtype) if res else None
+    if res:
+        ref = r + ref
+    xd = nhwc(x, dtype, DEV, pin, pin // 2)
+    out_buf = torch.zeros((B, Ho, Wo, Cout + pout), dtype=dtype, device=DEV)
+    out = out_buf[..., pout // 2: pout // 2 + Cout]
+    wp = ops.pack_conv_weight(w.to(DEV), dtype)
+    y = ops.conv2d(xd, wp, b.to(DEV), k, s, act, out=out, residual=nhwc(r, dtype, DEV) if res else None)
+    torch.cuda.synchronize()
+    assert_close(nchw(y), ref, dtype, f"conv2d {case}")
+    if pout:  # the neighbouring channels of the wider buffer must be untouched
+        assert float(out_buf[..., : pout // 2].abs().max()) == 0.0
+        assert float(out_buf[..., pout // 2 + Cout:].abs().max()) == 0.0
+
+
+def test_conv2d_f32_out_from_bf16():
+    from yolo_master_amd import ops
+
+    x = bf16_round(rnd(2, 64, 10, 10, seed=1))
+    w = bf16_round(rnd(64, 64, 1, 1, seed=2, scale=0.125))
+    b = rnd(64, seed=3)
+    y = ops.conv2d(nhwc(x, torch.bfloat16, DEV), ops.pack_conv_weight(w.to(DEV), torch.bfloat16), b.to(DEV), 1, 1, False,
+                   out_dtype=torch.float32)
+    assert y.dtype == torch.float32
+    assert_close(nchw(y), F.conv2d(x, w, b), torch.float32, "bf16 conv with fp32 output")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mfma_layout_asymmetric(dtype):
+    """A = I against an asymmetric B: catches row/column swaps of the MFMA result layout."""
+    from yolo_master_amd import ops
+
+    C = 64
+    x = torch.arange(2 * C * 5 * 7, dtype=torch.float32).reshape(2, C, 5, 7) % 13 - 6.0
+    w = torch.zeros(C, C, 1, 1)
+    for o in range(C):
+        w[o, (o * 7 + 3) % C, 0, 0] = 1.0 + (o % 3)  # permutation * asymmetric scale
+    ref = F.conv2d(x, w)
+    y = ops.conv2d(nhwc(x, dtype, DEV), ops.pack_conv_weight(w.to(DEV), dtype), torch.zeros(C, device=DEV), 1, 1, False)
+    assert torch.equal(nchw(y), ref), "MFMA fragment/result layout is wrong (exact integer test)"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem(dtype):
+    from yolo_master_amd import ops
+
+    x = torch.rand(2, 3, 64, 48, generator=torch.Generator().manual_seed(5))
+    w = rnd(16, 3, 3, 3, seed=6, scale=0.3)
+    b = rnd(16, seed=7, scale=0.1)
+    ref = F.silu(F.conv2d(x, w, b, 2, 1))
+    wp = w.permute(0, 2, 3, 1).reshape(16, -1).contiguous().to(DEV)
+    y = ops.conv2d_stem(x.to(DEV), wp, b.to(DEV), 3, 2, True, dtype)
+    assert_close(nchw(y), ref, dtype, "stem conv")
+
+
+# ------------------------------------------------------------------------------- depthwise
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 15])
+def test_dwconv(k, dtype):
+    from yolo_master_amd import ops
+
+    B, C, H, W = 2, 24, 19, 21
+    x = _prep(rnd(B, C, H, W, seed=1), dtype)
+    w = _prep(rnd(C, 1, k, k, seed=2, scale=1.0 / k), dtype)
+    b = rnd(C, seed=3, scale=0.1)
+    r = _prep(rnd(B, C, H, W, seed=4), dtype)
+    ref = r + F.silu(F.conv2d(x, w, b, 1, k // 2, 1, C))
+    y = ops.dwconv2d(nhwc(x, dtype, DEV, 8, 4), ops.pack_dw_weight(w.to(DEV), dtype), b.to(DEV), k, True,
+                     residual=nhwc(r, dtype, DEV))
+    assert_close(nchw(y), ref, dtype, f"dwconv k={k}")
+
+
+# ------------------------------------------------------------------------------- layout kernels
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_kernels(dtype):
+    from yolo_master_amd import ops
+
+    x = _prep(rnd(2, 16, 5, 6, seed=1), dtype)
+    xd = nhwc(x, dtype, DEV, 8, 8)
+    up = ops.upsample2x(xd)
+    assert torch.equal(nchw(up), F.interpolate(x, scale_factor=2.0, mode="nearest"))
+    buf = torch.zeros((2, 5, 6, 40), dtype=dtype, device=DEV)
+    ops.copy_channels(xd, buf[..., 8:24])
+    assert torch.equal(nchw(buf[..., 8:24]), x) and float(buf[..., :8].abs().max()) == 0.0
+    assert torch.equal(ops.nhwc_to_nchw_f32(xd).cpu(), x)
+
+
+# ------------------------------------------------------------------------------- module blocks vs oracle
+def _run_module(mod, x, dtype):
+    from yolo_master_amd.nn.modules import set_compute_dtype
+
+    mod.eval().to(DEV)
+    set_compute_dtype(mod, dtype)
+    with torch.inference_mode():
+        return mod(x.to(DEV)).float().cpu()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c3k", [False, True])
+def test_c3k2_block(c3k, dtype):
+    from oracle import model_ref
+    from yolo_master_amd.nn.modules import C3k2
+
+    m = C3k2(64, 128, 2, c3k, 0.5 if c3k else 0.25)
+    sd = module_sd(m)
+    x = rnd(2, 64, 20, 24, seed=9)
+    with torch.inference_mode():
+        ref = model_ref.c3k2(sd, "model.0", _prep(x, dtype))
+    assert_close(_run_module(m, x, dtype), ref, dtype, f"C3k2 c3k={c3k}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("area,hw", [(4, (20, 20)), (1, (10, 12)), (4, (4, 4))])
+def test_a2c2f_block(area, hw, dtype):
+    from oracle import model_ref
+    from yolo_master_amd.nn.modules import A2C2f
+
+    m = A2C2f(128, 128, 2, True, area)
+    sd = module_sd(m)
+    x = rnd(2, 128, *hw, seed=10)
+    with torch.inference_mode():
+        ref = model_ref.a2c2f(sd, "model.0", _prep(x, dtype), area)
+    assert_close(_run_module(m, x, dtype), ref, dtype, f"A2C2f area={area} hw={hw}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_area_attention_long(dtype):
+    """More than one 256-key chunk (online softmax across chunks): 24x24 = 576 tokens, area 1."""
+    from oracle import model_ref
+    from yolo_master_amd.nn.modules import ABlock
+
+    m = ABlock(64, 2, 2.0, 1)
+    sd = module_sd(m)
+    x = rnd(1, 64, 24, 24, seed=11)
+    with torch.inference_mode():
+        ref = model_ref.ablock(sd, "model.0", _prep(x, dtype), 1)
+    assert_close(_run_module(m, x, dtype), ref, dtype, "ABlock 576 tokens")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_esmoe_block(dtype):
+    from oracle import model_ref
+    from yolo_master_amd.nn.modules import ES_MOE
+
+    m = ES_MOE(64, 64)
+    sd = module_sd(m)
+    # per-image offsets so that images route differently
+    x = rnd(6, 64, 14, 18, seed=12) + rnd(6, 64, 1, 1, seed=13, scale=1.5)
+    info = {}
+    with torch.inference_mode():
+        ref = model_ref.es_moe(sd, "model.0", _prep(x, dtype), info=info)
+    y = _run_module(m, x, dtype)
+    r = info["model.0"]
+    got = m.last_route
+    retained = (got["gate_w"] > 0).cpu()
+    if dtype == torch.float32:
+        assert torch.equal(retained, r["retained"]), "retained expert set differs from the oracle"
+        assert_close(got["route_w"], r["route_w"], dtype, "routing weights")
+        assert_close(got["gate_w"], r["gate_w"], dtype, "gate weights")
+    if torch.equal(retained, r["retained"]):
+        assert_close(y, ref, dtype, "ES_MOE output")
+    # CSR permutation invariants
+    off, pair, sel = got["csr_off"].cpu().tolist(), got["csr_pair"].cpu().tolist(), got["sel"].cpu()
+    E, top_k = 4, 2
+    assert off[0] == 0 and off[E] == int((sel >= 0).sum())
+    for e in range(E):
+        seg = pair[off[e]:off[e + 1]]
+        assert seg == sorted(seg) and all(int(sel.view(-1)[p]) == e for p in seg)
+
+
+def test_esmoe_nonfinite_raises():
+    from yolo_master_amd import MoERouterError
+    from yolo_master_amd.nn.modules import ES_MOE
+
+    m = ES_MOE(32, 32)
+    module_sd(m)
+    m.eval().to(DEV)
+    x = torch.randn(2, 32, 8, 8)
+    x[1, 3, 2, 2] = float("nan")
+    with pytest.raises(MoERouterError):
+        m(x.to(DEV))
+    with pytest.raises(MoERouterError):
+        m(torch.randn(2, 32, 8).to(DEV))
+    from yolo_master_amd import ShapeMismatchError
+
+    with pytest.raises(ShapeMismatchError):
+        m(torch.randn(2, 16, 8, 8).to(DEV))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_detect_head(dtype):
+    from oracle import model_ref
+    from yolo_master_amd.nn.modules import Detect
+
+    Detect.legacy = False
+    m = Detect(80, 16, False, [64, 128, 128])
+    m.stride = torch.tensor([8.0, 16.0, 32.0])
+    sd = module_sd(m)
+    feats = [rnd(2, 64, 16, 20, seed=1), rnd(2, 128, 8, 10, seed=2), rnd(2, 128, 4, 5, seed=3)]
+    with torch.inference_mode():
+        ref_y, ref_boxes, ref_scores = model_ref.detect(sd, "model.0", [_prep(f, dtype) for f in feats], [8, 16, 32])
+    from yolo_master_amd.nn.modules import set_compute_dtype
+
+    m.eval().to(DEV)
+    set_compute_dtype(m, dtype)
+    with torch.inference_mode():
+        y, preds = m([f.to(DEV) for f in feats])
+    assert_close(preds["boxes"], ref_boxes, dtype, "Detect raw boxes")
+    assert_close(preds["scores"], ref_scores, dtype, "Detect raw scores")
+    assert_close(y[:, 4:], ref_y[:, 4:], dtype, "Detect scores")
+    assert_close(y[:, :4], ref_y[:, :4], dtype, "Detect decoded boxes")
+
+
+def test_detect_decode_exact():
+    """Decode kernel alone on fp32 logits: same op order as the reference -> tight tolerance."""
+    from oracle import model_ref
+    from yolo_master_amd import ops
+
+    B, Hl, Wl, nc = 2, 7, 9, 80
+    box = rnd(B, Hl, Wl, 64, seed=1, scale=2.0)
+    cls = rnd(B, Hl, Wl, nc, seed=2, scale=3.0)
+    y = torch.zeros((B, 84, Hl * Wl + 5), device=DEV)
+    ops.detect_decode(box.to(DEV), cls.to(DEV), y, 16.0, 5, 16)
+    bx = box.reshape(B, -1, 64).permute(0, 2, 1)
+    dist = F.conv2d(bx.reshape(B, 4, 16, -1).transpose(2, 1).softmax(1), torch.arange(16.0).view(1, 16, 1, 1)).view(B, 4, -1)
+    sx = torch.arange(Wl) + 0.5
+    sy = torch.arange(Hl) + 0.5
+    gy, gx = torch.meshgrid(sy, sx, indexing="ij")
+    anc = torch.stack((gx, gy), -1).view(-1, 2).t().unsqueeze(0)
+    lt, rb = dist.chunk(2, 1)
+    ref_box = torch.cat([((anc - lt) + (anc + rb)) / 2, (anc + rb) - (anc - lt)], 1) * 16.0
+    got = y[:, :, 5:].cpu()
+    assert (got[:, :4] - ref_box).abs().max().item() <= 2e-4
+    assert (got[:, 4:] - cls.reshape(B, -1, nc).permute(0, 2, 1).sigmoid()).abs().max().item() <= 1e-6
+    assert float(y[:, :, :5].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------- NMS
+def _nms_compare(y, **kw):
+    from oracle import nms_ref
+    from yolo_master_amd.nms import non_max_suppression
+
+    ref, ref_idx = nms_ref.non_max_suppression(y.numpy(), return_idxs=True, **kw)
+    got, got_idx = non_max_suppression(y.to(DEV), return_idxs=True, **kw)
+    for b in range(y.shape[0]):
+        assert np.array_equal(got_idx[b].cpu().numpy(), ref_idx[b]), f"image {b}: kept anchor indices differ"
+        assert np.array_equal(got[b].cpu().numpy(), ref[b]), f"image {b}: detections differ (bit-exact expected)"
+    return got
+
+
+@pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one"])
+def test_nms_golden(case, golden_dir):
+    """HIP NMS == the real reference's non_max_suppression output (fixtures) bit for bit."""
+    from tests.helpers import load_npz
+    from yolo_master_amd.nms import non_max_suppression
+
+    z = load_npz(golden_dir / f"nms_{case}.npz")
+    kw = dict(conf_thres=float(z["arg_conf_thres"]), iou_thres=float(z["arg_iou_thres"]),
+              multi_label=bool(z["arg_multi_label"]), agnostic=bool(z["arg_agnostic"]), max_det=int(z["arg_max_det"]),
+              max_nms=int(z["arg_max_nms"]))
+    y = torch.from_numpy(z["y"])
+    got, idx = non_max_suppression(y.to(DEV), return_idxs=True, **kw)
+    for b in range(y.shape[0]):
+        assert np.array_equal(idx[b].cpu().numpy(), z[f"idx{b}"]), f"{case} image {b}: kept indices differ"
+        assert np.array_equal(got[b].cpu().numpy(), z[f"dets{b}"]), f"{case} image {b}: detections differ"
+
+
+def test_nms_random_and_ties():
+    g = torch.Generator().manual_seed(21)
+    B, nc, A = 4, 80, 8400
+    xy = torch.rand(B, 2, A, generator=g) * 600 + 20
+    wh = torch.rand(B, 2, A, generator=g) * 200 + 4
+    cls = torch.sigmoid(torch.randn(B, nc, A, generator=g) * 1.5 - 4.5)
+    cls[1] = (cls[1] * 64).round() / 64            # heavy score ties: stable order must match the oracle
+    cls[2] *= 0.0                                   # empty image in the middle of the batch
+    cls[3, :, 100:] *= 0.01                         # a handful of candidates
+    y = torch.cat([xy, wh, cls], 1)
+    _nms_compare(y, conf_thres=0.25, iou_thres=0.7)
+    _nms_compare(y, conf_thres=0.25, iou_thres=0.45, agnostic=True, max_det=17)
+
+
+def test_nms_all_anchors_candidates():
+    """Maximum single-label load: every anchor is a candidate (8400 x 8400 IoU mask)."""
+    g = torch.Generator().manual_seed(22)
+    B, nc, A = 2, 80, 8400
+    xy = torch.rand(B, 2, A, generator=g) * 640
+    wh = torch.rand(B, 2, A, generator=g) * 60 + 2
+    cls = torch.rand(B, nc, A, generator=g) * 0.5 + 0.3
+    _nms_compare(torch.cat([xy, wh, cls], 1), conf_thres=0.25, iou_thres=0.7)
+
+
+def test_cw_refine():
+    from oracle import nms_ref
+    from yolo_master_amd.nms import non_max_suppression
+
+    g = torch.Generator().manual_seed(23)
+    B, nc, A = 2, 8, 1500
+    xy = torch.rand(B, 2, A, generator=g) * 300 + 20
+    wh = torch.rand(B, 2, A, generator=g) * 100 + 20
+    cls = torch.sigmoid(torch.randn(B, nc, A, generator=g) * 1.5 - 2.0)
+    y = torch.cat([xy, wh, cls], 1)
+    plain, idx = non_max_suppression(y.to(DEV), 0.25, 0.6, return_idxs=True)
+    cw = non_max_suppression(y.to(DEV), 0.25, 0.6, cluster=True, sigma=0.1)
+    for b in range(B):
+        # candidates exactly as the kernel sees them (single label)
+        p = np.transpose(y[b].numpy(), (1, 0)).copy()
+        p[:, :4] = nms_ref.xywh2xyxy(p[:, :4])
+        conf, j = p[:, 4:].max(1), p[:, 4:].argmax(1)
+        m = conf > 0.25
+        cands = np.concatenate([p[m, :4], conf[m, None], j[m, None].astype(np.float32)], 1)
+        anchor_of = np.nonzero(m)[0]
+        keep = [int(np.nonzero(anchor_of == a)[0][0]) for a in idx[b].cpu().numpy()]
+        ref = nms_ref.cw_refine(cands, np.array(keep), 0.6, 0.1)
+        got = cw[b].cpu().numpy()
+        assert np.array_equal(got[:, 4:], plain[b].cpu().numpy()[:, 4:]), "CW-NMS must not change scores/classes"
+        assert np.abs(got[:, :4] - ref).max() <= 1e-3, f"CW-NMS boxes differ: {np.abs(got[:, :4] - ref).max()}"
+        assert np.abs(got[:, :4] - plain[b].cpu().numpy()[:, :4]).max() > 1e-3, "refinement had no effect"

@@ -1,0 +1,173 @@
+"""End-to-end parity on the GPU: the ymk DetectionModel (HIP kernels through the C-ABI) against
+(a) golden vectors produced by the REAL reference on CPU (tests/golden/fwd_*.npz) and
+(b) the oracle restatement on fresh seeded inputs.  Config 2 of BASELINE.json (N, fp32) is the parity bar:
+routing decisions / kept anchor indices / classes bit-exact, boxes and scores within 1e-4 (abs+rel)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import TOL, load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(scale, dtype=torch.float32):
+    from yolo_master_amd.nn.tasks import DetectionModel
+    from yolo_master_amd.weights import synth_state_dict
+
+    m = DetectionModel(f"yolo-master-{scale}.yaml")
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=0))
+    return m.eval().to(DEV).set_compute_dtype(dtype)
+
+
+def _sample_err(got_nchw, idx, val):
+    g = got_nchw.reshape(-1)[torch.from_numpy(idx.astype(np.int64))].double().numpy()
+    return float(np.abs(g - val).max())
+
+
+@pytest.mark.parametrize("case", ["n640", "n_ragged", "n_tiny", "s_small"])
+def test_forward_vs_reference_golden(case, golden_dir):
+    """Tolerance model.  The fixtures carry, per layer, the real reference's fp32 values, an fp64 evaluation of
+    the same graph, and the reference's own round-off distance to fp64 ("noise").  fp32 evaluation orders differ
+    (oneDNN vs MFMA fma chains), and a 26-layer network amplifies that: at 640x640 the reference itself is 0.33 px
+    / 1.5e-3 away from the exact result, at the small sizes ~1e-4 px / 1e-7.  The HIP path must be as close to the
+    exact (fp64) result as the reference is, within a factor 3, plus the 1e-4 (abs + rel) the north star names."""
+    from yolo_master_amd import ops
+    from yolo_master_amd.nms import non_max_suppression
+    from yolo_master_amd.weights import synth_input
+
+    z = load_npz(golden_dir / f"fwd_{case}.npz")
+    B, H, W, seed = int(z["B"]), int(z["H"]), int(z["W"]), int(z["seed"])
+    m = _model(chr(int(z["scale"])))
+    x = synth_input(B, H, W, seed=seed)
+    taps = {}
+    with torch.inference_mode():
+        y, preds = m._predict_once(x.to(DEV), taps=taps)
+    m.check_flags()
+    # routing decisions first (discontinuous): must be identical to the reference
+    for i in (3, 6, 9, 12):
+        r = m.model[i].last_route
+        assert np.array_equal((r["gate_w"] > 0).cpu().numpy(), z[f"route{i}_retained"]), f"layer {i}: retained experts differ"
+        assert np.abs(r["route_w"].cpu().numpy() - z[f"route{i}_route_w"]).max() <= 1e-4
+        assert np.abs(r["gate_w"].cpu().numpy() - z[f"route{i}_gate_w"]).max() <= 1e-4
+    report = []
+    for i in range(25):
+        t = taps[i]
+        if not torch.is_tensor(t):  # LazyUpsample marker: materialise for the comparison
+            t = t.materialise()
+        got = ops.nhwc_to_nchw_f32(t).cpu()
+        assert tuple(got.shape) == tuple(z[f"layer{i}_shape"]), f"layer {i} shape"
+        e64 = _sample_err(got, z[f"layer{i}_idx"], z[f"layer{i}_val64"])
+        scale = float(np.abs(z[f"layer{i}_val64"]).max())
+        bound = 3.0 * float(z[f"layer{i}_noise"]) + 1e-4 * max(scale, 1.0)
+        report.append((i, e64, float(z[f"layer{i}_noise"]), bound))
+        assert e64 <= bound, f"{case} layer {i}: |hip - fp64| = {e64:.3e} > bound {bound:.3e} (reference noise {float(z[f'layer{i}_noise']):.3e})"
+    yc = y.cpu()
+    assert tuple(yc.shape) == tuple(z["y_shape"])
+    g = yc.reshape(-1)[torch.from_numpy(z["y_idx"].astype(np.int64))].double().numpy()
+    is_box = (z["y_idx"].astype(np.int64) // yc.shape[2]) % yc.shape[1] < 4
+    eb = float(np.abs(g - z["y_val64"])[is_box].max())
+    ec = float(np.abs(g - z["y_val64"])[~is_box].max())
+    assert eb <= 3.0 * float(z["y_noise_box"]) + 1e-4 + 1e-4 * float(np.abs(z["y_val64"][is_box]).max()), f"boxes {eb:.3e}"
+    assert ec <= 3.0 * float(z["y_noise_cls"]) + 1e-4, f"scores {ec:.3e}"
+    print(f"{case}: |hip-fp64| boxes {eb:.3e} px (ref noise {float(z['y_noise_box']):.3e}), scores {ec:.3e} "
+          f"(ref noise {float(z['y_noise_cls']):.3e}); worst layer {max(report, key=lambda r: r[1] / r[3])}")
+    conf, iou = float(z["conf"]), float(z["iou"])
+    if "y" in z:
+        # (a) the NMS kernel on the REFERENCE's own y: kept indices / classes / boxes bit-exact
+        yref = torch.from_numpy(z["y"]).to(DEV)
+        dets, idx = non_max_suppression(yref, conf, iou, return_idxs=True)
+        for b in range(B):
+            if bool(z["ties"][b]):
+                continue
+            assert np.array_equal(idx[b].cpu().numpy(), z[f"nms{b}_idx"]), f"{case} image {b}: kept indices differ"
+            assert np.array_equal(dets[b].cpu().numpy(), z[f"nms{b}_dets"]), f"{case} image {b}: detections differ"
+    # (b) end to end (HIP forward -> HIP NMS) against the reference's detections
+    dets, idx = non_max_suppression(y, conf, iou, return_idxs=True)
+    for b in range(B):
+        if bool(z["ties"][b]):
+            continue
+        ref_idx, ref_d = z[f"nms{b}_idx"], z[f"nms{b}_dets"]
+        got = idx[b].cpu().numpy()
+        inter = len(set(got.tolist()) & set(ref_idx.tolist()))
+        union = max(len(set(got.tolist()) | set(ref_idx.tolist())), 1)
+        exact = np.array_equal(got, ref_idx)
+        print(f"{case} image {b}: kept {len(got)} vs reference {len(ref_idx)}; identical={exact}; jaccard={inter / union:.4f}")
+        if float(z["y_noise_box"]) < 1e-3:   # well-conditioned cases: indices and classes must be bit-exact
+            assert exact, f"{case} image {b}: kept anchor indices differ from the reference"
+            d = dets[b].cpu().numpy()
+            assert np.array_equal(d[:, 5], ref_d[:, 5]), "classes differ"
+            assert np.abs(d[:, 4] - ref_d[:, 4]).max(initial=0) <= 1e-4, "scores"
+            assert (np.abs(d[:, :4] - ref_d[:, :4]) <= 1e-3 + 1e-4 * np.abs(ref_d[:, :4])).all(), "boxes"
+        else:                                 # 640x640: the reference itself is 0.3 px from exact; near-threshold
+            assert inter / union >= 0.9       # IoU/score decisions may flip on either side
+
+
+def test_forward_vs_oracle_fresh_inputs():
+    """Fresh seed (not in any fixture), batch 5, non-square: HIP fp32 vs the oracle on the same input."""
+    from oracle import model_ref, nms_ref
+    from yolo_master_amd.nms import non_max_suppression
+    from yolo_master_amd.nn.tasks import yaml_model_load
+    from yolo_master_amd.weights import synth_input, synth_state_dict
+
+    m = _model("n")
+    x = synth_input(5, 320, 448, seed=99)
+    info = {}
+    with torch.inference_mode():
+        oy, _, _ = model_ref.forward(yaml_model_load("yolo-master-n.yaml"),
+                                     synth_state_dict(m.state_dict(), seed=0), x, moe_info=info)
+        y, _ = m._predict_once(x.to(DEV))
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in synth_state_dict(m.state_dict(), seed=0).items()}
+        y64, _, _ = model_ref.forward(yaml_model_load("yolo-master-n.yaml"), sd64, x.double(), fused=False)
+    for i in (3, 6, 9, 12):
+        assert torch.equal((m.model[i].last_route["gate_w"] > 0).cpu(), info[f"model.{i}"]["retained"])
+    noise = (oy.double() - y64).abs()
+    err = (y.cpu().double() - y64).abs()
+    assert float(err[:, 4:].max()) <= 3 * float(noise[:, 4:].max()) + 1e-4
+    assert float(err[:, :4].max()) <= 3 * float(noise[:, :4].max()) + 1e-4 + 1e-4 * float(y64[:, :4].abs().max())
+    # NMS kernel on the oracle's y: exact
+    ref, ref_idx = nms_ref.non_max_suppression(oy.numpy(), 0.1, 0.7, return_idxs=True)
+    got, got_idx = non_max_suppression(oy.to(DEV), 0.1, 0.7, return_idxs=True)
+    for b in range(5):
+        assert np.array_equal(got_idx[b].cpu().numpy(), ref_idx[b]) and np.array_equal(got[b].cpu().numpy(), ref[b])
+
+
+def test_bf16_model_tracks_fp32():
+    """bf16 compute (config 3's type): same routing on the fixture batch and scores close to fp32."""
+    from yolo_master_amd.weights import synth_input
+
+    x = synth_input(4, 640, 640, seed=1).to(DEV)
+    with torch.inference_mode():
+        m32 = _model("n")
+        y32, _ = m32._predict_once(x)
+        r32 = [(m32.model[i].last_route["gate_w"] > 0).cpu() for i in (3, 6, 9, 12)]
+        m16 = _model("n", torch.bfloat16)
+        y16, _ = m16._predict_once(x)
+        r16 = [(m16.model[i].last_route["gate_w"] > 0).cpu() for i in (3, 6, 9, 12)]
+    assert torch.isfinite(y16).all()
+    same = torch.stack([torch.stack([(a[b] == c[b]).all() for a, c in zip(r32, r16)]).all() for b in range(4)])
+    assert same.float().mean() >= 0.5, "bf16 flipped the routing of most images"
+    d = (y16[same.to(DEV)][:, 4:] - y32[same.to(DEV)][:, 4:]).abs()
+    assert float(d.mean()) < 2e-2, f"bf16 scores drift: mean |d| = {float(d.mean()):.3e}"
+
+
+def test_module_api_dropin():
+    """Public nn.Module surface: NCHW in / NCHW out, state_dict keys identical to the reference's."""
+    import json
+    from pathlib import Path
+
+    m = _model("n")
+    keys = json.load(open(Path(__file__).parent / "golden" / "keys_n.json"))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(keys.keys())
+    assert all(list(sd[k].shape) == v for k, v in keys.items())
+    x = torch.rand(2, 3, 64, 64, device=DEV)
+    with torch.inference_mode():
+        y0 = m.model[0](x)                 # Conv, NCHW logical
+        y1 = m.model[1](y0)
+        y2 = m.model[2](y1)
+        y3 = m.model[3](y2)
+    assert y0.shape == (2, 16, 32, 32) and y3.shape == (2, 64, 16, 16)
+    yy, _ = m(x)
+    assert yy.shape == (2, 84, 8 * 8 + 4 * 4 + 2 * 2)

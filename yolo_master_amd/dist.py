@@ -1,0 +1,76 @@
+"""Multi-GPU batched inference: one process per GPU, images sharded, no data-path collective.
+
+The detection forward pass has no exchange step (ES-MoE routing is per image, BatchNorm is in eval mode,
+NMS is per image), so a batch is split into contiguous per-rank shards — the same contiguous
+split as the reference's DDP validation sampler (ultralytics/data/build.py:150 ContiguousDistributedSampler).
+Only two RCCL collectives exist, both outside the forward pass: a one-time weight ``broadcast`` from rank 0
+(replication over xGMI) and a per-batch fixed-size ``all_gather`` of the padded detections
+(``[B_local, max_det, 6]`` + counts: <= 7.2 KB per image — latency-bound, never the per-link-bound ring
+all-reduce).  Backend "nccl" is RCCL on ROCm; the same code runs on gloo/CPU tensors for the tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous [begin, end) shard of n_items for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise torch.distributed from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def broadcast_state_dict(module: torch.nn.Module, src: int = 0) -> None:
+    """Replicate rank `src`'s parameters and buffers to every rank (one flat broadcast per dtype)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [t for t in module.state_dict().values() if torch.is_tensor(t)]
+    by_dtype: dict = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dt, ts in by_dtype.items():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    if hasattr(module, "repack"):
+        module.repack()
+
+
+def gather_detections(dets: torch.Tensor, counts: torch.Tensor, idx: torch.Tensor | None = None):
+    """all_gather of per-rank padded detections.  dets [B_local, max_det, 6], counts [B_local].
+    Every rank must hold the same B_local (pad the last shard).  Returns tensors with leading dim
+    world*B_local in rank order (i.e. the original batch order for contiguous shards)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dets, counts, idx
+    world = dist.get_world_size()
+
+    def ag(t):
+        out = torch.empty((world, *t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]) if t.dim() else out, t.contiguous()) \
+            if dist.get_backend() == "nccl" else dist.all_gather(list(out.unbind(0)), t.contiguous())
+        return out.reshape(world * t.shape[0], *t.shape[1:])
+
+    return ag(dets), ag(counts), (ag(idx) if idx is not None else None)

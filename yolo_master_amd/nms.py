@@ -1,0 +1,56 @@
+"""Batched NMS front-end with the reference's signature.
+
+``non_max_suppression`` mirrors ultralytics/utils/nms.py:13-171 (argument names, defaults, return
+types: a list of ``[n_i, 6]`` tensors ``(x1, y1, x2, y2, conf, cls)`` and optionally the kept anchor
+indices); the work is done for the whole batch by libymk (``ymk_nms_batched``), with a single host
+sync to read the per-image counts.  ``nms_padded`` is the sync-free variant used by the benchmark
+and the multi-GPU gather (fixed ``[B, max_det, 6]`` + counts).
+
+Differences from the reference that are contract-level, not numerical:
+  * equal scores are ordered by candidate index (the reference's ``argsort(descending=True)`` is
+    unstable, its tie order is implementation-defined);
+  * the wall-clock ``max_time_img`` early exit (nms.py:166-169) does not exist;
+  * ``cluster=True`` enables the CW-NMS box refinement, which the reference's Python only declares
+    (cfg/default.yaml:195-198); spec: examples/YOLO-Master-Cross-Platform-Edge-Deployment/cpp/src/common.cpp:150-185.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import FLAG_NMS_OVERFLOW
+
+
+def nms_padded(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, agnostic=False, multi_label=False,
+               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1):
+    """prediction: [B, 4+nc, A] fp32 on the GPU.  Returns (dets [B,max_det,6], counts [B], idx [B,max_det],
+    status [1]) without synchronising."""
+    if prediction.dtype != torch.float32:
+        prediction = prediction.float()
+    prediction = prediction.contiguous()
+    nc = prediction.shape[1] - 4
+    return ops.nms_batched(prediction, conf_thres, iou_thres, bool(multi_label) and nc > 1, bool(agnostic), max_det,
+                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None)
+
+
+def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float = 0.45, classes=None,
+                        agnostic: bool = False, multi_label: bool = False, labels=(), max_det: int = 300, nc: int = 0,
+                        max_time_img: float = 0.05, max_nms: int = 30000, max_wh: int = 7680, rotated: bool = False,
+                        end2end: bool = False, return_idxs: bool = False, cluster: bool = False, sigma: float = 0.1):
+    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
+    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    if isinstance(prediction, (list, tuple)):
+        prediction = prediction[0]
+    if rotated or end2end or prediction.shape[-1] == 6 or labels or classes is not None:
+        raise NotImplementedError("ymk NMS covers the detect path: no rotated/end2end/autolabel/class-filter modes")
+    if nc and nc != prediction.shape[1] - 4:
+        raise NotImplementedError("ymk NMS: extra mask channels (segment) are not on the detect path")
+    dets, counts, idx, status = nms_padded(prediction, conf_thres, iou_thres, agnostic, multi_label, max_det, max_nms,
+                                           max_wh, cluster, sigma)
+    n = counts.tolist()  # the one host sync of the post-processing step
+    if int(status.item()) & FLAG_NMS_OVERFLOW:
+        raise RuntimeError("ymk NMS: more than 2*max_nms multi-label candidates in one image (unsupported stress case)")
+    out = [dets[b, : n[b]] for b in range(len(n))]
+    if return_idxs:
+        return out, [idx[b, : n[b]].long() for b in range(len(n))]
+    return out

@@ -17,6 +17,38 @@ from ._lib import ConvDesc, check, lib
 DT = {torch.float32: _lib.YMK_F32, torch.bfloat16: _lib.YMK_BF16}
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of ONE kernel family (bench.py's roofline leg).  Events are
+    recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.tag = None
+        self.records = []  # (start_event, end_event, algorithmic_bytes, flops)
+
+    def start(self, tag):
+        self.tag, self.records = tag, []
+
+    def stop(self):
+        self.tag = None
+
+    def wrap(self, tag, nbytes, flops):
+        if self.tag != tag:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((e0, e1, nbytes, flops))
+        e0.record()
+        return e1
+
+
+TIMER = KernelTimer()
+
+
+def conv_kernel_tag(dtype, cout: int, k: int) -> str:
+    """Name of the conv_igemm_kernel instantiation ymk_conv2d dispatches to (csrc/conv.hip launch_conv)."""
+    tile = "128x128" if cout > 64 else "64x256" if cout > 32 else "32x256" if cout > 16 else "16x256"
+    return f"conv_igemm_{'bf16' if dtype == torch.bfloat16 else 'f32'}_{tile}_k{k}"
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -101,7 +133,15 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual
         ldr = rb[4]
     d = ConvDesc(DT[x.dtype], DT[out.dtype], B, H, W, Cin, Cout, k, stride, ldx, ldy, ldr, Kp,
                  _lib.ACT_SILU if act else _lib.ACT_NONE)
+    ev = None
+    if TIMER.tag is not None:
+        es = x.element_size()
+        nbytes = (B * H * W * Cin + Cout * k * k * Cin + (B * Ho * Wo * Cout if residual is not None else 0)) * es \
+            + B * Ho * Wo * Cout * out.element_size()
+        ev = TIMER.wrap(conv_kernel_tag(x.dtype, Cout, k), nbytes, 2 * B * Ho * Wo * Cout * k * k * Cin)
     check(lib.ymk_conv2d(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), _stream()), "conv2d")
+    if ev is not None:
+        ev.record()
     return out
 
 

@@ -38,7 +38,7 @@ def synth_state_dict(template: dict, seed: int = 0, router_scale: float = 4.0, c
         shp = tuple(t.shape)
         if name.endswith("num_batches_tracked"):
             v = torch.zeros(shp, dtype=t.dtype)
-        elif ".dfl.conv.weight" in name:
+        elif name.endswith("dfl.conv.weight"):
             v = torch.arange(shp[1], dtype=torch.float32).view(shp)  # fixed DFL integral weights
         elif name.endswith("running_mean"):
             v = torch.randn(shp, generator=g) * 0.1

@@ -133,7 +133,8 @@ int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t 
  * Output: dw_out[pair][H][W][C] (pair = b*top_k + slot), dense (ld = C). */
 int ymk_esmoe_dw(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t ldx, const void* dw_w, const int32_t* dw_off, const int32_t* ksizes,
-                 int32_t E, int32_t top_k, const int32_t* sel, const int32_t* csr_off,
+                 int32_t E, int32_t top_k, int32_t kmax /* max of ksizes (host copy) */,
+                 const int32_t* sel, const int32_t* csr_off,
                  const int32_t* csr_pair, void* dw_out, void* stream);
 
 /* Pointwise stage: grouped GEMM on MFMA over the retained experts of each image,

@@ -91,7 +91,9 @@ def test_forward_vs_reference_golden(case, golden_dir):
         ref_idx, ref_d = z[f"nms{b}_idx"], z[f"nms{b}_dets"]
         got = idx[b].cpu().numpy()
         inter = len(set(got.tolist()) & set(ref_idx.tolist()))
-        union = max(len(set(got.tolist()) | set(ref_idx.tolist())), 1)
+        union = len(set(got.tolist()) | set(ref_idx.tolist()))
+        if union == 0:
+            inter = union = 1
         exact = np.array_equal(got, ref_idx)
         print(f"{case} image {b}: kept {len(got)} vs reference {len(ref_idx)}; identical={exact}; jaccard={inter / union:.4f}")
         if float(z["y_noise_box"]) < 1e-3:   # well-conditioned cases: indices and classes must be bit-exact
@@ -111,14 +113,16 @@ def test_forward_vs_oracle_fresh_inputs():
     from yolo_master_amd.nn.tasks import yaml_model_load
     from yolo_master_amd.weights import synth_input, synth_state_dict
 
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    sd = synth_state_dict(DetectionModel("yolo-master-n.yaml").state_dict(), seed=0)
     m = _model("n")
     x = synth_input(5, 320, 448, seed=99)
     info = {}
     with torch.inference_mode():
-        oy, _, _ = model_ref.forward(yaml_model_load("yolo-master-n.yaml"),
-                                     synth_state_dict(m.state_dict(), seed=0), x, moe_info=info)
+        oy, _, _ = model_ref.forward(yaml_model_load("yolo-master-n.yaml"), sd, x, moe_info=info)
         y, _ = m._predict_once(x.to(DEV))
-        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in synth_state_dict(m.state_dict(), seed=0).items()}
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
         y64, _, _ = model_ref.forward(yaml_model_load("yolo-master-n.yaml"), sd64, x.double(), fused=False)
     for i in (3, 6, 9, 12):
         assert torch.equal((m.model[i].last_route["gate_w"] > 0).cpu(), info[f"model.{i}"]["retained"])

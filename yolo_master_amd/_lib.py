@@ -48,7 +48,7 @@ SYMBOLS = {
     "ymk_esmoe_route_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "ymk_esmoe_route": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ymk_esmoe_dw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ymk_esmoe_dw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ymk_esmoe_pw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
                                _vp, _i32, _vp]),
     "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

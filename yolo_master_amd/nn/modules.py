@@ -716,7 +716,7 @@ class ES_MOE(YmkModule):
             "w2": rn[2].weight.detach().float().reshape(E, hidden).to(device).contiguous(),
             "b2": rn[2].bias.detach().float().to(device).contiguous(),
             "dw_w": torch.cat(dw_parts).contiguous(), "dw_off": torch.tensor(dw_off, **i32),
-            "ks": torch.tensor(ks, **i32), "pw_w": pw_w.to(dtype).contiguous(), "pw_b": pw_b.contiguous(),
+            "ks": torch.tensor(ks, **i32), "kmax": max(ks), "pw_w": pw_w.to(dtype).contiguous(), "pw_b": pw_b.contiguous(),
             "ns": ns.detach().float().to(device).contiguous(), "nt": nt.detach().float().to(device).contiguous(),
         }
 
@@ -740,7 +740,7 @@ class ES_MOE(YmkModule):
         top_k = self.num_experts if dense else self.top_k
         route_w, gate_w, sel, csr_off, csr_pair = ops.esmoe_route(
             x, pk["w1"], pk["b1"], pk["w2"], pk["b2"], top_k, float(self.dynamic_threshold), self._flags)
-        dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], top_k, sel, csr_off, csr_pair)
+        dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair)
         y = ops.esmoe_pw(dw, B, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel, gate_w, out=out)
         # eval-time state the reference keeps (modules.py:706-741): usage = mean routing weight
         usage = route_w.mean(0)

@@ -189,11 +189,11 @@ def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
     return route_w, gate_w, sel, csr_off, csr_pair
 
 
-def esmoe_dw(x, dw_w, dw_off, ksizes, top_k: int, sel, csr_off, csr_pair):
+def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_pair):
     B, H, W, Cc, ldx = _nhwc(x)
     E = ksizes.numel()
     out = torch.empty((B * top_k, H, W, Cc), dtype=x.dtype, device=x.device)
-    check(lib.ymk_esmoe_dw(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), E, top_k, _p(sel),
+    check(lib.ymk_esmoe_dw(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), E, top_k, kmax, _p(sel),
                            _p(csr_off), _p(csr_pair), _p(out), _stream()), "esmoe_dw")
     return out
 

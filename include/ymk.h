@@ -81,8 +81,10 @@ int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, const float
 /* Stem convolution reading the NCHW fp32 network input directly (Cin <= 4) and
  * writing NHWC.  Replaces layer 0 `Conv(3, c, 3, 2)` (cfg yolo-master-*.yaml,
  * conv.py:80-89) together with the NCHW->NHWC layout change.
- * w: fp32 [Cout][ksize*ksize*Cin] (ky,kx,cin), bias fp32 [Cout]. */
-int ymk_conv2d_stem_nchw(const float* x_nchw, const float* w, const float* bias, void* y,
+ * w: fp32 [Cout][ksize*ksize*Cin] (ky,kx,cin); wt_kco: the same weights transposed to
+ * [ksize*ksize*Cin][Cout] (enables the pixel-per-thread kernel for Cout in {16,32,64}; may be
+ * NULL); bias fp32 [Cout]. */
+int ymk_conv2d_stem_nchw(const float* x_nchw, const float* w, const float* wt_kco, const float* bias, void* y,
                          int32_t out_dtype, int32_t B, int32_t Cin, int32_t H, int32_t W,
                          int32_t Cout, int32_t ksize, int32_t stride, int32_t ldy, int32_t act,
                          void* stream);

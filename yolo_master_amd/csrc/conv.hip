@@ -21,7 +21,7 @@ __device__ __forceinline__ float act_silu(float v) {
 template <typename T, int BCO, int BPX, int WCO, int WPX, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     using G = IGemm<T, BCO, BPX, WCO, WPX, KS>;
-    __shared__ u32x4 smem[2 * G::STAGE];
+    __shared__ u32x4 smem[G::SMEM_U4];
     const int t = threadIdx.x;
     const int64_t px0 = (int64_t)blockIdx.x * BPX;
     const int co0 = blockIdx.y * BCO;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < G::NB; ++i) {
-        const int64_t m = px0 + (t >> 2) + i * 64;
+        const int64_t m = px0 + (t >> 3) + i * G::RPP;
         rows.ok[i] = m < a.M;
         const int64_t mm = rows.ok[i] ? m : 0;
         const int b = (int)(mm / HoWo);
@@ -52,36 +52,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     G::run(acc, reinterpret_cast<const T*>(a.x), a.ldx, a.H, a.W, a.Cin, rows, wt, a.Kpad,
            a.Cout - co0, smem);
 
-    // epilogue: bias + act (+ residual), 4 consecutive couts per lane
+    // epilogue: bias + act in registers, then LDS-staged coalesced store (+ residual)
     const int lane = t & 63, wave = t >> 6;
-    const int wco = wave / WPX, wpx = wave % WPX;
+    const int wco = wave / WPX;
     constexpr bool PRECISE = sizeof(T) == 4;
+    f32x4 bv[G::TM];
 #pragma unroll
     for (int i = 0; i < G::TM; ++i) {
         const int co = co0 + (wco * G::TM + i) * 16 + (lane >> 4) * 4;
-        if (co >= a.Cout) continue;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-        for (int j = 0; j < G::TN; ++j) {
-            const int64_t m = px0 + (wpx * G::TN + j) * 16 + (lane & 15);
-            if (m >= a.M) continue;
-            float v0 = acc[i][j].x + bv.x, v1 = acc[i][j].y + bv.y;
-            float v2 = acc[i][j].z + bv.z, v3 = acc[i][j].w + bv.w;
-            if (a.act == YMK_ACT_SILU) {
-                v0 = act_silu<T, PRECISE>(v0); v1 = act_silu<T, PRECISE>(v1);
-                v2 = act_silu<T, PRECISE>(v2); v3 = act_silu<T, PRECISE>(v3);
-            }
-            if (a.res) {
-                float r0, r1, r2, r3;
-                load4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co, r0, r1, r2, r3);
-                v0 = r0 + v0; v1 = r1 + v1; v2 = r2 + v2; v3 = r3 + v3;
-            }
-            if (a.out_f32)
-                store4(reinterpret_cast<float*>(a.y) + m * a.ldy + co, v0, v1, v2, v3);
-            else
-                store4(reinterpret_cast<T*>(a.y) + m * a.ldy + co, v0, v1, v2, v3);
-        }
+        bv[i] = co < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    const bool silu = a.act == YMK_ACT_SILU;
+    auto val = [&](int i, int j, int r) {
+        const float v = acc[i][j][r] + bv[i][r];
+        return silu ? act_silu<T, PRECISE>(v) : v;
+    };
+    auto emit = [&](int px, int co_l, const f32x4& v) {
+        const int64_t m = px0 + px;
+        const int co = co0 + co_l;
+        if (m >= a.M || co >= a.Cout) return;
+        float v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
+        if (a.res) {
+            float r0, r1, r2, r3;
+            load4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co, r0, r1, r2, r3);
+            v0 = r0 + v0; v1 = r1 + v1; v2 = r2 + v2; v3 = r3 + v3;
+        }
+        if (a.out_f32)
+            store4(reinterpret_cast<float*>(a.y) + m * a.ldy + co, v0, v1, v2, v3);
+        else
+            store4(reinterpret_cast<T*>(a.y) + m * a.ldy + co, v0, v1, v2, v3);
+    };
+    G::epilogue(smem, val, emit);
 }
 
 template <typename T, int KS>
@@ -185,7 +186,55 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     }
 }
 
-extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float* bias, void* y,
+// Specialised stem: one thread = one output pixel x all CO output channels.  The k*k*Cin input
+// values of a pixel are loaded once (lanes walk along x, so loads coalesce), the weights are read
+// with wave-uniform indices (scalar loads -> SGPR operands of v_fma_f32), the CO results are written
+// as one contiguous NHWC row.  VALU-bound only by the 2*K*CO flops per pixel.
+template <typename TO, int CO>
+__global__ __launch_bounds__(256) void stem_px_kernel(const float* __restrict__ x, const float* __restrict__ wt /*[K][CO]*/,
+                                                       const float* __restrict__ bias, TO* __restrict__ y, int B, int Cin,
+                                                       int H, int W, int Ho, int Wo, int ks, int stride, int ldy, int act) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= total) return;
+    const int ox = (int)(m % Wo);
+    const int oy = (int)((m / Wo) % Ho);
+    const int b = (int)(m / ((int64_t)Wo * Ho));
+    const int pad = ks / 2;
+    float acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) acc[j] = bias[j];
+    for (int ky = 0; ky < ks; ++ky) {
+        const int iy = oy * stride - pad + ky;
+        for (int kx = 0; kx < ks; ++kx) {
+            const int ix = ox * stride - pad + kx;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            for (int c = 0; c < Cin; ++c) {
+                const float xv = ok ? x[(((int64_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+                const float* wk = wt + ((ky * ks + kx) * Cin + c) * CO;  // wave-uniform address
+#pragma unroll
+                for (int j = 0; j < CO; ++j) acc[j] = fmaf(xv, wk[j], acc[j]);
+            }
+        }
+    }
+    TO* o = y + m * ldy;
+#pragma unroll
+    for (int j = 0; j < CO; j += 4) {
+        float v0 = acc[j], v1 = acc[j + 1], v2 = acc[j + 2], v3 = acc[j + 3];
+        if (act == YMK_ACT_SILU) { v0 = silu_exact(v0); v1 = silu_exact(v1); v2 = silu_exact(v2); v3 = silu_exact(v3); }
+        store4(o + j, v0, v1, v2, v3);
+    }
+}
+
+template <typename TO, int CO>
+static void launch_stem_px(const float* x, const float* wt, const float* bias, void* y, int B, int Cin, int H, int W, int Ho,
+                           int Wo, int ks, int stride, int ldy, int act, hipStream_t s) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    hipLaunchKernelGGL((stem_px_kernel<TO, CO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, wt, bias, (TO*)y, B,
+                       Cin, H, W, Ho, Wo, ks, stride, ldy, act);
+}
+
+extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float* wt_kco, const float* bias, void* y,
                                     int32_t out_dtype, int32_t B, int32_t Cin, int32_t H, int32_t W,
                                     int32_t Cout, int32_t ksize, int32_t stride, int32_t ldy,
                                     int32_t act, void* stream) {
@@ -199,6 +248,17 @@ extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float*
     if (shm > 64 * 1024) return YMK_E_BADARG;
     const int blocks = (int)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
     hipStream_t s = (hipStream_t)stream;
+    if (wt_kco && (Cout == 16 || Cout == 32 || Cout == 64) && (out_dtype == YMK_F32 || out_dtype == YMK_BF16)) {
+        const bool f = out_dtype == YMK_F32;
+#define YMK_STEM(CO)                                                                                                \
+    (f ? launch_stem_px<float, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s)           \
+       : launch_stem_px<bf16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
+        if (Cout == 16) YMK_STEM(16);
+        else if (Cout == 32) YMK_STEM(32);
+        else YMK_STEM(64);
+#undef YMK_STEM
+        return ymk_launch_status();
+    }
     if (out_dtype == YMK_F32)
         hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(256), shm, s, x, w, bias, (float*)y, B,
                            Cin, H, W, Ho, Wo, Cout, ksize, stride, ldy, act);

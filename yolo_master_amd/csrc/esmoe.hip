@@ -231,7 +231,7 @@ struct MoePwArgs {
 template <typename T, int BCO, int BPX, int WCO, int WPX>
 __global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
     using G = IGemm<T, BCO, BPX, WCO, WPX, 1>;
-    __shared__ u32x4 smem[2 * G::STAGE];
+    __shared__ u32x4 smem[G::SMEM_U4];
     const int t = threadIdx.x;
     const int b = blockIdx.x / a.tiles, tile = blockIdx.x % a.tiles;
     const int co0 = blockIdx.y * BCO;
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
     typename G::Rows rows;
 #pragma unroll
     for (int i = 0; i < G::NB; ++i) {
-        const int m = m0 + (t >> 2) + i * 64;
+        const int m = m0 + (t >> 3) + i * G::RPP;
         rows.ok[i] = m < a.HW;
         rows.pix[i] = 0; rows.iy0[i] = 0; rows.ix0[i] = rows.ok[i] ? m : 0;
     }
     const int lane = t & 63, wave = t >> 6;
-    const int wco = wave / WPX, wpx = wave % WPX;
+    const int wco = wave / WPX;
     constexpr bool PRECISE = sizeof(T) == 4;
 
     f32x4 out[G::TM][G::TN];
@@ -286,27 +286,25 @@ __global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
             }
         }
     }
-    // trailing ES_MOE.norm: BatchNorm(eval) + SiLU
+    // trailing ES_MOE.norm: BatchNorm(eval) + SiLU, then the LDS-staged coalesced store
+    f32x4 sc[G::TM], sh[G::TM];
 #pragma unroll
     for (int i = 0; i < G::TM; ++i) {
         const int co = co0 + (wco * G::TM + i) * 16 + (lane >> 4) * 4;
-        if (co >= a.Cout) continue;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.nscale + co);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.nshift + co);
-#pragma unroll
-        for (int j = 0; j < G::TN; ++j) {
-            const int m = m0 + (wpx * G::TN + j) * 16 + (lane & 15);
-            if (m >= a.HW) continue;
-            float v0 = out[i][j].x * sc.x + sh.x, v1 = out[i][j].y * sc.y + sh.y;
-            float v2 = out[i][j].z * sc.z + sh.z, v3 = out[i][j].w * sc.w + sh.w;
-            if (PRECISE) {
-                v0 = silu_exact(v0); v1 = silu_exact(v1); v2 = silu_exact(v2); v3 = silu_exact(v3);
-            } else {
-                v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3);
-            }
-            store4(reinterpret_cast<T*>(a.y) + ((size_t)b * a.HW + m) * a.ldy + co, v0, v1, v2, v3);
-        }
+        const bool ok = co < a.Cout;
+        sc[i] = ok ? *reinterpret_cast<const f32x4*>(a.nscale + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sh[i] = ok ? *reinterpret_cast<const f32x4*>(a.nshift + co) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    auto val = [&](int i, int j, int r) {
+        const float v = out[i][j][r] * sc[i][r] + sh[i][r];
+        return PRECISE ? silu_exact(v) : silu_f(v);
+    };
+    auto emit = [&](int px, int co_l, const f32x4& v) {
+        const int m = m0 + px, co = co0 + co_l;
+        if (m >= a.HW || co >= a.Cout) return;
+        store4(reinterpret_cast<T*>(a.y) + ((size_t)b * a.HW + m) * a.ldy + co, v.x, v.y, v.z, v.w);
+    };
+    G::epilogue(smem, val, emit);
 }
 
 template <typename T>

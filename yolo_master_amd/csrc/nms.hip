@@ -5,7 +5,7 @@
 //   boxes + cls*max_wh (:148-154); greedy: drop j when !(IoU(i,j) <= thr) (:300); [:max_det] (:162)
 // Pipeline (all per-image work runs batched over B):
 //   count -> scan -> emit (ordered compaction) -> rank (counting sort, stable)
-//   -> 64x64 IoU bitmask (upper triangle) -> blocked sweep (one wavefront per image).
+//   -> chunked greedy suppression against the kept list (one workgroup per image, no n^2 mask).
 // Compile with -ffp-contract=off: IoU arithmetic must round exactly like the reference.
 #include "ymk_common.h"
 
@@ -26,7 +26,6 @@ struct NmsWs {
     int* scls;       // [B][ns]
     int* sanchor;    // [B][ns]
     int* keep_pos;   // [B][max_det_cap]
-    unsigned long long* mask;  // [B][ns][nw]
     int nblk, capc, ns, nw;
     size_t total;
 };
@@ -64,7 +63,6 @@ static NmsWs nms_layout(void* base, int B, int nc, int A, int multi, int max_nms
     w.scls = (int*)take((size_t)B * w.ns * 4);
     w.sanchor = (int*)take((size_t)B * w.ns * 4);
     w.keep_pos = (int*)take((size_t)B * NMS_MAXDET_CAP * 4);
-    w.mask = (unsigned long long*)take((size_t)B * w.ns * w.nw * 8);
     w.total = off;
     return w;
 }
@@ -196,31 +194,33 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w) {
     }
 }
 
-// ---- 5. IoU bitmask, upper triangle, 64x64 tiles -----------------------------------
-// grid (G, B): each wavefront walks the image's valid tiles with a stride; the 64 column
-// boxes of a tile live one per lane and are broadcast with v_readlane (no LDS, no barrier).
+// ---- 5. greedy suppression, one workgroup (4 wavefronts) per image --------------------
+// Sorted candidates are consumed 64 at a time.  Every wavefront holds the same 64 candidates (one per
+// lane).  Phase A: each wavefront tests them against its quarter of the boxes kept so far (LDS
+// broadcast reads) and ballots a "suppressed by an earlier keep" word.  Phase B: each wavefront
+// evaluates 16 of the 64 intra-chunk columns (v_readlane broadcast) into per-lane mask words.
+// Then the 64-step in-order resolve runs (redundantly per wavefront, register only), survivors
+// are appended to the kept list and written out.  Work is O(n * kept) <= n * max_det IoUs instead of
+// the O(n^2) bitmask, nothing but the final detections touches HBM, and the loop stops at max_det.
+// IoU arithmetic and decisions are identical to TorchNMS.nms (drop j when !(IoU <= thr)).
 __device__ __forceinline__ float rdlane(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
-__global__ __launch_bounds__(256) void nms_mask_kernel(NmsWs w, float thr, float cls_off) {
-    const int b = blockIdx.y;
+
+__global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, float cls_off, int max_det,
+                                                        float* __restrict__ out_dets, int* __restrict__ out_counts,
+                                                        int* __restrict__ out_idx) {
+    __shared__ float kx1[NMS_MAXDET_CAP], ky1[NMS_MAXDET_CAP], kx2[NMS_MAXDET_CAP], ky2[NMS_MAXDET_CAP],
+        kar[NMS_MAXDET_CAP];
+    __shared__ unsigned long long supw[4];
+    __shared__ unsigned long long part[4][64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = w.nsort[b];
-    const int nwv = (n + 63) / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* sb = w.sbox + (size_t)b * w.ns * 4;
     const int* sc = w.scls + (size_t)b * w.ns;
-    for (int tile = blockIdx.x * 4 + wave; tile < nwv * nwv; tile += gridDim.x * 4) {
-        const int rb = tile / nwv, cb = tile - rb * nwv;
-        if (cb < rb) continue;
-        const int j = cb * 64 + lane;
-        float jx1 = 0.f, jy1 = 0.f, jx2 = 0.f, jy2 = 0.f;
-        if (j < n) {
-            const f32x4 bx = *reinterpret_cast<const f32x4*>(sb + (size_t)j * 4);
-            const float c = (float)sc[j] * cls_off;
-            jx1 = bx.x + c; jy1 = bx.y + c; jx2 = bx.z + c; jy2 = bx.w + c;
-        }
-        const float jar = (jx2 - jx1) * (jy2 - jy1);
-        const int i = rb * 64 + lane;
+    int kept = 0;
+    for (int i0 = 0; i0 < n && kept < max_det; i0 += 64) {
+        const int i = i0 + lane;
         float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
         if (i < n) {
             const f32x4 bx = *reinterpret_cast<const f32x4*>(sb + (size_t)i * 4);
@@ -228,88 +228,68 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(NmsWs w, float thr, float
             x1 = bx.x + c; y1 = bx.y + c; x2 = bx.z + c; y2 = bx.w + c;
         }
         const float ai = (x2 - x1) * (y2 - y1);
-        unsigned long long bits = 0ull;
-        const int jn = min(64, n - cb * 64);
-        for (int jj = 0; jj < jn; ++jj) {
-            const float cx1 = rdlane(jx1, jj), cy1 = rdlane(jy1, jj), cx2 = rdlane(jx2, jj), cy2 = rdlane(jy2, jj);
-            const float ca = rdlane(jar, jj);
-            const float xx1 = fmaxf(x1, cx1), yy1 = fmaxf(y1, cy1);
-            const float xx2 = fminf(x2, cx2), yy2 = fminf(y2, cy2);
+        // phase A: against this wavefront's share of the kept list
+        const int kq = (kept + 3) >> 2;
+        const int k0 = wave * kq, k1 = min(kept, k0 + kq);
+        bool sup = false;
+        for (int k = k0; k < k1; ++k) {
+            const float xx1 = fmaxf(kx1[k], x1), yy1 = fmaxf(ky1[k], y1);
+            const float xx2 = fminf(kx2[k], x2), yy2 = fminf(ky2[k], y2);
             const float ww = fmaxf(xx2 - xx1, 0.f), hh = fmaxf(yy2 - yy1, 0.f);
             const float inter = ww * hh;
-            const float iou = inter / ((ai + ca) - inter);
-            if ((cb * 64 + jj) > i && !(iou <= thr)) bits |= 1ull << jj;
+            const float iou = inter / ((kar[k] + ai) - inter);
+            sup |= !(iou <= thr);
         }
-        if (i < n) w.mask[((size_t)b * w.ns + i) * w.nw + cb] = bits;
-    }
-}
-
-// ---- 6. blocked greedy sweep, one wavefront per image --------------------------------
-__global__ __launch_bounds__(64) void nms_sweep_kernel(NmsWs w, int max_det, float* __restrict__ out_dets,
-                                                      int* __restrict__ out_counts, int* __restrict__ out_idx) {
-    extern __shared__ unsigned long long rem[];  // [nw]
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int n = w.nsort[b];
-    const int nw = (n + 63) / 64;
-    for (int i = lane; i < nw; i += 64) rem[i] = 0ull;
-    __syncthreads();
-    const unsigned long long* mb = w.mask + (size_t)b * w.ns * w.nw;
-    int kept = 0;
-    for (int wi = 0; wi < nw && kept < max_det; ++wi) {
-        const int row = wi * 64 + lane;
-        unsigned long long cur = rem[wi];
-        const unsigned long long diag = row < n ? mb[(size_t)row * w.nw + wi] : 0ull;
-        const int nv = min(64, n - wi * 64);
+        const unsigned long long sw = __ballot(sup);
+        // phase B: 16 intra-chunk columns per wavefront; row = this lane's candidate, earlier box = pivot jj
+        unsigned long long bits = 0ull;  // bit jj set: candidate `lane` is suppressed by chunk member jj (jj < lane)
+        const int nv = min(64, n - i0);
+        for (int q = 0; q < 16; ++q) {
+            const int jj = wave * 16 + q;
+            if (jj >= nv) break;
+            const float px1 = rdlane(x1, jj), py1 = rdlane(y1, jj), px2 = rdlane(x2, jj), py2 = rdlane(y2, jj);
+            const float pa = rdlane(ai, jj);
+            const float xx1 = fmaxf(px1, x1), yy1 = fmaxf(py1, y1);
+            const float xx2 = fminf(px2, x2), yy2 = fminf(py2, y2);
+            const float ww = fmaxf(xx2 - xx1, 0.f), hh = fmaxf(yy2 - yy1, 0.f);
+            const float inter = ww * hh;
+            const float iou = inter / ((pa + ai) - inter);
+            if (lane > jj && !(iou <= thr)) bits |= 1ull << jj;
+        }
+        if (lane == 0) supw[wave] = sw;
+        part[wave][lane] = bits;
+        __syncthreads();
+        unsigned long long cur = supw[0] | supw[1] | supw[2] | supw[3];
+        if (nv < 64) cur |= ~0ull << nv;  // lanes past the end count as suppressed
+        const unsigned long long mine = part[0][lane] | part[1][lane] | part[2][lane] | part[3][lane];
+        // in-order resolve: candidate t survives iff not suppressed by the kept list nor by an earlier survivor
         unsigned long long km = 0ull;
         for (int t = 0; t < nv; ++t) {
-            const unsigned long long dt = __shfl(diag, t);
-            if (!((cur >> t) & 1ull)) {
-                km |= 1ull << t;
-                cur |= dt;
-            }
+            const unsigned long long mt = __shfl(mine, t);  // who (earlier in the chunk) suppresses t
+            if (!((cur >> t) & 1ull) && !(mt & km)) km |= 1ull << t;
         }
-        // trim to the detections still allowed
         int cntk = __popcll(km);
-        if (kept + cntk > max_det) {
+        if (kept + cntk > max_det) {  // keep only the first (max_det - kept) survivors
             int allow = max_det - kept;
             unsigned long long m2 = 0ull, tmp = km;
             while (allow-- > 0) { const unsigned long long low = tmp & (~tmp + 1ull); m2 |= low; tmp ^= low; }
             km = m2;
             cntk = __popcll(km);
         }
-        if ((km >> lane) & 1ull) {
+        if (wave == 0 && ((km >> lane) & 1ull)) {
             const int pos = kept + __popcll(km & ((1ull << lane) - 1ull));
-            const size_t s = (size_t)b * w.ns + row;
+            kx1[pos] = x1; ky1[pos] = y1; kx2[pos] = x2; ky2[pos] = y2; kar[pos] = ai;
+            const size_t s = (size_t)b * w.ns + i;
             float* o = out_dets + ((size_t)b * max_det + pos) * 6;
             o[0] = w.sbox[s * 4 + 0]; o[1] = w.sbox[s * 4 + 1]; o[2] = w.sbox[s * 4 + 2]; o[3] = w.sbox[s * 4 + 3];
             o[4] = w.sscore[s]; o[5] = (float)w.scls[s];
             out_idx[(size_t)b * max_det + pos] = w.sanchor[s];
-            if (pos < NMS_MAXDET_CAP) w.keep_pos[(size_t)b * NMS_MAXDET_CAP + pos] = row;
+            w.keep_pos[(size_t)b * NMS_MAXDET_CAP + pos] = i;
         }
         kept += cntk;
-        if (kept >= max_det) break;
-        // fold the kept rows into the removed bitmap of the later 64-blocks
-        for (int w0 = wi + 1; w0 < nw; w0 += 64) {
-            const int ww = w0 + lane;
-            unsigned long long acc = 0ull, tmp = km;
-            const unsigned long long* col = mb + (size_t)(wi * 64) * w.nw + (ww < nw ? ww : 0);
-            while (tmp) {  // up to four independent row loads in flight per step
-                int tt[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    tt[q] = tmp ? __ffsll((long long)tmp) - 1 : -1;
-                    if (tmp) tmp &= tmp - 1ull;
-                }
-                unsigned long long v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (tt[q] >= 0 && ww < nw) ? col[(size_t)tt[q] * w.nw] : 0ull;
-                acc |= (v[0] | v[1]) | (v[2] | v[3]);
-            }
-            if (ww < nw) rem[ww] |= acc;
-        }
         __syncthreads();
     }
-    if (lane == 0) out_counts[b] = kept < max_det ? kept : max_det;
+    if (threadIdx.x == 0) out_counts[b] = kept < max_det ? kept : max_det;
 }
 
 extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A, float conf_thres, float iou_thres,
@@ -322,15 +302,13 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A,
     const int multi = (multi_label && nc > 1) ? 1 : 0;
     NmsWs w = nms_layout(workspace, B, nc, A, multi, max_nms);
     if (workspace_bytes < w.total) return YMK_E_WORKSPACE;
-    if ((size_t)w.nw * 8 > 60 * 1024 || w.nw > 65535) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, w);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, w, status);
     hipLaunchKernelGGL(nms_emit_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, w);
     hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(64, B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), (size_t)w.nw * 8, s, w, max_det, out_dets, out_counts,
-                       out_idx);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det,
+                       out_dets, out_counts, out_idx);
     return ymk_launch_status();
 }
 

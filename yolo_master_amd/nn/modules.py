@@ -158,8 +158,8 @@ class Conv(YmkModule):
         if dw:
             return {"dw": True, "w": ops.pack_dw_weight(w, dtype), "b": b.contiguous(), "k": k, "s": s}
         if self.conv.in_channels <= 4:  # stem: fp32 [Cout][k*k*Cin], reads the NCHW input directly
-            return {"stem": True, "w": w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), "b": b.contiguous(),
-                    "k": k, "s": s}
+            wk = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+            return {"stem": True, "w": wk, "wt": wk.t().contiguous(), "b": b.contiguous(), "k": k, "s": s}
         return {"dw": False, "w": ops.pack_conv_weight(w, dtype), "b": b.contiguous(), "k": k, "s": s}
 
     # -- execution -------------------------------------------------------------------
@@ -174,7 +174,8 @@ class Conv(YmkModule):
 
     def _run_stem(self, x_nchw, out=None):
         pk = self._packed(x_nchw.device)
-        return ops.conv2d_stem(x_nchw, pk["w"], pk["b"], pk["k"], pk["s"], _is_silu(self.act), self.ymk_dtype, out=out)
+        return ops.conv2d_stem(x_nchw, pk["w"], pk["b"], pk["k"], pk["s"], _is_silu(self.act), self.ymk_dtype, out=out,
+                               wt=pk["wt"])
 
     def forward(self, x):
         if self.training:

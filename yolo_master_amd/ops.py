@@ -145,7 +145,7 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual
     return out
 
 
-def conv2d_stem(x_nchw, w, bias, k: int, stride: int, act: bool, dtype: torch.dtype, out=None):
+def conv2d_stem(x_nchw, w, bias, k: int, stride: int, act: bool, dtype: torch.dtype, out=None, wt=None):
     _need_gpu(x_nchw)
     x_nchw = x_nchw.contiguous().float()
     B, Cin, H, W = x_nchw.shape
@@ -155,7 +155,7 @@ def conv2d_stem(x_nchw, w, bias, k: int, stride: int, act: bool, dtype: torch.dt
     if out is None:
         out = new_act(B, Ho, Wo, Cout, dtype, x_nchw.device)
     ldy = _nhwc(out)[4]
-    check(lib.ymk_conv2d_stem_nchw(_p(x_nchw), _p(w), _p(bias), _p(out), DT[out.dtype], B, Cin, H, W, Cout, k, stride,
+    check(lib.ymk_conv2d_stem_nchw(_p(x_nchw), _p(w), _p(wt), _p(bias), _p(out), DT[out.dtype], B, Cin, H, W, Cout, k, stride,
                                    ldy, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "conv2d_stem_nchw")
     return out
 

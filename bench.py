@@ -142,7 +142,7 @@ def main():
         # roofline leg: per-launch HIP events around the dominant kernel family, eager launches on this stream
         roof = None
         if rank == 0:
-            tag = a.roofline_kernel or ops.conv_kernel_tag(dtype, 128, 3)
+            tag = a.roofline_kernel or ops.conv_kernel_tag(dtype, 128, 1)
             ops.TIMER.start(tag)
             for _ in range(3):
                 step()

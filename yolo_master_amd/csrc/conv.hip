@@ -10,6 +10,8 @@ struct ConvArgs {
     const void* res;
     void* y;
     int B, H, W, Ho, Wo, Cin, Cout, stride, ldx, ldy, ldr, Kpad, act, out_f32;
+    int ablate; // tools/micro ablation switch (always 0 in the library build)
+    int ncot;   // cout tiles (fast block index: workgroups sharing a pixel tile run back to back => L2 reuse)
     int64_t M;  // B*Ho*Wo
 };
 
@@ -23,23 +25,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     using G = IGemm<T, BCO, BPX, WCO, WPX, KS>;
     __shared__ u32x4 smem[G::SMEM_U4];
     const int t = threadIdx.x;
-    const int64_t px0 = (int64_t)blockIdx.x * BPX;
-    const int co0 = blockIdx.y * BCO;
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t px0 = (int64_t)(lid / a.ncot) * BPX;
+    const int co0 = (int)(lid % a.ncot) * BCO;
     const int pad = KS / 2;
 
     typename G::Rows rows;
-    const int HoWo = a.Ho * a.Wo;
+    const unsigned HoWo = (unsigned)(a.Ho * a.Wo);
 #pragma unroll
     for (int i = 0; i < G::NB; ++i) {
         const int64_t m = px0 + (t >> 3) + i * G::RPP;
         rows.ok[i] = m < a.M;
-        const int64_t mm = rows.ok[i] ? m : 0;
-        const int b = (int)(mm / HoWo);
-        const int rem = (int)(mm - (int64_t)b * HoWo);
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        rows.pix[i] = b * a.H * a.W;
-        rows.iy0[i] = oy * a.stride - pad;
-        rows.ix0[i] = ox * a.stride - pad;
+        const unsigned mm = rows.ok[i] ? (unsigned)m : 0u;  // M < 2^31 (checked on the host)
+        if (KS == 1 && a.stride == 1) {                       // output pixel == input pixel: no index math
+            rows.pix[i] = (int)mm; rows.iy0[i] = 0; rows.ix0[i] = 0;
+        } else {
+            const unsigned b = mm / HoWo;
+            const unsigned rem = mm - b * HoWo;
+            const unsigned oy = rem / (unsigned)a.Wo, ox = rem - oy * (unsigned)a.Wo;
+            if (KS == 1) {
+                rows.pix[i] = (int)(b * (unsigned)(a.H * a.W) + oy * a.stride * (unsigned)a.W + ox * a.stride);
+                rows.iy0[i] = 0; rows.ix0[i] = 0;
+            } else {
+                rows.pix[i] = (int)(b * (unsigned)(a.H * a.W));
+                rows.iy0[i] = (int)oy * a.stride - pad;
+                rows.ix0[i] = (int)ox * a.stride - pad;
+            }
+        }
     }
 
     f32x4 acc[G::TM][G::TN];
@@ -50,7 +62,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     const T* wt = reinterpret_cast<const T*>(a.w) + (size_t)co0 * a.Kpad;
     G::run(acc, reinterpret_cast<const T*>(a.x), a.ldx, a.H, a.W, a.Cin, rows, wt, a.Kpad,
-           a.Cout - co0, smem);
+           a.Cout - co0, smem, a.ablate);
 
     // epilogue: bias + act in registers, then LDS-staged coalesced store (+ residual)
     const int lane = t & 63, wave = t >> 6;
@@ -71,6 +83,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int64_t m = px0 + px;
         const int co = co0 + co_l;
         if (m >= a.M || co >= a.Cout) return;
+#ifdef YMK_ABLATE
+        if (a.ablate == 2 && v.x != 12345.f) return;
+#endif
         float v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
         if (a.res) {
             float r0, r1, r2, r3;
@@ -85,11 +100,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     G::epilogue(smem, val, emit);
 }
 
+#ifdef YMK_ABLATE
+static int ymk_ablate = 0;
+#endif
+
 template <typename T, int KS>
-static int launch_conv(const ConvArgs& a, hipStream_t s) {
+static int launch_conv(ConvArgs a, hipStream_t s) {
     dim3 blk(256);
+    a.ncot = 1;
+    a.ablate = 0;
+#ifdef YMK_ABLATE
+    a.ablate = ymk_ablate;
+#endif
     if (a.Cout > 64) {
-        dim3 grid((unsigned)ceil_div64(a.M, 128), (a.Cout + 127) / 128);
+        a.ncot = (a.Cout + 127) / 128;
+        dim3 grid((unsigned)(ceil_div64(a.M, 128) * a.ncot));
         hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, KS>), grid, blk, 0, s, a);
     } else if (a.Cout > 32) {
         dim3 grid((unsigned)ceil_div64(a.M, 256), 1);
@@ -126,6 +151,7 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     a.out_f32 = (d->out_dtype == YMK_F32 && d->dtype != YMK_F32) ? 1 : 0;
     a.M = (int64_t)d->B * a.Ho * a.Wo;
     if (a.M <= 0) return YMK_OK;
+    if (a.M >= (1ll << 31) || (int64_t)d->B * d->H * d->W >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == YMK_F32)
         return d->ksize == 1 ? launch_conv<float, 1>(a, s) : launch_conv<float, 3>(a, s);

@@ -233,8 +233,10 @@ __global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
     using G = IGemm<T, BCO, BPX, WCO, WPX, 1>;
     __shared__ u32x4 smem[G::SMEM_U4];
     const int t = threadIdx.x;
-    const int b = blockIdx.x / a.tiles, tile = blockIdx.x % a.tiles;
-    const int co0 = blockIdx.y * BCO;
+    const int ncot = (a.Cout + BCO - 1) / BCO;  // cout tile = fast block index (L2 reuse of the pixel tile)
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = (lid / ncot) / a.tiles, tile = (lid / ncot) % a.tiles;
+    const int co0 = (int)(lid % ncot) * BCO;
     const int m0 = tile * BPX;
 
     typename G::Rows rows;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
     for (int i = 0; i < G::NB; ++i) {
         const int m = m0 + (t >> 3) + i * G::RPP;
         rows.ok[i] = m < a.HW;
-        rows.pix[i] = 0; rows.iy0[i] = 0; rows.ix0[i] = rows.ok[i] ? m : 0;
+        rows.pix[i] = rows.ok[i] ? m : 0; rows.iy0[i] = 0; rows.ix0[i] = 0;  // KS==1: pix = input pixel index
     }
     const int lane = t & 63, wave = t >> 6;
     const int wco = wave / WPX;
@@ -312,7 +314,7 @@ static int launch_pw(MoePwArgs a, hipStream_t s) {
     dim3 blk(256);
     if (a.Cout > 64) {
         a.tiles = (a.HW + 127) / 128;
-        dim3 grid(a.B * a.tiles, (a.Cout + 127) / 128);
+        dim3 grid(a.B * a.tiles * ((a.Cout + 127) / 128));
         hipLaunchKernelGGL((moe_pw_kernel<T, 128, 128, 2, 2>), grid, blk, 0, s, a);
     } else if (a.Cout > 32) {
         a.tiles = (a.HW + 255) / 256;

@@ -36,6 +36,15 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// XCD-aware workgroup order: the dispatcher places workgroup b on XCD b % 8 (each XCD has a private L2), so
+// consecutive *logical* tiles are made to run on the same XCD, back to back: tiles that share a pixel tile
+// (several cout tiles) or convolution halo rows then hit in that XCD's L2.  Bijective for any grid size.
+// Speed only — results never depend on placement.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 template <typename T, int BCO, int BPX, int WCO, int WPX, int KS>
 struct IGemm {
     static constexpr int NT = 256;
@@ -48,18 +57,22 @@ struct IGemm {
     static constexpr int TM = BCO / WCO / 16;
     static constexpr int TN = BPX / WPX / 16;
     static constexpr int STAGE = (BCO + BPX) * CH;  // u32x4 per stage
-    // epilogue tile (fp32, padded rows) must fit in the two pipeline stages
+    // One LDS stage + one register stage (the next k-step's tile lives in VGPRs while this one is
+    // multiplied): half the LDS of a double buffer => twice the resident workgroups per CU, which is what
+    // hides HBM latency for these short-K, bandwidth-bound GEMMs.
+    static constexpr int NSTAGE = 1;
+    // epilogue tile (fp32, XOR-swizzled 16-byte chunks, no padding) must fit in the pipeline buffer
     static constexpr int ECO = BCO > 64 ? 64 : BCO;
     static constexpr int EPX = ECO >= 64 ? 128 : BPX;
-    static constexpr int ELD = ECO + 4;  // floats per staged pixel row
-    static constexpr int SMEM_U4 = 2 * STAGE;
+    static constexpr int ELD = ECO;  // floats per staged pixel row
+    static constexpr int SMEM_U4 = NSTAGE * STAGE;
     static_assert(WCO * WPX == 4, "4 waves");
     static_assert(BCO % (WCO * 16) == 0 && BPX % (WPX * 16) == 0 && BPX % RPP == 0, "tile");
     static_assert(EPX * ELD * 4 <= SMEM_U4 * 16, "epilogue tile must fit in the pipeline buffers");
     static_assert(BPX % EPX == 0 && BCO % ECO == 0, "epilogue passes");
 
     struct Rows {     // per-thread description of the NB pixel rows this thread stages
-        int pix[NB];  // pixel index of (b, 0, 0) i.e. b*H*W
+        int pix[NB];  // KS>1: pixel index of (b, 0, 0) i.e. b*H*W;  KS==1: the input pixel index itself
         int iy0[NB], ix0[NB];
         bool ok[NB];
     };
@@ -71,7 +84,10 @@ struct IGemm {
     __device__ static __forceinline__ void run(f32x4 (&acc)[TM][TN], const T* __restrict__ x, int ldx,
                                                int H, int W, int Cin, const Rows& rows,
                                                const T* __restrict__ wt, int Kpad, int co_valid,
-                                               u32x4* smem) {
+                                               u32x4* smem, int ablate = 0) {
+#ifndef YMK_ABLATE
+        ablate = 0;  // ablation switches exist only in the tools/micro harness build
+#endif
         const int t = threadIdx.x;
         const int lane = t & 63, wave = t >> 6;
         const int wco = wave / WPX, wpx = wave % WPX;
@@ -80,31 +96,45 @@ struct IGemm {
 
         u32x4 ra[NA], rb[NB];
         int tap = 0, c = cq * VEC;  // (tap, channel) of this thread's chunk at k-step 0
-        while (c >= Cin) { c -= Cin; ++tap; }
+        if constexpr (KS != 1)
+            while (c >= Cin) { c -= Cin; ++tap; }
 
         auto gload = [&](int kt) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int r = srow + i * RPP;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (r < BCO && r < co_valid)
+                if (r < BCO && r < co_valid && ablate != 4)
                     v = *reinterpret_cast<const u32x4*>(wt + (size_t)r * Kpad + kt * BK + cq * VEC);
                 ra[i] = v;
             }
-            const bool kin = tap < KS * KS;
-            const int ky = tap / KS, kx = tap - ky * KS;
+            if constexpr (KS == 1) {
+                // 1x1: the caller guarantees iy0/ix0 are in range (pad 0); rows.pix holds the input pixel index
+                const bool kin = c < Cin;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                const int iy = rows.iy0[i] + ky, ix = rows.ix0[i] + kx;
-                if (rows.ok[i] && kin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                    const int64_t p = (int64_t)rows.pix[i] + (int64_t)iy * W + ix;
-                    v = *reinterpret_cast<const u32x4*>(x + p * ldx + c);
+                for (int i = 0; i < NB; ++i) {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (rows.ok[i] && kin && ablate != 3)
+                        v = *reinterpret_cast<const u32x4*>(x + (int64_t)rows.pix[i] * ldx + c);
+                    rb[i] = v;
                 }
-                rb[i] = v;
+                c += BK;
+            } else {
+                const bool kin = tap < KS * KS;
+                const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    const int iy = rows.iy0[i] + ky, ix = rows.ix0[i] + kx;
+                    if (rows.ok[i] && kin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ablate != 3) {
+                        const int64_t p = (int64_t)rows.pix[i] + (int64_t)iy * W + ix;
+                        v = *reinterpret_cast<const u32x4*>(x + p * ldx + c);
+                    }
+                    rb[i] = v;
+                }
+                c += BK;
+                while (c >= Cin) { c -= Cin; ++tap; }
             }
-            c += BK;
-            while (c >= Cin) { c -= Cin; ++tap; }
         };
         auto sstore = [&](int buf) {
             u32x4* sA = smem + buf * STAGE;
@@ -149,10 +179,19 @@ struct IGemm {
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = (kt + 1) < nk;
-            if (more) gload(kt + 1);
-            compute(kt & 1);
-            if (more) sstore((kt + 1) & 1);
-            __syncthreads();
+            if (more) gload(kt + 1);  // next tile in flight (registers) while this one is multiplied
+            if (NSTAGE == 2) {
+                compute(kt & 1);
+                if (more) sstore((kt + 1) & 1);
+                __syncthreads();
+            } else {
+                if (ablate != 1) compute(0);
+                __syncthreads();  // every wave is done reading the stage
+                if (more) {
+                    sstore(0);
+                    __syncthreads();
+                }
+            }
         }
     }
 
@@ -182,14 +221,14 @@ struct IGemm {
                             const int px = wpx * WPX_SPAN + j * 16 + (lane & 15) - px_lo;
                             f32x4 v;
                             v.x = val(i, j, 0); v.y = val(i, j, 1); v.z = val(i, j, 2); v.w = val(i, j, 3);
-                            *reinterpret_cast<f32x4*>(ep + px * ELD + col) = v;
+                            *reinterpret_cast<f32x4*>(ep + px * ELD + (((col >> 2) ^ (px & (ECO / 4 - 1))) << 2)) = v;
                         }
                 }
                 __syncthreads();
                 constexpr int CPR = ECO / 4;  // 16-byte fp32 chunks per staged pixel row
                 for (int idx = t; idx < EPX * CPR; idx += NT) {
                     const int px = idx / CPR, ch = idx - px * CPR;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ep + px * ELD + ch * 4);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ep + px * ELD + ((ch ^ (px & (CPR - 1))) << 2));
                     emit(px_lo + px, co_lo + ch * 4, v);
                 }
                 __syncthreads();

@@ -16,21 +16,21 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
     return __uint_as_float(((uint32_t)h) << 16);
 }
-// round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16 cast)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16: gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN quieted: the same rule as torch's
+// float->bfloat16 cast), one instruction per two values.
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const hw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // SiLU exactly as x * sigmoid(x) with sigmoid = 1/(1+exp(-x)) (torch CPU formula)
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// fast form for bf16 outputs: v_exp_f32 + v_rcp_f32 (~1 ulp), 5 instructions instead of an IEEE division
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
 
 template <typename T>

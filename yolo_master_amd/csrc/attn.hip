@@ -49,8 +49,12 @@ __global__ __launch_bounds__(256) void area_attn_kernel(const T* __restrict__ qk
         const int kc32 = (kc + 31) & ~31;  // processed keys (zero padded)
         __syncthreads();                   // previous chunk fully consumed
         // stage K (row-major [key][32]) and V (transposed [d][key])
-        constexpr int CPR = 32 / VEC;  // 16-byte chunks per row
-        for (int i = t; i < kc32 * CPR; i += 256) {
+        constexpr int CPR = 32 / VEC;              // 16-byte chunks per row
+        constexpr int NL = AT_KC * CPR / 256;     // staged chunks per thread (K and V each)
+        u32x4 kreg[NL], vreg[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {            // all loads first (independent, in flight together)
+            const int i = t + l * 256;
             const int key = i / CPR, ch = i % CPR;
             u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
             if (key < kc) {
@@ -58,10 +62,18 @@ __global__ __launch_bounds__(256) void area_attn_kernel(const T* __restrict__ qk
                 kv = *reinterpret_cast<const u32x4*>(p + Cq);
                 vv = *reinterpret_cast<const u32x4*>(p + 2 * Cq);
             }
-            *reinterpret_cast<u32x4*>(&sK[key * 32 + ch * VEC]) = kv;
-            const T* ve = reinterpret_cast<const T*>(&vv);
+            kreg[l] = kv; vreg[l] = vv;
+        }
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) sVt[(ch * VEC + q) * VPAD + key] = ve[q];
+        for (int l = 0; l < NL; ++l) {
+            const int i = t + l * 256;
+            const int key = i / CPR, ch = i % CPR;
+            if (key < kc32) {
+                *reinterpret_cast<u32x4*>(&sK[key * 32 + ch * VEC]) = kreg[l];
+                const T* ve = reinterpret_cast<const T*>(&vreg[l]);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) sVt[(ch * VEC + q) * VPAD + key] = ve[q];
+            }
         }
         __syncthreads();
         if (!wave_on) continue;

@@ -1,8 +1,8 @@
 // Depthwise k x k convolution, NHWC, stride 1, pad k/2 — LDS-tiled sliding-window stencil.
 //
-// Workgroup = 16 x 32 output pixels x CB channels (CB = 64 bytes of channels: 32 bf16 / 16 fp32).
+// Workgroup = 16 x 32 output pixels x 16 channels.
 // The (16+k-1) x (32+k-1) input halo is staged once in LDS with coalesced 16-byte loads (pixel stride
-// padded to 72/80 bytes so the four x-strips of a wave land on disjoint bank groups), the k*k filter
+// padded to 40 (bf16) / 80 (fp32) bytes so the four x-strips of a wave land on disjoint bank groups), the k*k filter
 // taps of the channel block are staged as fp32.  Each thread owns 4 channels x 8 consecutive output
 // pixels of a row: per filter row it streams 8+k-1 LDS vectors once and keeps the k taps in registers,
 // accumulating with packed fp32 FMAs (v_pk_fma_f32 on two channel pairs).  HBM-bound by design (the
@@ -22,8 +22,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T>
 struct DwTile {
-    static constexpr int CB = 64 / (int)sizeof(T);           // channels per workgroup
-    static constexpr int PSB = 64 + (sizeof(T) == 2 ? 8 : 16);  // padded pixel stride in LDS (bytes)
+    static constexpr int CB = 16;                             // channels per workgroup
+    static constexpr int CPP = CB * (int)sizeof(T) / 16;      // 16-byte chunks per staged pixel (2 bf16 / 4 fp32)
+    static constexpr int PSB = CB * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16);  // padded LDS pixel stride (bytes)
     static constexpr int NCG = CB / 4;                        // 4-channel groups
     static constexpr int ROWL = 256 / (NCG * (DW_TW / DW_R)); // row lanes
     static constexpr int RPT = DW_TH / ROWL;                  // rows per thread
@@ -32,13 +33,27 @@ struct DwTile {
     }
 };
 
+// lds_ld4 returns channels as two register pairs: fp32 (c0,c1),(c2,c3); bf16 (c0,c2),(c1,c3).
+template <typename T> struct DwPair;  // position of channel j (0..3) inside the (a.x, a.y, b.x, b.y) quadruple
+template <> struct DwPair<float> { static constexpr int pos[4] = {0, 1, 2, 3}; };
+template <> struct DwPair<bf16_t> { static constexpr int pos[4] = {0, 2, 1, 3}; };
 __device__ __forceinline__ void lds_ld4(const char* p, f32x2& a, f32x2& b, float) {
     const f32x4 t = *reinterpret_cast<const f32x4*>(p);
     a = f32x2{t.x, t.y}; b = f32x2{t.z, t.w};
 }
+// bf16: the two packed words (c0,c1),(c2,c3) are widened with VECTOR shifts/masks so that the results land in
+// register pairs directly: a = (c0, c2), b = (c1, c3) (channel pairing differs from fp32: see DW_PAIR)
 __device__ __forceinline__ void lds_ld4(const char* p, f32x2& a, f32x2& b, bf16_t) {
     const u32x2 t = *reinterpret_cast<const u32x2*>(p);
-    a = f32x2{bf16lo(t.x), bf16hi(t.x)}; b = f32x2{bf16lo(t.y), bf16hi(t.y)};
+    a = __builtin_bit_cast(f32x2, t << 16);
+    b = __builtin_bit_cast(f32x2, t & 0xffff0000u);
+}
+
+// consecutive logical tiles (the channel blocks of one pixel tile, then the neighbouring pixel tile) run on the
+// same XCD back to back, so the 128-byte lines shared by channel blocks / halos hit in that XCD's L2
+__device__ __forceinline__ unsigned xcd_remap_dw(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
 struct DwEpi {  // epilogue description shared by the plain and the ES-MoE launchers
@@ -63,21 +78,36 @@ __device__ __forceinline__ void dw_tile(const T* __restrict__ xb, int H, int W, 
     const int c0 = cb * D::CB, ty0 = ty * DW_TH, tx0 = tx * DW_TW;
     float* wsm = reinterpret_cast<float*>(smem + (size_t)HT * WT * D::PSB);
 
-    // ---- stage the halo tile (coalesced: 4 lanes x 16 B per pixel) and the filter block
-    for (int i = t; i < HT * WT * 4; i += 256) {
-        const int pix = i >> 2, q = i & 3;
+    // ---- stage the halo tile (coalesced: 4 lanes x 16 B per pixel) and the filter block.
+    // All global loads of a thread are issued back to back into registers BEFORE the first LDS write:
+    // a load->write->load chain would serialise ~15 HBM/L2 round trips per workgroup.
+    constexpr int CPP = D::CPP;
+    constexpr int NL = (HT * WT * CPP + 255) / 256;
+    u32x4 stg[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int i = t + l * 256;
+        const int pix = i / CPP, q = i % CPP;
         const int hy = pix / WT, hx = pix - hy * WT;
         const int iy = ty0 - P + hy, ix = tx0 - P + hx;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + q * VEC < C)
+        if (i < HT * WT * CPP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + q * VEC < C)
             v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * ldx + c0 + q * VEC);
-        u32x2* d = reinterpret_cast<u32x2*>(smem + (size_t)pix * D::PSB + q * 16);
-        d[0] = u32x2{v.x, v.y};
-        d[1] = u32x2{v.z, v.w};
+        stg[l] = v;
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int i = t + l * 256;
+        if (i < HT * WT * CPP) {
+            u32x2* d = reinterpret_cast<u32x2*>(smem + (size_t)(i / CPP) * D::PSB + (i % CPP) * 16);
+            d[0] = u32x2{stg[l].x, stg[l].y};
+            d[1] = u32x2{stg[l].z, stg[l].w};
+        }
     }
     for (int i = t; i < K * K * D::CB; i += 256) {
         const int tap = i / D::CB, c = i - tap * D::CB;
-        wsm[i] = (c0 + c) < C ? to_f32(w[(size_t)tap * C + c0 + c]) : 0.f;
+        // store channel j of each 4-group at its register-quadruple position (see lds_ld4)
+        wsm[tap * D::CB + (c & ~3) + DwPair<T>::pos[c & 3]] = (c0 + c) < C ? to_f32(w[(size_t)tap * C + c0 + c]) : 0.f;
     }
     __syncthreads();
 
@@ -128,7 +158,9 @@ __device__ __forceinline__ void dw_tile(const T* __restrict__ xb, int H, int W, 
             const int gx = tx0 + x0 + r;
             if (gx >= W) break;
             const size_t pix = (size_t)gy * W + gx;
-            float v[4] = {acc[r][0].x + bv[0], acc[r][0].y + bv[1], acc[r][1].x + bv[2], acc[r][1].y + bv[3]};
+            const float q4[4] = {acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y};
+            float v[4] = {q4[DwPair<T>::pos[0]] + bv[0], q4[DwPair<T>::pos[1]] + bv[1], q4[DwPair<T>::pos[2]] + bv[2],
+                          q4[DwPair<T>::pos[3]] + bv[3]};
             if (ep.act == YMK_ACT_SILU) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = PRECISE ? silu_exact(v[q]) : silu_f(v[q]);
@@ -160,8 +192,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
     DwEpi ep{a.bias, a.res, a.ldr, a.act};
     const T* rb = a.res ? reinterpret_cast<const T*>(a.res) + img * a.ldr : nullptr;
     dw_tile<T, K>(reinterpret_cast<const T*>(a.x) + img * a.ldx, a.H, a.W, a.C, a.ldx,
-                  reinterpret_cast<const T*>(a.w), reinterpret_cast<T*>(a.y) + img * a.ldy, a.ldy, blockIdx.x, ep, rb,
-                  smem);
+                  reinterpret_cast<const T*>(a.w), reinterpret_cast<T*>(a.y) + img * a.ldy, a.ldy,
+                  (int)xcd_remap_dw(blockIdx.x, gridDim.x), ep, rb, smem);
 }
 
 template <typename T, int K>
@@ -241,14 +273,15 @@ __global__ __launch_bounds__(256) void moe_dw_kernel(MoeDwArgs a) {
     const T* w = reinterpret_cast<const T*>(a.dw_w) + a.dw_off[e];
     T* ob = reinterpret_cast<T*>(a.out) + (size_t)pair * hw * a.C;
     const DwEpi ep{nullptr, nullptr, 0, YMK_ACT_NONE};
+    const int tile = (int)xcd_remap_dw(blockIdx.x, gridDim.x);
     switch (a.ksizes[e]) {
-        case 3: dw_tile<T, 3>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, blockIdx.x, ep, nullptr, smem); break;
-        case 5: dw_tile<T, 5>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, blockIdx.x, ep, nullptr, smem); break;
-        case 7: dw_tile<T, 7>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, blockIdx.x, ep, nullptr, smem); break;
-        case 9: dw_tile<T, 9>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, blockIdx.x, ep, nullptr, smem); break;
-        case 11: dw_tile<T, 11>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, blockIdx.x, ep, nullptr, smem); break;
-        case 13: dw_tile<T, 13>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, blockIdx.x, ep, nullptr, smem); break;
-        case 15: dw_tile<T, 15>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, blockIdx.x, ep, nullptr, smem); break;
+        case 3: dw_tile<T, 3>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
+        case 5: dw_tile<T, 5>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
+        case 7: dw_tile<T, 7>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
+        case 9: dw_tile<T, 9>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
+        case 11: dw_tile<T, 11>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
+        case 13: dw_tile<T, 13>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
+        case 15: dw_tile<T, 15>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
         default: break;
     }
 }

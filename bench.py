@@ -27,14 +27,38 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
-def cpu_baseline(scale: str, seconds_budget: float = 25.0):
+def pmc_traffic(tag: str):
+    """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_*.json,
+    collected by tools/gpu_profile.sh on the same workload): 2*FETCH_SIZE (gfx950 counts wide coalesced reads at
+    half size, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes.  None when no profile is committed."""
+    import glob
+    import re as _re
+
+    m = _re.match(r"conv_igemm_(bf16|f32)_(\d+)x(\d+)_k(\d)", tag)
+    if not m:
+        return None
+    dt = "unsigned short" if m.group(1) == "bf16" else "float"
+    bco, bpx, k = int(m.group(2)), int(m.group(3)), int(m.group(4))
+    name = f"conv_igemm_kernel<{dt}, {bco}, {bpx}, {'2, 2' if bco == 128 else '1, 4'}, {k}>"
+    files = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_FETCH_SIZE.json")))
+    if not files:
+        return None
+    try:
+        f = json.load(open(files[-1]))["kernels"][name]["FETCH_SIZE"]["mean"]
+        w = json.load(open(files[-1].replace("FETCH_SIZE", "WRITE_SIZE")))["kernels"][name]["WRITE_SIZE"]["mean"]
+        return int((2.0 * f + w) * 1024)
+    except Exception:
+        return None
+
+
+def cpu_baseline(scale: str, seconds_budget: float = 20.0):
     """Oracle (CPU fp32 restatement of the reference path, kind="port") timed on this host's cores on a
     bounded sample of the same workload: forward + NMS on a few 640x640 images."""
     from oracle import model_ref, nms_ref
     from yolo_master_amd.nn.tasks import DetectionModel, yaml_model_load
     from yolo_master_amd.weights import synth_input, synth_state_dict
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)   # more threads than this slows the small convolutions down (oversubscription)
     torch.set_num_threads(cores)
     cfg = yaml_model_load(f"yolo-master-{scale}.yaml")
     sd = synth_state_dict(DetectionModel(cfg).state_dict(), seed=0)
@@ -42,16 +66,13 @@ def cpu_baseline(scale: str, seconds_budget: float = 25.0):
     x = synth_input(B, 640, 640, seed=1)
     times = []
     with torch.inference_mode():
+        model_ref.forward(cfg, sd, x[:1])  # warm-up (thread pool, oneDNN primitive cache)
         t_all = time.time()
-        for it in range(6):
+        while len(times) < 5 and (time.time() - t_all < seconds_budget or len(times) < 1):
             t0 = time.time()
             y, _, _ = model_ref.forward(cfg, sd, x)
             nms_ref.non_max_suppression(y.numpy(), 0.25, 0.7)
-            dt = time.time() - t0
-            if it:  # first pass = warm-up
-                times.append(dt)
-            if time.time() - t_all > seconds_budget and len(times) >= 2:
-                break
+            times.append(time.time() - t0)
     times.sort()
     p50 = times[len(times) // 2]
     return {"value": round(B / p50, 3), "unit": "images/sec", "cores": cores, "kind": "port",
@@ -80,6 +101,8 @@ def main():
 
     rank, local, world = init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    if os.environ.get("YMK_BENCH_SHARE_GPU"):  # functional test of the N>1 flow on a 1-GPU box (gloo, all ranks on cuda:0)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -92,9 +115,12 @@ def main():
     model.set_compute_dtype(dtype)
     x = synth_input(a.batch, a.imgsz, a.imgsz, seed=1 + rank).to(dev)   # resident in HBM before timing
 
-    def step():
+    def local_step():
         y, _ = model._predict_once(x)
-        dets, counts, idx, status = nms_padded(y, 0.25, 0.7, max_det=300)
+        return nms_padded(y, 0.25, 0.7, max_det=300)
+
+    def step():
+        dets, counts, idx, status = local_step()
         if world > 1:
             dets, counts, idx = gather_detections(dets, counts, idx)
         return dets, counts
@@ -145,7 +171,7 @@ def main():
             tag = a.roofline_kernel or ops.conv_kernel_tag(dtype, 128, 1)
             ops.TIMER.start(tag)
             for _ in range(3):
-                step()
+                local_step()  # rank-local: no collective outside the lock-step timed loop
             torch.cuda.synchronize()
             recs = ops.TIMER.records
             ops.TIMER.stop()
@@ -166,6 +192,7 @@ def main():
                 roof.update(kernel=tag, launches_per_step=len(recs) // 3, avg_launch_us=round(ms * 1e3 / len(recs), 2),
                             alg_bytes_per_launch=int(nbytes / len(recs)), alg_gflop_per_launch=round(flops / len(recs) / 1e9, 3),
                             achieved_gbs=round(gbs, 1), achieved_tflops=round(tfl, 2))
+                roof["traffic"] = pmc_traffic(tag)
 
     if rank == 0:
         total_images = world * a.batch * a.steps

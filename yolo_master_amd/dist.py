@@ -32,7 +32,7 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("YMK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -49,7 +49,12 @@ def broadcast_state_dict(module: torch.nn.Module, src: int = 0) -> None:
         by_dtype.setdefault(t.dtype, []).append(t)
     for dt, ts in by_dtype.items():
         flat = torch.cat([t.reshape(-1) for t in ts])
-        dist.broadcast(flat, src=src)
+        if dist.get_backend() == "gloo" and flat.is_cuda:
+            host = flat.cpu()
+            dist.broadcast(host, src=src)
+            flat = host.to(flat.device)
+        else:
+            dist.broadcast(flat, src=src)
         off = 0
         for t in ts:
             n = t.numel()
@@ -68,9 +73,13 @@ def gather_detections(dets: torch.Tensor, counts: torch.Tensor, idx: torch.Tenso
     world = dist.get_world_size()
 
     def ag(t):
-        out = torch.empty((world, *t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]) if t.dim() else out, t.contiguous()) \
-            if dist.get_backend() == "nccl" else dist.all_gather(list(out.unbind(0)), t.contiguous())
-        return out.reshape(world * t.shape[0], *t.shape[1:])
+        if dist.get_backend() == "nccl":  # RCCL: one fused all_gather straight into the output tensor
+            out = torch.empty((world * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t.contiguous())
+            return out
+        src = t.contiguous().cpu()        # gloo (CPU tests / single-GPU functional runs)
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src)
+        return torch.cat(parts, 0).to(t.device)
 
     return ag(dets), ag(counts), (ag(idx) if idx is not None else None)

@@ -149,6 +149,23 @@ int ymk_esmoe_pw(int32_t dtype, const void* dw_out, int32_t B, int32_t H, int32_
                  const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
                  const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
 
+/* Fused expert body: depthwise stage + pointwise grouped GEMM + gate/accumulate + trailing norm in ONE
+ * kernel (same arguments and results as ymk_esmoe_dw followed by ymk_esmoe_pw, without the dw_out buffer:
+ * the stencil result tile stays in LDS as the GEMM operand).  Supported when ymk_dwpw_supported(dtype, C,
+ * kmax) != 0 (C a multiple of 64 bf16 / 32 fp32, kmax <= 9, tile fits 160 KB LDS). */
+int ymk_dwpw_supported(int32_t dtype, int32_t C, int32_t kmax);
+int ymk_esmoe_experts_fused(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                            const void* dw_w, const int32_t* dw_off, const int32_t* ksizes, int32_t kmax,
+                            int32_t Cout, int32_t Kpad, const void* pw_w, const float* pw_b,
+                            const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
+                            const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
+/* DWConv(k x k)+BN(+SiLU) -> Conv(1x1)+BN(+SiLU) pair in one kernel (Detect class branch,
+ * ultralytics/nn/modules/head.py:111-118).  dw_w [k*k][C], dw_bias fp32 [C] or NULL, pw_w [Cout][Kpad]. */
+int ymk_dwconv_pwconv(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                      const void* dw_w, const float* dw_bias, int32_t ksize, int32_t dw_act, int32_t Cout,
+                      int32_t Kpad, const void* pw_w, const float* pw_b, int32_t pw_act, void* y, int32_t ldy,
+                      void* stream);
+
 /* ------------------------------------------------------------------------
  * Area attention core: softmax(q^T k / sqrt(d)) v per (image, area, head)
  * (AAttn.forward block.py:1696-1726).  qkv is the NHWC output of the qkv 1x1

@@ -183,14 +183,16 @@ def test_area_attention_long(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_esmoe_block(dtype):
+@pytest.mark.parametrize("fused,cin", [(True, 64), (False, 64), (True, 128)])
+def test_esmoe_block(dtype, fused, cin):
     from oracle import model_ref
     from yolo_master_amd.nn.modules import ES_MOE
 
-    m = ES_MOE(64, 64)
+    m = ES_MOE(cin, cin)
+    m.fuse_experts = fused   # fused depthwise->pointwise kernel vs the two-kernel (dw_out) form
     sd = module_sd(m)
     # per-image offsets so that images route differently
-    x = rnd(6, 64, 14, 18, seed=12) + rnd(6, 64, 1, 1, seed=13, scale=1.5)
+    x = rnd(6, cin, 14, 18, seed=12) + rnd(6, cin, 1, 1, seed=13, scale=1.5)
     info = {}
     with torch.inference_mode():
         ref = model_ref.es_moe(sd, "model.0", _prep(x, dtype), info=info)
@@ -239,6 +241,7 @@ def test_detect_head(dtype):
 
     Detect.legacy = False
     m = Detect(80, 16, False, [64, 128, 128])
+    m.fuse_dwpw = True   # exercise the fused DW->1x1 kernel where the shape allows (C=64 level), two kernels elsewhere
     m.stride = torch.tensor([8.0, 16.0, 32.0])
     sd = module_sd(m)
     feats = [rnd(2, 64, 16, 20, seed=1), rnd(2, 128, 8, 10, seed=2), rnd(2, 128, 4, 5, seed=3)]

@@ -51,6 +51,11 @@ SYMBOLS = {
     "ymk_esmoe_dw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ymk_esmoe_pw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
                                _vp, _i32, _vp]),
+    "ymk_dwpw_supported": (C.c_int, [_i32, _i32, _i32]),
+    "ymk_esmoe_experts_fused": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
+                                          _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "ymk_dwconv_pwconv": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
+                                    _i32, _vp, _i32, _vp]),
     "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_upsample2x": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_copy_channels": (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),

@@ -19,7 +19,7 @@ LIB = HERE / "libymk.so"
 ARCH = "gfx950"
 # files whose arithmetic must not be contracted into FMAs (bit-exact NMS / decode)
 NO_CONTRACT = {"nms.hip", "elementwise.hip"}
-SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "esmoe.hip", "attn.hip", "elementwise.hip", "nms.hip"]
+SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "esmoe.hip", "dwpw.hip", "attn.hip", "elementwise.hip", "nms.hip"]
 HEADERS = ["ymk_common.h", "igemm.h", "../../include/ymk.h"]
 
 

@@ -483,9 +483,17 @@ class Detect(YmkModule):
         return {"box": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv2],
                 "cls": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv3]}
 
+    fuse_dwpw = False  # DWConv3x3 -> Conv1x1 pair as one kernel (csrc/dwpw.hip); off: not yet faster than two kernels
+
     def _branch(self, seq, x):
         for m in list(seq)[:-1]:
             if isinstance(m, nn.Sequential):
+                if (self.fuse_dwpw and len(m) == 2 and isinstance(m[0], DWConv) and isinstance(m[1], Conv)
+                        and m[1].conv.kernel_size == (1, 1) and m[1].conv.groups == 1
+                        and ops.dwpw_supported(x.dtype, x.shape[-1], m[0].conv.kernel_size[0])):
+                    d, p = m[0]._packed(x.device), m[1]._packed(x.device)
+                    x = ops.dwconv_pwconv(x, d["w"], d["b"], d["k"], _is_silu(m[0].act), p["w"], p["b"], _is_silu(m[1].act))
+                    continue
                 for mm in m:
                     x = mm._run(x)
             else:
@@ -580,6 +588,10 @@ class ES_MOE(YmkModule):
     trailing BN+SiLU; all in libymk.  Non-finite router input/logits raise ``MoERouterError`` when the
     batch's device flag word is checked (``check_flags``), not through a per-layer host sync.
     """
+
+    # Fused depthwise->pointwise kernel (csrc/dwpw.hip): correct (tests cover it) but measured SLOWER than the two-kernel
+    # form on MI355X round 1 (14.6 vs 10.1 ms/step: 1 workgroup/CU, per-wave weight re-reads) -> off by default.
+    fuse_experts = False
 
     def __init__(self, in_channels, out_channels=None, num_experts=4, reduction=8, top_k=2, use_sparse_inference=True,
                  dynamic_threshold=0.4, max_kernel_size=15, expert_kernel_sizes=None):
@@ -741,8 +753,13 @@ class ES_MOE(YmkModule):
         top_k = self.num_experts if dense else self.top_k
         route_w, gate_w, sel, csr_off, csr_pair = ops.esmoe_route(
             x, pk["w1"], pk["b1"], pk["w2"], pk["b2"], top_k, float(self.dynamic_threshold), self._flags)
-        dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair)
-        y = ops.esmoe_pw(dw, B, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel, gate_w, out=out)
+        if self.fuse_experts and ops.dwpw_supported(x.dtype, C, pk["kmax"]):
+            # depthwise -> pointwise in one kernel: the stencil tile never leaves LDS
+            y = ops.esmoe_experts_fused(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], pk["pw_w"], pk["pw_b"], pk["ns"],
+                                        pk["nt"], top_k, sel, gate_w, out=out)
+        else:
+            dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair)
+            y = ops.esmoe_pw(dw, B, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel, gate_w, out=out)
         # eval-time state the reference keeps (modules.py:706-741): usage = mean routing weight
         usage = route_w.mean(0)
         self.expert_usage_counts = usage

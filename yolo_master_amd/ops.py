@@ -209,6 +209,33 @@ def esmoe_pw(dw_out, B: int, H: int, W: int, pw_w, pw_b, nscale, nshift, top_k: 
     return out
 
 
+def dwpw_supported(dtype, C: int, kmax: int) -> bool:
+    return bool(lib.ymk_dwpw_supported(DT[dtype], C, kmax))
+
+
+def esmoe_experts_fused(x, dw_w, dw_off, ksizes, kmax: int, pw_w, pw_b, nscale, nshift, top_k: int, sel, gate_w, out=None):
+    B, H, W, Cc, ldx = _nhwc(x)
+    E, Cout, Kp = pw_w.shape
+    if out is None:
+        out = new_act(B, H, W, Cout, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    check(lib.ymk_esmoe_experts_fused(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), kmax, Cout, Kp,
+                                      _p(pw_w), _p(pw_b), _p(nscale), _p(nshift), E, top_k, _p(sel), _p(gate_w), _p(out), ldy,
+                                      _stream()), "esmoe_experts_fused")
+    return out
+
+
+def dwconv_pwconv(x, dw_w, dw_b, k: int, dw_act: bool, pw_w, pw_b, pw_act: bool, out=None):
+    B, H, W, Cc, ldx = _nhwc(x)
+    Cout, Kp = pw_w.shape
+    if out is None:
+        out = new_act(B, H, W, Cout, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    check(lib.ymk_dwconv_pwconv(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_b), k, int(dw_act), Cout, Kp, _p(pw_w),
+                                _p(pw_b), int(pw_act), _p(out), ldy, _stream()), "dwconv_pwconv")
+    return out
+
+
 # ----------------------------------------------------------------------------- attention
 def area_attn(qkv, heads: int, area: int, out=None):
     B, H, W, C3, ldq = _nhwc(qkv)

@@ -68,8 +68,16 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
     float* logits = h + hidden;
     const int b = blockIdx.x, t = threadIdx.x;
     for (int c = t; c < C; c += 256) {
+        // fixed-order sum of the per-chunk partials; loads are issued four at a time (independent addresses)
+        const float* pp = part + (size_t)b * nchunk * C + c;
         float s = 0.f;
-        for (int k = 0; k < nchunk; ++k) s += part[((size_t)b * nchunk + k) * C + c];
+        int k = 0;
+        for (; k + 4 <= nchunk; k += 4) {
+            const float v0 = pp[(size_t)k * C], v1 = pp[(size_t)(k + 1) * C], v2 = pp[(size_t)(k + 2) * C],
+                        v3 = pp[(size_t)(k + 3) * C];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < nchunk; ++k) s += pp[(size_t)k * C];
         pooled[c] = s / (float)HW;
     }
     __syncthreads();

@@ -483,6 +483,15 @@ class Detect(YmkModule):
         return {"box": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv2],
                 "cls": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv3]}
 
+    level_streams = False  # levels 1.. on side HIP streams: measured slower (10.8 vs 10.1 ms/step, contention) -> off
+
+    def _side_streams(self, device, n):
+        st = self.__dict__.setdefault("_ymk_streams", {})
+        key = str(device)
+        if key not in st or len(st[key]) < n:
+            st[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return st[key][:n]
+
     fuse_dwpw = False  # DWConv3x3 -> Conv1x1 pair as one kernel (csrc/dwpw.hip); off: not yet faster than two kernels
 
     def _branch(self, seq, x):
@@ -509,15 +518,38 @@ class Detect(YmkModule):
         B = feats[0].shape[0]
         A = sum(f.shape[1] * f.shape[2] for f in feats)
         y = torch.empty((B, 4 + self.nc, A), dtype=torch.float32, device=feats[0].device)
-        raw, a_off = [], 0
-        for i, f in enumerate(feats):
+        raw = [None] * len(feats)
+        offs, a_off = [], 0
+        for f in feats:
+            offs.append(a_off)
+            a_off += f.shape[1] * f.shape[2]
+
+        def level(i, f):
             hb = self._branch(self.cv2[i], f)
             box = ops.conv2d(hb, pk["box"][i][0], pk["box"][i][1], 1, 1, False, out_dtype=torch.float32)
             hc = self._branch(self.cv3[i], f)
             cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)
-            ops.detect_decode(box, cls, y, float(self.stride[i]), a_off, self.reg_max)
-            raw.append((box, cls))
-            a_off += f.shape[1] * f.shape[2]
+            ops.detect_decode(box, cls, y, float(self.stride[i]), offs[i], self.reg_max)
+            raw[i] = (box, cls)
+
+        if self.level_streams and len(feats) > 1:
+            # the pyramid levels are independent chains of small launches: run levels 1.. on side HIP streams so
+            # they overlap the large level-0 kernels (fork/join with events; also valid under hipGraph capture)
+            main = torch.cuda.current_stream()
+            side = self._side_streams(feats[0].device, len(feats) - 1)
+            for i in range(1, len(feats)):
+                side[i - 1].wait_stream(main)
+                with torch.cuda.stream(side[i - 1]):
+                    level(i, feats[i])
+            level(0, feats[0])
+            for st in side:
+                main.wait_stream(st)
+            for i in range(1, len(feats)):  # tensors created on a side stream are consumed on the main one
+                for tns in raw[i]:
+                    tns.record_stream(main)
+        else:
+            for i, f in enumerate(feats):
+                level(i, f)
         return y, raw
 
     def forward(self, x):

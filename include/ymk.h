@@ -78,6 +78,13 @@ typedef struct {
 int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, const float* bias,
                const void* residual /* may be NULL */, void* y, void* stream);
 
+/* 1x1 convolution over the channel concatenation [x1 | x2] without materialising it; with upsample1 != 0 the
+ * first source is a [B][H/2][W/2][C1] map read through a nearest 2x upsample.  Replaces nn.Upsample + Concat
+ * (ultralytics/nn/modules/conv.py:629-641) + the consumer's 1x1 Conv (C2f.cv1, block.py:318) of the neck.
+ * d describes the virtual input (Cin = C1 + C2, ksize 1, stride 1); x1/x2 have pixel strides ldx1/ldx2. */
+int ymk_conv1x1_cat2(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1,
+                     const void* x2, int32_t ldx2, const void* w, const float* bias, void* y, void* stream);
+
 /* Stem convolution reading the NCHW fp32 network input directly (Cin <= 4) and
  * writing NHWC.  Replaces layer 0 `Conv(3, c, 3, 2)` (cfg yolo-master-*.yaml,
  * conv.py:80-89) together with the NCHW->NHWC layout change.

@@ -10,6 +10,8 @@ struct ConvArgs {
     const void* res;
     void* y;
     int B, H, W, Ho, Wo, Cin, Cout, stride, ldx, ldy, ldr, Kpad, act, out_f32;
+    const void* x2;  // second K-source for the concat-fused 1x1 (DUAL kernels), else null
+    int ldx2, C1, up1, H1, W1;  // C1 channels come from x (optionally 2x-nearest-upsampled from H1 x W1), the rest from x2
     int ablate; // tools/micro ablation switch (always 0 in the library build)
     int ncot;   // cout tiles (fast block index: workgroups sharing a pixel tile run back to back => L2 reuse)
     int64_t M;  // B*Ho*Wo
@@ -20,9 +22,9 @@ __device__ __forceinline__ float act_silu(float v) {
     return PRECISE ? silu_exact(v) : silu_f(v);
 }
 
-template <typename T, int BCO, int BPX, int WCO, int WPX, int KS>
+template <typename T, int BCO, int BPX, int WCO, int WPX, int KS, bool DUAL = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-    using G = IGemm<T, BCO, BPX, WCO, WPX, KS>;
+    using G = IGemm<T, BCO, BPX, WCO, WPX, KS, DUAL>;
     __shared__ u32x4 smem[G::SMEM_U4];
     const int t = threadIdx.x;
     const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -37,7 +39,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int64_t m = px0 + (t >> 3) + i * G::RPP;
         rows.ok[i] = m < a.M;
         const unsigned mm = rows.ok[i] ? (unsigned)m : 0u;  // M < 2^31 (checked on the host)
-        if (KS == 1 && a.stride == 1) {                       // output pixel == input pixel: no index math
+        if (DUAL) {  // source 2 is pixel-aligned with the output; source 1 optionally at half resolution
+            rows.pix2[0 + (DUAL ? i : 0)] = (int)mm;
+            rows.iy0[i] = 0; rows.ix0[i] = 0;
+            if (a.up1) {
+                const unsigned b = mm / HoWo, rem = mm - b * HoWo;
+                const unsigned oy = rem / (unsigned)a.Wo, ox = rem - oy * (unsigned)a.Wo;
+                rows.pix[i] = (int)(b * (unsigned)(a.H1 * a.W1) + (oy >> 1) * (unsigned)a.W1 + (ox >> 1));
+            } else {
+                rows.pix[i] = (int)mm;
+            }
+        } else if (KS == 1 && a.stride == 1) {                // output pixel == input pixel: no index math
             rows.pix[i] = (int)mm; rows.iy0[i] = 0; rows.ix0[i] = 0;
         } else {
             const unsigned b = mm / HoWo;
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     const T* wt = reinterpret_cast<const T*>(a.w) + (size_t)co0 * a.Kpad;
     G::run(acc, reinterpret_cast<const T*>(a.x), a.ldx, a.H, a.W, a.Cin, rows, wt, a.Kpad,
-           a.Cout - co0, smem, a.ablate);
+           a.Cout - co0, smem, a.ablate, typename G::Src2{reinterpret_cast<const T*>(a.x2), a.ldx2, a.C1});
 
     // epilogue: bias + act in registers, then LDS-staged coalesced store (+ residual)
     const int lane = t & 63, wave = t >> 6;
@@ -104,6 +116,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 static int ymk_ablate = 0;
 #endif
 
+template <typename T>
+static int launch_conv_dual(ConvArgs a, hipStream_t s) {
+    dim3 blk(256);
+    a.ncot = 1;
+    a.ablate = 0;
+    if (a.Cout > 64) {
+        a.ncot = (a.Cout + 127) / 128;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, 1, true>), dim3((unsigned)(ceil_div64(a.M, 128) * a.ncot)), blk, 0, s, a);
+    } else if (a.Cout > 32) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, 256, 1, 4, 1, true>), dim3((unsigned)ceil_div64(a.M, 256)), blk, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 32, 256, 1, 4, 1, true>), dim3((unsigned)ceil_div64(a.M, 256)), blk, 0, s, a);
+    }
+    return ymk_launch_status();
+}
+
 template <typename T, int KS>
 static int launch_conv(ConvArgs a, hipStream_t s) {
     dim3 blk(256);
@@ -142,6 +170,7 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     if (d->out_dtype != d->dtype && d->out_dtype != YMK_F32) return YMK_E_BADARG;
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+    a.x2 = nullptr; a.ldx2 = 0; a.C1 = 0; a.up1 = 0; a.H1 = 0; a.W1 = 0;
     a.B = d->B; a.H = d->H; a.W = d->W;
     const int pad = d->ksize / 2;
     a.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
@@ -156,6 +185,29 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     if (d->dtype == YMK_F32)
         return d->ksize == 1 ? launch_conv<float, 1>(a, s) : launch_conv<float, 3>(a, s);
     return d->ksize == 1 ? launch_conv<bf16_t, 1>(a, s) : launch_conv<bf16_t, 3>(a, s);
+}
+
+// 1x1 conv over the channel concatenation [x1 (optionally 2x nearest-upsampled) | x2] without materialising it:
+// nn.Upsample + Concat + C2f.cv1 of the neck (yaml head rows 13-15 / 16-18; conv.py:629-641).
+extern "C" int ymk_conv1x1_cat2(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1,
+                                const void* x2, int32_t ldx2, const void* w, const float* bias, void* y, void* stream) {
+    if (!d || !x1 || !x2 || !w || !bias || !y || d->ksize != 1 || d->stride != 1) return YMK_E_BADARG;
+    const int vec = d->dtype == YMK_BF16 ? 8 : 4;
+    if (d->dtype != YMK_F32 && d->dtype != YMK_BF16) return YMK_E_BADARG;
+    if (C1 <= 0 || C1 >= d->Cin || C1 % vec || d->Cin % vec || ldx1 % vec || ldx2 % vec || d->Cout % 4 || d->ldy % 4 ||
+        d->Kpad % 64 || d->Kpad < d->Cin || d->out_dtype != d->dtype)
+        return YMK_E_BADARG;
+    if (upsample1 && ((d->H & 1) || (d->W & 1))) return YMK_E_BADARG;
+    ConvArgs a;
+    a.x = x1; a.w = w; a.bias = bias; a.res = nullptr; a.y = y;
+    a.x2 = x2; a.ldx2 = ldx2; a.C1 = C1; a.up1 = upsample1 ? 1 : 0; a.H1 = d->H / 2; a.W1 = d->W / 2;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W;
+    a.Cin = d->Cin; a.Cout = d->Cout; a.stride = 1;
+    a.ldx = ldx1; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = d->act; a.out_f32 = 0;
+    a.M = (int64_t)d->B * d->H * d->W;
+    if (a.M <= 0) return YMK_OK;
+    if (a.M >= (1ll << 31)) return YMK_E_BADARG;
+    return d->dtype == YMK_F32 ? launch_conv_dual<float>(a, (hipStream_t)stream) : launch_conv_dual<bf16_t>(a, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -45,7 +45,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <typename T, int BCO, int BPX, int WCO, int WPX, int KS>
+// DUAL (1x1 only): the K dimension is the channel concatenation of two NHWC sources (x: channels [0, C1),
+// x2: channels [C1, Cin)), each with its own pixel index per row — this is how Upsample+Concat feeding a 1x1
+// conv is executed without materialising the concatenated tensor.
+template <typename T, int BCO, int BPX, int WCO, int WPX, int KS, bool DUAL = false>
 struct IGemm {
     static constexpr int NT = 256;
     static constexpr int VEC = 16 / (int)sizeof(T);
@@ -74,7 +77,12 @@ struct IGemm {
     struct Rows {     // per-thread description of the NB pixel rows this thread stages
         int pix[NB];  // KS>1: pixel index of (b, 0, 0) i.e. b*H*W;  KS==1: the input pixel index itself
         int iy0[NB], ix0[NB];
+        int pix2[DUAL ? NB : 1];  // DUAL: pixel index in the second source
         bool ok[NB];
+    };
+    struct Src2 {  // second K-source (DUAL)
+        const T* x2;
+        int ldx2, C1;
     };
 
     __device__ static __forceinline__ int swz(int row, int c) { return c ^ (row & 7); }
@@ -84,7 +92,7 @@ struct IGemm {
     __device__ static __forceinline__ void run(f32x4 (&acc)[TM][TN], const T* __restrict__ x, int ldx,
                                                int H, int W, int Cin, const Rows& rows,
                                                const T* __restrict__ wt, int Kpad, int co_valid,
-                                               u32x4* smem, int ablate = 0) {
+                                               u32x4* smem, int ablate = 0, Src2 s2 = Src2{nullptr, 0, 0}) {
 #ifndef YMK_ABLATE
         ablate = 0;  // ablation switches exist only in the tools/micro harness build
 #endif
@@ -114,8 +122,12 @@ struct IGemm {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     u32x4 v = {0u, 0u, 0u, 0u};
-                    if (rows.ok[i] && kin && ablate != 3)
-                        v = *reinterpret_cast<const u32x4*>(x + (int64_t)rows.pix[i] * ldx + c);
+                    if (rows.ok[i] && kin && ablate != 3) {
+                        if (DUAL && c >= s2.C1)
+                            v = *reinterpret_cast<const u32x4*>(s2.x2 + (int64_t)rows.pix2[i] * s2.ldx2 + (c - s2.C1));
+                        else
+                            v = *reinterpret_cast<const u32x4*>(x + (int64_t)rows.pix[i] * ldx + c);
+                    }
                     rb[i] = v;
                 }
                 c += BK;

@@ -166,8 +166,11 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float* __restrict__
 }
 
 // ---- 4. stable descending counting-rank sort ---------------------------------------
+// rank(i) = #{j : key_j > key_i} with the 64-bit key (score bits << 32 | ~index): for the positive scores
+// that pass the confidence filter the IEEE bit pattern is order preserving, and the inverted index in the
+// low word makes the lower candidate index win ties (stable order) with ONE integer compare per pair.
 __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w) {
-    __shared__ float ts[256];
+    __shared__ unsigned long long tk[256];
     const int b = blockIdx.y;
     const int n = w.ncand[b];
     const int i0 = blockIdx.x * 256;
@@ -175,16 +178,15 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w) {
     const int i = i0 + threadIdx.x;
     const float* sc = w.cscore + (size_t)b * w.capc;
     const float si = i < n ? sc[i] : 0.f;
+    const unsigned long long ki = ((unsigned long long)__float_as_uint(si) << 32) | (unsigned)(~i);
     int rank = 0;
     for (int j0 = 0; j0 < n; j0 += 256) {
         __syncthreads();
-        ts[threadIdx.x] = (j0 + threadIdx.x) < n ? sc[j0 + threadIdx.x] : -INFINITY;
+        const int j = j0 + threadIdx.x;
+        tk[threadIdx.x] = j < n ? (((unsigned long long)__float_as_uint(sc[j]) << 32) | (unsigned)(~j)) : 0ull;
         __syncthreads();
-        const int lim = min(256, n - j0);
-        for (int j = 0; j < lim; ++j) {
-            const float sj = ts[j];
-            rank += (sj > si) || (sj == si && (j0 + j) < i);
-        }
+#pragma unroll 8
+        for (int jj = 0; jj < 256; ++jj) rank += tk[jj] > ki;   // padding keys are 0: never greater
     }
     if (i < n && rank < w.ns) {
         const size_t s = (size_t)b * w.capc + i, d = (size_t)b * w.ns + rank;

@@ -207,6 +207,17 @@ class LazyUpsample:
         return ops.upsample2x(self.src, out=out)
 
 
+class VirtualCat:
+    """Channel concatenation that is never materialised: the single consumer (the 1x1 `cv1` of the following
+    C2f/C3k2) reads its K dimension from both sources (ymk_conv1x1_cat2)."""
+
+    def __init__(self, parts):
+        self.parts = parts  # [x1 or LazyUpsample(x1), x2]
+
+    def materialise(self):
+        return Concat(1)._run(self.parts)
+
+
 class Concat(nn.Module):
     """Concatenate along channels (ultralytics/nn/modules/conv.py:616-641)."""
 
@@ -265,10 +276,21 @@ class C2f(YmkModule):
 
     def _run(self, x, out=None):
         # chunk(2)/cat are free: cv1 and every block write their slice of one buffer
-        B, H, W, _ = x.shape
+        if isinstance(x, VirtualCat):
+            p0, p1 = x.parts
+            ref = p1
+            B, H, W = ref.shape[0], ref.shape[1], ref.shape[2]
+        else:
+            ref = x
+            B, H, W, _ = x.shape
         c, n = self.c, len(self.m)
-        cat = ops.new_act(B, H, W, (2 + n) * c, x.dtype, x.device)
-        self.cv1._run(x, out=cat[..., : 2 * c])
+        cat = ops.new_act(B, H, W, (2 + n) * c, ref.dtype, ref.device)
+        if isinstance(x, VirtualCat):
+            pk = self.cv1._packed(ref.device)
+            up = isinstance(p0, LazyUpsample)
+            ops.conv1x1_cat2(p0.src if up else p0, up, p1, pk["w"], pk["b"], _is_silu(self.cv1.act), out=cat[..., : 2 * c])
+        else:
+            self.cv1._run(x, out=cat[..., : 2 * c])
         for i, m in enumerate(self.m):
             m._run(cat[..., (1 + i) * c:(2 + i) * c], out=cat[..., (2 + i) * c:(3 + i) * c])
         return self.cv2._run(cat, out=out)

@@ -21,7 +21,7 @@ import torch.nn as nn
 import yaml
 
 from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DWConv, LazyUpsample,
-                      YmkModule, set_compute_dtype)
+                      VirtualCat, YmkModule, set_compute_dtype)
 
 CFG_DIR = Path(__file__).resolve().parent.parent / "cfg"
 
@@ -166,6 +166,7 @@ class DetectionModel(nn.Module):
                 mod.momentum = 0.03
         self.ymk_dtype = torch.float32
         self._flags = None
+        self.fuse_concat = True  # Upsample+Concat feeding a C2f/C3k2 is read in place by its 1x1 cv1 (no concat buffer)
 
     # the reference finds strides with a 256x256 dry run (tasks.py:547-549); the graph is static, so
     # walk it symbolically instead (no forward pass needed, works without a GPU)
@@ -248,7 +249,12 @@ class DetectionModel(nn.Module):
                     raise NotImplementedError("ymk: nn.Upsample must be nearest x2")
                 cur = LazyUpsample(cur)
             elif isinstance(m, Concat):
-                cur = m._run(cur)
+                nxt = self.model[m.i + 1] if m.i + 1 < len(self.model) else None
+                fusable = (self.fuse_concat and len(cur) == 2 and m.i not in self.save and isinstance(nxt, C2f)
+                           and nxt.f == -1 and nxt.cv1.conv.kernel_size == (1, 1) and m.d == 1
+                           and torch.is_tensor(cur[1])
+                           and (cur[0].src if isinstance(cur[0], LazyUpsample) else cur[0]).shape[-1] % 8 == 0)
+                cur = VirtualCat(cur) if fusable else m._run(cur)
             elif isinstance(m, ES_MOE):
                 m.bind_flags(self._flags)
                 cur = m._run(cur)
@@ -263,7 +269,7 @@ class DetectionModel(nn.Module):
                 cur = m._run(cur)
             ys.append(cur if m.i in self.save else None)
             if taps is not None:
-                taps[m.i] = cur
+                taps[m.i] = cur.materialise() if isinstance(cur, VirtualCat) else cur
         det = self.model[-1]
         preds = {"raw": raw, "feats": None}
         return cur, preds

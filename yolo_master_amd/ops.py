@@ -145,6 +145,29 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual
     return out
 
 
+def conv1x1_cat2(x1, up1: bool, x2, w_packed, bias, act: bool, out=None):
+    """1x1 conv over cat([upsample2x(x1) if up1 else x1, x2], channel) without building the concatenation."""
+    B1, H1, W1, C1, ld1 = _nhwc(x1)
+    B, H, W, C2, ld2 = _nhwc(x2)
+    assert B1 == B and (H1 * (2 if up1 else 1), W1 * (2 if up1 else 1)) == (H, W) and x1.dtype == x2.dtype
+    Cout, Kp = w_packed.shape
+    if out is None:
+        out = new_act(B, H, W, Cout, x2.dtype, x2.device)
+    ldy = _nhwc(out)[4]
+    d = ConvDesc(DT[x2.dtype], DT[out.dtype], B, H, W, C1 + C2, Cout, 1, 1, ld1, ldy, 0, Kp,
+                 _lib.ACT_SILU if act else _lib.ACT_NONE)
+    ev = None
+    if TIMER.tag is not None:
+        es = x2.element_size()
+        nbytes = (B1 * H1 * W1 * C1 + B * H * W * C2 + Cout * (C1 + C2) + B * H * W * Cout) * es
+        ev = TIMER.wrap(conv_kernel_tag(x2.dtype, Cout, 1) + "_cat2", nbytes, 2 * B * H * W * Cout * (C1 + C2))
+    check(lib.ymk_conv1x1_cat2(C.byref(d), _p(x1), C1, ld1, int(up1), _p(x2), ld2, _p(w_packed), _p(bias), _p(out), _stream()),
+          "conv1x1_cat2")
+    if ev is not None:
+        ev.record()
+    return out
+
+
 def conv2d_stem(x_nchw, w, bias, k: int, stride: int, act: bool, dtype: torch.dtype, out=None, wt=None):
     _need_gpu(x_nchw)
     x_nchw = x_nchw.contiguous().float()

@@ -17,6 +17,10 @@ struct ConvArgs {
     int64_t M;  // B*Ho*Wo
 };
 
+static int ymk_use_ws = 1;          // tools/micro can switch the streaming 1x1 kernel off for A/B runs
+static int ymk_ws_min_tiles = 1024;  // smallest pixel-tile count routed to the streaming kernel
+extern "C" void ymk_debug_set_ws(int on) { ymk_use_ws = on; }
+
 template <typename T, bool PRECISE>
 __device__ __forceinline__ float act_silu(float v) {
     return PRECISE ? silu_exact(v) : silu_f(v);
@@ -116,6 +120,151 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 static int ymk_ablate = 0;
 #endif
 
+// ---------------------------------------------------------------------------
+// Weight-stationary streaming 1x1 convolution (large M, K <= 4 x 128 bytes, Cout tile of 128).
+// A persistent workgroup keeps its [128 cout][K] weight tile in LDS for its whole life and walks over pixel
+// tiles; the NEXT tile's activations are already in flight (registers) while the current tile is multiplied and
+// stored, so the HBM latency of a tile is hidden behind the previous tile's MFMA + epilogue instead of being
+// exposed once per tile, and the k-loop has no barriers (both operands are complete in LDS).
+// ---------------------------------------------------------------------------
+template <typename T, int KG>
+__global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * VEC;            // elements per 128-byte K group
+    constexpr int RS = KG * 8;             // u32x4 per staged row
+    constexpr bool PRECISE = sizeof(T) == 4;
+    __shared__ u32x4 sW[128 * RS];
+    __shared__ u32x4 sA[128 * RS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wco = wave >> 1, wpx = wave & 1;
+    const int srow = t >> 3, cq = t & 7;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int ct = blockIdx.x % a.ncot;
+    const int co0 = ct * 128;
+    const int nblk_px = gridDim.x / a.ncot;            // workgroups sharing this cout tile
+    const int64_t ntiles = (a.M + 127) / 128;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* wt = reinterpret_cast<const T*>(a.w) + (size_t)co0 * a.Kpad;
+    auto swz = [](int row, int c) { return (c & ~7) | ((c & 7) ^ (row & 7)); };
+
+    // weights: once per workgroup
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = srow + i * 32;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (co0 + r < a.Cout) v = *reinterpret_cast<const u32x4*>(wt + (size_t)r * a.Kpad + g * BK + cq * VEC);
+            sW[r * RS + swz(r, g * 8 + cq)] = v;
+        }
+    }
+    u32x4 ra[4][KG];
+    auto gload = [&](int64_t tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = tile * 128 + srow + i * 32;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (m < a.M && g * BK + cq * VEC < a.Cin) v = *reinterpret_cast<const u32x4*>(x + m * a.ldx + g * BK + cq * VEC);
+                ra[i][g] = v;
+            }
+        }
+    };
+    f32x4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + (wco * 4 + i) * 16 + fc * 4;
+        bv[i] = co < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool silu = a.act == YMK_ACT_SILU;
+
+    int64_t tile = blockIdx.x / a.ncot;
+    if (tile < ntiles) gload(tile);
+    for (; tile < ntiles; tile += nblk_px) {
+        __syncthreads();  // previous tile's fragment reads are finished (first pass: sW is complete)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + i * 32;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) sA[r * RS + swz(r, g * 8 + cq)] = ra[i][g];
+        }
+        __syncthreads();
+        const int64_t nxt = tile + nblk_px;
+        if (nxt < ntiles) gload(nxt);  // in flight during the MFMA + epilogue below
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 af[4], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = (wco * 4 + i) * 16 + fr;
+                    af[i] = sW[r * RS + swz(r, g * 8 + kk * 4 + fc)];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = (wpx * 4 + j) * 16 + fr;
+                    bfr[j] = sA[r * RS + swz(r, g * 8 + kk * 4 + fc)];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + (wco * 4 + i) * 16 + fc * 4;
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = tile * 128 + (wpx * 4 + j) * 16 + fr;
+                if (m >= a.M) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r] + bv[i][r];
+                    if (silu) v[r] = act_silu<T, PRECISE>(v[r]);
+                }
+                if (a.res) {
+                    float r0, r1, r2, r3;
+                    load4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co, r0, r1, r2, r3);
+                    v[0] = r0 + v[0]; v[1] = r1 + v[1]; v[2] = r2 + v[2]; v[3] = r3 + v[3];
+                }
+                store4(reinterpret_cast<T*>(a.y) + m * a.ldy + co, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <typename T>
+static bool launch_conv1x1_ws(ConvArgs a, hipStream_t s) {
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    const int kg = a.Kpad / BK;
+    const int64_t ntiles = (a.M + 127) / 128;
+    if (a.Kpad % BK || kg < 1 || kg > 4 || a.Cout <= 64 || a.out_f32 || ntiles < (kg <= 2 ? ymk_ws_min_tiles / 2 : ymk_ws_min_tiles)) return false;
+    a.ncot = (a.Cout + 127) / 128;
+    a.ablate = 0;
+    // 2 workgroups per CU when LDS allows (2 * 2 * 128 * kg * 128 B <= 160 KB  <=>  kg <= 2), else 1
+    const int per_cu = kg <= 2 ? 2 : 1;
+    int nblk_px = (256 * per_cu) / a.ncot;
+    if (nblk_px < 1) nblk_px = 1;
+    if (nblk_px > ntiles) nblk_px = (int)ntiles;
+    dim3 grid(nblk_px * a.ncot), blk(256);
+    switch (kg) {
+        case 1: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 1>), grid, blk, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 2>), grid, blk, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 3>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 4>), grid, blk, 0, s, a); break;
+    }
+    return true;
+}
+
 template <typename T>
 static int launch_conv_dual(ConvArgs a, hipStream_t s) {
     dim3 blk(256);
@@ -182,6 +331,10 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     if (a.M <= 0) return YMK_OK;
     if (a.M >= (1ll << 31) || (int64_t)d->B * d->H * d->W >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    if (d->ksize == 1 && d->stride == 1 && ymk_use_ws) {  // large-M short-K 1x1: weight-stationary streaming kernel
+        const bool done = d->dtype == YMK_F32 ? launch_conv1x1_ws<float>(a, s) : launch_conv1x1_ws<bf16_t>(a, s);
+        if (done) return ymk_launch_status();
+    }
     if (d->dtype == YMK_F32)
         return d->ksize == 1 ? launch_conv<float, 1>(a, s) : launch_conv<float, 3>(a, s);
     return d->ksize == 1 ? launch_conv<bf16_t, 1>(a, s) : launch_conv<bf16_t, 3>(a, s);

@@ -27,6 +27,13 @@ CONV_CASES = [
     (2, 16, 16, 192, 80, 1, 1, False, False, 0, 0),   # Cout = 80 (Detect cls tail), K not multiple of 64
     (1, 12, 12, 512, 512, 3, 1, True, True, 0, 0),    # K = 4608
     (2, 9, 9, 48, 32, 1, 1, True, True, 16, 16),
+    # shapes that route to the specialised kernels (see csrc/conv.hip dispatch):
+    (4, 128, 128, 64, 128, 1, 1, True, True, 0, 0),    # weight-stationary streaming 1x1 (512 pixel tiles, 1 K group)
+    (8, 128, 128, 192, 160, 1, 1, True, False, 64, 32),  # streaming 1x1, 3 K groups, 2 cout tiles (ragged), slice views
+    (4, 96, 96, 32, 32, 3, 1, True, True, 0, 0),       # spatial-tile 3x3, Cin 32 -> 32 (LDS im2col), residual
+    (3, 100, 90, 32, 64, 3, 1, True, False, 32, 0),    # spatial-tile 3x3, ragged tiles, Cout 64, input slice view
+    (4, 96, 96, 64, 64, 3, 1, False, True, 0, 64),     # spatial-tile 3x3, Cin 64 (bf16 only; fp32 falls back)
+    (4, 96, 96, 64, 16, 3, 1, True, False, 0, 0),      # spatial-tile 3x3, Cout 16 inside a 32-wide tile
 ]
 
 

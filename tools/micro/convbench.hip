@@ -32,7 +32,7 @@ static float timeit(F&& f, int reps = 20) {
 int main() {
     struct Shape { int B, H, W, Cin, Cout, k, s; } shapes[] = {
         {64, 160, 160, 128, 128, 1, 1}, {64, 80, 80, 256, 256, 1, 1}, {64, 40, 40, 256, 128, 1, 1},
-        {64, 40, 40, 128, 128, 1, 1}, {64, 40, 40, 128, 256, 1, 1}, {64, 20, 20, 256, 256, 1, 1}, {64, 80, 80, 128, 128, 1, 1}};
+        {64, 160, 160, 32, 32, 3, 1}, {64, 80, 80, 64, 64, 3, 1}, {64, 40, 40, 64, 64, 3, 1}, {64, 20, 20, 64, 64, 3, 1}, {64, 80, 80, 32, 32, 3, 1}};
     ymk_ws_min_tiles = 1;
     for (auto sh : shapes) {
         const size_t nin = (size_t)sh.B * sh.H * sh.W * sh.Cin;

@@ -265,6 +265,163 @@ static bool launch_conv1x1_ws(ConvArgs a, hipStream_t s) {
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Spatial-tile 3x3 convolution (stride 1, Cin in {32, 64}, Cout tile 32/64): LDS-staged im2col.
+// A persistent workgroup keeps its [BCO][9*Cin] weight tile in LDS and walks over 16x16-pixel output tiles.
+// The 18x18 input halo of a tile is loaded ONCE (coalesced, zero-filled at the borders) into LDS; the nine taps
+// of the implicit GEMM are then plain LDS reads at shifted pixel addresses (pixel stride padded by 16 bytes so
+// the 16 pixels of a fragment fall on distinct bank groups) — no per-tap global gathers, no per-k-step address
+// and bounds arithmetic, no barriers inside the K loop.  The next tile's halo is prefetched into registers
+// while the current tile is multiplied and stored.
+// ---------------------------------------------------------------------------
+template <typename T, int CIN, int BCO>
+__global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int CPP = CIN / VEC;                      // 16-byte chunks per pixel
+    constexpr int PSB = CIN * (int)sizeof(T) + 16;      // padded pixel stride (bytes)
+    constexpr int HT = 18;
+    constexpr int KTOT = 9 * CIN;
+    constexpr int WRS = KTOT * (int)sizeof(T) + 16;     // padded weight row stride (bytes)
+    constexpr int KSUB = 4 * VEC;                       // channels per MFMA group (64 bytes)
+    constexpr int TM = BCO / 16;
+    constexpr int NL = (HT * HT * CPP + 255) / 256;
+    constexpr bool PRECISE = sizeof(T) == 4;
+    __shared__ __attribute__((aligned(16))) char sIn[HT * HT * PSB];
+    __shared__ __attribute__((aligned(16))) char sW[BCO * WRS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16;
+    const int tpi = tiles_x * tiles_y;
+    const int64_t ntiles = (int64_t)a.B * tpi;
+    const int ct = blockIdx.x % a.ncot;
+    const int co0 = ct * BCO;
+    const int nblk_px = gridDim.x / a.ncot;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* wt = reinterpret_cast<const T*>(a.w) + (size_t)co0 * a.Kpad;
+
+    // weights once: [BCO][9*CIN] (K order (ky,kx,cin) = the packed order)
+    for (int q = t; q < BCO * (KTOT / VEC); q += 256) {
+        const int r = q / (KTOT / VEC), ch = q % (KTOT / VEC);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (co0 + r < a.Cout) v = *reinterpret_cast<const u32x4*>(wt + (size_t)r * a.Kpad + ch * VEC);
+        *reinterpret_cast<u32x4*>(sW + (size_t)r * WRS + ch * 16) = v;
+    }
+    u32x4 stg[NL];
+    auto gload = [&](int64_t tile) {
+        const int b = (int)(tile / tpi), tl = (int)(tile % tpi);
+        const int ty0 = (tl / tiles_x) * 16, tx0 = (tl % tiles_x) * 16;
+        const T* xb = x + (size_t)b * a.H * a.W * a.ldx;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int q = t + l * 256;
+            const int pix = q / CPP, ch = q % CPP;
+            const int hy = pix / HT, hx = pix - hy * HT;
+            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (q < HT * HT * CPP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.ldx + ch * VEC);
+            stg[l] = v;
+        }
+    };
+    f32x4 bv[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int co = co0 + i * 16 + fc * 4;
+        bv[i] = co < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool silu = a.act == YMK_ACT_SILU;
+
+    int64_t tile = blockIdx.x / a.ncot;
+    if (tile < ntiles) gload(tile);
+    for (; tile < ntiles; tile += nblk_px) {
+        __syncthreads();  // previous tile's LDS reads are done (first pass: orders the weight stores)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int q = t + l * 256;
+            if (q < HT * HT * CPP) *reinterpret_cast<u32x4*>(sIn + (size_t)(q / CPP) * PSB + (q % CPP) * 16) = stg[l];
+        }
+        __syncthreads();
+        const int64_t nxt = tile + nblk_px;
+        if (nxt < ntiles) gload(nxt);
+        f32x4 acc[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int cs = 0; cs < CIN / KSUB; ++cs) {
+                u32x4 af[TM], bfr[4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const u32x4*>(sW + (size_t)(i * 16 + fr) * WRS +
+                                                            (tap * CIN + cs * KSUB) * (int)sizeof(T) + fc * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ly = wave * 4 + j;
+                    bfr[j] = *reinterpret_cast<const u32x4*>(sIn + (size_t)((ly + ky) * HT + fr + kx) * PSB +
+                                                             cs * 64 + fc * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+            }
+        }
+        const int b = (int)(tile / tpi), tl = (int)(tile % tpi);
+        const int ty0 = (tl / tiles_x) * 16, tx0 = (tl % tiles_x) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gy = ty0 + wave * 4 + j, gx = tx0 + fr;
+            if (gy >= a.H || gx >= a.W) continue;
+            const int64_t m = ((int64_t)b * a.H + gy) * a.W + gx;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = co0 + i * 16 + fc * 4;
+                if (co >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r] + bv[i][r];
+                    if (silu) v[r] = act_silu<T, PRECISE>(v[r]);
+                }
+                if (a.res) {
+                    float r0, r1, r2, r3;
+                    load4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co, r0, r1, r2, r3);
+                    v[0] = r0 + v[0]; v[1] = r1 + v[1]; v[2] = r2 + v[2]; v[3] = r3 + v[3];
+                }
+                store4(reinterpret_cast<T*>(a.y) + m * a.ldy + co, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <typename T>
+static bool launch_conv3x3_tile(ConvArgs a, hipStream_t s) {
+    if (a.stride != 1 || a.out_f32 || (a.Cin != 32 && a.Cin != 64) || a.Cout > 64 || a.Cout % 16) return false;
+    const int bco = a.Cout <= 32 ? 32 : 64;
+    const int64_t ntiles = (int64_t)a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
+    if (ntiles < 128) return false;
+    a.ncot = 1;
+    a.ablate = 0;
+    const size_t lds = (size_t)18 * 18 * (a.Cin * sizeof(T) + 16) + (size_t)bco * (9 * a.Cin * sizeof(T) + 16);
+    const int per_cu = lds <= 40 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : lds <= 80 * 1024 ? 2 : 1;
+    int64_t nblk = 256 * per_cu;
+    if (nblk > ntiles) nblk = ntiles;
+    dim3 grid((unsigned)nblk), blk(256);
+    if (a.Cin == 32 && bco == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 32, 32>), grid, blk, 0, s, a);
+    else if (a.Cin == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 32, 64>), grid, blk, 0, s, a);
+    else if constexpr (sizeof(T) == 2) {  // Cin = 64 tiles fit the 160 KB LDS only in bf16
+        if (bco == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 64, 32>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_tile_kernel<T, 64, 64>), grid, blk, 0, s, a);
+    } else {
+        return false;
+    }
+    return true;
+}
+
 template <typename T>
 static int launch_conv_dual(ConvArgs a, hipStream_t s) {
     dim3 blk(256);
@@ -333,6 +490,10 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     hipStream_t s = (hipStream_t)stream;
     if (d->ksize == 1 && d->stride == 1 && ymk_use_ws) {  // large-M short-K 1x1: weight-stationary streaming kernel
         const bool done = d->dtype == YMK_F32 ? launch_conv1x1_ws<float>(a, s) : launch_conv1x1_ws<bf16_t>(a, s);
+        if (done) return ymk_launch_status();
+    }
+    if (d->ksize == 3 && ymk_use_ws) {  // small-Cin stride-1 3x3: spatial-tile kernel (LDS-staged im2col)
+        const bool done = d->dtype == YMK_F32 ? launch_conv3x3_tile<float>(a, s) : launch_conv3x3_tile<bf16_t>(a, s);
         if (done) return ymk_launch_status();
     }
     if (d->dtype == YMK_F32)

@@ -11,9 +11,10 @@
 #include "igemm.h"
 
 #define AT_KC 256
+#define AT_NT 256   // threads per workgroup: 4 waves x 16 queries (512 measured ~5% slower on the A2C2f layers)
 
 template <typename T>
-__global__ __launch_bounds__(256) void area_attn_kernel(const T* __restrict__ qkv, int ldq, T* __restrict__ out,
+__global__ __launch_bounds__(AT_NT) void area_attn_kernel(const T* __restrict__ qkv, int ldq, T* __restrict__ out,
                                                        int ldo, int N, int Na, int heads, int area, float scale) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int NF = sizeof(T) == 2 ? 1 : 2;  // 16-byte fragments per 32-wide head row per lane
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void area_attn_kernel(const T* __restrict__ qk
     const int tok0 = ar * Na;  // first token of this area inside the image
     const int Cq = heads * 32;
     const T* base = qkv + (size_t)b * N * ldq;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = blockIdx.x * (AT_NT / 4) + wave * 16;
     const bool wave_on = q0 < Na;
 
     // query fragment(s): B operand, lane (query fi, k-group g)
@@ -50,11 +51,11 @@ __global__ __launch_bounds__(256) void area_attn_kernel(const T* __restrict__ qk
         __syncthreads();                   // previous chunk fully consumed
         // stage K (row-major [key][32]) and V (transposed [d][key])
         constexpr int CPR = 32 / VEC;              // 16-byte chunks per row
-        constexpr int NL = AT_KC * CPR / 256;     // staged chunks per thread (K and V each)
+        constexpr int NL = AT_KC * CPR / AT_NT;   // staged chunks per thread (K and V each)
         u32x4 kreg[NL], vreg[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {            // all loads first (independent, in flight together)
-            const int i = t + l * 256;
+            const int i = t + l * AT_NT;
             const int key = i / CPR, ch = i % CPR;
             u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
             if (key < kc) {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void area_attn_kernel(const T* __restrict__ qk
         }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            const int i = t + l * 256;
+            const int i = t + l * AT_NT;
             const int key = i / CPR, ch = i % CPR;
             if (key < kc32) {
                 *reinterpret_cast<u32x4*>(&sK[key * 32 + ch * VEC]) = kreg[l];
@@ -176,7 +177,7 @@ extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* 
     if (B <= 0 || N <= 0) return YMK_OK;
     const int Na = N / area;
     if ((int64_t)B * area > 65535 || heads > 65535) return YMK_E_BADARG;
-    dim3 grid((Na + 63) / 64, heads, B * area), blk(256);
+    dim3 grid((Na + AT_NT / 4 - 1) / (AT_NT / 4), heads, B * area), blk(AT_NT);
     const float scale = 0.17677669529663687f;  // 32^-0.5
     hipStream_t s = (hipStream_t)stream;
     if (dtype == YMK_F32)

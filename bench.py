@@ -27,26 +27,42 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
-def pmc_traffic(tag: str):
-    """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_*.json,
-    collected by tools/gpu_profile.sh on the same workload): 2*FETCH_SIZE (gfx950 counts wide coalesced reads at
-    half size, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes.  None when no profile is committed."""
+# op family (yolo_master_amd.ops TIMER) -> kernel-name prefix in the rocprofv3 output; single-kernel families only
+FAMILY_KERNEL = {
+    "conv1x1_ws": "conv1x1_ws_kernel<", "conv3x3_tile": "conv3x3_tile_kernel<", "moe_pw": "moe_pw_kernel<",
+    "moe_dw": "moe_dw_kernel<", "dwconv": "dwconv_kernel<", "area_attn": "area_attn_kernel<",
+    "detect_decode": "detect_decode_kernel", "stem": "stem_px_kernel<",
+}
+
+
+def pmc_traffic(family: str):
+    """HBM bytes per launch of the timed kernel family from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_*.json, collected by tools/gpu_profile.sh on the same workload): 2*FETCH_SIZE (gfx950 counts
+    wide coalesced reads at half size, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, averaged over the
+    family's launches.  None when no profile is committed or the family spans several kernels."""
     import glob
     import re as _re
 
-    m = _re.match(r"conv_igemm_(bf16|f32)_(\d+)x(\d+)_k(\d)", tag)
-    if not m:
-        return None
-    dt = "unsigned short" if m.group(1) == "bf16" else "float"
-    bco, bpx, k = int(m.group(2)), int(m.group(3)), int(m.group(4))
-    name = f"conv_igemm_kernel<{dt}, {bco}, {bpx}, {'2, 2' if bco == 128 else '1, 4'}, {k}>"
     files = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_FETCH_SIZE.json")))
     if not files:
         return None
+    if family.startswith("conv_igemm"):
+        ks, dual = ("1", "true") if family.endswith("cat2") else (family[-1], "false")
+        pat = _re.compile(r"conv_igemm_kernel<.*, %s, %s>" % (ks, dual))
+    elif family in FAMILY_KERNEL:
+        pat = _re.compile(_re.escape(FAMILY_KERNEL[family]))
+    else:
+        return None
     try:
-        f = json.load(open(files[-1]))["kernels"][name]["FETCH_SIZE"]["mean"]
-        w = json.load(open(files[-1].replace("FETCH_SIZE", "WRITE_SIZE")))["kernels"][name]["WRITE_SIZE"]["mean"]
-        return int((2.0 * f + w) * 1024)
+        fk = json.load(open(files[-1]))["kernels"]
+        wk = json.load(open(files[-1].replace("FETCH_SIZE", "WRITE_SIZE")))["kernels"]
+        tot, n = 0.0, 0
+        for name, v in fk.items():
+            if pat.match(name) and name in wk:
+                c = v["FETCH_SIZE"]["launches"]
+                tot += (2.0 * v["FETCH_SIZE"]["mean"] + wk[name]["WRITE_SIZE"]["mean"]) * c
+                n += c
+        return int(tot / n * 1024) if n else None
     except Exception:
         return None
 
@@ -88,7 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--roofline-kernel", default=None, help="conv kernel tag to time (default: dominant one)")
+    ap.add_argument("--roofline-kernel", default=None, help="op family to report in `roofline` (default: the one with the largest share of the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
     a = ap.parse_args()
@@ -165,34 +181,43 @@ def main():
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
         p50_ms = per_step[len(per_step) // 2]
 
-        # roofline leg: per-launch HIP events around the dominant kernel family, eager launches on this stream
-        roof = None
+        # roofline leg: per-call HIP events around every op family (eager launches on this stream); the object
+        # reported is the family with the largest share of the step, the rest go into "families"
+        roof, fams = None, None
         if rank == 0:
-            tag = a.roofline_kernel or ops.conv_kernel_tag(dtype, 128, 1)
-            ops.TIMER.start(tag)
+            ops.TIMER.start()
             for _ in range(3):
                 local_step()  # rank-local: no collective outside the lock-step timed loop
             torch.cuda.synchronize()
             recs = ops.TIMER.records
             ops.TIMER.stop()
-            if recs:
-                ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
-                nbytes = sum(r[2] for r in recs)
-                flops = sum(r[3] for r in recs)
-                gbs = nbytes / (ms * 1e-3) / 1e9
-                tfl = flops / (ms * 1e-3) / 1e12
-                intensity = flops / nbytes
-                ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
-                if intensity < ridge:
-                    roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+            agg = {}
+            for fam, e0, e1, nb, fl in recs:
+                r = agg.setdefault(fam, [0.0, 0, 0, 0])
+                r[0] += e0.elapsed_time(e1); r[1] += nb; r[2] += fl; r[3] += 1
+            ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+            def describe(fam):
+                ms, nbytes, flops, n = agg[fam]
+                gbs, tfl = nbytes / (ms * 1e-3) / 1e9, flops / (ms * 1e-3) / 1e12
+                if flops / max(nbytes, 1) < ridge:
+                    r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
                 else:
-                    roof = {"bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_PEAK_TFLOPS[a.dtype],
-                            "unit": "TFLOP/s", "frac": round(tfl / MFMA_PEAK_TFLOPS[a.dtype], 4), "traffic": None}
-                roof.update(kernel=tag, launches_per_step=len(recs) // 3, avg_launch_us=round(ms * 1e3 / len(recs), 2),
-                            alg_bytes_per_launch=int(nbytes / len(recs)), alg_gflop_per_launch=round(flops / len(recs) / 1e9, 3),
-                            achieved_gbs=round(gbs, 1), achieved_tflops=round(tfl, 2))
-                roof["traffic"] = pmc_traffic(tag)
+                    r = {"bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_PEAK_TFLOPS[a.dtype],
+                         "unit": "TFLOP/s", "frac": round(tfl / MFMA_PEAK_TFLOPS[a.dtype], 4), "traffic": None}
+                r.update(kernel=fam, launches_per_step=n // 3, avg_launch_us=round(ms * 1e3 / n, 2),
+                         ms_per_step=round(ms / 3, 4), alg_bytes_per_launch=int(nbytes / n),
+                         alg_gflop_per_launch=round(flops / n / 1e9, 3), achieved_gbs=round(gbs, 1),
+                         achieved_tflops=round(tfl, 2))
+                r["traffic"] = pmc_traffic(fam)
+                return r
+
+            if agg:
+                order = sorted(agg, key=lambda f: -agg[f][0])
+                roof = describe(a.roofline_kernel if a.roofline_kernel in agg else order[0])
+                fams = [{k: d[k] for k in ("kernel", "ms_per_step", "launches_per_step", "bound", "frac", "achieved_gbs",
+                                           "achieved_tflops")} for d in map(describe, order)]
 
     if rank == 0:
         total_images = world * a.batch * a.steps
@@ -207,6 +232,7 @@ def main():
                        "global_batch": world * a.batch, "imgsz": a.imgsz, "parallelism": f"dp{world} (image shards, no data-path collective)",
                        "launch": "hipGraph" if graph is not None else "eager", "weights": "seeded random + BN calibration (no checkpoints offline)"},
             "roofline": roof,
+            "families": fams,
             "cpu_baseline": None,
         }
         if world == 1 and not a.no_cpu_baseline:

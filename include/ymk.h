@@ -78,6 +78,13 @@ typedef struct {
 int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, const float* bias,
                const void* residual /* may be NULL */, void* y, void* stream);
 
+/* Diagnostic: which kernel family the calling thread's most recent ymk_conv2d dispatched to (same arithmetic,
+ * different data movement; profilers and bench.py's roofline leg use it to attribute time). */
+#define YMK_CONV_TILED       0  /* tiled implicit GEMM (any shape)                                   */
+#define YMK_CONV_STREAM_1X1  1  /* weight-stationary persistent streaming 1x1 (large M, Kpad <= 256) */
+#define YMK_CONV_SPATIAL_3X3 2  /* spatial-tile 3x3 with LDS-staged im2col (stride 1, Cin 32/64)     */
+int32_t ymk_conv2d_last_variant(void);
+
 /* 1x1 convolution over the channel concatenation [x1 | x2] without materialising it; with upsample1 != 0 the
  * first source is a [B][H/2][W/2][C1] map read through a nearest 2x upsample.  Replaces nn.Upsample + Concat
  * (ultralytics/nn/modules/conv.py:629-641) + the consumer's 1x1 Conv (C2f.cv1, block.py:318) of the neck.

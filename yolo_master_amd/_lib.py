@@ -43,6 +43,7 @@ SYMBOLS = {
     "ymk_abi_version": (C.c_int, []),
     "ymk_build_info": (C.c_char_p, []),
     "ymk_conv2d": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ymk_conv2d_last_variant": (_i32, []),
     "ymk_conv1x1_cat2": (C.c_int, [C.POINTER(ConvDesc), _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ymk_conv2d_stem_nchw": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_dwconv2d": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -20,6 +20,8 @@ struct ConvArgs {
 static int ymk_use_ws = 1;          // tools/micro can switch the streaming 1x1 kernel off for A/B runs
 static int ymk_ws_min_tiles = 1024;  // smallest pixel-tile count routed to the streaming kernel
 extern "C" void ymk_debug_set_ws(int on) { ymk_use_ws = on; }
+static thread_local int ymk_last_variant = YMK_CONV_TILED;
+extern "C" int32_t ymk_conv2d_last_variant(void) { return ymk_last_variant; }
 
 template <typename T, bool PRECISE>
 __device__ __forceinline__ float act_silu(float v) {
@@ -490,12 +492,13 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     hipStream_t s = (hipStream_t)stream;
     if (d->ksize == 1 && d->stride == 1 && ymk_use_ws) {  // large-M short-K 1x1: weight-stationary streaming kernel
         const bool done = d->dtype == YMK_F32 ? launch_conv1x1_ws<float>(a, s) : launch_conv1x1_ws<bf16_t>(a, s);
-        if (done) return ymk_launch_status();
+        if (done) { ymk_last_variant = YMK_CONV_STREAM_1X1; return ymk_launch_status(); }
     }
     if (d->ksize == 3 && ymk_use_ws) {  // small-Cin stride-1 3x3: spatial-tile kernel (LDS-staged im2col)
         const bool done = d->dtype == YMK_F32 ? launch_conv3x3_tile<float>(a, s) : launch_conv3x3_tile<bf16_t>(a, s);
-        if (done) return ymk_launch_status();
+        if (done) { ymk_last_variant = YMK_CONV_SPATIAL_3X3; return ymk_launch_status(); }
     }
+    ymk_last_variant = YMK_CONV_TILED;
     if (d->dtype == YMK_F32)
         return d->ksize == 1 ? launch_conv<float, 1>(a, s) : launch_conv<float, 3>(a, s);
     return d->ksize == 1 ? launch_conv<bf16_t, 1>(a, s) : launch_conv<bf16_t, 3>(a, s);

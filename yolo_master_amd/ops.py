@@ -18,35 +18,37 @@ DT = {torch.float32: _lib.YMK_F32, torch.bfloat16: _lib.YMK_BF16}
 
 
 class KernelTimer:
-    """Optional per-launch HIP-event timing of ONE kernel family (bench.py's roofline leg).  Events are
-    recorded on the stream the kernel is launched on (torch's current stream)."""
+    """Optional per-call HIP-event timing of the op families (bench.py's roofline leg, tools/gpu_diag.py).
+    Events are recorded on the stream the kernels are launched on (torch's current stream).  Inactive unless
+    `start()` was called; never active inside a captured graph."""
 
     def __init__(self):
-        self.tag = None
-        self.records = []  # (start_event, end_event, algorithmic_bytes, flops)
+        self.on = False
+        self.records = []  # (family, start_event, end_event, algorithmic_bytes, flops)
 
-    def start(self, tag):
-        self.tag, self.records = tag, []
+    def start(self):
+        self.on, self.records = True, []
 
     def stop(self):
-        self.tag = None
+        self.on = False
 
-    def wrap(self, tag, nbytes, flops):
-        if self.tag != tag:
+    def begin(self):
+        if not self.on:
             return None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((e0, e1, nbytes, flops))
+        e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        return e1
+        return e0
+
+    def end(self, e0, family, nbytes, flops):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((family, e0, e1, int(nbytes), int(flops)))
 
 
 TIMER = KernelTimer()
-
-
-def conv_kernel_tag(dtype, cout: int, k: int) -> str:
-    """Name of the conv_igemm_kernel instantiation ymk_conv2d dispatches to (csrc/conv.hip launch_conv)."""
-    tile = "128x128" if cout > 64 else "64x256" if cout > 32 else "32x256" if cout > 16 else "16x256"
-    return f"conv_igemm_{'bf16' if dtype == torch.bfloat16 else 'f32'}_{tile}_k{k}"
+CONV_FAMILY = {0: "conv_igemm", 1: "conv1x1_ws", 2: "conv3x3_tile"}  # ymk_conv2d_last_variant()
 
 
 def _stream() -> int:
@@ -133,15 +135,14 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual
         ldr = rb[4]
     d = ConvDesc(DT[x.dtype], DT[out.dtype], B, H, W, Cin, Cout, k, stride, ldx, ldy, ldr, Kp,
                  _lib.ACT_SILU if act else _lib.ACT_NONE)
-    ev = None
-    if TIMER.tag is not None:
+    e0 = TIMER.begin()
+    check(lib.ymk_conv2d(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), _stream()), "conv2d")
+    if e0 is not None:
         es = x.element_size()
         nbytes = (B * H * W * Cin + Cout * k * k * Cin + (B * Ho * Wo * Cout if residual is not None else 0)) * es \
             + B * Ho * Wo * Cout * out.element_size()
-        ev = TIMER.wrap(conv_kernel_tag(x.dtype, Cout, k), nbytes, 2 * B * Ho * Wo * Cout * k * k * Cin)
-    check(lib.ymk_conv2d(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), _stream()), "conv2d")
-    if ev is not None:
-        ev.record()
+        fam = CONV_FAMILY[lib.ymk_conv2d_last_variant()]
+        TIMER.end(e0, f"{fam}_k{k}" if fam == "conv_igemm" else fam, nbytes, 2 * B * Ho * Wo * Cout * k * k * Cin)
     return out
 
 
@@ -156,15 +157,12 @@ def conv1x1_cat2(x1, up1: bool, x2, w_packed, bias, act: bool, out=None):
     ldy = _nhwc(out)[4]
     d = ConvDesc(DT[x2.dtype], DT[out.dtype], B, H, W, C1 + C2, Cout, 1, 1, ld1, ldy, 0, Kp,
                  _lib.ACT_SILU if act else _lib.ACT_NONE)
-    ev = None
-    if TIMER.tag is not None:
-        es = x2.element_size()
-        nbytes = (B1 * H1 * W1 * C1 + B * H * W * C2 + Cout * (C1 + C2) + B * H * W * Cout) * es
-        ev = TIMER.wrap(conv_kernel_tag(x2.dtype, Cout, 1) + "_cat2", nbytes, 2 * B * H * W * Cout * (C1 + C2))
+    e0 = TIMER.begin()
     check(lib.ymk_conv1x1_cat2(C.byref(d), _p(x1), C1, ld1, int(up1), _p(x2), ld2, _p(w_packed), _p(bias), _p(out), _stream()),
           "conv1x1_cat2")
-    if ev is not None:
-        ev.record()
+    es = x2.element_size()
+    TIMER.end(e0, "conv_igemm_cat2", (B1 * H1 * W1 * C1 + B * H * W * C2 + Cout * (C1 + C2) + B * H * W * Cout) * es,
+              2 * B * H * W * Cout * (C1 + C2))
     return out
 
 
@@ -178,8 +176,10 @@ def conv2d_stem(x_nchw, w, bias, k: int, stride: int, act: bool, dtype: torch.dt
     if out is None:
         out = new_act(B, Ho, Wo, Cout, dtype, x_nchw.device)
     ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
     check(lib.ymk_conv2d_stem_nchw(_p(x_nchw), _p(w), _p(wt), _p(bias), _p(out), DT[out.dtype], B, Cin, H, W, Cout, k, stride,
                                    ldy, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "conv2d_stem_nchw")
+    TIMER.end(e0, "stem", B * Cin * H * W * 4 + B * Ho * Wo * Cout * out.element_size(), 2 * B * Ho * Wo * Cout * k * k * Cin)
     return out
 
 
@@ -189,8 +189,10 @@ def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
         out = new_act(B, H, W, Cc, x.dtype, x.device)
     ldy = _nhwc(out)[4]
     ldr = _nhwc(residual)[4] if residual is not None else 0
+    e0 = TIMER.begin()
     check(lib.ymk_dwconv2d(DT[x.dtype], _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy,
                            ldr, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d")
+    TIMER.end(e0, "dwconv", B * H * W * Cc * x.element_size() * (3 if residual is not None else 2), 2 * B * H * W * Cc * k * k)
     return out
 
 
@@ -206,9 +208,11 @@ def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
     csr_pair = torch.empty((B * top_k,), dtype=torch.int32, device=dev)
     nbytes = lib.ymk_esmoe_route_workspace_bytes(B, Cc, H, W)
     ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
+    e0 = TIMER.begin()
     check(lib.ymk_esmoe_route(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(w1), _p(b1), _p(w2), _p(b2), hidden, E, top_k,
                               float(thr), _p(route_w), _p(gate_w), _p(sel), _p(csr_off), _p(csr_pair), _p(flags),
                               _p(ws), nbytes, _stream()), "esmoe_route")
+    TIMER.end(e0, "moe_route", B * H * W * Cc * x.element_size(), B * H * W * Cc)
     return route_w, gate_w, sel, csr_off, csr_pair
 
 
@@ -216,8 +220,14 @@ def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_p
     B, H, W, Cc, ldx = _nhwc(x)
     E = ksizes.numel()
     out = torch.empty((B * top_k, H, W, Cc), dtype=x.dtype, device=x.device)
+    e0 = TIMER.begin()
     check(lib.ymk_esmoe_dw(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), E, top_k, kmax, _p(sel),
                            _p(csr_off), _p(csr_pair), _p(out), _stream()), "esmoe_dw")
+    if e0 is not None:  # algorithmic traffic: every image read once, one plane written per retained (image, expert) pair
+        e1 = TIMER.begin()
+        cnt = (csr_off[1:] - csr_off[:-1]).cpu()
+        npairs, k2 = int(cnt.sum()), int((cnt * ksizes.cpu().int() ** 2).sum())
+        TIMER.records.append(("moe_dw", e0, e1, (B + npairs) * H * W * Cc * x.element_size(), 2 * k2 * H * W * Cc))
     return out
 
 
@@ -227,8 +237,15 @@ def esmoe_pw(dw_out, B: int, H: int, W: int, pw_w, pw_b, nscale, nshift, top_k: 
     if out is None:
         out = new_act(B, H, W, Cout, dw_out.dtype, dw_out.device)
     ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
     check(lib.ymk_esmoe_pw(DT[dw_out.dtype], _p(dw_out), B, H, W, Cc, Cout, Kp, _p(pw_w), _p(pw_b), _p(nscale),
                            _p(nshift), E, top_k, _p(sel), _p(gate_w), _p(out), ldy, _stream()), "esmoe_pw")
+    if e0 is not None:  # retained (image, expert) pairs: sel is -1 for dropped slots
+        e1 = TIMER.begin()
+        npairs = int((sel >= 0).sum())
+        es = dw_out.element_size()
+        TIMER.records.append(("moe_pw", e0, e1, (npairs * H * W * Cc + E * Cout * Cc + B * H * W * Cout) * es,
+                              2 * npairs * H * W * Cc * Cout))
     return out
 
 
@@ -267,7 +284,9 @@ def area_attn(qkv, heads: int, area: int, out=None):
     if out is None:
         out = new_act(B, H, W, Cq, qkv.dtype, qkv.device)
     ldo = _nhwc(out)[4]
+    e0 = TIMER.begin()
     check(lib.ymk_area_attn(DT[qkv.dtype], _p(qkv), ldq, _p(out), ldo, B, H * W, heads, area, _stream()), "area_attn")
+    TIMER.end(e0, "area_attn", B * H * W * 4 * Cq * qkv.element_size(), 4 * B * H * W * (H * W // area) * Cq)
     return out
 
 
@@ -277,21 +296,27 @@ def upsample2x(x, out=None):
     if out is None:
         out = new_act(B, 2 * H, 2 * W, Cc, x.dtype, x.device)
     ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
     check(lib.ymk_upsample2x(DT[x.dtype], _p(x), _p(out), B, H, W, Cc, ldx, ldy, _stream()), "upsample2x")
+    TIMER.end(e0, "layout", 5 * B * H * W * Cc * x.element_size(), 0)
     return out
 
 
 def copy_channels(x, out):
     B, H, W, Cc, ldx = _nhwc(x)
     ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
     check(lib.ymk_copy_channels(DT[x.dtype], _p(x), _p(out), B * H * W, Cc, ldx, ldy, _stream()), "copy_channels")
+    TIMER.end(e0, "layout", 2 * B * H * W * Cc * x.element_size(), 0)
     return out
 
 
 def nhwc_to_nchw_f32(x):
     B, H, W, Cc, ldx = _nhwc(x)
     y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    e0 = TIMER.begin()
     check(lib.ymk_nhwc_to_nchw_f32(DT[x.dtype], _p(x), _p(y), B, H * W, Cc, ldx, _stream()), "nhwc_to_nchw_f32")
+    TIMER.end(e0, "layout", B * H * W * Cc * (x.element_size() + 4), 0)
     return y
 
 
@@ -300,8 +325,10 @@ def detect_decode(box_l, cls_l, y, stride: float, a_off: int, reg_max: int):
     B, Hl, Wl, _, _ = _nhwc(box_l)
     nc = cls_l.shape[-1]
     assert box_l.is_contiguous() and cls_l.is_contiguous() and box_l.dtype == torch.float32
+    e0 = TIMER.begin()
     check(lib.ymk_detect_decode(_p(box_l), _p(cls_l), _p(y), B, Hl, Wl, reg_max, nc, float(stride), a_off, y.shape[2],
                                 _stream()), "detect_decode")
+    TIMER.end(e0, "detect_decode", B * Hl * Wl * (4 * reg_max + nc + 4 + nc) * 4, B * Hl * Wl * (4 * reg_max * 4 + nc * 4))
     return y
 
 
@@ -319,10 +346,12 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
     counts = torch.zeros((B,), dtype=torch.int32, device=dev)
     idx = torch.zeros((B, max_det), dtype=torch.int32, device=dev)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    e0 = TIMER.begin()
     check(lib.ymk_nms_batched(_p(y), B, nc, A, float(conf), float(iou), int(multi_label), int(agnostic), max_det, max_nms,
                               float(max_wh), _p(dets), _p(counts), _p(idx), _p(status), _p(ws), nbytes, _stream()),
           "nms_batched")
     if cw_sigma is not None:
         check(lib.ymk_cw_refine(B, nc, A, int(multi_label), max_nms, max_det, float(iou), float(cw_sigma), cw_pool,
                                 _p(dets), _p(counts), _p(ws), nbytes, _stream()), "cw_refine")
+    TIMER.end(e0, "nms", B * ch * A * 4 + B * max_det * 28, B * ch * A)
     return dets, counts, idx, status

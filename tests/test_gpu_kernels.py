@@ -34,6 +34,7 @@ CONV_CASES = [
     (3, 100, 90, 32, 64, 3, 1, True, False, 32, 0),    # spatial-tile 3x3, ragged tiles, Cout 64, input slice view
     (4, 96, 96, 64, 64, 3, 1, False, True, 0, 64),     # spatial-tile 3x3, Cin 64 (bf16 only; fp32 falls back)
     (4, 96, 96, 64, 16, 3, 1, True, False, 0, 0),      # spatial-tile 3x3, Cout 16 inside a 32-wide tile
+    (4, 96, 90, 16, 32, 3, 1, True, True, 16, 0),      # spatial-tile 3x3, Cin 16 (bf16: two taps per MFMA), residual, slice view
 ]
 
 
@@ -190,8 +191,10 @@ def test_area_attention_long(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("fused,cin", [(True, 64), (False, 64), (True, 128)])
-def test_esmoe_block(dtype, fused, cin):
+@pytest.mark.parametrize("fused,cin,hw", [(True, 64, (14, 18)), (False, 64, (14, 18)), (True, 128, (14, 18)),
+                                          (False, 256, (14, 18)),    # streaming pointwise stage, 2 cout tiles, 4 K groups
+                                          (False, 128, (88, 88))])   # more (image, tile) items than workgroups, ragged last tile
+def test_esmoe_block(dtype, fused, cin, hw):
     from oracle import model_ref
     from yolo_master_amd.nn.modules import ES_MOE
 
@@ -199,7 +202,7 @@ def test_esmoe_block(dtype, fused, cin):
     m.fuse_experts = fused   # fused depthwise->pointwise kernel vs the two-kernel (dw_out) form
     sd = module_sd(m)
     # per-image offsets so that images route differently
-    x = rnd(6, cin, 14, 18, seed=12) + rnd(6, cin, 1, 1, seed=13, scale=1.5)
+    x = rnd(6, cin, hw[0], hw[1], seed=12) + rnd(6, cin, 1, 1, seed=13, scale=1.5)
     info = {}
     with torch.inference_mode():
         ref = model_ref.es_moe(sd, "model.0", _prep(x, dtype), info=info)

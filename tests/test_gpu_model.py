@@ -138,22 +138,26 @@ def test_forward_vs_oracle_fresh_inputs():
 
 
 def test_bf16_model_tracks_fp32():
-    """bf16 compute (config 3's type): same routing on the fixture batch and scores close to fp32."""
+    """bf16 compute (config 3's type): same routing as fp32 on most fixture images and class scores close to fp32.
+    The random-weight network amplifies rounding chaotically on individual images (one saturating image moves
+    the batch mean by 2x), so the statistic is the per-image mean |d| over 12 images: median and worst case."""
     from yolo_master_amd.weights import synth_input
 
-    x = synth_input(4, 640, 640, seed=1).to(DEV)
+    same, drift = [], []
     with torch.inference_mode():
-        m32 = _model("n")
-        y32, _ = m32._predict_once(x)
-        r32 = [(m32.model[i].last_route["gate_w"] > 0).cpu() for i in (3, 6, 9, 12)]
-        m16 = _model("n", torch.bfloat16)
-        y16, _ = m16._predict_once(x)
-        r16 = [(m16.model[i].last_route["gate_w"] > 0).cpu() for i in (3, 6, 9, 12)]
-    assert torch.isfinite(y16).all()
-    same = torch.stack([torch.stack([(a[b] == c[b]).all() for a, c in zip(r32, r16)]).all() for b in range(4)])
-    assert same.float().mean() >= 0.5, "bf16 flipped the routing of most images"
-    d = (y16[same.to(DEV)][:, 4:] - y32[same.to(DEV)][:, 4:]).abs()
-    assert float(d.mean()) < 2e-2, f"bf16 scores drift: mean |d| = {float(d.mean()):.3e}"
+        m32, m16 = _model("n"), _model("n", torch.bfloat16)
+        for seed in (1, 2, 3):
+            x = synth_input(4, 640, 640, seed=seed).to(DEV)
+            y32, _ = m32._predict_once(x)
+            r32 = [(m32.model[i].last_route["gate_w"] > 0).cpu() for i in (3, 6, 9, 12)]
+            y16, _ = m16._predict_once(x)
+            r16 = [(m16.model[i].last_route["gate_w"] > 0).cpu() for i in (3, 6, 9, 12)]
+            assert torch.isfinite(y16).all()
+            same += [bool(torch.stack([(a[b] == c[b]).all() for a, c in zip(r32, r16)]).all()) for b in range(4)]
+            drift += (y16[:, 4:] - y32[:, 4:]).abs().mean(dim=(1, 2)).cpu().tolist()
+    assert sum(same) >= 9, f"bf16 flipped the routing of {12 - sum(same)} of 12 images"
+    d = sorted(v for v, s_ in zip(drift, same) if s_)
+    assert d[len(d) // 2] < 1e-2 and d[-1] < 8e-2, f"bf16 scores drift: per-image mean |d| = {d}"
 
 
 def test_module_api_dropin():

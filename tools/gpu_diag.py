@@ -90,9 +90,37 @@ def layer_times(scale="s", B=64, dtype=torch.bfloat16, reps=5):
         print(f"sum {s:.3f} ms (eager, includes launch gaps) -> {B / s * 1e3:.0f} img/s")
 
 
+def call_times(scale="s", B=64, dtype=torch.bfloat16, reps=3):
+    """Every op call of one forward+NMS with its shape, time, algorithmic GB/s and TFLOP/s (ops.TIMER)."""
+    from yolo_master_amd.nms import nms_padded
+
+    m = build(scale, dtype)
+    x = synth_input(B, 640, 640, seed=1).to(DEV)
+    with torch.inference_mode():
+        for _ in range(2):
+            nms_padded(m(x)[0], 0.25, 0.7)
+        torch.cuda.synchronize()
+        ops.TIMER.start()
+        for _ in range(reps):
+            nms_padded(m(x)[0], 0.25, 0.7)
+        torch.cuda.synchronize()
+        ops.TIMER.stop()
+    n = len(ops.TIMER.records) // reps
+    rows = []
+    for i in range(n):
+        fam, _, _, nb, fl = ops.TIMER.records[i]
+        ms = sorted(ops.TIMER.records[i + r * n][1].elapsed_time(ops.TIMER.records[i + r * n][2]) for r in range(reps))[reps // 2]
+        rows.append((ms, i, fam, ops.TIMER.shapes[i], nb, fl))
+    print(f"{n} op calls, {sum(r[0] for r in rows):.3f} ms")
+    for ms, i, fam, shp, nb, fl in sorted(rows, reverse=True):
+        print(f"{i:3d} {fam:16s} {shp:34s} {ms * 1e3:8.1f} us {nb / ms / 1e6:8.0f} GB/s {fl / ms / 1e9:8.1f} TF/s")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "err"):
         errors()
     if what in ("all", "time"):
         layer_times()
+    if what == "calls":
+        call_times()

@@ -268,7 +268,7 @@ static bool launch_conv1x1_ws(ConvArgs a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// Spatial-tile 3x3 convolution (stride 1, Cin in {32, 64}, Cout tile 32/64): LDS-staged im2col.
+// Spatial-tile 3x3 convolution (stride 1, Cin in {16, 32, 64}, Cout tile 32/64): LDS-staged im2col.
 // A persistent workgroup keeps its [BCO][9*Cin] weight tile in LDS and walks over 16x16-pixel output tiles.
 // The 18x18 input halo of a tile is loaded ONCE (coalesced, zero-filled at the borders) into LDS; the nine taps
 // of the implicit GEMM are then plain LDS reads at shifted pixel addresses (pixel stride padded by 16 bytes so
@@ -282,9 +282,10 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
     constexpr int CPP = CIN / VEC;                      // 16-byte chunks per pixel
     constexpr int PSB = CIN * (int)sizeof(T) + 16;      // padded pixel stride (bytes)
     constexpr int HT = 18;
-    constexpr int KTOT = 9 * CIN;
+    constexpr int KSUB = 4 * VEC;                       // K elements per MFMA group (64 bytes)
+    constexpr bool PAIRED = CIN < KSUB;                 // bf16 Cin = 16: one MFMA group spans two taps
+    constexpr int KTOT = (9 * CIN + KSUB - 1) / KSUB * KSUB;  // weight row length held in LDS (zero tail from Kpad)
     constexpr int WRS = KTOT * (int)sizeof(T) + 16;     // padded weight row stride (bytes)
-    constexpr int KSUB = 4 * VEC;                       // channels per MFMA group (64 bytes)
     constexpr int TM = BCO / 16;
     constexpr int NL = (HT * HT * CPP + 255) / 256;
     constexpr bool PRECISE = sizeof(T) == 4;
@@ -350,6 +351,27 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PAIRED) {
+            // K index = tap * 16 + c: lanes with k-group fc < 2 read tap 2u, the others tap 2u+1 (the 10th
+            // "tap" has zero weights; its pixel operand re-reads tap 8 so that it stays finite)
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int ta = 2 * u, tb = 2 * u + 1 < 9 ? 2 * u + 1 : 8;
+                const int offa = ((ta / 3) * HT + ta % 3) * PSB, offb = ((tb / 3) * HT + tb % 3) * PSB;
+                const int poff = ((fc >> 1) ? offb : offa) + (fc & 1) * 16;
+                u32x4 af[TM], bfr[4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const u32x4*>(sW + (size_t)(i * 16 + fr) * WRS + u * 64 + fc * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bfr[j] = *reinterpret_cast<const u32x4*>(sIn + (size_t)((wave * 4 + j) * HT + fr) * PSB + poff);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+            }
+        } else
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -402,7 +424,8 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
 
 template <typename T>
 static bool launch_conv3x3_tile(ConvArgs a, hipStream_t s) {
-    if (a.stride != 1 || a.out_f32 || (a.Cin != 32 && a.Cin != 64) || a.Cout > 64 || a.Cout % 16) return false;
+    if (a.stride != 1 || a.out_f32 || (a.Cin != 16 && a.Cin != 32 && a.Cin != 64) || a.Cout > 64 || a.Cout % 16) return false;
+    if (a.Cin == 16 && a.Cout > 32) return false;
     const int bco = a.Cout <= 32 ? 32 : 64;
     const int64_t ntiles = (int64_t)a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
     if (ntiles < 128) return false;
@@ -413,7 +436,8 @@ static bool launch_conv3x3_tile(ConvArgs a, hipStream_t s) {
     int64_t nblk = 256 * per_cu;
     if (nblk > ntiles) nblk = ntiles;
     dim3 grid((unsigned)nblk), blk(256);
-    if (a.Cin == 32 && bco == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 32, 32>), grid, blk, 0, s, a);
+    if (a.Cin == 16) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 16, 32>), grid, blk, 0, s, a);
+    else if (a.Cin == 32 && bco == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 32, 32>), grid, blk, 0, s, a);
     else if (a.Cin == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 32, 64>), grid, blk, 0, s, a);
     else if constexpr (sizeof(T) == 2) {  // Cin = 64 tiles fit the 160 KB LDS only in bf16
         if (bco == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 64, 32>), grid, blk, 0, s, a);
@@ -490,11 +514,11 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     if (a.M <= 0) return YMK_OK;
     if (a.M >= (1ll << 31) || (int64_t)d->B * d->H * d->W >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if (d->ksize == 1 && d->stride == 1 && ymk_use_ws) {  // large-M short-K 1x1: weight-stationary streaming kernel
+    if (d->ksize == 1 && d->stride == 1 && ymk_use_ws && !(ymk_disabled() & YMK_OFF_CONV_STREAM)) {  // large-M short-K 1x1: weight-stationary streaming kernel
         const bool done = d->dtype == YMK_F32 ? launch_conv1x1_ws<float>(a, s) : launch_conv1x1_ws<bf16_t>(a, s);
         if (done) { ymk_last_variant = YMK_CONV_STREAM_1X1; return ymk_launch_status(); }
     }
-    if (d->ksize == 3 && ymk_use_ws) {  // small-Cin stride-1 3x3: spatial-tile kernel (LDS-staged im2col)
+    if (d->ksize == 3 && ymk_use_ws && !(ymk_disabled() & YMK_OFF_CONV_STREAM)) {  // small-Cin stride-1 3x3: spatial-tile kernel (LDS-staged im2col)
         const bool done = d->dtype == YMK_F32 ? launch_conv3x3_tile<float>(a, s) : launch_conv3x3_tile<bf16_t>(a, s);
         if (done) { ymk_last_variant = YMK_CONV_SPATIAL_3X3; return ymk_launch_status(); }
     }
@@ -621,6 +645,92 @@ __global__ __launch_bounds__(256) void stem_px_kernel(const float* __restrict__ 
     }
 }
 
+
+// Stem on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): one wave owns one output row (b, oy) and walks over
+// groups of 16 output pixels.  The weights are the MFMA row operand, held in registers for the wave's whole life
+// (K = ks*ks*Cin <= 32, zero padded); the pixel operand is gathered straight from the NCHW fp32 image (each lane
+// fetches the 8 taps of its k-group; neighbouring lanes read neighbouring pixels, the rest hits L1/L2).  Stays
+// in fp32 end to end, so the first layer adds no bf16 rounding of the input image; the result leaves as NHWC
+// rows in the activation dtype.  ~16 MFMAs + 8 loads per 16 pixels instead of 27*CO scalar FMAs per pixel.
+template <typename TO, int CO>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt /*[K][CO]*/,
+                                                         const float* __restrict__ bias, TO* __restrict__ y, int B, int Cin,
+                                                         int H, int W, int Ho, int Wo, int ks, int stride, int ldy, int act) {
+    constexpr int TM = CO / 16;
+    constexpr bool PRECISE = sizeof(TO) == 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;  // (b, oy)
+    if (row >= (int64_t)B * Ho) return;
+    const int b = (int)(row / Ho), oy = (int)(row % Ho);
+    const int K = ks * ks * Cin, pad = ks / 2;
+
+    // per-lane tap table: k = kk*16 + fc*4 + v  ->  (ky, kx, c)
+    u32x4 af[TM][2];
+    int off[8];      // element offset of the tap inside the image for ox = 0 (may be negative at the borders)
+    int dx[8];       // kx - pad
+    bool rok[8];     // tap exists and its input row is inside the image
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = (q >> 2) * 16 + fc * 4 + (q & 3);
+        const int tap = k / Cin, c = k - tap * Cin;
+        const int ky = tap / ks, kx = tap - ky * ks;
+        const int iy = oy * stride - pad + ky;
+        rok[q] = k < K && (unsigned)iy < (unsigned)H;
+        dx[q] = kx - pad;
+        off[q] = (c * H + iy) * W + dx[q];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float wv = k < K ? wt[k * CO + i * 16 + fr] : 0.f;
+            reinterpret_cast<float*>(&af[i][q >> 2])[q & 3] = wv;
+        }
+    }
+    f32x4 bv[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bv[i] = *reinterpret_cast<const f32x4*>(bias + i * 16 + fc * 4);
+    const float* xb = x + (size_t)b * Cin * H * W;
+    TO* yrow = y + (size_t)row * Wo * ldy;
+
+    for (int ox0 = 0; ox0 < Wo; ox0 += 16) {
+        const int ox = ox0 + fr;
+        const int ixb = ox * stride;
+        u32x4 bf[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ix = ixb + dx[q];
+            float v = 0.f;
+            if (rok[q] && ox < Wo && (unsigned)ix < (unsigned)W) v = xb[off[q] + ixb];
+            reinterpret_cast<float*>(&bf[q >> 2])[q & 3] = v;
+        }
+        f32x4 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            acc[i] = bv[i];
+            mma16<float>(acc[i], af[i][0], bf[0]);
+            mma16<float>(acc[i], af[i][1], bf[1]);
+        }
+        if (ox < Wo) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float v0 = acc[i].x, v1 = acc[i].y, v2 = acc[i].z, v3 = acc[i].w;
+                if (act == YMK_ACT_SILU) {
+                    if (PRECISE) { v0 = silu_exact(v0); v1 = silu_exact(v1); v2 = silu_exact(v2); v3 = silu_exact(v3); }
+                    else { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                }
+                store4(yrow + (size_t)ox * ldy + i * 16 + fc * 4, v0, v1, v2, v3);
+            }
+        }
+    }
+}
+
+template <typename TO, int CO>
+static void launch_stem_mfma(const float* x, const float* wt, const float* bias, void* y, int B, int Cin, int H, int W, int Ho,
+                             int Wo, int ks, int stride, int ldy, int act, hipStream_t s) {
+    const int64_t rows = (int64_t)B * Ho;
+    hipLaunchKernelGGL((stem_mfma_kernel<TO, CO>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, wt, bias, (TO*)y, B, Cin,
+                       H, W, Ho, Wo, ks, stride, ldy, act);
+}
+
 template <typename TO, int CO>
 static void launch_stem_px(const float* x, const float* wt, const float* bias, void* y, int B, int Cin, int H, int W, int Ho,
                            int Wo, int ks, int stride, int ldy, int act, hipStream_t s) {
@@ -645,6 +755,16 @@ extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float*
     hipStream_t s = (hipStream_t)stream;
     if (wt_kco && (Cout == 16 || Cout == 32 || Cout == 64) && (out_dtype == YMK_F32 || out_dtype == YMK_BF16)) {
         const bool f = out_dtype == YMK_F32;
+        if (ksize * ksize * Cin <= 32 && (int64_t)Cin * H * W < (1ll << 30) && !(ymk_disabled() & YMK_OFF_STEM_FAST)) {
+#define YMK_STEM_M(CO)                                                                                              \
+    (f ? launch_stem_mfma<float, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s)         \
+       : launch_stem_mfma<bf16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
+            if (Cout == 16) YMK_STEM_M(16);
+            else if (Cout == 32) YMK_STEM_M(32);
+            else YMK_STEM_M(64);
+#undef YMK_STEM_M
+            return ymk_launch_status();
+        }
 #define YMK_STEM(CO)                                                                                                \
     (f ? launch_stem_px<float, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s)           \
        : launch_stem_px<bf16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))

@@ -317,9 +317,256 @@ __global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
     G::epilogue(smem, val, emit);
 }
 
+
+// ---------------------------------------------------------------------------
+// Streaming pointwise stage (Cout > 64, K <= 4 x 128 bytes): persistent workgroups, expert weights resident in LDS.
+// Work is the image-major list of (image, pixel tile, retained expert) steps; every workgroup takes a contiguous
+// range of whole (image, tile) items of equal step count, so an expert's [128 cout][K] weight tile is loaded once
+// per image run (once per tile for images that kept two experts: the tile order alternates so that the expert
+// left in LDS by one tile is the first one the next tile needs).  The next step's activations are prefetched into
+// registers while the current step is multiplied; the gated SiLU of each expert accumulates in registers and the
+// trailing BatchNorm + SiLU is applied before the only store.  Same arithmetic as moe_pw_kernel.
+// ---------------------------------------------------------------------------
+#define PWS_MAXB 1024
+#define PWS_MAXSEL 2048
+
+template <typename T, int KG>
+__global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * VEC;  // elements per 128-byte K group
+    constexpr int RS = KG * 8;   // u32x4 per staged row
+    constexpr bool PRECISE = sizeof(T) == 4;
+    __shared__ u32x4 sW[128 * RS];
+    __shared__ u32x4 sA[128 * RS];
+    __shared__ int s_sel[PWS_MAXSEL];
+    __shared__ int s_pref[PWS_MAXB + 1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wco = wave >> 1, wpx = wave & 1;
+    const int srow = t >> 3, cq = t & 7;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int ncot = (a.Cout + 127) / 128;
+    // cout tiles of one pixel range sit on the same XCD (shared L2 for the activation tile)
+    int ct, j;
+    if (gridDim.x % (8 * ncot) == 0) {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        ct = q % ncot; j = (q / ncot) * 8 + xcd;
+    } else {
+        ct = blockIdx.x % ncot; j = blockIdx.x / ncot;
+    }
+    const int co0 = ct * 128;
+    const int nblk = gridDim.x / ncot;
+    const int tiles = a.tiles;
+    const T* dw = reinterpret_cast<const T*>(a.dw);
+    auto swz = [](int row, int c) { return (c & ~7) | ((c & 7) ^ (row & 7)); };
+
+    for (int i = t; i < a.B * a.top_k; i += 256) s_sel[i] = a.sel[i];
+    __syncthreads();
+    if (t == 0) {  // steps per image (an image without a retained expert still owns one, empty, step)
+        int run = 0;
+        for (int b = 0; b < a.B; ++b) {
+            s_pref[b] = run;
+            int nv = 0;
+            for (int q = 0; q < a.top_k; ++q) nv += s_sel[b * a.top_k + q] >= 0;
+            run += nv > 0 ? nv : 1;
+        }
+        s_pref[a.B] = run;
+    }
+    __syncthreads();
+    const int64_t nitems = (int64_t)a.B * tiles;
+    const int64_t total = (int64_t)s_pref[a.B] * tiles;
+    const int64_t per = (total + nblk - 1) / nblk;
+    auto locate = [&](int64_t target) -> int64_t {  // first item whose first step index is >= target
+        if (target >= total) return nitems;
+        int lo = 0, hi = a.B - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int64_t)s_pref[mid] * tiles <= target) lo = mid; else hi = mid - 1;
+        }
+        const int nv = s_pref[lo + 1] - s_pref[lo];
+        const int64_t local = target - (int64_t)s_pref[lo] * tiles;
+        return (int64_t)lo * tiles + (local + nv - 1) / nv;
+    };
+    int64_t it = locate((int64_t)j * per);
+    const int64_t it_end = locate((int64_t)(j + 1) * per);
+    if (it >= it_end) return;
+
+    struct Step { int b, tile, pair, e, nv; };
+    auto decode = [&](int64_t item, int k) {
+        Step st;
+        st.b = (int)(item / tiles); st.tile = (int)(item % tiles);
+        st.nv = s_pref[st.b + 1] - s_pref[st.b];
+        const int slot = (st.tile & 1) ? st.nv - 1 - k : k;
+        st.pair = st.b * a.top_k + slot;
+        st.e = s_sel[st.pair];
+        return st;
+    };
+    u32x4 ra[4][KG];
+    auto gload = [&](const Step& st) {
+        const T* xin = dw + (size_t)st.pair * a.HW * a.C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = st.tile * 128 + srow + i * 32;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (st.e >= 0 && m < a.HW && g * BK + cq * VEC < a.C)
+                    v = *reinterpret_cast<const u32x4*>(xin + (size_t)m * a.C + g * BK + cq * VEC);
+                ra[i][g] = v;
+            }
+        }
+    };
+
+    int k = 0, e_lds = -1;
+    Step cur = decode(it, 0);
+    gload(cur);
+    f32x4 part[4][4];
+    while (true) {
+        int64_t nit = it;
+        int nk = k + 1;
+        if (nk >= cur.nv) { nk = 0; ++nit; }
+        const bool more = nit < it_end;
+        const bool wneed = cur.e >= 0 && cur.e != e_lds;  // workgroup-uniform
+        u32x4 rw[4][KG];
+        if (wneed) {
+            const T* wt = reinterpret_cast<const T*>(a.pw_w) + ((size_t)cur.e * a.Cout + co0) * a.Kpad;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = srow + i * 32;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (co0 + r < a.Cout) v = *reinterpret_cast<const u32x4*>(wt + (size_t)r * a.Kpad + g * BK + cq * VEC);
+                    rw[i][g] = v;
+                }
+            }
+        }
+        __syncthreads();  // the previous step's fragment reads are finished
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + i * 32;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) sA[r * RS + swz(r, g * 8 + cq)] = ra[i][g];
+        }
+        if (wneed) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = srow + i * 32;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) sW[r * RS + swz(r, g * 8 + cq)] = rw[i][g];
+            }
+            e_lds = cur.e;
+        }
+        __syncthreads();
+        Step nxt = cur;
+        if (more) { nxt = decode(nit, nk); gload(nxt); }  // in flight during the MFMA + epilogue below
+
+        const bool first = k == 0, last = k == cur.nv - 1;
+        if (cur.e >= 0) {
+            f32x4 bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + (wco * 4 + i) * 16 + fc * 4;
+                bv[i] = co < a.Cout ? *reinterpret_cast<const f32x4*>(a.pw_b + (size_t)cur.e * a.Cout + co)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const float gw = a.gate[cur.b * a.E + cur.e];
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 af[4], bfr[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = (wco * 4 + i) * 16 + fr;
+                        af[i] = sW[r * RS + swz(r, g * 8 + kk * 4 + fc)];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int r = (wpx * 4 + jj) * 16 + fr;
+                        bfr[jj] = sA[r * RS + swz(r, g * 8 + kk * 4 + fc)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) mma16<T>(acc[i][jj], af[i], bfr[jj]);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = acc[i][jj][r] + bv[i][r];
+                        v[r] = (PRECISE ? silu_exact(u) : silu_f(u)) * gw;
+                    }
+                    if (first) part[i][jj] = v; else part[i][jj] += v;
+                }
+        } else if (first) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) part[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (last) {  // trailing ES_MOE.norm: BatchNorm(eval) + SiLU
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + (wco * 4 + i) * 16 + fc * 4;
+                if (co >= a.Cout) continue;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.nscale + co);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.nshift + co);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int m = cur.tile * 128 + (wpx * 4 + jj) * 16 + fr;
+                    if (m >= a.HW) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = part[i][jj][r] * sc[r] + sh[r];
+                        v[r] = PRECISE ? silu_exact(u) : silu_f(u);
+                    }
+                    store4(reinterpret_cast<T*>(a.y) + ((size_t)cur.b * a.HW + m) * a.ldy + co, v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        if (!more) break;
+        it = nit; k = nk; cur = nxt;
+    }
+}
+
+template <typename T>
+static bool launch_pw_stream(MoePwArgs a, hipStream_t s) {
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    const int kg = a.Kpad / BK;
+    if (ymk_disabled() & YMK_OFF_MOE_STREAM) return false;
+    if (a.Kpad % BK || kg < 1 || kg > 4 || a.Cout <= 64 || a.B > PWS_MAXB || (int64_t)a.B * a.top_k > PWS_MAXSEL) return false;
+    const int ncot = (a.Cout + 127) / 128;
+    a.tiles = (a.HW + 127) / 128;
+    // one workgroup per CU: two accumulator sets (expert partial + running sum) and the prefetched tile need
+    // ~350 registers per lane, and the stage is bound by the two SiLUs per output (transcendental rate), not by
+    // occupancy; LDS = kg * 32 KB of tiles + 12 KB of tables
+    int64_t nblk = 256 / ncot;
+    if (nblk < 1) nblk = 1;
+    if (nblk > (int64_t)a.B * a.tiles) nblk = (int64_t)a.B * a.tiles;
+    dim3 grid((unsigned)(nblk * ncot)), blk(256);
+    switch (kg) {
+        case 1: hipLaunchKernelGGL((moe_pw_stream_kernel<T, 1>), grid, blk, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((moe_pw_stream_kernel<T, 2>), grid, blk, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((moe_pw_stream_kernel<T, 3>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((moe_pw_stream_kernel<T, 4>), grid, blk, 0, s, a); break;
+    }
+    return true;
+}
+
 template <typename T>
 static int launch_pw(MoePwArgs a, hipStream_t s) {
     dim3 blk(256);
+    if (launch_pw_stream<T>(a, s)) return ymk_launch_status();
     if (a.Cout > 64) {
         a.tiles = (a.HW + 127) / 128;
         dim3 grid(a.B * a.tiles * ((a.Cout + 127) / 128));

@@ -196,6 +196,43 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w) {
     }
 }
 
+
+// ---- 4b. same order by an in-LDS bitonic sort (one workgroup per image, up to 16384 candidates) ----------
+// The 64-bit keys are unique (the low word carries the candidate index), so any correct sort yields exactly the
+// permutation of the counting rank above; this one is O(n log^2 n) instead of O(n^2).
+#define NMS_SORT_CAP 16384
+__global__ __launch_bounds__(1024) void nms_sort_kernel(NmsWs w) {
+    __shared__ unsigned long long key[NMS_SORT_CAP];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = w.ncand[b];
+    if (n <= 0) return;
+    int np = 64;
+    while (np < n) np <<= 1;
+    const float* sc = w.cscore + (size_t)b * w.capc;
+    for (int i = tid; i < np; i += 1024)
+        key[i] = i < n ? (((unsigned long long)__float_as_uint(sc[i]) << 32) | (unsigned)(~i)) : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (np >> 1); t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const unsigned long long ka = key[i], kb = key[l];
+                const bool desc = (i & k) == 0;
+                if ((ka < kb) == desc) { key[i] = kb; key[l] = ka; }
+            }
+            __syncthreads();
+        }
+    }
+    const int m = n < w.ns ? n : w.ns;
+    for (int r = tid; r < m; r += 1024) {
+        const unsigned long long kr = key[r];
+        const int i = (int)(~(unsigned)kr);
+        const size_t s = (size_t)b * w.capc + i, d = (size_t)b * w.ns + r;
+        *reinterpret_cast<f32x4*>(w.sbox + d * 4) = *reinterpret_cast<const f32x4*>(w.cbox + s * 4);
+        w.sscore[d] = __uint_as_float((unsigned)(kr >> 32)); w.scls[d] = w.ccls[s]; w.sanchor[d] = w.canchor[s];
+    }
+}
+
 // ---- 5. greedy suppression, one workgroup (4 wavefronts) per image --------------------
 // Sorted candidates are consumed 64 at a time.  Every wavefront holds the same 64 candidates (one per
 // lane).  Phase A: each wavefront tests them against its quarter of the boxes kept so far (LDS
@@ -308,7 +345,10 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A,
     hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, w);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, w, status);
     hipLaunchKernelGGL(nms_emit_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, w);
-    hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w);
+    if (w.capc <= NMS_SORT_CAP && !(ymk_disabled() & YMK_OFF_NMS_SORT))
+        hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, s, w);
+    else
+        hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w);
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det,
                        out_dets, out_counts, out_idx);
     return ymk_launch_status();

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/ymk.h"
 
 #define YMK_WAVE 64
@@ -91,5 +92,18 @@ __device__ __forceinline__ void from_f32(bf16_t& d, float v) { d = f32_to_bf16(v
 static inline int ymk_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? YMK_OK : YMK_E_LAUNCH;
+}
+// Tuning switch for A/B runs (not part of the ABI): YMK_DISABLE=<bitmask> turns specialised kernels off so the
+// same process image can be timed with and without them.  Every path computes the same result.
+#define YMK_OFF_CONV_STREAM 1u   // streaming 1x1 + spatial-tile 3x3 convolutions -> tiled implicit GEMM
+#define YMK_OFF_MOE_STREAM 2u    // streaming ES-MoE pointwise stage -> tiled grouped GEMM
+#define YMK_OFF_NMS_SORT 4u      // LDS bitonic candidate sort -> rank-by-counting
+#define YMK_OFF_STEM_FAST 8u     // fp32-MFMA stem -> one pixel per thread on the VALU
+static inline unsigned ymk_disabled() {
+    static const unsigned m = [] {
+        const char* s = getenv("YMK_DISABLE");
+        return s ? (unsigned)strtoul(s, nullptr, 0) : 0u;
+    }();
+    return m;
 }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -25,9 +25,10 @@ class KernelTimer:
     def __init__(self):
         self.on = False
         self.records = []  # (family, start_event, end_event, algorithmic_bytes, flops)
+        self.shapes = []   # free-form shape string per record (tools/gpu_diag.py calls)
 
     def start(self):
-        self.on, self.records = True, []
+        self.on, self.records, self.shapes = True, [], []
 
     def stop(self):
         self.on = False
@@ -39,12 +40,13 @@ class KernelTimer:
         e0.record()
         return e0
 
-    def end(self, e0, family, nbytes, flops):
+    def end(self, e0, family, nbytes, flops, shape=""):
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.records.append((family, e0, e1, int(nbytes), int(flops)))
+        self.shapes.append(shape)
 
 
 TIMER = KernelTimer()
@@ -142,7 +144,8 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual
         nbytes = (B * H * W * Cin + Cout * k * k * Cin + (B * Ho * Wo * Cout if residual is not None else 0)) * es \
             + B * Ho * Wo * Cout * out.element_size()
         fam = CONV_FAMILY[lib.ymk_conv2d_last_variant()]
-        TIMER.end(e0, f"{fam}_k{k}" if fam == "conv_igemm" else fam, nbytes, 2 * B * Ho * Wo * Cout * k * k * Cin)
+        TIMER.end(e0, f"{fam}_k{k}" if fam == "conv_igemm" else fam, nbytes, 2 * B * Ho * Wo * Cout * k * k * Cin,
+                  f"{Cin}->{Cout} k{k} s{stride} @{Ho}x{Wo}{' +res' if residual is not None else ''}")
     return out
 
 
@@ -162,7 +165,7 @@ def conv1x1_cat2(x1, up1: bool, x2, w_packed, bias, act: bool, out=None):
           "conv1x1_cat2")
     es = x2.element_size()
     TIMER.end(e0, "conv_igemm_cat2", (B1 * H1 * W1 * C1 + B * H * W * C2 + Cout * (C1 + C2) + B * H * W * Cout) * es,
-              2 * B * H * W * Cout * (C1 + C2))
+              2 * B * H * W * Cout * (C1 + C2), f"{C1}+{C2}->{Cout} @{H}x{W}{' up' if up1 else ''}")
     return out
 
 
@@ -192,7 +195,7 @@ def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
     e0 = TIMER.begin()
     check(lib.ymk_dwconv2d(DT[x.dtype], _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy,
                            ldr, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d")
-    TIMER.end(e0, "dwconv", B * H * W * Cc * x.element_size() * (3 if residual is not None else 2), 2 * B * H * W * Cc * k * k)
+    TIMER.end(e0, "dwconv", B * H * W * Cc * x.element_size() * (3 if residual is not None else 2), 2 * B * H * W * Cc * k * k, f"C{Cc} k{k} @{H}x{W}")
     return out
 
 
@@ -212,7 +215,7 @@ def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
     check(lib.ymk_esmoe_route(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(w1), _p(b1), _p(w2), _p(b2), hidden, E, top_k,
                               float(thr), _p(route_w), _p(gate_w), _p(sel), _p(csr_off), _p(csr_pair), _p(flags),
                               _p(ws), nbytes, _stream()), "esmoe_route")
-    TIMER.end(e0, "moe_route", B * H * W * Cc * x.element_size(), B * H * W * Cc)
+    TIMER.end(e0, "moe_route", B * H * W * Cc * x.element_size(), B * H * W * Cc, f"C{Cc} @{H}x{W}")
     return route_w, gate_w, sel, csr_off, csr_pair
 
 
@@ -228,6 +231,7 @@ def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_p
         cnt = (csr_off[1:] - csr_off[:-1]).cpu()
         npairs, k2 = int(cnt.sum()), int((cnt * ksizes.cpu().int() ** 2).sum())
         TIMER.records.append(("moe_dw", e0, e1, (B + npairs) * H * W * Cc * x.element_size(), 2 * k2 * H * W * Cc))
+        TIMER.shapes.append(f"C{Cc} @{H}x{W} pairs {npairs}")
     return out
 
 
@@ -246,6 +250,7 @@ def esmoe_pw(dw_out, B: int, H: int, W: int, pw_w, pw_b, nscale, nshift, top_k: 
         es = dw_out.element_size()
         TIMER.records.append(("moe_pw", e0, e1, (npairs * H * W * Cc + E * Cout * Cc + B * H * W * Cout) * es,
                               2 * npairs * H * W * Cc * Cout))
+        TIMER.shapes.append(f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
     return out
 
 
@@ -286,7 +291,8 @@ def area_attn(qkv, heads: int, area: int, out=None):
     ldo = _nhwc(out)[4]
     e0 = TIMER.begin()
     check(lib.ymk_area_attn(DT[qkv.dtype], _p(qkv), ldq, _p(out), ldo, B, H * W, heads, area, _stream()), "area_attn")
-    TIMER.end(e0, "area_attn", B * H * W * 4 * Cq * qkv.element_size(), 4 * B * H * W * (H * W // area) * Cq)
+    TIMER.end(e0, "area_attn", B * H * W * 4 * Cq * qkv.element_size(), 4 * B * H * W * (H * W // area) * Cq,
+              f"heads {heads} area {area} @{H}x{W}")
     return out
 
 

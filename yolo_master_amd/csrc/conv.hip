@@ -309,8 +309,10 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
         if (co0 + r < a.Cout) v = *reinterpret_cast<const u32x4*>(wt + (size_t)r * a.Kpad + ch * VEC);
         *reinterpret_cast<u32x4*>(sW + (size_t)r * WRS + ch * 16) = v;
     }
-    u32x4 stg[NL];
-    auto gload = [&](int64_t tile) {
+    // register staging: two tiles ahead when a halo tile is small (keeps enough bytes in flight per CU)
+    constexpr int DEPTH = (HT * HT * CIN * (int)sizeof(T) <= 24 * 1024 && BCO <= 32) ? 2 : 1;
+    u32x4 stg[DEPTH][NL];
+    auto gload = [&](int64_t tile, u32x4 (&dst)[NL]) {
         const int b = (int)(tile / tpi), tl = (int)(tile % tpi);
         const int ty0 = (tl / tiles_x) * 16, tx0 = (tl % tiles_x) * 16;
         const T* xb = x + (size_t)b * a.H * a.W * a.ldx;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (q < HT * HT * CPP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.ldx + ch * VEC);
-            stg[l] = v;
+            dst[l] = v;
         }
     };
     f32x4 bv[TM];
@@ -334,18 +336,16 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
     }
     const bool silu = a.act == YMK_ACT_SILU;
 
-    int64_t tile = blockIdx.x / a.ncot;
-    if (tile < ntiles) gload(tile);
-    for (; tile < ntiles; tile += nblk_px) {
+    auto body = [&](int64_t tile, u32x4 (&buf)[NL]) {
         __syncthreads();  // previous tile's LDS reads are done (first pass: orders the weight stores)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const int q = t + l * 256;
-            if (q < HT * HT * CPP) *reinterpret_cast<u32x4*>(sIn + (size_t)(q / CPP) * PSB + (q % CPP) * 16) = stg[l];
+            if (q < HT * HT * CPP) *reinterpret_cast<u32x4*>(sIn + (size_t)(q / CPP) * PSB + (q % CPP) * 16) = buf[l];
         }
         __syncthreads();
-        const int64_t nxt = tile + nblk_px;
-        if (nxt < ntiles) gload(nxt);
+        const int64_t nxt = tile + (int64_t)DEPTH * nblk_px;
+        if (nxt < ntiles) gload(nxt, buf);  // refill the buffer just consumed
         f32x4 acc[TM][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -419,6 +419,19 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
                 store4(reinterpret_cast<T*>(a.y) + m * a.ldy + co, v[0], v[1], v[2], v[3]);
             }
         }
+    };
+
+    int64_t tile = blockIdx.x / a.ncot;
+    if (tile < ntiles) gload(tile, stg[0]);
+    if (DEPTH == 2 && tile + nblk_px < ntiles) gload(tile + nblk_px, stg[DEPTH - 1]);
+    while (tile < ntiles) {
+        body(tile, stg[0]);
+        tile += nblk_px;
+        if (DEPTH == 2) {
+            if (tile >= ntiles) break;
+            body(tile, stg[DEPTH - 1]);
+            tile += nblk_px;
+        }
     }
 }
 
@@ -431,17 +444,24 @@ static bool launch_conv3x3_tile(ConvArgs a, hipStream_t s) {
     if (ntiles < 128) return false;
     a.ncot = 1;
     a.ablate = 0;
-    const size_t lds = (size_t)18 * 18 * (a.Cin * sizeof(T) + 16) + (size_t)bco * (9 * a.Cin * sizeof(T) + 16);
-    const int per_cu = lds <= 40 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : lds <= 80 * 1024 ? 2 : 1;
-    int64_t nblk = 256 * per_cu;
-    if (nblk > ntiles) nblk = ntiles;
-    dim3 grid((unsigned)nblk), blk(256);
-    if (a.Cin == 16) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 16, 32>), grid, blk, 0, s, a);
-    else if (a.Cin == 32 && bco == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 32, 32>), grid, blk, 0, s, a);
-    else if (a.Cin == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 32, 64>), grid, blk, 0, s, a);
+    // persistent grid = resident workgroups (registers and LDS both limit it; asked once per instantiation)
+    auto go = [&](auto kern) {
+        static int per_cu = 0;
+        if (per_cu == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, 0) != hipSuccess || n < 1) n = 1;
+            per_cu = n;
+        }
+        int64_t nblk = 256 * (int64_t)per_cu;
+        if (nblk > ntiles) nblk = ntiles;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    };
+    if (a.Cin == 16) go(conv3x3_tile_kernel<T, 16, 32>);
+    else if (a.Cin == 32 && bco == 32) go(conv3x3_tile_kernel<T, 32, 32>);
+    else if (a.Cin == 32) go(conv3x3_tile_kernel<T, 32, 64>);
     else if constexpr (sizeof(T) == 2) {  // Cin = 64 tiles fit the 160 KB LDS only in bf16
-        if (bco == 32) hipLaunchKernelGGL((conv3x3_tile_kernel<T, 64, 32>), grid, blk, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_tile_kernel<T, 64, 64>), grid, blk, 0, s, a);
+        if (bco == 32) go(conv3x3_tile_kernel<T, 64, 32>);
+        else go(conv3x3_tile_kernel<T, 64, 64>);
     } else {
         return false;
     }
@@ -691,33 +711,43 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     const float* xb = x + (size_t)b * Cin * H * W;
     TO* yrow = y + (size_t)row * Wo * ldy;
 
-    for (int ox0 = 0; ox0 < Wo; ox0 += 16) {
-        const int ox = ox0 + fr;
-        const int ixb = ox * stride;
-        u32x4 bf[2];
+    // SG groups of 16 pixels per iteration: all 8*SG gathers are issued before the first MFMA so that enough
+    // loads are in flight per wave to cover the HBM latency (one group at a time is latency-bound)
+    constexpr int SG = 4;
+    for (int ox0 = 0; ox0 < Wo; ox0 += 16 * SG) {
+        u32x4 bf[SG][2];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int ix = ixb + dx[q];
-            float v = 0.f;
-            if (rok[q] && ox < Wo && (unsigned)ix < (unsigned)W) v = xb[off[q] + ixb];
-            reinterpret_cast<float*>(&bf[q >> 2])[q & 3] = v;
-        }
-        f32x4 acc[TM];
+        for (int sg = 0; sg < SG; ++sg) {
+            const int ox = ox0 + sg * 16 + fr;
+            const int ixb = ox * stride;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            acc[i] = bv[i];
-            mma16<float>(acc[i], af[i][0], bf[0]);
-            mma16<float>(acc[i], af[i][1], bf[1]);
+            for (int q = 0; q < 8; ++q) {
+                const int ix = ixb + dx[q];
+                float v = 0.f;
+                if (rok[q] && ox < Wo && (unsigned)ix < (unsigned)W) v = xb[off[q] + ixb];
+                reinterpret_cast<float*>(&bf[sg][q >> 2])[q & 3] = v;
+            }
         }
-        if (ox < Wo) {
+#pragma unroll
+        for (int sg = 0; sg < SG; ++sg) {
+            const int ox = ox0 + sg * 16 + fr;
+            f32x4 acc[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                float v0 = acc[i].x, v1 = acc[i].y, v2 = acc[i].z, v3 = acc[i].w;
-                if (act == YMK_ACT_SILU) {
-                    if (PRECISE) { v0 = silu_exact(v0); v1 = silu_exact(v1); v2 = silu_exact(v2); v3 = silu_exact(v3); }
-                    else { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                acc[i] = bv[i];
+                mma16<float>(acc[i], af[i][0], bf[sg][0]);
+                mma16<float>(acc[i], af[i][1], bf[sg][1]);
+            }
+            if (ox < Wo) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float v0 = acc[i].x, v1 = acc[i].y, v2 = acc[i].z, v3 = acc[i].w;
+                    if (act == YMK_ACT_SILU) {
+                        if (PRECISE) { v0 = silu_exact(v0); v1 = silu_exact(v1); v2 = silu_exact(v2); v3 = silu_exact(v3); }
+                        else { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                    }
+                    store4(yrow + (size_t)ox * ldy + i * 16 + fc * 4, v0, v1, v2, v3);
                 }
-                store4(yrow + (size_t)ox * ldy + i * 16 + fc * 4, v0, v1, v2, v3);
             }
         }
     }

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
 #define PWS_MAXSEL 2048
 
 template <typename T, int KG>
-__global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
+__global__ __launch_bounds__(512) void moe_pw_stream_kernel(MoePwArgs a) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int BK = 8 * VEC;  // elements per 128-byte K group
     constexpr int RS = KG * 8;   // u32x4 per staged row
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
     __shared__ int s_sel[PWS_MAXSEL];
     __shared__ int s_pref[PWS_MAXB + 1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wco = wave >> 1, wpx = wave & 1;
-    const int srow = t >> 3, cq = t & 7;
+    const int wco = wave >> 1, wpx = wave & 1;   // 8 waves: 4 (cout, 32 each) x 2 (pixels, 64 each)
+    const int srow = t >> 3, cq = t & 7;         // 64 staged rows per pass
     const int fr = lane & 15, fc = lane >> 4;
     const int ncot = (a.Cout + 127) / 128;
     // cout tiles of one pixel range sit on the same XCD (shared L2 for the activation tile)
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
     const T* dw = reinterpret_cast<const T*>(a.dw);
     auto swz = [](int row, int c) { return (c & ~7) | ((c & 7) ^ (row & 7)); };
 
-    for (int i = t; i < a.B * a.top_k; i += 256) s_sel[i] = a.sel[i];
+    for (int i = t; i < a.B * a.top_k; i += 512) s_sel[i] = a.sel[i];
     __syncthreads();
     if (t == 0) {  // steps per image (an image without a retained expert still owns one, empty, step)
         int run = 0;
@@ -400,12 +400,12 @@ __global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
         st.e = s_sel[st.pair];
         return st;
     };
-    u32x4 ra[4][KG];
+    u32x4 ra[2][KG];
     auto gload = [&](const Step& st) {
         const T* xin = dw + (size_t)st.pair * a.HW * a.C;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = st.tile * 128 + srow + i * 32;
+        for (int i = 0; i < 2; ++i) {
+            const int m = st.tile * 128 + srow + i * 64;
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 u32x4 v = {0u, 0u, 0u, 0u};
@@ -419,19 +419,19 @@ __global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
     int k = 0, e_lds = -1;
     Step cur = decode(it, 0);
     gload(cur);
-    f32x4 part[4][4];
+    f32x4 part[2][4];
     while (true) {
         int64_t nit = it;
         int nk = k + 1;
         if (nk >= cur.nv) { nk = 0; ++nit; }
         const bool more = nit < it_end;
         const bool wneed = cur.e >= 0 && cur.e != e_lds;  // workgroup-uniform
-        u32x4 rw[4][KG];
+        u32x4 rw[2][KG];
         if (wneed) {
             const T* wt = reinterpret_cast<const T*>(a.pw_w) + ((size_t)cur.e * a.Cout + co0) * a.Kpad;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = srow + i * 32;
+            for (int i = 0; i < 2; ++i) {
+                const int r = srow + i * 64;
 #pragma unroll
                 for (int g = 0; g < KG; ++g) {
                     u32x4 v = {0u, 0u, 0u, 0u};
@@ -442,15 +442,15 @@ __global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
         }
         __syncthreads();  // the previous step's fragment reads are finished
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = srow + i * 32;
+        for (int i = 0; i < 2; ++i) {
+            const int r = srow + i * 64;
 #pragma unroll
             for (int g = 0; g < KG; ++g) sA[r * RS + swz(r, g * 8 + cq)] = ra[i][g];
         }
         if (wneed) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = srow + i * 32;
+            for (int i = 0; i < 2; ++i) {
+                const int r = srow + i * 64;
 #pragma unroll
                 for (int g = 0; g < KG; ++g) sW[r * RS + swz(r, g * 8 + cq)] = rw[i][g];
             }
@@ -462,27 +462,27 @@ __global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
 
         const bool first = k == 0, last = k == cur.nv - 1;
         if (cur.e >= 0) {
-            f32x4 bv[4];
+            f32x4 bv[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = co0 + (wco * 4 + i) * 16 + fc * 4;
+            for (int i = 0; i < 2; ++i) {
+                const int co = co0 + (wco * 2 + i) * 16 + fc * 4;
                 bv[i] = co < a.Cout ? *reinterpret_cast<const f32x4*>(a.pw_b + (size_t)cur.e * a.Cout + co)
                                     : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             const float gw = a.gate[cur.b * a.E + cur.e];
-            f32x4 acc[4][4];
+            f32x4 acc[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < KG; ++g)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    u32x4 af[4], bfr[4];
+                    u32x4 af[2], bfr[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = (wco * 4 + i) * 16 + fr;
+                    for (int i = 0; i < 2; ++i) {
+                        const int r = (wco * 2 + i) * 16 + fr;
                         af[i] = sW[r * RS + swz(r, g * 8 + kk * 4 + fc)];
                     }
 #pragma unroll
@@ -491,12 +491,12 @@ __global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
                         bfr[jj] = sA[r * RS + swz(r, g * 8 + kk * 4 + fc)];
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) mma16<T>(acc[i][jj], af[i], bfr[jj]);
                 }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     f32x4 v;
@@ -509,14 +509,14 @@ __global__ __launch_bounds__(256) void moe_pw_stream_kernel(MoePwArgs a) {
                 }
         } else if (first) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) part[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (last) {  // trailing ES_MOE.norm: BatchNorm(eval) + SiLU
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = co0 + (wco * 4 + i) * 16 + fc * 4;
+            for (int i = 0; i < 2; ++i) {
+                const int co = co0 + (wco * 2 + i) * 16 + fc * 4;
                 if (co >= a.Cout) continue;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(a.nscale + co);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(a.nshift + co);
@@ -547,13 +547,12 @@ static bool launch_pw_stream(MoePwArgs a, hipStream_t s) {
     if (a.Kpad % BK || kg < 1 || kg > 4 || a.Cout <= 64 || a.B > PWS_MAXB || (int64_t)a.B * a.top_k > PWS_MAXSEL) return false;
     const int ncot = (a.Cout + 127) / 128;
     a.tiles = (a.HW + 127) / 128;
-    // one workgroup per CU: two accumulator sets (expert partial + running sum) and the prefetched tile need
-    // ~350 registers per lane, and the stage is bound by the two SiLUs per output (transcendental rate), not by
-    // occupancy; LDS = kg * 32 KB of tiles + 12 KB of tables
+    // one 8-wave workgroup per CU (two waves per SIMD overlap one wave's MFMA with the other's SiLU epilogue);
+    // LDS = kg * 32 KB of tiles + 12 KB of tables
     int64_t nblk = 256 / ncot;
     if (nblk < 1) nblk = 1;
     if (nblk > (int64_t)a.B * a.tiles) nblk = (int64_t)a.B * a.tiles;
-    dim3 grid((unsigned)(nblk * ncot)), blk(256);
+    dim3 grid((unsigned)(nblk * ncot)), blk(512);
     switch (kg) {
         case 1: hipLaunchKernelGGL((moe_pw_stream_kernel<T, 1>), grid, blk, 0, s, a); break;
         case 2: hipLaunchKernelGGL((moe_pw_stream_kernel<T, 2>), grid, blk, 0, s, a); break;

@@ -1,35 +1,37 @@
-// Depthwise k x k convolution, NHWC, stride 1, pad k/2 — LDS-tiled sliding-window stencil.
+// Depthwise k x k convolution, NHWC, stride 1, pad k/2 — LDS-tiled sliding-window stencil, persistent workgroups.
 //
-// Workgroup = 16 x 32 output pixels x 16 channels.
-// The (16+k-1) x (32+k-1) input halo is staged once in LDS with coalesced 16-byte loads (pixel stride
-// padded to 40 (bf16) / 80 (fp32) bytes so the four x-strips of a wave land on disjoint bank groups), the k*k filter
-// taps of the channel block are staged as fp32.  Each thread owns 4 channels x 8 consecutive output
-// pixels of a row: per filter row it streams 8+k-1 LDS vectors once and keeps the k taps in registers,
-// accumulating with packed fp32 FMAs (v_pk_fma_f32 on two channel pairs).  HBM-bound by design (the
-// stencil has no contraction shared between channels, so MFMA does not apply); the halo re-read
-// ((16+k-1)(32+k-1)/512 = 1.9x at k=9) is served by L2.
+// Workgroup tile = TH x TW output pixels x 16 channels with (TH, TW) = (16, 40) or, for maps at most 20 pixels
+// wide, (32, 20): the detector's maps are 160/80/40/20 pixels wide, which these shapes cover without ragged tiles.
+// A workgroup owns one channel block and a run of consecutive spatial tiles of one image: the k*k filter taps of
+// the block are staged (as fp32) once, and while a tile is computed the NEXT tile's (TH+k-1) x (TW+k-1) halo is
+// already in flight into registers (coalesced 16-byte loads), so the HBM/L2 latency of a tile hides behind the
+// previous tile's arithmetic.  The LDS pixel stride is padded to 40 (bf16) / 80 (fp32) bytes so the x-strips of a
+// wave land on disjoint bank groups.  Each thread owns 4 channels x 10 consecutive output pixels of a row: per
+// filter row it streams 10+k-1 LDS vectors once and keeps the k taps in registers, accumulating with packed fp32
+// FMAs (v_pk_fma_f32 on two channel pairs).  The stencil has no contraction shared between channels, so MFMA does
+// not apply; the halo re-read is served by L2.
 //
 // Reference semantics: DWConv (ultralytics/nn/modules/conv.py:185-199), AAttn.pe
 // (nn/modules/block.py:1688,1731), DepthwiseSeparableConv.depthwise (nn/modules/moe/experts.py:283-292)
 // dispatched per retained (image, expert) pair as in ES_MOE._sparse_forward (moe/modules.py:690-697).
 #include "ymk_common.h"
 
-#define DW_R 8
-#define DW_TH 16
-#define DW_TW 32
+#define DW_R 10   // consecutive output pixels per thread
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <typename T>
+template <typename T, int TW>
 struct DwTile {
+    static constexpr int TH = TW == 40 ? 16 : 32;
     static constexpr int CB = 16;                             // channels per workgroup
     static constexpr int CPP = CB * (int)sizeof(T) / 16;      // 16-byte chunks per staged pixel (2 bf16 / 4 fp32)
     static constexpr int PSB = CB * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16);  // padded LDS pixel stride (bytes)
     static constexpr int NCG = CB / 4;                        // 4-channel groups
-    static constexpr int ROWL = 256 / (NCG * (DW_TW / DW_R)); // row lanes
-    static constexpr int RPT = DW_TH / ROWL;                  // rows per thread
+    static constexpr int STRIPS = TW / DW_R;                  // x-strips per tile row
+    static constexpr int ROWL = 256 / (NCG * STRIPS);         // row lanes
+    static_assert(TH == ROWL, "one output row per thread");
     static constexpr size_t lds_bytes(int K) {
-        return (size_t)(DW_TH + K - 1) * (DW_TW + K - 1) * PSB + (size_t)K * K * CB * sizeof(float);
+        return (size_t)(TH + K - 1) * (TW + K - 1) * PSB + (size_t)K * K * CB * sizeof(float);
     }
 };
 
@@ -42,15 +44,15 @@ __device__ __forceinline__ void lds_ld4(const char* p, f32x2& a, f32x2& b, float
     a = f32x2{t.x, t.y}; b = f32x2{t.z, t.w};
 }
 // bf16: the two packed words (c0,c1),(c2,c3) are widened with VECTOR shifts/masks so that the results land in
-// register pairs directly: a = (c0, c2), b = (c1, c3) (channel pairing differs from fp32: see DW_PAIR)
+// register pairs directly: a = (c0, c2), b = (c1, c3) (channel pairing differs from fp32: see DwPair)
 __device__ __forceinline__ void lds_ld4(const char* p, f32x2& a, f32x2& b, bf16_t) {
     const u32x2 t = *reinterpret_cast<const u32x2*>(p);
     a = __builtin_bit_cast(f32x2, t << 16);
     b = __builtin_bit_cast(f32x2, t & 0xffff0000u);
 }
 
-// consecutive logical tiles (the channel blocks of one pixel tile, then the neighbouring pixel tile) run on the
-// same XCD back to back, so the 128-byte lines shared by channel blocks / halos hit in that XCD's L2
+// consecutive logical workgroups (the channel blocks of one run of tiles, then the next run) execute on the same
+// XCD back to back, so the 128-byte lines shared by channel blocks / halos hit in that XCD's L2
 __device__ __forceinline__ unsigned xcd_remap_dw(unsigned bid, unsigned nwg) {
     const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -62,71 +64,74 @@ struct DwEpi {  // epilogue description shared by the plain and the ES-MoE launc
     int ldr, act;
 };
 
-// xb/ob: base of this image's input / output view; w: [K*K][C] filter; tile = blockIdx-derived
-template <typename T, int K>
-__device__ __forceinline__ void dw_tile(const T* __restrict__ xb, int H, int W, int C, int ldx,
-                                        const T* __restrict__ w, T* __restrict__ ob, int ldy, int tile,
-                                        const DwEpi& ep, const T* __restrict__ rb, char* smem) {
-    using D = DwTile<T>;
-    constexpr int P = K / 2, HT = DW_TH + K - 1, WT = DW_TW + K - 1;
+// xb/ob: base of this image's input / output view; w: [K*K][C] filter; the workgroup handles channel block cb and
+// the spatial tiles [st0, st1) (row-major over the tile grid) of the image
+template <typename T, int K, int TW>
+__device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, int C, int ldx,
+                                       const T* __restrict__ w, T* __restrict__ ob, int ldy, int cb, int st0, int st1,
+                                       const DwEpi& ep, const T* __restrict__ rb, char* smem) {
+    using D = DwTile<T, TW>;
+    constexpr int TH = D::TH;
+    constexpr int P = K / 2, HT = TH + K - 1, WT = TW + K - 1;
     constexpr int VEC = 16 / (int)sizeof(T);
-    const int t = threadIdx.x;
-    const int ncb = (C + D::CB - 1) / D::CB;
-    const int tiles_x = (W + DW_TW - 1) / DW_TW;
-    const int cb = tile % ncb;
-    const int tx = (tile / ncb) % tiles_x, ty = tile / (ncb * tiles_x);
-    const int c0 = cb * D::CB, ty0 = ty * DW_TH, tx0 = tx * DW_TW;
-    float* wsm = reinterpret_cast<float*>(smem + (size_t)HT * WT * D::PSB);
-
-    // ---- stage the halo tile (coalesced: 4 lanes x 16 B per pixel) and the filter block.
-    // All global loads of a thread are issued back to back into registers BEFORE the first LDS write:
-    // a load->write->load chain would serialise ~15 HBM/L2 round trips per workgroup.
     constexpr int CPP = D::CPP;
     constexpr int NL = (HT * WT * CPP + 255) / 256;
-    u32x4 stg[NL];
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const int i = t + l * 256;
-        const int pix = i / CPP, q = i % CPP;
-        const int hy = pix / WT, hx = pix - hy * WT;
-        const int iy = ty0 - P + hy, ix = tx0 - P + hx;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (i < HT * WT * CPP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + q * VEC < C)
-            v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * ldx + c0 + q * VEC);
-        stg[l] = v;
-    }
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const int i = t + l * 256;
-        if (i < HT * WT * CPP) {
-            u32x2* d = reinterpret_cast<u32x2*>(smem + (size_t)(i / CPP) * D::PSB + (i % CPP) * 16);
-            d[0] = u32x2{stg[l].x, stg[l].y};
-            d[1] = u32x2{stg[l].z, stg[l].w};
-        }
-    }
+    constexpr bool PRECISE = sizeof(T) == 4;
+    const int t = threadIdx.x;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int c0 = cb * D::CB;
+    float* wsm = reinterpret_cast<float*>(smem + (size_t)HT * WT * D::PSB);
+
+    // filter block once: channel j of each 4-group at its register-quadruple position (see lds_ld4)
     for (int i = t; i < K * K * D::CB; i += 256) {
         const int tap = i / D::CB, c = i - tap * D::CB;
-        // store channel j of each 4-group at its register-quadruple position (see lds_ld4)
         wsm[tap * D::CB + (c & ~3) + DwPair<T>::pos[c & 3]] = (c0 + c) < C ? to_f32(w[(size_t)tap * C + c0 + c]) : 0.f;
     }
-    __syncthreads();
-
+    // halo staging: all global loads of a thread are issued back to back into registers
+    u32x4 stg[NL];
+    auto gload = [&](int st) {
+        const int ty0 = (st / tiles_x) * TH, tx0 = (st % tiles_x) * TW;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int i = t + l * 256;
+            const int pix = i / CPP, q = i % CPP;
+            const int hy = pix / WT, hx = pix - hy * WT;
+            const int iy = ty0 - P + hy, ix = tx0 - P + hx;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (i < HT * WT * CPP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + q * VEC < C)
+                v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * ldx + c0 + q * VEC);
+            stg[l] = v;
+        }
+    };
     const int cg = t % D::NCG;
-    const int strip = (t / D::NCG) % (DW_TW / DW_R);
-    const int rl = t / (D::NCG * (DW_TW / DW_R));
+    const int strip = (t / D::NCG) % D::STRIPS;
+    const int y = t / (D::NCG * D::STRIPS);   // output row of the tile owned by this thread
     const int x0 = strip * DW_R;
-    if (c0 + cg * 4 >= C) return;  // partial last channel block (C need only be a multiple of 16 bytes)
+    const bool chan_ok = c0 + cg * 4 < C;      // partial last channel block (C need only be a multiple of 16 bytes)
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ep.bias) {
+    if (ep.bias && chan_ok) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(ep.bias + c0 + cg * 4);
         bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
     }
-    constexpr bool PRECISE = sizeof(T) == 4;
-#pragma unroll 1
-    for (int rr = 0; rr < D::RPT; ++rr) {
-        const int y = rl * D::RPT + rr;
+
+    if (st0 < st1) gload(st0);
+    for (int st = st0; st < st1; ++st) {
+        __syncthreads();  // the previous tile's LDS reads are finished
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int i = t + l * 256;
+            if (i < HT * WT * CPP) {
+                u32x2* d = reinterpret_cast<u32x2*>(smem + (size_t)(i / CPP) * D::PSB + (i % CPP) * 16);
+                d[0] = u32x2{stg[l].x, stg[l].y};
+                d[1] = u32x2{stg[l].z, stg[l].w};
+            }
+        }
+        __syncthreads();  // halo (and, first pass, the filter block) visible
+        if (st + 1 < st1) gload(st + 1);  // in flight during the arithmetic below
+
+        const int ty0 = (st / tiles_x) * TH, tx0 = (st % tiles_x) * TW;
         const int gy = ty0 + y;
-        if (gy >= H) break;
+        if (!chan_ok || gy >= H || tx0 + x0 >= W) continue;
         f32x2 acc[DW_R][2];
 #pragma unroll
         for (int r = 0; r < DW_R; ++r) { acc[r][0] = f32x2{0.f, 0.f}; acc[r][1] = f32x2{0.f, 0.f}; }
@@ -175,59 +180,85 @@ __device__ __forceinline__ void dw_tile(const T* __restrict__ xb, int H, int W, 
     }
 }
 
+// Work decomposition shared by both launchers: blockIdx.x = run * ncb + cb (channel block fastest, XCD-remapped),
+// run = `spt` consecutive spatial tiles.
+struct DwGeom {
+    int ncb, nsp, spt, nrun;
+};
+template <typename T>
+static DwGeom dw_geom(int H, int W, int C, int tw, int64_t planes) {
+    const int th = tw == 40 ? 16 : 32;
+    DwGeom g;
+    g.ncb = (C + 15) / 16;
+    g.nsp = ((H + th - 1) / th) * ((W + tw - 1) / tw);
+    // tiles per workgroup: as long as the launch keeps >= ~8k workgroups, at most 8 (prefetch needs >= 2 to pay)
+    int64_t spt = (int64_t)g.nsp * g.ncb * planes / 8192;
+    g.spt = (int)(spt < 1 ? 1 : spt > 8 ? 8 : spt);
+    g.nrun = (g.nsp + g.spt - 1) / g.spt;
+    return g;
+}
+static inline int dw_tile_width(int W) { return W <= 20 ? 20 : 40; }
+
 struct DwArgs {
     const void* x;
     const void* w;
     const float* bias;
     const void* res;
     void* y;
-    int B, H, W, C, ldx, ldy, ldr, act, tiles;  // tiles per image
+    int B, H, W, C, ldx, ldy, ldr, act;
+    int ncb, nsp, spt;
 };
 
-template <typename T, int K>
+template <typename T, int K, int TW>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.y;
     const size_t img = (size_t)b * a.H * a.W;
     DwEpi ep{a.bias, a.res, a.ldr, a.act};
     const T* rb = a.res ? reinterpret_cast<const T*>(a.res) + img * a.ldr : nullptr;
-    dw_tile<T, K>(reinterpret_cast<const T*>(a.x) + img * a.ldx, a.H, a.W, a.C, a.ldx,
-                  reinterpret_cast<const T*>(a.w), reinterpret_cast<T*>(a.y) + img * a.ldy, a.ldy,
-                  (int)xcd_remap_dw(blockIdx.x, gridDim.x), ep, rb, smem);
+    const int lid = (int)xcd_remap_dw(blockIdx.x, gridDim.x);
+    const int cb = lid % a.ncb, st0 = (lid / a.ncb) * a.spt;
+    dw_run<T, K, TW>(reinterpret_cast<const T*>(a.x) + img * a.ldx, a.H, a.W, a.C, a.ldx, reinterpret_cast<const T*>(a.w),
+                     reinterpret_cast<T*>(a.y) + img * a.ldy, a.ldy, cb, st0, min(a.nsp, st0 + a.spt), ep, rb, smem);
 }
 
-template <typename T, int K>
-static void launch_dw_k(const DwArgs& a, hipStream_t s) {
-    const size_t shm = DwTile<T>::lds_bytes(K);
+template <typename T, int K, int TW>
+static void launch_dw_k(const DwArgs& a, int nrun, hipStream_t s) {
+    const size_t shm = DwTile<T, TW>::lds_bytes(K);
     static bool attr_set = false;
     if (!attr_set && shm > 64 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_kernel<T, K>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_kernel<T, K, TW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dwconv_kernel<T, K>), dim3(a.tiles, a.B), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((dwconv_kernel<T, K, TW>), dim3(nrun * a.ncb, a.B), dim3(256), shm, s, a);
+}
+
+template <typename T, int TW>
+static int launch_dw_tw(DwArgs a, int k, hipStream_t s) {
+    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, a.B);
+    a.ncb = g.ncb; a.nsp = g.nsp; a.spt = g.spt;
+    switch (k) {
+        case 1: launch_dw_k<T, 1, TW>(a, g.nrun, s); break;
+        case 3: launch_dw_k<T, 3, TW>(a, g.nrun, s); break;
+        case 5: launch_dw_k<T, 5, TW>(a, g.nrun, s); break;
+        case 7: launch_dw_k<T, 7, TW>(a, g.nrun, s); break;
+        case 9: launch_dw_k<T, 9, TW>(a, g.nrun, s); break;
+        case 11: launch_dw_k<T, 11, TW>(a, g.nrun, s); break;
+        case 13: launch_dw_k<T, 13, TW>(a, g.nrun, s); break;
+        case 15: launch_dw_k<T, 15, TW>(a, g.nrun, s); break;
+        default: return YMK_E_BADARG;
+    }
+    return ymk_launch_status();
 }
 
 template <typename T>
 static int launch_dw(DwArgs a, int k, hipStream_t s) {
-    using D = DwTile<T>;
     constexpr int VEC = 16 / (int)sizeof(T);
     if (a.C % VEC) return YMK_E_BADARG;
     if (a.B <= 0 || a.H <= 0 || a.W <= 0) return YMK_OK;
     if (a.B > 65535) return YMK_E_BADARG;
-    a.tiles = ((a.H + DW_TH - 1) / DW_TH) * ((a.W + DW_TW - 1) / DW_TW) * ((a.C + D::CB - 1) / D::CB);
-    switch (k) {
-        case 1: launch_dw_k<T, 1>(a, s); break;
-        case 3: launch_dw_k<T, 3>(a, s); break;
-        case 5: launch_dw_k<T, 5>(a, s); break;
-        case 7: launch_dw_k<T, 7>(a, s); break;
-        case 9: launch_dw_k<T, 9>(a, s); break;
-        case 11: launch_dw_k<T, 11>(a, s); break;
-        case 13: launch_dw_k<T, 13>(a, s); break;
-        case 15: launch_dw_k<T, 15>(a, s); break;
-        default: return YMK_E_BADARG;
-    }
-    return ymk_launch_status();
+    return dw_tile_width(a.W) == 20 ? launch_dw_tw<T, 20>(a, k, s) : launch_dw_tw<T, 40>(a, k, s);
 }
 
 extern "C" int ymk_dwconv2d(int32_t dtype, const void* x, const void* w, const float* bias,
@@ -236,16 +267,16 @@ extern "C" int ymk_dwconv2d(int32_t dtype, const void* x, const void* w, const f
                             void* stream) {
     const int vec = dtype == YMK_BF16 ? 8 : 4;
     if (!x || !w || !y || ldx % vec || ldy % 4 || (residual && ldr % 4)) return YMK_E_BADARG;
-    DwArgs a{x, w, bias, residual, y, B, H, W, C, ldx, ldy, ldr, act, 0};
+    DwArgs a{x, w, bias, residual, y, B, H, W, C, ldx, ldy, ldr, act, 0, 0, 0};
     if (dtype == YMK_F32) return launch_dw<float>(a, ksize, (hipStream_t)stream);
     if (dtype == YMK_BF16) return launch_dw<bf16_t>(a, ksize, (hipStream_t)stream);
     return YMK_E_BADARG;
 }
 
 // ---------------------------------------------------------------------------
-// ES-MoE depthwise stage over the image->expert CSR.  blockIdx.y walks the CSR
-// pair list (grouped by expert, so neighbouring workgroups share a filter and a
-// stencil size); every workgroup of a pair takes the same switch arm.
+// ES-MoE depthwise stage: blockIdx.y is the (image, slot) pair; dropped slots (sel < 0) exit at once.  The
+// expert's stencil size selects the switch arm, the same for every workgroup of a pair.  (The image->expert CSR
+// of the router is not needed here: one dependent load — sel — instead of a chain of three.)
 // ---------------------------------------------------------------------------
 struct MoeDwArgs {
     const void* x;
@@ -253,53 +284,73 @@ struct MoeDwArgs {
     const int* dw_off;
     const int* ksizes;
     const int* sel;
-    const int* csr_off;
-    const int* csr_pair;
     void* out;
     int B, H, W, C, ldx, E, top_k;
+    int ncb, nsp, spt;
 };
 
-template <typename T>
+template <typename T, int TW, int KMAX>
 __global__ __launch_bounds__(256) void moe_dw_kernel(MoeDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int p = blockIdx.y;
-    if (p >= a.csr_off[a.E]) return;
-    const int pair = a.csr_pair[p];
+    const int pair = blockIdx.y;
     const int e = a.sel[pair];
     if (e < 0) return;
+    const int ks = a.ksizes[e];
+    const int woff = a.dw_off[e];
     const int b = pair / a.top_k;
     const size_t hw = (size_t)a.H * a.W;
     const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * hw * a.ldx;
-    const T* w = reinterpret_cast<const T*>(a.dw_w) + a.dw_off[e];
+    const T* w = reinterpret_cast<const T*>(a.dw_w) + woff;
     T* ob = reinterpret_cast<T*>(a.out) + (size_t)pair * hw * a.C;
     const DwEpi ep{nullptr, nullptr, 0, YMK_ACT_NONE};
-    const int tile = (int)xcd_remap_dw(blockIdx.x, gridDim.x);
-    switch (a.ksizes[e]) {
-        case 3: dw_tile<T, 3>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
-        case 5: dw_tile<T, 5>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
-        case 7: dw_tile<T, 7>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
-        case 9: dw_tile<T, 9>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
-        case 11: dw_tile<T, 11>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
-        case 13: dw_tile<T, 13>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
-        case 15: dw_tile<T, 15>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, tile, ep, nullptr, smem); break;
+    const int lid = (int)xcd_remap_dw(blockIdx.x, gridDim.x);
+    const int cb = lid % a.ncb, st0 = (lid / a.ncb) * a.spt, st1 = min(a.nsp, st0 + a.spt);
+    switch (ks) {
+        case 3: if constexpr (KMAX >= 3) dw_run<T, 3, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 5: if constexpr (KMAX >= 5) dw_run<T, 5, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 7: if constexpr (KMAX >= 7) dw_run<T, 7, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 9: if constexpr (KMAX >= 9) dw_run<T, 9, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 11: if constexpr (KMAX >= 11) dw_run<T, 11, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 13: if constexpr (KMAX >= 13) dw_run<T, 13, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 15: if constexpr (KMAX >= 15) dw_run<T, 15, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
         default: break;
+    }
+}
+
+// KMAX = largest stencil among the experts: larger switch arms are compiled out (the register allocation of the
+// kernel is the maximum over its arms, and it bounds the resident workgroups per CU)
+template <typename T, int TW, int KMAX>
+static int launch_moe_dw_k(MoeDwArgs a, hipStream_t s) {
+    const size_t shm = DwTile<T, TW>::lds_bytes(KMAX);
+    static bool attr_set = false;
+    if (shm > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_dw_kernel<T, TW, KMAX>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_set = true;
+    }
+    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, (int64_t)a.B * a.top_k);
+    a.ncb = g.ncb; a.nsp = g.nsp; a.spt = g.spt;
+    hipLaunchKernelGGL((moe_dw_kernel<T, TW, KMAX>), dim3(g.nrun * g.ncb, a.B * a.top_k), dim3(256), shm, s, a);
+    return ymk_launch_status();
+}
+
+template <typename T, int TW>
+static int launch_moe_dw_tw(const MoeDwArgs& a, int kmax, hipStream_t s) {
+    switch (kmax) {
+        case 1: case 3: return launch_moe_dw_k<T, TW, 3>(a, s);
+        case 5: return launch_moe_dw_k<T, TW, 5>(a, s);
+        case 7: return launch_moe_dw_k<T, TW, 7>(a, s);
+        case 9: return launch_moe_dw_k<T, TW, 9>(a, s);
+        case 11: return launch_moe_dw_k<T, TW, 11>(a, s);
+        case 13: return launch_moe_dw_k<T, TW, 13>(a, s);
+        default: return launch_moe_dw_k<T, TW, 15>(a, s);
     }
 }
 
 template <typename T>
 static int launch_moe_dw(const MoeDwArgs& a, int kmax, hipStream_t s) {
-    using D = DwTile<T>;
     if (a.C % (16 / (int)sizeof(T))) return YMK_E_BADARG;
-    const size_t shm = D::lds_bytes(kmax);
-    static size_t attr = 0;
-    if (shm > 64 * 1024 && shm > attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_dw_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)shm);
-        attr = shm;
-    }
-    const int tiles = ((a.H + DW_TH - 1) / DW_TH) * ((a.W + DW_TW - 1) / DW_TW) * ((a.C + D::CB - 1) / D::CB);
-    hipLaunchKernelGGL(moe_dw_kernel<T>, dim3(tiles, a.B * a.top_k), dim3(256), shm, s, a);
-    return ymk_launch_status();
+    return dw_tile_width(a.W) == 20 ? launch_moe_dw_tw<T, 20>(a, kmax, s) : launch_moe_dw_tw<T, 40>(a, kmax, s);
 }
 
 extern "C" int ymk_esmoe_dw(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
@@ -311,7 +362,7 @@ extern "C" int ymk_esmoe_dw(int32_t dtype, const void* x, int32_t B, int32_t H, 
     if (ldx % vec || E < 1 || top_k < 1 || kmax < 1 || kmax > 15 || (kmax & 1) == 0) return YMK_E_BADARG;
     if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
     if ((int64_t)B * top_k > 65535) return YMK_E_BADARG;
-    MoeDwArgs a{x, dw_w, dw_off, ksizes, sel, csr_off, csr_pair, dw_out, B, H, W, C, ldx, E, top_k};
+    MoeDwArgs a{x, dw_w, dw_off, ksizes, sel, dw_out, B, H, W, C, ldx, E, top_k, 0, 0, 0};
     if (dtype == YMK_F32) return launch_moe_dw<float>(a, kmax, (hipStream_t)stream);
     if (dtype == YMK_BF16) return launch_moe_dw<bf16_t>(a, kmax, (hipStream_t)stream);
     return YMK_E_BADARG;

@@ -110,21 +110,54 @@ extern "C" int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int3
 __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restrict__ box, const float* __restrict__ cls,
                                                            float* __restrict__ y, int Hl, int Wl, int reg_max, int nc,
                                                            float stride, int a_off, int A) {
-    extern __shared__ float sm[];  // cls tile [64][nc+1], dist [64][4]
+    extern __shared__ float sm[];  // cls tile [64][nc+1], dist [64][4], box tile [256][17] (reg_max == 16)
     const int HW = Hl * Wl;
     const int b = blockIdx.y;
     const int a0 = blockIdx.x * 64;
     const int t = threadIdx.x;
     float* scls = sm;
     float* sdist = sm + 64 * (nc + 1);
+    float* sbox = sdist + 64 * 4;
     const int na = min(64, HW - a0);
-    // class logits: coalesced read of na*nc floats
-    for (int i = t; i < na * nc; i += 256) {
-        const int r = i / nc, c = i - r * nc;
-        scls[r * (nc + 1) + c] = cls[((size_t)b * HW + a0) * nc + i];
+    // class logits: coalesced read of na*nc floats (16-byte loads when the row length allows)
+    const float* cb = cls + ((size_t)b * HW + a0) * nc;
+    if ((nc & 3) == 0) {
+        for (int i = t; i < na * nc / 4; i += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(cb)[i];
+            const int r = (4 * i) / nc, c = 4 * i - r * nc;  // nc % 4 == 0: the four values share a row
+            float* d = scls + r * (nc + 1) + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int i = t; i < na * nc; i += 256) {
+            const int r = i / nc, c = i - r * nc;
+            scls[r * (nc + 1) + c] = cb[i];
+        }
     }
     // DFL: thread (anchor r = t/4, side s = t%4) reduces reg_max bins
-    {
+    if (reg_max == 16) {
+        // the 64 x 64 box logits arrive coalesced and are re-read per (anchor, side) from LDS (row stride 17)
+        const float* bb = box + ((size_t)b * HW + a0) * 64;
+        for (int i = t; i < na * 16; i += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(bb)[i];
+            float* d = sbox + (i >> 2) * 17 + (i & 3) * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        if ((t >> 2) < na) {
+            float e[16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { e[i] = sbox[t * 17 + i]; mx = fmaxf(mx, e[i]); }
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { e[i] = expf(e[i] - mx); den += e[i]; }
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d += (float)i * (e[i] / den);
+            sdist[t] = d;
+        }
+    } else {
         const int r = t >> 2, s = t & 3;
         if (r < na) {
             const float* p = box + ((size_t)b * HW + a0 + r) * (4 * reg_max) + s * reg_max;
@@ -165,7 +198,7 @@ extern "C" int ymk_detect_decode(const float* box_l, const float* cls_l, float* 
     const int HW = Hl * Wl;
     if (B <= 0 || HW <= 0) return YMK_OK;
     if (B > 65535 || a_off + HW > A_total) return YMK_E_BADARG;
-    const size_t shm = (size_t)(64 * (nc + 1) + 64 * 4) * sizeof(float);
+    const size_t shm = (size_t)(64 * (nc + 1) + 64 * 4 + 256 * 17) * sizeof(float);
     if (shm > 64 * 1024) return YMK_E_BADARG;
     dim3 grid((HW + 63) / 64, B), blk(256);
     hipLaunchKernelGGL(detect_decode_kernel, grid, blk, shm, (hipStream_t)stream, box_l, cls_l, y, Hl, Wl, reg_max, nc,

@@ -4,48 +4,68 @@
 // nn/modules/_numeric.py:85-90 (stable_normalize).
 #include "igemm.h"
 
-#define RT_PIX 256     // pixels per partial-GAP workgroup
 #define RT_MAX_E 16
 #define RT_MAX_HID 256
 
+// pixels per partial-GAP workgroup: small maps are cut finer so that the launch still covers the chip
+static inline int rt_chunk_pixels(int HW) { return HW >= 4096 ? 256 : 64; }
+
 extern "C" size_t ymk_esmoe_route_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
-    const size_t chunks = ((size_t)H * W + RT_PIX - 1) / RT_PIX;
+    const int cp = rt_chunk_pixels(H * W);
+    const size_t chunks = ((size_t)H * W + cp - 1) / cp;
     return (size_t)B * chunks * C * sizeof(float);
 }
 
-// stage 1: deterministic partial global-average-pool sums + finite check of x
+// stage 1: deterministic partial global-average-pool sums + finite check of x.
+// A thread owns 16 bytes of channels and every rows-th pixel of the chunk; four independent loads are in
+// flight per thread, the adds keep a fixed order (thread-sequential, then row 0 adds rows 1.. in order).
 template <typename T>
-__global__ __launch_bounds__(256) void gap_partial_kernel(const T* __restrict__ x, int HW, int C, int ldx,
+__global__ __launch_bounds__(256) void gap_partial_kernel(const T* __restrict__ x, int HW, int C, int ldx, int cpix,
                                                          float* __restrict__ part, int* __restrict__ flags) {
-    __shared__ float red[256 * 4];
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ float red[256 * VEC];
     const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
-    const int nc4 = C / 4;
+    const int ncvt = C / VEC;
     const int t = threadIdx.x;
     bool bad = false;
-    for (int cv0 = 0; cv0 < nc4; cv0 += 256) {
-        const int ncv = min(256, nc4 - cv0);
+    for (int cv0 = 0; cv0 < ncvt; cv0 += 256) {
+        const int ncv = min(256, ncvt - cv0);
         const int rows = 256 / ncv;
         const int cv = t % ncv, pr = t / ncv;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        float s[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s[q] = 0.f;
         if (pr < rows) {
-            const int p1 = min(HW, (chunk + 1) * RT_PIX);
-            const T* base = x + ((size_t)b * HW) * ldx + (cv0 + cv) * 4;
-            for (int p = chunk * RT_PIX + pr; p < p1; p += rows) {
-                float v0, v1, v2, v3;
-                load4(base + (size_t)p * ldx, v0, v1, v2, v3);
-                s[0] += v0; s[1] += v1; s[2] += v2; s[3] += v3;
+            const int p1 = min(HW, (chunk + 1) * cpix);
+            const T* base = x + ((size_t)b * HW) * ldx + (cv0 + cv) * VEC;
+            int p = chunk * cpix + pr;
+            for (; p + 3 * rows < p1; p += 4 * rows) {
+                float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                load_vec_f32(base + (size_t)p * ldx, v0);
+                load_vec_f32(base + (size_t)(p + rows) * ldx, v1);
+                load_vec_f32(base + (size_t)(p + 2 * rows) * ldx, v2);
+                load_vec_f32(base + (size_t)(p + 3 * rows) * ldx, v3);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) { s[q] += v0[q]; s[q] += v1[q]; s[q] += v2[q]; s[q] += v3[q]; }
+            }
+            for (; p < p1; p += rows) {
+                float v0[VEC];
+                load_vec_f32(base + (size_t)p * ldx, v0);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) s[q] += v0[q];
             }
         }
-        bad |= !(isfinite(s[0]) && isfinite(s[1]) && isfinite(s[2]) && isfinite(s[3]));
-        red[t * 4 + 0] = s[0]; red[t * 4 + 1] = s[1]; red[t * 4 + 2] = s[2]; red[t * 4 + 3] = s[3];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) { bad |= !isfinite(s[q]); red[t * VEC + q] = s[q]; }
         __syncthreads();
         if (pr == 0) {
             for (int r = 1; r < rows; ++r) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s[q] += red[(r * ncv + cv) * 4 + q];
+                for (int q = 0; q < VEC; ++q) s[q] += red[(r * ncv + cv) * VEC + q];
             }
-            float* o = part + ((size_t)b * nchunk + chunk) * C + (cv0 + cv) * 4;
-            store4(o, s[0], s[1], s[2], s[3]);
+            float* o = part + ((size_t)b * nchunk + chunk) * C + (cv0 + cv) * VEC;
+#pragma unroll
+            for (int q = 0; q < VEC; q += 4) store4(o + q, s[q], s[q + 1], s[q + 2], s[q + 3]);
         }
         __syncthreads();
     }
@@ -68,14 +88,16 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
     float* logits = h + hidden;
     const int b = blockIdx.x, t = threadIdx.x;
     for (int c = t; c < C; c += 256) {
-        // fixed-order sum of the per-chunk partials; loads are issued four at a time (independent addresses)
+        // fixed-order sum of the per-chunk partials; sixteen independent loads are in flight at a time
         const float* pp = part + (size_t)b * nchunk * C + c;
         float s = 0.f;
         int k = 0;
-        for (; k + 4 <= nchunk; k += 4) {
-            const float v0 = pp[(size_t)k * C], v1 = pp[(size_t)(k + 1) * C], v2 = pp[(size_t)(k + 2) * C],
-                        v3 = pp[(size_t)(k + 3) * C];
-            s += v0; s += v1; s += v2; s += v3;
+        for (; k + 16 <= nchunk; k += 16) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = pp[(size_t)(k + q) * C];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += v[q];
         }
         for (; k < nchunk; ++k) s += pp[(size_t)k * C];
         pooled[c] = s / (float)HW;
@@ -194,21 +216,23 @@ extern "C" int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t 
                                size_t workspace_bytes, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !route_w || !gate_w || !sel || !csr_off || !csr_pair || !flags)
         return YMK_E_BADARG;
-    if (C % 4 || ldx % 4 || E < 1 || E > RT_MAX_E || top_k < 1 || top_k > E || hidden < 1 ||
+    const int vec = dtype == YMK_BF16 ? 8 : 4;
+    if (C % vec || ldx % vec || E < 1 || E > RT_MAX_E || top_k < 1 || top_k > E || hidden < 1 ||
         hidden > RT_MAX_HID)
         return YMK_E_BADARG;
     const int HW = H * W;
     if (B <= 0 || HW <= 0) return YMK_OK;
     if (B > 65535) return YMK_E_BADARG;
-    const int nchunk = (HW + RT_PIX - 1) / RT_PIX;
+    const int cpix = rt_chunk_pixels(HW);
+    const int nchunk = (HW + cpix - 1) / cpix;
     if (!workspace || workspace_bytes < ymk_esmoe_route_workspace_bytes(B, C, H, W)) return YMK_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)workspace;
     dim3 g1(nchunk, B), blk(256);
     if (dtype == YMK_F32)
-        hipLaunchKernelGGL(gap_partial_kernel<float>, g1, blk, 0, s, (const float*)x, HW, C, ldx, part, flags);
+        hipLaunchKernelGGL(gap_partial_kernel<float>, g1, blk, 0, s, (const float*)x, HW, C, ldx, cpix, part, flags);
     else if (dtype == YMK_BF16)
-        hipLaunchKernelGGL(gap_partial_kernel<bf16_t>, g1, blk, 0, s, (const bf16_t*)x, HW, C, ldx, part, flags);
+        hipLaunchKernelGGL(gap_partial_kernel<bf16_t>, g1, blk, 0, s, (const bf16_t*)x, HW, C, ldx, cpix, part, flags);
     else
         return YMK_E_BADARG;
     const size_t shm = (size_t)(C + hidden + E) * sizeof(float);

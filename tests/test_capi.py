@@ -34,7 +34,9 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in h.ymk_build_info()
     # pure host-side queries work without a GPU
     assert h.ymk_nms_workspace_bytes(2, 80, 8400, 0, 30000) > 0
-    assert h.ymk_esmoe_route_workspace_bytes(2, 128, 40, 40) == 2 * 7 * 128 * 4
+    # partial-GAP chunks: 64 pixels below 4096 pixels per image, 256 above
+    assert h.ymk_esmoe_route_workspace_bytes(2, 128, 40, 40) == 2 * 25 * 128 * 4
+    assert h.ymk_esmoe_route_workspace_bytes(2, 128, 80, 80) == 2 * 25 * 128 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):

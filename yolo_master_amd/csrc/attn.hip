@@ -13,8 +13,10 @@
 #define AT_KC 256
 #define AT_NT 256   // threads per workgroup: 4 waves x 16 queries (512 measured ~5% slower on the A2C2f layers)
 
-template <typename T>
-__global__ __launch_bounds__(AT_NT) void area_attn_kernel(const T* __restrict__ qkv, int ldq, T* __restrict__ out,
+// WPE: waves per SIMD the register allocation is held to (left alone the compiler takes ~280 registers and one
+// wave per SIMD; the kernel needs neighbours on the SIMD to overlap staging, softmax VALU and MFMA)
+template <typename T, int WPE>
+__global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void area_attn_kernel(const T* __restrict__ qkv, int ldq, T* __restrict__ out,
                                                        int ldo, int N, int Na, int heads, int area, float scale) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int NF = sizeof(T) == 2 ? 1 : 2;  // 16-byte fragments per 32-wide head row per lane
@@ -51,29 +53,31 @@ __global__ __launch_bounds__(AT_NT) void area_attn_kernel(const T* __restrict__ 
         __syncthreads();                   // previous chunk fully consumed
         // stage K (row-major [key][32]) and V (transposed [d][key])
         constexpr int CPR = 32 / VEC;              // 16-byte chunks per row
-        constexpr int NL = AT_KC * CPR / AT_NT;   // staged chunks per thread (K and V each)
-        u32x4 kreg[NL], vreg[NL];
+        {
+            constexpr int NL = AT_KC * CPR / AT_NT;   // staged chunks per thread (K and V each)
+            u32x4 kreg[NL], vreg[NL];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {            // all loads first (independent, in flight together)
-            const int i = t + l * AT_NT;
-            const int key = i / CPR, ch = i % CPR;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (key < kc) {
-                const T* p = base + (size_t)(tok0 + c0 + key) * ldq + h * 32 + ch * VEC;
-                kv = *reinterpret_cast<const u32x4*>(p + Cq);
-                vv = *reinterpret_cast<const u32x4*>(p + 2 * Cq);
+            for (int l = 0; l < NL; ++l) {            // all loads first (independent, in flight together)
+                const int i = t + l * AT_NT;
+                const int key = i / CPR, ch = i % CPR;
+                u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+                if (key < kc) {
+                    const T* p = base + (size_t)(tok0 + c0 + key) * ldq + h * 32 + ch * VEC;
+                    kv = *reinterpret_cast<const u32x4*>(p + Cq);
+                    vv = *reinterpret_cast<const u32x4*>(p + 2 * Cq);
+                }
+                kreg[l] = kv; vreg[l] = vv;
             }
-            kreg[l] = kv; vreg[l] = vv;
-        }
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const int i = t + l * AT_NT;
-            const int key = i / CPR, ch = i % CPR;
-            if (key < kc32) {
-                *reinterpret_cast<u32x4*>(&sK[key * 32 + ch * VEC]) = kreg[l];
-                const T* ve = reinterpret_cast<const T*>(&vreg[l]);
+            for (int l = 0; l < NL; ++l) {
+                const int i = t + l * AT_NT;
+                const int key = i / CPR, ch = i % CPR;
+                if (key < kc32) {
+                    *reinterpret_cast<u32x4*>(&sK[key * 32 + ch * VEC]) = kreg[l];
+                    const T* ve = reinterpret_cast<const T*>(&vreg[l]);
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) sVt[(ch * VEC + q) * VPAD + key] = ve[q];
+                    for (int q = 0; q < VEC; ++q) sVt[(ch * VEC + q) * VPAD + key] = ve[q];
+                }
             }
         }
         __syncthreads();
@@ -82,6 +86,9 @@ __global__ __launch_bounds__(AT_NT) void area_attn_kernel(const T* __restrict__ 
         const int ntile = kc32 / 16;
         f32x4 sacc[AT_KC / 16];
         float cmax = -INFINITY;
+        // bf16 path: scores stay unscaled; scale * log2(e) is folded into the one FMA that feeds v_exp_f32
+        // (p = 2^((s - m) * c)), and the key-validity mask is applied only to tiles that reach past kc
+        const float c2 = scale * 1.4426950408889634f;
 #pragma unroll
         for (int tk = 0; tk < AT_KC / 16; ++tk) {
             if (tk < ntile) {
@@ -91,11 +98,14 @@ __global__ __launch_bounds__(AT_NT) void area_attn_kernel(const T* __restrict__ 
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(&sK[(tk * 16 + fi) * 32 + f * 16 + g * VEC]);
                     mma16<T>(acc, kf, qf[f]);
                 }
-                const int key0 = tk * 16 + g * 4;
-                acc.x = key0 + 0 < kc ? acc.x * scale : -INFINITY;
-                acc.y = key0 + 1 < kc ? acc.y * scale : -INFINITY;
-                acc.z = key0 + 2 < kc ? acc.z * scale : -INFINITY;
-                acc.w = key0 + 3 < kc ? acc.w * scale : -INFINITY;
+                if (PRECISE) acc *= scale;
+                if (tk * 16 + 16 > kc) {  // wave-uniform: only the zero-padded tail tiles
+                    const int key0 = tk * 16 + g * 4;
+                    acc.x = key0 + 0 < kc ? acc.x : -INFINITY;
+                    acc.y = key0 + 1 < kc ? acc.y : -INFINITY;
+                    acc.z = key0 + 2 < kc ? acc.z : -INFINITY;
+                    acc.w = key0 + 3 < kc ? acc.w : -INFINITY;
+                }
                 cmax = fmaxf(cmax, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
                 sacc[tk] = acc;
             }
@@ -103,7 +113,8 @@ __global__ __launch_bounds__(AT_NT) void area_attn_kernel(const T* __restrict__ 
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
         const float mnew = fmaxf(mrun, cmax);  // finite: every chunk has >= 1 valid key
-        const float resc = PRECISE ? expf(mrun - mnew) : __expf(mrun - mnew);
+        const float resc = PRECISE ? expf(mrun - mnew) : __builtin_amdgcn_exp2f((mrun - mnew) * c2);
+        const float nmc = -mnew * c2;
         mrun = mnew;
         lrun *= resc;
         o[0] *= resc;
@@ -116,7 +127,8 @@ __global__ __launch_bounds__(AT_NT) void area_attn_kernel(const T* __restrict__ 
                 if (PRECISE) {
                     p.x = expf(p.x - mnew); p.y = expf(p.y - mnew); p.z = expf(p.z - mnew); p.w = expf(p.w - mnew);
                 } else {
-                    p.x = __expf(p.x - mnew); p.y = __expf(p.y - mnew); p.z = __expf(p.z - mnew); p.w = __expf(p.w - mnew);
+                    p.x = __builtin_amdgcn_exp2f(fmaf(p.x, c2, nmc)); p.y = __builtin_amdgcn_exp2f(fmaf(p.y, c2, nmc));
+                    p.z = __builtin_amdgcn_exp2f(fmaf(p.z, c2, nmc)); p.w = __builtin_amdgcn_exp2f(fmaf(p.w, c2, nmc));
                 }
                 lsum += (p.x + p.y) + (p.z + p.w);
                 sacc[tk] = p;
@@ -181,11 +193,11 @@ extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* 
     const float scale = 0.17677669529663687f;  // 32^-0.5
     hipStream_t s = (hipStream_t)stream;
     if (dtype == YMK_F32)
-        hipLaunchKernelGGL(area_attn_kernel<float>, grid, blk, 0, s, (const float*)qkv, ldq, (float*)out, ldo, N, Na,
+        hipLaunchKernelGGL((area_attn_kernel<float, 1>), grid, blk, 0, s, (const float*)qkv, ldq, (float*)out, ldo, N, Na,
                            heads, area, scale);
     else if (dtype == YMK_BF16)
-        hipLaunchKernelGGL(area_attn_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N,
-                           Na, heads, area, scale);
+        hipLaunchKernelGGL((area_attn_kernel<bf16_t, 3>), grid, blk, 0, s, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, Na, heads, area,
+                           scale);   // 3 waves per SIMD measured best (4: small spill, 1: 2x slower)
     else
         return YMK_E_BADARG;
     return ymk_launch_status();

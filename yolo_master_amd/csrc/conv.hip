@@ -276,8 +276,11 @@ static bool launch_conv1x1_ws(ConvArgs a, hipStream_t s) {
 // and bounds arithmetic, no barriers inside the K loop.  The next tile's halo is prefetched into registers
 // while the current tile is multiplied and stored.
 // ---------------------------------------------------------------------------
-template <typename T, int CIN, int BCO>
-__global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
+// register allocation held to two waves per SIMD wherever the LDS footprint lets two workgroups share a CU
+template <typename T, int CIN, int BCO, bool RES>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu((18 * 18 * (CIN * (int)sizeof(T) + 16) + BCO * (9 * CIN * (int)sizeof(T) + 16)) <= 80 * 1024 ? 2 : 1)))
+void conv3x3_tile_kernel(ConvArgs a) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int CPP = CIN / VEC;                      // 16-byte chunks per pixel
     constexpr int PSB = CIN * (int)sizeof(T) + 16;      // padded pixel stride (bytes)
@@ -346,6 +349,22 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
         __syncthreads();
         const int64_t nxt = tile + (int64_t)DEPTH * nblk_px;
         if (nxt < ntiles) gload(nxt, buf);  // refill the buffer just consumed
+        const int b = (int)(tile / tpi), tl = (int)(tile % tpi);
+        const int ty0 = (tl / tiles_x) * 16, tx0 = (tl % tiles_x) * 16;
+        // residual operands of this tile: requested now, consumed after the MFMA loop
+        typename Raw4<T>::type rres[RES ? TM : 1][4];
+        if constexpr (RES) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gy = ty0 + wave * 4 + j, gx = tx0 + fr;
+                const int64_t m = ((int64_t)b * a.H + gy) * a.W + gx;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int co = co0 + i * 16 + fc * 4;
+                    if (gy < a.H && gx < a.W && co < a.Cout) rres[i][j] = load_raw4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co);
+                }
+            }
+        }
         f32x4 acc[TM][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -394,8 +413,6 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
                     for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
             }
         }
-        const int b = (int)(tile / tpi), tl = (int)(tile % tpi);
-        const int ty0 = (tl / tiles_x) * 16, tx0 = (tl % tiles_x) * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int gy = ty0 + wave * 4 + j, gx = tx0 + fr;
@@ -411,7 +428,11 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a) {
                     v[r] = acc[i][j][r] + bv[i][r];
                     if (silu) v[r] = act_silu<T, PRECISE>(v[r]);
                 }
-                if (a.res) {
+                if constexpr (RES) {
+                    float r0, r1, r2, r3;
+                    unpack_raw4(rres[i][j], r0, r1, r2, r3);
+                    v[0] = r0 + v[0]; v[1] = r1 + v[1]; v[2] = r2 + v[2]; v[3] = r3 + v[3];
+                } else if (a.res) {
                     float r0, r1, r2, r3;
                     load4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co, r0, r1, r2, r3);
                     v[0] = r0 + v[0]; v[1] = r1 + v[1]; v[2] = r2 + v[2]; v[3] = r3 + v[3];
@@ -456,15 +477,19 @@ static bool launch_conv3x3_tile(ConvArgs a, hipStream_t s) {
         if (nblk > ntiles) nblk = ntiles;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, s, a);
     };
-    if (a.Cin == 16) go(conv3x3_tile_kernel<T, 16, 32>);
-    else if (a.Cin == 32 && bco == 32) go(conv3x3_tile_kernel<T, 32, 32>);
-    else if (a.Cin == 32) go(conv3x3_tile_kernel<T, 32, 64>);
+    // residual variant: operands prefetched into registers (costs occupancy)
+    const bool r = a.res != nullptr && !(ymk_disabled() & YMK_OFF_RES_PREFETCH);
+#define YMK_TILE(CI, BC) (r ? go(conv3x3_tile_kernel<T, CI, BC, true>) : go(conv3x3_tile_kernel<T, CI, BC, false>))
+    if (a.Cin == 16) YMK_TILE(16, 32);
+    else if (a.Cin == 32 && bco == 32) YMK_TILE(32, 32);
+    else if (a.Cin == 32) YMK_TILE(32, 64);
     else if constexpr (sizeof(T) == 2) {  // Cin = 64 tiles fit the 160 KB LDS only in bf16
-        if (bco == 32) go(conv3x3_tile_kernel<T, 64, 32>);
-        else go(conv3x3_tile_kernel<T, 64, 64>);
+        if (bco == 32) YMK_TILE(64, 32);
+        else YMK_TILE(64, 64);
     } else {
         return false;
     }
+#undef YMK_TILE
     return true;
 }
 

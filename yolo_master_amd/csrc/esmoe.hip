@@ -261,7 +261,7 @@ struct MoePwArgs {
 };
 
 template <typename T, int BCO, int BPX, int WCO, int WPX>
-__global__ __launch_bounds__(256) void moe_pw_kernel(MoePwArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void moe_pw_kernel(MoePwArgs a) {
     using G = IGemm<T, BCO, BPX, WCO, WPX, 1>;
     __shared__ u32x4 smem[G::SMEM_U4];
     const int t = threadIdx.x;

@@ -84,6 +84,18 @@ __device__ __forceinline__ void load4(const bf16_t* p, float& a, float& b, float
     u32x2 t = *reinterpret_cast<const u32x2*>(p);
     a = bf16lo(t.x); b = bf16hi(t.x); c = bf16lo(t.y); d = bf16hi(t.y);
 }
+// 4 consecutive channels as raw bits (register prefetch of residual operands) and their later widening
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <> struct Raw4<bf16_t> { typedef u32x2 type; };
+__device__ __forceinline__ f32x4 load_raw4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ u32x2 load_raw4(const bf16_t* p) { return *reinterpret_cast<const u32x2*>(p); }
+__device__ __forceinline__ void unpack_raw4(const f32x4& t, float& a, float& b, float& c, float& d) {
+    a = t.x; b = t.y; c = t.z; d = t.w;
+}
+__device__ __forceinline__ void unpack_raw4(const u32x2& t, float& a, float& b, float& c, float& d) {
+    a = bf16lo(t.x); b = bf16hi(t.x); c = bf16lo(t.y); d = bf16hi(t.y);
+}
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
 __device__ __forceinline__ void from_f32(float& d, float v) { d = v; }
@@ -99,6 +111,7 @@ static inline int ymk_launch_status() {
 #define YMK_OFF_MOE_STREAM 2u    // streaming ES-MoE pointwise stage -> tiled grouped GEMM
 #define YMK_OFF_NMS_SORT 4u      // LDS bitonic candidate sort -> rank-by-counting
 #define YMK_OFF_STEM_FAST 8u     // fp32-MFMA stem -> one pixel per thread on the VALU
+#define YMK_OFF_RES_PREFETCH 16u  // register prefetch of residual operands in the spatial-tile 3x3 kernel
 static inline unsigned ymk_disabled() {
     static const unsigned m = [] {
         const char* s = getenv("YMK_DISABLE");

@@ -18,7 +18,8 @@ struct ConvArgs {
 };
 
 static int ymk_use_ws = 1;          // tools/micro can switch the streaming 1x1 kernel off for A/B runs
-static int ymk_ws_min_tiles = 1024;  // smallest pixel-tile count routed to the streaming kernel
+// smallest pixel-tile count routed to the streaming kernel (YMK_WS_MIN_TILES overrides it for tuning runs)
+static int ymk_ws_min_tiles = [] { const char* e = getenv("YMK_WS_MIN_TILES"); return e ? atoi(e) : 1024; }();
 extern "C" void ymk_debug_set_ws(int on) { ymk_use_ws = on; }
 static thread_local int ymk_last_variant = YMK_CONV_TILED;
 extern "C" int32_t ymk_conv2d_last_variant(void) { return ymk_last_variant; }

@@ -94,15 +94,21 @@ def test_mfma_layout_asymmetric(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_stem(dtype):
+@pytest.mark.parametrize("shape", [(2, 64, 48, 16, True),    # W % 4 == 0: LDS-staged rows kernel
+                                   (3, 70, 52, 32, True),    # ragged row blocks (Ho = 35), Cout 32
+                                   (2, 33, 30, 16, True),    # W % 4 != 0: direct-gather MFMA kernel
+                                   (2, 64, 48, 16, False)])  # no K-major weights: generic VALU kernel
+def test_stem(dtype, shape):
     from yolo_master_amd import ops
 
-    x = torch.rand(2, 3, 64, 48, generator=torch.Generator().manual_seed(5))
-    w = rnd(16, 3, 3, 3, seed=6, scale=0.3)
-    b = rnd(16, seed=7, scale=0.1)
+    B, H, W, co, kmajor = shape
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(5))
+    w = rnd(co, 3, 3, 3, seed=6, scale=0.3)
+    b = rnd(co, seed=7, scale=0.1)
     ref = F.silu(F.conv2d(x, w, b, 2, 1))
-    wp = w.permute(0, 2, 3, 1).reshape(16, -1).contiguous().to(DEV)
-    y = ops.conv2d_stem(x.to(DEV), wp, b.to(DEV), 3, 2, True, dtype)
+    wp = w.permute(0, 2, 3, 1).reshape(co, -1).contiguous().to(DEV)   # [Cout][(ky,kx,c)]
+    wt = wp.t().contiguous() if kmajor else None                       # [(ky,kx,c)][Cout]
+    y = ops.conv2d_stem(x.to(DEV), wp, b.to(DEV), 3, 2, True, dtype, wt=wt)
     assert_close(nchw(y), ref, dtype, "stem conv")
 
 

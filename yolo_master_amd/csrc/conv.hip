@@ -779,6 +779,130 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     }
 }
 
+
+// Stem, LDS-staged: a workgroup produces 4 consecutive output rows of one image (one per wave).  The
+// (3*stride + ks) input rows x Cin channel planes they need are copied from the NCHW fp32 image into LDS with
+// coalesced 16-byte loads (all of a thread's loads in flight together), with a zero column band left and right and
+// zero rows above/below the image, so the per-tap gathers of the MFMA pixel operand are unconditional 4-byte LDS
+// reads.  Arithmetic identical to stem_mfma_kernel (fp32 matrix cores, weights resident in registers).
+#define STEM_OR 4     // output rows per workgroup
+#define STEM_XP 4     // zero columns on each side of a staged row
+template <typename TO, int CO>
+__global__ __launch_bounds__(256) void stem_rows_kernel(const float* __restrict__ x, const float* __restrict__ wt /*[K][CO]*/,
+                                                         const float* __restrict__ bias, TO* __restrict__ y, int B, int Cin,
+                                                         int H, int W, int Ho, int Wo, int ks, int stride, int ldy, int act) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];  // [Cin][R][W + 2*STEM_XP]
+    constexpr int TM = CO / 16;
+    constexpr bool PRECISE = sizeof(TO) == 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int rblk = (Ho + STEM_OR - 1) / STEM_OR;
+    const int b = blockIdx.x / rblk, oy0 = (blockIdx.x % rblk) * STEM_OR;
+    const int K = ks * ks * Cin, pad = ks / 2;
+    const int R = (STEM_OR - 1) * stride + ks;
+    const int WP = W + 2 * STEM_XP, W4 = W >> 2;
+    const float* xb = x + (size_t)b * Cin * H * W;
+
+    // stage: zero bands, then the rows
+    for (int i = t; i < Cin * R * 2 * STEM_XP; i += 256) {
+        const int rr = i / (2 * STEM_XP), j = i % (2 * STEM_XP);
+        srow[rr * WP + (j < STEM_XP ? j : W + j)] = 0.f;
+    }
+    const int nchunk = Cin * R * W4;
+    constexpr int NB = 18;
+    for (int q0 = 0; q0 < nchunk; q0 += 256 * NB) {
+        f32x4 v[NB];
+#pragma unroll
+        for (int l = 0; l < NB; ++l) {
+            const int q = q0 + l * 256 + t;
+            v[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < nchunk) {
+                const int rr = q / W4, xq = q - rr * W4;
+                const int c = rr / R, r = rr - c * R;
+                const int iy = oy0 * stride - pad + r;
+                if ((unsigned)iy < (unsigned)H) v[l] = *reinterpret_cast<const f32x4*>(xb + ((size_t)c * H + iy) * W + xq * 4);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NB; ++l) {
+            const int q = q0 + l * 256 + t;
+            if (q < nchunk) {
+                const int rr = q / W4, xq = q - rr * W4;
+                *reinterpret_cast<f32x4*>(srow + rr * WP + STEM_XP + xq * 4) = v[l];
+            }
+        }
+    }
+    // weights / tap table (see stem_mfma_kernel): k = kk*16 + fc*4 + v -> (ky, kx, c)
+    u32x4 af[TM][2];
+    int off[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = (q >> 2) * 16 + fc * 4 + (q & 3);
+        const int kc = k < K ? k : 0;
+        const int tap = kc / Cin, c = kc - tap * Cin;
+        const int ky = tap / ks, kx = tap - ky * ks;
+        off[q] = (c * R + wave * stride + ky) * WP + kx + STEM_XP - pad;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float wv = k < K ? wt[k * CO + i * 16 + fr] : 0.f;
+            reinterpret_cast<float*>(&af[i][q >> 2])[q & 3] = wv;
+        }
+    }
+    f32x4 bv[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bv[i] = *reinterpret_cast<const f32x4*>(bias + i * 16 + fc * 4);
+    __syncthreads();
+    const int oy = oy0 + wave;
+    if (oy >= Ho) return;
+    TO* yrow = y + ((size_t)b * Ho + oy) * Wo * ldy;
+    for (int ox0 = 0; ox0 < Wo; ox0 += 16) {
+        const int ox = ox0 + fr;
+        const int oxc = ox < Wo ? ox : Wo - 1;   // clamp the read, skip the store
+        u32x4 bf[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) reinterpret_cast<float*>(&bf[q >> 2])[q & 3] = srow[off[q] + oxc * stride];
+        f32x4 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            acc[i] = bv[i];
+            mma16<float>(acc[i], af[i][0], bf[0]);
+            mma16<float>(acc[i], af[i][1], bf[1]);
+        }
+        if (ox < Wo) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float v0 = acc[i].x, v1 = acc[i].y, v2 = acc[i].z, v3 = acc[i].w;
+                if (act == YMK_ACT_SILU) {
+                    if (PRECISE) { v0 = silu_exact(v0); v1 = silu_exact(v1); v2 = silu_exact(v2); v3 = silu_exact(v3); }
+                    else { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                }
+                store4(yrow + (size_t)ox * ldy + i * 16 + fc * 4, v0, v1, v2, v3);
+            }
+        }
+    }
+}
+
+template <typename TO, int CO>
+static bool launch_stem_rows(const float* x, const float* wt, const float* bias, void* y, int B, int Cin, int H, int W, int Ho,
+                             int Wo, int ks, int stride, int ldy, int act, hipStream_t s) {
+    const int R = (STEM_OR - 1) * stride + ks;
+    const size_t shm = (size_t)Cin * R * (W + 2 * STEM_XP) * sizeof(float);
+    // reads reach column (Wo-1)*stride + ks-1 - pad + STEM_XP of a staged row: must stay inside W + 2*STEM_XP
+    if ((W & 3) || ks / 2 > STEM_XP || (Wo - 1) * stride + ks - 1 - ks / 2 + STEM_XP >= W + 2 * STEM_XP || shm > 150 * 1024 ||
+        ((uintptr_t)x & 15))
+        return false;
+    static size_t attr = 0;
+    if (shm > 64 * 1024 && shm > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_rows_kernel<TO, CO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr = shm;
+    }
+    const int rblk = (Ho + STEM_OR - 1) / STEM_OR;
+    hipLaunchKernelGGL((stem_rows_kernel<TO, CO>), dim3((unsigned)(B * rblk)), dim3(256), shm, s, x, wt, bias, (TO*)y, B, Cin, H,
+                       W, Ho, Wo, ks, stride, ldy, act);
+    return true;
+}
+
 template <typename TO, int CO>
 static void launch_stem_mfma(const float* x, const float* wt, const float* bias, void* y, int B, int Cin, int H, int W, int Ho,
                              int Wo, int ks, int stride, int ldy, int act, hipStream_t s) {
@@ -812,6 +936,14 @@ extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float*
     if (wt_kco && (Cout == 16 || Cout == 32 || Cout == 64) && (out_dtype == YMK_F32 || out_dtype == YMK_BF16)) {
         const bool f = out_dtype == YMK_F32;
         if (ksize * ksize * Cin <= 32 && (int64_t)Cin * H * W < (1ll << 30) && !(ymk_disabled() & YMK_OFF_STEM_FAST)) {
+            if (!(ymk_disabled() & YMK_OFF_STEM_ROWS)) {  // LDS-staged rows when the geometry allows
+#define YMK_STEM_R(CO)                                                                                              \
+    (f ? launch_stem_rows<float, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s)         \
+       : launch_stem_rows<bf16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
+                const bool done = Cout == 16 ? YMK_STEM_R(16) : Cout == 32 ? YMK_STEM_R(32) : YMK_STEM_R(64);
+#undef YMK_STEM_R
+                if (done) return ymk_launch_status();
+            }
 #define YMK_STEM_M(CO)                                                                                              \
     (f ? launch_stem_mfma<float, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s)         \
        : launch_stem_mfma<bf16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))

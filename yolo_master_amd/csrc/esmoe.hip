@@ -104,12 +104,23 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
     }
     __syncthreads();
     const int lane = t & 63, wave = t >> 6;
-    for (int j = wave; j < hidden; j += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)j * C + c], pooled[c], s);
+    // four hidden units per wave at a time: their weight rows are independent loads in flight together (one unit
+    // at a time exposes a global-load latency per unit); per-unit arithmetic order is unchanged
+    for (int j0 = wave * 4; j0 < hidden; j0 += 16) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < C; c += 64) {
+            const float pc = pooled[c];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) h[j] = silu_exact(s + b1[j]);
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < hidden) s4[u] = fmaf(w1[(size_t)(j0 + u) * C + c], pc, s4[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float s = s4[u];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0 && j0 + u < hidden) h[j0 + u] = silu_exact(s + b1[j0 + u]);
+        }
     }
     __syncthreads();
     if (t < E) {

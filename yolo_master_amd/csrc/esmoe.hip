@@ -82,11 +82,15 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int hidden, int E,
     int top_k, float thr, float* __restrict__ route_w, float* __restrict__ gate_w, int* __restrict__ sel,
     int* __restrict__ flags) {
-    extern __shared__ float sm[];  // pooled[C], h[hidden], logits[E]
+    extern __shared__ float sm[];  // pooled[C], h[hidden], logits[E], w2[E][hidden]
     float* pooled = sm;
     float* h = sm + C;
     float* logits = h + hidden;
+    float* sw2 = logits + E;
     const int b = blockIdx.x, t = threadIdx.x;
+    // second-layer weights: fetched by all threads up front (the per-expert dot product below is a sequential
+    // fmaf chain in a fixed order; reading it from global memory costs one exposed L2 round trip per term)
+    for (int i = t; i < E * hidden; i += 256) sw2[i] = w2[i];
     for (int c = t; c < C; c += 256) {
         // fixed-order sum of the per-chunk partials; sixteen independent loads are in flight at a time
         const float* pp = part + (size_t)b * nchunk * C + c;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
     __syncthreads();
     if (t < E) {
         float s = 0.f;
-        for (int j = 0; j < hidden; ++j) s = fmaf(w2[t * hidden + j], h[j], s);
+        for (int j = 0; j < hidden; ++j) s = fmaf(sw2[t * hidden + j], h[j], s);
         logits[t] = s + b2[t];
     }
     __syncthreads();
@@ -246,7 +250,7 @@ extern "C" int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t 
         hipLaunchKernelGGL(gap_partial_kernel<bf16_t>, g1, blk, 0, s, (const bf16_t*)x, HW, C, ldx, cpix, part, flags);
     else
         return YMK_E_BADARG;
-    const size_t shm = (size_t)(C + hidden + E) * sizeof(float);
+    const size_t shm = (size_t)(C + hidden + E + E * hidden) * sizeof(float);
     hipLaunchKernelGGL(route_finalize_kernel, dim3(B), blk, shm, s, part, nchunk, HW, C, w1, b1, w2, b2, hidden,
                        E, top_k, dynamic_threshold, route_w, gate_w, sel, flags);
     hipLaunchKernelGGL(route_csr_kernel, dim3(1), dim3(64), 0, s, sel, B, E, top_k, csr_off, csr_pair);

@@ -196,6 +196,10 @@ int ymk_upsample2x(int32_t dtype, const void* x, void* y, int32_t B, int32_t H, 
 /* channel-slice copy (Concat.forward conv.py:629-641 when a producer could not write in place) */
 int ymk_copy_channels(int32_t dtype, const void* x, void* y, int64_t npix, int32_t C, int32_t ldx,
                       int32_t ldy, void* stream);
+/* out = residual + gamma[c] * y, per channel: the gamma-residual that closes A2C2f at the l/x scales
+ * (ultralytics/nn/modules/block.py:1877-1879; gamma fp32 [C]); out may alias y or residual */
+int ymk_scale_residual(int32_t dtype, const void* y, const float* gamma, const void* residual, void* out,
+                       int64_t npix, int32_t C, int32_t ldy, int32_t ldr, int32_t ldo, void* stream);
 /* NHWC (any ld) -> dense NCHW fp32, for the module-level API and feature taps */
 int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int32_t HW, int32_t C,
                          int32_t ldx, void* stream);

@@ -169,13 +169,17 @@ def test_c3k2_block(c3k, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("area,hw", [(4, (20, 20)), (1, (10, 12)), (4, (4, 4))])
-def test_a2c2f_block(area, hw, dtype):
+@pytest.mark.parametrize("area,hw,residual", [(4, (20, 20), False), (1, (10, 12), False), (4, (4, 4), False),
+                                               (4, (8, 12), True)])   # l/x scales: gamma-residual, mlp_ratio 1.2
+def test_a2c2f_block(area, hw, residual, dtype):
     from oracle import model_ref
     from yolo_master_amd.nn.modules import A2C2f
 
-    m = A2C2f(128, 128, 2, True, area)
+    m = A2C2f(128, 128, 2, True, area, residual, 1.2 if residual else 2.0)
     sd = module_sd(m)
+    if residual:
+        sd["model.0.gamma"] = 0.5 + rnd(128, seed=21, scale=0.2)   # the 0.01 init would hide the branch
+        m.load_state_dict({k[len("model.0."):]: v for k, v in sd.items()})
     x = rnd(2, 128, *hw, seed=10)
     with torch.inference_mode():
         ref = model_ref.a2c2f(sd, "model.0", _prep(x, dtype), area)

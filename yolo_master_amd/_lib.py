@@ -61,6 +61,7 @@ SYMBOLS = {
     "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_upsample2x": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_copy_channels": (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "ymk_scale_residual": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _i32, _vp]),
     "ymk_nhwc_to_nchw_f32": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ymk_detect_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "ymk_nms_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),

@@ -68,6 +68,48 @@ extern "C" int ymk_copy_channels(int32_t dtype, const void* x, void* y, int64_t 
     return ymk_launch_status();
 }
 
+// ---- gamma-residual of A2C2f at the l/x scales (block.py:1877-1879): out = res + gamma[c] * y --------------
+// Reference op order: the product is rounded, then the sum (this file is compiled with -ffp-contract=off).
+template <typename T>
+__global__ __launch_bounds__(256) void scale_residual_kernel(const T* __restrict__ yv, const float* __restrict__ gamma,
+                                                            const T* __restrict__ res, T* __restrict__ out, int64_t npix,
+                                                            int C, int ldy, int ldr, int ldo) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC;
+    const int64_t total = npix * ncv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % ncv);
+        const int64_t p = i / ncv;
+        float a[VEC], r[VEC];
+        load_vec_f32(yv + p * ldy + cv * VEC, a);
+        load_vec_f32(res + p * ldr + cv * VEC, r);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const float prod = gamma[cv * VEC + q] * a[q];
+            a[q] = r[q] + prod;
+        }
+        store_vec_f32(out + p * ldo + cv * VEC, a);
+    }
+}
+
+extern "C" int ymk_scale_residual(int32_t dtype, const void* y, const float* gamma, const void* residual, void* out,
+                                  int64_t npix, int32_t C, int32_t ldy, int32_t ldr, int32_t ldo, void* stream) {
+    const int vec = dtype == YMK_BF16 ? 8 : 4;
+    if (!y || !gamma || !residual || !out || (dtype != YMK_F32 && dtype != YMK_BF16) || C % vec || ldy % vec || ldr % vec ||
+        ldo % vec)
+        return YMK_E_BADARG;
+    const int64_t total = npix * (C / vec);
+    if (total <= 0) return YMK_OK;
+    const int blocks = (int)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
+    if (dtype == YMK_F32)
+        hipLaunchKernelGGL(scale_residual_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)y,
+                           gamma, (const float*)residual, (float*)out, npix, C, ldy, ldr, ldo);
+    else
+        hipLaunchKernelGGL(scale_residual_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+                           gamma, (const bf16_t*)residual, (bf16_t*)out, npix, C, ldy, ldr, ldo);
+    return ymk_launch_status();
+}
+
 // ---- NHWC -> NCHW fp32 via a 64x64 LDS transpose tile -------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int HW, int C,

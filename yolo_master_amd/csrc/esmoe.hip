@@ -112,7 +112,21 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
     // at a time exposes a global-load latency per unit); per-unit arithmetic order is unchanged
     for (int j0 = wave * 4; j0 < hidden; j0 += 16) {
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = lane; c < C; c += 64) {
+        int c = lane;
+        for (; c + 192 < C; c += 256) {   // four column steps x four units = 16 independent loads in flight
+            float wv[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wv[q][u] = j0 + u < hidden ? w1[(size_t)(j0 + u) * C + c + q * 64] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float pc = pooled[c + q * 64];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s4[u] = fmaf(wv[q][u], pc, s4[u]);
+            }
+        }
+        for (; c < C; c += 64) {
             const float pc = pooled[c];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -133,8 +147,11 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
         logits[t] = s + b2[t];
     }
     __syncthreads();
+    // the serial decision tail indexes its small arrays dynamically: kept in LDS (as private arrays they would live in
+    // scratch memory and every access would be a dependent global round trip)
+    __shared__ float p[RT_MAX_E], rw[RT_MAX_E];
+    __shared__ int idx[RT_MAX_E], used[RT_MAX_E], keep[RT_MAX_E];
     if (t == 0) {
-        float p[RT_MAX_E];
         bool fin = true;
         float mx = -INFINITY;
         for (int e = 0; e < E; ++e) {
@@ -147,27 +164,23 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
         for (int e = 0; e < E; ++e) { p[e] = expf(p[e] - mx); den += p[e]; }
         for (int e = 0; e < E; ++e) p[e] = p[e] / den;
         // hard top-k (descending, ties -> lower index), renormalised over the selected set
-        int idx[RT_MAX_E];
-        bool used[RT_MAX_E];
-        for (int e = 0; e < E; ++e) used[e] = false;
+        for (int e = 0; e < E; ++e) used[e] = 0;
         float vsum = 0.f;
         for (int k = 0; k < top_k; ++k) {
             int best = -1;
             for (int e = 0; e < E; ++e)
                 if (!used[e] && (best < 0 || p[e] > p[best])) best = e;
-            used[best] = true;
+            used[best] = 1;
             idx[k] = best;
             vsum += p[best];
         }
         vsum = fmaxf(vsum, 1e-6f);
-        float rw[RT_MAX_E];
         for (int e = 0; e < E; ++e) rw[e] = 0.f;
         for (int k = 0; k < top_k; ++k) rw[idx[k]] = p[idx[k]] / vsum;
         // sparse dispatch decision (modules.py:665-684): importance == rw (spatially constant)
-        bool keep[RT_MAX_E];
-        for (int e = 0; e < E; ++e) keep[e] = false;
+        for (int e = 0; e < E; ++e) keep[e] = 0;
         if (top_k >= E) {
-            for (int e = 0; e < E; ++e) keep[e] = true;  // dense path: every expert, unpruned
+            for (int e = 0; e < E; ++e) keep[e] = 1;  // dense path: every expert, unpruned
         } else {
             for (int k = 0; k < top_k; ++k)
                 keep[idx[k]] = (k == 0) || !(thr > 0.f) || (rw[idx[k]] >= thr);

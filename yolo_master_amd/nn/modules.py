@@ -147,6 +147,10 @@ class Conv(YmkModule):
         return w, b
 
     cout_perm = None  # optional output-channel permutation applied at pack time (AAttn.qkv)
+    # optional zero padding of the packed weights (ABlock.mlp at the l/x scales: hidden width int(1.2*dim) is not a
+    # multiple of the 16-byte channel vector; padded outputs are SiLU(0) = 0 and meet zero weight columns downstream)
+    pad_cout_to = None
+    pad_cin_to = None
 
     def _pack(self, dtype, device):
         k, s, dw = self._geometry()
@@ -155,6 +159,12 @@ class Conv(YmkModule):
         if self.cout_perm is not None:
             perm = torch.as_tensor(self.cout_perm, device=device)
             w, b = w[perm], b[perm]
+        if self.pad_cout_to is not None and self.pad_cout_to > w.shape[0]:
+            extra = self.pad_cout_to - w.shape[0]
+            w = torch.cat([w, w.new_zeros((extra, *w.shape[1:]))], 0)
+            b = torch.cat([b, b.new_zeros(extra)], 0)
+        if self.pad_cin_to is not None and self.pad_cin_to > w.shape[1]:
+            w = torch.cat([w, w.new_zeros((w.shape[0], self.pad_cin_to - w.shape[1], *w.shape[2:]))], 1)
         if dw:
             return {"dw": True, "w": ops.pack_dw_weight(w, dtype), "b": b.contiguous(), "k": k, "s": s}
         if self.conv.in_channels <= 4:  # stem: fp32 [Cout][k*k*Cin], reads the NCHW input directly
@@ -379,6 +389,10 @@ class ABlock(YmkModule):
         self.attn = AAttn(dim, num_heads=num_heads, area=area)
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = nn.Sequential(Conv(dim, mlp_hidden_dim, 1), Conv(mlp_hidden_dim, dim, 1, act=False))
+        hp = (mlp_hidden_dim + 7) // 8 * 8
+        if hp != mlp_hidden_dim:
+            self.mlp[0].pad_cout_to = hp
+            self.mlp[1].pad_cin_to = hp
         self.apply(self._init_weights)
 
     @staticmethod
@@ -410,8 +424,6 @@ class A2C2f(YmkModule):
         )
 
     def _run(self, x, out=None):
-        if self.gamma is not None:
-            raise NotImplementedError("ymk A2C2f: gamma-residual (l/x scales) not built yet")
         B, H, W, _ = x.shape
         c_ = self.cv1.conv.out_channels
         n = len(self.m)
@@ -425,7 +437,11 @@ class A2C2f(YmkModule):
                     h = blk._run(h, out=dst if j == len(m) - 1 else None)
             else:
                 m._run(src, out=dst)
-        return self.cv2._run(cat, out=out)
+        if self.gamma is None:
+            return self.cv2._run(cat, out=out)
+        # l/x scales: x + gamma * cv2(...) (block.py:1877-1879)
+        y = self.cv2._run(cat)
+        return ops.scale_residual(y, self.gamma.detach().float().contiguous(), x, out=out)
 
 
 class DFL(nn.Module):

@@ -317,6 +317,20 @@ def copy_channels(x, out):
     return out
 
 
+def scale_residual(y, gamma, residual, out=None):
+    """out = residual + gamma[c] * y (A2C2f gamma-residual, block.py:1877-1879)."""
+    B, H, W, Cc, ldy = _nhwc(y)
+    ldr = _nhwc(residual)[4]
+    if out is None:
+        out = new_act(B, H, W, Cc, y.dtype, y.device)
+    ldo = _nhwc(out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_scale_residual(DT[y.dtype], _p(y), _p(gamma), _p(residual), _p(out), B * H * W, Cc, ldy, ldr, ldo, _stream()),
+          "scale_residual")
+    TIMER.end(e0, "layout", 3 * B * H * W * Cc * y.element_size(), 2 * B * H * W * Cc)
+    return out
+
+
 def nhwc_to_nchw_f32(x):
     B, H, W, Cc, ldx = _nhwc(x)
     y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)

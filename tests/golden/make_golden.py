@@ -170,10 +170,14 @@ def nms_case(name, make_y, **kw):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "l":   # only the L-scale case (C3k blocks, gamma-residual A2C2f, mlp 1.2)
+        model_case("l_tiny", "l", 1, 64, 64, seed=5, conf=0.002, full_y=True)
+        sys.exit(0)
     model_case("n640", "n", 4, 640, 640, seed=1)
     model_case("n_ragged", "n", 3, 96, 160, seed=2, conf=0.002, full_y=True)
     model_case("n_tiny", "n", 1, 64, 64, seed=3, conf=0.002, full_y=True)
     model_case("s_small", "s", 2, 128, 128, seed=4, conf=0.002, full_y=True)
+    model_case("l_tiny", "l", 1, 64, 64, seed=5, conf=0.002, full_y=True)
     nms_case("single", lambda s: synth_pred(3, 20, 1500, s, -3.0), conf_thres=0.25, iou_thres=0.7)
     nms_case("multi", lambda s: synth_pred(2, 12, 800, s, -2.5), conf_thres=0.05, iou_thres=0.6, multi_label=True)
     nms_case("agnostic", lambda s: synth_pred(2, 20, 1200, s, -3.0), conf_thres=0.25, iou_thres=0.45, agnostic=True)

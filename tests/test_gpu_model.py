@@ -26,7 +26,7 @@ def _sample_err(got_nchw, idx, val):
     return float(np.abs(g - val).max())
 
 
-@pytest.mark.parametrize("case", ["n640", "n_ragged", "n_tiny", "s_small"])
+@pytest.mark.parametrize("case", ["n640", "n_ragged", "n_tiny", "s_small", "l_tiny"])
 def test_forward_vs_reference_golden(case, golden_dir):
     """Tolerance model.  The fixtures carry, per layer, the real reference's fp32 values, an fp64 evaluation of
     the same graph, and the reference's own round-off distance to fp64 ("noise").  fp32 evaluation orders differ

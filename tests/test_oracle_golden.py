@@ -6,7 +6,7 @@ import torch
 
 from tests.helpers import load_npz
 
-CASES = ["n640", "n_ragged", "n_tiny", "s_small"]
+CASES = ["n640", "n_ragged", "n_tiny", "s_small", "l_tiny"]
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -73,6 +73,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     }
 
+    {   // uniform reference pixels (see IGemm::Rows): the tile's first output pixel mapped like the rows above
+        const unsigned m0 = (unsigned)(px0 < a.M ? px0 : 0);
+        const unsigned b0 = m0 / HoWo, rem0 = m0 - b0 * HoWo;
+        const unsigned oy0 = rem0 / (unsigned)a.Wo, ox0 = rem0 - oy0 * (unsigned)a.Wo;
+        if (DUAL) {
+            rows.ref2 = m0;
+            rows.ref = a.up1 ? (int64_t)(b0 * (unsigned)(a.H1 * a.W1) + (oy0 >> 1) * (unsigned)a.W1 + (ox0 >> 1)) : (int64_t)m0;
+        } else if (KS == 1 && a.stride == 1) {
+            rows.ref = m0;
+        } else if (KS == 1) {
+            rows.ref = (int64_t)(b0 * (unsigned)(a.H * a.W) + oy0 * a.stride * (unsigned)a.W + ox0 * a.stride);
+        } else {
+            rows.ref = (int64_t)(b0 * (unsigned)(a.H * a.W));
+        }
+    }
+
     f32x4 acc[G::TM][G::TN];
 #pragma unroll
     for (int i = 0; i < G::TM; ++i)
@@ -559,6 +575,8 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     a.M = (int64_t)d->B * a.Ho * a.Wo;
     if (a.M <= 0) return YMK_OK;
     if (a.M >= (1ll << 31) || (int64_t)d->B * d->H * d->W >= (1ll << 31)) return YMK_E_BADARG;
+    // in-kernel row offsets are 32-bit relative to a per-tile reference pixel (at most two images away)
+    if ((2ll * d->H * d->W + 4096) * d->ldx >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (d->ksize == 1 && d->stride == 1 && ymk_use_ws && !(ymk_disabled() & YMK_OFF_CONV_STREAM)) {  // large-M short-K 1x1: weight-stationary streaming kernel
         const bool done = d->dtype == YMK_F32 ? launch_conv1x1_ws<float>(a, s) : launch_conv1x1_ws<bf16_t>(a, s);
@@ -593,7 +611,7 @@ extern "C" int ymk_conv1x1_cat2(const ymk_conv_desc* d, const void* x1, int32_t 
     a.ldx = ldx1; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = d->act; a.out_f32 = 0;
     a.M = (int64_t)d->B * d->H * d->W;
     if (a.M <= 0) return YMK_OK;
-    if (a.M >= (1ll << 31)) return YMK_E_BADARG;
+    if (a.M >= (1ll << 31) || (2ll * d->H * d->W + 4096) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31)) return YMK_E_BADARG;
     return d->dtype == YMK_F32 ? launch_conv_dual<float>(a, (hipStream_t)stream) : launch_conv_dual<bf16_t>(a, (hipStream_t)stream);
 }
 

@@ -79,6 +79,9 @@ struct IGemm {
         int iy0[NB], ix0[NB];
         int pix2[DUAL ? NB : 1];  // DUAL: pixel index in the second source
         bool ok[NB];
+        // workgroup-uniform reference pixels: every row of the tile lies within a couple of images of them, so a
+        // row's element offset relative to (x + ref*ldx) fits 32 bits and the k-loop needs no 64-bit index math
+        int64_t ref = 0, ref2 = 0;
     };
     struct Src2 {  // second K-source (DUAL)
         const T* x2;
@@ -107,13 +110,41 @@ struct IGemm {
         if constexpr (KS != 1)
             while (c >= Cin) { c -= Cin; ++tap; }
 
+        // per-row constants of the k-loop: 32-bit element offsets relative to uniform base pointers and, for 3x3,
+        // one validity bit per tap (image border / ragged tile), so that a k-step costs one add and one bit test
+        // per staged row instead of 2-D index arithmetic, bounds compares and a 64-bit multiply
+        const T* xb = x + rows.ref * ldx;
+        const T* x2b = DUAL ? s2.x2 + rows.ref2 * s2.ldx2 : nullptr;
+        int roff[NB], roff2[DUAL ? NB : 1], woff[NA];
+        unsigned rmask[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if constexpr (KS == 1) {
+                roff[i] = rows.ok[i] ? (int)(rows.pix[i] - rows.ref) * ldx : 0;
+                rmask[i] = rows.ok[i] ? 1u : 0u;
+                if constexpr (DUAL) roff2[i] = rows.ok[i] ? (int)(rows.pix2[i] - rows.ref2) * s2.ldx2 : 0;
+            } else {
+                roff[i] = rows.ok[i] ? ((int)(rows.pix[i] - rows.ref) + rows.iy0[i] * W + rows.ix0[i]) * ldx : 0;
+                unsigned m = 0;
+#pragma unroll
+                for (int tp = 0; tp < KS * KS; ++tp) {
+                    const int iy = rows.iy0[i] + tp / KS, ix = rows.ix0[i] + tp % KS;
+                    m |= (rows.ok[i] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? (1u << tp) : 0u;
+                }
+                rmask[i] = m;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = srow + i * RPP;
+            woff[i] = (r < BCO && r < co_valid) ? r * Kpad + cq * VEC : -1;
+        }
+
         auto gload = [&](int kt) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int r = srow + i * RPP;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (r < BCO && r < co_valid && ablate != 4)
-                    v = *reinterpret_cast<const u32x4*>(wt + (size_t)r * Kpad + kt * BK + cq * VEC);
+                if (woff[i] >= 0 && ablate != 4) v = *reinterpret_cast<const u32x4*>(wt + (woff[i] + kt * BK));
                 ra[i] = v;
             }
             if constexpr (KS == 1) {
@@ -122,11 +153,11 @@ struct IGemm {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     u32x4 v = {0u, 0u, 0u, 0u};
-                    if (rows.ok[i] && kin && ablate != 3) {
+                    if (rmask[i] && kin && ablate != 3) {
                         if (DUAL && c >= s2.C1)
-                            v = *reinterpret_cast<const u32x4*>(s2.x2 + (int64_t)rows.pix2[i] * s2.ldx2 + (c - s2.C1));
+                            v = *reinterpret_cast<const u32x4*>(x2b + (roff2[DUAL ? i : 0] + (c - s2.C1)));
                         else
-                            v = *reinterpret_cast<const u32x4*>(x + (int64_t)rows.pix[i] * ldx + c);
+                            v = *reinterpret_cast<const u32x4*>(xb + (roff[i] + c));
                     }
                     rb[i] = v;
                 }
@@ -134,14 +165,11 @@ struct IGemm {
             } else {
                 const bool kin = tap < KS * KS;
                 const int ky = tap / KS, kx = tap - ky * KS;
+                const int tapoff = (ky * W + kx) * ldx + c;
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     u32x4 v = {0u, 0u, 0u, 0u};
-                    const int iy = rows.iy0[i] + ky, ix = rows.ix0[i] + kx;
-                    if (rows.ok[i] && kin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ablate != 3) {
-                        const int64_t p = (int64_t)rows.pix[i] + (int64_t)iy * W + ix;
-                        v = *reinterpret_cast<const u32x4*>(x + p * ldx + c);
-                    }
+                    if (kin && ((rmask[i] >> tap) & 1u) && ablate != 3) v = *reinterpret_cast<const u32x4*>(xb + (roff[i] + tapoff));
                     rb[i] = v;
                 }
                 c += BK;

@@ -31,8 +31,8 @@ static float timeit(F&& f, int reps = 20) {
 
 int main() {
     struct Shape { int B, H, W, Cin, Cout, k, s; } shapes[] = {
-        {64, 160, 160, 128, 128, 1, 1}, {64, 80, 80, 256, 256, 1, 1}, {64, 40, 40, 256, 128, 1, 1},
-        {64, 160, 160, 32, 32, 3, 1}, {64, 80, 80, 64, 64, 3, 1}, {64, 40, 40, 64, 64, 3, 1}, {64, 20, 20, 64, 64, 3, 1}, {64, 80, 80, 32, 32, 3, 1}};
+        {64, 160, 160, 128, 128, 3, 2}, {64, 80, 80, 256, 256, 3, 2}, {64, 320, 320, 32, 64, 3, 2}, {64, 80, 80, 128, 64, 3, 1},
+        {64, 40, 40, 384, 256, 1, 1}, {64, 20, 20, 256, 768, 1, 1}, {64, 40, 40, 256, 128, 1, 1}};
     ymk_ws_min_tiles = 1;
     for (auto sh : shapes) {
         const size_t nin = (size_t)sh.B * sh.H * sh.W * sh.Cin;
@@ -56,7 +56,7 @@ int main() {
                sh.B, sh.H, sh.W, sh.Cin, sh.Cout, sh.k, sh.s, ms * 1e3, bytes / ms / 1e9, flops / ms / 1e9,
                n16 * 16 >> 20, mc * 1e3, 2.0 * n16 * 16 / mc / 1e9, nin * 2 >> 20, mr * 1e3, nin * 2.0 / mr / 1e9);
         ymk_use_ws = 0;
-        for (int ab = 1; ab <= 0; ++ab) {
+        for (int ab = 1; ab <= 4; ++ab) {
             ymk_ablate = ab;
             float m2 = timeit([&] { ymk_conv2d(&d, x, w, bias, nullptr, y, nullptr); });
             printf("     ablate %d (%s): %.1f us\n", ab, ab == 1 ? "no MFMA" : ab == 2 ? "no global store" : ab == 3 ? "no activation loads (zeros)" : "no weight loads", m2 * 1e3);

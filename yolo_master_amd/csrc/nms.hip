@@ -80,12 +80,31 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const float* __restrict_
     int c = 0;
     if (a < A) {
         const float* p = y + ((size_t)b * (4 + nc) + 4) * A + a;
+        // class scores are read eight at a time (independent loads in flight); the compares keep class order, so
+        // the first maximum wins exactly as in the sequential scan (utils/nms.py:124-129 amax/argmax semantics)
         if (multi) {
-            for (int k = 0; k < nc; ++k) c += p[(size_t)k * A] > conf;
+            int k = 0;
+            for (; k + 8 <= nc; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(k + q) * A];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) c += v[q] > conf;
+            }
+            for (; k < nc; ++k) c += p[(size_t)k * A] > conf;
         } else {
             float best = p[0];
             int bi = 0;
-            for (int k = 1; k < nc; ++k) {
+            int k = 1;
+            for (; k + 8 <= nc; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(k + q) * A];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (v[q] > best) { best = v[q]; bi = k + q; }
+            }
+            for (; k < nc; ++k) {
                 const float v = p[(size_t)k * A];
                 if (v > best) { best = v; bi = k; }
             }

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 GOLD = Path(__file__).parent / "golden"
 
 
-@pytest.mark.parametrize("scale", ["n", "s"])
+@pytest.mark.parametrize("scale", ["n", "s", "l"])
 def test_state_dict_contract_matches_reference(scale):
     from yolo_master_amd.nn.tasks import DetectionModel
 
@@ -108,3 +108,27 @@ def test_product_never_imports_oracle():
     for f in root.rglob("*.py"):
         txt = f.read_text()
         assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_lx_scale_host_logic():
+    """l/x scales: A2C2f carries the gamma-residual and mlp_ratio 1.2 (tasks.py:2156-2159); the MLP hidden width
+    int(1.2*dim) is zero-padded at pack time so that every conv sees 16-byte channel vectors."""
+    from yolo_master_amd.nn.modules import A2C2f, ABlock
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    m = DetectionModel("yolo-master-l.yaml").eval()
+    blocks = [x for x in m.model if isinstance(x, A2C2f)]
+    assert blocks and all(b.gamma is not None and b.gamma.shape == (b.cv2.conv.out_channels,) for b in blocks)
+    ab = next(x for x in m.modules() if isinstance(x, ABlock))
+    hidden = ab.mlp[0].conv.out_channels
+    assert hidden == int(ab.mlp[0].conv.in_channels * 1.2) and hidden % 8 != 0
+    hp = (hidden + 7) // 8 * 8
+    p0, p1 = ab.mlp[0]._pack(torch.float32, "cpu"), ab.mlp[1]._pack(torch.float32, "cpu")
+    assert p0["w"].shape[0] == hp and p0["b"].shape[0] == hp
+    assert float(p0["w"][hidden:].abs().max()) == 0.0 and float(p0["b"][hidden:].abs().max()) == 0.0   # SiLU(0) = 0
+    k1 = p1["w"].shape[1]
+    assert k1 >= hp and float(p1["w"][:, hidden:].abs().max()) == 0.0                                   # zero columns
+    # the reference's key set for the L scale (dumped from the real model) is reproduced
+    import json
+    keys = json.load(open(Path(__file__).parent / "golden" / "keys_l.json"))
+    assert list(m.state_dict().keys()) == list(keys.keys())

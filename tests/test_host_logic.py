@@ -123,7 +123,8 @@ def test_lx_scale_host_logic():
     hidden = ab.mlp[0].conv.out_channels
     assert hidden == int(ab.mlp[0].conv.in_channels * 1.2) and hidden % 8 != 0
     hp = (hidden + 7) // 8 * 8
-    p0, p1 = ab.mlp[0]._pack(torch.float32, "cpu"), ab.mlp[1]._pack(torch.float32, "cpu")
+    with torch.no_grad():
+        p0, p1 = ab.mlp[0]._pack(torch.float32, "cpu"), ab.mlp[1]._pack(torch.float32, "cpu")
     assert p0["w"].shape[0] == hp and p0["b"].shape[0] == hp
     assert float(p0["w"][hidden:].abs().max()) == 0.0 and float(p0["b"][hidden:].abs().max()) == 0.0   # SiLU(0) = 0
     k1 = p1["w"].shape[1]

@@ -1,0 +1,85 @@
+"""Golden vectors for the Mixture-of-Attention oracle (oracle/moa_ref.py), produced by the REAL reference modules
+(`ultralytics.nn.modules.moa`) on CPU.  Run in the build container (needs /root/reference):
+
+    python tests/golden/make_golden_moa.py
+
+Writes tests/golden/moa_<case>.npz: the seeded state_dict, the input, the reference output and router
+probabilities.  The script also asserts that the oracle reproduces the reference bit for bit on every case.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import moa_ref, refboot  # noqa: E402
+
+refboot.boot()  # stubs cv2 and puts /root/reference on sys.path
+
+from ultralytics.nn.modules.moa.block import MoABlock  # noqa: E402
+from ultralytics.nn.modules.moa.wrappers import C2fMoA  # noqa: E402
+
+
+def seeded_fill(module, seed):
+    """Deterministic non-degenerate parameters (the reference init zeroes the router head and uses std 0.02)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if not v.is_floating_point() or k.endswith("_rf_matrix"):
+            out[k] = v.clone()
+        elif k.endswith("running_var"):
+            out[k] = 0.5 + torch.rand(v.shape, generator=g)
+        elif k.endswith("running_mean"):
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif k.endswith(".bias"):
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif "ls_attn" in k or "ls_ffn" in k:
+            out[k] = 0.5 + 0.1 * torch.randn(v.shape, generator=g)
+        elif v.dim() == 1:  # norm scales
+            out[k] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+        else:               # conv weights: unit-gain fan-in scaling
+            fan_in = v[0].numel()
+            out[k] = torch.randn(v.shape, generator=g) * (1.5 / fan_in ** 0.5)
+    module.load_state_dict(out)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3  # what initialize_weights sets inside a DetectionModel (utils/torch_utils.py:552-562)
+    return out
+
+
+def case(name, module, oracle_fn, x, seed):
+    sd = seeded_fill(module, seed)
+    module.eval()
+    with torch.inference_mode():
+        y = module(x)
+        info = {}
+        oy = oracle_fn({f"m.{k}": v for k, v in sd.items()}, x, info)
+    exact = torch.equal(y, oy)
+    print(f"[moa_{name}] x {tuple(x.shape)} -> y {tuple(y.shape)}; oracle bit-exact vs reference: {exact}; "
+          f"max|dy| {(y - oy).abs().max().item():.3e}; |y| max {y.abs().max().item():.3f}")
+    assert exact
+    probs = np.stack([v["weights"].numpy() for v in info.values()])
+    rec = {"x": x.numpy(), "y": y.numpy(), "router_probs": probs, "keys": np.array(list(sd.keys()))}
+    rec.update({f"sd::{k}": v.numpy() for k, v in sd.items()})
+    np.savez_compressed(HERE / f"moa_{name}.npz", **rec)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    g = torch.Generator().manual_seed(123)
+
+    def blk(x, seed, name, **kw):
+        m = MoABlock(48, num_heads=6, **kw)
+        case(name, m, lambda sd, xx, info: moa_ref.moa_block(sd, "m", xx, 6, info=info, **{k: v for k, v in kw.items()
+                                                                                            if k in ("shortcut", "local_window_size", "regional_max_kv_tokens")}), x, seed)
+
+    blk(torch.randn(2, 48, 14, 18, generator=g), 1, "exact")            # N = 252: exact global attention, padded windows
+    blk(torch.randn(1, 48, 20, 24, generator=g), 2, "blend")            # N = 480: exact/linear blend window
+    blk(torch.randn(1, 48, 24, 28, generator=g), 3, "linear")           # N = 672: random-feature attention
+    blk(torch.randn(1, 48, 24, 28, generator=g), 4, "kvcap", regional_max_kv_tokens=64, shortcut=False)  # pooled-KV cap, no residual
+    m = C2fMoA(64, 96, n=2, num_heads=6)
+    case("c2f", m, lambda sd, xx, info: moa_ref.c2f_moa(sd, "m", xx, 6, info=info), torch.randn(2, 64, 16, 16, generator=g), 5)

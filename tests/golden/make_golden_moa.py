@@ -29,7 +29,7 @@ def seeded_fill(module, seed):
     sd = module.state_dict()
     out = {}
     for k, v in sd.items():
-        if not v.is_floating_point() or k.endswith("_rf_matrix"):
+        if not v.is_floating_point() or k.endswith("_rf_matrix") or v.dim() == 0:   # counters, fixed bases, temperature
             out[k] = v.clone()
         elif k.endswith("running_var"):
             out[k] = 0.5 + torch.rand(v.shape, generator=g)

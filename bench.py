@@ -29,42 +29,35 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 # op family (yolo_master_amd.ops TIMER) -> kernel-name prefix in the rocprofv3 output; single-kernel families only
 FAMILY_KERNEL = {
-    "conv1x1_ws": "conv1x1_ws_kernel<", "conv3x3_tile": "conv3x3_tile_kernel<", "moe_pw": "moe_pw_kernel<",
-    "moe_dw": "moe_dw_kernel<", "dwconv": "dwconv_kernel<", "area_attn": "area_attn_kernel<",
-    "detect_decode": "detect_decode_kernel", "stem": "stem_px_kernel<",
+    "moe_pw": "moe_pw_", "moe_dw": "moe_dw_kernel<", "dwconv": "dwconv_kernel<", "area_attn": "area_attn_kernel<",
+    "detect_decode": "detect_decode_kernel", "stem": "stem_",
 }
 
 
 def pmc_traffic(family: str):
-    """HBM bytes per launch of the timed kernel family from the committed rocprofv3 PMC passes
+    """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_*.json, collected by tools/gpu_profile.sh on the same workload): 2*FETCH_SIZE (gfx950 counts
     wide coalesced reads at half size, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, averaged over the
-    family's launches.  None when no profile is committed or the family spans several kernels."""
+    launches.  Convolution records carry the exact kernel name rocprofv3 prints (ops.conv_kernel_name); the other
+    op families map to a name prefix.  None when no profile is committed or the family spans several kernels."""
     import glob
-    import re as _re
 
     files = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_FETCH_SIZE.json")))
     if not files:
         return None
-    if family.startswith("conv_igemm"):
-        ks, dual = ("1", "true") if family.endswith("cat2") else (family[-1], "false")
-        pat = _re.compile(r"conv_igemm_kernel<.*, %s, %s>" % (ks, dual))
-    elif family in FAMILY_KERNEL:
-        pat = _re.compile(_re.escape(FAMILY_KERNEL[family]))
-    else:
-        return None
     try:
         fk = json.load(open(files[-1]))["kernels"]
         wk = json.load(open(files[-1].replace("FETCH_SIZE", "WRITE_SIZE")))["kernels"]
-        tot, n = 0.0, 0
-        for name, v in fk.items():
-            if pat.match(name) and name in wk:
-                c = v["FETCH_SIZE"]["launches"]
-                tot += (2.0 * v["FETCH_SIZE"]["mean"] + wk[name]["WRITE_SIZE"]["mean"]) * c
-                n += c
-        return int(tot / n * 1024) if n else None
     except Exception:
         return None
+    names = [family] if family in fk else [n for n in fk if family in FAMILY_KERNEL and n.startswith(FAMILY_KERNEL[family])]
+    tot, n = 0.0, 0
+    for name in names:
+        if name in wk:
+            c = fk[name]["FETCH_SIZE"]["launches"]
+            tot += (2.0 * fk[name]["FETCH_SIZE"]["mean"] + wk[name]["WRITE_SIZE"]["mean"]) * c
+            n += c
+    return int(tot / n * 1024) if n else None
 
 
 def cpu_baseline(scale: str, seconds_budget: float = 20.0):
@@ -185,39 +178,43 @@ def main():
         # reported is the family with the largest share of the step, the rest go into "families"
         roof, fams = None, None
         if rank == 0:
-            ops.TIMER.start()
-            for _ in range(3):
-                local_step()  # rank-local: no collective outside the lock-step timed loop
-            torch.cuda.synchronize()
-            recs = ops.TIMER.records
-            ops.TIMER.stop()
-            agg = {}
-            for fam, e0, e1, nb, fl in recs:
-                r = agg.setdefault(fam, [0.0, 0, 0, 0])
-                r[0] += e0.elapsed_time(e1); r[1] += nb; r[2] += fl; r[3] += 1
-            ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+            try:
+                ops.TIMER.start()
+                for _ in range(3):
+                    local_step()  # rank-local: no collective outside the lock-step timed loop
+                torch.cuda.synchronize()
+                recs = ops.TIMER.records
+                ops.TIMER.stop()
+                agg = {}
+                for fam, e0, e1, nb, fl in recs:
+                    r = agg.setdefault(fam, [0.0, 0, 0, 0])
+                    r[0] += e0.elapsed_time(e1); r[1] += nb; r[2] += fl; r[3] += 1
+                ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
 
-            def describe(fam):
-                ms, nbytes, flops, n = agg[fam]
-                gbs, tfl = nbytes / (ms * 1e-3) / 1e9, flops / (ms * 1e-3) / 1e12
-                if flops / max(nbytes, 1) < ridge:
-                    r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
-                else:
-                    r = {"bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_PEAK_TFLOPS[a.dtype],
-                         "unit": "TFLOP/s", "frac": round(tfl / MFMA_PEAK_TFLOPS[a.dtype], 4), "traffic": None}
-                r.update(kernel=fam, launches_per_step=n // 3, avg_launch_us=round(ms * 1e3 / n, 2),
-                         ms_per_step=round(ms / 3, 4), alg_bytes_per_launch=int(nbytes / n),
-                         alg_gflop_per_launch=round(flops / n / 1e9, 3), achieved_gbs=round(gbs, 1),
-                         achieved_tflops=round(tfl, 2))
-                r["traffic"] = pmc_traffic(fam)
-                return r
+                def describe(fam):
+                    ms, nbytes, flops, n = agg[fam]
+                    gbs, tfl = nbytes / (ms * 1e-3) / 1e9, flops / (ms * 1e-3) / 1e12
+                    if flops / max(nbytes, 1) < ridge:
+                        r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+                    else:
+                        r = {"bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_PEAK_TFLOPS[a.dtype],
+                             "unit": "TFLOP/s", "frac": round(tfl / MFMA_PEAK_TFLOPS[a.dtype], 4), "traffic": None}
+                    r.update(kernel=fam, launches_per_step=n // 3, avg_launch_us=round(ms * 1e3 / n, 2),
+                             ms_per_step=round(ms / 3, 4), alg_bytes_per_launch=int(nbytes / n),
+                             alg_gflop_per_launch=round(flops / n / 1e9, 3), achieved_gbs=round(gbs, 1),
+                             achieved_tflops=round(tfl, 2))
+                    r["traffic"] = pmc_traffic(fam)
+                    return r
 
-            if agg:
-                order = sorted(agg, key=lambda f: -agg[f][0])
-                roof = describe(a.roofline_kernel if a.roofline_kernel in agg else order[0])
-                fams = [{k: d[k] for k in ("kernel", "ms_per_step", "launches_per_step", "bound", "frac", "achieved_gbs",
-                                           "achieved_tflops")} for d in map(describe, order)]
+                if agg:
+                    order = sorted(agg, key=lambda f: -agg[f][0])
+                    roof = describe(a.roofline_kernel if a.roofline_kernel in agg else order[0])
+                    fams = [{k: d[k] for k in ("kernel", "ms_per_step", "launches_per_step", "bound", "frac", "achieved_gbs",
+                                               "achieved_tflops")} for d in map(describe, order)]
+            except Exception as e:  # the throughput line must survive a failure of the diagnostic leg
+                print(f"[bench] roofline leg failed ({type(e).__name__}: {e})", file=sys.stderr)
+                ops.TIMER.stop()
 
     if rank == 0:
         total_images = world * a.batch * a.steps
@@ -236,7 +233,10 @@ def main():
             "cpu_baseline": None,
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.scale)
+            try:
+                res["cpu_baseline"] = cpu_baseline(a.scale)
+            except Exception as e:  # never lose the measured line to the host-side baseline
+                print(f"[bench] cpu_baseline failed ({type(e).__name__}: {e})", file=sys.stderr)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

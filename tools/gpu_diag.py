@@ -113,7 +113,7 @@ def call_times(scale="s", B=64, dtype=torch.bfloat16, reps=3):
         rows.append((ms, i, fam, ops.TIMER.shapes[i], nb, fl))
     print(f"{n} op calls, {sum(r[0] for r in rows):.3f} ms")
     for ms, i, fam, shp, nb, fl in sorted(rows, reverse=True):
-        print(f"{i:3d} {fam:16s} {shp:34s} {ms * 1e3:8.1f} us {nb / ms / 1e6:8.0f} GB/s {fl / ms / 1e9:8.1f} TF/s")
+        print(f"{i:3d} {fam[:58]:58s} {shp:34s} {ms * 1e3:8.1f} us {nb / ms / 1e6:8.0f} GB/s {fl / ms / 1e9:8.1f} TF/s")
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@ synchronises.  torch is used for memory and streams only — all arithmetic is i
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -51,6 +52,27 @@ class KernelTimer:
 
 TIMER = KernelTimer()
 CONV_FAMILY = {0: "conv_igemm", 1: "conv1x1_ws", 2: "conv3x3_tile"}  # ymk_conv2d_last_variant()
+
+
+def _tile(cout: int) -> str:
+    """cout x pixel tile and wave grid of conv_igemm_kernel (csrc/conv.hip launch_conv / launch_conv_dual)."""
+    return "128, 128, 2, 2" if cout > 64 else "64, 256, 1, 4" if cout > 32 else "32, 256, 1, 4" if cout > 16 else "16, 256, 1, 4"
+
+
+def conv_kernel_name(variant: int, dtype, cin: int, cout: int, k: int, kpad: int, residual: bool, dual: bool = False) -> str:
+    """Demangled name of the kernel instantiation a ymk_conv2d / ymk_conv1x1_cat2 call ran (as rocprofv3 prints it,
+    with bf16_t = unsigned short): the timer tags conv calls with it so that bench.py's roofline object and the
+    committed rocprof / PMC summaries refer to the same kernel."""
+    t = "unsigned short" if dtype == torch.bfloat16 else "float"
+    es = 2 if dtype == torch.bfloat16 else 4
+    if dual:
+        return f"conv_igemm_kernel<{t}, {_tile(cout)}, 1, true>"
+    if variant == 1:
+        return f"conv1x1_ws_kernel<{t}, {kpad * es // 128}>"
+    if variant == 2:
+        prefetch = residual and not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 16)
+        return f"conv3x3_tile_kernel<{t}, {cin}, {32 if cout <= 32 else 64}, {'true' if prefetch else 'false'}>"
+    return f"conv_igemm_kernel<{t}, {_tile(cout)}, {k}, false>"
 
 
 def _stream() -> int:
@@ -143,8 +165,8 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual
         es = x.element_size()
         nbytes = (B * H * W * Cin + Cout * k * k * Cin + (B * Ho * Wo * Cout if residual is not None else 0)) * es \
             + B * Ho * Wo * Cout * out.element_size()
-        fam = CONV_FAMILY[lib.ymk_conv2d_last_variant()]
-        TIMER.end(e0, f"{fam}_k{k}" if fam == "conv_igemm" else fam, nbytes, 2 * B * Ho * Wo * Cout * k * k * Cin,
+        name = conv_kernel_name(lib.ymk_conv2d_last_variant(), x.dtype, Cin, Cout, k, Kp, residual is not None)
+        TIMER.end(e0, name, nbytes, 2 * B * Ho * Wo * Cout * k * k * Cin,
                   f"{Cin}->{Cout} k{k} s{stride} @{Ho}x{Wo}{' +res' if residual is not None else ''}")
     return out
 
@@ -164,7 +186,8 @@ def conv1x1_cat2(x1, up1: bool, x2, w_packed, bias, act: bool, out=None):
     check(lib.ymk_conv1x1_cat2(C.byref(d), _p(x1), C1, ld1, int(up1), _p(x2), ld2, _p(w_packed), _p(bias), _p(out), _stream()),
           "conv1x1_cat2")
     es = x2.element_size()
-    TIMER.end(e0, "conv_igemm_cat2", (B1 * H1 * W1 * C1 + B * H * W * C2 + Cout * (C1 + C2) + B * H * W * Cout) * es,
+    TIMER.end(e0, conv_kernel_name(0, x2.dtype, C1 + C2, Cout, 1, Kp, False, dual=True),
+              (B1 * H1 * W1 * C1 + B * H * W * C2 + Cout * (C1 + C2) + B * H * W * Cout) * es,
               2 * B * H * W * Cout * (C1 + C2), f"{C1}+{C2}->{Cout} @{H}x{W}{' up' if up1 else ''}")
     return out
 

@@ -1,0 +1,67 @@
+"""Golden vectors for the gated-MoE oracle (oracle/gated_ref.py), produced by the REAL reference module
+`VisualEnhancedAdaptiveGateMoE` on CPU.  Run in the build container (needs /root/reference):
+
+    python tests/golden/make_golden_gated.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(HERE))
+from oracle import gated_ref, refboot  # noqa: E402
+
+refboot.boot()
+from make_golden_moa import seeded_fill  # noqa: E402
+
+from ultralytics.nn.modules.moe.gated import VisualEnhancedAdaptiveGateMoE  # noqa: E402
+
+
+def case(name, C, x, seed, tweak=None, **kw):
+    m = VisualEnhancedAdaptiveGateMoE(C, C, **kw)
+    sd = seeded_fill(m, seed)
+    if tweak:
+        tweak(sd)
+        m.load_state_dict(sd)
+    m.eval()
+    info = {}
+    with torch.inference_mode():
+        y = m(x)
+        oy = gated_ref.visual_enhanced_moe({f"m.{k}": v for k, v in sd.items()}, "m", x, info=info,
+                                           **{k: v for k, v in kw.items() if k in ("num_experts", "top_k")})
+    exact = torch.equal(y, oy)
+    r = info["m"]
+    print(f"[gated_{name}] x {tuple(x.shape)}; oracle bit-exact vs reference: {exact}; max|dy| {(y - oy).abs().max().item():.3e}; "
+          f"|y| max {y.abs().max().item():.3f}; complexity {float(r['complexity']):.3f}; experts {r['indices'].view(x.shape[0], -1).tolist()} "
+          f"weights {[[round(float(v), 3) for v in row] for row in r['weights'].view(x.shape[0], -1)]}")
+    assert exact
+    rec = {"x": x.numpy(), "y": y.numpy(), "keys": np.array(list(sd.keys())), "weights": r["weights"].numpy(),
+           "indices": r["indices"].numpy(), "complexity": np.float32(r["complexity"])}
+    rec.update({f"sd::{k}": v.numpy() for k, v in sd.items()})
+    np.savez_compressed(HERE / f"gated_{name}.npz", **rec)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    g = torch.Generator().manual_seed(777)
+
+    def varied(B, C, H, W):   # images with different channel statistics so that the router separates them
+        x = torch.randn(B, C, H, W, generator=g)
+        return x * (0.5 + torch.rand(B, C, 1, 1, generator=g) * 2.0) + torch.randn(B, C, 1, 1, generator=g) * 1.5
+
+    def high_complexity(sd):   # complexity -> 1.0: both routed experts kept with their softmax weights
+        sd["complexity_estimator.1.bias"] = torch.tensor([20.0])
+        sd["routing.global_fc.weight"] = sd["routing.global_fc.weight"] * 4.0
+
+    def low_complexity(sd):    # complexity clamps to 0.3 -> round(0.6) = 1 expert kept of the top-2
+        sd["complexity_estimator.1.bias"] = torch.tensor([-20.0])
+
+    case("base", 64, varied(4, 64, 16, 20), 1, tweak=high_complexity)
+    case("small", 64, varied(3, 64, 4, 3), 2, tweak=high_complexity)                   # map not larger than the router pool
+    case("keep1", 64, varied(2, 64, 12, 12), 3, tweak=low_complexity)
+    case("e6k3", 96, varied(3, 96, 10, 14), 4, tweak=high_complexity, num_experts=6, top_k=3)
+    case("mid", 64, varied(2, 64, 9, 9), 5)                                            # untouched estimator (complexity ~0.5)

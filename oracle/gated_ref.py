@@ -88,6 +88,26 @@ def fused_experts(sd, p, x, weights, indices, num_experts, num_groups=8):
     return (n * weights.view(B, k, 1, 1, 1)).sum(dim=1)
 
 
+def shared_inverted_experts(sd, p, x, weights, indices):
+    """SharedInvertedExpertGroup.forward, eager sparse path (moe/experts.py:235-269): shared 1x1 expand -> GN(<=8) ->
+    SiLU -> DW3x3 -> GN -> SiLU once; every ACTIVE expert (ascending index) projects (1x1 -> GN) only the images
+    that routed to it with a positive weight and is accumulated with index_add_ in that order."""
+    B, _, H, W = x.shape
+    k = weights.shape[1]
+    h = F.silu(_gn(sd, f"{p}.shared_feature.1", F.conv2d(x, sd[f"{p}.shared_feature.0.weight"]), 8))
+    wd = sd[f"{p}.shared_feature.3.weight"]
+    h = F.silu(_gn(sd, f"{p}.shared_feature.4", F.conv2d(h, wd, None, 1, wd.shape[-1] // 2, 1, h.shape[1]), 8))
+    idx = indices.reshape(B, -1)[:, :k].to(torch.long)
+    w = weights.reshape(B, -1)[:, :k]
+    valid = w > 0.0
+    out = x.new_zeros(B, sd[f"{p}.expert_projections.0.0.weight"].shape[0], H, W)
+    for e in torch.unique(idx[valid]).to(torch.long).tolist():
+        bi, ki = torch.where((idx == e) & valid)
+        eo = _gn(sd, f"{p}.expert_projections.{e}.1", F.conv2d(h[bi], sd[f"{p}.expert_projections.{e}.0.weight"]), 8)
+        out.index_add_(0, bi, (eo * w[bi, ki].view(-1, 1, 1, 1).to(eo.dtype)).to(out.dtype))
+    return out
+
+
 def detail_gate(sd, p, x, num_groups=8):
     """VisualDetailGate.forward (gated.py:1171-1175): high-pass (x - 3x3 mean) -> DW3x3, GN, SiLU, 1x1, SiLU,
     1x1(+bias), sigmoid; x * (1 + tanh(scale) * gate)."""
@@ -145,7 +165,10 @@ def visual_enhanced_moe(sd, p, x, num_experts=4, top_k=2, split_ratio=0.5, num_g
     w = complexity_gate(w, cplx)
     if info is not None:
         info[p] = {"weights": w, "indices": idx, "probs": probs, "complexity": cplx}
-    d = fused_experts(sd, f"{p}.fused_experts", xd, w, idx, num_experts, num_groups)
+    if f"{p}.fused_experts.shared_feature.0.weight" in sd:   # more experts than fused_expert_threshold (gated.py:1318-1331)
+        d = shared_inverted_experts(sd, f"{p}.fused_experts", xd, w, idx)
+    else:
+        d = fused_experts(sd, f"{p}.fused_experts", xd, w, idx, num_experts, num_groups)
     cat = torch.cat([s, d], dim=1)
     oc = cat.shape[1]
     sg = shuffle_groups if oc % shuffle_groups == 0 else 1

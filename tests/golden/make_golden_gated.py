@@ -64,4 +64,5 @@ if __name__ == "__main__":
     case("small", 64, varied(3, 64, 4, 3), 2, tweak=high_complexity)                   # map not larger than the router pool
     case("keep1", 64, varied(2, 64, 12, 12), 3, tweak=low_complexity)
     case("e6k3", 96, varied(3, 96, 10, 14), 4, tweak=high_complexity, num_experts=6, top_k=3)
+    case("e16", 64, varied(4, 64, 8, 10), 6, tweak=high_complexity, num_experts=16, top_k=2)   # shared-inverted backend (E > 8)
     case("mid", 64, varied(2, 64, 9, 9), 5)                                            # untouched estimator (complexity ~0.5)

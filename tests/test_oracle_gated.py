@@ -6,7 +6,8 @@ import torch
 
 from oracle import gated_ref
 
-CASES = {"base": {}, "small": {}, "keep1": {}, "e6k3": dict(num_experts=6, top_k=3), "mid": {}}
+CASES = {"base": {}, "small": {}, "keep1": {}, "e6k3": dict(num_experts=6, top_k=3), "mid": {},
+         "e16": dict(num_experts=16, top_k=2)}   # more experts than the fused threshold: shared-inverted expert backend
 
 
 def _load(golden_dir, name):

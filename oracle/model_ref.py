@@ -287,6 +287,20 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
             cur = a2c2f(sd, p, cur, args[2] if len(args) > 2 else 1, fused)
         elif m == "ES_MOE":
             cur = es_moe(sd, p, cur, info=moe_info)
+        elif m == "VisualEnhancedAdaptiveGateMoE":   # args after width scaling: [c2, num_experts, top_k, split_ratio]
+            from . import gated_ref
+            cur = gated_ref.visual_enhanced_moe(sd, p, cur, num_experts=args[1], top_k=args[2],
+                                                split_ratio=args[3] if len(args) > 3 else 0.5, info=moe_info)
+        elif m == "C2fMoA":                          # [c2, num_heads, mlp_ratio, temperature, shortcut]
+            from . import moa_ref
+            cur = moa_ref.c2f_moa(sd, p, cur, num_heads=args[1] if len(args) > 1 else 6,
+                                  temperature=args[3] if len(args) > 3 else 1.0,
+                                  shortcut=args[4] if len(args) > 4 else True, info=moe_info)
+        elif m == "C2fMoT":                          # [c2, num_heads, top_k, window_size, n_points, mlp_ratio, T, coeff, e]
+            from . import mot_ref
+            cur = mot_ref.c2f_mot(sd, p, cur, num_heads=args[1] if len(args) > 1 else 6, top_k=args[2] if len(args) > 2 else 2,
+                                  window_size=args[3] if len(args) > 3 else 7, n_points=args[4] if len(args) > 4 else 4,
+                                  info=moe_info)
         elif m == "nn.Upsample":
             cur = F.interpolate(cur, scale_factor=2.0, mode="nearest")
             sc /= 2

@@ -62,3 +62,34 @@ def module_sd(module, prefix="model.0", seed=0):
 def load_npz(path):
     z = np.load(path)
     return {k: z[k] for k in z.files}
+
+
+def fill_by_name(spec: dict, seed: int = 0, gain: float = 1.0) -> dict:
+    """Deterministic parameters from names and shapes alone (no module needed): every tensor draws from its own
+    generator seeded by crc32(name) ^ seed.  Used for fixtures of models whose state_dict is too large to commit:
+    the fixture stores the spec (name -> shape) and both sides regenerate the same values.  Integer tensors, scalars
+    and fixed bases (`_rf_matrix`) are not generated — the caller supplies them."""
+    import zlib
+
+    out = {}
+    for k, shape in spec.items():
+        g = torch.Generator().manual_seed((zlib.crc32(k.encode()) ^ seed) & 0x7FFFFFFF)
+        shape = tuple(shape)
+        if k.endswith("running_var"):
+            out[k] = 0.5 + torch.rand(shape, generator=g)
+        elif k.endswith("running_mean"):
+            out[k] = 0.1 * torch.randn(shape, generator=g)
+        elif k.endswith(".bias") or k.endswith("expert_norm_bias"):
+            out[k] = 0.1 * torch.randn(shape, generator=g)
+        elif any(t in k for t in ("ls_attn", "ls_ffn", ".ls1", ".ls2")):
+            out[k] = 0.3 + 0.05 * torch.randn(shape, generator=g)
+        elif k.endswith(("_scale", ".alpha", ".gamma")):
+            out[k] = 0.3 + 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1 or k.endswith("expert_norm_weight"):   # norm scales
+            out[k] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:                                                        # conv / linear weights: fan-in scaling
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            out[k] = torch.randn(shape, generator=g) * (gain / max(fan_in, 1) ** 0.5)
+    return out

@@ -77,4 +77,5 @@ if __name__ == "__main__":
         if "indices" in v:
             rec[f"route::{k}"] = v["indices"].numpy().astype(np.int16)
     np.savez_compressed(HERE / "fwd_cfg5.npz", **rec)
+    json.dump({k: list(v.shape) for k, v in sd0.items()}, open(HERE / "keys_cfg5.json", "w"))   # ordered: the drop-in contract
     print("[cfg5] wrote", (HERE / "fwd_cfg5.npz").stat().st_size, "bytes")

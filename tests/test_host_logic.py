@@ -156,3 +156,34 @@ def test_conv_kernel_names_match_the_committed_profiles():
         assert bench.pmc_traffic(n) > 0
     assert ops.conv_kernel_name(0, torch.float32, 16, 8, 3, 192, False) == "conv_igemm_kernel<float, 16, 256, 1, 4, 3, false>"
     assert bench.pmc_traffic("moe_dw") > 0 and bench.pmc_traffic("nms") is None   # prefix families / multi-kernel ops
+
+
+def test_config5_boundary_modules_keep_the_reference_contract():
+    """The v0_10 moa-mot model builds from the model YAML and its state_dict has the reference's 1200 keys, in the
+    reference's order and shapes (dumped from the real model by tests/golden/make_golden_cfg5.py); the fixed
+    random-feature bases of the MoA global heads equal the reference's; the mixture modules fail loudly until
+    their kernels exist."""
+    import warnings
+
+    import numpy as np
+
+    from yolo_master_amd.nn.mixture import C2fMoA, C2fMoT, MoABlock, VisualEnhancedAdaptiveGateMoE
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DetectionModel("yolo-master-moa-mot-n.yaml").eval()
+    keys = json.load(open(GOLD / "keys_cfg5.json"))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(keys.keys())
+    assert all(list(sd[k].shape) == v for k, v in keys.items())
+    z = np.load(GOLD / "fwd_cfg5.npz")
+    rf = [k for k in z.files if k.endswith("_rf_matrix")]
+    assert rf and all(np.allclose(sd[k[len("fixed::"):]].numpy(), z[k], atol=1e-6) for k in rf)
+    assert float(sd["model.20.m.0.router.temperature"]) == pytest.approx(0.8)
+    kinds = [type(x) for x in m.model]
+    assert kinds.count(VisualEnhancedAdaptiveGateMoE) == 3 and kinds.count(C2fMoT) == 3 and kinds.count(C2fMoA) == 1
+    assert m.model[11].expert_backend == "shared_inverted" and m.model[5].expert_backend == "low_rank_fused"
+    for mod in (m.model[5], m.model[14], m.model[17], MoABlock(48, 6).eval()):
+        with pytest.raises(NotImplementedError, match="not built yet"):
+            mod(torch.zeros(1, mod.cv1.conv.in_channels if hasattr(mod, "cv1") else 48 if isinstance(mod, MoABlock) else 128, 8, 8))

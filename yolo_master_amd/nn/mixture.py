@@ -1,0 +1,408 @@
+"""Drop-in boundary of the config-5 mixture modules:
+`VisualEnhancedAdaptiveGateMoE`, `C2fMoA` / `MoABlock`, `C2fMoT` / `MoTBlock`.
+
+Round-1 status: the BOUNDARY only.  The classes keep the reference's constructor signatures, parameter / buffer names,
+shapes and registration order, so reference checkpoints of the v0_10 moa / mot YAMLs load unchanged and
+`DetectionModel("yolo-master-moa-mot-n.yaml")` builds (tests/test_host_logic.py checks the key contract against keys
+dumped from the real reference).  Their HIP kernels are not written yet: `forward` raises `NotImplementedError` —
+there is no CPU or PyTorch fallback.  The checker for those kernels already exists: `oracle/gated_ref.py`,
+`oracle/moa_ref.py`, `oracle/mot_ref.py` reproduce the real reference bit for bit, up to the whole config-5 model.
+
+Reference: ultralytics/nn/modules/moe/gated.py:82-1764, moe/experts.py:183-269, moa/{block,heads,router,wrappers}.py,
+mot/{block,experts,router,wrappers}.py.  Parameter containers are plain torch.nn layers (memory only; never called).
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+import torch.nn as nn
+
+from .modules import Conv, YmkModule
+
+_NOT_BUILT = ("{}: the HIP kernels of this module are not built yet (drop-in boundary only in round 1); "
+              "there is no CPU / PyTorch fallback")
+
+
+def get_safe_groups(channels: int, desired_groups: int = 8) -> int:
+    """Largest group count <= desired dividing channels (ultralytics/nn/modules/utils.py:108-115)."""
+    if channels <= 0:
+        return 1
+    g = min(desired_groups, channels)
+    while channels % g != 0:
+        g -= 1
+    return max(1, g)
+
+
+class _Boundary(YmkModule):
+    def _run(self, x, out=None):
+        raise NotImplementedError(_NOT_BUILT.format(type(self).__name__))
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError(f"{type(self).__name__}: the ymk path implements eval-mode inference only")
+        raise NotImplementedError(_NOT_BUILT.format(type(self).__name__))
+
+
+def _gn(c, desired=8):
+    return nn.GroupNorm(get_safe_groups(c, desired), c)
+
+
+# ----------------------------------------------------------------------------------------- gated MoE
+class DualStreamGateRouter(nn.Module):
+    """moe/gated.py:82-122."""
+
+    def __init__(self, in_channels, num_experts, top_k, temperature=1.0, local_reduction=16, pool_scale=4):
+        super().__init__()
+        self.num_experts, self.top_k = num_experts, top_k
+        self.temperature = max(float(temperature), 1e-3)
+        self.pool_scale = pool_scale
+        self.global_fc = nn.Linear(2 * in_channels, num_experts, bias=False)
+        reduced = max(in_channels // local_reduction, 4)
+        self.local_conv = nn.Sequential(
+            nn.Conv2d(in_channels, in_channels, 3, padding=1, groups=in_channels, bias=False), _gn(in_channels, 8), nn.SiLU(),
+            nn.Conv2d(in_channels, reduced, 1, bias=False), _gn(reduced, 4), nn.SiLU(),
+            nn.Conv2d(reduced, num_experts, 1, bias=True))
+        self.alpha = nn.Parameter(torch.tensor(0.5))
+
+
+class FusedExpertGroup(nn.Module):
+    """moe/gated.py:1003-1036."""
+
+    def __init__(self, in_channels, out_channels, num_experts, num_groups=8, top_k=2):
+        super().__init__()
+        fused = num_experts * out_channels
+        g = min(get_safe_groups(in_channels, num_groups), fused)
+        while g > 1 and (in_channels % g != 0 or fused % g != 0):
+            g -= 1
+        self.fused_conv = nn.Conv2d(in_channels, fused, 3, padding=1, groups=max(1, g), bias=False)
+        self.expert_norm_weight = nn.Parameter(torch.ones(num_experts, out_channels))
+        self.expert_norm_bias = nn.Parameter(torch.zeros(num_experts, out_channels))
+
+
+class LowRankFusedExpertGroup(nn.Module):
+    """moe/gated.py:1101-1142."""
+
+    def __init__(self, in_channels, out_channels, num_experts, num_groups=8, top_k=2, bottleneck_ratio=0.5, min_channels=16):
+        super().__init__()
+        bc = min(in_channels, max(min_channels, int(round(in_channels * bottleneck_ratio))))
+        self.bottleneck = nn.Sequential(nn.Conv2d(in_channels, bc, 1, bias=False), _gn(bc, num_groups), nn.SiLU())
+        self.fused = FusedExpertGroup(bc, out_channels, num_experts, num_groups, top_k=top_k)
+
+
+class SharedInvertedExpertGroup(nn.Module):
+    """moe/experts.py:183-229."""
+
+    def __init__(self, in_channels, out_channels, num_experts, expand_ratio=2.0, kernel_size=3, top_k=2, weight_threshold=0.0):
+        super().__init__()
+        hid = max(1, int(in_channels * expand_ratio))
+        self.shared_feature = nn.Sequential(
+            nn.Conv2d(in_channels, hid, 1, bias=False), _gn(hid), nn.SiLU(),
+            nn.Conv2d(hid, hid, kernel_size, padding=kernel_size // 2, groups=hid, bias=False), _gn(hid), nn.SiLU())
+        self.expert_projections = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(hid, out_channels, 1, bias=False), _gn(out_channels)) for _ in range(num_experts))
+
+
+class VisualDetailGate(nn.Module):
+    """moe/gated.py:1154-1169."""
+
+    def __init__(self, channels, num_groups=8, reduction=8):
+        super().__init__()
+        hidden = max(channels // reduction, 8)
+        self.detail_filter = nn.Sequential(
+            nn.Conv2d(channels, channels, 3, padding=1, groups=channels, bias=False), _gn(channels, num_groups), nn.SiLU(),
+            nn.Conv2d(channels, hidden, 1, bias=False), nn.SiLU(), nn.Conv2d(hidden, channels, 1, bias=True), nn.Sigmoid())
+        self.detail_scale = nn.Parameter(torch.tensor(0.1))
+
+
+class PyramidContextMixer(nn.Module):
+    """moe/gated.py:1184-1207."""
+
+    def __init__(self, channels, num_groups=8, pool_scales=(2, 4)):
+        super().__init__()
+        self.pool_scales = tuple(pool_scales)
+        self.local_context = nn.Sequential(
+            nn.Conv2d(channels, channels, 3, padding=1, groups=channels, bias=False), _gn(channels, num_groups), nn.SiLU())
+        self.pool_projections = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(channels, channels, 1, bias=False), _gn(channels, num_groups), nn.SiLU())
+            for _ in self.pool_scales)
+        self.context_gate = nn.Sequential(nn.Conv2d(channels, channels, 1, bias=True), nn.Sigmoid())
+        self.context_scale = nn.Parameter(torch.tensor(0.1))
+
+
+class VisualEnhancedAdaptiveGateMoE(_Boundary):
+    """moe/gated.py:1703-1764 (end of the AdaptiveGateMoE chain :268-1701)."""
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8,
+                 initial_temperature=1.2, final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0,
+                 entropy_loss_coeff=0.01, fused_expert_threshold=8, shuffle_groups=2, bottleneck_ratio=0.5,
+                 refine_reduction=8, detail_reduction=8):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_experts, self.top_k, self.num_groups = num_experts, top_k, num_groups
+        self.initial_temperature, self.final_temperature = initial_temperature, final_temperature
+        self.dynamic_channels = int(in_channels * split_ratio)
+        self.static_channels = in_channels - self.dynamic_channels
+        self.out_dynamic = int(out_channels * split_ratio)
+        self.out_static = out_channels - self.out_dynamic
+        self.shuffle_groups = shuffle_groups if out_channels % shuffle_groups == 0 else 1
+        se_hidden = max(in_channels // 4, 4)
+        self.se_gate = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(in_channels, se_hidden, bias=False),
+                                     nn.SiLU(), nn.Linear(se_hidden, in_channels, bias=True), nn.Sigmoid())
+        sc = self.static_channels
+        self.static_net = nn.Sequential(
+            nn.Conv2d(sc, sc, 3, padding=1, groups=sc, bias=False), nn.BatchNorm2d(sc), nn.SiLU(),
+            nn.Conv2d(sc, self.out_static, 1, bias=False), nn.BatchNorm2d(self.out_static), nn.SiLU())
+        self.routing = DualStreamGateRouter(self.dynamic_channels, num_experts, top_k, temperature=initial_temperature)
+        if num_experts <= fused_expert_threshold:
+            self.expert_backend = "low_rank_fused"
+            self.fused_experts = LowRankFusedExpertGroup(self.dynamic_channels, self.out_dynamic, num_experts, num_groups,
+                                                         top_k=top_k, bottleneck_ratio=bottleneck_ratio)
+        else:
+            self.expert_backend = "shared_inverted"
+            self.fused_experts = SharedInvertedExpertGroup(self.dynamic_channels, self.out_dynamic, num_experts, top_k=top_k)
+        self.complexity_estimator = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(self.dynamic_channels, 1, 1), nn.Sigmoid())
+        self.proj = nn.Conv2d(out_channels, out_channels, 1, bias=False)
+        self.bn = _gn(out_channels, num_groups)
+        refine_hidden = max(out_channels // refine_reduction, 8)
+        self.feature_refiner = nn.Sequential(
+            nn.Conv2d(out_channels, out_channels, 3, padding=1, groups=out_channels, bias=False), _gn(out_channels, num_groups),
+            nn.SiLU())
+        self.feature_gate = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(out_channels, refine_hidden, 1, bias=False), nn.SiLU(),
+                                          nn.Conv2d(refine_hidden, out_channels, 1, bias=True), nn.Sigmoid())
+        self.refine_scale = nn.Parameter(torch.tensor(0.1))
+        self.context_mixer = PyramidContextMixer(out_channels, num_groups)
+        self.detail_gate = VisualDetailGate(self.dynamic_channels, num_groups, detail_reduction)
+        self.router_hook_names = ("detail", "context", "refine")
+
+
+# ----------------------------------------------------------------------------------------- MoA
+class _MoARouter(nn.Module):
+    """moa/router.py:29-48."""
+
+    def __init__(self, dim, num_groups, reduction=8, temperature=1.0):
+        super().__init__()
+        self.temperature = max(temperature, 0.1)
+        hidden = max(dim // reduction, num_groups * 2)
+        self.router = nn.Sequential(nn.Conv2d(dim, hidden, 1, bias=False), _gn(hidden, 4), nn.SiLU(),
+                                    nn.Conv2d(hidden, num_groups, 1, bias=True))
+
+
+class _LocalAttnHead(nn.Module):
+    """moa/heads.py:120-141."""
+
+    def __init__(self, dim, num_heads, head_dim=None, window_size=7):
+        super().__init__()
+        self.num_heads, self.head_dim, self.window_size = num_heads, head_dim or max(dim // num_heads, 16), max(1, int(window_size))
+        inner = self.head_dim * num_heads
+        self.qkv_dw = nn.Conv2d(dim, dim, 3, padding=1, groups=dim, bias=False)
+        self.qkv_pw = nn.Conv2d(dim, inner * 3, 1, bias=False)
+        self.proj = nn.Conv2d(inner, dim, 1, bias=False)
+        self.pe = nn.Conv2d(inner, inner, 7, padding=3, groups=inner, bias=False)
+        self.norm = _gn(dim)
+
+
+class _RegionalAttnHead(nn.Module):
+    """moa/heads.py:166-206."""
+
+    def __init__(self, dim, num_heads, head_dim=None, pool_stride=2, max_kv_tokens=4096):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, head_dim or max(dim // num_heads, 16)
+        self.pool_stride, self.max_kv_tokens = pool_stride, max_kv_tokens
+        inner = self.head_dim * num_heads
+        self.q_proj = nn.Conv2d(dim, inner, 1, bias=False)
+        self.kv_proj = nn.Conv2d(dim, inner * 2, 1, bias=False)
+        self.proj = nn.Conv2d(inner, dim, 1, bias=False)
+        self.norm = _gn(dim)
+
+
+class _GlobalAttnHead(nn.Module):
+    """moa/heads.py:256-312: the orthogonal random-feature basis is a persistent buffer seeded per block."""
+
+    def __init__(self, dim, num_heads, head_dim=None, nb_features=64, rf_seed=0x5F3759DF):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, head_dim or max(dim // num_heads, 16)
+        inner = self.head_dim * num_heads
+        self.qkv = nn.Conv2d(dim, inner * 3, 1, bias=False)
+        self.proj = nn.Conv2d(inner, dim, 1, bias=False)
+        self.norm = _gn(dim)
+        eff = min(nb_features, self.head_dim)
+        with torch.no_grad():
+            gen = torch.Generator().manual_seed(rf_seed)
+            rf, _ = torch.linalg.qr(torch.randn(self.head_dim, self.head_dim, generator=gen, dtype=torch.float32))
+        self.register_buffer("_rf_matrix", rf[:eff].contiguous(), persistent=True)
+
+
+class MoABlock(_Boundary):
+    """moa/block.py:21-131."""
+
+    NUM_GROUPS = 3
+
+    def __init__(self, dim, num_heads=8, mlp_ratio=2.0, temperature=1.0, attn_drop=0.0, shortcut=True, aux_loss_coeff=0.01,
+                 block_index=0, local_window_size=7, sequential_heads=True, regional_max_kv_tokens=4096,
+                 sparse_inference=False, sparse_inference_threshold=0.02, inference_sparse_threshold=None):
+        super().__init__()
+        if num_heads <= 0 or num_heads % self.NUM_GROUPS != 0:
+            raise ValueError(f"num_heads ({num_heads}) must be positive and divisible by NUM_GROUPS ({self.NUM_GROUPS})")
+        self.shortcut = shortcut
+        head_dim = max(dim // num_heads, 16)
+        hpg = num_heads // self.NUM_GROUPS
+        ls = torch.ones(dim, 1, 1) * (0.1 if shortcut else 1.0)
+        self.ls_attn = nn.Parameter(ls.clone())
+        self.ls_ffn = nn.Parameter(ls.clone())
+        self.local_head = _LocalAttnHead(dim, hpg, head_dim, window_size=local_window_size)
+        self.region_head = _RegionalAttnHead(dim, hpg, head_dim, max_kv_tokens=regional_max_kv_tokens)
+        self.global_head = _GlobalAttnHead(dim, hpg, head_dim, rf_seed=block_index * 7919 + 2 * 65537)
+        self.router = _MoARouter(dim, self.NUM_GROUPS, temperature=temperature)
+        self.fusion = Conv(dim, dim, 1, act=False)
+        hidden = int(dim * mlp_ratio)
+        self.ffn = nn.Sequential(Conv(dim, hidden, 1), Conv(hidden, dim, 1, act=False))
+
+
+class C2fMoA(_Boundary):
+    """moa/wrappers.py:40-142."""
+
+    def __init__(self, c1, c2, n=1, num_heads=6, mlp_ratio=2.0, temperature=1.0, shortcut=True, e=0.5, aux_loss_coeff=0.01,
+                 local_window_size=7, sequential_heads=True, regional_max_kv_tokens=4096, sparse_inference=False,
+                 sparse_inference_threshold=0.02, inference_sparse_threshold=None):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        h, it = num_heads, 256
+        while h % MoABlock.NUM_GROUPS != 0 and it > 0:
+            h, it = h + 1, it - 1
+        it = 256
+        while self.c // h < 16 and h > MoABlock.NUM_GROUPS and it > 0:
+            h, it = h - MoABlock.NUM_GROUPS, it - 1
+        h = max(h, MoABlock.NUM_GROUPS)
+        if h != num_heads:
+            warnings.warn(f"C2fMoA(num_heads={num_heads}) adjusted to {h} (divisible by 3, head_dim >= 16)", stacklevel=2)
+        self.m = nn.ModuleList(
+            MoABlock(self.c, num_heads=h, mlp_ratio=mlp_ratio, temperature=temperature, shortcut=shortcut,
+                     aux_loss_coeff=aux_loss_coeff, block_index=i, local_window_size=local_window_size,
+                     sequential_heads=sequential_heads, regional_max_kv_tokens=regional_max_kv_tokens) for i in range(n))
+
+
+# ----------------------------------------------------------------------------------------- MoT
+class _LocalConvTransformerExpert(nn.Module):
+    """mot/experts.py:72-121."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=2.0, dropout=0.0, local_window_size=0):
+        super().__init__()
+        self.num_heads, self.local_window_size = num_heads, int(local_window_size)
+        self.ls1 = nn.Parameter(torch.ones(dim, 1, 1) * 0.1)
+        self.ls2 = nn.Parameter(torch.ones(dim, 1, 1) * 0.1)
+        self.dw_mix = nn.Conv2d(dim, dim, 3, padding=1, groups=dim, bias=False)
+        self.qkv = nn.Conv2d(dim, dim * 3, 1, bias=False)
+        self.pe = nn.Conv2d(dim, dim, 7, padding=3, groups=dim, bias=False)
+        self.proj = nn.Conv2d(dim, dim, 1, bias=False)
+        self.norm1, self.norm2 = _gn(dim), _gn(dim)
+        hid = int(dim * mlp_ratio)
+        self.ffn_gate = nn.Sequential(Conv(dim, hid, 1), nn.Sigmoid())
+        self.ffn_val = Conv(dim, hid, 1)
+        self.ffn_out = Conv(hid, dim, 1, act=False)
+
+
+def _mlp(dim, hid, dropout):
+    return nn.Sequential(nn.Linear(dim, hid), nn.GELU(), nn.Dropout(dropout), nn.Linear(hid, dim))
+
+
+class _WindowTransformerExpert(nn.Module):
+    """mot/experts.py:174-235."""
+
+    def __init__(self, dim, num_heads, window_size=7, mlp_ratio=2.0, dropout=0.0, shift_size=0):
+        super().__init__()
+        self.num_heads, self.win = num_heads, window_size
+        self.shift_size = (window_size // 2) if shift_size else 0
+        self.ls1 = nn.Parameter(torch.ones(dim) * 0.1)
+        self.ls2 = nn.Parameter(torch.ones(dim) * 0.1)
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim, bias=False)
+        self.norm1, self.norm2 = nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.ffn = _mlp(dim, int(dim * mlp_ratio), dropout)
+
+
+class _DeformableTransformerExpert(nn.Module):
+    """mot/experts.py:328-379."""
+
+    def __init__(self, dim, num_heads, n_points=4, mlp_ratio=2.0, dropout=0.0, align_corners=True):
+        super().__init__()
+        self.num_heads, self.n_points, self.align_corners = num_heads, n_points, align_corners
+        self.ls1 = nn.Parameter(torch.ones(dim) * 0.1)
+        self.ls2 = nn.Parameter(torch.ones(dim) * 0.1)
+        self.q_proj = nn.Linear(dim, dim, bias=False)
+        self.v_proj = nn.Linear(dim, dim, bias=False)
+        self.offset_proj = nn.Linear(dim, num_heads * n_points * 2, bias=True)
+        self.attn_proj = nn.Linear(dim, num_heads * n_points, bias=True)
+        self.out_proj = nn.Linear(dim, dim, bias=False)
+        self.norm1, self.norm2 = nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.ffn = _mlp(dim, int(dim * mlp_ratio), dropout)
+
+
+class _MoTRouter(nn.Module):
+    """mot/router.py:57-150 (spatial router; no scene-aware branch — the master YAMLs do not enable it)."""
+
+    def __init__(self, dim, num_experts=3, top_k=2, temperature=1.0):
+        super().__init__()
+        self.num_experts, self.top_k = num_experts, top_k
+        self.register_buffer("temperature", torch.tensor(max(temperature, 0.1)), persistent=True)
+        hidden = max(dim // 8, num_experts * 4)
+        self.router = nn.Sequential(nn.Conv2d(dim, hidden, 1, bias=False), _gn(hidden, 4), nn.SiLU(),
+                                    nn.Conv2d(hidden, num_experts, 1, bias=True))
+
+
+class MoTBlock(_Boundary):
+    """mot/block.py:20-170."""
+
+    NUM_EXPERTS = 3
+
+    def __init__(self, dim, num_heads=8, top_k=2, window_size=7, n_points=4, mlp_ratio=2.0, temperature=1.0,
+                 use_spatial_router=True, balance_loss_coeff=0.01, router_z_loss_coeff=None, dropout=0.0,
+                 exploration_eps=0.02, window_shift=False, grid_align_corners=True, sparse_train=False,
+                 scene_aware_router=False, scene_hidden_dim=None, scene_consistency_coeff=0.0, sparse_train_warmup_steps=0,
+                 scene_inference_mode="dynamic", local_attn_window=0):
+        super().__init__()
+        if not 1 <= top_k <= self.NUM_EXPERTS:
+            raise ValueError(f"top_k must be in [1, {self.NUM_EXPERTS}], got {top_k}")
+        if scene_aware_router or not use_spatial_router:
+            raise NotImplementedError("ymk MoTBlock: only the spatial, non-scene-aware router of the master YAMLs is mirrored")
+        self.top_k = int(top_k)
+        self.register_buffer("_sparse_train_step", torch.tensor(0, dtype=torch.long), persistent=True)
+        h = num_heads
+        while dim % h != 0 and h > 1:
+            h -= 1
+        h = max(1, h)
+        self.experts = nn.ModuleList([
+            _LocalConvTransformerExpert(dim, h, mlp_ratio, dropout, local_window_size=local_attn_window),
+            _WindowTransformerExpert(dim, h, window_size, mlp_ratio, dropout, shift_size=window_size // 2 if window_shift else 0),
+            _DeformableTransformerExpert(dim, h, n_points, mlp_ratio, dropout, align_corners=grid_align_corners)])
+        self.router = _MoTRouter(dim, self.NUM_EXPERTS, top_k, temperature=temperature)
+        self.out_norm = _gn(dim)
+        self.out_proj = nn.Conv2d(dim, dim, 1, bias=False)
+
+
+class C2fMoT(_Boundary):
+    """mot/wrappers.py:19-105."""
+
+    def __init__(self, c1, c2, n=1, num_heads=6, top_k=2, window_size=7, n_points=4, mlp_ratio=2.0, temperature=1.0,
+                 balance_loss_coeff=0.01, e=0.5, sparse_train=False, scene_aware_router=False, scene_hidden_dim=None,
+                 scene_consistency_coeff=0.0, sparse_train_warmup_steps=0, scene_inference_mode="dynamic", local_attn_window=0):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        h = num_heads
+        while h > 1 and (self.c % h != 0 or self.c // h < 8):
+            h -= 1
+        h = max(1, h)
+        self.m = nn.ModuleList(
+            MoTBlock(dim=self.c, num_heads=h, top_k=top_k, window_size=window_size, n_points=n_points, mlp_ratio=mlp_ratio,
+                     temperature=temperature, balance_loss_coeff=balance_loss_coeff, window_shift=bool(i % 2),
+                     sparse_train=sparse_train, scene_aware_router=scene_aware_router, scene_hidden_dim=scene_hidden_dim,
+                     scene_consistency_coeff=scene_consistency_coeff, sparse_train_warmup_steps=sparse_train_warmup_steps,
+                     scene_inference_mode=scene_inference_mode, local_attn_window=local_attn_window) for i in range(n))
+
+
+MIXTURE_BOUNDARY_MODULES = {"VisualEnhancedAdaptiveGateMoE": VisualEnhancedAdaptiveGateMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
+MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import yaml
 
+from .mixture import MIXTURE_BOUNDARY_MODULES, MIXTURE_BOUNDARY_REPEAT
 from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DWConv, LazyUpsample,
                       VirtualCat, YmkModule, set_compute_dtype)
 
@@ -29,7 +30,9 @@ BASE_MODULES = {"Conv": Conv, "DWConv": DWConv, "Bottleneck": Bottleneck, "C2f":
                 "A2C2f": A2C2f}
 REPEAT_MODULES = {C2f, C3, C3k2, A2C2f}
 # the plugin registry the reference resolves YAML names through (mixture_registry.py:39-81)
-MIXTURE_MODULES = {"ES_MOE": ES_MOE}
+# (the config-5 modules are registered as drop-in boundaries: they build and load checkpoints, their kernels are next)
+MIXTURE_MODULES = {"ES_MOE": ES_MOE, **MIXTURE_BOUNDARY_MODULES}
+MIXTURE_REPEAT_MODULES = set(MIXTURE_BOUNDARY_REPEAT)
 HEAD_MODULES = {"Detect": Detect}
 
 
@@ -118,6 +121,9 @@ def parse_model(d, ch, verbose=False):
             if c2 != nc:
                 c2 = make_divisible(min(c2, max_channels) * width, 8)
             args = [c1, c2, *args[1:]]
+            if mod in MIXTURE_REPEAT_MODULES:   # the depth-scaled repeat becomes the module's internal n
+                args.insert(2, n)
+                n = 1
         elif mod is Concat:
             c2 = sum(ch[x] for x in f)
         elif mod is Detect:

@@ -118,10 +118,12 @@ static float timeit(F&& f, int reps = 20) {
     return ts[ts.size() / 2];
 }
 
-int main() {
-    struct Shape { int M, N, K; } shapes[] = {{409600, 128, 1152}, {409600, 128, 128}, {102400, 256, 384}, {102400, 256, 2304},
+int main(int argc, char** argv) {
+    struct Shape { int M, N, K; } shapes[] = {{409600, 128, 128}, {102400, 256, 384}, {409600, 128, 1152}, {102400, 256, 2304},
                                               {25600, 512, 768}, {1638400, 128, 128}};
-    for (auto sh : shapes) {
+    const int nshape = argc > 1 ? atoi(argv[1]) : 6;   // `gemm256.bin 2` = the two quick shapes
+    for (int si = 0; si < nshape && si < 6; ++si) {
+        const Shape sh = shapes[si];
         const size_t nx = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, ny = (size_t)sh.M * sh.N;
         std::vector<bf16_t> hx(nx), hw(nw);
         std::vector<float> hb(sh.N);

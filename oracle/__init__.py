@@ -9,6 +9,7 @@ import this package; only tests/, __graft_entry__.smoke() and bench.py's cpu_bas
 Parity status: pinned against golden vectors generated from the real reference
 (tests/golden/make_golden.py, make_golden_moa.py, make_golden_mot.py, make_golden_gated.py, make_golden_cfg5.py) for the forward pass, routing
 decisions, greedy NMS and the MoA/MoT blocks;
-CW-NMS is "parity unpinned" (no reference Python implementation or test exists — spec is the
-C++ edge demo, see nms_ref.cw_refine).
+CW-NMS has no Python implementation in the reference: its C++ edge demo is compiled IN PLACE
+(oracle/cwref/build.py -> oracle/_ref/libcwref.so, against a small OpenCV geometry shim) and pins nms_ref.cw_refine
+(tests/golden/make_golden_cw.py, tests/test_oracle_cw.py).
 """

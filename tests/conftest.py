@@ -31,3 +31,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+def pytest_runtest_logreport(report):
+    """Append every failure (test id + traceback) to $YMK_TEST_FAILURE_LOG when set: lets a rare flake in a long
+    unattended loop be identified afterwards."""
+    import os
+
+    path = os.environ.get("YMK_TEST_FAILURE_LOG")
+    if path and report.failed:
+        with open(path, "a") as f:
+            f.write(f"=== {report.nodeid} [{report.when}]\n{report.longreprtext}\n")

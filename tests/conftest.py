@@ -42,3 +42,29 @@ def pytest_runtest_logreport(report):
     if path and report.failed:
         with open(path, "a") as f:
             f.write(f"=== {report.nodeid} [{report.when}]\n{report.longreprtext}\n")
+
+
+def pytest_runtest_protocol(item, nextitem):
+    """CPU-side tests get ONE retry (rendezvous ports, process spawning and compiler invocations can fail
+    transiently on a busy host); a test has to fail twice to be reported as failed, and every retry is printed.
+    GPU parity tests are never retried.  Disable with YMK_NO_RERUN=1."""
+    import os
+
+    from _pytest.runner import runtestprotocol
+
+    if "gpu" in item.keywords or os.environ.get("YMK_NO_RERUN"):
+        return None
+    item.ihook.pytest_runtest_logstart(nodeid=item.nodeid, location=item.location)
+    reports = runtestprotocol(item, nextitem=nextitem, log=False)
+    if any(r.failed for r in reports):
+        first = next(r for r in reports if r.failed)
+        print(f"\n[retry] {item.nodeid} failed once ({first.when}): {first.longreprtext.splitlines()[-1] if first.longreprtext else ''}")
+        log = os.environ.get("YMK_TEST_FAILURE_LOG")
+        if log:
+            with open(log, "a") as f:
+                f.write(f"=== first attempt of {item.nodeid} [{first.when}]\n{first.longreprtext}\n")
+        reports = runtestprotocol(item, nextitem=nextitem, log=False)
+    for r in reports:
+        item.ihook.pytest_runtest_logreport(report=r)
+    item.ihook.pytest_runtest_logfinish(nodeid=item.nodeid, location=item.location)
+    return True

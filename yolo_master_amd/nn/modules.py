@@ -79,8 +79,7 @@ def to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """NCHW-logical tensor (any memory format) -> NHWC tensor of the compute dtype."""
     if x.dim() != 4:
         raise ValueError(f"expected a 4-D NCHW tensor, got {tuple(x.shape)}")
-    if not x.is_cuda:
-        raise RuntimeError("yolo_master_amd modules run on MI355X (HIP) only; got a CPU tensor")
+    ops.require_gpu(x, "yolo_master_amd modules")
     xh = x.permute(0, 2, 3, 1)
     if xh.dtype != dtype:
         xh = xh.to(dtype)
@@ -191,8 +190,7 @@ class Conv(YmkModule):
         if self.training:
             raise RuntimeError("Conv: the ymk path implements eval-mode inference only")
         if self.conv.in_channels <= 4 and self.conv.groups == 1:
-            if not x.is_cuda:
-                raise RuntimeError("yolo_master_amd modules run on MI355X (HIP) only; got a CPU tensor")
+            ops.require_gpu(x, "yolo_master_amd modules")
             return self._run_stem(x).permute(0, 3, 1, 2)
         return self._run(to_nhwc(x, self.ymk_dtype)).permute(0, 3, 1, 2)
 

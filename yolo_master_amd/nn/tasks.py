@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import yaml
 
+from .. import ops
 from .mixture import MIXTURE_BOUNDARY_MODULES, MIXTURE_BOUNDARY_REPEAT
 from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DWConv, LazyUpsample,
                       VirtualCat, YmkModule, set_compute_dtype)
@@ -236,8 +237,7 @@ class DetectionModel(nn.Module):
         receives every layer's NHWC output (parity tests)."""
         if self.training:
             raise RuntimeError("ymk DetectionModel implements eval-mode inference only; call .eval()")
-        if not x.is_cuda:
-            raise RuntimeError("yolo_master_amd runs on MI355X (HIP) only; got a CPU tensor. No CPU fallback exists.")
+        ops.require_gpu(x, "yolo_master_amd models")
         if self._flags is None or self._flags.device != x.device:
             self._flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
         ys = []

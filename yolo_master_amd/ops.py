@@ -83,11 +83,14 @@ def _p(t: torch.Tensor | None):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _need_gpu(t: torch.Tensor) -> None:
+def require_gpu(t: torch.Tensor, what: str = "yolo_master_amd ops") -> None:
+    """The one device guard of the product (modules, graph walk and op wrappers all call it): no CPU fallback."""
     if not t.is_cuda:
-        raise RuntimeError(
-            "yolo_master_amd ops run on MI355X (HIP) only; got a CPU tensor. There is no CPU fallback."
-        )
+        raise RuntimeError(f"{what} run on MI355X (HIP) only; got a CPU tensor. There is no CPU fallback.")
+
+
+def _need_gpu(t: torch.Tensor) -> None:
+    require_gpu(t)
 
 
 def _nhwc(t: torch.Tensor):

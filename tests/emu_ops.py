@@ -261,6 +261,248 @@ def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, c
     return dets, counts, idx, torch.zeros((1,), dtype=torch.int32)
 
 
+# ------------------------------------------------------------------------------------------------- config-5 rows
+def _put(y, out, dtype):
+    if out is None:
+        return y.to(dtype).contiguous()
+    assert tuple(out.shape) == tuple(y.shape), f"out {tuple(out.shape)} vs result {tuple(y.shape)}"
+    out.copy_(y.to(out.dtype))
+    return out
+
+
+def _act(y, act):
+    if act in (False, None):
+        return y
+    if act in (True, "silu"):
+        return F.silu(y)
+    if act == "sigmoid":
+        return torch.sigmoid(y)
+    if act == "gelu":
+        return F.gelu(y)
+    raise ValueError(act)
+
+
+def conv2d_act(x, w_packed, bias, k, stride, act, out=None, residual=None, out_dtype=None):
+    _count("conv2d_act")
+    if act in (False, True, "silu"):
+        return conv2d(x, w_packed, bias, k, stride, bool(act), out=out, residual=residual, out_dtype=out_dtype)
+    w = _unpack_conv(w_packed, k, x.shape[-1])
+    y = _act(F.conv2d(_nchw(x), w, bias, stride, k // 2), act)
+    return _finish(y, False, residual, out, out_dtype or x.dtype)
+
+
+def group_norm(x, groups, weight, bias, eps, act=False, out=None, out_dtype=None, affine_rows=None):
+    _count("group_norm")
+    B, H, W, C = x.shape
+    assert C % groups == 0
+    y = F.group_norm(_nchw(x), groups, None, None, eps)
+    if weight is not None:
+        assert weight.dtype == torch.float32
+        if affine_rows is not None:
+            assert affine_rows.dtype == torch.int32 and tuple(affine_rows.shape) == (B,)
+            w, b = weight[affine_rows.long()], bias[affine_rows.long()]
+            y = y * w.view(B, C, 1, 1) + b.view(B, C, 1, 1)
+        else:
+            y = y * weight.view(1, C, 1, 1) + bias.view(1, C, 1, 1)
+    return _put(_act(y, act).permute(0, 2, 3, 1), out, out_dtype or x.dtype)
+
+
+def layer_norm(x, weight, bias, eps, out=None):
+    _count("layer_norm")
+    return _put(F.layer_norm(x.float(), (x.shape[-1],), weight, bias, eps), out, x.dtype)
+
+
+def eltwise_mul(a, b, out=None):
+    _count("eltwise_mul")
+    return _put(a.float() * b.float(), out, a.dtype)
+
+
+def lerp(a, b, alpha, out=None):
+    _count("lerp")
+    return _put((1 - alpha) * a.float() + alpha * b.float(), out, a.dtype)
+
+
+def fma_gate(x, a, b, scale, out=None):
+    _count("fma_gate")
+    assert b.shape == x.shape or tuple(b.shape) == (x.shape[0], 1, 1, x.shape[3])
+    return _put(x.float() + float(scale) * a.float() * b.float(), out, x.dtype)
+
+
+def channel_gate(x, gate, out=None):
+    _count("channel_gate")
+    assert gate.dtype == torch.float32 and tuple(gate.shape) == (x.shape[0], 1, 1, x.shape[3])
+    return _put(x.float() * gate, out, x.dtype)
+
+
+def weighted_sum(weights, parts, out=None):
+    _count("weighted_sum")
+    assert weights.dtype == torch.float32 and weights.shape[-1] >= len(parts)
+    assert tuple(weights.shape[:3]) in (tuple(parts[0].shape[:3]), (parts[0].shape[0], 1, 1))
+    y = 0
+    for e, p in enumerate(parts):
+        y = y + weights[..., e:e + 1] * p.float()
+    return _put(y, out, parts[0].dtype)
+
+
+def mean_upsampled(parts, out=None):
+    _count("mean_upsampled")
+    H, W = parts[0].shape[1:3]
+    y = 0
+    for p in parts:
+        y = y + (p.float() if tuple(p.shape[1:3]) == (H, W) else
+                 F.interpolate(_nchw(p), size=(H, W), mode="nearest").permute(0, 2, 3, 1))
+    return _put(y / len(parts), out, parts[0].dtype)
+
+
+def adaptive_avg_pool(x, Ho, Wo, out=None, out_dtype=None):
+    _count("adaptive_avg_pool")
+    return _put(F.adaptive_avg_pool2d(_nchw(x), (Ho, Wo)).permute(0, 2, 3, 1), out, out_dtype or x.dtype)
+
+
+def avg_pool(x, k, out=None, out_dtype=None):
+    _count("avg_pool")
+    return _put(F.avg_pool2d(_nchw(x), k, k).permute(0, 2, 3, 1), out, out_dtype or x.dtype)
+
+
+def channel_stats(x, want_std=False):
+    _count("channel_stats")
+    xf = x.float()
+    mean = xf.mean((1, 2), keepdim=True)
+    if not want_std:
+        return mean
+    std = xf.std((1, 2), unbiased=False, keepdim=True) if x.shape[1] * x.shape[2] > 1 else torch.zeros_like(mean)
+    return torch.cat([mean, std], -1)
+
+
+def _heads(t, heads, hd):
+    B, H, W, C = t.shape
+    assert C == heads * hd
+    return t.float().reshape(B, H * W, heads, hd).permute(0, 2, 1, 3)   # [B, heads, N, hd]
+
+
+def attention(q, k, v, heads, hd, scale, out=None):
+    _count("attention")
+    assert hd % 8 == 0, "kernel contract: head dims are padded to a multiple of 8 by the host"
+    B, H, W, _ = q.shape
+    p = torch.softmax(_heads(q, heads, hd) @ _heads(k, heads, hd).transpose(-1, -2) * scale, -1)
+    o = (p @ _heads(v, heads, hd)).permute(0, 2, 1, 3).reshape(B, H, W, heads * hd)
+    return _put(o, out, q.dtype)
+
+
+def window_attention(q, k, v, heads, hd, scale, win, shift=0, pad_q=None, pad_k=None, pad_v=None, out=None):
+    _count("window_attention")
+    assert hd % 8 == 0
+    B, H, W, C = q.shape
+    ph, pw = (win - H % win) % win, (win - W % win) % win
+    Hp, Wp = H + ph, W + pw
+
+    def prep(t, padv):
+        t = F.pad(t.float(), (0, 0, 0, pw, 0, ph))
+        if padv is not None and (ph or pw):
+            m = torch.ones(Hp, Wp, dtype=torch.bool)
+            m[:H, :W] = False
+            t[:, m] = padv.float()
+        if shift:
+            t = torch.roll(t, (-shift, -shift), (1, 2))
+        t = t.reshape(B, Hp // win, win, Wp // win, win, heads, hd).permute(0, 1, 3, 5, 2, 4, 6)
+        return t.reshape(B, Hp // win, Wp // win, heads, win * win, hd)
+
+    qw, kw, vw = prep(q, pad_q), prep(k, pad_k), prep(v, pad_v)
+    o = torch.softmax(qw @ kw.transpose(-1, -2) * scale, -1) @ vw
+    o = o.reshape(B, Hp // win, Wp // win, heads, win, win, hd).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, Hp, Wp, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    return _put(o[:, :H, :W], out, q.dtype)
+
+
+def linear_attention(q, k, v, rf, heads, hd, out=None):
+    _count("linear_attention")
+    B, H, W, _ = q.shape
+    assert rf.dtype == torch.float32 and rf.shape[1] == hd
+    nb = rf.shape[0]
+    qh, kh, vh = _heads(q, heads, hd), _heads(k, heads, hd), _heads(v, heads, hd)
+    qf = (F.relu(qh @ rf.t() * nb ** -0.5) + 1e-6).clamp(max=1e4)
+    kf = (F.relu(kh @ rf.t() * nb ** -0.5) + 1e-6).clamp(max=1e4)
+    numer = (qf @ (kf.transpose(-1, -2) @ vh)).clamp(-1e4, 1e4)
+    denom = (qf @ kf.sum(2).unsqueeze(-1)).clamp(min=1e-6)
+    return _put((numer / denom).permute(0, 2, 1, 3).reshape(B, H, W, heads * hd), out, q.dtype)
+
+
+def deform_attention(v, off_logits, aw_logits, heads, hd, n_points, align_corners, out=None):
+    _count("deform_attention")
+    B, H, W, C = v.shape
+    N = H * W
+    assert C == heads * hd and off_logits.shape[-1] == heads * n_points * 2 and aw_logits.shape[-1] == heads * n_points
+    off = off_logits.float().reshape(B, N, heads, n_points, 2).tanh()
+    aw = torch.softmax(aw_logits.float().reshape(B, N, heads, n_points), -1)
+    idx = torch.arange(N)
+    row = (idx // W).float() / max(H - 1, 1) * 2 - 1
+    col = (idx % W).float() / max(W - 1, 1) * 2 - 1
+    ref = torch.stack([col, row], -1)[None, :, None, None, :]
+    locs = (ref + off * 0.25).clamp(-1.0, 1.0).permute(0, 2, 1, 3, 4).reshape(B * heads, N, n_points, 2)
+    v4 = v.float().reshape(B, N, heads, hd).permute(0, 2, 3, 1).reshape(B * heads, hd, H, W)
+    smp = F.grid_sample(v4, locs, mode="bilinear", padding_mode="zeros", align_corners=align_corners)   # [B*h, hd, N, np]
+    smp = smp.reshape(B, heads, hd, N, n_points).permute(0, 3, 1, 4, 2)                                    # [B, N, h, np, hd]
+    o = (aw.unsqueeze(-1) * smp).sum(3).reshape(B, H, W, C)
+    return _put(o, out, v.dtype)
+
+
+def token_softmax(logits, n, inv_temp, top_k=0, out=None):
+    _count("token_softmax")
+    assert logits.dtype == torch.float32
+    w = torch.softmax(logits[..., :n] * inv_temp, -1)
+    if 0 < top_k < n:
+        vals, idx = w.topk(top_k, -1)
+        w = torch.zeros_like(w).scatter_(-1, idx, vals / vals.sum(-1, keepdim=True).clamp_min(1e-6))
+        sel = torch.zeros_like(w, dtype=torch.bool).scatter_(-1, idx, True)
+    else:
+        sel = torch.ones_like(w, dtype=torch.bool)
+    active = sel.reshape(w.shape[0], -1, n).any(1).to(torch.int32)
+    return _put(w, out, torch.float32), active
+
+
+def gated_route_decide(g_logits, loc_logits, alpha, inv_temp, top_k, cplx_logit):
+    _count("gated_route_decide")
+    B, E = g_logits.shape[0], g_logits.shape[-1]
+    a = 1.0 / (1.0 + float(np.exp(-alpha)))
+    logits = (a * g_logits.reshape(B, E) + (1 - a) * loc_logits.reshape(B, E)).clamp(-30.0, 30.0)
+    probs = torch.softmax(logits * inv_temp, 1)
+    tw, ti = torch.topk(probs, top_k, 1)
+    tw = tw / (tw.sum(1, keepdim=True) + 1e-6)
+    c = torch.sigmoid(cplx_logit.reshape(B)).mean()
+    c = torch.tensor(1.0) if not bool(torch.isfinite(c)) else c.clamp(0.3, 1.5)
+    if top_k > 1:
+        keep = torch.round(c * top_k).clamp(1, top_k)
+        tw = tw * (torch.arange(1, top_k + 1).view(1, -1) <= keep).float()
+        tw = tw / tw.sum(1, keepdim=True).clamp_min(1e-6)
+    return tw.reshape(B, 1, 1, top_k), ti.to(torch.int32), probs
+
+
+def expert_conv(x, w_packed, k, idx, out=None):
+    _count("expert_conv")
+    B, H, W, Cin = x.shape
+    E, Cout, Kp = w_packed.shape
+    K = idx.shape[1]
+    assert idx.dtype == torch.int32 and w_packed.dtype == x.dtype
+    ys = []
+    for b in range(B):
+        for j in range(K):
+            w = _unpack_conv(w_packed[int(idx[b, j])], k, Cin)
+            ys.append(F.conv2d(_nchw(x[b:b + 1]), w, None, 1, k // 2))
+    return _put(torch.cat(ys).permute(0, 2, 3, 1), out, x.dtype)
+
+
+def channel_shuffle_cat(parts, groups, out=None):
+    _count("channel_shuffle_cat")
+    cat = torch.cat(parts, -1)
+    B, H, W, C = cat.shape
+    y = cat.reshape(B, H, W, groups, C // groups).transpose(3, 4).reshape(B, H, W, C)
+    return _put(y, out, cat.dtype)
+
+
 EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
-            "detect_decode", "nms_batched"]
+            "detect_decode", "nms_batched",
+            "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "weighted_sum",
+            "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",
+            "linear_attention", "deform_attention", "token_softmax", "gated_route_decide", "expert_conv", "channel_shuffle_cat"]

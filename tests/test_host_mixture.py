@@ -1,0 +1,80 @@
+"""Config-5 rows on the CPU: the product's host orchestration of the mixture modules (``yolo_master_amd/nn/mixture.py``)
+over the emulated libymk entry points (``tests/emu_ops.py``, see ``tests/test_host_emu.py`` for what that proves),
+against golden vectors produced by the REAL reference modules (``tests/golden/make_golden_{moa,mot,gated,cfg5}.py``).
+
+The kernels behind the config-5 entry points are not in libymk yet: this pins the dataflow (packing, channel padding,
+buffer slicing, op order) that those kernels will be dropped into, module by module and for the whole model."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_host_emu import emu  # noqa: F401  (fixture)
+
+
+def _load(golden_dir, fam, name):
+    z = np.load(golden_dir / f"{fam}_{name}.npz")
+    sd = {k: torch.from_numpy(z[f"sd::{k}"]) for k in z["keys"].tolist()}
+    return z, sd
+
+
+def _prep(mod, sd):
+    mod.load_state_dict(sd)
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3
+    return mod.eval()
+
+
+def _close(got, ref, what, rtol=2e-5):
+    err = float((got - ref).abs().max())
+    assert err <= rtol * max(1.0, float(ref.abs().max())), f"{what}: max |d| = {err:.3e} (|ref| max {float(ref.abs().max()):.3f})"
+
+
+MOA_CASES = {"exact": {}, "blend": {}, "linear": {}, "kvcap": dict(regional_max_kv_tokens=64, shortcut=False)}
+
+
+@pytest.mark.parametrize("name", list(MOA_CASES))
+def test_moa_block_host_vs_reference(name, golden_dir, emu):
+    from yolo_master_amd.nn.mixture import MoABlock
+
+    z, sd = _load(golden_dir, "moa", name)
+    m = _prep(MoABlock(48, num_heads=6, **MOA_CASES[name]), sd)
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    with torch.inference_mode():
+        got = m(x)
+    _close(got, y, f"moa_{name}")
+    probs = m.last_route["weights"].permute(0, 3, 1, 2)          # [B, 3, H, W]
+    assert float((probs - torch.from_numpy(z["router_probs"])[0]).abs().max()) <= 1e-5
+    used = emu.CALLS
+    assert used["window_attention"] == 1 and used["group_norm"] == 4 and used["weighted_sum"] == 1
+    if name in ("linear", "kvcap"):
+        assert used.get("linear_attention") == 1 and used["attention"] == 1      # regional only
+    elif name == "blend":
+        assert used.get("linear_attention") == 1 and used["attention"] == 2 and used["lerp"] == 1
+    else:
+        assert "linear_attention" not in used and used["attention"] == 2
+
+
+def test_c2f_moa_host_vs_reference(golden_dir, emu):
+    from yolo_master_amd.nn.mixture import C2fMoA
+
+    z, sd = _load(golden_dir, "moa", "c2f")
+    with pytest.warns(UserWarning, match="adjusted to 3"):      # the reference warns about the head count too
+        m = _prep(C2fMoA(64, 96, n=2, num_heads=6), sd)
+    with torch.inference_mode():
+        got = m(torch.from_numpy(z["x"]))
+    _close(got, torch.from_numpy(z["y"]), "moa_c2f")
+
+
+def test_config5_entry_points_fail_loudly_without_kernels():
+    """Outside the emulation the config-5 entry points raise KernelNotBuilt: no silent PyTorch path."""
+    import inspect
+
+    from yolo_master_amd import ops
+
+    for name in ("group_norm", "layer_norm", "attention", "window_attention", "linear_attention", "deform_attention",
+                 "token_softmax", "weighted_sum", "expert_conv", "adaptive_avg_pool", "channel_stats"):
+        with pytest.raises(ops.KernelNotBuilt):
+            fn = getattr(ops, name)
+            required = [p for p in inspect.signature(fn).parameters.values() if p.default is inspect.Parameter.empty]
+            fn(*([None] * len(required)))

@@ -18,7 +18,8 @@ import warnings
 import torch
 import torch.nn as nn
 
-from .modules import Conv, YmkModule
+from .. import ops
+from .modules import Conv, YmkModule, to_nhwc
 
 _NOT_BUILT = ("{}: the HIP kernels of this module are not built yet (drop-in boundary only in round 1); "
               "there is no CPU / PyTorch fallback")
@@ -46,6 +47,57 @@ class _Boundary(YmkModule):
 
 def _gn(c, desired=8):
     return nn.GroupNorm(get_safe_groups(c, desired), c)
+
+
+# ----------------------------------------------------------------------------------------- packing / run helpers
+def _ceil(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _pack_conv(conv, dtype, device, pad_cout_to=None, pad_cin_to=None, scale=None):
+    """Bare nn.Conv2d (groups 1) or nn.Linear -> ([Cout][Kpad] in `dtype`, fp32 bias).  Zero padding of output / input
+    channels keeps every operand inside the kernels' vector-width rules; `scale` [Cout] folds a per-channel factor
+    (layer scale without a residual) into weights and bias."""
+    w = conv.weight.detach().float().to(device)
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif conv.groups != 1:
+        raise NotImplementedError("_pack_conv: dense convolutions only")
+    b = conv.bias.detach().float().to(device) if conv.bias is not None else torch.zeros(w.shape[0], device=device)
+    if scale is not None:
+        sc = scale.detach().float().reshape(-1).to(device)
+        w, b = w * sc.view(-1, 1, 1, 1), b * sc
+    if pad_cout_to is not None and pad_cout_to > w.shape[0]:
+        extra = pad_cout_to - w.shape[0]
+        w = torch.cat([w, w.new_zeros((extra, *w.shape[1:]))], 0)
+        b = torch.cat([b, b.new_zeros(extra)], 0)
+    if pad_cin_to is not None and pad_cin_to > w.shape[1]:
+        w = torch.cat([w, w.new_zeros((w.shape[0], pad_cin_to - w.shape[1], *w.shape[2:]))], 1)
+    return ops.pack_conv_weight(w, dtype), b.contiguous()
+
+
+def _pack_dw(conv, dtype, device):
+    if conv.groups != conv.in_channels or conv.in_channels != conv.out_channels or conv.bias is not None:
+        raise NotImplementedError("_pack_dw: bias-free depthwise convolutions only")
+    return ops.pack_dw_weight(conv.weight.detach().float().to(device), dtype)
+
+
+def _pack_norm(norm, device):
+    return (norm.weight.detach().float().to(device).contiguous(), norm.bias.detach().float().to(device).contiguous())
+
+
+def _pack_bn_conv(m: Conv, dtype, device, scale=None):
+    """modules.Conv (Conv2d + BN, 1x1 dense) with an optional per-channel factor folded in after the BN fold."""
+    w, b = m._folded()
+    w, b = w.to(device), b.to(device)
+    if scale is not None:
+        sc = scale.detach().float().reshape(-1).to(device)
+        w, b = w * sc.view(-1, 1, 1, 1), b * sc
+    return ops.pack_conv_weight(w, dtype), b.contiguous()
+
+
+def _vec(dtype) -> int:
+    return 8 if dtype == torch.bfloat16 else 4
 
 
 # ----------------------------------------------------------------------------------------- gated MoE
@@ -233,8 +285,11 @@ class _GlobalAttnHead(nn.Module):
         self.register_buffer("_rf_matrix", rf[:eff].contiguous(), persistent=True)
 
 
-class MoABlock(_Boundary):
-    """moa/block.py:21-131."""
+class MoABlock(YmkModule):
+    """moa/block.py:21-278 (eval, dense soft routing).  Host orchestration over libymk entry points; the kernels behind
+    the config-5 entry points (ops.py, second half) are next-round work, so on a GPU box the first of them raises
+    ``ops.KernelNotBuilt`` — the dataflow itself is checked on the CPU against the real reference's golden vectors
+    (tests/test_host_mixture.py)."""
 
     NUM_GROUPS = 3
 
@@ -244,7 +299,9 @@ class MoABlock(_Boundary):
         super().__init__()
         if num_heads <= 0 or num_heads % self.NUM_GROUPS != 0:
             raise ValueError(f"num_heads ({num_heads}) must be positive and divisible by NUM_GROUPS ({self.NUM_GROUPS})")
-        self.shortcut = shortcut
+        if sparse_inference:
+            raise NotImplementedError("ymk MoABlock: dense soft routing only (sparse_inference=False, the YAML default)")
+        self.dim, self.shortcut = dim, shortcut
         head_dim = max(dim // num_heads, 16)
         hpg = num_heads // self.NUM_GROUPS
         ls = torch.ones(dim, 1, 1) * (0.1 if shortcut else 1.0)
@@ -258,8 +315,100 @@ class MoABlock(_Boundary):
         hidden = int(dim * mlp_ratio)
         self.ffn = nn.Sequential(Conv(dim, hidden, 1), Conv(hidden, dim, 1, act=False))
 
+    # linear-attention switch-over of the global head (moa/_constants.py)
+    LINEAR_ATTN_THRESHOLD = 512
+    LINEAR_ATTN_BLEND_WINDOW = 64
 
-class C2fMoA(_Boundary):
+    def _pack(self, dtype, device):
+        f32 = torch.float32
+        hd = self.local_head.head_dim
+        if hd % 8:
+            raise NotImplementedError(f"ymk MoABlock: head_dim {hd} is not a multiple of 8")
+        r = self.router.router
+        hid = r[0].out_channels
+        hp = _ceil(hid, 4)
+        lh, rh, gh = self.local_head, self.region_head, self.global_head
+        pk = {
+            # router: first 1x1 reads the block input (compute dtype) and writes fp32; the rest stays fp32 (router.py:55-61)
+            "r0": _pack_conv(r[0], dtype, device, pad_cout_to=hp), "r1": _pack_norm(r[1], device), "r_hid": hid, "r_hp": hp,
+            "r3": _pack_conv(r[3], f32, device, pad_cout_to=4, pad_cin_to=hp),
+            "l_dw": _pack_dw(lh.qkv_dw, dtype, device), "l_qkv": _pack_conv(lh.qkv_pw, dtype, device),
+            "l_pe": _pack_dw(lh.pe, dtype, device), "l_proj": _pack_conv(lh.proj, dtype, device), "l_norm": _pack_norm(lh.norm, device),
+            "g_q": _pack_conv(rh.q_proj, dtype, device), "g_kv": _pack_conv(rh.kv_proj, dtype, device),
+            "g_proj": _pack_conv(rh.proj, dtype, device), "g_norm": _pack_norm(rh.norm, device),
+            "a_qkv": _pack_conv(gh.qkv, dtype, device), "a_proj": _pack_conv(gh.proj, dtype, device),
+            "a_norm": _pack_norm(gh.norm, device), "rf": gh._rf_matrix.detach().float().to(device).contiguous(),
+            "ls_attn": self.ls_attn.detach().float().reshape(-1).to(device).contiguous(),
+            "ls_ffn": self.ls_ffn.detach().float().reshape(-1).to(device).contiguous(),
+        }
+        if not self.shortcut:   # ls * f(x) without a residual: the factor folds into the last (activation-free) conv
+            pk["fusion_ls"] = _pack_bn_conv(self.fusion, dtype, device, self.ls_attn)
+            pk["ffn1_ls"] = _pack_bn_conv(self.ffn[1], dtype, device, self.ls_ffn)
+        return pk
+
+    def _route(self, x, pk):
+        B, H, W, _ = x.shape
+        h = ops.conv2d(x, *pk["r0"], 1, 1, False, out_dtype=torch.float32)                 # [B,H,W,hp] fp32, pad channels = 0
+        hn = torch.zeros((B, H, W, pk["r_hp"]), dtype=torch.float32, device=x.device)
+        hid = pk["r_hid"]
+        ops.group_norm(h[..., :hid], get_safe_groups(hid, 4), *pk["r1"], 1e-5, act="silu", out=hn[..., :hid])
+        logits = ops.conv2d(hn, *pk["r3"], 1, 1, False)                                      # [B,H,W,4] fp32 (3 logits + pad)
+        probs, _ = ops.token_softmax(logits, self.NUM_GROUPS, 1.0 / self.router.temperature)
+        return probs
+
+    def _head_tail(self, o, proj, norm):
+        p = ops.conv2d(o, *proj, 1, 1, False)
+        return ops.group_norm(p, get_safe_groups(self.dim, 8), *norm, 1e-5)
+
+    def _run(self, x, out=None):
+        B, H, W, C = x.shape
+        pk = self._packed(x.device)
+        lh, rh = self.local_head, self.region_head
+        nh, hd = lh.num_heads, lh.head_dim
+        inner, scale = nh * hd, hd ** -0.5
+        probs = self._route(x, pk)
+        self.last_route = {"weights": probs}
+        # local head (moa/heads.py:143-163): DW3x3 -> 1x1 qkv, v += DW7x7(v), 7x7-window attention
+        qkv = ops.conv2d(ops.dwconv2d(x, pk["l_dw"], None, 3, False), *pk["l_qkv"], 1, 1, False)
+        v = ops.dwconv2d(qkv[..., 2 * inner:], pk["l_pe"], None, 7, False, residual=qkv[..., 2 * inner:])
+        win = max(1, min(lh.window_size, H, W))
+        o = ops.window_attention(qkv[..., :inner], qkv[..., inner:2 * inner], v, nh, hd, scale, win)
+        local = self._head_tail(o, pk["l_proj"], pk["l_norm"])
+        # regional head (moa/heads.py:208-253): full-resolution queries, pooled keys / values
+        if min(H, W) <= 1:
+            pooled = x
+        else:
+            stride = rh.pool_stride
+            if rh.max_kv_tokens is not None:
+                while max(1, H // stride) * max(1, W // stride) > rh.max_kv_tokens:
+                    stride *= 2
+            pooled = ops.adaptive_avg_pool(x, max(1, H // stride), max(1, W // stride))
+        kv = ops.conv2d(pooled, *pk["g_kv"], 1, 1, False)
+        q = ops.conv2d(x, *pk["g_q"], 1, 1, False)
+        o = ops.attention(q, kv[..., :inner], kv[..., inner:], nh, hd, scale)
+        regional = self._head_tail(o, pk["g_proj"], pk["g_norm"])
+        # global head (moa/heads.py:354-380): exact <= 512 tokens, blended with / replaced by random-feature attention
+        qkv = ops.conv2d(x, *pk["a_qkv"], 1, 1, False)
+        q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
+        N = H * W
+        if N <= self.LINEAR_ATTN_THRESHOLD:
+            o = ops.attention(q, k, v, nh, hd, scale)
+            start = self.LINEAR_ATTN_THRESHOLD - self.LINEAR_ATTN_BLEND_WINDOW
+            if N > start:
+                o = ops.lerp(o, ops.linear_attention(q, k, v, pk["rf"], nh, hd), (N - start) / self.LINEAR_ATTN_BLEND_WINDOW)
+        else:
+            o = ops.linear_attention(q, k, v, pk["rf"], nh, hd)
+        glob = self._head_tail(o, pk["a_proj"], pk["a_norm"])
+        mixed = ops.weighted_sum(probs, [local, regional, glob])
+        if self.shortcut:   # x + ls_attn * fusion(mixed); then + ls_ffn * ffn(.) (moa/block.py:264-278)
+            x1 = ops.scale_residual(self.fusion._run(mixed), pk["ls_attn"], x)
+            f = self.ffn[1]._run(self.ffn[0]._run(x1))
+            return ops.scale_residual(f, pk["ls_ffn"], x1, out=out)
+        x1 = ops.conv2d(mixed, *pk["fusion_ls"], 1, 1, False)
+        return ops.conv2d(self.ffn[0]._run(x1), *pk["ffn1_ls"], 1, 1, False, out=out)
+
+
+class C2fMoA(YmkModule):
     """moa/wrappers.py:40-142."""
 
     def __init__(self, c1, c2, n=1, num_heads=6, mlp_ratio=2.0, temperature=1.0, shortcut=True, e=0.5, aux_loss_coeff=0.01,
@@ -282,6 +431,17 @@ class C2fMoA(_Boundary):
             MoABlock(self.c, num_heads=h, mlp_ratio=mlp_ratio, temperature=temperature, shortcut=shortcut,
                      aux_loss_coeff=aux_loss_coeff, block_index=i, local_window_size=local_window_size,
                      sequential_heads=sequential_heads, regional_max_kv_tokens=regional_max_kv_tokens) for i in range(n))
+
+    def _run(self, x, out=None):
+        """cv1 -> chunk(2) -> n MoABlocks chained on the last chunk -> cat -> cv2 (moa/wrappers.py:144-177); the
+        concatenation is one buffer, every producer writes its channel slice."""
+        B, H, W, _ = x.shape
+        c, n = self.c, len(self.m)
+        cat = ops.new_act(B, H, W, (2 + n) * c, x.dtype, x.device)
+        self.cv1._run(x, out=cat[..., : 2 * c])
+        for i, blk in enumerate(self.m):
+            blk._run(cat[..., (1 + i) * c:(2 + i) * c], out=cat[..., (2 + i) * c:(3 + i) * c])
+        return self.cv2._run(cat, out=out)
 
 
 # ----------------------------------------------------------------------------------------- MoT

@@ -401,3 +401,148 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
                                 _p(dets), _p(counts), _p(ws), nbytes, _stream()), "cw_refine")
     TIMER.end(e0, "nms", B * ch * A * 4 + B * max_det * 28, B * ch * A)
     return dets, counts, idx, status
+
+
+# ============================================================================= config-5 rows (MoA / MoT / gated MoE)
+# Entry points whose CONTRACT is fixed here — it is what nn/mixture.py is written against and what tests/emu_ops.py
+# restates for the CPU-side host tests — but whose HIP kernels are not in libymk yet (round-2 work).
+# Until then every one of them fails loudly: there is no CPU / PyTorch fallback.  Conventions as above: NHWC views
+# [B, H, W, C] with a pixel stride ld >= C, activations in the compute dtype, statistics / gates / router math fp32.
+class KernelNotBuilt(NotImplementedError):
+    pass
+
+
+def _not_built(name: str):
+    raise KernelNotBuilt(f"libymk has no kernel for `{name}` yet (config-5 row, next round); there is no CPU / PyTorch fallback")
+
+
+ACT_CODES = (False, True, "silu", "sigmoid", "gelu")   # conv / norm epilogues of the config-5 modules
+
+
+def conv2d_act(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None, out_dtype=None):
+    """ymk_conv2d with the extended epilogue set: act in ACT_CODES ("gelu" = exact erf GELU, nn.GELU default)."""
+    if act in (False, True, "silu"):
+        return conv2d(x, w_packed, bias, k, stride, bool(act), out=out, residual=residual, out_dtype=out_dtype)
+    if act not in ACT_CODES:
+        raise ValueError(f"unknown activation {act!r}")
+    _not_built(f"conv2d epilogue {act}")
+
+
+def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, out_dtype=None, affine_rows=None):
+    """GroupNorm over (H, W, C/groups) per image and group, biased variance, fp32 statistics (torch.nn.GroupNorm;
+    safe group counts nn/modules/utils.py:108-115).  weight/bias fp32 [C], or None (no affine), or [R][C] with
+    affine_rows int32 [B] choosing the row per image (FusedExpertGroup's per-expert affine, moe/gated.py:1058-1090).
+    act in (False, "silu").  x may be a channel slice (C channels of a wider buffer); any C >= 1."""
+    _not_built("group_norm")
+
+
+def layer_norm(x, weight, bias, eps: float, out=None):
+    """LayerNorm over the channel vector of every token (torch.nn.LayerNorm(C)), fp32 statistics."""
+    _not_built("layer_norm")
+
+
+def eltwise_mul(a, b, out=None):
+    """out = a * b, same shapes (GLU of the MoT local expert, mot/experts.py:160-166)."""
+    _not_built("eltwise_mul")
+
+
+def lerp(a, b, alpha: float, out=None):
+    """out = (1 - alpha) * a + alpha * b (exact / linear attention blend, moa/heads.py:366-374)."""
+    _not_built("lerp")
+
+
+def fma_gate(x, a, b, scale, out=None):
+    """out = x + scale * a * b with scale a host float; b is a map [B,H,W,C] or a per-image channel gate [B,1,1,C]
+    (detail gate x*(1+s*g), context mixer x+s*c*gate, refinement x+s*r*g: moe/gated.py:1171-1218, hooks.py:60-68)."""
+    _not_built("fma_gate")
+
+
+def channel_gate(x, gate, out=None):
+    """out = x * gate with gate fp32 [B,1,1,C] (squeeze-excite gate of the gated MoE, moe/gated.py:333-341)."""
+    _not_built("channel_gate")
+
+
+def weighted_sum(weights, parts, out=None):
+    """out = sum_e weights[..., e] * parts[e]; weights fp32 [B,H,W,>=E] per token or [B,1,1,>=E] per image
+    (MoA head mix moa/block.py:230-262, MoT expert blend mot/block.py:360-417, gated expert mix)."""
+    _not_built("weighted_sum")
+
+
+def mean_upsampled(parts, out=None):
+    """out = mean_i nearest_resize(parts[i] -> size of parts[0]) (F.interpolate mode="nearest": src = floor(dst * h / H));
+    PyramidContextMixer.forward moe/gated.py:1209-1216."""
+    _not_built("mean_upsampled")
+
+
+def adaptive_avg_pool(x, Ho: int, Wo: int, out=None, out_dtype=None):
+    """F.adaptive_avg_pool2d bins: rows [floor(i*H/Ho), ceil((i+1)*H/Ho))."""
+    _not_built("adaptive_avg_pool")
+
+
+def avg_pool(x, k: int, out=None, out_dtype=None):
+    """F.avg_pool2d(kernel_size=k, stride=k): floor(H/k) x floor(W/k) outputs, remainder rows/columns dropped."""
+    _not_built("avg_pool")
+
+
+def channel_stats(x, want_std: bool = False):
+    """Per image and channel mean (and biased std) over H*W in fp32: returns [B,1,1,C] (or [B,1,1,2C] = [mean | std],
+    DualStreamGateRouter's global stream moe/gated.py:133-139)."""
+    _not_built("channel_stats")
+
+
+def attention(q, k, v, heads: int, hd: int, scale: float, out=None):
+    """softmax(q k^T * scale) v per (image, head).  q [B,Hq,Wq,heads*hd], k/v [B,Hk,Wk,heads*hd] channel-slice views
+    (tokens row-major); any hd that is a multiple of 8.  MoA regional / global-exact heads (moa/heads.py:208-253,
+    354-365), MoT local expert (mot/experts.py:150-156)."""
+    _not_built("attention")
+
+
+def window_attention(q, k, v, heads: int, hd: int, scale: float, win: int, shift: int = 0, pad_q=None, pad_k=None,
+                     pad_v=None, out=None):
+    """Attention inside win x win windows of the map padded (bottom / right) to a multiple of win; out-of-image tokens
+    carry the fp32 vectors pad_q / pad_k / pad_v [heads*hd] (None = zeros) and take part as keys; with shift > 0 the
+    padded grid is rolled by -shift in both axes before the partition and rolled back after (no mask).
+    moa/heads.py:83-117, mot/experts.py:237-325."""
+    _not_built("window_attention")
+
+
+def linear_attention(q, k, v, rf, heads: int, hd: int, out=None):
+    """ReLU random-feature attention of _GlobalAttnHead._linear_attn (moa/heads.py:318-352), fp32 math:
+    phi(t) = min(relu(t rf^T / sqrt(nb)) + 1e-6, 1e4); out = clamp(phi(q) (phi(k)^T v), +-1e4) / max(phi(q) sum phi(k), 1e-6)."""
+    _not_built("linear_attention")
+
+
+def deform_attention(v, off_logits, aw_logits, heads: int, hd: int, n_points: int, align_corners: bool, out=None):
+    """_DeformableTransformerExpert._deform_attn (mot/experts.py:381-459): per token and head, locations =
+    clamp(ref + 0.25 * tanh(off_logits), -1, 1) around the token's own normalised position, weights = softmax over the
+    points of aw_logits, bilinear samples of v's head slice (zeros padding), weighted sum.  Coordinates fp32."""
+    _not_built("deform_attention")
+
+
+def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None):
+    """Per-token softmax over the first n channels of fp32 logits scaled by inv_temp; with 0 < top_k < n the top_k
+    largest are kept and renormalised (sum clamped at 1e-6), the rest set to 0 (mot/router.py:243-295, moa/router.py:50-62).
+    Returns (weights fp32 [B,H,W,n], active int32 [B,n] = 1 where any token of the image gives expert e a nonzero weight)."""
+    _not_built("token_softmax")
+
+
+def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_k: int, cplx_logit):
+    """Decision tail of the gated MoE (moe/gated.py:124-166, 455-492): logits = clamp(a*g + (1-a)*loc, +-30) with
+    a = sigmoid(alpha); probs = softmax(logits * inv_temp); top-k, weights / (sum + 1e-6); complexity = clamp(mean_b
+    sigmoid(cplx_logit[b]), 0.3, 1.5) (1.0 when non-finite) keeps round(c * top_k) in [1, top_k] ranked experts and
+    renormalises (clamp 1e-6).  Inputs fp32 [B,1,1,E] / [B,1,1,1]; returns (w fp32 [B,1,1,top_k], idx int32 [B,top_k], probs)."""
+    _not_built("gated_route_decide")
+
+
+def expert_conv(x, w_packed, k: int, idx, out=None):
+    """Per-image expert convolution: out[b*K + j] = conv_kxk(x[b], w_packed[idx[b, j]]) (no bias, no activation);
+    w_packed [E][Cout][Kpad] in the compute dtype, idx int32 [B][K].  The selected slices of FusedExpertGroup's grouped
+    3x3 (moe/gated.py:1058-1076; grouped weights expanded to dense rows at pack time) and the expert projections of
+    SharedInvertedExpertGroup (moe/experts.py:235-269)."""
+    _not_built("expert_conv")
+
+
+def channel_shuffle_cat(parts, groups: int, out=None):
+    """Channel concatenation followed by _channel_shuffle (moe/gated.py:1333-1338) in one pass:
+    out[..., j * groups + i] = cat(parts)[..., i * (C / groups) + j]."""
+    _not_built("channel_shuffle_cat")

@@ -185,5 +185,6 @@ def test_config5_boundary_modules_keep_the_reference_contract():
     assert kinds.count(VisualEnhancedAdaptiveGateMoE) == 3 and kinds.count(C2fMoT) == 3 and kinds.count(C2fMoA) == 1
     assert m.model[11].expert_backend == "shared_inverted" and m.model[5].expert_backend == "low_rank_fused"
     for mod in (m.model[5], m.model[14], m.model[17], MoABlock(48, 6).eval()):
-        with pytest.raises(NotImplementedError, match="not built yet"):
+        # no CPU path: modules whose host orchestration exists refuse the CPU tensor, the others say "not built yet"
+        with pytest.raises((NotImplementedError, RuntimeError), match="not built yet|MI355X"):
             mod(torch.zeros(1, mod.cv1.conv.in_channels if hasattr(mod, "cv1") else 48 if isinstance(mod, MoABlock) else 128, 8, 8))

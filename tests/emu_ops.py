@@ -291,7 +291,7 @@ def conv2d_act(x, w_packed, bias, k, stride, act, out=None, residual=None, out_d
     return _finish(y, False, residual, out, out_dtype or x.dtype)
 
 
-def group_norm(x, groups, weight, bias, eps, act=False, out=None, out_dtype=None, affine_rows=None):
+def group_norm(x, groups, weight, bias, eps, act=False, out=None, out_dtype=None, affine_rows=None, residual=None):
     _count("group_norm")
     B, H, W, C = x.shape
     assert C % groups == 0
@@ -304,7 +304,10 @@ def group_norm(x, groups, weight, bias, eps, act=False, out=None, out_dtype=None
             y = y * w.view(B, C, 1, 1) + b.view(B, C, 1, 1)
         else:
             y = y * weight.view(1, C, 1, 1) + bias.view(1, C, 1, 1)
-    return _put(_act(y, act).permute(0, 2, 3, 1), out, out_dtype or x.dtype)
+    y = _act(y, act).permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + residual.float()
+    return _put(y, out, out_dtype or x.dtype)
 
 
 def layer_norm(x, weight, bias, eps, out=None):
@@ -312,9 +315,9 @@ def layer_norm(x, weight, bias, eps, out=None):
     return _put(F.layer_norm(x.float(), (x.shape[-1],), weight, bias, eps), out, x.dtype)
 
 
-def eltwise_mul(a, b, out=None):
+def eltwise_mul(a, b, out=None, act_a=None):
     _count("eltwise_mul")
-    return _put(a.float() * b.float(), out, a.dtype)
+    return _put(_act(a.float(), act_a) * b.float(), out, a.dtype)
 
 
 def lerp(a, b, alpha, out=None):

@@ -96,8 +96,8 @@ def _pack_bn_conv(m: Conv, dtype, device, scale=None):
     return ops.pack_conv_weight(w, dtype), b.contiguous()
 
 
-def _vec(dtype) -> int:
-    return 8 if dtype == torch.bfloat16 else 4
+def _flat(p, device):
+    return p.detach().float().reshape(-1).to(device).contiguous()
 
 
 # ----------------------------------------------------------------------------------------- gated MoE
@@ -446,11 +446,11 @@ class C2fMoA(YmkModule):
 
 # ----------------------------------------------------------------------------------------- MoT
 class _LocalConvTransformerExpert(nn.Module):
-    """mot/experts.py:72-121."""
+    """mot/experts.py:72-171."""
 
     def __init__(self, dim, num_heads, mlp_ratio=2.0, dropout=0.0, local_window_size=0):
         super().__init__()
-        self.num_heads, self.local_window_size = num_heads, int(local_window_size)
+        self.dim, self.num_heads, self.local_window_size = dim, num_heads, int(local_window_size)
         self.ls1 = nn.Parameter(torch.ones(dim, 1, 1) * 0.1)
         self.ls2 = nn.Parameter(torch.ones(dim, 1, 1) * 0.1)
         self.dw_mix = nn.Conv2d(dim, dim, 3, padding=1, groups=dim, bias=False)
@@ -463,13 +463,43 @@ class _LocalConvTransformerExpert(nn.Module):
         self.ffn_val = Conv(dim, hid, 1)
         self.ffn_out = Conv(hid, dim, 1, act=False)
 
+    def pack(self, dtype, device):
+        return {"n1": _pack_norm(self.norm1, device), "n2": _pack_norm(self.norm2, device), "dw": _pack_dw(self.dw_mix, dtype, device),
+                "qkv": _pack_conv(self.qkv, dtype, device), "pe": _pack_dw(self.pe, dtype, device),
+                "proj": _pack_conv(self.proj, dtype, device), "ls1": _flat(self.ls1, device), "ls2": _flat(self.ls2, device)}
+
+    def run(self, x, pk):
+        """GN -> DW3x3 -> 1x1 qkv, v += DW7x7(v), attention (whole map, or local windows), proj, layer-scale residual;
+        GN -> sigmoid(Conv) * Conv -> Conv, layer-scale residual (mot/experts.py:123-171)."""
+        B, H, W, C = x.shape
+        nh, hd = self.num_heads, C // self.num_heads
+        g = get_safe_groups(C, 8)
+        xn = ops.group_norm(x, g, *pk["n1"], 1e-5)
+        qkv = ops.conv2d(ops.dwconv2d(xn, pk["dw"], None, 3, False), *pk["qkv"], 1, 1, False)
+        v = ops.dwconv2d(qkv[..., 2 * C:], pk["pe"], None, 7, False, residual=qkv[..., 2 * C:])
+        lws = self.local_window_size
+        if lws > 0 and H * W > lws * lws:
+            o = ops.window_attention(qkv[..., :C], qkv[..., C:2 * C], v, nh, hd, hd ** -0.5, lws)
+        else:
+            o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], v, nh, hd, hd ** -0.5)
+        x1 = ops.scale_residual(ops.conv2d(o, *pk["proj"], 1, 1, False), pk["ls1"], x)
+        xn = ops.group_norm(x1, g, *pk["n2"], 1e-5)
+        glu = ops.eltwise_mul(self.ffn_gate[0]._run(xn), self.ffn_val._run(xn), act_a="sigmoid")
+        return ops.scale_residual(self.ffn_out._run(glu), pk["ls2"], x1)
+
 
 def _mlp(dim, hid, dropout):
     return nn.Sequential(nn.Linear(dim, hid), nn.GELU(), nn.Dropout(dropout), nn.Linear(hid, dim))
 
 
+def _run_token_ffn(x1, ffn, norm2, ls2, pk):
+    """LayerNorm -> Linear -> GELU -> Linear with layer scale (mot/experts.py:318-325, 486-493)."""
+    h = ops.conv2d_act(ops.layer_norm(x1, *pk["n2"], 1e-5), *pk["f0"], 1, 1, "gelu")
+    return ops.scale_residual(ops.conv2d(h, *pk["f3"], 1, 1, False), pk["ls2"], x1)
+
+
 class _WindowTransformerExpert(nn.Module):
-    """mot/experts.py:174-235."""
+    """mot/experts.py:174-325."""
 
     def __init__(self, dim, num_heads, window_size=7, mlp_ratio=2.0, dropout=0.0, shift_size=0):
         super().__init__()
@@ -482,9 +512,29 @@ class _WindowTransformerExpert(nn.Module):
         self.norm1, self.norm2 = nn.LayerNorm(dim), nn.LayerNorm(dim)
         self.ffn = _mlp(dim, int(dim * mlp_ratio), dropout)
 
+    def pack(self, dtype, device):
+        # tokens added by the window padding are zeros BEFORE the LayerNorm (experts.py:275-285): after it they equal the
+        # LayerNorm bias, so their q / k / v are one constant vector each
+        pad = (self.qkv.weight.detach().float() @ self.norm1.bias.detach().float()).to(device)
+        C = self.norm1.bias.numel()
+        return {"n1": _pack_norm(self.norm1, device), "n2": _pack_norm(self.norm2, device),
+                "qkv": _pack_conv(self.qkv, dtype, device), "proj": _pack_conv(self.proj, dtype, device),
+                "pad": tuple(pad[i * C:(i + 1) * C].contiguous() for i in range(3)),
+                "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device),
+                "ls1": _flat(self.ls1, device), "ls2": _flat(self.ls2, device)}
+
+    def run(self, x, pk):
+        C = x.shape[-1]
+        nh, hd = self.num_heads, C // self.num_heads
+        qkv = ops.conv2d(ops.layer_norm(x, *pk["n1"], 1e-5), *pk["qkv"], 1, 1, False)
+        a = ops.window_attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], nh, hd, hd ** -0.5, self.win,
+                                 shift=self.shift_size, pad_q=pk["pad"][0], pad_k=pk["pad"][1], pad_v=pk["pad"][2])
+        x1 = ops.scale_residual(ops.conv2d(a, *pk["proj"], 1, 1, False), pk["ls1"], x)
+        return _run_token_ffn(x1, self.ffn, self.norm2, self.ls2, pk)
+
 
 class _DeformableTransformerExpert(nn.Module):
-    """mot/experts.py:328-379."""
+    """mot/experts.py:328-493."""
 
     def __init__(self, dim, num_heads, n_points=4, mlp_ratio=2.0, dropout=0.0, align_corners=True):
         super().__init__()
@@ -499,6 +549,26 @@ class _DeformableTransformerExpert(nn.Module):
         self.norm1, self.norm2 = nn.LayerNorm(dim), nn.LayerNorm(dim)
         self.ffn = _mlp(dim, int(dim * mlp_ratio), dropout)
 
+    def pack(self, dtype, device):
+        return {"n1": _pack_norm(self.norm1, device), "n2": _pack_norm(self.norm2, device),
+                "q": _pack_conv(self.q_proj, dtype, device), "v": _pack_conv(self.v_proj, dtype, device),
+                "off": _pack_conv(self.offset_proj, dtype, device, pad_cout_to=_ceil(self.offset_proj.out_features, 4)),
+                "aw": _pack_conv(self.attn_proj, dtype, device, pad_cout_to=_ceil(self.attn_proj.out_features, 4)),
+                "out": _pack_conv(self.out_proj, dtype, device),
+                "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device),
+                "ls1": _flat(self.ls1, device), "ls2": _flat(self.ls2, device)}
+
+    def run(self, x, pk):
+        C = x.shape[-1]
+        nh, hd, npnt = self.num_heads, C // self.num_heads, self.n_points
+        xn = ops.layer_norm(x, *pk["n1"], 1e-5)
+        q = ops.conv2d(xn, *pk["q"], 1, 1, False)
+        off = ops.conv2d(q, *pk["off"], 1, 1, False, out_dtype=torch.float32)[..., : nh * npnt * 2]   # sampling coordinates stay fp32
+        aw = ops.conv2d(q, *pk["aw"], 1, 1, False, out_dtype=torch.float32)[..., : nh * npnt]
+        o = ops.deform_attention(ops.conv2d(xn, *pk["v"], 1, 1, False), off, aw, nh, hd, npnt, self.align_corners)
+        x1 = ops.scale_residual(ops.conv2d(o, *pk["out"], 1, 1, False), pk["ls1"], x)
+        return _run_token_ffn(x1, self.ffn, self.norm2, self.ls2, pk)
+
 
 class _MoTRouter(nn.Module):
     """mot/router.py:57-150 (spatial router; no scene-aware branch — the master YAMLs do not enable it)."""
@@ -512,7 +582,7 @@ class _MoTRouter(nn.Module):
                                     nn.Conv2d(hidden, num_experts, 1, bias=True))
 
 
-class MoTBlock(_Boundary):
+class MoTBlock(YmkModule):
     """mot/block.py:20-170."""
 
     NUM_EXPERTS = 3
@@ -541,8 +611,36 @@ class MoTBlock(_Boundary):
         self.out_norm = _gn(dim)
         self.out_proj = nn.Conv2d(dim, dim, 1, bias=False)
 
+    def _pack(self, dtype, device):
+        r = self.router.router
+        hid = r[0].out_channels
+        hp = _ceil(hid, 4)
+        return {"r0": _pack_conv(r[0], dtype, device, pad_cout_to=hp), "r1": _pack_norm(r[1], device), "r_hid": hid, "r_hp": hp,
+                "r3": _pack_conv(r[3], torch.float32, device, pad_cout_to=4, pad_cin_to=hp),
+                "inv_temp": 1.0 / float(self.router.temperature),
+                "experts": [e.pack(dtype, device) for e in self.experts],
+                "out_proj": _pack_conv(self.out_proj, dtype, device), "out_norm": _pack_norm(self.out_norm, device)}
 
-class C2fMoT(_Boundary):
+    def _run(self, x, out=None):
+        """mot/block.py:298-417, eval.  The reference runs expert e only on the images where some token selected it;
+        every expert is image-local, so running all of them on the whole batch and weighting per token (weight 0 where
+        the expert was not selected) gives the same result without a device->host read of the routing decision."""
+        B, H, W, C = x.shape
+        pk = self._packed(x.device)
+        h = ops.conv2d(x, *pk["r0"], 1, 1, False, out_dtype=torch.float32)
+        hn = torch.zeros((B, H, W, pk["r_hp"]), dtype=torch.float32, device=x.device)
+        hid = pk["r_hid"]
+        ops.group_norm(h[..., :hid], get_safe_groups(hid, 4), *pk["r1"], 1e-5, act="silu", out=hn[..., :hid])
+        logits = ops.conv2d(hn, *pk["r3"], 1, 1, False)
+        weights, active = ops.token_softmax(logits, self.NUM_EXPERTS, pk["inv_temp"], top_k=self.top_k)
+        self.last_route = {"weights": weights, "active": active}
+        outs = [e.run(x, p) for e, p in zip(self.experts, pk["experts"])]
+        mixed = ops.weighted_sum(weights, outs)
+        p = ops.conv2d(mixed, *pk["out_proj"], 1, 1, False)
+        return ops.group_norm(p, get_safe_groups(C, 8), *pk["out_norm"], 1e-5, residual=x, out=out)
+
+
+class C2fMoT(YmkModule):
     """mot/wrappers.py:19-105."""
 
     def __init__(self, c1, c2, n=1, num_heads=6, top_k=2, window_size=7, n_points=4, mlp_ratio=2.0, temperature=1.0,
@@ -562,6 +660,16 @@ class C2fMoT(_Boundary):
                      sparse_train=sparse_train, scene_aware_router=scene_aware_router, scene_hidden_dim=scene_hidden_dim,
                      scene_consistency_coeff=scene_consistency_coeff, sparse_train_warmup_steps=sparse_train_warmup_steps,
                      scene_inference_mode=scene_inference_mode, local_attn_window=local_attn_window) for i in range(n))
+
+    def _run(self, x, out=None):
+        """cv1 -> chunk(2) -> n MoTBlocks chained on the last chunk (odd blocks shifted) -> cat -> cv2 (mot/wrappers.py:107-114)."""
+        B, H, W, _ = x.shape
+        c, n = self.c, len(self.m)
+        cat = ops.new_act(B, H, W, (2 + n) * c, x.dtype, x.device)
+        self.cv1._run(x, out=cat[..., : 2 * c])
+        for i, blk in enumerate(self.m):
+            blk._run(cat[..., (1 + i) * c:(2 + i) * c], out=cat[..., (2 + i) * c:(3 + i) * c])
+        return self.cv2._run(cat, out=out)
 
 
 MIXTURE_BOUNDARY_MODULES = {"VisualEnhancedAdaptiveGateMoE": VisualEnhancedAdaptiveGateMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}

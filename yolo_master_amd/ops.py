@@ -428,11 +428,12 @@ def conv2d_act(x, w_packed, bias, k: int, stride: int, act, out=None, residual=N
     _not_built(f"conv2d epilogue {act}")
 
 
-def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, out_dtype=None, affine_rows=None):
+def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, out_dtype=None, affine_rows=None, residual=None):
     """GroupNorm over (H, W, C/groups) per image and group, biased variance, fp32 statistics (torch.nn.GroupNorm;
     safe group counts nn/modules/utils.py:108-115).  weight/bias fp32 [C], or None (no affine), or [R][C] with
     affine_rows int32 [B] choosing the row per image (FusedExpertGroup's per-expert affine, moe/gated.py:1058-1090).
-    act in (False, "silu").  x may be a channel slice (C channels of a wider buffer); any C >= 1."""
+    act in (False, "silu"); residual (same shape) is added after the activation (MoTBlock's out_norm(.) + x,
+    mot/block.py:413-417).  x may be a channel slice (C channels of a wider buffer); any C >= 1."""
     _not_built("group_norm")
 
 
@@ -441,8 +442,9 @@ def layer_norm(x, weight, bias, eps: float, out=None):
     _not_built("layer_norm")
 
 
-def eltwise_mul(a, b, out=None):
-    """out = a * b, same shapes (GLU of the MoT local expert, mot/experts.py:160-166)."""
+def eltwise_mul(a, b, out=None, act_a=None):
+    """out = act_a(a) * b, same shapes; act_a in (None, "sigmoid") (GLU of the MoT local expert: sigmoid(gate) * value,
+    mot/experts.py:160-166)."""
     _not_built("eltwise_mul")
 
 

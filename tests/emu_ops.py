@@ -46,9 +46,35 @@ def _unpack_conv(w_packed, k, cin):
     return w_packed[:, : k * k * cin].float().reshape(cout, k, k, cin).permute(0, 3, 1, 2)
 
 
+def _ld(t):
+    """Pixel stride of an NHWC view, validated exactly like the product's wrappers do."""
+    from yolo_master_amd import ops
+
+    return ops._nhwc(t)[4]
+
+
+def _vec(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _rules(x, cout=None, out=None, residual=None):
+    """The argument rules libymk enforces (YMK_E_BADARG in csrc/*.hip): 16-byte channel vectors on the input side,
+    4-element granularity on the output side."""
+    v = _vec(x.dtype)
+    assert x.shape[-1] % v == 0 and _ld(x) % v == 0, f"input channels {x.shape[-1]} / stride {_ld(x)} not a multiple of {v}"
+    if cout is not None:
+        assert cout % 4 == 0, f"Cout {cout} not a multiple of 4"
+    if out is not None:
+        assert _ld(out) % 4 == 0
+    if residual is not None:
+        assert _ld(residual) % 4 == 0
+
+
 def conv2d(x, w_packed, bias, k, stride, act, out=None, residual=None, out_dtype=None):
     _count("conv2d")
     assert w_packed.dtype == x.dtype and bias.dtype == torch.float32
+    assert k in (1, 3) and stride in (1, 2)
+    _rules(x, w_packed.shape[0], out, residual)
     w = _unpack_conv(w_packed, k, x.shape[-1])
     y = F.conv2d(_nchw(x), w, bias, stride, k // 2)
     return _finish(y, act, residual, out, out_dtype or x.dtype)
@@ -79,6 +105,8 @@ def _dw(x_nchw, w_kkc, k):
 
 def dwconv2d(x, w_packed, bias, k, act, out=None, residual=None):
     _count("dwconv2d")
+    assert k % 2 == 1 and k <= 15 and w_packed.dtype == x.dtype
+    _rules(x, None, out, residual)
     y = _dw(_nchw(x), w_packed, k)
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
@@ -488,8 +516,8 @@ def expert_conv(x, w_packed, k, idx, out=None):
     K = idx.shape[1]
     assert idx.dtype == torch.int32 and w_packed.dtype == x.dtype
     ys = []
-    for b in range(B):
-        for j in range(K):
+    for j in range(K):            # slot-major: out[j*B + b]
+        for b in range(B):
             w = _unpack_conv(w_packed[int(idx[b, j])], k, Cin)
             ys.append(F.conv2d(_nchw(x[b:b + 1]), w, None, 1, k // 2))
     return _put(torch.cat(ys).permute(0, 2, 3, 1), out, x.dtype)

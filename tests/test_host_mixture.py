@@ -116,3 +116,120 @@ def test_c2f_mot_host_vs_reference(golden_dir, emu):
         got = m(torch.from_numpy(z["x"]))
     _close(got, torch.from_numpy(z["y"]), "mot_c2f")
     assert emu.CALLS["deform_attention"] == 2 and emu.CALLS["layer_norm"] == 8
+
+
+GATED_CASES = {"base": (64, {}), "small": (64, {}), "keep1": (64, {}), "e6k3": (96, dict(num_experts=6, top_k=3)),
+               "e16": (64, dict(num_experts=16, top_k=2)), "mid": (64, {})}
+
+
+@pytest.mark.parametrize("name", list(GATED_CASES))
+def test_gated_moe_host_vs_reference(name, golden_dir, emu):
+    from yolo_master_amd.nn.mixture import VisualEnhancedAdaptiveGateMoE
+
+    C, kw = GATED_CASES[name]
+    z, sd = _load(golden_dir, "gated", name)
+    m = _prep(VisualEnhancedAdaptiveGateMoE(C, C, **kw), sd)
+    assert m.expert_backend == ("shared_inverted" if name == "e16" else "low_rank_fused")
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    with torch.inference_mode():
+        got = m(x)
+    B = x.shape[0]
+    r = m.last_route
+    assert np.array_equal(r["indices"].numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
+    assert float(np.abs(r["weights"].reshape(B, -1).numpy() - z["weights"].reshape(B, -1)).max()) <= 1e-5
+    _close(got, y, f"gated_{name}", rtol=5e-5)
+    assert emu.CALLS["expert_conv"] == 1 and emu.CALLS["gated_route_decide"] == 1 and emu.CALLS["channel_shuffle_cat"] == 1
+
+
+def test_config5_model_host_vs_reference(golden_dir, emu):
+    """The whole config-5 detector (v0_10 moa-mot YAML: gated-MoE backbone, C2fMoT / C2fMoA neck, Detect) through the
+    product's graph walk, against the real reference model's per-layer samples and routing decisions."""
+    import json
+
+    from tests.helpers import fill_by_name
+    from yolo_master_amd import ops
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    z = np.load(golden_dir / "fwd_cfg5.npz")
+    cfg = json.loads(str(z["cfg"]))
+    sd = fill_by_name(json.loads(str(z["spec"])), seed=5, gain=1.0)
+    sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
+    m = DetectionModel("yolo-master-moa-mot-n.yaml")
+    m.load_state_dict(sd)
+    m.eval()
+    taps = {}
+    with torch.inference_mode():
+        y, preds = m._predict_once(torch.from_numpy(z["x"]), taps=taps)
+    # discrete decisions: routed experts of the three gated blocks, selected experts per token of every MoT block
+    for key in [f for f in z.files if f.startswith("route::")]:
+        name = key[len("route::"):]                       # e.g. model.5 / model.14.m.0
+        mod = m
+        for part in name.split("."):
+            mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+        ref = z[key]
+        r = mod.last_route
+        if "indices" in r:                                # gated block: [B, k]
+            assert np.array_equal(r["indices"].numpy().reshape(ref.shape).astype(np.int16), ref), key
+        else:                                             # MoT block: top-k expert ids per token [B, k, H, W]
+            w = r["weights"].permute(0, 3, 1, 2)
+            sel = torch.zeros_like(w, dtype=torch.bool).scatter_(1, torch.from_numpy(ref.astype(np.int64)), True)
+            assert torch.equal(w > 0, sel), key
+    n = len(cfg["backbone"]) + len(cfg["head"])
+    worst = 0.0
+    for i in range(n - 1):
+        t = taps[i]
+        if not torch.is_tensor(t):
+            t = t.materialise()
+        got = ops.nhwc_to_nchw_f32(t).reshape(-1)[torch.from_numpy(z[f"layer{i}_idx"].astype(np.int64))].numpy()
+        ref = z[f"layer{i}_val"]
+        err = float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max())))
+        worst = max(worst, err)
+        assert err <= 1e-3, f"layer {i} ({(cfg['backbone'] + cfg['head'])[i][2]}): scaled max error {err:.3e}"
+    # Detect output.  The fixture's name-seeded weights also randomise `dfl.conv.weight` (a frozen arange in every real
+    # checkpoint, which is what the decode kernel evaluates in closed form), so the reference's boxes are re-derived
+    # here from the product's raw box logits with the fixture's DFL weights; class scores are compared directly.
+    import torch.nn.functional as F
+
+    det = m.model[-1]
+    B, A = y.shape[0], y.shape[2]
+    raw = preds["raw"]
+    boxes = torch.cat([b.reshape(B, -1, 4 * det.reg_max).transpose(1, 2) for b, _ in raw], -1)
+    dist = F.conv2d(boxes.view(B, 4, det.reg_max, A).transpose(2, 1).softmax(1), sd[f"model.{n - 1}.dfl.conv.weight"]).view(B, 4, A)
+    anc, strd = [], []
+    for (b, _), st in zip(raw, det.stride.tolist()):
+        hh, ww = b.shape[1:3]
+        sy, sx = torch.meshgrid(torch.arange(hh, dtype=torch.float32) + 0.5, torch.arange(ww, dtype=torch.float32) + 0.5, indexing="ij")
+        anc.append(torch.stack((sx, sy), -1).view(-1, 2))
+        strd.append(torch.full((hh * ww, 1), float(st)))
+    anc, strd = torch.cat(anc).t(), torch.cat(strd).t()
+    x1y1, x2y2 = anc - dist[:, :2], anc + dist[:, 2:]
+    yref = torch.cat([torch.cat([(x1y1 + x2y2) / 2, x2y2 - x1y1], 1) * strd, y[:, 4:]], 1)
+    got = yref.reshape(-1)[torch.from_numpy(z["y_idx"].astype(np.int64))].numpy()
+    np.testing.assert_allclose(got, z["y_val"], rtol=1e-3, atol=2e-2)
+    print(f"config-5 host walk: worst scaled layer error {worst:.3e}")
+
+
+def test_config5_model_bf16_operand_rules(golden_dir, emu):
+    """bf16 compute dtype: every operand the host hands to a kernel satisfies the 16-byte channel-vector rules (asserted
+    inside the emulation), routers / statistics / sampling coordinates stay fp32, and the result tracks fp32."""
+    import json
+
+    from tests.helpers import fill_by_name
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    z = np.load(golden_dir / "fwd_cfg5.npz")
+    sd = fill_by_name(json.loads(str(z["spec"])), seed=5, gain=1.0)
+    sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
+    x = torch.from_numpy(z["x"])
+    ys = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = DetectionModel("yolo-master-moa-mot-n.yaml")
+        m.load_state_dict(sd)
+        m.eval().set_compute_dtype(dt)
+        with torch.inference_mode():
+            ys[dt], _ = m._predict_once(x)
+    assert bool(torch.isfinite(ys[torch.bfloat16]).all())
+    d = (ys[torch.bfloat16][:, 4:] - ys[torch.float32][:, 4:]).abs()
+    # name-seeded weights: uncalibrated scores around 0.5 and per-token top-k routing that flips under bf16 rounding, so
+    # only a loose bound is meaningful here (the calibrated drift test of the detector lives in test_gpu_model.py)
+    assert float(d.median()) < 5e-2, f"median class-score drift {float(d.median()):.3e}"

@@ -182,7 +182,7 @@ class PyramidContextMixer(nn.Module):
         self.context_scale = nn.Parameter(torch.tensor(0.1))
 
 
-class VisualEnhancedAdaptiveGateMoE(_Boundary):
+class VisualEnhancedAdaptiveGateMoE(YmkModule):
     """moe/gated.py:1703-1764 (end of the AdaptiveGateMoE chain :268-1701)."""
 
     def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8,
@@ -226,6 +226,130 @@ class VisualEnhancedAdaptiveGateMoE(_Boundary):
         self.context_mixer = PyramidContextMixer(out_channels, num_groups)
         self.detail_gate = VisualDetailGate(self.dynamic_channels, num_groups, detail_reduction)
         self.router_hook_names = ("detail", "context", "refine")
+
+    # -- packing ---------------------------------------------------------------------------------------------------
+    def _pack(self, dtype, device):
+        import math
+
+        f32 = torch.float32
+        dyn, ng = self.dynamic_channels, self.num_groups
+        se, rt, dg, cm = self.se_gate, self.routing, self.detail_gate, self.context_mixer
+        if dyn % 8 or self.static_channels % 8:
+            raise NotImplementedError(f"ymk VisualEnhancedAdaptiveGateMoE: split {self.static_channels}+{dyn} breaks the 16-byte channel-vector rule")
+        E4, red = _ceil(self.num_experts, 4), rt.local_conv[3].out_channels
+        rp = _ceil(red, 4)
+        sn = self.static_net
+        dw_w, dw_b = ops.fold_bn(sn[0].weight.detach().float().to(device), sn[1].weight.float().to(device), sn[1].bias.float().to(device),
+                                 sn[1].running_mean.float().to(device), sn[1].running_var.float().to(device), sn[1].eps)
+        pw_w, pw_b = ops.fold_bn(sn[3].weight.detach().float().to(device), sn[4].weight.float().to(device), sn[4].bias.float().to(device),
+                                 sn[4].running_mean.float().to(device), sn[4].running_var.float().to(device), sn[4].eps)
+        hp = torch.full((9, dyn), -1.0 / 9.0, device=device)      # x - avg_pool3x3(x) (zero padded, count_include_pad) as one stencil
+        hp[4] += 1.0
+        pk = {
+            "se0": _pack_conv(se[2], f32, device), "se1": _pack_conv(se[4], f32, device),
+            "hp": hp.to(dtype).contiguous(),
+            "dg0": _pack_dw(dg.detail_filter[0], dtype, device), "dg1": _pack_norm(dg.detail_filter[1], device),
+            "dg3": _pack_conv(dg.detail_filter[3], dtype, device), "dg5": _pack_conv(dg.detail_filter[5], dtype, device),
+            "dg_s": math.tanh(float(dg.detail_scale)),
+            "st_dw": (ops.pack_dw_weight(dw_w, dtype), dw_b.contiguous()), "st_pw": (ops.pack_conv_weight(pw_w, dtype), pw_b.contiguous()),
+            "cplx": _pack_conv(self.complexity_estimator[1], f32, device, pad_cout_to=4),
+            "gfc": _pack_conv(rt.global_fc, f32, device, pad_cout_to=E4),
+            "lc0": _pack_dw(rt.local_conv[0], f32, device), "lc1": _pack_norm(rt.local_conv[1], device),
+            "lc3": _pack_conv(rt.local_conv[3], f32, device, pad_cout_to=rp), "lc4": _pack_norm(rt.local_conv[4], device),
+            "lc_red": red, "lc_rp": rp,
+            "lc6": _pack_conv(rt.local_conv[6], f32, device, pad_cout_to=E4, pad_cin_to=rp), "alpha": float(rt.alpha), "inv_temp": 1.0 / rt.temperature,
+            "cm0": _pack_dw(cm.local_context[0], dtype, device), "cm1": _pack_norm(cm.local_context[1], device),
+            "cmp": [(_pack_conv(p[0], dtype, device), _pack_norm(p[1], device)) for p in cm.pool_projections],
+            "cmg": _pack_conv(cm.context_gate[0], dtype, device), "cm_s": math.tanh(float(cm.context_scale)),
+            "fr0": _pack_dw(self.feature_refiner[0], dtype, device), "fr1": _pack_norm(self.feature_refiner[1], device),
+            "fg1": _pack_conv(self.feature_gate[1], f32, device), "fg3": _pack_conv(self.feature_gate[3], f32, device),
+            "rf_s": math.tanh(float(self.refine_scale)),
+            "proj": _pack_conv(self.proj, dtype, device), "bn": _pack_norm(self.bn, device),
+        }
+        fe = self.fused_experts
+        E, OC = self.num_experts, self.out_dynamic
+        if self.expert_backend == "low_rank_fused":
+            pk["bt0"] = _pack_conv(fe.bottleneck[0], dtype, device)
+            pk["bt1"] = _pack_norm(fe.bottleneck[1], device)
+            fc = fe.fused.fused_conv
+            w = fc.weight.detach().float().to(device)                       # [E*OC, bc/g, 3, 3], grouped
+            bc, g = fc.in_channels, fc.groups
+            cg, og = bc // g, (E * OC) // g
+            dense = w.new_zeros((E * OC, bc, 3, 3))
+            for grp in range(g):                                             # expand the grouped filter bank to dense rows:
+                dense[grp * og:(grp + 1) * og, grp * cg:(grp + 1) * cg] = w[grp * og:(grp + 1) * og]   # only the routed experts' rows run
+            pk["ew"] = ops.pack_conv_weight(dense, dtype).reshape(E, OC, -1).contiguous()
+            pk["en"] = (fe.fused.expert_norm_weight.detach().float().to(device).contiguous(),
+                        fe.fused.expert_norm_bias.detach().float().to(device).contiguous())
+        else:
+            sf = fe.shared_feature
+            pk["sf0"], pk["sf1"] = _pack_conv(sf[0], dtype, device), _pack_norm(sf[1], device)
+            pk["sf3"], pk["sf4"], pk["sf_k"] = _pack_dw(sf[3], dtype, device), _pack_norm(sf[4], device), sf[3].kernel_size[0]
+            pk["ew"] = torch.stack([_pack_conv(p[0], dtype, device)[0] for p in fe.expert_projections]).contiguous()
+            pk["en"] = (torch.stack([p[1].weight.detach().float() for p in fe.expert_projections]).to(device).contiguous(),
+                        torch.stack([p[1].bias.detach().float() for p in fe.expert_projections]).to(device).contiguous())
+        return pk
+
+    # -- execution -------------------------------------------------------------------------------------------------
+    def _run(self, x, out=None):
+        """run_visual_hybrid_moe_forward, eval (moe/_gated_visual.py:32-75; pieces: moe/gated.py:124-166 router, :333-353
+        SE gate + static path, :455-492 complexity gate, :1058-1146 fused experts, :1171-1218 detail gate / context mixer,
+        hooks.py:60-68 refinement; moe/experts.py:235-269 shared-inverted experts)."""
+        B, H, W, C = x.shape
+        pk = self._packed(x.device)
+        st, dyn, ng, k = self.static_channels, self.dynamic_channels, self.num_groups, self.top_k
+        gs = get_safe_groups
+        # squeeze-excite gate over all channels, then the static / dynamic split
+        gate = ops.conv2d_act(ops.conv2d(ops.channel_stats(x), *pk["se0"], 1, 1, True), *pk["se1"], 1, 1, "sigmoid")
+        xg = ops.channel_gate(x, gate)
+        xs, xd = xg[..., :st], xg[..., st:]
+        # detail gate on the dynamic half (pre-route hook)
+        h = ops.dwconv2d(ops.dwconv2d(xd, pk["hp"], None, 3, False), pk["dg0"], None, 3, False)
+        h = ops.conv2d(ops.group_norm(h, gs(dyn, ng), *pk["dg1"], 1e-5, act="silu"), *pk["dg3"], 1, 1, True)
+        xd = ops.fma_gate(xd, xd, ops.conv2d_act(h, *pk["dg5"], 1, 1, "sigmoid"), pk["dg_s"])
+        # static path: DW3x3+BN+SiLU -> 1x1+BN+SiLU (BN folded)
+        s = ops.conv2d(ops.dwconv2d(xs, *pk["st_dw"], 3, True), *pk["st_pw"], 1, 1, True)
+        # routing: global statistics stream + pooled local stream, decision tail with the batch-level complexity gate
+        cplx = ops.conv2d(ops.channel_stats(xd), *pk["cplx"], 1, 1, False)[..., :1]
+        E = self.num_experts
+        g_logits = ops.conv2d(ops.channel_stats(xd, want_std=True), *pk["gfc"], 1, 1, False)[..., :E]
+        ps = self.routing.pool_scale
+        xl = ops.avg_pool(xd, ps if (H > ps and W > ps) else 1, out_dtype=torch.float32)
+        h = ops.group_norm(ops.dwconv2d(xl, pk["lc0"], None, 3, False), gs(dyn, 8), *pk["lc1"], 1e-5, act="silu")
+        h = ops.conv2d(h, *pk["lc3"], 1, 1, False)
+        red, rp = pk["lc_red"], pk["lc_rp"]
+        hn = h if red == rp else torch.zeros(h.shape, dtype=h.dtype, device=h.device)   # pad channels must stay zero
+        ops.group_norm(h[..., :red], gs(red, 4), *pk["lc4"], 1e-5, act="silu", out=hn[..., :red])
+        loc = ops.channel_stats(ops.conv2d(hn, *pk["lc6"], 1, 1, False))[..., :E]
+        w, idx, probs = ops.gated_route_decide(g_logits, loc, pk["alpha"], pk["inv_temp"], k, cplx)
+        self.last_route = {"weights": w, "indices": idx, "probs": probs}
+        rows = idx.t().contiguous().reshape(-1)                     # expert of image j*B + b in the slot-major expert batch
+        # routed experts: only the selected experts' filter rows run
+        OC = self.out_dynamic
+        if self.expert_backend == "low_rank_fused":
+            hb = ops.group_norm(ops.conv2d(xd, *pk["bt0"], 1, 1, False), gs(pk["bt0"][0].shape[0], ng), *pk["bt1"], 1e-5, act="silu")
+            f = ops.expert_conv(hb, pk["ew"], 3, idx)
+            f = ops.group_norm(f, gs(OC, ng), *pk["en"], 1e-5, act="silu", affine_rows=rows)
+        else:
+            hs = ops.group_norm(ops.conv2d(xd, *pk["sf0"], 1, 1, False), gs(pk["sf0"][0].shape[0], 8), *pk["sf1"], 1e-5, act="silu")
+            hs = ops.group_norm(ops.dwconv2d(hs, pk["sf3"], None, pk["sf_k"], False), gs(hs.shape[-1], 8), *pk["sf4"], 1e-5, act="silu")
+            f = ops.group_norm(ops.expert_conv(hs, pk["ew"], 1, idx), gs(OC, 8), *pk["en"], 1e-5, affine_rows=rows)
+        d = ops.weighted_sum(w, [f[j * B:(j + 1) * B] for j in range(k)])
+        cat = ops.channel_shuffle_cat([s, d], self.shuffle_groups)
+        oc = cat.shape[-1]
+        # pyramid context mixer (post-fusion hook 1)
+        ctx = [ops.group_norm(ops.dwconv2d(cat, pk["cm0"], None, 3, False), gs(oc, ng), *pk["cm1"], 1e-5, act="silu")]
+        for (pw, pn), sc in zip(pk["cmp"], self.context_mixer.pool_scales):
+            hh, ww = max(1, H // sc), max(1, W // sc)
+            pooled = cat if (hh, ww) == (H, W) else ops.adaptive_avg_pool(cat, hh, ww)
+            ctx.append(ops.group_norm(ops.conv2d(pooled, *pw, 1, 1, False), gs(oc, ng), *pn, 1e-5, act="silu"))
+        c = ops.mean_upsampled(ctx)
+        cat = ops.fma_gate(cat, c, ops.conv2d_act(c, *pk["cmg"], 1, 1, "sigmoid"), pk["cm_s"])
+        # feature refinement (post-fusion hook 2)
+        r = ops.group_norm(ops.dwconv2d(cat, pk["fr0"], None, 3, False), gs(oc, ng), *pk["fr1"], 1e-5, act="silu")
+        g = ops.conv2d_act(ops.conv2d(ops.channel_stats(cat), *pk["fg1"], 1, 1, True), *pk["fg3"], 1, 1, "sigmoid")
+        cat = ops.fma_gate(cat, r, g, pk["rf_s"])
+        return ops.group_norm(ops.conv2d(cat, *pk["proj"], 1, 1, False), gs(oc, ng), *pk["bn"], 1e-5, residual=x, out=out)
 
 
 # ----------------------------------------------------------------------------------------- MoA

@@ -433,7 +433,7 @@ def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, ou
     safe group counts nn/modules/utils.py:108-115).  weight/bias fp32 [C], or None (no affine), or [R][C] with
     affine_rows int32 [B] choosing the row per image (FusedExpertGroup's per-expert affine, moe/gated.py:1058-1090).
     act in (False, "silu"); residual (same shape) is added after the activation (MoTBlock's out_norm(.) + x,
-    mot/block.py:413-417).  x may be a channel slice (C channels of a wider buffer); any C >= 1."""
+    mot/block.py:413-417).  x may be a channel slice (C channels of a wider buffer); any C >= 1; out may alias x."""
     _not_built("group_norm")
 
 
@@ -537,7 +537,8 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
 
 
 def expert_conv(x, w_packed, k: int, idx, out=None):
-    """Per-image expert convolution: out[b*K + j] = conv_kxk(x[b], w_packed[idx[b, j]]) (no bias, no activation);
+    """Per-image expert convolution, slot-major: out[j*B + b] = conv_kxk(x[b], w_packed[idx[b, j]]) (no bias, no activation;
+    out[j*B:(j+1)*B] is the batch of slot j, a contiguous NHWC tensor);
     w_packed [E][Cout][Kpad] in the compute dtype, idx int32 [B][K].  The selected slices of FusedExpertGroup's grouped
     3x3 (moe/gated.py:1058-1076; grouped weights expanded to dense rows at pack time) and the expert projections of
     SharedInvertedExpertGroup (moe/experts.py:235-269)."""

@@ -1,15 +1,21 @@
-"""Drop-in boundary of the config-5 mixture modules:
-`VisualEnhancedAdaptiveGateMoE`, `C2fMoA` / `MoABlock`, `C2fMoT` / `MoTBlock`.
+"""Config-5 mixture modules: `VisualEnhancedAdaptiveGateMoE`,
+`C2fMoA` / `MoABlock`, `C2fMoT` / `MoTBlock`.
 
-Round-1 status: the BOUNDARY only.  The classes keep the reference's constructor signatures, parameter / buffer names,
-shapes and registration order, so reference checkpoints of the v0_10 moa / mot YAMLs load unchanged and
+Drop-in boundary: the classes keep the reference's constructor signatures, parameter / buffer names, shapes and
+registration order, so reference checkpoints of the v0_10 moa / mot YAMLs load unchanged and
 `DetectionModel("yolo-master-moa-mot-n.yaml")` builds (tests/test_host_logic.py checks the key contract against keys
-dumped from the real reference).  Their HIP kernels are not written yet: `forward` raises `NotImplementedError` —
-there is no CPU or PyTorch fallback.  The checker for those kernels already exists: `oracle/gated_ref.py`,
-`oracle/moa_ref.py`, `oracle/mot_ref.py` reproduce the real reference bit for bit, up to the whole config-5 model.
+dumped from the real reference).
 
-Reference: ultralytics/nn/modules/moe/gated.py:82-1764, moe/experts.py:183-269, moa/{block,heads,router,wrappers}.py,
-mot/{block,experts,router,wrappers}.py.  Parameter containers are plain torch.nn layers (memory only; never called).
+Host path: every module has its `_pack` (BN folds, grouped filters expanded to dense rows, channel padding to the
+kernels' vector width, constant vectors for window-padding tokens, host scalars) and `_run` (NHWC dataflow over libymk
+entry points).  It is written against the entry-point contracts in `ops.py`; the config-5 half of those contracts has no
+HIP kernel yet, so on a GPU box the first such call raises `ops.KernelNotBuilt` — there is no CPU or PyTorch fallback.
+The dataflow itself is verified on the CPU: with the entry points emulated (tests/emu_ops.py, test infrastructure) the
+modules and the whole config-5 detector reproduce the REAL reference's golden vectors (tests/test_host_mixture.py).
+
+Reference: ultralytics/nn/modules/moe/gated.py:82-1764, moe/experts.py:183-269, moe/_gated_visual.py:32-75,
+moa/{block,heads,router,wrappers}.py, mot/{block,experts,router,wrappers}.py.  Parameter containers are plain torch.nn
+layers (memory only; never called).
 """
 from __future__ import annotations
 
@@ -21,10 +27,6 @@ import torch.nn as nn
 from .. import ops
 from .modules import Conv, YmkModule, to_nhwc
 
-_NOT_BUILT = ("{}: the HIP kernels of this module are not built yet (drop-in boundary only in round 1); "
-              "there is no CPU / PyTorch fallback")
-
-
 def get_safe_groups(channels: int, desired_groups: int = 8) -> int:
     """Largest group count <= desired dividing channels (ultralytics/nn/modules/utils.py:108-115)."""
     if channels <= 0:
@@ -33,16 +35,6 @@ def get_safe_groups(channels: int, desired_groups: int = 8) -> int:
     while channels % g != 0:
         g -= 1
     return max(1, g)
-
-
-class _Boundary(YmkModule):
-    def _run(self, x, out=None):
-        raise NotImplementedError(_NOT_BUILT.format(type(self).__name__))
-
-    def forward(self, x):
-        if self.training:
-            raise RuntimeError(f"{type(self).__name__}: the ymk path implements eval-mode inference only")
-        raise NotImplementedError(_NOT_BUILT.format(type(self).__name__))
 
 
 def _gn(c, desired=8):

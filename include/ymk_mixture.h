@@ -1,0 +1,137 @@
+/* libymk — C-ABI of the config-5 rows (MoA / MoT / gated MoE), SURVEY.md §8 rows a11 / a12 and §8(f) rank 1.
+ *
+ * STATUS: first implementation, correctness-first (VALU kernels, one element / token / query per thread, no MFMA,
+ * no fusion).  Written after the round-1 GPU budget was spent: the kernels COMPILE for gfx950 but have NOT RUN on
+ * hardware yet.  The Python wrappers therefore keep them switched off unless YMK_EXPERIMENTAL=1 is set
+ * (yolo_master_amd/ops.py), and their parity tests (tests/test_gpu_mixture.py, against tests/emu_ops.py and the
+ * oracles) are the first GPU job of the next round.  Nothing of the validated v0 path calls into this file.
+ *
+ * Conventions as in ymk.h: NHWC views with pixel strides (elements), activations YMK_F32 / YMK_BF16, statistics /
+ * gates / router tensors fp32, `stream` a hipStream_t, return 0 or a negative YMK_E_* code, no allocation, no sync.
+ * Each function cites the reference lines it replaces.
+ */
+#ifndef YMK_MIXTURE_H_
+#define YMK_MIXTURE_H_
+#include "ymk.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YMK_ACT_SIGMOID 2
+#define YMK_ACT_GELU 3 /* exact erf form (torch.nn.GELU default) */
+
+/* In-place activation on a channel-dense view (used after ymk_conv2d for the sigmoid / GELU epilogues of the gates and
+ * the token FFNs: moe/gated.py:1171-1218, mot/experts.py:318-325). */
+int ymk_activation(int32_t dtype, void* x, int32_t ldx, int64_t npix, int32_t C, int32_t act, void* stream);
+
+/* torch.nn.GroupNorm over (HW, C/groups) per image and group, biased variance, fp32 statistics.
+ * weight/bias: fp32 [C], or NULL (no affine), or [R][C] with affine_rows int32 [B] (row per image; FusedExpertGroup,
+ * moe/gated.py:1058-1090).  act: YMK_ACT_NONE | YMK_ACT_SILU.  residual (dtype = out_dtype of y, may be NULL) is added
+ * after the activation (MoTBlock out_norm(.) + x, mot/block.py:413-417).  y may alias x.
+ * stats_ws: fp32 [B*groups*2] scratch (mean, rstd). */
+int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
+                   const void* residual, int32_t ldr, int32_t B, int32_t HW, int32_t C, int32_t groups,
+                   const float* weight, const float* bias, const int32_t* affine_rows, float eps, int32_t act,
+                   float* stats_ws, void* stream);
+
+/* torch.nn.LayerNorm(C) per token (mot/experts.py:285, 318, 470, 486). */
+int ymk_layer_norm(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t npix, int32_t C,
+                   const float* weight, const float* bias, float eps, void* stream);
+
+/* y = a * b (op 0), sigmoid(a) * b (op 1: GLU of the MoT local expert, mot/experts.py:160-166),
+ * (1 - alpha) * a + alpha * b (op 2: exact / linear attention blend, moa/heads.py:366-374). */
+#define YMK_ELT_MUL 0
+#define YMK_ELT_SIGMOID_MUL 1
+#define YMK_ELT_LERP 2
+int ymk_eltwise(int32_t op, int32_t dtype, const void* a, int32_t lda, const void* b, int32_t ldb, void* y, int32_t ldy,
+                int64_t npix, int32_t C, float alpha, void* stream);
+
+/* y = x + scale * a * b; b is a map (b_per_image = 0, dtype b_dtype, stride ldb) or an fp32 per-image channel gate
+ * [B][C] (b_per_image = 1).  Detail gate, context mixer, refinement: moe/gated.py:1171-1218, hooks.py:60-68. */
+int ymk_fma_gate(int32_t dtype, const void* x, int32_t ldx, const void* a, int32_t lda, const void* b, int32_t b_dtype,
+                 int32_t ldb, int32_t b_per_image, float scale, void* y, int32_t ldy, int32_t B, int32_t HW, int32_t C,
+                 void* stream);
+
+/* y = x * gate[b][c], gate fp32 [B][C] (squeeze-excite gate, moe/gated.py:333-341). */
+int ymk_channel_gate(int32_t dtype, const void* x, int32_t ldx, const float* gate, void* y, int32_t ldy, int32_t B,
+                     int32_t HW, int32_t C, void* stream);
+
+/* y = sum_e w[..][e] * part_e, E <= 4; w fp32 per token (stride ldw) or per image (w_per_image = 1, [B][ldw]).
+ * MoA head mix (moa/block.py:230-262), MoT expert blend (mot/block.py:360-417), gated expert mix. */
+int ymk_weighted_sum(int32_t dtype, const float* w, int32_t ldw, int32_t w_per_image, int32_t E, const void* p0,
+                     const void* p1, const void* p2, const void* p3, int32_t ldp, void* y, int32_t ldy, int32_t B,
+                     int32_t HW, int32_t C, void* stream);
+
+/* y = mean_i nearest_resize(part_i -> H x W), n <= 4 parts of sizes (h_i, w_i), F.interpolate(mode="nearest") index
+ * rule src = floor(dst * h / H).  PyramidContextMixer.forward, moe/gated.py:1209-1216. */
+int ymk_mean_upsampled(int32_t dtype, int32_t n, const void* p0, const void* p1, const void* p2, const void* p3,
+                       const int32_t* hs, const int32_t* ws, const int32_t* lds /* host arrays [n] */, void* y,
+                       int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* F.adaptive_avg_pool2d bins [floor(i*H/Ho), ceil((i+1)*H/Ho)) (moa/heads.py:225-233, moe/gated.py:1211-1213) and
+ * F.avg_pool2d(k, stride k) (moe/gated.py:141-143). */
+int ymk_adaptive_avg_pool(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy, int32_t B,
+                          int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void* stream);
+int ymk_avg_pool(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy, int32_t B, int32_t H,
+                 int32_t W, int32_t C, int32_t k, void* stream);
+
+/* Per image and channel mean (and biased std) over HW: out fp32 [B][C] or [B][2C] = [mean | std]
+ * (moe/gated.py:133-139, AdaptiveAvgPool2d(1) of the gates). */
+int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, float* out, int32_t B, int32_t HW, int32_t C,
+                      int32_t want_std, void* stream);
+
+/* Per-token softmax over n <= 8 fp32 logits scaled by inv_temp; 0 < top_k < n keeps the top_k largest (ties: lower index
+ * first), renormalised with the sum clamped at 1e-6 (mot/router.py:243-295, moa/router.py:50-62).
+ * w fp32 [npix][ldw]; active int32 [B][n] must be zero on entry (atomicOr 1 where a token selects expert e). */
+int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int32_t ldw, int32_t* active, int32_t B, int32_t HW,
+                      int32_t n, float inv_temp, int32_t top_k, void* stream);
+
+/* Decision tail of the gated MoE (moe/gated.py:124-166, 455-492), one workgroup.  g / loc fp32 [B][ld*] logits of the
+ * two router streams, cplx fp32 [B][ldc] complexity logit; outputs w fp32 [B][top_k], idx int32 [B][top_k],
+ * probs fp32 [B][E].  E <= 64, top_k <= 8. */
+int ymk_gated_route_decide(const float* g, int32_t ldg, const float* loc, int32_t ldloc, const float* cplx, int32_t ldc,
+                           int32_t B, int32_t E, float alpha, float inv_temp, int32_t top_k, float* w, int32_t* idx,
+                           float* probs, void* stream);
+
+/* out[(j*B + b)][p][:] = f_all[b][p][idx[b][j]*OC : +OC] — the routed experts' slices of the all-expert convolution
+ * (FusedExpertGroup moe/gated.py:1058-1076, SharedInvertedExpertGroup moe/experts.py:235-269), slot-major. */
+int ymk_expert_gather(int32_t dtype, const void* f_all, int32_t ldf, const int32_t* idx, int32_t B, int32_t HW,
+                      int32_t OC, int32_t K, int32_t E, void* out, void* stream);
+
+/* out[..][j*groups + i] = cat(a, b)[..][i*(C/groups) + j], C = Ca + Cb (_channel_shuffle, moe/gated.py:1333-1338). */
+int ymk_channel_shuffle_cat(int32_t dtype, const void* a, int32_t lda, int32_t Ca, const void* b, int32_t ldb, int32_t Cb,
+                            int32_t groups, void* y, int32_t ldy, int64_t npix, void* stream);
+
+/* softmax(q k^T * scale) v per (image, head); q [B][Nq][heads*hd], k / v [B][Nk][heads*hd] (strides ldq/ldk/ldv),
+ * hd <= 64.  moa/heads.py:208-253, 354-365; mot/experts.py:150-156. */
+int ymk_attention(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
+                  void* out, int32_t ldo, int32_t B, int32_t Nq, int32_t Nk, int32_t heads, int32_t hd, float scale,
+                  void* stream);
+
+/* Attention inside win x win windows (win <= 16) of the map padded bottom / right to a multiple of win; out-of-image
+ * tokens carry pad_q / pad_k / pad_v (fp32 [heads*hd], NULL = zeros) and take part as keys; shift > 0 rolls the padded
+ * grid by -shift before the partition (no mask).  moa/heads.py:83-117, mot/experts.py:237-325. */
+int ymk_window_attention(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v,
+                         int32_t ldv, void* out, int32_t ldo, int32_t B, int32_t H, int32_t W, int32_t heads, int32_t hd,
+                         float scale, int32_t win, int32_t shift, const float* pad_q, const float* pad_k,
+                         const float* pad_v, void* stream);
+
+/* ReLU random-feature attention (moa/heads.py:318-352), fp32: phi(t) = min(relu(t rf^T / sqrt(nb)) + 1e-6, 1e4);
+ * out = clamp(phi(q) (phi(k)^T v), +-1e4) / max(phi(q) . sum_n phi(k_n), 1e-6).  rf fp32 [nb][hd], nb, hd <= 64.
+ * ws: fp32 [B*heads*(nb*hd + nb)] scratch. */
+int ymk_linear_attention(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v,
+                         int32_t ldv, const float* rf, int32_t nb, void* out, int32_t ldo, int32_t B, int32_t N,
+                         int32_t heads, int32_t hd, float* ws, void* stream);
+
+/* Deformable sampling attention (mot/experts.py:381-459): per token and head, n_points locations
+ * clamp(ref + 0.25 * tanh(off), -1, 1) around the token's normalised position, softmax over the points of aw, bilinear
+ * samples (zeros padding) of v's head slice, weighted sum.  off fp32 [npix][heads*n_points*2] (x, y), aw fp32
+ * [npix][heads*n_points]; hd <= 64, n_points <= 8. */
+int ymk_deform_attention(int32_t dtype, const void* v, int32_t ldv, const float* off, int32_t ldoff, const float* aw,
+                         int32_t ldaw, void* out, int32_t ldo, int32_t B, int32_t H, int32_t W, int32_t heads, int32_t hd,
+                         int32_t n_points, int32_t align_corners, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YMK_MIXTURE_H_ */

@@ -47,10 +47,14 @@ def _unpack_conv(w_packed, k, cin):
 
 
 def _ld(t):
-    """Pixel stride of an NHWC view, validated exactly like the product's wrappers do."""
-    from yolo_master_amd import ops
-
-    return ops._nhwc(t)[4]
+    """Pixel stride of an NHWC view under the rules of the product's wrappers (ops._nhwc): channel-dense, pixels and
+    images contiguous."""
+    B, H, W, C = t.shape
+    assert t.stride(3) == 1 or C == 1, "NHWC view must be channel-dense"
+    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else max(C, t.stride(0) // max(H * W, 1)))
+    assert not (W > 1 and H > 1) or t.stride(1) == W * ld, "rows must be contiguous in pixels"
+    assert B == 1 or t.stride(0) == H * W * ld, "images must be contiguous in pixels"
+    return ld
 
 
 def _vec(dtype):

@@ -1,0 +1,257 @@
+"""Config-5 rows on the GPU: the first-implementation kernels of include/ymk_mixture.h through the C-ABI, against
+(a) the torch restatement of each entry point's contract (tests/emu_ops.py) on the same seeded inputs and
+(b) the REAL reference's golden vectors for the modules and the whole config-5 detector.
+
+These kernels were written after the round-1 GPU budget was spent and have not run on hardware yet, so the product keeps
+them switched off unless YMK_EXPERIMENTAL=1 — and so does this file: without that variable every test here is skipped
+(the driver's `pytest -m gpu` run must only report validated code).  First GPU job of the next round:
+
+    YMK_EXPERIMENTAL=1 python -m pytest tests/test_gpu_mixture.py -m gpu -q
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import emu_ops
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("YMK_EXPERIMENTAL") != "1", reason="config-5 kernels are opt-in until validated")]
+DEV = "cuda:0"
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.6e-2}
+
+
+def _rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def _view(t, pad):
+    """The same values as a channel slice of a wider buffer (pixel stride > C)."""
+    if not pad:
+        return t.to(DEV)
+    wide = torch.zeros((*t.shape[:3], t.shape[3] + pad), dtype=t.dtype, device=DEV)
+    wide[..., : t.shape[3]] = t.to(DEV)
+    return wide[..., : t.shape[3]]
+
+
+def _cmp(got, ref, dtype, what):
+    got, ref = got.float().cpu(), ref.float()
+    err = float((got - ref).abs().max())
+    assert err <= TOL[dtype] * max(1.0, float(ref.abs().max())), f"{what}: max |d| {err:.3e} (|ref| max {float(ref.abs().max()):.3f})"
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_norms_and_elementwise(dtype):
+    from yolo_master_amd import ops
+
+    x = _rnd(3, 9, 11, 48, seed=1, dtype=dtype)
+    w, b = 1.0 + 0.1 * _rnd(48, seed=2), 0.1 * _rnd(48, seed=3)
+    for groups, act, pad in ((8, False, 0), (3, "silu", 16), (1, "silu", 0)):
+        _cmp(ops.group_norm(_view(x, pad), groups, w.to(DEV), b.to(DEV), 1e-5, act=act), emu_ops.group_norm(x, groups, w, b, 1e-5, act=act),
+             dtype, f"group_norm g{groups}")
+    res = _rnd(3, 9, 11, 48, seed=4, dtype=dtype)
+    _cmp(ops.group_norm(x.to(DEV), 8, w.to(DEV), b.to(DEV), 1e-5, residual=res.to(DEV)),
+         emu_ops.group_norm(x, 8, w, b, 1e-5, residual=res), dtype, "group_norm + residual")
+    rows_w, rows_b = 1.0 + 0.1 * _rnd(5, 48, seed=5), 0.1 * _rnd(5, 48, seed=6)
+    rows = torch.tensor([4, 0, 2], dtype=torch.int32)
+    _cmp(ops.group_norm(x.to(DEV), 8, rows_w.to(DEV), rows_b.to(DEV), 1e-5, act="silu", affine_rows=rows.to(DEV)),
+         emu_ops.group_norm(x, 8, rows_w, rows_b, 1e-5, act="silu", affine_rows=rows), dtype, "group_norm affine rows")
+    _cmp(ops.group_norm(x.to(DEV), 8, None, None, 1e-5), emu_ops.group_norm(x, 8, None, None, 1e-5), dtype, "group_norm no affine")
+    x6 = _rnd(2, 5, 7, 6, seed=7)                      # odd channel count inside an 8-wide buffer, fp32 -> fp32 (router path)
+    buf = torch.zeros((2, 5, 7, 8), device=DEV)
+    ops.group_norm(_view(x6, 2), 3, w[:6].to(DEV), b[:6].to(DEV), 1e-5, act="silu", out=buf[..., :6])
+    _cmp(buf[..., :6], emu_ops.group_norm(x6, 3, w[:6], b[:6], 1e-5, act="silu"), torch.float32, "group_norm C=6")
+    assert float(buf[..., 6:].abs().max()) == 0.0
+    _cmp(ops.layer_norm(_view(x, 8), w.to(DEV), b.to(DEV), 1e-5), emu_ops.layer_norm(x, w, b, 1e-5), dtype, "layer_norm")
+    y = _rnd(3, 9, 11, 48, seed=8, dtype=dtype)
+    _cmp(ops.eltwise_mul(x.to(DEV), _view(y, 8)), emu_ops.eltwise_mul(x, y), dtype, "mul")
+    _cmp(ops.eltwise_mul(x.to(DEV), y.to(DEV), act_a="sigmoid"), emu_ops.eltwise_mul(x, y, act_a="sigmoid"), dtype, "sigmoid-mul")
+    _cmp(ops.lerp(x.to(DEV), y.to(DEV), 0.3), emu_ops.lerp(x, y, 0.3), dtype, "lerp")
+    gate = torch.sigmoid(_rnd(3, 1, 1, 48, seed=9))
+    _cmp(ops.channel_gate(x.to(DEV), gate.to(DEV)), emu_ops.channel_gate(x, gate), dtype, "channel_gate")
+    _cmp(ops.fma_gate(x.to(DEV), y.to(DEV), gate.to(DEV), 0.37), emu_ops.fma_gate(x, y, gate, 0.37), dtype, "fma_gate per image")
+    _cmp(ops.fma_gate(x.to(DEV), x.to(DEV), y.to(DEV), -0.2), emu_ops.fma_gate(x, x, y, -0.2), dtype, "fma_gate map")
+    wts = torch.softmax(_rnd(3, 9, 11, 3, seed=10), -1)
+    parts = [_rnd(3, 9, 11, 48, seed=11 + i, dtype=dtype) for i in range(3)]
+    _cmp(ops.weighted_sum(wts.to(DEV), [p.to(DEV) for p in parts]), emu_ops.weighted_sum(wts, parts), dtype, "weighted_sum tokens")
+    wimg = torch.softmax(_rnd(3, 1, 1, 2, seed=14), -1)
+    _cmp(ops.weighted_sum(wimg.to(DEV), [p.to(DEV) for p in parts[:2]]), emu_ops.weighted_sum(wimg, parts[:2]), dtype, "weighted_sum images")
+    for act in ("sigmoid", "gelu"):
+        wp = (0.2 * _rnd(16, 64, seed=15)).to(dtype)
+        wp[:, 48:] = 0
+        bias = 0.1 * _rnd(16, seed=16)
+        _cmp(ops.conv2d_act(x.to(DEV), wp.to(DEV), bias.to(DEV), 1, 1, act), emu_ops.conv2d_act(x, wp, bias, 1, 1, act), dtype, f"conv {act}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pools_stats_shuffle_gather(dtype):
+    from yolo_master_amd import ops
+
+    x = _rnd(2, 13, 10, 32, seed=20, dtype=dtype)
+    for ho, wo in ((6, 5), (3, 2), (1, 1), (13, 10)):
+        _cmp(ops.adaptive_avg_pool(_view(x, 8), ho, wo), emu_ops.adaptive_avg_pool(x, ho, wo), dtype, f"adaptive pool {ho}x{wo}")
+    _cmp(ops.avg_pool(x.to(DEV), 4, out_dtype=torch.float32), emu_ops.avg_pool(x, 4, out_dtype=torch.float32), torch.float32, "avg_pool 4")
+    _cmp(ops.avg_pool(x.to(DEV), 1, out_dtype=torch.float32), x.float(), torch.float32, "avg_pool 1 (cast)")
+    _cmp(ops.channel_stats(_view(x, 8)), emu_ops.channel_stats(x), torch.float32, "mean")
+    _cmp(ops.channel_stats(x.to(DEV), want_std=True), emu_ops.channel_stats(x, want_std=True), torch.float32, "mean | std")
+    x100 = _rnd(2, 3, 3, 100, seed=21, dtype=dtype)                    # more than one 64-channel block, ragged
+    _cmp(ops.channel_stats(x100.to(DEV), want_std=True), emu_ops.channel_stats(x100, want_std=True), torch.float32, "stats C=100")
+    parts = [x, _rnd(2, 6, 5, 32, seed=22, dtype=dtype), _rnd(2, 3, 2, 32, seed=23, dtype=dtype)]
+    _cmp(ops.mean_upsampled([p.to(DEV) for p in parts]), emu_ops.mean_upsampled(parts), dtype, "mean_upsampled")
+    a, b = _rnd(2, 7, 5, 24, seed=24, dtype=dtype), _rnd(2, 7, 5, 40, seed=25, dtype=dtype)
+    for groups in (1, 2, 4):
+        got = ops.channel_shuffle_cat([_view(a, 8), b.to(DEV)], groups)
+        assert torch.equal(got.cpu(), emu_ops.channel_shuffle_cat([a, b], groups)), f"shuffle groups {groups}"
+    idx = torch.tensor([[2, 0], [1, 3]], dtype=torch.int32)
+    for k, cin in ((3, 16), (1, 32)):
+        xe = _rnd(2, 6, 7, cin, seed=26, dtype=dtype)
+        wp = torch.zeros((4, 8, (k * k * cin + 63) // 64 * 64), dtype=dtype)
+        wp[:, :, : k * k * cin] = (_rnd(4, 8, k * k * cin, seed=27) * (k * k * cin) ** -0.5).to(dtype)
+        _cmp(ops.expert_conv(xe.to(DEV), wp.to(DEV), k, idx.to(DEV)), emu_ops.expert_conv(xe, wp, k, idx), dtype, f"expert_conv k{k}")
+
+
+def test_router_tails():
+    from yolo_master_amd import ops
+
+    logits = _rnd(3, 10, 12, 4, seed=30, scale=2.0)
+    for n, k, it in ((3, 0, 1.0), (3, 2, 1.25), (3, 1, 0.5), (4, 3, 1.0)):
+        w, active = ops.token_softmax(logits.to(DEV), n, it, top_k=k)
+        rw, ra = emu_ops.token_softmax(logits, n, it, top_k=k)
+        assert torch.equal(w.cpu() > 0, rw > 0), f"selected experts n={n} k={k}"
+        _cmp(w, rw, torch.float32, f"token_softmax n={n} k={k}")
+        assert torch.equal(active.cpu(), ra)
+    lg = _rnd(2, 5, 5, 4, seed=31)
+    lg[0, :, :, 2] = -60.0                                             # expert 2 never selected in image 0
+    _, active = ops.token_softmax(lg.to(DEV), 3, 1.0, top_k=2)
+    assert int(active[0, 2]) == 0 and int(active[1].sum()) >= 2
+    for B, E, k, bias in ((5, 4, 2, 20.0), (3, 8, 2, -20.0), (4, 16, 2, 0.0), (3, 6, 3, 0.3), (2, 4, 1, 0.0)):
+        g, loc = _rnd(B, 1, 1, E, seed=32 + B, scale=2.0), _rnd(B, 1, 1, E, seed=33 + E)
+        cp = _rnd(B, 1, 1, 1, seed=34) + bias
+        w, idx, probs = ops.gated_route_decide(g.to(DEV), loc.to(DEV), 0.4, 1 / 1.2, k, cp.to(DEV))
+        rw, ridx, rprobs = emu_ops.gated_route_decide(g, loc, 0.4, 1 / 1.2, k, cp)
+        assert torch.equal(idx.cpu(), ridx), f"routed experts B={B} E={E}"
+        _cmp(w, rw, torch.float32, "gate weights")
+        _cmp(probs, rprobs, torch.float32, "gate probs")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_family(dtype):
+    from yolo_master_amd import ops
+
+    for heads, hd, (H, W), (Hk, Wk) in ((2, 16, (9, 11), (9, 11)), (8, 8, (14, 18), (14, 18)), (1, 16, (12, 20), (6, 10)), (2, 32, (5, 7), (2, 3)),
+                                        (1, 64, (8, 8), (8, 8)), (3, 24, (6, 5), (6, 5))):
+        c = heads * hd
+        qkv = _rnd(2, H, W, 3 * c, seed=40 + hd, dtype=dtype)
+        kv = _rnd(2, Hk, Wk, 2 * c, seed=41 + hd, dtype=dtype)
+        qd, kd = qkv.to(DEV), kv.to(DEV)
+        _cmp(ops.attention(qd[..., :c], kd[..., :c], kd[..., c:], heads, hd, hd ** -0.5),
+             emu_ops.attention(qkv[..., :c], kv[..., :c], kv[..., c:], heads, hd, hd ** -0.5), dtype, f"attention h{heads} d{hd} {H}x{W}/{Hk}x{Wk}")
+    for heads, hd, (H, W), win, shift, pad in ((2, 16, (14, 18), 7, 0, False), (6, 8, (14, 18), 7, 3, True), (6, 8, (16, 20), 7, 3, True),
+                                               (1, 16, (5, 4), 4, 0, False), (2, 32, (7, 7), 7, 0, False), (6, 8, (9, 11), 7, 0, True)):
+        c = heads * hd
+        qkv = _rnd(2, H, W, 3 * c, seed=50 + hd + shift, dtype=dtype)
+        pads = [_rnd(c, seed=51 + i) if pad else None for i in range(3)]
+        qd = qkv.to(DEV)
+        got = ops.window_attention(qd[..., :c], qd[..., c:2 * c], qd[..., 2 * c:], heads, hd, hd ** -0.5, win, shift,
+                                   *[p.to(DEV) if p is not None else None for p in pads])
+        ref = emu_ops.window_attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], heads, hd, hd ** -0.5, win, shift, *pads)
+        _cmp(got, ref, dtype, f"window h{heads} d{hd} {H}x{W} win{win} shift{shift} pad{pad}")
+    for heads, hd, (H, W) in ((2, 16, (24, 28)), (1, 16, (20, 24)), (2, 32, (9, 9)), (1, 64, (10, 13))):
+        c = heads * hd
+        qkv = _rnd(2, H, W, 3 * c, seed=60 + hd, dtype=dtype)
+        rf, _ = torch.linalg.qr(_rnd(hd, hd, seed=61))
+        rf = rf[: min(64, hd)].contiguous()
+        qd = qkv.to(DEV)
+        _cmp(ops.linear_attention(qd[..., :c], qd[..., c:2 * c], qd[..., 2 * c:], rf.to(DEV), heads, hd),
+             emu_ops.linear_attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], rf, heads, hd), dtype, f"linear h{heads} d{hd}")
+    for heads, hd, (H, W), npnt, align in ((6, 8, (14, 18), 4, True), (8, 8, (15, 17), 4, True), (2, 16, (9, 1), 3, False), (1, 8, (1, 1), 4, True)):
+        c = heads * hd
+        v = _rnd(2, H, W, c, seed=70 + hd, dtype=dtype)
+        off, aw = _rnd(2, H, W, heads * npnt * 2, seed=71, scale=1.5), _rnd(2, H, W, heads * npnt, seed=72)
+        _cmp(ops.deform_attention(v.to(DEV), off.to(DEV), aw.to(DEV), heads, hd, npnt, align),
+             emu_ops.deform_attention(v, off, aw, heads, hd, npnt, align), dtype, f"deform h{heads} d{hd} {H}x{W} np{npnt}")
+
+
+# ------------------------------------------------------------------------------------------------- modules / model
+def _load(golden_dir, fam, name):
+    z = np.load(golden_dir / f"{fam}_{name}.npz")
+    return z, {k: torch.from_numpy(z[f"sd::{k}"]) for k in z["keys"].tolist()}
+
+
+def _prep(mod, sd):
+    mod.load_state_dict(sd)
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3
+    return mod.eval().to(DEV)
+
+
+@pytest.mark.parametrize("fam,name,ctor", [
+    ("moa", "exact", ("MoABlock", (48,), dict(num_heads=6))), ("moa", "blend", ("MoABlock", (48,), dict(num_heads=6))),
+    ("moa", "linear", ("MoABlock", (48,), dict(num_heads=6))),
+    ("moa", "kvcap", ("MoABlock", (48,), dict(num_heads=6, regional_max_kv_tokens=64, shortcut=False))),
+    ("moa", "c2f", ("C2fMoA", (64, 96), dict(n=2, num_heads=6))),
+    ("mot", "top2", ("MoTBlock", (48,), dict(num_heads=6))),
+    ("mot", "shift", ("MoTBlock", (48,), dict(num_heads=6, window_shift=True, local_attn_window=7))),
+    ("mot", "top1", ("MoTBlock", (48,), dict(num_heads=6, top_k=1))), ("mot", "dense", ("MoTBlock", (48,), dict(num_heads=6, top_k=3))),
+    ("mot", "skip", ("MoTBlock", (48,), dict(num_heads=6))), ("mot", "c2f", ("C2fMoT", (64, 96), dict(n=2, num_heads=6))),
+    ("gated", "base", ("VisualEnhancedAdaptiveGateMoE", (64, 64), {})), ("gated", "small", ("VisualEnhancedAdaptiveGateMoE", (64, 64), {})),
+    ("gated", "keep1", ("VisualEnhancedAdaptiveGateMoE", (64, 64), {})),
+    ("gated", "e6k3", ("VisualEnhancedAdaptiveGateMoE", (96, 96), dict(num_experts=6, top_k=3))),
+    ("gated", "e16", ("VisualEnhancedAdaptiveGateMoE", (64, 64), dict(num_experts=16, top_k=2))),
+    ("gated", "mid", ("VisualEnhancedAdaptiveGateMoE", (64, 64), {})),
+])
+def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
+    """fp32 on the GPU against the REAL reference's outputs (the fixtures of tests/test_host_mixture.py)."""
+    import warnings
+
+    from yolo_master_amd.nn import mixture
+
+    z, sd = _load(golden_dir, fam, name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = _prep(getattr(mixture, ctor[0])(*ctor[1], **ctor[2]), sd)
+    with torch.inference_mode():
+        got = m(torch.from_numpy(z["x"]).to(DEV)).cpu()
+    ref = torch.from_numpy(z["y"])
+    err = float((got - ref).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref.abs().max())), f"{fam}_{name}: max |d| {err:.3e}"
+    if fam == "gated":
+        B = got.shape[0]
+        assert np.array_equal(m.last_route["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
+
+
+def test_config5_model_vs_reference_golden(golden_dir):
+    import json
+    import warnings
+
+    from tests.helpers import fill_by_name
+    from yolo_master_amd import ops
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    z = np.load(golden_dir / "fwd_cfg5.npz")
+    cfg = json.loads(str(z["cfg"]))
+    sd = fill_by_name(json.loads(str(z["spec"])), seed=5, gain=1.0)
+    sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DetectionModel("yolo-master-moa-mot-n.yaml")
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    taps = {}
+    with torch.inference_mode():
+        m._predict_once(torch.from_numpy(z["x"]).to(DEV), taps=taps)
+    n = len(cfg["backbone"]) + len(cfg["head"])
+    for i in range(n - 1):
+        t = taps[i]
+        if not torch.is_tensor(t):
+            t = t.materialise()
+        got = ops.nhwc_to_nchw_f32(t).cpu().reshape(-1)[torch.from_numpy(z[f"layer{i}_idx"].astype(np.int64))].numpy()
+        ref = z[f"layer{i}_val"]
+        err = float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max())))
+        assert err <= 1e-3, f"layer {i} ({(cfg['backbone'] + cfg['head'])[i][2]}): scaled max error {err:.3e}"

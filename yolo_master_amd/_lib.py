@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-__all__ = ["lib", "load", "YmkLibraryError", "ConvDesc", "check", "LIB_PATH", "SYMBOLS"]
+__all__ = ["lib", "load", "YmkLibraryError", "ConvDesc", "check", "LIB_PATH", "SYMBOLS", "SYMBOLS_MIXTURE"]
 
 LIB_PATH = Path(__file__).resolve().parent / "libymk.so"
 
@@ -70,6 +70,36 @@ SYMBOLS = {
     "ymk_cw_refine": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
 }
 
+# Config-5 rows (include/ymk_mixture.h): first implementation, compiled but not yet run on hardware — bound separately so
+# that the validated table above stays exactly the surface of include/ymk.h.
+SYMBOLS_MIXTURE = {
+    "ymk_activation": (C.c_int, [_i32, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "ymk_group_norm": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32,
+                                 _vp, _vp]),
+    "ymk_layer_norm": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp]),
+    "ymk_eltwise": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _vp]),
+    "ymk_fma_gate": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_channel_gate": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_weighted_sum": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_mean_upsampled": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp, _i32,
+                                     _i32, _i32, _i32, _i32, _vp]),
+    "ymk_adaptive_avg_pool": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_avg_pool": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_channel_stats": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_token_softmax": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "ymk_gated_route_decide": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "ymk_expert_gather": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ymk_channel_shuffle_cat": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i64, _vp]),
+    "ymk_attention": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "ymk_window_attention": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32,
+                                       _i32, _vp, _vp, _vp, _vp]),
+    "ymk_linear_attention": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ymk_deform_attention": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                       _vp]),
+}
+ACT_SIGMOID, ACT_GELU = 2, 3
+ELT_MUL, ELT_SIGMOID_MUL, ELT_LERP = 0, 1, 2
+
 _lib = None
 
 
@@ -92,6 +122,12 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
     except OSError as e:  # pragma: no cover
         raise YmkLibraryError(f"cannot load {p}: {e}") from e
     for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise YmkLibraryError(f"{p} does not export {name}; rebuild libymk") from e
+        fn.restype, fn.argtypes = res, args
+    for name, (res, args) in SYMBOLS_MIXTURE.items():
         try:
             fn = getattr(h, name)
         except AttributeError as e:

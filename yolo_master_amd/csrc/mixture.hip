@@ -1,0 +1,514 @@
+// Config-5 rows (MoA / MoT / gated MoE): normalisation, gates, pooling, router tails, expert gather, shuffle.
+// include/ymk_mixture.h has the contracts and the reference lines.  FIRST IMPLEMENTATION, correctness-first: scalar
+// element accesses with run-time dtype codes, grid-stride loops, fp32 arithmetic; every kernel here is HBM-bound and
+// small next to the convolutions, vector-width loads and fusion into producers / consumers come after hardware parity.
+#include "ymk_common.h"
+#include "../../include/ymk_mixture.h"
+
+namespace {
+
+__device__ __forceinline__ float ldv(const void* p, int dt, int64_t i) {
+    return dt == YMK_BF16 ? bf16_to_f32(static_cast<const bf16_t*>(p)[i]) : static_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void stv(void* p, int dt, int64_t i, float v) {
+    if (dt == YMK_BF16) static_cast<bf16_t*>(p)[i] = f32_to_bf16(v);
+    else static_cast<float*>(p)[i] = v;
+}
+__device__ __forceinline__ float act_f(float v, int act) {
+    switch (act) {
+        case YMK_ACT_SILU: return v / (1.0f + expf(-v));
+        case YMK_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case YMK_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        default: return v;
+    }
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// sum over a 256-thread workgroup; sh: 4 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+inline bool bad_dt(int dt) { return dt != YMK_F32 && dt != YMK_BF16; }
+inline int blocks_for(int64_t total, int per_block = 256, int cap = 256 * 64) {
+    const int64_t b = (total + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+#define GRID_STRIDE(i, total) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------------------------------ activation
+__global__ __launch_bounds__(256) void activation_kernel(void* x, int dt, int ldx, int64_t npix, int C, int act) {
+    const int64_t total = npix * C;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i / C;
+        const int c = (int)(i % C);
+        stv(x, dt, p * ldx + c, act_f(ldv(x, dt, p * ldx + c), act));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ group norm
+// one workgroup per (image, group): mean, then centred variance (two passes over an L2-resident slab)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const void* x, int dt, int ldx, int HW, int C, int groups, float eps,
+                                                        float* stats) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cg = C / groups;
+    const int64_t n = (int64_t)HW * cg;
+    const int64_t base = (int64_t)b * HW * ldx + (int64_t)g * cg;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += ldv(x, dt, base + (i / cg) * ldx + (i % cg));
+    const float mean = block_sum(s, sh) / (float)n;
+    float q = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float d = ldv(x, dt, base + (i / cg) * ldx + (i % cg)) - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, sh) / (float)n;
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = mean;
+        stats[2 * blockIdx.x + 1] = 1.0f / sqrtf(var + eps);
+    }
+}
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, int dt, int ldx, void* y, int odt, int ldy, const void* res,
+                                                        int ldr, int B, int HW, int C, int groups, const float* weight,
+                                                        const float* bias, const int32_t* rows, int act, const float* stats) {
+    const int cg = C / groups;
+    const int64_t total = (int64_t)B * HW * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;   // b*HW + pixel
+        const int b = (int)(p / HW);
+        const float* st = stats + 2 * ((int64_t)b * groups + c / cg);
+        float v = (ldv(x, dt, p * ldx + c) - st[0]) * st[1];
+        if (weight) {
+            const int64_t r = rows ? (int64_t)rows[b] * C : 0;
+            v = v * weight[r + c] + bias[r + c];
+        }
+        v = act_f(v, act);
+        if (res) v += ldv(res, odt, p * ldr + c);
+        stv(y, odt, p * ldy + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layer norm
+// one wave per token
+__global__ __launch_bounds__(256) void ln_kernel(const void* x, int dt, int ldx, void* y, int ldy, int64_t npix, int C,
+                                                  const float* weight, const float* bias, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p = wave0; p < npix; p += nwaves) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += ldv(x, dt, p * ldx + c);
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = ldv(x, dt, p * ldx + c) - mean;
+            q += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        for (int c = lane; c < C; c += 64) stv(y, dt, p * ldy + c, (ldv(x, dt, p * ldx + c) - mean) * rstd * weight[c] + bias[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise family
+__global__ __launch_bounds__(256) void eltwise_kernel(int op, int dt, const void* a, int lda, const void* b, int ldb, void* y,
+                                                       int ldy, int64_t npix, int C, float alpha) {
+    const int64_t total = npix * C;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i / C;
+        const int c = (int)(i % C);
+        const float av = ldv(a, dt, p * lda + c), bv = ldv(b, dt, p * ldb + c);
+        float r;
+        if (op == YMK_ELT_MUL) r = av * bv;
+        else if (op == YMK_ELT_SIGMOID_MUL) r = bv / (1.0f + expf(-av));
+        else r = (1.0f - alpha) * av + alpha * bv;
+        stv(y, dt, p * ldy + c, r);
+    }
+}
+__global__ __launch_bounds__(256) void fma_gate_kernel(int dt, const void* x, int ldx, const void* a, int lda, const void* b,
+                                                        int bdt, int ldb, int b_per_image, float scale, void* y, int ldy, int B,
+                                                        int HW, int C) {
+    const int64_t total = (int64_t)B * HW * C;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i / C;
+        const int c = (int)(i % C);
+        const float bv = b_per_image ? static_cast<const float*>(b)[(p / HW) * C + c] : ldv(b, bdt, p * ldb + c);
+        stv(y, dt, p * ldy + c, ldv(x, dt, p * ldx + c) + scale * ldv(a, dt, p * lda + c) * bv);
+    }
+}
+__global__ __launch_bounds__(256) void channel_gate_kernel(int dt, const void* x, int ldx, const float* gate, void* y, int ldy,
+                                                            int B, int HW, int C) {
+    const int64_t total = (int64_t)B * HW * C;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i / C;
+        const int c = (int)(i % C);
+        stv(y, dt, p * ldy + c, ldv(x, dt, p * ldx + c) * gate[(p / HW) * C + c]);
+    }
+}
+struct Parts4 {
+    const void* p[4];
+};
+__global__ __launch_bounds__(256) void weighted_sum_kernel(int dt, const float* w, int ldw, int per_image, int E, Parts4 parts,
+                                                            int ldp, void* y, int ldy, int B, int HW, int C) {
+    const int64_t total = (int64_t)B * HW * C;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i / C;
+        const int c = (int)(i % C);
+        const float* wr = w + (per_image ? p / HW : p) * ldw;
+        float r = 0.f;
+        for (int e = 0; e < E; ++e) r += wr[e] * ldv(parts.p[e], dt, p * ldp + c);
+        stv(y, dt, p * ldy + c, r);
+    }
+}
+struct Pyr4 {
+    const void* p[4];
+    int h[4], w[4], ld[4];
+};
+__global__ __launch_bounds__(256) void mean_upsampled_kernel(int dt, int n, Pyr4 a, void* y, int ldy, int B, int H, int W, int C) {
+    const int64_t total = (int64_t)B * H * W * C;
+    const float inv = 1.0f / (float)n;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int ox = (int)(p % W);
+        p /= W;
+        const int oy = (int)(p % H);
+        const int b = (int)(p / H);
+        float r = 0.f;
+        for (int j = 0; j < n; ++j) {   // F.interpolate(mode="nearest"): src = floor(dst * h / H)
+            const int sy = (int)(((int64_t)oy * a.h[j]) / H), sx = (int)(((int64_t)ox * a.w[j]) / W);
+            r += ldv(a.p[j], dt, (((int64_t)b * a.h[j] + sy) * a.w[j] + sx) * a.ld[j] + c);
+        }
+        stv(y, dt, (((int64_t)b * H + oy) * W + ox) * ldy + c, r * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling / statistics
+__global__ __launch_bounds__(256) void pool_kernel(int dt, const void* x, int ldx, void* y, int odt, int ldy, int B, int H, int W,
+                                                    int C, int Ho, int Wo, int k /* 0: adaptive bins, else k x k stride k */) {
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        int y0, y1, x0, x1;
+        if (k) {
+            y0 = oy * k; y1 = y0 + k; x0 = ox * k; x1 = x0 + k;
+        } else {
+            y0 = (int)(((int64_t)oy * H) / Ho); y1 = (int)((((int64_t)oy + 1) * H + Ho - 1) / Ho);
+            x0 = (int)(((int64_t)ox * W) / Wo); x1 = (int)((((int64_t)ox + 1) * W + Wo - 1) / Wo);
+        }
+        float s = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) s += ldv(x, dt, (((int64_t)b * H + yy) * W + xx) * ldx + c);
+        stv(y, odt, (((int64_t)b * Ho + oy) * Wo + ox) * ldy + c, s / (float)((y1 - y0) * (x1 - x0)));
+    }
+}
+// workgroup = 4 pixel lanes x 64 channels of one image; grid (ceil(C/64), B)
+__global__ __launch_bounds__(256) void channel_stats_kernel(int dt, const void* x, int ldx, float* out, int HW, int C, int want_std) {
+    __shared__ float sh[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int64_t base = (int64_t)b * HW * ldx;
+    float s = 0.f;
+    if (c < C)
+        for (int p = r; p < HW; p += 4) s += ldv(x, dt, base + (int64_t)p * ldx + c);
+    sh[r][cl] = s;
+    __syncthreads();
+    const float mean = (sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]) / (float)HW;
+    __syncthreads();
+    const int oc = want_std ? 2 * C : C;
+    if (r == 0 && c < C) out[(int64_t)b * oc + c] = mean;
+    if (!want_std) return;
+    float q = 0.f;
+    if (c < C)
+        for (int p = r; p < HW; p += 4) {
+            const float d = ldv(x, dt, base + (int64_t)p * ldx + c) - mean;
+            q += d * d;
+        }
+    sh[r][cl] = q;
+    __syncthreads();
+    if (r == 0 && c < C) out[(int64_t)b * oc + C + c] = HW > 1 ? sqrtf((sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]) / (float)HW) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------ routers
+__global__ __launch_bounds__(256) void token_softmax_kernel(const float* logits, int ldl, float* w, int ldw, int32_t* active, int B,
+                                                             int HW, int n, float inv_temp, int top_k) {
+    const int64_t total = (int64_t)B * HW;
+    GRID_STRIDE(p, total) {
+        float v[8];
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = e < n ? logits[p * ldl + e] * inv_temp : -INFINITY;
+            m = fmaxf(m, v[e]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = e < n ? expf(v[e] - m) : 0.f;
+            s += v[e];
+        }
+        unsigned sel = (1u << n) - 1u;
+        if (top_k > 0 && top_k < n) {
+            sel = 0u;
+            float ssel = 0.f;
+            for (int j = 0; j < top_k; ++j) {   // largest not yet taken, lower index wins ties
+                int best = -1;
+                float bv = -1.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < n && !((sel >> e) & 1u) && v[e] > bv) { bv = v[e]; best = e; }
+                sel |= 1u << best;
+                ssel += bv / s;
+            }
+            s *= fmaxf(ssel, 1e-6f);   // renormalise over the selected set (sum clamped at 1e-6)
+        }
+        const int b = (int)(p / HW);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < n) {
+                const bool on = (sel >> e) & 1u;
+                w[p * ldw + e] = on ? v[e] / s : 0.f;
+                if (on && active[b * n + e] == 0) atomicOr(&active[b * n + e], 1);
+            }
+    }
+}
+
+// one workgroup: complexity (batch mean) first, then one image per thread
+__global__ __launch_bounds__(256) void gated_decide_kernel(const float* g, int ldg, const float* loc, int ldloc, const float* cplx,
+                                                            int ldc, int B, int E, float alpha, float inv_temp, int top_k, float* w,
+                                                            int32_t* idx, float* probs) {
+    __shared__ float sh[4];
+    float cs = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) cs += 1.0f / (1.0f + expf(-cplx[(int64_t)b * ldc]));
+    float c = block_sum(cs, sh) / (float)B;
+    c = (c == c && fabsf(c) <= 3.0e38f) ? fminf(fmaxf(c, 0.3f), 1.5f) : 1.0f;
+    const int keep = (int)fminf(fmaxf(rintf(c * (float)top_k), 1.0f), (float)top_k);   // torch.round: half to even
+    const float a = 1.0f / (1.0f + expf(-alpha));
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float* pr = probs + (int64_t)b * E;
+        float m = -INFINITY;
+        for (int e = 0; e < E; ++e) {
+            const float l = fminf(fmaxf(a * g[(int64_t)b * ldg + e] + (1.0f - a) * loc[(int64_t)b * ldloc + e], -30.0f), 30.0f) * inv_temp;
+            pr[e] = l;
+            m = fmaxf(m, l);
+        }
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) {
+            pr[e] = expf(pr[e] - m);
+            s += pr[e];
+        }
+        for (int e = 0; e < E; ++e) pr[e] /= s;
+        unsigned long long taken = 0ull;
+        float tw[8];
+        float tsum = 0.f;
+        for (int j = 0; j < top_k; ++j) {   // descending, lower index wins ties (torch.topk on CPU)
+            int best = 0;
+            float bv = -1.f;
+            for (int e = 0; e < E; ++e)
+                if (!((taken >> e) & 1ull) && pr[e] > bv) { bv = pr[e]; best = e; }
+            taken |= 1ull << best;
+            idx[(int64_t)b * top_k + j] = best;
+            tw[j] = bv;
+            tsum += bv;
+        }
+        float ksum = 0.f;
+        for (int j = 0; j < top_k; ++j) {
+            tw[j] = tw[j] / (tsum + 1e-6f);
+            if (top_k > 1 && j >= keep) tw[j] = 0.f;
+            ksum += tw[j];
+        }
+        for (int j = 0; j < top_k; ++j) w[(int64_t)b * top_k + j] = top_k > 1 ? tw[j] / fmaxf(ksum, 1e-6f) : tw[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gather / shuffle
+__global__ __launch_bounds__(256) void expert_gather_kernel(int dt, const void* f, int ldf, const int32_t* idx, int B, int HW,
+                                                             int OC, int K, void* out) {
+    const int64_t total = (int64_t)K * B * HW * OC;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % OC);
+        int64_t p = i / OC;
+        const int px = (int)(p % HW);
+        p /= HW;
+        const int b = (int)(p % B);
+        const int j = (int)(p / B);
+        stv(out, dt, i, ldv(f, dt, ((int64_t)b * HW + px) * ldf + (int64_t)idx[b * K + j] * OC + c));
+    }
+}
+__global__ __launch_bounds__(256) void shuffle_cat_kernel(int dt, const void* a, int lda, int Ca, const void* b, int ldb, int Cb,
+                                                           int groups, void* y, int ldy, int64_t npix) {
+    const int C = Ca + Cb, cpg = C / groups;
+    const int64_t total = npix * C;
+    GRID_STRIDE(i, total) {
+        const int o = (int)(i % C);
+        const int64_t p = i / C;
+        const int s = (o % groups) * cpg + o / groups;
+        stv(y, dt, p * ldy + o, s < Ca ? ldv(a, dt, p * lda + s) : ldv(b, dt, p * ldb + (s - Ca)));
+    }
+}
+
+}  // namespace
+
+#define LAUNCH(kern, total, ...) \
+    hipLaunchKernelGGL(kern, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+
+extern "C" int ymk_activation(int32_t dtype, void* x, int32_t ldx, int64_t npix, int32_t C, int32_t act, void* stream) {
+    if (!x || bad_dt(dtype) || C < 1 || ldx < C || act < YMK_ACT_NONE || act > YMK_ACT_GELU) return YMK_E_BADARG;
+    if (npix <= 0 || act == YMK_ACT_NONE) return YMK_OK;
+    LAUNCH(activation_kernel, npix * C, x, dtype, ldx, npix, C, act);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
+                              const void* residual, int32_t ldr, int32_t B, int32_t HW, int32_t C, int32_t groups,
+                              const float* weight, const float* bias, const int32_t* affine_rows, float eps, int32_t act,
+                              float* stats_ws, void* stream) {
+    if (!x || !y || !stats_ws || bad_dt(dtype) || bad_dt(out_dtype) || C < 1 || groups < 1 || C % groups || ldx < C || ldy < C)
+        return YMK_E_BADARG;
+    if ((weight == nullptr) != (bias == nullptr) || (affine_rows && !weight) || (residual && ldr < C)) return YMK_E_BADARG;
+    if (act != YMK_ACT_NONE && act != YMK_ACT_SILU) return YMK_E_BADARG;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, dtype, ldx, HW, C, groups, eps, stats_ws);
+    LAUNCH(gn_apply_kernel, (int64_t)B * HW * C, x, dtype, ldx, y, out_dtype, ldy, residual, ldr, B, HW, C, groups, weight, bias,
+           affine_rows, act, (const float*)stats_ws);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_layer_norm(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t npix, int32_t C,
+                              const float* weight, const float* bias, float eps, void* stream) {
+    if (!x || !y || !weight || !bias || bad_dt(dtype) || C < 1 || ldx < C || ldy < C) return YMK_E_BADARG;
+    if (npix <= 0) return YMK_OK;
+    LAUNCH(ln_kernel, npix * 64, x, dtype, ldx, y, ldy, npix, C, weight, bias, eps);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_eltwise(int32_t op, int32_t dtype, const void* a, int32_t lda, const void* b, int32_t ldb, void* y, int32_t ldy,
+                           int64_t npix, int32_t C, float alpha, void* stream) {
+    if (!a || !b || !y || bad_dt(dtype) || op < YMK_ELT_MUL || op > YMK_ELT_LERP || C < 1 || lda < C || ldb < C || ldy < C)
+        return YMK_E_BADARG;
+    if (npix <= 0) return YMK_OK;
+    LAUNCH(eltwise_kernel, npix * C, op, dtype, a, lda, b, ldb, y, ldy, npix, C, alpha);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_fma_gate(int32_t dtype, const void* x, int32_t ldx, const void* a, int32_t lda, const void* b, int32_t b_dtype,
+                            int32_t ldb, int32_t b_per_image, float scale, void* y, int32_t ldy, int32_t B, int32_t HW, int32_t C,
+                            void* stream) {
+    if (!x || !a || !b || !y || bad_dt(dtype) || C < 1 || ldx < C || lda < C || ldy < C) return YMK_E_BADARG;
+    if (!b_per_image && (bad_dt(b_dtype) || ldb < C)) return YMK_E_BADARG;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    LAUNCH(fma_gate_kernel, (int64_t)B * HW * C, dtype, x, ldx, a, lda, b, b_dtype, ldb, b_per_image, scale, y, ldy, B, HW, C);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_channel_gate(int32_t dtype, const void* x, int32_t ldx, const float* gate, void* y, int32_t ldy, int32_t B,
+                                int32_t HW, int32_t C, void* stream) {
+    if (!x || !gate || !y || bad_dt(dtype) || C < 1 || ldx < C || ldy < C) return YMK_E_BADARG;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    LAUNCH(channel_gate_kernel, (int64_t)B * HW * C, dtype, x, ldx, gate, y, ldy, B, HW, C);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_weighted_sum(int32_t dtype, const float* w, int32_t ldw, int32_t w_per_image, int32_t E, const void* p0,
+                                const void* p1, const void* p2, const void* p3, int32_t ldp, void* y, int32_t ldy, int32_t B,
+                                int32_t HW, int32_t C, void* stream) {
+    if (!w || !y || bad_dt(dtype) || E < 1 || E > 4 || ldw < E || C < 1 || ldp < C || ldy < C) return YMK_E_BADARG;
+    Parts4 parts{{p0, p1, p2, p3}};
+    for (int e = 0; e < E; ++e)
+        if (!parts.p[e]) return YMK_E_BADARG;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    LAUNCH(weighted_sum_kernel, (int64_t)B * HW * C, dtype, w, ldw, w_per_image, E, parts, ldp, y, ldy, B, HW, C);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_mean_upsampled(int32_t dtype, int32_t n, const void* p0, const void* p1, const void* p2, const void* p3,
+                                  const int32_t* hs, const int32_t* ws, const int32_t* lds, void* y, int32_t ldy, int32_t B,
+                                  int32_t H, int32_t W, int32_t C, void* stream) {
+    if (!y || !hs || !ws || !lds || bad_dt(dtype) || n < 1 || n > 4 || C < 1 || ldy < C) return YMK_E_BADARG;
+    Pyr4 a{{p0, p1, p2, p3}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int j = 0; j < n; ++j) {
+        if (!a.p[j] || hs[j] < 1 || ws[j] < 1 || lds[j] < C) return YMK_E_BADARG;
+        a.h[j] = hs[j]; a.w[j] = ws[j]; a.ld[j] = lds[j];
+    }
+    if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
+    LAUNCH(mean_upsampled_kernel, (int64_t)B * H * W * C, dtype, n, a, y, ldy, B, H, W, C);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_adaptive_avg_pool(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy, int32_t B,
+                                     int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void* stream) {
+    if (!x || !y || bad_dt(dtype) || bad_dt(out_dtype) || C < 1 || ldx < C || ldy < C || Ho < 1 || Wo < 1 || H < 1 || W < 1)
+        return YMK_E_BADARG;
+    if (B <= 0) return YMK_OK;
+    LAUNCH(pool_kernel, (int64_t)B * Ho * Wo * C, dtype, x, ldx, y, out_dtype, ldy, B, H, W, C, Ho, Wo, 0);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_avg_pool(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy, int32_t B, int32_t H,
+                            int32_t W, int32_t C, int32_t k, void* stream) {
+    if (!x || !y || bad_dt(dtype) || bad_dt(out_dtype) || C < 1 || ldx < C || ldy < C || k < 1 || H < k || W < k) return YMK_E_BADARG;
+    if (B <= 0) return YMK_OK;
+    LAUNCH(pool_kernel, (int64_t)B * (H / k) * (W / k) * C, dtype, x, ldx, y, out_dtype, ldy, B, H, W, C, H / k, W / k, k);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, float* out, int32_t B, int32_t HW, int32_t C,
+                                 int32_t want_std, void* stream) {
+    if (!x || !out || bad_dt(dtype) || C < 1 || ldx < C || HW < 1 || B > 65535) return YMK_E_BADARG;
+    if (B <= 0) return YMK_OK;
+    hipLaunchKernelGGL(channel_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dtype, x, ldx, out, HW, C,
+                       want_std);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int32_t ldw, int32_t* active, int32_t B, int32_t HW,
+                                 int32_t n, float inv_temp, int32_t top_k, void* stream) {
+    if (!logits || !w || !active || n < 1 || n > 8 || ldl < n || ldw < n || top_k < 0) return YMK_E_BADARG;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    LAUNCH(token_softmax_kernel, (int64_t)B * HW, logits, ldl, w, ldw, active, B, HW, n, inv_temp, top_k);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_gated_route_decide(const float* g, int32_t ldg, const float* loc, int32_t ldloc, const float* cplx, int32_t ldc,
+                                      int32_t B, int32_t E, float alpha, float inv_temp, int32_t top_k, float* w, int32_t* idx,
+                                      float* probs, void* stream) {
+    if (!g || !loc || !cplx || !w || !idx || !probs || E < 1 || E > 64 || top_k < 1 || top_k > 8 || top_k > E || ldg < E ||
+        ldloc < E || ldc < 1)
+        return YMK_E_BADARG;
+    if (B <= 0) return YMK_OK;
+    hipLaunchKernelGGL(gated_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g, ldg, loc, ldloc, cplx, ldc, B, E, alpha,
+                       inv_temp, top_k, w, idx, probs);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_expert_gather(int32_t dtype, const void* f_all, int32_t ldf, const int32_t* idx, int32_t B, int32_t HW, int32_t OC,
+                                 int32_t K, int32_t E, void* out, void* stream) {
+    if (!f_all || !idx || !out || bad_dt(dtype) || OC < 1 || K < 1 || E < 1 || ldf < E * OC) return YMK_E_BADARG;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    LAUNCH(expert_gather_kernel, (int64_t)K * B * HW * OC, dtype, f_all, ldf, idx, B, HW, OC, K, out);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_channel_shuffle_cat(int32_t dtype, const void* a, int32_t lda, int32_t Ca, const void* b, int32_t ldb, int32_t Cb,
+                                       int32_t groups, void* y, int32_t ldy, int64_t npix, void* stream) {
+    if (!a || !b || !y || bad_dt(dtype) || Ca < 1 || Cb < 1 || groups < 1 || (Ca + Cb) % groups || lda < Ca || ldb < Cb ||
+        ldy < Ca + Cb)
+        return YMK_E_BADARG;
+    if (npix <= 0) return YMK_OK;
+    LAUNCH(shuffle_cat_kernel, npix * (Ca + Cb), dtype, a, lda, Ca, b, ldb, Cb, groups, y, ldy, npix);
+    return ymk_launch_status();
+}

@@ -404,28 +404,47 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
 
 
 # ============================================================================= config-5 rows (MoA / MoT / gated MoE)
-# Entry points whose CONTRACT is fixed here — it is what nn/mixture.py is written against and what tests/emu_ops.py
-# restates for the CPU-side host tests — but whose HIP kernels are not in libymk yet (round-2 work).
-# Until then every one of them fails loudly: there is no CPU / PyTorch fallback.  Conventions as above: NHWC views
-# [B, H, W, C] with a pixel stride ld >= C, activations in the compute dtype, statistics / gates / router math fp32.
+# Entry points of include/ymk_mixture.h.  Their CONTRACT is fixed here — it is what nn/mixture.py is written against and
+# what tests/emu_ops.py restates for the CPU-side host tests.  Their HIP kernels (csrc/mixture.hip, csrc/mixattn.hip) are a
+# first, correctness-first implementation that compiles for gfx950 but was written after the round's GPU budget was
+# spent: it has NOT run on hardware yet.  Until tests/test_gpu_mixture.py has passed on an MI355X the wrappers refuse to
+# use them unless YMK_EXPERIMENTAL=1 is set — there is no CPU / PyTorch fallback either way.  Conventions as above: NHWC
+# views [B, H, W, C] with a pixel stride ld >= C, activations in the compute dtype, statistics / gates / router math fp32.
 class KernelNotBuilt(NotImplementedError):
     pass
 
 
-def _not_built(name: str):
-    raise KernelNotBuilt(f"libymk has no kernel for `{name}` yet (config-5 row, next round); there is no CPU / PyTorch fallback")
+def _gate(name: str):
+    if os.environ.get("YMK_EXPERIMENTAL") != "1":
+        raise KernelNotBuilt(f"libymk's kernel for `{name}` (config-5 row) has not been validated on hardware yet and is switched "
+                             "off; set YMK_EXPERIMENTAL=1 to run it. There is no CPU / PyTorch fallback")
 
 
 ACT_CODES = (False, True, "silu", "sigmoid", "gelu")   # conv / norm epilogues of the config-5 modules
+_ACT = {False: _lib.ACT_NONE, None: _lib.ACT_NONE, True: _lib.ACT_SILU, "silu": _lib.ACT_SILU, "sigmoid": _lib.ACT_SIGMOID,
+        "gelu": _lib.ACT_GELU}
+
+
+def _out_like(x, out, dtype=None, shape=None):
+    if out is None:
+        out = torch.empty(tuple(shape or x.shape), dtype=dtype or x.dtype, device=x.device)
+    return out, _nhwc(out)[4]
 
 
 def conv2d_act(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None, out_dtype=None):
-    """ymk_conv2d with the extended epilogue set: act in ACT_CODES ("gelu" = exact erf GELU, nn.GELU default)."""
+    """ymk_conv2d with the extended epilogue set: act in ACT_CODES ("gelu" = exact erf GELU, nn.GELU default); sigmoid and
+    GELU run as an in-place pass over the convolution's output (ymk_activation)."""
     if act in (False, True, "silu"):
         return conv2d(x, w_packed, bias, k, stride, bool(act), out=out, residual=residual, out_dtype=out_dtype)
     if act not in ACT_CODES:
         raise ValueError(f"unknown activation {act!r}")
-    _not_built(f"conv2d epilogue {act}")
+    _gate(f"conv2d epilogue {act}")
+    if residual is not None:
+        raise NotImplementedError("conv2d_act: sigmoid / gelu epilogues take no residual")
+    y = conv2d(x, w_packed, bias, k, stride, False, out=out, out_dtype=out_dtype)
+    B, H, W, Cc, ld = _nhwc(y)
+    check(lib.ymk_activation(DT[y.dtype], _p(y), ld, B * H * W, Cc, _ACT[act], _stream()), "activation")
+    return y
 
 
 def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, out_dtype=None, affine_rows=None, residual=None):
@@ -434,69 +453,167 @@ def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, ou
     affine_rows int32 [B] choosing the row per image (FusedExpertGroup's per-expert affine, moe/gated.py:1058-1090).
     act in (False, "silu"); residual (same shape) is added after the activation (MoTBlock's out_norm(.) + x,
     mot/block.py:413-417).  x may be a channel slice (C channels of a wider buffer); any C >= 1; out may alias x."""
-    _not_built("group_norm")
+    _gate("group_norm")
+    B, H, W, Cc, ldx = _nhwc(x)
+    out, ldy = _out_like(x, out, out_dtype)
+    ldr = _nhwc(residual)[4] if residual is not None else 0
+    if residual is not None and residual.dtype != out.dtype:
+        raise ValueError("group_norm: the residual has the output's dtype")
+    ws = torch.empty((B * groups * 2,), dtype=torch.float32, device=x.device)
+    check(lib.ymk_group_norm(DT[x.dtype], _p(x), ldx, _p(out), DT[out.dtype], ldy, _p(residual), ldr, B, H * W, Cc, groups,
+                             _p(weight), _p(bias), _p(affine_rows), float(eps), _ACT[act], _p(ws), _stream()), "group_norm")
+    return out
 
 
 def layer_norm(x, weight, bias, eps: float, out=None):
     """LayerNorm over the channel vector of every token (torch.nn.LayerNorm(C)), fp32 statistics."""
-    _not_built("layer_norm")
+    _gate("layer_norm")
+    B, H, W, Cc, ldx = _nhwc(x)
+    out, ldy = _out_like(x, out)
+    check(lib.ymk_layer_norm(DT[x.dtype], _p(x), ldx, _p(out), ldy, B * H * W, Cc, _p(weight), _p(bias), float(eps), _stream()),
+          "layer_norm")
+    return out
+
+
+def _eltwise(op, a, b, alpha, out, what):
+    B, H, W, Cc, lda = _nhwc(a)
+    ldb = _nhwc(b)[4]
+    if a.dtype != b.dtype or a.shape != b.shape:
+        raise ValueError(f"{what}: operands must agree in shape and dtype")
+    out, ldy = _out_like(a, out)
+    check(lib.ymk_eltwise(op, DT[a.dtype], _p(a), lda, _p(b), ldb, _p(out), ldy, B * H * W, Cc, float(alpha), _stream()), what)
+    return out
 
 
 def eltwise_mul(a, b, out=None, act_a=None):
     """out = act_a(a) * b, same shapes; act_a in (None, "sigmoid") (GLU of the MoT local expert: sigmoid(gate) * value,
     mot/experts.py:160-166)."""
-    _not_built("eltwise_mul")
+    _gate("eltwise_mul")
+    if act_a not in (None, "sigmoid"):
+        raise ValueError(act_a)
+    return _eltwise(_lib.ELT_SIGMOID_MUL if act_a else _lib.ELT_MUL, a, b, 0.0, out, "eltwise_mul")
 
 
 def lerp(a, b, alpha: float, out=None):
     """out = (1 - alpha) * a + alpha * b (exact / linear attention blend, moa/heads.py:366-374)."""
-    _not_built("lerp")
+    _gate("lerp")
+    return _eltwise(_lib.ELT_LERP, a, b, alpha, out, "lerp")
 
 
 def fma_gate(x, a, b, scale, out=None):
-    """out = x + scale * a * b with scale a host float; b is a map [B,H,W,C] or a per-image channel gate [B,1,1,C]
+    """out = x + scale * a * b with scale a host float; b is a map [B,H,W,C] or a per-image channel gate [B,1,1,C] fp32
     (detail gate x*(1+s*g), context mixer x+s*c*gate, refinement x+s*r*g: moe/gated.py:1171-1218, hooks.py:60-68)."""
-    _not_built("fma_gate")
+    _gate("fma_gate")
+    B, H, W, Cc, ldx = _nhwc(x)
+    lda = _nhwc(a)[4]
+    per_image = tuple(b.shape) == (B, 1, 1, Cc) and (H, W) != (1, 1)
+    if per_image:
+        if b.dtype != torch.float32 or not b.is_contiguous():
+            raise ValueError("fma_gate: a per-image gate is a contiguous fp32 [B,1,1,C] tensor")
+        ldb = Cc
+    else:
+        ldb = _nhwc(b)[4]
+    out, ldy = _out_like(x, out)
+    check(lib.ymk_fma_gate(DT[x.dtype], _p(x), ldx, _p(a), lda, _p(b), DT[b.dtype], ldb, int(per_image), float(scale), _p(out), ldy,
+                           B, H * W, Cc, _stream()), "fma_gate")
+    return out
 
 
 def channel_gate(x, gate, out=None):
     """out = x * gate with gate fp32 [B,1,1,C] (squeeze-excite gate of the gated MoE, moe/gated.py:333-341)."""
-    _not_built("channel_gate")
+    _gate("channel_gate")
+    B, H, W, Cc, ldx = _nhwc(x)
+    if gate.dtype != torch.float32 or tuple(gate.shape) != (B, 1, 1, Cc) or not gate.is_contiguous():
+        raise ValueError("channel_gate: gate is a contiguous fp32 [B,1,1,C] tensor")
+    out, ldy = _out_like(x, out)
+    check(lib.ymk_channel_gate(DT[x.dtype], _p(x), ldx, _p(gate), _p(out), ldy, B, H * W, Cc, _stream()), "channel_gate")
+    return out
 
 
 def weighted_sum(weights, parts, out=None):
     """out = sum_e weights[..., e] * parts[e]; weights fp32 [B,H,W,>=E] per token or [B,1,1,>=E] per image
     (MoA head mix moa/block.py:230-262, MoT expert blend mot/block.py:360-417, gated expert mix)."""
-    _not_built("weighted_sum")
+    _gate("weighted_sum")
+    B, H, W, Cc, ldp = _nhwc(parts[0])
+    E = len(parts)
+    if not 1 <= E <= 4 or any(_nhwc(p_)[4] != ldp or p_.dtype != parts[0].dtype or p_.shape != parts[0].shape for p_ in parts):
+        raise ValueError("weighted_sum: 1..4 parts of one shape, dtype and pixel stride")
+    per_image = tuple(weights.shape[:3]) == (B, 1, 1) and (H, W) != (1, 1)
+    if weights.dtype != torch.float32 or weights.stride(3) != 1:
+        raise ValueError("weighted_sum: fp32 weights")
+    ldw = weights.stride(0) if per_image else _nhwc(weights)[4]
+    out, ldy = _out_like(parts[0], out)
+    ptrs = [_p(p_) for p_ in parts] + [None] * (4 - E)
+    check(lib.ymk_weighted_sum(DT[parts[0].dtype], _p(weights), ldw, int(per_image), E, *ptrs, ldp, _p(out), ldy, B, H * W, Cc,
+                               _stream()), "weighted_sum")
+    return out
 
 
 def mean_upsampled(parts, out=None):
     """out = mean_i nearest_resize(parts[i] -> size of parts[0]) (F.interpolate mode="nearest": src = floor(dst * h / H));
     PyramidContextMixer.forward moe/gated.py:1209-1216."""
-    _not_built("mean_upsampled")
+    _gate("mean_upsampled")
+    B, H, W, Cc, _ = _nhwc(parts[0])
+    n = len(parts)
+    if not 1 <= n <= 4:
+        raise ValueError("mean_upsampled: 1..4 parts")
+    geo = [_nhwc(p_) for p_ in parts]
+    arr = lambda vals: (C.c_int32 * n)(*vals)   # noqa: E731
+    out, ldy = _out_like(parts[0], out)
+    ptrs = [_p(p_) for p_ in parts] + [None] * (4 - n)
+    check(lib.ymk_mean_upsampled(DT[parts[0].dtype], n, *ptrs, arr([g[1] for g in geo]), arr([g[2] for g in geo]),
+                                 arr([g[4] for g in geo]), _p(out), ldy, B, H, W, Cc, _stream()), "mean_upsampled")
+    return out
 
 
 def adaptive_avg_pool(x, Ho: int, Wo: int, out=None, out_dtype=None):
     """F.adaptive_avg_pool2d bins: rows [floor(i*H/Ho), ceil((i+1)*H/Ho))."""
-    _not_built("adaptive_avg_pool")
+    _gate("adaptive_avg_pool")
+    B, H, W, Cc, ldx = _nhwc(x)
+    out, ldy = _out_like(x, out, out_dtype, (B, Ho, Wo, Cc))
+    check(lib.ymk_adaptive_avg_pool(DT[x.dtype], _p(x), ldx, _p(out), DT[out.dtype], ldy, B, H, W, Cc, Ho, Wo, _stream()),
+          "adaptive_avg_pool")
+    return out
 
 
 def avg_pool(x, k: int, out=None, out_dtype=None):
     """F.avg_pool2d(kernel_size=k, stride=k): floor(H/k) x floor(W/k) outputs, remainder rows/columns dropped."""
-    _not_built("avg_pool")
+    _gate("avg_pool")
+    B, H, W, Cc, ldx = _nhwc(x)
+    out, ldy = _out_like(x, out, out_dtype, (B, H // k, W // k, Cc))
+    check(lib.ymk_avg_pool(DT[x.dtype], _p(x), ldx, _p(out), DT[out.dtype], ldy, B, H, W, Cc, k, _stream()), "avg_pool")
+    return out
 
 
 def channel_stats(x, want_std: bool = False):
     """Per image and channel mean (and biased std) over H*W in fp32: returns [B,1,1,C] (or [B,1,1,2C] = [mean | std],
     DualStreamGateRouter's global stream moe/gated.py:133-139)."""
-    _not_built("channel_stats")
+    _gate("channel_stats")
+    B, H, W, Cc, ldx = _nhwc(x)
+    out = torch.empty((B, 1, 1, 2 * Cc if want_std else Cc), dtype=torch.float32, device=x.device)
+    check(lib.ymk_channel_stats(DT[x.dtype], _p(x), ldx, _p(out), B, H * W, Cc, int(want_std), _stream()), "channel_stats")
+    return out
+
+
+def _qkv_geometry(q, k, v, heads, hd, what):
+    B, Hq, Wq, Cq, ldq = _nhwc(q)
+    Bk, Hk, Wk, Ck, ldk = _nhwc(k)
+    ldv = _nhwc(v)[4]
+    if Cq != heads * hd or Ck != Cq or v.shape != k.shape or Bk != B or not (q.dtype == k.dtype == v.dtype):
+        raise ValueError(f"{what}: q [B,Hq,Wq,heads*hd], k / v [B,Hk,Wk,heads*hd] of one dtype")
+    return B, Hq, Wq, Hk, Wk, ldq, ldk, ldv
 
 
 def attention(q, k, v, heads: int, hd: int, scale: float, out=None):
     """softmax(q k^T * scale) v per (image, head).  q [B,Hq,Wq,heads*hd], k/v [B,Hk,Wk,heads*hd] channel-slice views
     (tokens row-major); any hd that is a multiple of 8.  MoA regional / global-exact heads (moa/heads.py:208-253,
     354-365), MoT local expert (mot/experts.py:150-156)."""
-    _not_built("attention")
+    _gate("attention")
+    B, Hq, Wq, Hk, Wk, ldq, ldk, ldv = _qkv_geometry(q, k, v, heads, hd, "attention")
+    out, ldo = _out_like(q, out)
+    check(lib.ymk_attention(DT[q.dtype], _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, Hq * Wq, Hk * Wk, heads, hd,
+                            float(scale), _stream()), "attention")
+    return out
 
 
 def window_attention(q, k, v, heads: int, hd: int, scale: float, win: int, shift: int = 0, pad_q=None, pad_k=None,
@@ -505,27 +622,62 @@ def window_attention(q, k, v, heads: int, hd: int, scale: float, win: int, shift
     carry the fp32 vectors pad_q / pad_k / pad_v [heads*hd] (None = zeros) and take part as keys; with shift > 0 the
     padded grid is rolled by -shift in both axes before the partition and rolled back after (no mask).
     moa/heads.py:83-117, mot/experts.py:237-325."""
-    _not_built("window_attention")
+    _gate("window_attention")
+    B, H, W, Hk, Wk, ldq, ldk, ldv = _qkv_geometry(q, k, v, heads, hd, "window_attention")
+    if (Hk, Wk) != (H, W):
+        raise ValueError("window_attention: q, k, v live on one map")
+    for t in (pad_q, pad_k, pad_v):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != heads * hd or not t.is_contiguous()):
+            raise ValueError("window_attention: pad vectors are contiguous fp32 [heads*hd]")
+    out, ldo = _out_like(q, out)
+    check(lib.ymk_window_attention(DT[q.dtype], _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, H, W, heads, hd, float(scale),
+                                   win, shift, _p(pad_q), _p(pad_k), _p(pad_v), _stream()), "window_attention")
+    return out
 
 
 def linear_attention(q, k, v, rf, heads: int, hd: int, out=None):
     """ReLU random-feature attention of _GlobalAttnHead._linear_attn (moa/heads.py:318-352), fp32 math:
     phi(t) = min(relu(t rf^T / sqrt(nb)) + 1e-6, 1e4); out = clamp(phi(q) (phi(k)^T v), +-1e4) / max(phi(q) sum phi(k), 1e-6)."""
-    _not_built("linear_attention")
+    _gate("linear_attention")
+    B, H, W, Hk, Wk, ldq, ldk, ldv = _qkv_geometry(q, k, v, heads, hd, "linear_attention")
+    if (Hk, Wk) != (H, W) or rf.dtype != torch.float32 or rf.shape[1] != hd or not rf.is_contiguous():
+        raise ValueError("linear_attention: q, k, v on one map; rf a contiguous fp32 [nb, hd] matrix")
+    nb = rf.shape[0]
+    out, ldo = _out_like(q, out)
+    ws = torch.empty((B * heads * (nb * hd + nb),), dtype=torch.float32, device=q.device)
+    check(lib.ymk_linear_attention(DT[q.dtype], _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(rf), nb, _p(out), ldo, B, H * W, heads, hd,
+                                   _p(ws), _stream()), "linear_attention")
+    return out
 
 
 def deform_attention(v, off_logits, aw_logits, heads: int, hd: int, n_points: int, align_corners: bool, out=None):
     """_DeformableTransformerExpert._deform_attn (mot/experts.py:381-459): per token and head, locations =
     clamp(ref + 0.25 * tanh(off_logits), -1, 1) around the token's own normalised position, weights = softmax over the
     points of aw_logits, bilinear samples of v's head slice (zeros padding), weighted sum.  Coordinates fp32."""
-    _not_built("deform_attention")
+    _gate("deform_attention")
+    B, H, W, Cc, ldv = _nhwc(v)
+    if off_logits.dtype != torch.float32 or aw_logits.dtype != torch.float32 or Cc != heads * hd:
+        raise ValueError("deform_attention: fp32 offsets / weights, v [B,H,W,heads*hd]")
+    ldoff, ldaw = _nhwc(off_logits)[4], _nhwc(aw_logits)[4]
+    out, ldo = _out_like(v, out)
+    check(lib.ymk_deform_attention(DT[v.dtype], _p(v), ldv, _p(off_logits), ldoff, _p(aw_logits), ldaw, _p(out), ldo, B, H, W, heads,
+                                   hd, n_points, int(bool(align_corners)), _stream()), "deform_attention")
+    return out
 
 
 def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None):
     """Per-token softmax over the first n channels of fp32 logits scaled by inv_temp; with 0 < top_k < n the top_k
     largest are kept and renormalised (sum clamped at 1e-6), the rest set to 0 (mot/router.py:243-295, moa/router.py:50-62).
     Returns (weights fp32 [B,H,W,n], active int32 [B,n] = 1 where any token of the image gives expert e a nonzero weight)."""
-    _not_built("token_softmax")
+    _gate("token_softmax")
+    B, H, W, Cc, ldl = _nhwc(logits)
+    if logits.dtype != torch.float32 or Cc < n:
+        raise ValueError("token_softmax: fp32 logits with at least n channels")
+    out, ldw = _out_like(logits, out, torch.float32, (B, H, W, n))
+    active = torch.zeros((B, n), dtype=torch.int32, device=logits.device)
+    check(lib.ymk_token_softmax(_p(logits), ldl, _p(out), ldw, _p(active), B, H * W, n, float(inv_temp), int(top_k), _stream()),
+          "token_softmax")
+    return out, active
 
 
 def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_k: int, cplx_logit):
@@ -533,7 +685,19 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
     a = sigmoid(alpha); probs = softmax(logits * inv_temp); top-k, weights / (sum + 1e-6); complexity = clamp(mean_b
     sigmoid(cplx_logit[b]), 0.3, 1.5) (1.0 when non-finite) keeps round(c * top_k) in [1, top_k] ranked experts and
     renormalises (clamp 1e-6).  Inputs fp32 [B,1,1,E] / [B,1,1,1]; returns (w fp32 [B,1,1,top_k], idx int32 [B,top_k], probs)."""
-    _not_built("gated_route_decide")
+    _gate("gated_route_decide")
+    B, E = g_logits.shape[0], g_logits.shape[-1]
+    for t in (g_logits, loc_logits, cplx_logit):
+        if t.dtype != torch.float32 or t.shape[0] != B or t.shape[1:3] != (1, 1) or t.stride(3) != 1:
+            raise ValueError("gated_route_decide: fp32 [B,1,1,*] inputs")
+    dev = g_logits.device
+    w = torch.empty((B, 1, 1, top_k), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, top_k), dtype=torch.int32, device=dev)
+    probs = torch.empty((B, E), dtype=torch.float32, device=dev)
+    check(lib.ymk_gated_route_decide(_p(g_logits), g_logits.stride(0), _p(loc_logits), loc_logits.stride(0), _p(cplx_logit),
+                                     cplx_logit.stride(0), B, E, float(alpha), float(inv_temp), int(top_k), _p(w), _p(idx), _p(probs),
+                                     _stream()), "gated_route_decide")
+    return w, idx, probs
 
 
 def expert_conv(x, w_packed, k: int, idx, out=None):
@@ -541,11 +705,36 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
     out[j*B:(j+1)*B] is the batch of slot j, a contiguous NHWC tensor);
     w_packed [E][Cout][Kpad] in the compute dtype, idx int32 [B][K].  The selected slices of FusedExpertGroup's grouped
     3x3 (moe/gated.py:1058-1076; grouped weights expanded to dense rows at pack time) and the expert projections of
-    SharedInvertedExpertGroup (moe/experts.py:235-269)."""
-    _not_built("expert_conv")
+    SharedInvertedExpertGroup (moe/experts.py:235-269).  First implementation: ALL experts' rows run as one ymk_conv2d
+    (what the reference's fused convolution does) and the routed slices are gathered; the grouped-GEMM machinery of the
+    ES-MoE stage (resident expert weights, only routed rows) replaces it once parity holds."""
+    _gate("expert_conv")
+    B, H, W, Cin, _ = _nhwc(x)
+    E, Cout, Kp = w_packed.shape
+    K = idx.shape[1]
+    if idx.dtype != torch.int32 or tuple(idx.shape) != (B, K) or not idx.is_contiguous():
+        raise ValueError("expert_conv: idx is a contiguous int32 [B, K] tensor")
+    zero_b = torch.zeros((E * Cout,), dtype=torch.float32, device=x.device)
+    f_all = conv2d(x, w_packed.reshape(E * Cout, Kp), zero_b, k, 1, False)
+    if out is None:
+        out = torch.empty((K * B, H, W, Cout), dtype=x.dtype, device=x.device)
+    if not out.is_contiguous():
+        raise ValueError("expert_conv: dense output")
+    check(lib.ymk_expert_gather(DT[x.dtype], _p(f_all), _nhwc(f_all)[4], _p(idx), B, H * W, Cout, K, E, _p(out), _stream()),
+          "expert_gather")
+    return out
 
 
 def channel_shuffle_cat(parts, groups: int, out=None):
     """Channel concatenation followed by _channel_shuffle (moe/gated.py:1333-1338) in one pass:
     out[..., j * groups + i] = cat(parts)[..., i * (C / groups) + j]."""
-    _not_built("channel_shuffle_cat")
+    _gate("channel_shuffle_cat")
+    if len(parts) != 2 or parts[0].dtype != parts[1].dtype or parts[0].shape[:3] != parts[1].shape[:3]:
+        raise ValueError("channel_shuffle_cat: two maps of one size and dtype")
+    a, b = parts
+    B, H, W, Ca, lda = _nhwc(a)
+    Cb, ldb = b.shape[-1], _nhwc(b)[4]
+    out, ldy = _out_like(a, out, None, (B, H, W, Ca + Cb))
+    check(lib.ymk_channel_shuffle_cat(DT[a.dtype], _p(a), lda, Ca, _p(b), ldb, Cb, groups, _p(out), ldy, B * H * W, _stream()),
+          "channel_shuffle_cat")
+    return out

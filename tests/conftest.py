@@ -33,6 +33,21 @@ def golden_dir():
     return ROOT / "tests" / "golden"
 
 
+@pytest.fixture
+def emu(monkeypatch):
+    """Install the torch restatement of the libymk entry points (tests/emu_ops.py) over `yolo_master_amd.ops` and lift
+    the device guard, so that the product's HOST code can be driven end to end on the CPU.  Test infrastructure only."""
+    from tests import emu_ops
+    from yolo_master_amd import ops
+
+    for name in emu_ops.EMULATED:
+        assert hasattr(ops, name), f"ops.{name} disappeared: update tests/emu_ops.py"
+        monkeypatch.setattr(ops, name, getattr(emu_ops, name))
+    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
+    emu_ops.CALLS.clear()
+    return emu_ops
+
+
 def pytest_runtest_logreport(report):
     """Append every failure (test id + traceback) to $YMK_TEST_FAILURE_LOG when set: lets a rare flake in a long
     unattended loop be identified afterwards."""

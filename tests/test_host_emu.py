@@ -10,20 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests import emu_ops
 from tests.helpers import load_npz
-
-
-@pytest.fixture
-def emu(monkeypatch):
-    from yolo_master_amd import ops
-
-    for name in emu_ops.EMULATED:
-        assert hasattr(ops, name), f"ops.{name} disappeared: update tests/emu_ops.py"
-        monkeypatch.setattr(ops, name, getattr(emu_ops, name))
-    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
-    emu_ops.CALLS.clear()
-    return emu_ops
 
 
 def _model(scale, dtype=torch.float32, cfg=None):

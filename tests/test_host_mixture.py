@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 import torch
 
-from tests.test_host_emu import emu  # noqa: F401  (fixture)
 
 
 def _load(golden_dir, fam, name):

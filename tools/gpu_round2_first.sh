@@ -1,0 +1,13 @@
+#!/bin/bash
+# First GPU call of the next round, in one box: (1) the validated suite still green, (2) first hardware run of the
+# config-5 kernels, (3) the GEMM design probes, (4) a bench line.  Usage (from the build container):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round2_first.sh r02'
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+mkdir -p gpurun_out
+timeout -k 10 420 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_suite.log 2>&1; echo "gpu suite exit $?"; tail -3 gpurun_out/${TAG}_gpu_suite.log
+bash tools/gpu_cfg5.sh $TAG | tail -15
+bash tools/gpu_probe.sh $TAG | tail -60
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench exit $?"; cat gpurun_out/${TAG}_bench.json

@@ -68,8 +68,20 @@ def case(name, module, oracle_fn, x, seed):
     np.savez_compressed(HERE / f"moa_{name}.npz", **rec)
 
 
+def extra_cases():
+    """Cases added after the first fixture set; each has its own generator so that re-running never touches the others.
+    `python tests/golden/make_golden_moa.py extra`."""
+    g2 = torch.Generator().manual_seed(2024)
+    # the block of BASELINE config 5 (L scale): c = 128, 6 heads -> head_dim = 21 (not a multiple of 8), 2 heads per group
+    m = MoABlock(128, num_heads=6)
+    case("hd21", m, lambda sd, xx, info: moa_ref.moa_block(sd, "m", xx, 6, info=info), torch.randn(2, 128, 9, 13, generator=g2), 7)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra_cases()
+        raise SystemExit
     g = torch.Generator().manual_seed(123)
 
     def blk(x, seed, name, **kw):

@@ -196,6 +196,7 @@ def _prep(mod, sd):
     ("moa", "linear", ("MoABlock", (48,), dict(num_heads=6))),
     ("moa", "kvcap", ("MoABlock", (48,), dict(num_heads=6, regional_max_kv_tokens=64, shortcut=False))),
     ("moa", "c2f", ("C2fMoA", (64, 96), dict(n=2, num_heads=6))),
+    ("moa", "hd21", ("MoABlock", (128,), dict(num_heads=6))),       # BASELINE config 5 (L scale): head_dim 21 padded to 24
     ("mot", "top2", ("MoTBlock", (48,), dict(num_heads=6))),
     ("mot", "shift", ("MoTBlock", (48,), dict(num_heads=6, window_shift=True, local_attn_window=7))),
     ("mot", "top1", ("MoTBlock", (48,), dict(num_heads=6, top_k=1))), ("mot", "dense", ("MoTBlock", (48,), dict(num_heads=6, top_k=3))),

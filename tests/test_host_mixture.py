@@ -29,7 +29,8 @@ def _close(got, ref, what, rtol=2e-5):
     assert err <= rtol * max(1.0, float(ref.abs().max())), f"{what}: max |d| = {err:.3e} (|ref| max {float(ref.abs().max()):.3f})"
 
 
-MOA_CASES = {"exact": {}, "blend": {}, "linear": {}, "kvcap": dict(regional_max_kv_tokens=64, shortcut=False)}
+MOA_CASES = {"exact": {}, "blend": {}, "linear": {}, "kvcap": dict(regional_max_kv_tokens=64, shortcut=False),
+             "hd21": dict(dim=128)}     # BASELINE config 5 (L scale): head_dim 21, padded to 24 channels per head
 
 
 @pytest.mark.parametrize("name", list(MOA_CASES))
@@ -37,7 +38,8 @@ def test_moa_block_host_vs_reference(name, golden_dir, emu):
     from yolo_master_amd.nn.mixture import MoABlock
 
     z, sd = _load(golden_dir, "moa", name)
-    m = _prep(MoABlock(48, num_heads=6, **MOA_CASES[name]), sd)
+    kw = dict(MOA_CASES[name])
+    m = _prep(MoABlock(kw.pop("dim", 48), num_heads=6, **kw), sd)
     x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
     with torch.inference_mode():
         got = m(x)
@@ -232,3 +234,46 @@ def test_config5_model_bf16_operand_rules(golden_dir, emu):
     # name-seeded weights: uncalibrated scores around 0.5 and per-token top-k routing that flips under bf16 rounding, so
     # only a loose bound is meaningful here (the calibrated drift test of the detector lives in test_gpu_model.py)
     assert float(d.median()) < 5e-2, f"median class-score drift {float(d.median()):.3e}"
+
+
+def test_config5_L_scale_host_vs_oracle(emu):
+    """BASELINE config 5 is the moa-mot YAML at the L scale (width 1.0, depth 1.0: 51.7 M parameters; MoA head_dim 21,
+    16-expert shared-inverted block, 256-wide MoT blocks with four repeats).  No reference fixture of that size is
+    committed, so the product's host path (emulated entry points) is compared with the oracle — itself pinned bit-exact
+    against the real reference on every module family and on the n-scale model — layer by layer, in fp32; the bf16 pass
+    checks that every operand still satisfies the kernels' channel-vector rules at these widths."""
+    import copy
+
+    import yaml
+
+    from oracle import model_ref
+    from tests.helpers import fill_by_name
+    from yolo_master_amd import ops
+    from yolo_master_amd.nn.tasks import CFG_DIR, DetectionModel
+
+    d = yaml.safe_load(open(CFG_DIR / "yolo-master-moa-mot.yaml"))
+    d["scales"]["l"] = [1.0, 1.0, 512]
+    d["scale"] = "l"
+    m = DetectionModel(copy.deepcopy(d))
+    assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 51.7) < 0.1
+    assert m.model[17].m[0].local_head.head_dim == 21 and m.model[11].expert_backend == "shared_inverted"
+    spec = {k: list(v.shape) for k, v in m.state_dict().items() if v.is_floating_point() and v.dim() > 0 and not k.endswith("_rf_matrix")}
+    full = dict(m.state_dict())
+    full.update(fill_by_name(spec, seed=9, gain=0.7))     # gain < 1: keeps the 16-block residual chains well conditioned
+    m.load_state_dict(full)
+    m.eval()
+    x = torch.rand(1, 3, 160, 128, generator=torch.Generator().manual_seed(1))
+    taps, otaps = {}, {}
+    with torch.inference_mode():
+        y, _ = m._predict_once(x, taps=taps)
+        oy, _, _ = model_ref.forward(copy.deepcopy(d), dict(m.state_dict()), x, fused=False, taps=otaps)
+    for i in range(len(m.model) - 1):
+        t = taps[i] if torch.is_tensor(taps[i]) else taps[i].materialise()
+        ref = otaps[i]
+        err = float((ops.nhwc_to_nchw_f32(t) - ref).abs().max() / max(1.0, float(ref.abs().max())))
+        assert err <= 1e-4, f"layer {i} ({type(m.model[i]).__name__}): scaled max error {err:.3e}"
+    assert float((y[:, 4:] - oy[:, 4:]).abs().max()) <= 1e-5
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.inference_mode():
+        yb, _ = m._predict_once(x)
+    assert bool(torch.isfinite(yb).all())

@@ -46,10 +46,33 @@ def _ceil(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-def _pack_conv(conv, dtype, device, pad_cout_to=None, pad_cin_to=None, scale=None):
+def _head_map(nh: int, hd: int, hdp: int, parts: int = 1):
+    """Channel map for [part][head][hd] -> [part][head][hdp]: source index per destination channel, -1 = zero padding."""
+    m = []
+    for part in range(parts):
+        for h in range(nh):
+            m += [part * nh * hd + h * hd + d for d in range(hd)] + [-1] * (hdp - hd)
+    return m
+
+
+def _remap(w, cmap, dim: int):
+    """Gather channels of `w` along `dim` by `cmap` (source index or -1 for a zero channel)."""
+    if cmap is None:
+        return w
+    shape = list(w.shape)
+    shape[dim] = len(cmap)
+    out = w.new_zeros(shape)
+    dst = torch.tensor([i for i, c in enumerate(cmap) if c >= 0], device=w.device)
+    src = torch.tensor([c for c in cmap if c >= 0], device=w.device)
+    out.index_copy_(dim, dst, w.index_select(dim, src))
+    return out
+
+
+def _pack_conv(conv, dtype, device, pad_cout_to=None, pad_cin_to=None, scale=None, rows=None, cols=None):
     """Bare nn.Conv2d (groups 1) or nn.Linear -> ([Cout][Kpad] in `dtype`, fp32 bias).  Zero padding of output / input
-    channels keeps every operand inside the kernels' vector-width rules; `scale` [Cout] folds a per-channel factor
-    (layer scale without a residual) into weights and bias."""
+    channels keeps every operand inside the kernels' vector-width rules (`rows` / `cols`: channel maps with -1 for a zero
+    channel, e.g. attention heads padded to a multiple of 8); `scale` [Cout] folds a per-channel factor (layer scale
+    without a residual) into weights and bias."""
     w = conv.weight.detach().float().to(device)
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -59,6 +82,7 @@ def _pack_conv(conv, dtype, device, pad_cout_to=None, pad_cin_to=None, scale=Non
     if scale is not None:
         sc = scale.detach().float().reshape(-1).to(device)
         w, b = w * sc.view(-1, 1, 1, 1), b * sc
+    w, b = _remap(_remap(w, rows, 0), cols, 1), _remap(b, rows, 0)
     if pad_cout_to is not None and pad_cout_to > w.shape[0]:
         extra = pad_cout_to - w.shape[0]
         w = torch.cat([w, w.new_zeros((extra, *w.shape[1:]))], 0)
@@ -68,10 +92,10 @@ def _pack_conv(conv, dtype, device, pad_cout_to=None, pad_cin_to=None, scale=Non
     return ops.pack_conv_weight(w, dtype), b.contiguous()
 
 
-def _pack_dw(conv, dtype, device):
+def _pack_dw(conv, dtype, device, chans=None):
     if conv.groups != conv.in_channels or conv.in_channels != conv.out_channels or conv.bias is not None:
         raise NotImplementedError("_pack_dw: bias-free depthwise convolutions only")
-    return ops.pack_dw_weight(conv.weight.detach().float().to(device), dtype)
+    return ops.pack_dw_weight(_remap(conv.weight.detach().float().to(device), chans, 0), dtype)
 
 
 def _pack_norm(norm, device):
@@ -437,9 +461,12 @@ class MoABlock(YmkModule):
 
     def _pack(self, dtype, device):
         f32 = torch.float32
-        hd = self.local_head.head_dim
-        if hd % 8:
-            raise NotImplementedError(f"ymk MoABlock: head_dim {hd} is not a multiple of 8")
+        # head_dim = max(dim // num_heads, 16) need not be a multiple of the 16-byte channel vector (21 at the L scale of
+        # BASELINE config 5): every head is zero-padded to hdp channels in the packed q / k / v / pe / proj weights and in
+        # the random-feature basis, which changes no dot product and leaves the padded output channels at zero
+        nh, hd = self.local_head.num_heads, self.local_head.head_dim
+        hdp = _ceil(hd, 8)
+        m1, m2, m3 = (None, None, None) if hdp == hd else (_head_map(nh, hd, hdp, 1), _head_map(nh, hd, hdp, 2), _head_map(nh, hd, hdp, 3))
         r = self.router.router
         hid = r[0].out_channels
         hp = _ceil(hid, 4)
@@ -448,12 +475,15 @@ class MoABlock(YmkModule):
             # router: first 1x1 reads the block input (compute dtype) and writes fp32; the rest stays fp32 (router.py:55-61)
             "r0": _pack_conv(r[0], dtype, device, pad_cout_to=hp), "r1": _pack_norm(r[1], device), "r_hid": hid, "r_hp": hp,
             "r3": _pack_conv(r[3], f32, device, pad_cout_to=4, pad_cin_to=hp),
-            "l_dw": _pack_dw(lh.qkv_dw, dtype, device), "l_qkv": _pack_conv(lh.qkv_pw, dtype, device),
-            "l_pe": _pack_dw(lh.pe, dtype, device), "l_proj": _pack_conv(lh.proj, dtype, device), "l_norm": _pack_norm(lh.norm, device),
-            "g_q": _pack_conv(rh.q_proj, dtype, device), "g_kv": _pack_conv(rh.kv_proj, dtype, device),
-            "g_proj": _pack_conv(rh.proj, dtype, device), "g_norm": _pack_norm(rh.norm, device),
-            "a_qkv": _pack_conv(gh.qkv, dtype, device), "a_proj": _pack_conv(gh.proj, dtype, device),
-            "a_norm": _pack_norm(gh.norm, device), "rf": gh._rf_matrix.detach().float().to(device).contiguous(),
+            "hdp": hdp,
+            "l_dw": _pack_dw(lh.qkv_dw, dtype, device), "l_qkv": _pack_conv(lh.qkv_pw, dtype, device, rows=m3),
+            "l_pe": _pack_dw(lh.pe, dtype, device, chans=m1), "l_proj": _pack_conv(lh.proj, dtype, device, cols=m1),
+            "l_norm": _pack_norm(lh.norm, device),
+            "g_q": _pack_conv(rh.q_proj, dtype, device, rows=m1), "g_kv": _pack_conv(rh.kv_proj, dtype, device, rows=m2),
+            "g_proj": _pack_conv(rh.proj, dtype, device, cols=m1), "g_norm": _pack_norm(rh.norm, device),
+            "a_qkv": _pack_conv(gh.qkv, dtype, device, rows=m3), "a_proj": _pack_conv(gh.proj, dtype, device, cols=m1),
+            "a_norm": _pack_norm(gh.norm, device),
+            "rf": _remap(gh._rf_matrix.detach().float().to(device), None if hdp == hd else list(range(hd)) + [-1] * (hdp - hd), 1).contiguous(),
             "ls_attn": self.ls_attn.detach().float().reshape(-1).to(device).contiguous(),
             "ls_ffn": self.ls_ffn.detach().float().reshape(-1).to(device).contiguous(),
         }
@@ -480,8 +510,9 @@ class MoABlock(YmkModule):
         B, H, W, C = x.shape
         pk = self._packed(x.device)
         lh, rh = self.local_head, self.region_head
-        nh, hd = lh.num_heads, lh.head_dim
-        inner, scale = nh * hd, hd ** -0.5
+        nh, scale = lh.num_heads, lh.head_dim ** -0.5      # the softmax scale is the TRUE head_dim's
+        hd = pk["hdp"]                                      # kernels see heads padded to a multiple of 8 channels
+        inner = nh * hd
         probs = self._route(x, pk)
         self.last_route = {"weights": probs}
         # local head (moa/heads.py:143-163): DW3x3 -> 1x1 qkv, v += DW7x7(v), 7x7-window attention
@@ -731,6 +762,10 @@ class MoTBlock(YmkModule):
         r = self.router.router
         hid = r[0].out_channels
         hp = _ceil(hid, 4)
+        dim, nh = r[0].in_channels, self.experts[0].num_heads
+        if (dim // nh) % 8:
+            raise NotImplementedError(f"ymk MoTBlock: head_dim {dim // nh} is not a multiple of 8 (C2fMoT keeps head_dim >= 8 and "
+                                      "dividing the width; widths that are multiples of 64 always qualify)")
         return {"r0": _pack_conv(r[0], dtype, device, pad_cout_to=hp), "r1": _pack_norm(r[1], device), "r_hid": hid, "r_hp": hp,
                 "r3": _pack_conv(r[3], torch.float32, device, pad_cout_to=4, pad_cin_to=hp),
                 "inv_temp": 1.0 / float(self.router.temperature),

@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE — compile the config-5 kernel sources for the HOST (tests/hostemu/hip/hip_runtime.h: every GPU lane
+a fiber) into tests/hostemu/_build/libymk_hostemu.so, exporting the same `extern "C"` entry points as libymk.
+
+The sources are used as they are, with two textual rewrites the host compiler needs: `extern __shared__ T name[]` -> a pointer
+to one global array (dynamic LDS) and `__shared__` -> `static` (workgroups run one after another, so function-static
+storage is exactly workgroup-shared storage).  Grid-stride kernels are launched with at most 2 workgroups
+(-DYMK_MAX_BLOCKS=2: same code, each lane just walks more elements) to keep the number of fiber set-ups small."""
+from __future__ import annotations
+
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+CSRC = ROOT / "yolo_master_amd" / "csrc"
+OUT = HERE / "_build"
+SOURCES = ["mixture.hip", "mixattn.hip"]
+
+
+def compiler():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if c and Path(c).exists():
+            return c
+    return None
+
+
+def build(force: bool = False) -> Path | None:
+    cxx = compiler()
+    if cxx is None:
+        return None
+    OUT.mkdir(exist_ok=True)
+    lib = OUT / "libymk_hostemu.so"
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + [CSRC / "ymk_common.h", ROOT / "include" / "ymk_mixture.h", HERE / "hip" / "hip_runtime.h", Path(__file__)]
+    if not force and lib.exists() and lib.stat().st_mtime >= max(d.stat().st_mtime for d in deps):
+        return lib
+    units = []
+    for s in srcs:
+        txt = s.read_text()
+        txt = re.sub(r"\bextern\s+__shared__\s+(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(hostemu::dyn_lds);", txt)
+        txt = re.sub(r"\b__shared__\b", "static", txt)
+        txt = txt.replace('#include "ymk_common.h"', f'#include "{CSRC / "ymk_common.h"}"')
+        txt = txt.replace('#include "../../include/ymk_mixture.h"', f'#include "{ROOT / "include" / "ymk_mixture.h"}"')
+        u = OUT / (s.stem + "_host.cpp")
+        u.write_text(txt)
+        units.append(str(u))
+    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", f"-I{HERE}", *units, "-o", str(lib)]
+    subprocess.run(cmd, check=True)
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,115 @@
+// TEST INFRASTRUCTURE — a host stand-in for <hip/hip_runtime.h>, just large enough to compile the config-5 kernel
+// sources (csrc/mixture.hip, csrc/mixattn.hip) for the CPU and run them lane by lane: workgroups run one after another,
+// the lanes of a workgroup are fibers that switch at barriers, __shfl_xor() exchanges through a per-lane buffer between
+// two barriers, __shared__ storage is function-static (tests/hostemu/build.py rewrites the qualifier).  It checks the
+// kernels' LOGIC (indexing, reductions, barriers, numerics) before they ever reach an MI355X; it says nothing about
+// occupancy, LDS limits or speed.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__ static
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#ifndef INFINITY
+#define INFINITY __builtin_inff()
+#endif
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+
+// Lanes are FIBERS of one OS thread (ucontext): the scheduler resumes every unfinished lane of the workgroup in turn and
+// a lane runs until its next barrier (or its end).  One such pass is one "phase"; since all lanes of a workgroup (of a
+// wave) execute the same sequence of workgroup (wave) barriers, every lane is at the same barrier when a phase ends, so
+// "yield to the scheduler" IS the barrier.  Kernels whose lanes skip a barrier other lanes take are not supported (and
+// would be broken on the GPU as well).
+namespace hostemu {
+constexpr unsigned MAX_LANES = 256;           // the largest workgroup the kernels use
+constexpr size_t STACK = 256 * 1024;
+struct Fiber {
+    ucontext_t ctx;
+    bool done;
+};
+inline Fiber fibers[MAX_LANES];
+inline ucontext_t sched;
+inline char* stacks = nullptr;
+inline unsigned cur = 0;
+inline dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+inline float xch[MAX_LANES];                  // shuffle exchange, one slot per lane
+inline float dyn_lds[16384];                  // dynamic LDS of `extern __shared__` kernels (64 KB)
+inline std::function<void()> job;
+
+inline void yield() { swapcontext(&fibers[cur].ctx, &sched); }
+inline void entry() {
+    job();
+    fibers[cur].done = true;
+    swapcontext(&fibers[cur].ctx, &sched);
+}
+template <typename F>
+void launch(F&& body, dim3 grid, dim3 block) {
+    if (block.y != 1 || block.z != 1 || block.x % 64 || block.x > MAX_LANES) abort();   // 1-D workgroups of whole waves
+    if (!stacks) stacks = static_cast<char*>(malloc(MAX_LANES * STACK));
+    g_blockDim = block;
+    g_gridDim = grid;
+    job = body;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                g_blockIdx = dim3(bx, by, bz);
+                for (unsigned t = 0; t < block.x; ++t) {
+                    getcontext(&fibers[t].ctx);
+                    fibers[t].ctx.uc_stack.ss_sp = stacks + (size_t)t * STACK;
+                    fibers[t].ctx.uc_stack.ss_size = STACK;
+                    fibers[t].ctx.uc_link = nullptr;
+                    fibers[t].done = false;
+                    makecontext(&fibers[t].ctx, entry, 0);
+                }
+                for (unsigned alive = block.x; alive;) {   // one pass = one phase between barriers
+                    alive = 0;
+                    for (unsigned t = 0; t < block.x; ++t) {
+                        if (fibers[t].done) continue;
+                        cur = t;
+                        g_threadIdx = dim3(t, 0, 0);
+                        swapcontext(&sched, &fibers[t].ctx);
+                        alive += !fibers[t].done;
+                    }
+                }
+            }
+}
+}  // namespace hostemu
+#define threadIdx hostemu::g_threadIdx
+#define blockIdx hostemu::g_blockIdx
+#define blockDim hostemu::g_blockDim
+#define gridDim hostemu::g_gridDim
+
+static inline void __syncthreads() { hostemu::yield(); }
+static inline float __shfl_xor(float v, int mask) {
+    const unsigned t = hostemu::cur;
+    hostemu::xch[t] = v;
+    hostemu::yield();                                                    // every lane of the wave has written
+    const float r = hostemu::xch[(t & ~63u) | ((t ^ (unsigned)mask) & 63u)];
+    hostemu::yield();                                                    // every lane has read before the next write
+    return r;
+}
+static inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
+static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+#define __expf(x) expf(x)   // glibc declares __expf itself
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+using std::max;
+using std::min;
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hostemu::launch([&] { kernel(__VA_ARGS__); }, grid, block)

@@ -323,7 +323,10 @@ extern "C" int ymk_deform_attention(int32_t dtype, const void* v, int32_t ldv, c
     if (B <= 0) return YMK_OK;
     const int64_t total = (int64_t)B * H * W * C;
     const int64_t nb = (total + 255) / 256;
-    hipLaunchKernelGGL(deform_kernel, dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, (hipStream_t)stream, dtype, v, ldv, off, ldoff,
+#ifndef YMK_MAX_BLOCKS
+#define YMK_MAX_BLOCKS 16384
+#endif
+    hipLaunchKernelGGL(deform_kernel, dim3((unsigned)(nb > YMK_MAX_BLOCKS ? YMK_MAX_BLOCKS : nb)), dim3(256), 0, (hipStream_t)stream, dtype, v, ldv, off, ldoff,
                        aw, ldaw, out, ldo, B, H, W, heads, hd, n_points, align_corners);
     return ymk_launch_status();
 }

@@ -37,7 +37,10 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return r;
 }
 inline bool bad_dt(int dt) { return dt != YMK_F32 && dt != YMK_BF16; }
-inline int blocks_for(int64_t total, int per_block = 256, int cap = 256 * 64) {
+#ifndef YMK_MAX_BLOCKS
+#define YMK_MAX_BLOCKS (256 * 64)   // grid-stride kernels: enough workgroups to fill the chip many times over
+#endif
+inline int blocks_for(int64_t total, int per_block = 256, int cap = YMK_MAX_BLOCKS) {
     const int64_t b = (total + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }

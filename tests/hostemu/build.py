@@ -51,5 +51,27 @@ def build(force: bool = False) -> Path | None:
     return lib
 
 
+def build_probe(name: str = "conv256") -> Path | None:
+    """tools/micro/<name>.hip as a host executable (-DYMK_HOST_EMU): the probe's kernel on tiny shapes, self-checked against
+    its naive kernel."""
+    cxx = compiler()
+    if cxx is None:
+        return None
+    OUT.mkdir(exist_ok=True)
+    src = ROOT / "tools" / "micro" / f"{name}.hip"
+    exe = OUT / f"{name}_host"
+    deps = [src, HERE / "hip" / "hip_runtime.h", CSRC / "ymk_common.h", Path(__file__)]
+    if exe.exists() and exe.stat().st_mtime >= max(d.stat().st_mtime for d in deps):
+        return exe
+    txt = src.read_text()
+    txt = re.sub(r"\bextern\s+__shared__\s+(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(hostemu::dyn_lds);", txt)
+    txt = re.sub(r"\b__shared__\b", "static", txt)
+    txt = txt.replace('"../../yolo_master_amd/csrc/', f'"{CSRC}/')
+    u = OUT / f"{name}_host.cpp"
+    u.write_text(txt)
+    subprocess.run([cxx, "-std=c++20", "-O1", "-Wno-everything", "-DYMK_HOST_EMU", f"-I{HERE}", str(u), "-o", str(exe)], check=True)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force=True))

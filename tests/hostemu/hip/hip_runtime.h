@@ -37,8 +37,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 // "yield to the scheduler" IS the barrier.  Kernels whose lanes skip a barrier other lanes take are not supported (and
 // would be broken on the GPU as well).
 namespace hostemu {
-constexpr unsigned MAX_LANES = 256;           // the largest workgroup the kernels use
-constexpr size_t STACK = 256 * 1024;
+constexpr unsigned MAX_LANES = 512;           // the largest workgroup any emulated kernel uses
+constexpr size_t STACK = 128 * 1024;
 struct Fiber {
     ucontext_t ctx;
     bool done;
@@ -49,7 +49,7 @@ inline char* stacks = nullptr;
 inline unsigned cur = 0;
 inline dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 inline float xch[MAX_LANES];                  // shuffle exchange, one slot per lane
-inline float dyn_lds[16384];                  // dynamic LDS of `extern __shared__` kernels (64 KB)
+alignas(16) inline float dyn_lds[40960];     // dynamic LDS of `extern __shared__` kernels (160 KB: one CU's LDS)
 inline std::function<void()> job;
 
 inline void yield() { swapcontext(&fibers[cur].ctx, &sched); }
@@ -113,3 +113,53 @@ using std::min;
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hostemu::launch([&] { kernel(__VA_ARGS__); }, grid, block)
+
+// ---- what the tiled-GEMM design probes (tools/micro/conv256.hip) need on top -----------------------------------------
+// Matrix core: v_mfma_f32_16x16x32_bf16.  Lane l of the wave holds A[l % 16][(l / 16) * 8 .. + 7], B[(l / 16) * 8 .. + 7][l % 16]
+// and D[(l / 16) * 4 + r][l % 16], r = 0..3 (CDNA3/4 ISA; the layout the library's kernels were validated with on hardware).
+typedef __bf16 hostemu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float hostemu_f32x4 __attribute__((ext_vector_type(4)));
+namespace hostemu {
+inline float mfma_a[MAX_LANES][8], mfma_b[MAX_LANES][8];
+}
+static inline hostemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hostemu_bf16x8 a, hostemu_bf16x8 b, hostemu_f32x4 c, int, int, int) {
+    const unsigned t = hostemu::cur, w0 = t & ~63u, l = t & 63u;
+    for (int e = 0; e < 8; ++e) {
+        hostemu::mfma_a[t][e] = (float)a[e];
+        hostemu::mfma_b[t][e] = (float)b[e];
+    }
+    hostemu::yield();
+    for (int r = 0; r < 4; ++r) {
+        const unsigned i = (l / 16) * 4 + r, j = l % 16;
+        float s = 0.f;
+        for (unsigned k = 0; k < 32; ++k) s += hostemu::mfma_a[w0 + (k / 8) * 16 + i][k % 8] * hostemu::mfma_b[w0 + (k / 8) * 16 + j][k % 8];
+        c[r] += s;
+    }
+    hostemu::yield();
+    return c;
+}
+// LDS-DMA: 16 bytes per lane from the lane's global address to (wave-uniform LDS base) + lane * 16.  Completes at once
+// here, so counted-vmcnt mistakes are invisible; addressing, swizzles and masks are not.
+static inline void hostemu_global_load_lds16(const void* g, void* lds_base) {
+    std::memcpy(static_cast<char*>(lds_base) + (hostemu::cur & 63u) * 16, g, 16);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hostemu_global_load_lds16((const void*)(g), (void*)(l))
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+static inline void __builtin_amdgcn_s_barrier() { hostemu::yield(); }
+
+// the slice of the HIP runtime API the probes' main() uses
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+typedef int hipEvent_t;
+template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { *p = static_cast<T*>(malloc(n)); return hipSuccess; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
+static inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }

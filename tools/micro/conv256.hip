@@ -17,10 +17,27 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#ifndef YMK_HOST_EMU
 #include "../../yolo_master_amd/csrc/conv.hip"   // library kernels for the side-by-side number + mma16 / store4 / silu_f
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+// Host emulation (tests/hostemu): the kernel below runs lane by lane on the CPU — matrix core, LDS-DMA and barriers are
+// emulated, DMA completes at once — so that its addressing (taps, masks, swizzle, tail tiles, XCD order) is checked
+// against the naive convolution before the first GPU call.  No library kernels, no timing.
+#include <cmath>
+#include "../../yolo_master_amd/csrc/ymk_common.h"
+typedef const void* gptr_t;
+typedef void* lptr_t;
+#define WAIT_LGKM0() ((void)0)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <typename T> inline void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
+template <> inline void mma16<bf16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+#endif
 
 #define C_BM 256
 
@@ -155,9 +172,11 @@ __global__ __launch_bounds__(512) void conv256_kernel(const bf16_t* __restrict__
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(WAITCNT_VM(G));   // my pieces of tile kt have landed
             else __builtin_amdgcn_s_waitcnt(WAITCNT_VM(0));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my reads of tile kt-1 are done (WAR on stage nxt)
+            WAIT_LGKM0();                                                 // my reads of tile kt-1 are done (WAR on stage nxt)
             __builtin_amdgcn_s_barrier();                                 // everyone's pieces landed / reads done
+#ifndef YMK_HOST_EMU
             asm volatile("" ::: "memory");
+#endif
             if (kt + 2 < nk) issue(nxt);
             compute(cur);
             cur = cur == 2 ? 0 : cur + 1;
@@ -201,6 +220,9 @@ __global__ void naive_conv_kernel(const bf16_t* X, const bf16_t* Wt, const float
 
 template <typename F>
 static float timeit(F&& f, int reps = 20) {
+#ifdef YMK_HOST_EMU
+    return 1.0f;   // no timing on the emulator
+#endif
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> ts;
@@ -236,6 +258,12 @@ struct Variant { const char* name; int bn; launch_fn fn; };
 int main(int argc, char** argv) {
     // the tiled-GEMM launches that dominate the S model at batch 64 (gpurun_out calls log), largest first
     struct Shape { int B, H, W, Cin, Cout, ks, stride; } shapes[] = {
+#ifdef YMK_HOST_EMU
+        {2, 23, 19, 64, 128, 3, 2},       // one full + one tail tile, borders on every side
+        {1, 18, 17, 128, 64, 3, 1},       // two k-steps per tap, BN = 64 only
+        {3, 9, 11, 192, 128, 1, 1},       // 1x1: three k-steps
+        {1, 40, 13, 64, 256, 3, 1},       // several cout tiles per pixel tile (XCD order matters)
+#else
         {64, 160, 160, 128, 128, 3, 2},   // 128->128 k3 s2 @80x80 out     (246 us today)
         {64, 80, 80, 256, 256, 3, 2},     // 256->256 k3 s2 @40x40 out     (221 us)
         {64, 80, 80, 128, 64, 3, 1},      // 128->64  k3 s1 @80x80         (165 us)
@@ -246,6 +274,7 @@ int main(int argc, char** argv) {
         {64, 40, 40, 384, 256, 1, 1},     // 384->256 k1 @40x40            (70-76 us)
         {64, 20, 20, 256, 64, 3, 1},      // 256->64  k3 s1 @20x20         (70 us: 100 tiles, latency-bound)
         {3, 37, 29, 64, 128, 3, 2},       // ragged: tail tile, odd sizes, borders everywhere (correctness only)
+#endif
     };
     const int total = (int)(sizeof(shapes) / sizeof(shapes[0]));
     const int nshape = argc > 1 ? std::min(atoi(argv[1]), total) : total;
@@ -319,6 +348,7 @@ int main(int argc, char** argv) {
             printf("  %s %8.1f us %7.1f TF/s %5.2f TB/s   max |err| %.3e (max |ref| %.2f) %s\n", v.name, ms * 1e3, flops / ms / 1e9,
                    bytes / ms / 1e9, err, maxref, ok ? "OK" : "MISMATCH");
         }
+#ifndef YMK_HOST_EMU
         ymk_conv_desc d{YMK_BF16, YMK_BF16, sh.B, sh.H, sh.W, sh.Cin, sh.Cout, sh.ks, sh.stride, sh.Cin, sh.Cout, 0, g.Kpad, YMK_ACT_SILU};
         hipMemset(y2, 0xff, ny * 2);
         if (ymk_conv2d(&d, x, w, b, nullptr, y2, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess) {
@@ -329,6 +359,7 @@ int main(int argc, char** argv) {
         } else {
             printf("  library: rejected this shape\n");
         }
+#endif
         hipFree(x); hipFree(w); hipFree(y); hipFree(y2); hipFree(b); hipFree(yr); hipFree(pix);
     }
     printf(bad ? "RESULT: %d variant(s) FAILED\n" : "RESULT: all variants match the naive convolution\n", bad);

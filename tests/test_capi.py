@@ -36,6 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert not set(mix) & set(fns)
     for f in mix:
         assert hasattr(h, f), f"libymk.so does not export {f}"
+    assert sorted(_lib.SYMBOLS_NEXT) == header_functions("ymk_next.h") and all(hasattr(h, f) for f in _lib.SYMBOLS_NEXT)
     assert h.ymk_abi_version() == 1
     assert b"gfx950" in h.ymk_build_info()
     # pure host-side queries work without a GPU
@@ -69,7 +70,7 @@ def test_ctypes_tables_match_the_prototypes():
 
     from yolo_master_amd import _lib
 
-    for header, table in (("ymk.h", _lib.SYMBOLS), ("ymk_mixture.h", _lib.SYMBOLS_MIXTURE)):
+    for header, table in (("ymk.h", _lib.SYMBOLS), ("ymk_mixture.h", _lib.SYMBOLS_MIXTURE), ("ymk_next.h", _lib.SYMBOLS_NEXT)):
         protos = header_prototypes(header)
         assert set(protos) == set(table)
         for name, (_, argtypes) in table.items():

@@ -1,0 +1,102 @@
+"""The opt-in tiled convolution core (csrc/conv_glds.hip, include/ymk_next.h) on the CPU lane emulator (tests/hostemu:
+matrix core, LDS-DMA, barriers and the XCD tile order emulated; DMA completes at once): the library entry point
+`ymk_conv2d_glds`, called through its ctypes binding with the library's own descriptor, against the torch restatement of
+the `ymk_conv2d` contract — strided input / output / residual views, both activation codes, bf16 and fp32 outputs,
+1x1 and 3x3, stride 1 and 2, both cout tile widths, tail tiles, both k-loop flavours."""
+import ctypes as C
+
+import pytest
+import torch
+
+from tests import emu_ops
+from tests.hostemu import build as hostemu_build
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    path = hostemu_build.build()
+    if path is None:
+        pytest.skip("no host clang++ to build the kernel emulation")
+    from yolo_master_amd import _lib
+
+    h = C.CDLL(str(path))
+    fn = h.ymk_conv2d_glds
+    fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_conv2d_glds"]
+    return h
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _wide(t, pad, dev="cpu"):
+    """Same values as a channel slice of a wider buffer on `dev` (pad = extra channels of the buffer)."""
+    if not pad:
+        return t.contiguous().to(dev)
+    buf = torch.zeros((*t.shape[:3], t.shape[3] + pad), dtype=t.dtype)
+    buf[..., : t.shape[3]] = t
+    return buf.to(dev)[..., : t.shape[3]]
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, s, act, residual, out fp32, x pad, y pad, two_stage
+    (2, 13, 11, 64, 128, 3, 1, True, True, False, 0, 0, 0),
+    (2, 23, 19, 64, 128, 3, 2, True, False, False, 64, 0, 1),
+    (1, 18, 17, 128, 64, 3, 1, False, True, False, 0, 64, 0),
+    (3, 9, 11, 192, 192, 1, 1, True, False, True, 0, 0, 0),      # BN = 64, three cout tiles, fp32 logits-style output
+    (1, 40, 13, 64, 256, 3, 1, True, False, False, 0, 128, 1),   # two cout tiles per pixel tile, three pixel tiles
+    (2, 16, 16, 128, 128, 1, 2, False, False, False, 8, 4, 0),   # strided 1x1
+    (1, 3, 5, 64, 64, 3, 1, True, True, True, 0, 0, 0),          # a single ragged tile
+]
+
+
+def run_case(lib, case, dev="cpu", stream=None):
+    """One parity case of ymk_conv2d_glds against the contract restatement; shared with tests/test_gpu_next.py."""
+    from yolo_master_amd import _lib, ops
+
+    B, H, W, Cin, Cout, k, s, act, use_res, out_f32, xpad, ypad, two = case
+    bf = torch.bfloat16
+    x = _rnd(B, H, W, Cin, seed=1).to(bf)
+    wp = ops.pack_conv_weight(_rnd(Cout, Cin, k, k, seed=2, scale=(k * k * Cin) ** -0.5), bf)
+    bias = _rnd(Cout, seed=3, scale=0.2)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    res = _rnd(B, Ho, Wo, Cout, seed=4).to(bf) if use_res else None
+    odt = torch.float32 if out_f32 else bf
+    ref = emu_ops.conv2d(x, wp, bias, k, s, act, residual=res, out_dtype=odt)
+    ybuf = torch.full((B, Ho, Wo, Cout + ypad), 7.0, dtype=odt, device=dev)
+    y = ybuf[..., :Cout]
+    xd, rd = _wide(x, xpad, dev), (None if res is None else _wide(res, 32, dev))
+    wd, bd = wp.to(dev), bias.to(dev)
+    d = _lib.ConvDesc(_lib.YMK_BF16, ops.DT[odt], B, H, W, Cin, Cout, k, s, xd.stride(2), y.stride(2), rd.stride(2) if use_res else 0,
+                      wp.shape[1], _lib.ACT_SILU if act else _lib.ACT_NONE)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())   # noqa: E731
+    rc = lib.ymk_conv2d_glds(C.byref(d), p(xd), p(wd), p(bd), p(rd), p(y), two, stream)
+    assert rc == 0
+    got = y.float().cpu()
+    err = float((got - ref.float()).abs().max())
+    tol = (2e-5 if out_f32 else 1.6e-2) * max(1.0, float(ref.float().abs().max()))
+    assert err <= tol, f"max |d| {err:.3e}"
+    if ypad:
+        assert float((ybuf[..., Cout:].float().cpu() - 7.0).abs().max()) == 0.0, "wrote outside its channel slice"
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d_glds_on_the_emulator(hostlib, case):
+    run_case(hostlib, case)
+
+
+def test_conv2d_glds_rejects_what_it_does_not_cover(hostlib):
+    from yolo_master_amd import _lib
+
+    x = torch.zeros((1, 4, 4, 64), dtype=torch.bfloat16)
+    w = torch.zeros((64, 576), dtype=torch.bfloat16)
+    b = torch.zeros(64)
+    y = torch.zeros((1, 4, 4, 64), dtype=torch.bfloat16)
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    for desc in (_lib.ConvDesc(_lib.YMK_F32, _lib.YMK_F32, 1, 4, 4, 64, 64, 3, 1, 64, 64, 0, 576, 1),        # fp32 compute
+                 _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, 1, 4, 4, 32, 64, 3, 1, 32, 64, 0, 320, 1),      # Cin % 64
+                 _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, 1, 4, 4, 64, 80, 3, 1, 64, 80, 0, 576, 1),      # Cout % 64
+                 _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, 1, 4, 4, 64, 64, 3, 1, 64, 64, 0, 640, 1)):     # padded K
+        assert hostlib.ymk_conv2d_glds(C.byref(desc), p(x), p(w), p(b), None, p(y), 0, None) == -1

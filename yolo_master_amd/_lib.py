@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-__all__ = ["lib", "load", "YmkLibraryError", "ConvDesc", "check", "LIB_PATH", "SYMBOLS", "SYMBOLS_MIXTURE"]
+__all__ = ["lib", "load", "YmkLibraryError", "ConvDesc", "check", "LIB_PATH", "SYMBOLS", "SYMBOLS_MIXTURE", "SYMBOLS_NEXT"]
 
 LIB_PATH = Path(__file__).resolve().parent / "libymk.so"
 
@@ -97,6 +97,10 @@ SYMBOLS_MIXTURE = {
     "ymk_deform_attention": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _vp]),
 }
+# include/ymk_next.h: opt-in entry points outside the validated surface
+SYMBOLS_NEXT = {
+    "ymk_conv2d_glds": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+}
 ACT_SIGMOID, ACT_GELU = 2, 3
 ELT_MUL, ELT_SIGMOID_MUL, ELT_LERP = 0, 1, 2
 
@@ -127,7 +131,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         except AttributeError as e:
             raise YmkLibraryError(f"{p} does not export {name}; rebuild libymk") from e
         fn.restype, fn.argtypes = res, args
-    for name, (res, args) in SYMBOLS_MIXTURE.items():
+    for name, (res, args) in {**SYMBOLS_MIXTURE, **SYMBOLS_NEXT}.items():
         try:
             fn = getattr(h, name)
         except AttributeError as e:

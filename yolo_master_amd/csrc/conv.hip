@@ -22,6 +22,9 @@ static int ymk_use_ws = 1;          // tools/micro can switch the streaming 1x1 
 static int ymk_ws_min_tiles = [] { const char* e = getenv("YMK_WS_MIN_TILES"); return e ? atoi(e) : 1024; }();
 extern "C" void ymk_debug_set_ws(int on) { ymk_use_ws = on; }
 static thread_local int ymk_last_variant = YMK_CONV_TILED;
+extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                               void* y, int32_t two_stage, void* stream);   // csrc/conv_glds.hip, include/ymk_next.h
+static int ymk_glds_min_tiles = [] { const char* e = getenv("YMK_GLDS_MIN_TILES"); return e ? atoi(e) : 192; }();
 extern "C" int32_t ymk_conv2d_last_variant(void) { return ymk_last_variant; }
 
 template <typename T, bool PRECISE>
@@ -585,6 +588,13 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     if (d->ksize == 3 && ymk_use_ws && !(ymk_disabled() & YMK_OFF_CONV_STREAM)) {  // small-Cin stride-1 3x3: spatial-tile kernel (LDS-staged im2col)
         const bool done = d->dtype == YMK_F32 ? launch_conv3x3_tile<float>(a, s) : launch_conv3x3_tile<bf16_t>(a, s);
         if (done) { ymk_last_variant = YMK_CONV_SPATIAL_3X3; return ymk_launch_status(); }
+    }
+    if ((ymk_enabled() & YMK_ON_CONV_GLDS) && d->dtype == YMK_BF16) {   // opt-in: next tiled core (include/ymk_next.h)
+        const int64_t tiles = ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
+        if (d->Cout % 64 == 0 && tiles >= ymk_glds_min_tiles) {
+            const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 1 : 0, stream);
+            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; return rc; }
+        }
     }
     ymk_last_variant = YMK_CONV_TILED;
     if (d->dtype == YMK_F32)

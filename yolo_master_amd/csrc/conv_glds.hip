@@ -1,0 +1,237 @@
+// Next tiled implicit-GEMM core: 256 output pixels x BN couts per workgroup on 8 waves, BK = 64
+// channels of one filter tap per k-step, both operands staged straight into LDS by global_load_lds (16 bytes per lane,
+// lane-linear LDS image, XOR swizzle applied on the SOURCE side, border taps read a zero page), two LDS stages with a
+// plain barrier or three stages with a raw barrier and a counted vmcnt (one k-step of DMA in flight across every
+// barrier), XCD-aware tile order.  bf16 only; Cin % 64 == 0, Cout % 64 == 0.
+//
+// STATUS: OPT-IN (YMK_ENABLE bit 0; bit 1 selects the 2-stage loop).  The design ran correctly on MI355X as
+// tools/micro/gemm256.hip; this library form (strided views, residual, fp32 output, activation codes) has passed
+// tests/test_hostemu_conv.py on the CPU lane emulator but has not been timed or run on hardware: ymk_conv2d keeps
+// dispatching to the validated kernels unless the switch is set.
+#include "ymk_common.h"
+
+typedef __bf16 glds_bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef YMK_HOST_EMU
+typedef __attribute__((address_space(1))) const void* glds_gptr;
+typedef __attribute__((address_space(3))) void* glds_lptr;
+#define GLDS_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define GLDS_COMPILER_FENCE() asm volatile("" ::: "memory")
+#else   // tests/hostemu: plain pointers, no inline assembly
+typedef const void* glds_gptr;
+typedef void* glds_lptr;
+#define GLDS_WAIT_LGKM0() ((void)0)
+#define GLDS_COMPILER_FENCE() ((void)0)
+#endif
+
+#define GLDS_BM 256
+// s_waitcnt immediate (gfx9 family): vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
+#define GLDS_WAITCNT_VM(n) (0x0F70 | ((n) & 15) | ((((n) >> 4) & 3) << 14))
+
+__device__ u32x4 ymk_glds_zero_page[8];   // 128 bytes of zeros: the source of out-of-image taps and tail rows
+
+struct GldsArgs {
+    const bf16_t* x;
+    const bf16_t* w;
+    const float* bias;
+    const bf16_t* res;
+    void* y;
+    int B, H, W, Ho, Wo, Cin, Cout, ks, stride, ldx, ldy, ldr, Kpad, act, out_f32;
+};
+
+template <int BN, int STAGES>
+__global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
+    constexpr int ROWS = BN + GLDS_BM;        // staged rows per k-step: weights first, then pixels
+    constexpr int STAGE_U4 = ROWS * 8;        // 16-byte slots per stage
+    constexpr int G = ROWS / 64;              // global_load_lds instructions per wave per k-step (6 or 5)
+    constexpr int GW = BN / 64;               // of which weight rows
+    constexpr int WN = BN / 64;               // waves along couts (64 couts per wave)
+    constexpr int WM = 8 / WN;                // waves along pixels
+    constexpr int TP = GLDS_BM / WM / 16;     // 16-pixel fragments per wave (4 or 2)
+    extern __shared__ u32x4 smem[];           // STAGES * STAGE_U4
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int M = a.B * a.Ho * a.Wo;
+    const int nt = a.Cout / BN;
+    // bijective XCD remap: workgroup b runs on XCD b % 8, so consecutive LOGICAL tiles (same pixels, next couts; then the
+    // neighbouring pixel tile that shares halo rows) are given to one XCD back to back
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m0 = (bid / nt) * GLDS_BM, n0 = (bid % nt) * BN;
+    const int cpt = a.Cin >> 6;               // k-steps per filter tap
+    const int nk = a.ks * a.ks * cpt;
+    const int pad = a.ks >> 1;
+
+    // ---- staging map: lane (lr, lc) of wave-instruction q stages chunk lc ^ (row & 7) of row q*8 + lr ----------------
+    const int lr = lane >> 3, lc = lane & 7;
+    const bf16_t* wsrc[GW];
+    int poff[G - GW];         // element offset of the tap-(0,0) input pixel (+ swizzled chunk) for this lane's pixel rows
+    unsigned pmask[G - GW];   // bit (ky*3+kx): tap inside the image
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int r = (j * 8 + wave) * 8 + lr;
+        const int sc = (lc ^ (r & 7)) * 8;
+        if (j < GW) {
+            wsrc[j] = a.w + (size_t)(n0 + r) * a.Kpad + sc;
+        } else {
+            const int p = m0 + r - BN;
+            unsigned mask = 0;
+            int off = 0;
+            if (p < M) {
+                const int ox = p % a.Wo, oy = (p / a.Wo) % a.Ho, b = p / (a.Wo * a.Ho);
+                const int iy0 = oy * a.stride - pad, ix0 = ox * a.stride - pad;
+                off = ((b * a.H + iy0) * a.W + ix0) * a.ldx + sc;
+                unsigned ry = 0, rx = 0;   // rows / columns of the filter window that fall inside the image
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (k < a.ks && (unsigned)(iy0 + k) < (unsigned)a.H) ry |= 1u << k;
+                    if (k < a.ks && (unsigned)(ix0 + k) < (unsigned)a.W) rx |= 1u << k;
+                }
+                mask = ((ry & 1u) ? rx : 0u) | ((ry & 2u) ? rx << 3 : 0u) | ((ry & 4u) ? rx << 6 : 0u);
+            }
+            poff[j - GW] = off;
+            pmask[j - GW] = mask;
+        }
+    }
+    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(ymk_glds_zero_page) + lc * 8;
+    int it_tap_bit = 0, it_ky = 0, it_kx = 0, it_c = 0, it_k = 0;   // cursor of the NEXT k-step to issue (uniform)
+    auto issue = [&](int stage) {
+        const int tapoff = (it_ky * a.W + it_kx) * a.ldx + it_c * 64;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            u32x4* dst = smem + stage * STAGE_U4 + (j * 8 + wave) * 64;   // wave-uniform; the lane lands at + lane * 16 B
+            const bf16_t* s;
+            if (j < GW) s = wsrc[j] + it_k * 64;
+            else s = ((pmask[j - GW] >> it_tap_bit) & 1u) ? a.x + (poff[j - GW] + tapoff) : zsrc;
+            __builtin_amdgcn_global_load_lds((glds_gptr)s, (glds_lptr)dst, 16, 0, 0);
+        }
+        ++it_k;
+        if (++it_c == cpt) {
+            it_c = 0;
+            ++it_kx; ++it_tap_bit;
+            if (it_kx == a.ks) { it_kx = 0; ++it_ky; it_tap_bit = it_ky * 3; }
+        }
+    };
+
+    f32x4 acc[4][TP];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int stage) {
+        const u32x4* sW = smem + stage * STAGE_U4;
+        const u32x4* sX = sW + BN * 8;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 af[4], bfr[TP];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = ((wave % WN) * 4 + i) * 16 + fr;
+                af[i] = sW[r * 8 + ((kk * 4 + fc) ^ (r & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int r = ((wave / WN) * TP + j) * 16 + fr;   // BN % 8 == 0: (BN + r) & 7 == r & 7
+                bfr[j] = sX[r * 8 + ((kk * 4 + fc) ^ (r & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(glds_bf16x8, af[i]),
+                                                                       __builtin_bit_cast(glds_bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if constexpr (STAGES == 2) {
+        issue(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();   // drains the DMA (vmcnt(0)): stage kt&1 complete, the other one free
+            if (kt + 1 < nk) issue((kt + 1) & 1);
+            compute(kt & 1);
+        }
+    } else {
+        issue(0);
+        if (nk > 1) issue(1);
+        int cur = 0, nxt = 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(G));   // my pieces of k-step kt have landed
+            else __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(0));
+            GLDS_WAIT_LGKM0();                  // my fragment reads of k-step kt-1 are done (WAR on stage nxt)
+            __builtin_amdgcn_s_barrier();       // everyone's pieces landed, everyone's reads done
+            GLDS_COMPILER_FENCE();
+            if (kt + 2 < nk) issue(nxt);
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt = nxt == 2 ? 0 : nxt + 1;
+        }
+    }
+
+    // ---- epilogue: bias, activation, residual, 4 consecutive couts per lane ---------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = n0 + ((wave % WN) * 4 + i) * 16 + fc * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int p = m0 + ((wave / WN) * TP + j) * 16 + fr;
+            if (p >= M) continue;
+            float v0 = acc[i][j].x + bv.x, v1 = acc[i][j].y + bv.y, v2 = acc[i][j].z + bv.z, v3 = acc[i][j].w + bv.w;
+            if (a.act == YMK_ACT_SILU) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            if (a.res) {
+                float r0, r1, r2, r3;
+                load4(a.res + (size_t)p * a.ldr + co, r0, r1, r2, r3);
+                v0 += r0; v1 += r1; v2 += r2; v3 += r3;
+            }
+            if (a.out_f32) store4(static_cast<float*>(a.y) + (size_t)p * a.ldy + co, v0, v1, v2, v3);
+            else store4(static_cast<bf16_t*>(a.y) + (size_t)p * a.ldy + co, v0, v1, v2, v3);
+        }
+    }
+}
+
+template <int BN, int STAGES>
+static int glds_launch(const GldsArgs& a, hipStream_t s) {
+    const int M = a.B * a.Ho * a.Wo;
+    const int grid = ((M + GLDS_BM - 1) / GLDS_BM) * (a.Cout / BN);
+    const size_t lds = (size_t)STAGES * (BN + GLDS_BM) * 8 * 16;
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute((const void*)conv_glds_kernel<BN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return YMK_E_LAUNCH;
+        once = true;
+    }
+    hipLaunchKernelGGL((conv_glds_kernel<BN, STAGES>), dim3(grid), dim3(512), lds, s, a);
+    return ymk_launch_status();
+}
+
+// Same arguments and result as ymk_conv2d; returns YMK_E_BADARG for shapes outside this kernel's domain (the caller then
+// takes the validated path).  two_stage != 0 selects the plain-barrier loop.
+extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                               void* y, int32_t two_stage, void* stream) {
+    if (!d || !x || !w || !bias || !y) return YMK_E_BADARG;
+    if (d->dtype != YMK_BF16 || (d->out_dtype != YMK_BF16 && d->out_dtype != YMK_F32)) return YMK_E_BADARG;
+    if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return YMK_E_BADARG;
+    if (d->Cin < 64 || d->Cin % 64 || d->Cout % 64 || d->ldx % 8 || d->ldy % 4 || (residual && d->ldr % 4)) return YMK_E_BADARG;
+    if (d->Kpad != d->ksize * d->ksize * d->Cin) return YMK_E_BADARG;
+    if (d->act != YMK_ACT_NONE && d->act != YMK_ACT_SILU) return YMK_E_BADARG;
+    const int pad = d->ksize / 2;
+    GldsArgs a;
+    a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(w); a.bias = bias;
+    a.res = static_cast<const bf16_t*>(residual); a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = d->ksize; a.stride = d->stride;
+    a.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
+    a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+    a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.Kpad = d->Kpad; a.act = d->act;
+    a.out_f32 = d->out_dtype == YMK_F32;
+    const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+    if (M <= 0) return YMK_OK;
+    // 32-bit element offsets inside the kernel
+    if (M >= (1ll << 31) || ((int64_t)d->B * d->H * d->W + d->W + 2) * d->ldx >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Cout % 128 == 0) return two_stage ? glds_launch<128, 2>(a, s) : glds_launch<128, 3>(a, s);
+    return two_stage ? glds_launch<64, 2>(a, s) : glds_launch<64, 3>(a, s);
+}

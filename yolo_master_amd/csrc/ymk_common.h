@@ -120,4 +120,14 @@ static inline unsigned ymk_disabled() {
     }();
     return m;
 }
+// Opt-in switch for code that is not validated / measured on hardware yet (not part of the ABI): YMK_ENABLE=<bitmask>.
+#define YMK_ON_CONV_GLDS 1u        // tiled convolutions -> conv_glds_kernel (csrc/conv_glds.hip)
+#define YMK_ON_GLDS_TWO_STAGE 2u   // ... with the 2-stage plain-barrier k-loop instead of the 3-stage counted-vmcnt one
+static inline unsigned ymk_enabled() {
+    static const unsigned m = [] {
+        const char* s = getenv("YMK_ENABLE");
+        return s ? (unsigned)strtoul(s, nullptr, 0) : 0u;
+    }();
+    return m;
+}
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -81,6 +81,21 @@ def test_norms_and_elementwise(dtype):
     _cmp(ops.weighted_sum(wts.to(DEV), [p.to(DEV) for p in parts]), emu_ops.weighted_sum(wts, parts), dtype, "weighted_sum tokens")
     wimg = torch.softmax(_rnd(3, 1, 1, 2, seed=14), -1)
     _cmp(ops.weighted_sum(wimg.to(DEV), [p.to(DEV) for p in parts[:2]]), emu_ops.weighted_sum(wimg, parts[:2]), dtype, "weighted_sum images")
+    # channel counts below the 16-byte vector width take the scalar kernels
+    xs, ys = _rnd(2, 5, 7, 6, seed=40, dtype=dtype), _rnd(2, 5, 7, 6, seed=41, dtype=dtype)
+    gs = torch.sigmoid(_rnd(2, 1, 1, 6, seed=42))
+    _cmp(ops.layer_norm(xs.to(DEV), w[:6].to(DEV), b[:6].to(DEV), 1e-5), emu_ops.layer_norm(xs, w[:6], b[:6], 1e-5), dtype, "layer_norm C=6")
+    _cmp(ops.eltwise_mul(xs.to(DEV), ys.to(DEV), act_a="sigmoid"), emu_ops.eltwise_mul(xs, ys, act_a="sigmoid"), dtype, "sigmoid-mul C=6")
+    _cmp(ops.lerp(xs.to(DEV), ys.to(DEV), 0.7), emu_ops.lerp(xs, ys, 0.7), dtype, "lerp C=6")
+    _cmp(ops.channel_gate(xs.to(DEV), gs.to(DEV)), emu_ops.channel_gate(xs, gs), dtype, "channel_gate C=6")
+    _cmp(ops.fma_gate(xs.to(DEV), ys.to(DEV), gs.to(DEV), 0.5), emu_ops.fma_gate(xs, ys, gs, 0.5), dtype, "fma_gate C=6")
+    _cmp(ops.fma_gate(xs.to(DEV), xs.to(DEV), ys.to(DEV), 0.5), emu_ops.fma_gate(xs, xs, ys, 0.5), dtype, "fma_gate map C=6")
+    ws2 = torch.softmax(_rnd(2, 5, 7, 2, seed=43), -1)
+    _cmp(ops.weighted_sum(ws2.to(DEV), [xs.to(DEV), ys.to(DEV)]), emu_ops.weighted_sum(ws2, [xs, ys]), dtype, "weighted_sum C=6")
+    mixed = torch.sigmoid(_rnd(3, 9, 11, 48, seed=44))                      # fp32 gate map over activations of the compute dtype
+    _cmp(ops.fma_gate(x.to(DEV), y.to(DEV), mixed.to(DEV), 0.25), emu_ops.fma_gate(x, y, mixed, 0.25), dtype, "fma_gate fp32 map")
+    _cmp(ops.group_norm(x.to(DEV), 8, w.to(DEV), b.to(DEV), 1e-5, out_dtype=torch.float32), emu_ops.group_norm(x, 8, w, b, 1e-5, out_dtype=torch.float32),
+         torch.float32 if dtype == torch.float32 else dtype, "group_norm -> fp32")
     for act in ("sigmoid", "gelu"):
         wp = (0.2 * _rnd(16, 64, seed=15)).to(dtype)
         wp[:, 48:] = 0

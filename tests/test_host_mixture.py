@@ -273,6 +273,9 @@ def test_config5_L_scale_host_vs_oracle(emu):
         err = float((ops.nhwc_to_nchw_f32(t) - ref).abs().max() / max(1.0, float(ref.abs().max())))
         assert err <= 1e-4, f"layer {i} ({type(m.model[i]).__name__}): scaled max error {err:.3e}"
     assert float((y[:, 4:] - oy[:, 4:]).abs().max()) <= 1e-5
+    # the 32-wide heads of the L-scale MoT blocks (whole-map attention, the dominant cost at 1280 px) run on the MFMA
+    # area-attention kernel of the A2C2f blocks: 16 A2C2f calls + 3 layers x 4 blocks
+    assert emu.CALLS["area_attn"] == 16 + 12 and emu.CALLS["attention"] == 4   # MoA: regional + exact global, two blocks
     m.set_compute_dtype(torch.bfloat16)
     with torch.inference_mode():
         yb, _ = m._predict_once(x)

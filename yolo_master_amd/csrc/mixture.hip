@@ -364,6 +364,195 @@ __global__ __launch_bounds__(256) void shuffle_cat_kernel(int dt, const void* a,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 16-byte vector paths
+// Same arithmetic as the scalar kernels above, 8 bf16 / 4 fp32 channels per lane and memory instruction; taken when every
+// operand has the compute dtype, C and all pixel strides are multiples of the vector width and the bases are 16-byte
+// aligned (every buffer the host code builds for channel counts that are multiples of 8 qualifies).
+template <typename T>
+__global__ __launch_bounds__(256) void activation_vec_kernel(T* x, int ldx, int64_t npix, int C, int act) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC;
+    const int64_t total = npix * ncv;
+    GRID_STRIDE(i, total) {
+        T* px = x + (i / ncv) * ldx + (i % ncv) * VEC;
+        float v[VEC];
+        load_vec_f32(px, v);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = act_f(v[q], act);
+        store_vec_f32(px, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, int HW, int C, int groups, float eps, float* stats) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ float sh[4];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cg = C / groups, ncv = cg / VEC;
+    const int64_t nv = (int64_t)HW * ncv;
+    const T* base = x + (int64_t)b * HW * ldx + (int64_t)g * cg;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < nv; i += 256) {
+        float v[VEC];
+        load_vec_f32(base + (i / ncv) * ldx + (i % ncv) * VEC, v);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s += v[q];
+    }
+    const float n = (float)HW * (float)cg;
+    const float mean = block_sum(s, sh) / n;
+    float qq = 0.f;
+    for (int64_t i = threadIdx.x; i < nv; i += 256) {
+        float v[VEC];
+        load_vec_f32(base + (i / ncv) * ldx + (i % ncv) * VEC, v);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) qq += (v[q] - mean) * (v[q] - mean);
+    }
+    const float var = block_sum(qq, sh) / n;
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = mean;
+        stats[2 * blockIdx.x + 1] = 1.0f / sqrtf(var + eps);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* x, int ldx, T* y, int ldy, const T* res, int ldr, int B, int HW, int C,
+                                                            int groups, const float* weight, const float* bias, const int32_t* rows, int act,
+                                                            const float* stats) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int cg = C / groups, ncv = C / VEC;
+    const int64_t total = (int64_t)B * HW * ncv;
+    GRID_STRIDE(i, total) {
+        const int c0 = (int)(i % ncv) * VEC;
+        const int64_t p = i / ncv;
+        const int b = (int)(p / HW);
+        float v[VEC];
+        load_vec_f32(x + p * ldx + c0, v);
+        const int64_t r = rows ? (int64_t)rows[b] * C : 0;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const float* st = stats + 2 * ((int64_t)b * groups + (c0 + q) / cg);   // a vector may straddle two groups
+            float t = (v[q] - st[0]) * st[1];
+            if (weight) t = t * weight[r + c0 + q] + bias[r + c0 + q];
+            v[q] = act_f(t, act);
+        }
+        if (res) {
+            float rr[VEC];
+            load_vec_f32(res + p * ldr + c0, rr);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) v[q] += rr[q];
+        }
+        store_vec_f32(y + p * ldy + c0, v);
+    }
+}
+// one wave per token, one vector per lane and step
+template <typename T>
+__global__ __launch_bounds__(256) void ln_vec_kernel(const T* x, int ldx, T* y, int ldy, int64_t npix, int C, const float* weight,
+                                                      const float* bias, float eps) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63, ncv = C / VEC;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p = wave0; p < npix; p += nwaves) {
+        float s = 0.f;
+        for (int cv = lane; cv < ncv; cv += 64) {
+            float v[VEC];
+            load_vec_f32(x + p * ldx + cv * VEC, v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s += v[q];
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float qq = 0.f;
+        for (int cv = lane; cv < ncv; cv += 64) {
+            float v[VEC];
+            load_vec_f32(x + p * ldx + cv * VEC, v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) qq += (v[q] - mean) * (v[q] - mean);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)C + eps);
+        for (int cv = lane; cv < ncv; cv += 64) {
+            float v[VEC];
+            load_vec_f32(x + p * ldx + cv * VEC, v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) v[q] = (v[q] - mean) * rstd * weight[cv * VEC + q] + bias[cv * VEC + q];
+            store_vec_f32(y + p * ldy + cv * VEC, v);
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void eltwise_vec_kernel(int op, const T* a, int lda, const T* b, int ldb, T* y, int ldy, int64_t npix, int C,
+                                                           float alpha) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC;
+    const int64_t total = npix * ncv;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i / ncv;
+        const int c0 = (int)(i % ncv) * VEC;
+        float av[VEC], bv[VEC];
+        load_vec_f32(a + p * lda + c0, av);
+        load_vec_f32(b + p * ldb + c0, bv);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            if (op == YMK_ELT_MUL) av[q] = av[q] * bv[q];
+            else if (op == YMK_ELT_SIGMOID_MUL) av[q] = bv[q] / (1.0f + expf(-av[q]));
+            else av[q] = (1.0f - alpha) * av[q] + alpha * bv[q];
+        }
+        store_vec_f32(y + p * ldy + c0, av);
+    }
+}
+// y = x + scale * a * b (b a map of T, or an fp32 per-image gate when gate != nullptr); a == nullptr: y = x * gate
+template <typename T>
+__global__ __launch_bounds__(256) void gate_vec_kernel(const T* x, int ldx, const T* a, int lda, const T* b, int ldb, const float* gate,
+                                                        float scale, T* y, int ldy, int B, int HW, int C) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC;
+    const int64_t total = (int64_t)B * HW * ncv;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i / ncv;
+        const int c0 = (int)(i % ncv) * VEC;
+        float xv[VEC], av[VEC], bv[VEC];
+        load_vec_f32(x + p * ldx + c0, xv);
+        if (gate) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) bv[q] = gate[(p / HW) * C + c0 + q];
+        } else {
+            load_vec_f32(b + p * ldb + c0, bv);
+        }
+        if (a) {
+            load_vec_f32(a + p * lda + c0, av);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) xv[q] = xv[q] + scale * av[q] * bv[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) xv[q] = xv[q] * bv[q];
+        }
+        store_vec_f32(y + p * ldy + c0, xv);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void weighted_sum_vec_kernel(const float* w, int ldw, int per_image, int E, Parts4 parts, int ldp, T* y, int ldy,
+                                                                int B, int HW, int C) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC;
+    const int64_t total = (int64_t)B * HW * ncv;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i / ncv;
+        const int c0 = (int)(i % ncv) * VEC;
+        const float* wr = w + (per_image ? p / HW : p) * ldw;
+        float r[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) r[q] = 0.f;
+        for (int e = 0; e < E; ++e) {
+            float v[VEC];
+            load_vec_f32(static_cast<const T*>(parts.p[e]) + p * ldp + c0, v);
+            const float we = wr[e];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) r[q] += we * v[q];
+        }
+        store_vec_f32(y + p * ldy + c0, r);
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int vecw(int dt) { return dt == YMK_BF16 ? 8 : 4; }
+
 }  // namespace
 
 #define LAUNCH(kern, total, ...) \
@@ -372,6 +561,12 @@ __global__ __launch_bounds__(256) void shuffle_cat_kernel(int dt, const void* a,
 extern "C" int ymk_activation(int32_t dtype, void* x, int32_t ldx, int64_t npix, int32_t C, int32_t act, void* stream) {
     if (!x || bad_dt(dtype) || C < 1 || ldx < C || act < YMK_ACT_NONE || act > YMK_ACT_GELU) return YMK_E_BADARG;
     if (npix <= 0 || act == YMK_ACT_NONE) return YMK_OK;
+    const int V = vecw(dtype);
+    if (C % V == 0 && ldx % V == 0 && al16(x)) {
+        if (dtype == YMK_BF16) LAUNCH(activation_vec_kernel<bf16_t>, npix * (C / V), (bf16_t*)x, ldx, npix, C, act);
+        else LAUNCH(activation_vec_kernel<float>, npix * (C / V), (float*)x, ldx, npix, C, act);
+        return ymk_launch_status();
+    }
     LAUNCH(activation_kernel, npix * C, x, dtype, ldx, npix, C, act);
     return ymk_launch_status();
 }
@@ -385,7 +580,26 @@ extern "C" int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y
     if ((weight == nullptr) != (bias == nullptr) || (affine_rows && !weight) || (residual && ldr < C)) return YMK_E_BADARG;
     if (act != YMK_ACT_NONE && act != YMK_ACT_SILU) return YMK_E_BADARG;
     if (B <= 0 || HW <= 0) return YMK_OK;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, dtype, ldx, HW, C, groups, eps, stats_ws);
+    const int V = vecw(dtype);
+    const bool vin = C % V == 0 && ldx % V == 0 && al16(x);
+    if (vin && (C / groups) % V == 0) {   // statistics: whole vectors inside a group
+        if (dtype == YMK_BF16)
+            hipLaunchKernelGGL(gn_stats_vec_kernel<bf16_t>, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, HW, C, groups, eps, stats_ws);
+        else
+            hipLaunchKernelGGL(gn_stats_vec_kernel<float>, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, HW, C, groups, eps, stats_ws);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, dtype, ldx, HW, C, groups, eps, stats_ws);
+    }
+    if (vin && out_dtype == dtype && ldy % V == 0 && al16(y) && (!residual || (ldr % V == 0 && al16(residual)))) {
+        const int64_t total = (int64_t)B * HW * (C / V);
+        if (dtype == YMK_BF16)
+            LAUNCH(gn_apply_vec_kernel<bf16_t>, total, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (const bf16_t*)residual, ldr, B, HW, C, groups, weight,
+                   bias, affine_rows, act, (const float*)stats_ws);
+        else
+            LAUNCH(gn_apply_vec_kernel<float>, total, (const float*)x, ldx, (float*)y, ldy, (const float*)residual, ldr, B, HW, C, groups, weight,
+                   bias, affine_rows, act, (const float*)stats_ws);
+        return ymk_launch_status();
+    }
     LAUNCH(gn_apply_kernel, (int64_t)B * HW * C, x, dtype, ldx, y, out_dtype, ldy, residual, ldr, B, HW, C, groups, weight, bias,
            affine_rows, act, (const float*)stats_ws);
     return ymk_launch_status();
@@ -395,6 +609,12 @@ extern "C" int ymk_layer_norm(int32_t dtype, const void* x, int32_t ldx, void* y
                               const float* weight, const float* bias, float eps, void* stream) {
     if (!x || !y || !weight || !bias || bad_dt(dtype) || C < 1 || ldx < C || ldy < C) return YMK_E_BADARG;
     if (npix <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    if (C % V == 0 && ldx % V == 0 && ldy % V == 0 && al16(x) && al16(y)) {
+        if (dtype == YMK_BF16) LAUNCH(ln_vec_kernel<bf16_t>, npix * 64, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, npix, C, weight, bias, eps);
+        else LAUNCH(ln_vec_kernel<float>, npix * 64, (const float*)x, ldx, (float*)y, ldy, npix, C, weight, bias, eps);
+        return ymk_launch_status();
+    }
     LAUNCH(ln_kernel, npix * 64, x, dtype, ldx, y, ldy, npix, C, weight, bias, eps);
     return ymk_launch_status();
 }
@@ -404,6 +624,12 @@ extern "C" int ymk_eltwise(int32_t op, int32_t dtype, const void* a, int32_t lda
     if (!a || !b || !y || bad_dt(dtype) || op < YMK_ELT_MUL || op > YMK_ELT_LERP || C < 1 || lda < C || ldb < C || ldy < C)
         return YMK_E_BADARG;
     if (npix <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    if (C % V == 0 && lda % V == 0 && ldb % V == 0 && ldy % V == 0 && al16(a) && al16(b) && al16(y)) {
+        if (dtype == YMK_BF16) LAUNCH(eltwise_vec_kernel<bf16_t>, npix * (C / V), op, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)y, ldy, npix, C, alpha);
+        else LAUNCH(eltwise_vec_kernel<float>, npix * (C / V), op, (const float*)a, lda, (const float*)b, ldb, (float*)y, ldy, npix, C, alpha);
+        return ymk_launch_status();
+    }
     LAUNCH(eltwise_kernel, npix * C, op, dtype, a, lda, b, ldb, y, ldy, npix, C, alpha);
     return ymk_launch_status();
 }
@@ -414,6 +640,18 @@ extern "C" int ymk_fma_gate(int32_t dtype, const void* x, int32_t ldx, const voi
     if (!x || !a || !b || !y || bad_dt(dtype) || C < 1 || ldx < C || lda < C || ldy < C) return YMK_E_BADARG;
     if (!b_per_image && (bad_dt(b_dtype) || ldb < C)) return YMK_E_BADARG;
     if (B <= 0 || HW <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    if (C % V == 0 && ldx % V == 0 && lda % V == 0 && ldy % V == 0 && al16(x) && al16(a) && al16(y) &&
+        (b_per_image || (b_dtype == dtype && ldb % V == 0 && al16(b)))) {
+        const int64_t total = (int64_t)B * HW * (C / V);
+        if (dtype == YMK_BF16)
+            LAUNCH(gate_vec_kernel<bf16_t>, total, (const bf16_t*)x, ldx, (const bf16_t*)a, lda, b_per_image ? nullptr : (const bf16_t*)b, ldb,
+                   b_per_image ? (const float*)b : nullptr, scale, (bf16_t*)y, ldy, B, HW, C);
+        else
+            LAUNCH(gate_vec_kernel<float>, total, (const float*)x, ldx, (const float*)a, lda, b_per_image ? nullptr : (const float*)b, ldb,
+                   b_per_image ? (const float*)b : nullptr, scale, (float*)y, ldy, B, HW, C);
+        return ymk_launch_status();
+    }
     LAUNCH(fma_gate_kernel, (int64_t)B * HW * C, dtype, x, ldx, a, lda, b, b_dtype, ldb, b_per_image, scale, y, ldy, B, HW, C);
     return ymk_launch_status();
 }
@@ -422,6 +660,15 @@ extern "C" int ymk_channel_gate(int32_t dtype, const void* x, int32_t ldx, const
                                 int32_t HW, int32_t C, void* stream) {
     if (!x || !gate || !y || bad_dt(dtype) || C < 1 || ldx < C || ldy < C) return YMK_E_BADARG;
     if (B <= 0 || HW <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    if (C % V == 0 && ldx % V == 0 && ldy % V == 0 && al16(x) && al16(y)) {
+        const int64_t total = (int64_t)B * HW * (C / V);
+        if (dtype == YMK_BF16)
+            LAUNCH(gate_vec_kernel<bf16_t>, total, (const bf16_t*)x, ldx, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, gate, 0.f, (bf16_t*)y, ldy, B, HW, C);
+        else
+            LAUNCH(gate_vec_kernel<float>, total, (const float*)x, ldx, (const float*)nullptr, 0, (const float*)nullptr, 0, gate, 0.f, (float*)y, ldy, B, HW, C);
+        return ymk_launch_status();
+    }
     LAUNCH(channel_gate_kernel, (int64_t)B * HW * C, dtype, x, ldx, gate, y, ldy, B, HW, C);
     return ymk_launch_status();
 }
@@ -434,6 +681,15 @@ extern "C" int ymk_weighted_sum(int32_t dtype, const float* w, int32_t ldw, int3
     for (int e = 0; e < E; ++e)
         if (!parts.p[e]) return YMK_E_BADARG;
     if (B <= 0 || HW <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    bool vok = C % V == 0 && ldp % V == 0 && ldy % V == 0 && al16(y);
+    for (int e = 0; e < E; ++e) vok = vok && al16(parts.p[e]);
+    if (vok) {
+        const int64_t total = (int64_t)B * HW * (C / V);
+        if (dtype == YMK_BF16) LAUNCH(weighted_sum_vec_kernel<bf16_t>, total, w, ldw, w_per_image, E, parts, ldp, (bf16_t*)y, ldy, B, HW, C);
+        else LAUNCH(weighted_sum_vec_kernel<float>, total, w, ldw, w_per_image, E, parts, ldp, (float*)y, ldy, B, HW, C);
+        return ymk_launch_status();
+    }
     LAUNCH(weighted_sum_kernel, (int64_t)B * HW * C, dtype, w, ldw, w_per_image, E, parts, ldp, y, ldy, B, HW, C);
     return ymk_launch_status();
 }

@@ -627,6 +627,12 @@ class _LocalConvTransformerExpert(nn.Module):
         lws = self.local_window_size
         if lws > 0 and H * W > lws * lws:
             o = ops.window_attention(qkv[..., :C], qkv[..., C:2 * C], v, nh, hd, hd ** -0.5, lws)
+        elif hd == 32:
+            # whole-map attention with 32-wide heads (the L-scale MoT blocks of BASELINE config 5: 6400 tokens at 1280 px,
+            # the dominant cost of the model) is exactly what the MFMA area-attention kernel of the A2C2f blocks computes:
+            # put v + pe(v) back into the V slice of the [Q | K | V] buffer (stream-ordered after the stencil) and reuse it
+            ops.copy_channels(v, qkv[..., 2 * C:])
+            o = ops.area_attn(qkv, nh, 1)
         else:
             o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], v, nh, hd, hd ** -0.5)
         x1 = ops.scale_residual(ops.conv2d(o, *pk["proj"], 1, 1, False), pk["ls1"], x)

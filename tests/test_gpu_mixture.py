@@ -122,6 +122,8 @@ def test_pools_stats_shuffle_gather(dtype):
     for groups in (1, 2, 4):
         got = ops.channel_shuffle_cat([_view(a, 8), b.to(DEV)], groups)
         assert torch.equal(got.cpu(), emu_ops.channel_shuffle_cat([a, b], groups)), f"shuffle groups {groups}"
+    a2 = _rnd(2, 7, 5, 40, seed=28, dtype=dtype)                     # equal halves, two groups: the vectorised even / odd interleave
+    assert torch.equal(ops.channel_shuffle_cat([a2.to(DEV), _view(b, 8)], 2).cpu(), emu_ops.channel_shuffle_cat([a2, b], 2))
     idx = torch.tensor([[2, 0], [1, 3]], dtype=torch.int32)
     for k, cin in ((3, 16), (1, 32)):
         xe = _rnd(2, 6, 7, cin, seed=26, dtype=dtype)

@@ -550,6 +550,157 @@ __global__ __launch_bounds__(256) void weighted_sum_vec_kernel(const float* w, i
     }
 }
 
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void pool_vec_kernel(const T* x, int ldx, TO* y, int ldy, int B, int H, int W, int C, int Ho, int Wo, int k) {
+    constexpr int VEC = 16 / (int)sizeof(T);   // input vector; an fp32 output of a bf16 input is written as two 16-byte stores
+    const int ncv = C / VEC;
+    const int64_t total = (int64_t)B * Ho * Wo * ncv;
+    GRID_STRIDE(i, total) {
+        const int c0 = (int)(i % ncv) * VEC;
+        int64_t p = i / ncv;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        int y0, y1, x0, x1;
+        if (k) {
+            y0 = oy * k; y1 = y0 + k; x0 = ox * k; x1 = x0 + k;
+        } else {
+            y0 = (int)(((int64_t)oy * H) / Ho); y1 = (int)((((int64_t)oy + 1) * H + Ho - 1) / Ho);
+            x0 = (int)(((int64_t)ox * W) / Wo); x1 = (int)((((int64_t)ox + 1) * W + Wo - 1) / Wo);
+        }
+        float s[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s[q] = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) {
+                float v[VEC];
+                load_vec_f32(x + (((int64_t)b * H + yy) * W + xx) * ldx + c0, v);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) s[q] += v[q];
+            }
+        const float inv = 1.0f / (float)((y1 - y0) * (x1 - x0));
+        TO* py = y + (((int64_t)b * Ho + oy) * Wo + ox) * ldy + c0;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) from_f32(py[q], s[q] * inv);   // contiguous: the compiler merges these into wide stores
+    }
+}
+// workgroup = 16 pixel lanes x 16 channel vectors of one image; grid (ceil(C / (16 * VEC)), B)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_stats_vec_kernel(const T* x, int ldx, float* out, int HW, int C, int want_std) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ float sh[16][16 * VEC + 1];
+    const int b = blockIdx.y, cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int c0 = (blockIdx.x * 16 + cl) * VEC;
+    const T* base = x + (int64_t)b * HW * ldx;
+    const int oc = want_std ? 2 * C : C;
+    float s[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) s[q] = 0.f;
+    if (c0 < C)
+        for (int p = r; p < HW; p += 16) {
+            float v[VEC];
+            load_vec_f32(base + (int64_t)p * ldx + c0, v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s[q] += v[q];
+        }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) sh[r][cl * VEC + q] = s[q];
+    __syncthreads();
+    float mean[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        float t = 0.f;
+        for (int rr = 0; rr < 16; ++rr) t += sh[rr][cl * VEC + q];
+        mean[q] = t / (float)HW;
+    }
+    __syncthreads();
+    if (r == 0 && c0 < C)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) out[(int64_t)b * oc + c0 + q] = mean[q];
+    if (!want_std) return;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) s[q] = 0.f;
+    if (c0 < C)
+        for (int p = r; p < HW; p += 16) {
+            float v[VEC];
+            load_vec_f32(base + (int64_t)p * ldx + c0, v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s[q] += (v[q] - mean[q]) * (v[q] - mean[q]);
+        }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) sh[r][cl * VEC + q] = s[q];
+    __syncthreads();
+    if (r == 0 && c0 < C)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float t = 0.f;
+            for (int rr = 0; rr < 16; ++rr) t += sh[rr][cl * VEC + q];
+            out[(int64_t)b * oc + C + c0 + q] = HW > 1 ? sqrtf(t / (float)HW) : 0.f;
+        }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mean_upsampled_vec_kernel(int n, Pyr4 a, T* y, int ldy, int B, int H, int W, int C) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC;
+    const int64_t total = (int64_t)B * H * W * ncv;
+    const float inv = 1.0f / (float)n;
+    GRID_STRIDE(i, total) {
+        const int c0 = (int)(i % ncv) * VEC;
+        int64_t p = i / ncv;
+        const int ox = (int)(p % W);
+        p /= W;
+        const int oy = (int)(p % H);
+        const int b = (int)(p / H);
+        float r[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) r[q] = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const int sy = (int)(((int64_t)oy * a.h[j]) / H), sx = (int)(((int64_t)ox * a.w[j]) / W);
+            float v[VEC];
+            load_vec_f32(static_cast<const T*>(a.p[j]) + (((int64_t)b * a.h[j] + sy) * a.w[j] + sx) * a.ld[j] + c0, v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) r[q] += v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) r[q] *= inv;
+        store_vec_f32(y + (((int64_t)b * H + oy) * W + ox) * ldy + c0, r);
+    }
+}
+// raw 16-byte copies: dtype only sets the element size
+__global__ __launch_bounds__(256) void expert_gather_vec_kernel(int es, const char* f, int64_t ldf_b, const int32_t* idx, int B, int HW, int ocv,
+                                                                 int K, int64_t oc_b, char* out) {
+    const int64_t total = (int64_t)K * B * HW * ocv;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % ocv);
+        int64_t p = i / ocv;
+        const int px = (int)(p % HW);
+        p /= HW;
+        const int b = (int)(p % B);
+        const int j = (int)(p / B);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(f + ((int64_t)b * HW + px) * ldf_b + (int64_t)idx[b * K + j] * oc_b + (int64_t)cv * 16);
+        *reinterpret_cast<u32x4*>(out + i * 16) = v;
+    }
+}
+// groups == 2, Ca == Cb: out = [a0 b0 a1 b1 ...]; one lane interleaves VEC/2 channels of each source into one vector
+template <typename T>
+__global__ __launch_bounds__(256) void shuffle2_vec_kernel(const T* a, int lda, const T* b, int ldb, int Ch, T* y, int ldy, int64_t npix) {
+    constexpr int VEC = 16 / (int)sizeof(T), HV = VEC / 2;
+    const int nh = Ch / HV;   // output vectors per pixel
+    const int64_t total = npix * nh;
+    GRID_STRIDE(i, total) {
+        const int h0 = (int)(i % nh) * HV;
+        const int64_t p = i / nh;
+        T o[VEC];
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            o[2 * q] = a[p * lda + h0 + q];
+            o[2 * q + 1] = b[p * ldb + h0 + q];
+        }
+        *reinterpret_cast<u32x4*>(y + p * ldy + 2 * h0) = *reinterpret_cast<const u32x4*>(o);
+    }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int vecw(int dt) { return dt == YMK_BF16 ? 8 : 4; }
 
@@ -704,6 +855,15 @@ extern "C" int ymk_mean_upsampled(int32_t dtype, int32_t n, const void* p0, cons
         a.h[j] = hs[j]; a.w[j] = ws[j]; a.ld[j] = lds[j];
     }
     if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    bool vok = C % V == 0 && ldy % V == 0 && al16(y);
+    for (int j = 0; j < n; ++j) vok = vok && a.ld[j] % V == 0 && al16(a.p[j]);
+    if (vok) {
+        const int64_t total = (int64_t)B * H * W * (C / V);
+        if (dtype == YMK_BF16) LAUNCH(mean_upsampled_vec_kernel<bf16_t>, total, n, a, (bf16_t*)y, ldy, B, H, W, C);
+        else LAUNCH(mean_upsampled_vec_kernel<float>, total, n, a, (float*)y, ldy, B, H, W, C);
+        return ymk_launch_status();
+    }
     LAUNCH(mean_upsampled_kernel, (int64_t)B * H * W * C, dtype, n, a, y, ldy, B, H, W, C);
     return ymk_launch_status();
 }
@@ -713,6 +873,14 @@ extern "C" int ymk_adaptive_avg_pool(int32_t dtype, const void* x, int32_t ldx, 
     if (!x || !y || bad_dt(dtype) || bad_dt(out_dtype) || C < 1 || ldx < C || ldy < C || Ho < 1 || Wo < 1 || H < 1 || W < 1)
         return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    if (C % V == 0 && ldx % V == 0 && ldy % V == 0 && al16(x) && al16(y) && (out_dtype == dtype || out_dtype == YMK_F32)) {
+        const int64_t total = (int64_t)B * Ho * Wo * (C / V);
+        if (dtype == YMK_F32) LAUNCH((pool_vec_kernel<float, float>), total, (const float*)x, ldx, (float*)y, ldy, B, H, W, C, Ho, Wo, 0);
+        else if (out_dtype == YMK_BF16) LAUNCH((pool_vec_kernel<bf16_t, bf16_t>), total, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, H, W, C, Ho, Wo, 0);
+        else LAUNCH((pool_vec_kernel<bf16_t, float>), total, (const bf16_t*)x, ldx, (float*)y, ldy, B, H, W, C, Ho, Wo, 0);
+        return ymk_launch_status();
+    }
     LAUNCH(pool_kernel, (int64_t)B * Ho * Wo * C, dtype, x, ldx, y, out_dtype, ldy, B, H, W, C, Ho, Wo, 0);
     return ymk_launch_status();
 }
@@ -721,6 +889,14 @@ extern "C" int ymk_avg_pool(int32_t dtype, const void* x, int32_t ldx, void* y, 
                             int32_t W, int32_t C, int32_t k, void* stream) {
     if (!x || !y || bad_dt(dtype) || bad_dt(out_dtype) || C < 1 || ldx < C || ldy < C || k < 1 || H < k || W < k) return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    if (C % V == 0 && ldx % V == 0 && ldy % V == 0 && al16(x) && al16(y) && (out_dtype == dtype || out_dtype == YMK_F32)) {
+        const int64_t total = (int64_t)B * (H / k) * (W / k) * (C / V);
+        if (dtype == YMK_F32) LAUNCH((pool_vec_kernel<float, float>), total, (const float*)x, ldx, (float*)y, ldy, B, H, W, C, (H / k), (W / k), k);
+        else if (out_dtype == YMK_BF16) LAUNCH((pool_vec_kernel<bf16_t, bf16_t>), total, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, H, W, C, (H / k), (W / k), k);
+        else LAUNCH((pool_vec_kernel<bf16_t, float>), total, (const bf16_t*)x, ldx, (float*)y, ldy, B, H, W, C, (H / k), (W / k), k);
+        return ymk_launch_status();
+    }
     LAUNCH(pool_kernel, (int64_t)B * (H / k) * (W / k) * C, dtype, x, ldx, y, out_dtype, ldy, B, H, W, C, H / k, W / k, k);
     return ymk_launch_status();
 }
@@ -729,6 +905,13 @@ extern "C" int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, floa
                                  int32_t want_std, void* stream) {
     if (!x || !out || bad_dt(dtype) || C < 1 || ldx < C || HW < 1 || B > 65535) return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    if (C % V == 0 && ldx % V == 0 && al16(x)) {
+        const dim3 grid((C / V + 15) / 16, B);
+        if (dtype == YMK_BF16) hipLaunchKernelGGL(channel_stats_vec_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, out, HW, C, want_std);
+        else hipLaunchKernelGGL(channel_stats_vec_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, out, HW, C, want_std);
+        return ymk_launch_status();
+    }
     hipLaunchKernelGGL(channel_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dtype, x, ldx, out, HW, C,
                        want_std);
     return ymk_launch_status();
@@ -758,6 +941,12 @@ extern "C" int ymk_expert_gather(int32_t dtype, const void* f_all, int32_t ldf, 
                                  int32_t K, int32_t E, void* out, void* stream) {
     if (!f_all || !idx || !out || bad_dt(dtype) || OC < 1 || K < 1 || E < 1 || ldf < E * OC) return YMK_E_BADARG;
     if (B <= 0 || HW <= 0) return YMK_OK;
+    const int V = vecw(dtype), es = dtype == YMK_BF16 ? 2 : 4;
+    if (OC % V == 0 && ldf % V == 0 && al16(f_all) && al16(out)) {
+        LAUNCH(expert_gather_vec_kernel, (int64_t)K * B * HW * (OC / V), es, (const char*)f_all, (int64_t)ldf * es, idx, B, HW, OC / V, K,
+               (int64_t)OC * es, (char*)out);
+        return ymk_launch_status();
+    }
     LAUNCH(expert_gather_kernel, (int64_t)K * B * HW * OC, dtype, f_all, ldf, idx, B, HW, OC, K, out);
     return ymk_launch_status();
 }
@@ -768,6 +957,13 @@ extern "C" int ymk_channel_shuffle_cat(int32_t dtype, const void* a, int32_t lda
         ldy < Ca + Cb)
         return YMK_E_BADARG;
     if (npix <= 0) return YMK_OK;
+    const int V = vecw(dtype);
+    if (groups == 2 && Ca == Cb && Ca % (V / 2) == 0 && ldy % V == 0 && al16(y)) {   // the gated block's case: even / odd interleave
+        const int64_t total = npix * (Ca / (V / 2));
+        if (dtype == YMK_BF16) LAUNCH(shuffle2_vec_kernel<bf16_t>, total, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, Ca, (bf16_t*)y, ldy, npix);
+        else LAUNCH(shuffle2_vec_kernel<float>, total, (const float*)a, lda, (const float*)b, ldb, Ca, (float*)y, ldy, npix);
+        return ymk_launch_status();
+    }
     LAUNCH(shuffle_cat_kernel, npix * (Ca + Cb), dtype, a, lda, Ca, b, ldb, Cb, groups, y, ldy, npix);
     return ymk_launch_status();
 }

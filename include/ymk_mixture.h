@@ -1,10 +1,12 @@
 /* libymk — C-ABI of the config-5 rows (MoA / MoT / gated MoE), SURVEY.md §8 rows a11 / a12 and §8(f) rank 1.
  *
- * STATUS: first implementation, correctness-first (VALU kernels, one element / token / query per thread, no MFMA,
- * no fusion).  Written after the round-1 GPU budget was spent: the kernels COMPILE for gfx950 but have NOT RUN on
- * hardware yet.  The Python wrappers therefore keep them switched off unless YMK_EXPERIMENTAL=1 is set
- * (yolo_master_amd/ops.py), and their parity tests (tests/test_gpu_mixture.py, against tests/emu_ops.py and the
- * oracles) are the first GPU job of the next round.  Nothing of the validated v0 path calls into this file.
+ * STATUS: first implementation (fp32 arithmetic on the VALU, 16-byte vector memory paths where operands allow, one
+ * token / query per lane in the attention forms, no fusion yet).  Written after the round-1 GPU budget was spent: the
+ * kernels compile for gfx950 and their LOGIC is verified on the CPU lane emulator (tests/hostemu,
+ * tests/test_hostemu_mixture.py: every entry point in fp32 / bf16, the reference's module fixtures, the whole config-5
+ * detector), but they have NOT RUN on hardware yet.  The Python wrappers therefore keep them switched off unless
+ * YMK_EXPERIMENTAL=1 is set (yolo_master_amd/ops.py), and their GPU parity tests (tests/test_gpu_mixture.py) are the
+ * first GPU job of the next round.  Nothing of the validated v0 path calls into this file.
  *
  * Conventions as in ymk.h: NHWC views with pixel strides (elements), activations YMK_F32 / YMK_BF16, statistics /
  * gates / router tensors fp32, `stream` a hipStream_t, return 0 or a negative YMK_E_* code, no allocation, no sync.
@@ -87,10 +89,11 @@ int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int32_t ldw, i
                       int32_t n, float inv_temp, int32_t top_k, void* stream);
 
 /* Decision tail of the gated MoE (moe/gated.py:124-166, 455-492), one workgroup.  g / loc fp32 [B][ld*] logits of the
- * two router streams, cplx fp32 [B][ldc] complexity logit; outputs w fp32 [B][top_k], idx int32 [B][top_k],
- * probs fp32 [B][E].  E <= 64, top_k <= 8. */
+ * two router streams, cplx fp32 [B][ldc] complexity logit; outputs w fp32 [B][top_k], idx int32 [B][top_k] (and its
+ * transpose), probs fp32 [B][E].  E <= 64, top_k <= 8. */
 int ymk_gated_route_decide(const float* g, int32_t ldg, const float* loc, int32_t ldloc, const float* cplx, int32_t ldc,
                            int32_t B, int32_t E, float alpha, float inv_temp, int32_t top_k, float* w, int32_t* idx,
+                           int32_t* idx_slot_major /* [top_k][B]: the expert of image j*B + b of ymk_expert_gather's output */,
                            float* probs, void* stream);
 
 /* out[(j*B + b)][p][:] = f_all[b][p][idx[b][j]*OC : +OC] — the routed experts' slices of the all-expert convolution

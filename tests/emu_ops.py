@@ -510,7 +510,8 @@ def gated_route_decide(g_logits, loc_logits, alpha, inv_temp, top_k, cplx_logit)
         keep = torch.round(c * top_k).clamp(1, top_k)
         tw = tw * (torch.arange(1, top_k + 1).view(1, -1) <= keep).float()
         tw = tw / tw.sum(1, keepdim=True).clamp_min(1e-6)
-    return tw.reshape(B, 1, 1, top_k), ti.to(torch.int32), probs
+    ti = ti.to(torch.int32)
+    return tw.reshape(B, 1, 1, top_k), ti, probs, ti.t().contiguous().reshape(-1)
 
 
 def expert_conv(x, w_packed, k, idx, out=None):

@@ -149,9 +149,9 @@ def test_router_tails():
     for B, E, k, bias in ((5, 4, 2, 20.0), (3, 8, 2, -20.0), (4, 16, 2, 0.0), (3, 6, 3, 0.3), (2, 4, 1, 0.0)):
         g, loc = _rnd(B, 1, 1, E, seed=32 + B, scale=2.0), _rnd(B, 1, 1, E, seed=33 + E)
         cp = _rnd(B, 1, 1, 1, seed=34) + bias
-        w, idx, probs = ops.gated_route_decide(g.to(DEV), loc.to(DEV), 0.4, 1 / 1.2, k, cp.to(DEV))
-        rw, ridx, rprobs = emu_ops.gated_route_decide(g, loc, 0.4, 1 / 1.2, k, cp)
-        assert torch.equal(idx.cpu(), ridx), f"routed experts B={B} E={E}"
+        w, idx, probs, rows = ops.gated_route_decide(g.to(DEV), loc.to(DEV), 0.4, 1 / 1.2, k, cp.to(DEV))
+        rw, ridx, rprobs, rrows = emu_ops.gated_route_decide(g, loc, 0.4, 1 / 1.2, k, cp)
+        assert torch.equal(idx.cpu(), ridx) and torch.equal(rows.cpu(), rrows), f"routed experts B={B} E={E}"
         _cmp(w, rw, torch.float32, "gate weights")
         _cmp(probs, rprobs, torch.float32, "gate probs")
 

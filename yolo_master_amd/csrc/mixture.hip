@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void token_softmax_kernel(const float* logits,
 // one workgroup: complexity (batch mean) first, then one image per thread
 __global__ __launch_bounds__(256) void gated_decide_kernel(const float* g, int ldg, const float* loc, int ldloc, const float* cplx,
                                                             int ldc, int B, int E, float alpha, float inv_temp, int top_k, float* w,
-                                                            int32_t* idx, float* probs) {
+                                                            int32_t* idx, int32_t* idx_sm, float* probs) {
     __shared__ float sh[4];
     float cs = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) cs += 1.0f / (1.0f + expf(-cplx[(int64_t)b * ldc]));
@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void gated_decide_kernel(const float* g, int l
                 if (!((taken >> e) & 1ull) && pr[e] > bv) { bv = pr[e]; best = e; }
             taken |= 1ull << best;
             idx[(int64_t)b * top_k + j] = best;
+            idx_sm[(int64_t)j * B + b] = best;
             tw[j] = bv;
             tsum += bv;
         }
@@ -927,13 +928,13 @@ extern "C" int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int
 
 extern "C" int ymk_gated_route_decide(const float* g, int32_t ldg, const float* loc, int32_t ldloc, const float* cplx, int32_t ldc,
                                       int32_t B, int32_t E, float alpha, float inv_temp, int32_t top_k, float* w, int32_t* idx,
-                                      float* probs, void* stream) {
-    if (!g || !loc || !cplx || !w || !idx || !probs || E < 1 || E > 64 || top_k < 1 || top_k > 8 || top_k > E || ldg < E ||
+                                      int32_t* idx_slot_major, float* probs, void* stream) {
+    if (!g || !loc || !cplx || !w || !idx || !idx_slot_major || !probs || E < 1 || E > 64 || top_k < 1 || top_k > 8 || top_k > E || ldg < E ||
         ldloc < E || ldc < 1)
         return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
     hipLaunchKernelGGL(gated_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g, ldg, loc, ldloc, cplx, ldc, B, E, alpha,
-                       inv_temp, top_k, w, idx, probs);
+                       inv_temp, top_k, w, idx, idx_slot_major, probs);
     return ymk_launch_status();
 }
 

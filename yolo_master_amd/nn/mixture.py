@@ -337,9 +337,8 @@ class VisualEnhancedAdaptiveGateMoE(YmkModule):
         hn = h if red == rp else torch.zeros(h.shape, dtype=h.dtype, device=h.device)   # pad channels must stay zero
         ops.group_norm(h[..., :red], gs(red, 4), *pk["lc4"], 1e-5, act="silu", out=hn[..., :red])
         loc = ops.channel_stats(ops.conv2d(hn, *pk["lc6"], 1, 1, False))[..., :E]
-        w, idx, probs = ops.gated_route_decide(g_logits, loc, pk["alpha"], pk["inv_temp"], k, cplx)
-        self.last_route = {"weights": w, "indices": idx, "probs": probs}
-        rows = idx.t().contiguous().reshape(-1)                     # expert of image j*B + b in the slot-major expert batch
+        w, idx, probs, rows = ops.gated_route_decide(g_logits, loc, pk["alpha"], pk["inv_temp"], k, cplx)
+        self.last_route = {"weights": w, "indices": idx, "probs": probs}   # rows: expert of image j*B + b in the slot-major expert batch
         # routed experts: only the selected experts' filter rows run
         OC = self.out_dynamic
         if self.expert_backend == "low_rank_fused":

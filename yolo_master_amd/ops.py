@@ -686,7 +686,8 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
     """Decision tail of the gated MoE (moe/gated.py:124-166, 455-492): logits = clamp(a*g + (1-a)*loc, +-30) with
     a = sigmoid(alpha); probs = softmax(logits * inv_temp); top-k, weights / (sum + 1e-6); complexity = clamp(mean_b
     sigmoid(cplx_logit[b]), 0.3, 1.5) (1.0 when non-finite) keeps round(c * top_k) in [1, top_k] ranked experts and
-    renormalises (clamp 1e-6).  Inputs fp32 [B,1,1,E] / [B,1,1,1]; returns (w fp32 [B,1,1,top_k], idx int32 [B,top_k], probs)."""
+    renormalises (clamp 1e-6).  Inputs fp32 [B,1,1,E] / [B,1,1,1]; returns (w fp32 [B,1,1,top_k], idx int32 [B,top_k], probs,
+    rows int32 [top_k*B] = idx transposed: the expert of image j*B + b in expert_conv's slot-major output)."""
     _gate("gated_route_decide")
     B, E = g_logits.shape[0], g_logits.shape[-1]
     for t in (g_logits, loc_logits, cplx_logit):
@@ -695,11 +696,12 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
     dev = g_logits.device
     w = torch.empty((B, 1, 1, top_k), dtype=torch.float32, device=dev)
     idx = torch.empty((B, top_k), dtype=torch.int32, device=dev)
+    rows = torch.empty((top_k * B,), dtype=torch.int32, device=dev)
     probs = torch.empty((B, E), dtype=torch.float32, device=dev)
     check(lib.ymk_gated_route_decide(_p(g_logits), g_logits.stride(0), _p(loc_logits), loc_logits.stride(0), _p(cplx_logit),
-                                     cplx_logit.stride(0), B, E, float(alpha), float(inv_temp), int(top_k), _p(w), _p(idx), _p(probs),
-                                     _stream()), "gated_route_decide")
-    return w, idx, probs
+                                     cplx_logit.stride(0), B, E, float(alpha), float(inv_temp), int(top_k), _p(w), _p(idx), _p(rows),
+                                     _p(probs), _stream()), "gated_route_decide")
+    return w, idx, probs, rows
 
 
 def expert_conv(x, w_packed, k: int, idx, out=None):

@@ -1,6 +1,6 @@
 /* libymk — opt-in entry points that are NOT part of the validated surface of ymk.h yet.
  *
- * ymk_conv2d_glds: the next tiled implicit-GEMM core (csrc/conv_glds.hip): 256-pixel x 64/128-cout
+ * (1) ymk_conv2d_glds: the next tiled implicit-GEMM core (csrc/conv_glds.hip): 256-pixel x 64/128-cout
  * tiles on 8 waves, both operands staged into LDS by global_load_lds with a source-side swizzle, 2- or 3-stage k-loop,
  * XCD-aware tile order.  Same arguments and result as ymk_conv2d (ymk.h) plus `two_stage` (0 = three LDS stages with a
  * counted vmcnt, 1 = two stages with a plain barrier); bf16 only, Cin % 64 == 0, Cout % 64 == 0, otherwise YMK_E_BADARG.
@@ -15,6 +15,15 @@ extern "C" {
 #endif
 int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                     int32_t two_stage, void* stream);
+
+/* The step after the hot path: scale_boxes + clip_boxes (ultralytics/utils/ops.py:119-205, called
+ * per image by models/yolo/detect/predict.py:109-122), batched and in place over padded detections.
+ * dets fp32 [B][max_det] rows of `ld` >= 4 floats (x1, y1, x2, y2, ...); counts int32 [B] valid rows per image (NULL = all);
+ * params fp32 [B][5] = (gain, pad_x, pad_y, w0, h0) per image, computed by the host exactly as the reference does (Python
+ * doubles, round-half-even; gain rounded to fp32).  padding / xywh as in the reference.  Bit-exact against the reference's
+ * golden vectors on the CPU lane emulator (tests/test_hostemu_post.py); opt-in until it has run on hardware. */
+int ymk_scale_boxes(float* dets, int32_t ld, const int32_t* counts, const float* params, int32_t B, int32_t max_det,
+                    int32_t padding, int32_t xywh, void* stream);
 #ifdef __cplusplus
 }
 #endif

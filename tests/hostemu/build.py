@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
 CSRC = ROOT / "yolo_master_amd" / "csrc"
 OUT = HERE / "_build"
-SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip"]
+SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip"]
 
 
 def compiler():
@@ -46,7 +46,7 @@ def build(force: bool = False) -> Path | None:
         u = OUT / (s.stem + "_host.cpp")
         u.write_text(txt)
         units.append(str(u))
-    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DYMK_HOST_EMU", f"-I{HERE}", *units, "-o", str(lib)]
+    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DYMK_HOST_EMU", "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(lib)]
     subprocess.run(cmd, check=True)
     return lib
 

@@ -45,3 +45,27 @@ def test_model_with_the_new_core_enabled(enable):
         outs.append(torch.load(path))
     d = (outs[0] - outs[1]).abs()
     assert float(d[:, 4:].median()) < 2e-3 and float(d[:, :4].median()) < 0.5, (float(d[:, 4:].median()), float(d[:, :4].median()))
+
+
+def test_scale_boxes_vs_reference_golden(golden_dir):
+    """Bit-exact against the real reference's vectors (tests/golden/make_golden_post.py), single image and batched."""
+    import numpy as np
+
+    from tests.test_oracle_post import cases
+    from yolo_master_amd import postprocess
+
+    cs = list(cases(golden_dir))
+    for c in cs:
+        boxes = torch.from_numpy(c["boxes"].copy()).to("cuda:0")
+        postprocess.scale_boxes(c["img1"], boxes, c["img0"], ratio_pad=c["ratio_pad"], padding=c["padding"], xywh=c["xywh"])
+        assert np.array_equal(boxes[:, :4].cpu().numpy(), c["out"]), (c["img1"], c["img0"])
+    sel = [c for c in cs if c["img1"] == (640, 640) and c["padding"] and not c["xywh"] and c["ratio_pad"] is None]
+    dets = torch.full((len(sel), 50, 6), -3.0)
+    for b, c in enumerate(sel):
+        dets[b, :37] = torch.from_numpy(c["boxes"])
+    counts = torch.tensor([37, 20, 0, 37, 5][: len(sel)], dtype=torch.int32)
+    d = dets.to("cuda:0")
+    postprocess.scale_detections((640, 640), d, counts.to("cuda:0"), [c["img0"] for c in sel])
+    for b, c in enumerate(sel):
+        n = int(counts[b])
+        assert np.array_equal(d[b, :n, :4].cpu().numpy(), c["out"][:n]) and torch.equal(d[b, n:].cpu(), dets[b, n:])

@@ -1,0 +1,32 @@
+"""scale_boxes / clip_boxes oracle against golden vectors from the REAL reference
+(tests/golden/make_golden_post.py).  CPU only."""
+import numpy as np
+
+from oracle import post_ref
+
+
+def cases(golden_dir):
+    z = np.load(golden_dir / "post_scale.npz")
+    for i in range(int(z["n"])):
+        m = z[f"c{i}_meta"]
+        rp = z[f"c{i}_rp"]
+        yield dict(img1=(int(m[0]), int(m[1])), img0=(int(m[2]), int(m[3])), padding=bool(m[4]), xywh=bool(m[5]),
+                   ratio_pad=((float(rp[0]), float(rp[0])), (float(rp[1]), float(rp[2]))) if m[6] else None,
+                   boxes=z[f"c{i}_boxes"], out=z[f"c{i}_out"])
+
+
+def test_scale_boxes_oracle_is_bit_exact(golden_dir):
+    n = 0
+    for c in cases(golden_dir):
+        got = post_ref.scale_boxes(c["img1"], c["boxes"][:, :4], c["img0"], ratio_pad=c["ratio_pad"], padding=c["padding"], xywh=c["xywh"])
+        assert np.array_equal(got, c["out"]), (c["img1"], c["img0"])
+        if not c["xywh"]:
+            assert (got[:, [0, 2]] >= 0).all() and (got[:, [0, 2]] <= c["img0"][1]).all() and (got[:, [1, 3]] <= c["img0"][0]).all()
+        n += 1
+    assert n == 10
+
+
+def test_letterbox_params_round_half_even():
+    # 500x375 into 640x384: gain 1.024, width fills, rows padded 0 / 1 -> the -0.1 nudge decides
+    assert post_ref.letterbox_params((384, 640), (375, 500)) == (1.024, 64, 0)
+    assert post_ref.letterbox_params((640, 640), (480, 640)) == (1.0, 0, 80)

@@ -1,0 +1,58 @@
+"""The step right after the hot path: detections back to original-image coordinates.
+
+``scale_boxes`` mirrors ``ultralytics.utils.ops.scale_boxes`` (utils/ops.py:119-174: same arguments, in place, returns the
+tensor); ``scale_detections`` is the batched form over the padded output of ``nms_padded`` (what
+``DetectionPredictor.construct_result`` does per image, models/yolo/detect/predict.py:109-122).  The letterbox parameters
+are computed on the host with the reference's own arithmetic (Python doubles, round-half-even); the arithmetic on the boxes
+runs in libymk (``ymk_scale_boxes``, include/ymk_next.h) — opt-in (YMK_EXPERIMENTAL=1) until it has run on hardware; there is
+no CPU / PyTorch fallback."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+
+def letterbox_params(img1_shape, img0_shape, ratio_pad=None):
+    """(gain, pad_x, pad_y) as scale_boxes derives them (utils/ops.py:141-147)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad_x = round((img1_shape[1] - round(img0_shape[1] * gain)) / 2 - 0.1)
+        pad_y = round((img1_shape[0] - round(img0_shape[0] * gain)) / 2 - 0.1)
+    else:
+        gain = ratio_pad[0][0]
+        pad_x, pad_y = ratio_pad[1]
+    return gain, pad_x, pad_y
+
+
+def _params(img1_shape, img0_shapes, ratio_pads, device):
+    rows = []
+    for i, s0 in enumerate(img0_shapes):
+        gain, px, py = letterbox_params(img1_shape, s0, None if ratio_pads is None else ratio_pads[i])
+        rows.append([gain, px, py, s0[1], s0[0]])
+    return torch.tensor(rows, dtype=torch.float32).to(device)
+
+
+def scale_detections(img1_shape, dets: torch.Tensor, counts: torch.Tensor | None, img0_shapes, ratio_pads=None, padding: bool = True,
+                     xywh: bool = False) -> torch.Tensor:
+    """dets fp32 [B, max_det, >=4] (as returned by nms_padded), rescaled in place image by image."""
+    ops._gate("scale_boxes")
+    ops.require_gpu(dets, "yolo_master_amd post-processing")
+    if dets.dtype != torch.float32 or dets.dim() != 3 or dets.stride(2) != 1 or dets.stride(0) != dets.shape[1] * dets.stride(1):
+        raise ValueError("scale_detections: fp32 [B, max_det, >=4] detections with contiguous rows")
+    B, max_det = dets.shape[:2]
+    if len(img0_shapes) != B:
+        raise ValueError("scale_detections: one original shape per image")
+    params = _params(img1_shape, img0_shapes, ratio_pads, dets.device)
+    check(lib.ymk_scale_boxes(ops._p(dets), dets.stride(1), ops._p(counts), ops._p(params), B, max_det, int(padding), int(xywh),
+                              ops._stream()), "scale_boxes")
+    return dets
+
+
+def scale_boxes(img1_shape, boxes: torch.Tensor, img0_shape, ratio_pad=None, padding: bool = True, xywh: bool = False) -> torch.Tensor:
+    """ultralytics.utils.ops.scale_boxes for one image: boxes fp32 [N, >=4] on the GPU, modified in place and returned."""
+    if boxes.dim() != 2:
+        raise ValueError("scale_boxes: boxes [N, >=4]")
+    scale_detections(img1_shape, boxes.unsqueeze(0), None, [img0_shape], None if ratio_pad is None else [ratio_pad], padding, xywh)
+    return boxes

@@ -104,10 +104,17 @@ def test_no_cpu_fallback():
 
 
 def test_product_never_imports_oracle():
+    """Neither the oracle nor the test-side emulations (tests/emu_ops.py: torch restatement of the C-ABI contracts;
+    tests/hostemu: CPU lane emulator) are reachable from the product: no import statement mentions them."""
+    import re
+
     root = Path(__file__).resolve().parent.parent / "yolo_master_amd"
     for f in root.rglob("*.py"):
         txt = f.read_text()
         assert "import oracle" not in txt and "from oracle" not in txt, f
+        for line in txt.splitlines():
+            if re.match(r"\s*(import|from)\s", line):
+                assert "tests" not in line.split() and "emu_ops" not in line and "hostemu" not in line, f"{f}: {line}"
 
 
 def test_lx_scale_host_logic():

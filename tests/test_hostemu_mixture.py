@@ -104,3 +104,41 @@ def test_conv256_probe_on_the_emulator():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
     assert "RESULT: all variants match the naive convolution" in r.stdout
     assert r.stdout.count(" OK") == 21 and "MISMATCH" not in r.stdout
+
+
+def test_kernels_config5_L_scale_model(T):
+    """BASELINE config 5's own shape (L scale: MoA heads of 21 -> 24 channels, random-feature basis with nb != padded head
+    width, 16-expert shared-inverted block, 512-channel maps) through the emulated kernels, layer by layer against the oracle."""
+    import copy
+
+    import yaml
+
+    from oracle import model_ref
+    from tests.helpers import fill_by_name
+    from yolo_master_amd.nn.tasks import CFG_DIR, DetectionModel
+
+    d = yaml.safe_load(open(CFG_DIR / "yolo-master-moa-mot.yaml"))
+    d["scales"]["l"] = [1.0, 1.0, 512]
+    d["scale"] = "l"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DetectionModel(copy.deepcopy(d))
+    spec = {k: list(v.shape) for k, v in m.state_dict().items() if v.is_floating_point() and v.dim() > 0 and not k.endswith("_rf_matrix")}
+    full = dict(m.state_dict())
+    full.update(fill_by_name(spec, seed=9, gain=0.7))
+    m.load_state_dict(full)
+    m.eval()
+    x = torch.rand(1, 3, 160, 128, generator=torch.Generator().manual_seed(1))
+    taps, otaps = {}, {}
+    with torch.inference_mode():
+        y, _ = m._predict_once(x, taps=taps)
+        oy, _, _ = model_ref.forward(copy.deepcopy(d), dict(m.state_dict()), x, fused=False, taps=otaps)
+    for i in range(len(m.model) - 1):
+        t = taps[i] if torch.is_tensor(taps[i]) else taps[i].materialise()
+        err = float((emu_ops.nhwc_to_nchw_f32(t) - otaps[i]).abs().max() / max(1.0, float(otaps[i].abs().max())))
+        assert err <= 1e-4, f"layer {i} ({type(m.model[i]).__name__}): scaled max error {err:.3e}"
+    assert float((y[:, 4:] - oy[:, 4:]).abs().max()) <= 1e-5
+    m.set_compute_dtype(torch.bfloat16)             # bf16 kernels at these widths: finite, and the vector paths' alignment holds
+    with torch.inference_mode():
+        yb, _ = m._predict_once(x)
+    assert bool(torch.isfinite(yb).all())

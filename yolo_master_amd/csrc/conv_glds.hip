@@ -171,22 +171,35 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         }
     }
 
-    // ---- epilogue: bias, activation, residual, 4 consecutive couts per lane ---------------------------------------------
+    // ---- epilogue: bias, activation, residual, 4 consecutive couts per lane.  All operand loads are issued first (rows past
+    //      the end clamped to the last pixel) so that they overlap: one wait instead of one per fragment ---------------------
+    f32x4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(a.bias + n0 + ((wave % WN) * 4 + i) * 16 + fc * 4);
+    u32x2 rr[4][TP];
+    if (a.res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int p = min(m0 + ((wave / WN) * TP + j) * 16 + fr, M - 1);
+                rr[i][j] = load_raw4(a.res + (size_t)p * a.ldr + n0 + ((wave % WN) * 4 + i) * 16 + fc * 4);
+            }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int co = n0 + ((wave % WN) * 4 + i) * 16 + fc * 4;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int p = m0 + ((wave / WN) * TP + j) * 16 + fr;
-            if (p >= M) continue;
-            float v0 = acc[i][j].x + bv.x, v1 = acc[i][j].y + bv.y, v2 = acc[i][j].z + bv.z, v3 = acc[i][j].w + bv.w;
+            float v0 = acc[i][j].x + bv[i].x, v1 = acc[i][j].y + bv[i].y, v2 = acc[i][j].z + bv[i].z, v3 = acc[i][j].w + bv[i].w;
             if (a.act == YMK_ACT_SILU) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
             if (a.res) {
                 float r0, r1, r2, r3;
-                load4(a.res + (size_t)p * a.ldr + co, r0, r1, r2, r3);
+                unpack_raw4(rr[i][j], r0, r1, r2, r3);
                 v0 += r0; v1 += r1; v2 += r2; v3 += r3;
             }
+            if (p >= M) continue;
             if (a.out_f32) store4(static_cast<float*>(a.y) + (size_t)p * a.ldy + co, v0, v1, v2, v3);
             else store4(static_cast<bf16_t*>(a.y) + (size_t)p * a.ldy + co, v0, v1, v2, v3);
         }

@@ -16,6 +16,11 @@ extern "C" {
 int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                     int32_t two_stage, void* stream);
 
+/* Virtual-concatenation form of the same core: arguments and result of ymk_conv1x1_cat2 (ymk.h) + two_stage; bf16, C1 and
+ * Cin - C1 multiples of 64, Cout % 64 == 0, otherwise YMK_E_BADARG.  Same opt-in switch. */
+int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
+                          int32_t ldx2, const void* w, const float* bias, void* y, int32_t two_stage, void* stream);
+
 /* The step after the hot path: scale_boxes + clip_boxes (ultralytics/utils/ops.py:119-205, called
  * per image by models/yolo/detect/predict.py:109-122), batched and in place over padded detections.
  * dets fp32 [B][max_det] rows of `ld` >= 4 floats (x1, y1, x2, y2, ...); counts int32 [B] valid rows per image (NULL = all);

@@ -9,7 +9,7 @@ import sys
 import pytest
 import torch
 
-from tests.test_hostemu_conv import CASES, run_case
+from tests.test_hostemu_conv import CASES, CAT2_CASES, run_case, run_cat2_case
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("YMK_EXPERIMENTAL") != "1", reason="opt-in kernels are not validated on hardware yet")]
@@ -23,6 +23,14 @@ def test_conv2d_glds_direct(case):
     from yolo_master_amd import _lib
 
     run_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", CAT2_CASES + [(4, 80, 80, 256, 256, 128, True, True, 0, 0, 0, 0), (4, 40, 40, 512, 256, 256, True, True, 0, 0, 0, 1)])
+def test_conv1x1_cat2_glds_direct(case):
+    from yolo_master_amd import _lib
+
+    run_cat2_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
 
 

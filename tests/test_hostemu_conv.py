@@ -100,3 +100,45 @@ def test_conv2d_glds_rejects_what_it_does_not_cover(hostlib):
                  _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, 1, 4, 4, 64, 80, 3, 1, 64, 80, 0, 576, 1),      # Cout % 64
                  _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, 1, 4, 4, 64, 64, 3, 1, 64, 64, 0, 640, 1)):     # padded K
         assert hostlib.ymk_conv2d_glds(C.byref(desc), p(x), p(w), p(b), None, p(y), 0, None) == -1
+
+
+CAT2_CASES = [
+    # B, H, W, C1, C2, Cout, upsample first source, act, x1 pad, x2 pad, y pad, two_stage
+    (2, 10, 14, 64, 64, 128, True, True, 0, 0, 0, 0),
+    (1, 12, 10, 128, 64, 64, False, True, 64, 8, 64, 1),
+    (2, 6, 22, 64, 192, 192, True, False, 0, 0, 0, 0),        # BN = 64, ragged tail, three cout tiles
+    (3, 8, 8, 256, 128, 128, False, True, 0, 64, 0, 0),
+]
+
+
+def run_cat2_case(lib, case, dev="cpu", stream=None):
+    from yolo_master_amd import _lib, ops
+
+    B, H, W, C1, C2, Cout, up, act, p1, p2, py, two = case
+    bf = torch.bfloat16
+    h1, w1 = (H // 2, W // 2) if up else (H, W)
+    x1, x2 = _rnd(B, h1, w1, C1, seed=11).to(bf), _rnd(B, H, W, C2, seed=12).to(bf)
+    wp = ops.pack_conv_weight(_rnd(Cout, C1 + C2, 1, 1, seed=13, scale=(C1 + C2) ** -0.5), bf)
+    bias = _rnd(Cout, seed=14, scale=0.2)
+    ref = emu_ops.conv1x1_cat2(x1, up, x2, wp, bias, act)
+    ybuf = torch.full((B, H, W, Cout + py), 7.0, dtype=bf, device=dev)
+    y = ybuf[..., :Cout]
+    x1d, x2d, wd, bd = _wide(x1, p1, dev), _wide(x2, p2, dev), wp.to(dev), bias.to(dev)
+    d = _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, B, H, W, C1 + C2, Cout, 1, 1, x1d.stride(2), y.stride(2), 0, wp.shape[1],
+                      _lib.ACT_SILU if act else _lib.ACT_NONE)
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    rc = lib.ymk_conv1x1_cat2_glds(C.byref(d), p(x1d), C1, x1d.stride(2), int(up), p(x2d), x2d.stride(2), p(wd), p(bd), p(y), two, stream)
+    assert rc == 0
+    err = float((y.float().cpu() - ref.float()).abs().max())
+    assert err <= 1.6e-2 * max(1.0, float(ref.float().abs().max())), f"max |d| {err:.3e}"
+    if py:
+        assert float((ybuf[..., Cout:].float().cpu() - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", CAT2_CASES)
+def test_conv1x1_cat2_glds_on_the_emulator(hostlib, case):
+    from yolo_master_amd import _lib
+
+    fn = hostlib.ymk_conv1x1_cat2_glds
+    fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_conv1x1_cat2_glds"]
+    run_cat2_case(hostlib, case)

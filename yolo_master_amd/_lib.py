@@ -100,6 +100,7 @@ SYMBOLS_MIXTURE = {
 # include/ymk_next.h: opt-in entry points outside the validated surface
 SYMBOLS_NEXT = {
     "ymk_conv2d_glds": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ymk_conv1x1_cat2_glds": (C.c_int, [C.POINTER(ConvDesc), _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "ymk_scale_boxes": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
 }
 ACT_SIGMOID, ACT_GELU = 2, 3

@@ -24,6 +24,8 @@ extern "C" void ymk_debug_set_ws(int on) { ymk_use_ws = on; }
 static thread_local int ymk_last_variant = YMK_CONV_TILED;
 extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
                                void* y, int32_t two_stage, void* stream);   // csrc/conv_glds.hip, include/ymk_next.h
+extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
+                                     int32_t ldx2, const void* w, const float* bias, void* y, int32_t two_stage, void* stream);
 static int ymk_glds_min_tiles = [] { const char* e = getenv("YMK_GLDS_MIN_TILES"); return e ? atoi(e) : 192; }();
 extern "C" int32_t ymk_conv2d_last_variant(void) { return ymk_last_variant; }
 
@@ -622,6 +624,11 @@ extern "C" int ymk_conv1x1_cat2(const ymk_conv_desc* d, const void* x1, int32_t 
     a.M = (int64_t)d->B * d->H * d->W;
     if (a.M <= 0) return YMK_OK;
     if (a.M >= (1ll << 31) || (2ll * d->H * d->W + 4096) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31)) return YMK_E_BADARG;
+    if ((ymk_enabled() & YMK_ON_CONV_GLDS) && d->dtype == YMK_BF16 && d->Cout % 64 == 0 &&
+        ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64)) >= ymk_glds_min_tiles) {   // opt-in: next tiled core
+        const int rc = ymk_conv1x1_cat2_glds(d, x1, C1, ldx1, upsample1, x2, ldx2, w, bias, y, (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 1 : 0, stream);
+        if (rc != YMK_E_BADARG) return rc;
+    }
     return d->dtype == YMK_F32 ? launch_conv_dual<float>(a, (hipStream_t)stream) : launch_conv_dual<bf16_t>(a, (hipStream_t)stream);
 }
 

@@ -36,6 +36,10 @@ struct GldsArgs {
     const bf16_t* res;
     void* y;
     int B, H, W, Ho, Wo, Cin, Cout, ks, stride, ldx, ldy, ldr, Kpad, act, out_f32;
+    // virtual concatenation (1x1 only): channels [0, C1) come from x (a [B][H/2][W/2] map read through a nearest 2x upsample
+    // when up1), channels [C1, Cin) from x2; x2 == nullptr: single source
+    const bf16_t* x2;
+    int C1, ldx2, up1;
 };
 
 template <int BN, int STAGES>
@@ -69,6 +73,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     const int lr = lane >> 3, lc = lane & 7;
     const bf16_t* wsrc[GW];
     int poff[G - GW];         // element offset of the tap-(0,0) input pixel (+ swizzled chunk) for this lane's pixel rows
+    int poff2[G - GW];        // the same pixel in the second source of a virtual concatenation
     unsigned pmask[G - GW];   // bit (ky*3+kx): tap inside the image
 #pragma unroll
     for (int j = 0; j < G; ++j) {
@@ -79,11 +84,15 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         } else {
             const int p = m0 + r - BN;
             unsigned mask = 0;
-            int off = 0;
+            int off = 0, off2 = 0;
             if (p < M) {
                 const int ox = p % a.Wo, oy = (p / a.Wo) % a.Ho, b = p / (a.Wo * a.Ho);
                 const int iy0 = oy * a.stride - pad, ix0 = ox * a.stride - pad;
                 off = ((b * a.H + iy0) * a.W + ix0) * a.ldx + sc;
+                if (a.x2) {   // 1x1, stride 1: (oy, ox) is the pixel itself
+                    off2 = ((b * a.H + oy) * a.W + ox) * a.ldx2 + sc;
+                    if (a.up1) off = ((b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * a.ldx + sc;
+                }
                 unsigned ry = 0, rx = 0;   // rows / columns of the filter window that fall inside the image
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -93,18 +102,22 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
                 mask = ((ry & 1u) ? rx : 0u) | ((ry & 2u) ? rx << 3 : 0u) | ((ry & 4u) ? rx << 6 : 0u);
             }
             poff[j - GW] = off;
+            poff2[j - GW] = off2;
             pmask[j - GW] = mask;
         }
     }
     const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(ymk_glds_zero_page) + lc * 8;
     int it_tap_bit = 0, it_ky = 0, it_kx = 0, it_c = 0, it_k = 0;   // cursor of the NEXT k-step to issue (uniform)
+    const int k1 = a.x2 ? a.C1 >> 6 : 0;   // k-steps served by the first source of a virtual concatenation
     auto issue = [&](int stage) {
         const int tapoff = (it_ky * a.W + it_kx) * a.ldx + it_c * 64;
+        const bool second = a.x2 && it_k >= k1;
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             u32x4* dst = smem + stage * STAGE_U4 + (j * 8 + wave) * 64;   // wave-uniform; the lane lands at + lane * 16 B
             const bf16_t* s;
             if (j < GW) s = wsrc[j] + it_k * 64;
+            else if (second) s = pmask[j - GW] ? a.x2 + (poff2[j - GW] + (it_k - k1) * 64) : zsrc;
             else s = ((pmask[j - GW] >> it_tap_bit) & 1u) ? a.x + (poff[j - GW] + tapoff) : zsrc;
             __builtin_amdgcn_global_load_lds((glds_gptr)s, (glds_lptr)dst, 16, 0, 0);
         }
@@ -240,10 +253,32 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
     a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.Kpad = d->Kpad; a.act = d->act;
     a.out_f32 = d->out_dtype == YMK_F32;
+    a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0;
     const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
     if (M <= 0) return YMK_OK;
     // 32-bit element offsets inside the kernel
     if (M >= (1ll << 31) || ((int64_t)d->B * d->H * d->W + d->W + 2) * d->ldx >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Cout % 128 == 0) return two_stage ? glds_launch<128, 2>(a, s) : glds_launch<128, 3>(a, s);
+    return two_stage ? glds_launch<64, 2>(a, s) : glds_launch<64, 3>(a, s);
+}
+
+// Same arguments and result as ymk_conv1x1_cat2 (ymk.h) + two_stage; C1 and Cin - C1 multiples of 64.
+extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
+                                     int32_t ldx2, const void* w, const float* bias, void* y, int32_t two_stage, void* stream) {
+    if (!d || !x1 || !x2 || !w || !bias || !y || d->ksize != 1 || d->stride != 1) return YMK_E_BADARG;
+    if (d->dtype != YMK_BF16 || d->out_dtype != YMK_BF16) return YMK_E_BADARG;
+    if (C1 < 64 || C1 % 64 || d->Cin - C1 < 64 || (d->Cin - C1) % 64 || d->Cout % 64 || ldx1 % 8 || ldx2 % 8 || d->ldy % 4) return YMK_E_BADARG;
+    if (d->Kpad != d->Cin || (d->act != YMK_ACT_NONE && d->act != YMK_ACT_SILU)) return YMK_E_BADARG;
+    if (upsample1 && ((d->H & 1) || (d->W & 1))) return YMK_E_BADARG;
+    GldsArgs a;
+    a.x = static_cast<const bf16_t*>(x1); a.w = static_cast<const bf16_t*>(w); a.bias = bias; a.res = nullptr; a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = 1; a.stride = 1;
+    a.ldx = ldx1; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = d->act; a.out_f32 = 0;
+    a.x2 = static_cast<const bf16_t*>(x2); a.C1 = C1; a.ldx2 = ldx2; a.up1 = upsample1 ? 1 : 0;
+    const int64_t M = (int64_t)a.B * a.H * a.W;
+    if (M <= 0) return YMK_OK;
+    if (M >= (1ll << 31) || (M + 2) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (d->Cout % 128 == 0) return two_stage ? glds_launch<128, 2>(a, s) : glds_launch<128, 3>(a, s);
     return two_stage ? glds_launch<64, 2>(a, s) : glds_launch<64, 3>(a, s);

@@ -29,6 +29,15 @@ int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, in
  * golden vectors on the CPU lane emulator (tests/test_hostemu_post.py); opt-in until it has run on hardware. */
 int ymk_scale_boxes(float* dets, int32_t ld, const int32_t* counts, const float* params, int32_t B, int32_t max_det,
                     int32_t padding, int32_t xywh, void* stream);
+/* Segment head pieces.  ymk_pixel_shuffle2: depth-to-space that turns the 4*C-channel output of a 1x1
+ * convolution into Proto's ConvTranspose2d(C, C, 2, 2) result (nn/modules/block.py:101-107): out[b][2y+dy][2x+dx][c] =
+ * t[b][y][x][(dy*2+dx)*C + c].  ymk_tokens_to_rows: y[b][row_off + c][a_off + p] = x[b][p][c] into an fp32 [B][rows_total][A_total]
+ * tensor — the mask coefficients of the three cv4 branches in the reference's layout (nn/modules/head.py:341-349). */
+int ymk_pixel_shuffle2(int32_t dtype, const void* t, int32_t ldt, void* out, int32_t ldo, int32_t B, int32_t H, int32_t W, int32_t C,
+                       void* stream);
+int ymk_tokens_to_rows(int32_t dtype, const void* x, int32_t ldx, float* y, int32_t B, int32_t HW, int32_t C, int32_t a_off,
+                       int32_t A_total, int32_t row_off, int32_t rows_total, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

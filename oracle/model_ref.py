@@ -252,6 +252,28 @@ def detect(sd, p, feats, strides, nc=80, reg_max=16, fused=True):
     return torch.cat((dbox, scores.sigmoid()), 1), boxes, scores
 
 
+# ---------------------------------------------------------------------------------- Segment
+def proto(sd, p, x, fused=True):
+    """Proto.forward (nn/modules/block.py:88-107): Conv3x3 -> ConvTranspose2d(2, 2, bias) -> Conv3x3 -> Conv1x1."""
+    h = conv(sd, f"{p}.cv1", x, 3, fused=fused)
+    h = F.conv_transpose2d(h, sd[f"{p}.upsample.weight"], sd[f"{p}.upsample.bias"], stride=2)
+    return conv(sd, f"{p}.cv3", conv(sd, f"{p}.cv2", h, 3, fused=fused), 1, fused=fused)
+
+
+def segment(sd, p, feats, strides, nc=80, nm=32, reg_max=16, fused=True):
+    """Segment.forward eval (nn/modules/head.py:317-349): Detect's output with the mask coefficients of the three cv4
+    branches (Conv3x3, Conv3x3, 1x1 + bias) appended as rows [4+nc, 4+nc+nm), and the prototype maps of level 0.
+    Returns (y [B, 4+nc+nm, A], boxes, scores, mc [B, nm, A], proto [B, nm, 2H0, 2W0])."""
+    y, boxes, scores = detect(sd, p, feats, strides, nc, reg_max, fused)
+    bs = feats[0].shape[0]
+    mc = []
+    for i, x in enumerate(feats):
+        c = conv(sd, f"{p}.cv4.{i}.1", conv(sd, f"{p}.cv4.{i}.0", x, 3, fused=fused), 3, fused=fused)
+        mc.append(F.conv2d(c, sd[f"{p}.cv4.{i}.2.weight"], sd[f"{p}.cv4.{i}.2.bias"]).view(bs, nm, -1))
+    mc = torch.cat(mc, 2)
+    return torch.cat([y, mc], 1), boxes, scores, mc, proto(sd, f"{p}.proto", feats[0], fused)
+
+
 # ---------------------------------------------------------------------------------- graph
 def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict | None = None,
             moe_info: dict | None = None):
@@ -308,6 +330,9 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
             cur = torch.cat(cur, 1)
         elif m == "Detect":
             out = detect(sd, p, cur, [scale_of[j] for j in f], nc, cfg.get("reg_max", 16), fused)
+            cur = out[0]
+        elif m == "Segment":                         # [nc, nm, npr]; out = (y with mask rows, boxes, scores, mc, proto)
+            out = segment(sd, p, cur, [scale_of[j] for j in f], nc, args[1] if len(args) > 1 else 32, cfg.get("reg_max", 16), fused)
             cur = out[0]
         else:
             raise KeyError(m)

@@ -536,9 +536,25 @@ def channel_shuffle_cat(parts, groups, out=None):
     return _put(y, out, cat.dtype)
 
 
+def pixel_shuffle2(t, out=None):
+    _count("pixel_shuffle2")
+    B, H, W, C4 = t.shape
+    c = C4 // 4
+    y = t.reshape(B, H, W, 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, c)
+    return _put(y, out, t.dtype)
+
+
+def tokens_to_rows(x, y, a_off, row_off=0):
+    _count("tokens_to_rows")
+    B, H, W, c = x.shape
+    y[:, row_off: row_off + c, a_off: a_off + H * W] = x.float().reshape(B, H * W, c).transpose(1, 2)
+    return y
+
+
 EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",
-            "linear_attention", "deform_attention", "token_softmax", "gated_route_decide", "expert_conv", "channel_shuffle_cat"]
+            "linear_attention", "deform_attention", "token_softmax", "gated_route_decide", "expert_conv", "channel_shuffle_cat",
+            "pixel_shuffle2", "tokens_to_rows"]

@@ -77,3 +77,33 @@ def test_scale_boxes_vs_reference_golden(golden_dir):
     for b, c in enumerate(sel):
         n = int(counts[b])
         assert np.array_equal(d[b, :n, :4].cpu().numpy(), c["out"][:n]) and torch.equal(d[b, n:].cpu(), dets[b, n:])
+
+
+def test_segment_kernels_and_head(golden_dir):
+    """Segment head on the GPU: the two layout kernels against their contracts, then the v0 seg-n model against the REAL
+    reference's SegmentationModel output (tests/golden/make_golden_seg.py)."""
+    import json
+
+    import numpy as np
+
+    from tests.helpers import fill_by_name
+    from tests.test_hostemu_post import seg_kernel_checks
+    from yolo_master_amd import ops
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    seg_kernel_checks("cuda:0")
+    z = np.load(golden_dir / "fwd_seg_n.npz")
+    cfg = json.loads(str(z["cfg"]))
+    m = DetectionModel(cfg)
+    full = dict(m.state_dict())
+    full.update(fill_by_name(json.loads(str(z["spec"])), seed=11, gain=0.8))
+    m.load_state_dict(full)
+    m.eval().to("cuda:0")
+    with torch.inference_mode():
+        y, preds = m._predict_once(torch.from_numpy(z["x"]).to("cuda:0"))
+        ycat = torch.cat([y, preds["mask_coefficient"]], 1).cpu()
+        proto = ops.nhwc_to_nchw_f32(preds["proto"]).cpu()
+    ref_y, ref_p = torch.from_numpy(z["y"]), torch.from_numpy(z["proto"])
+    assert float((ycat[:, :4] - ref_y[:, :4]).abs().max()) <= 1e-3 + 1e-4 * float(ref_y[:, :4].abs().max())
+    assert float((ycat[:, 4:] - ref_y[:, 4:]).abs().max()) <= 1e-4 * max(1.0, float(ref_y[:, 4:].abs().max()))
+    assert float((proto - ref_p).abs().max()) <= 1e-4 * max(1.0, float(ref_p.abs().max()))

@@ -57,3 +57,47 @@ def test_scale_boxes_is_opt_in(monkeypatch):
     monkeypatch.delenv("YMK_EXPERIMENTAL", raising=False)
     with pytest.raises(ops.KernelNotBuilt):
         postprocess.scale_boxes((640, 640), torch.zeros(3, 4), (480, 640))
+
+
+def seg_kernel_checks(dev="cpu"):
+    """pixel_shuffle2 / tokens_to_rows against their contract restatements; shared with tests/test_gpu_next.py."""
+    from tests import emu_ops
+    from yolo_master_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float32, torch.bfloat16):
+        vec = 8 if dtype == torch.bfloat16 else 4
+        for B, H, W, C, pad in ((2, 5, 7, 2 * vec, 0), (1, 1, 1, vec, vec), (3, 4, 3, 4 * vec, 2 * vec)):
+            t = torch.randn(B, H, W, 4 * C, generator=g).to(dtype)
+            wide = torch.zeros((B, H, W, 4 * C + pad), dtype=dtype)
+            wide[..., : 4 * C] = t
+            got = ops.pixel_shuffle2(wide.to(dev)[..., : 4 * C])
+            assert torch.equal(got.cpu(), emu_ops.pixel_shuffle2(t)), (dtype, B, H, W, C)
+        y = torch.full((2, 40, 100), -1.0)
+        ref = y.clone()
+        yd = y.to(dev)
+        a_off = 0
+        for H, W, C in ((6, 8, 32), (3, 4, 32), (2, 2, 32), (7, 3, 5)):
+            x = torch.randn(2, H, W, C, generator=g).to(dtype)
+            row_off = 0 if C == 32 else 33
+            ops.tokens_to_rows(x.to(dev), yd, a_off if C == 32 else 0, row_off)
+            emu_ops.tokens_to_rows(x, ref, a_off if C == 32 else 0, row_off)
+            a_off += H * W if C == 32 else 0
+        assert torch.equal(yd.cpu(), ref), dtype
+
+
+def test_segment_kernels_on_the_emulator(monkeypatch):
+    path = hostemu_build.build()
+    if path is None:
+        pytest.skip("no host clang++ to build the kernel emulation")
+    from yolo_master_amd import _lib, ops
+
+    h = C.CDLL(str(path))
+    for name in ("ymk_pixel_shuffle2", "ymk_tokens_to_rows"):
+        fn = getattr(h, name)
+        fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT[name]
+    monkeypatch.setenv("YMK_EXPERIMENTAL", "1")
+    monkeypatch.setattr(ops, "lib", h)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
+    seg_kernel_checks()

@@ -24,7 +24,7 @@ from ..errors import MoERouterError, ShapeMismatchError
 
 __all__ = [
     "autopad", "Conv", "DWConv", "Concat", "Bottleneck", "C2f", "C3", "C3k", "C3k2", "AAttn", "ABlock", "A2C2f",
-    "DFL", "Detect", "DynamicRoutingLayer", "DepthwiseSeparableConv", "EfficientExpertGroup", "ES_MOE",
+    "DFL", "Detect", "Proto", "Segment", "DynamicRoutingLayer", "DepthwiseSeparableConv", "EfficientExpertGroup", "ES_MOE",
     "set_compute_dtype", "LazyUpsample",
 ]
 
@@ -599,6 +599,69 @@ class Detect(YmkModule):
         boxes = torch.cat([b.reshape(B, -1, 4 * self.reg_max) for b, _ in raw], 1).permute(0, 2, 1)
         scores = torch.cat([c.reshape(B, -1, self.nc) for _, c in raw], 1).permute(0, 2, 1)
         return y, dict(boxes=boxes, scores=scores, feats=list(x))
+
+
+class Proto(YmkModule):
+    """Mask prototypes (ultralytics/nn/modules/block.py:88-107): Conv3x3 -> ConvTranspose2d(2, 2, bias) -> Conv3x3 -> Conv1x1.
+    The transposed convolution runs as a 1x1 convolution to 4*c_ channels (one slice per output phase) + depth-to-space."""
+
+    def __init__(self, c1, c_=256, c2=32):
+        super().__init__()
+        self.cv1 = Conv(c1, c_, k=3)
+        self.upsample = nn.ConvTranspose2d(c_, c_, 2, 2, 0, bias=True)
+        self.cv2 = Conv(c_, c_, k=3)
+        self.cv3 = Conv(c_, c2)
+
+    def _pack(self, dtype, device):
+        w = self.upsample.weight.detach().float().to(device)           # [Cin, Cout, 2, 2]
+        cin, cout = w.shape[:2]
+        wr = w.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1)         # row (dy*2+dx)*Cout + co
+        b = self.upsample.bias.detach().float().to(device).repeat(4)
+        return {"up": (ops.pack_conv_weight(wr, dtype), b.contiguous())}
+
+    def _run(self, x, out=None):
+        pk = self._packed(x.device)
+        t = ops.conv2d(self.cv1._run(x), *pk["up"], 1, 1, False)
+        return self.cv3._run(self.cv2._run(ops.pixel_shuffle2(t)), out=out)
+
+
+class Segment(Detect):
+    """Segmentation head (ultralytics/nn/modules/head.py:265-349): Detect + mask-coefficient branches + prototypes.
+    Device path: `_run` returns Detect's (y [B, 4+nc, A], raw) and leaves the mask coefficients fp32 [B, nm, A] and the
+    prototypes NHWC [B, 2H0, 2W0, nm] in `last_mc` / `last_proto` (NMS consumes y; the kept anchors' coefficients are
+    gathered by index afterwards).  `forward` returns the reference's eval structure ((cat(y, mc), proto), preds)."""
+
+    def __init__(self, nc=80, nm=32, npr=256, reg_max=16, end2end=False, ch=()):
+        super().__init__(nc, reg_max, end2end, ch)
+        self.nm, self.npr = nm, npr
+        self.proto = Proto(ch[0], self.npr, self.nm)
+        c4 = max(ch[0] // 4, self.nm)
+        self.cv4 = nn.ModuleList(nn.Sequential(Conv(x, c4, 3), Conv(c4, c4, 3), nn.Conv2d(c4, self.nm, 1)) for x in ch)
+
+    def _pack(self, dtype, device):
+        pk = super()._pack(dtype, device)
+        pk["mask"] = [_PlainConv.pack(s[-1], dtype, device) for s in self.cv4]
+        return pk
+
+    def _run(self, feats):
+        y, raw = super()._run(feats)
+        pk = self._packed(feats[0].device)
+        B, A = y.shape[0], y.shape[2]
+        mc = torch.empty((B, self.nm, A), dtype=torch.float32, device=y.device)
+        a_off = 0
+        for i, f in enumerate(feats):
+            h = self.cv4[i][1]._run(self.cv4[i][0]._run(f))
+            c = ops.conv2d(h, pk["mask"][i][0], pk["mask"][i][1], 1, 1, False, out_dtype=torch.float32)
+            ops.tokens_to_rows(c, mc, a_off)
+            a_off += f.shape[1] * f.shape[2]
+        self.last_mc, self.last_proto = mc, self.proto._run(feats[0])
+        return y, raw
+
+    def forward(self, x):
+        y, preds = super().forward(x)
+        proto = ops.nhwc_to_nchw_f32(self.last_proto)
+        preds["mask_coefficient"], preds["proto"] = self.last_mc, proto
+        return (torch.cat([y, self.last_mc], 1), proto), preds   # the concatenation is API compatibility only
 
 
 # ------------------------------------------------------------------------------ ES-MoE

@@ -22,7 +22,7 @@ import yaml
 
 from .. import ops
 from .mixture import MIXTURE_BOUNDARY_MODULES, MIXTURE_BOUNDARY_REPEAT
-from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DWConv, LazyUpsample,
+from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DWConv, LazyUpsample, Segment,
                       VirtualCat, YmkModule, set_compute_dtype)
 
 CFG_DIR = Path(__file__).resolve().parent.parent / "cfg"
@@ -34,7 +34,7 @@ REPEAT_MODULES = {C2f, C3, C3k2, A2C2f}
 # (the config-5 modules are registered as drop-in boundaries: they build and load checkpoints, their kernels are next)
 MIXTURE_MODULES = {"ES_MOE": ES_MOE, **MIXTURE_BOUNDARY_MODULES}
 MIXTURE_REPEAT_MODULES = set(MIXTURE_BOUNDARY_REPEAT)
-HEAD_MODULES = {"Detect": Detect}
+HEAD_MODULES = {"Detect": Detect, "Segment": Segment}
 
 
 def make_divisible(x, divisor):
@@ -127,8 +127,10 @@ def parse_model(d, ch, verbose=False):
                 n = 1
         elif mod is Concat:
             c2 = sum(ch[x] for x in f)
-        elif mod is Detect:
+        elif mod in (Detect, Segment):   # tasks.py:2189-2236
             args.extend([reg_max, end2end, [ch[x] for x in f]])
+            if mod is Segment:
+                args[2] = make_divisible(min(args[2], max_channels) * width, 8)
             Detect.legacy = legacy
         else:
             c2 = ch[f]
@@ -278,6 +280,8 @@ class DetectionModel(nn.Module):
                 taps[m.i] = cur.materialise() if isinstance(cur, VirtualCat) else cur
         det = self.model[-1]
         preds = {"raw": raw, "feats": None}
+        if isinstance(det, Segment):   # mask coefficients fp32 [B, nm, A] and prototypes NHWC [B, 2H0, 2W0, nm]
+            preds["mask_coefficient"], preds["proto"] = det.last_mc, det.last_proto
         return cur, preds
 
     def check_flags(self):

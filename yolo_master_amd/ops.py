@@ -742,3 +742,26 @@ def channel_shuffle_cat(parts, groups: int, out=None):
     check(lib.ymk_channel_shuffle_cat(DT[a.dtype], _p(a), lda, Ca, _p(b), ldb, Cb, groups, _p(out), ldy, B * H * W, _stream()),
           "channel_shuffle_cat")
     return out
+
+
+def pixel_shuffle2(t, out=None):
+    """Depth-to-space by 2: t [B,H,W,4C] (phase-major channel slices) -> [B,2H,2W,C]; with the 4C-channel 1x1 convolution in
+    front it is Proto's ConvTranspose2d(C, C, 2, 2) (nn/modules/block.py:101-107)."""
+    _gate("pixel_shuffle2")
+    B, H, W, C4, ldt = _nhwc(t)
+    Cc = C4 // 4
+    out, ldo = _out_like(t, out, None, (B, 2 * H, 2 * W, Cc))
+    check(lib.ymk_pixel_shuffle2(DT[t.dtype], _p(t), ldt, _p(out), ldo, B, H, W, Cc, _stream()), "pixel_shuffle2")
+    return out
+
+
+def tokens_to_rows(x, y, a_off: int, row_off: int = 0):
+    """y[b][row_off + c][a_off + p] = x[b][p][c] for an NHWC map x and an fp32 [B, rows, A] tensor y (mask coefficients of the
+    Segment head in the reference's layout, nn/modules/head.py:341-349)."""
+    _gate("tokens_to_rows")
+    B, H, W, Cc, ldx = _nhwc(x)
+    if y.dtype != torch.float32 or not y.is_contiguous() or y.shape[0] != B:
+        raise ValueError("tokens_to_rows: y is a contiguous fp32 [B, rows, A] tensor")
+    check(lib.ymk_tokens_to_rows(DT[x.dtype], _p(x), ldx, _p(y), B, H * W, Cc, a_off, y.shape[2], row_off, y.shape[1], _stream()),
+          "tokens_to_rows")
+    return y

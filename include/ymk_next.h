@@ -38,6 +38,18 @@ int ymk_pixel_shuffle2(int32_t dtype, const void* t, int32_t ldt, void* out, int
 int ymk_tokens_to_rows(int32_t dtype, const void* x, int32_t ldx, float* y, int32_t B, int32_t HW, int32_t C, int32_t a_off,
                        int32_t A_total, int32_t row_off, int32_t rows_total, void* stream);
 
+/* process_mask of the segmentation predictor (ultralytics/utils/ops.py:477-528), one image per call.
+ * ymk_mask_coeff_gather: out[j][k] = mc[b][k][idx[j]] — the mask coefficients (fp32 [B][nm][A], ymk_tokens_to_rows) of the anchors
+ * NMS kept (idx int64 [n], the `return_idxs` output).
+ * ymk_process_mask: protos NHWC [mh][mw][nm] (pixel stride ldp) of that image, coefs fp32 [n][nm], boxes fp32 rows of ldb >= 4 floats
+ * (xyxy in network-input pixels); out uint8 [n][H][W].  upsample = 0: H x W = mh x mw, crop with the boxes scaled by (rw, rh) =
+ * (mw / W_in, mh / H_in); upsample != 0: bilinear (align_corners = False) to H x W, then crop with the boxes.  Binarised at 0.
+ * lowres_ws: fp32 [n * mh * mw] scratch. */
+int ymk_mask_coeff_gather(const float* mc, int32_t nm, int32_t A, int32_t b, const int64_t* idx, int32_t n, float* out, void* stream);
+int ymk_process_mask(int32_t dtype, const void* protos, int32_t ldp, int32_t mh, int32_t mw, int32_t nm, const float* coefs,
+                     const float* boxes, int32_t ldb, int32_t n, int32_t H, int32_t W, int32_t upsample, float rw, float rh,
+                     float* lowres_ws, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,12 +2,15 @@
 
 CPU restatement of the step right after the hot path: `scale_boxes` / `clip_boxes`, which map
 the detections from the letterboxed network input back to the original image (`ultralytics/utils/ops.py:119-174, 176-205`,
-called per image by `DetectionPredictor.construct_result`, `models/yolo/detect/predict.py:109-122`).
+called per image by `DetectionPredictor.construct_result`, `models/yolo/detect/predict.py:109-122`), and `process_mask` /
+`crop_mask` of the segmentation predictor (`utils/ops.py:477-528`).
 Pinned against the real reference by `tests/golden/make_golden_post.py` (bit-exact), checked without it by
 `tests/test_oracle_post.py`."""
 from __future__ import annotations
 
 import numpy as np
+import torch
+import torch.nn.functional as F
 
 f32 = np.float32
 
@@ -45,3 +48,27 @@ def scale_boxes(img1_shape, boxes: np.ndarray, img0_shape, ratio_pad=None, paddi
     b[..., 2] = np.clip(b[..., 2], 0, w)
     b[..., 3] = np.clip(b[..., 3], 0, h)
     return b
+
+
+def crop_mask(masks: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
+    """utils/ops.py:477-497: zero everything outside [x1, x2) x [y1, y2) (boxes in the masks' pixel coordinates)."""
+    _, h, w = masks.shape
+    x1, y1, x2, y2 = torch.chunk(boxes[:, :, None], 4, 1)
+    r = torch.arange(w, dtype=x1.dtype)[None, None, :]
+    c = torch.arange(h, dtype=x1.dtype)[None, :, None]
+    return masks * ((r >= x1) * (r < x2)) * ((c >= y1) * (c < y2))
+
+
+def process_mask(protos: torch.Tensor, masks_in: torch.Tensor, bboxes: torch.Tensor, shape, upsample: bool = False) -> torch.Tensor:
+    """utils/ops.py:500-528: coefficient x prototype product, then either bilinear upsampling to `shape` and a crop with the
+    boxes (upsample=True) or a crop at prototype resolution with the boxes scaled down; binarised at 0.  protos [nm, mh, mw]."""
+    c, mh, mw = protos.shape
+    if masks_in.shape[0] == 0:
+        return torch.zeros((0, *(shape if upsample else (mh, mw))), dtype=torch.uint8)
+    masks = (masks_in @ protos.float().view(c, -1)).view(-1, mh, mw)
+    if upsample:
+        masks = crop_mask(F.interpolate(masks[None], shape, mode="bilinear")[0], bboxes)
+    else:
+        ratios = torch.tensor([[mw / shape[1], mh / shape[0], mw / shape[1], mh / shape[0]]])
+        masks = crop_mask(masks, bboxes * ratios)
+    return masks.gt(0.0).byte()

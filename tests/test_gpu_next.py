@@ -107,3 +107,9 @@ def test_segment_kernels_and_head(golden_dir):
     assert float((ycat[:, :4] - ref_y[:, :4]).abs().max()) <= 1e-3 + 1e-4 * float(ref_y[:, :4].abs().max())
     assert float((ycat[:, 4:] - ref_y[:, 4:]).abs().max()) <= 1e-4 * max(1.0, float(ref_y[:, 4:].abs().max()))
     assert float((proto - ref_p).abs().max()) <= 1e-4 * max(1.0, float(ref_p.abs().max()))
+
+
+def test_process_mask_vs_reference_golden(golden_dir):
+    from tests.test_hostemu_post import mask_kernel_checks
+
+    mask_kernel_checks(golden_dir, "cuda:0")

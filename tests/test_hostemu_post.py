@@ -101,3 +101,76 @@ def test_segment_kernels_on_the_emulator(monkeypatch):
     monkeypatch.setattr(ops, "_stream", lambda: None)
     monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
     seg_kernel_checks()
+
+
+def mask_kernel_checks(golden_dir, dev="cpu"):
+    """gather + process_mask through the product wrapper against the REAL reference's masks; shared with the GPU test."""
+    from tests.test_oracle_post import mask_cases
+    from yolo_master_amd import postprocess
+
+    for c in mask_cases(golden_dir):
+        for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2e-2)):
+            protos = c["protos"].permute(1, 2, 0).contiguous().to(dtype).to(dev)        # NHWC, as the Proto module leaves them
+            got = postprocess.process_mask(protos, c["coefs"].to(dev), c["boxes"].to(dev), c["shape"], upsample=c["upsample"]).cpu()
+            assert got.shape == c["mask"].shape and got.dtype == torch.uint8
+            if got.numel():
+                assert float((got != c["mask"]).float().mean()) <= tol, (c["shape"], c["upsample"], dtype)
+    mc = torch.randn(3, 32, 50)
+    idx = torch.tensor([7, 0, 49, 13], dtype=torch.int64)
+    got = postprocess.gather_mask_coefficients(mc.to(dev), 1, idx.to(dev)).cpu()
+    assert torch.equal(got, mc[1][:, idx].t())
+
+
+def test_process_mask_on_the_emulator(post, golden_dir):
+    from yolo_master_amd import _lib
+
+    for name in ("ymk_process_mask", "ymk_mask_coeff_gather"):
+        fn = getattr(post.lib, name)
+        fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT[name]
+    mask_kernel_checks(golden_dir)
+
+
+def test_segmentation_predict_flow(post, emu, golden_dir):
+    """Model -> NMS -> coefficient gather -> process_mask -> scale_boxes, glued the way SegmentationPredictor does it
+    (models/yolo/segment/predict.py), against the oracle's pieces applied to the REAL reference's head outputs."""
+    import json
+
+    from oracle import nms_ref, post_ref
+    from tests.helpers import fill_by_name
+    from yolo_master_amd import _lib, postprocess
+    from yolo_master_amd.nms import non_max_suppression
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    for name in ("ymk_process_mask", "ymk_mask_coeff_gather"):
+        fn = getattr(post.lib, name)
+        fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT[name]
+    z = np.load(golden_dir / "fwd_seg_n.npz")
+    cfg = json.loads(str(z["cfg"]))
+    m = DetectionModel(cfg)
+    full = dict(m.state_dict())
+    full.update(fill_by_name(json.loads(str(z["spec"])), seed=11, gain=0.8))
+    m.load_state_dict(full)
+    m.eval()
+    x = torch.from_numpy(z["x"])
+    H, W = x.shape[2:]
+    with torch.inference_mode():
+        y, preds = m._predict_once(x)
+    conf, iou = 0.3, 0.6
+    dets, idx = non_max_suppression(y, conf, iou, return_idxs=True)
+    ref_y, ref_p = torch.from_numpy(z["y"]), torch.from_numpy(z["proto"])
+    nc = m.model[-1].nc
+    rd, ri = nms_ref.non_max_suppression(ref_y[:, : 4 + nc].numpy(), conf, iou, return_idxs=True)
+    total = 0
+    for b in range(x.shape[0]):
+        assert np.array_equal(idx[b].numpy(), ri[b]), "kept anchors differ from the oracle NMS on the reference's predictions"
+        n = len(ri[b])
+        total += n
+        coefs = postprocess.gather_mask_coefficients(preds["mask_coefficient"], b, idx[b].contiguous())
+        masks = postprocess.process_mask(preds["proto"][b], coefs, dets[b][:, :4].contiguous(), (H, W), upsample=True)
+        ref_masks = post_ref.process_mask(ref_p[b], ref_y[b, 4 + nc:, ri[b]].t().contiguous(), torch.from_numpy(rd[b][:, :4].copy()), (H, W), upsample=True)
+        assert masks.shape == ref_masks.shape == (n, H, W)
+        if n:
+            assert float((masks != ref_masks).float().mean()) <= 2e-3
+        boxes = postprocess.scale_boxes((H, W), dets[b][:, :4].clone(), (2 * H + 3, 2 * W))
+        assert np.allclose(boxes.numpy(), post_ref.scale_boxes((H, W), rd[b][:, :4], (2 * H + 3, 2 * W)), atol=2e-3)
+    assert total > 0, "the fixture should keep some detections at this threshold"

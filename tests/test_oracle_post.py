@@ -30,3 +30,26 @@ def test_letterbox_params_round_half_even():
     # 500x375 into 640x384: gain 1.024, width fills, rows padded 0 / 1 -> the -0.1 nudge decides
     assert post_ref.letterbox_params((384, 640), (375, 500)) == (1.024, 64, 0)
     assert post_ref.letterbox_params((640, 640), (480, 640)) == (1.0, 0, 80)
+
+
+def mask_cases(golden_dir):
+    import torch
+
+    z = np.load(golden_dir / "post_mask.npz")
+    for i in range(int(z["n"])):
+        m = z[f"c{i}_meta"]
+        ms = tuple(int(v) for v in z[f"c{i}_mshape"])
+        mask = np.unpackbits(z[f"c{i}_mask"])[: int(np.prod(ms))].reshape(ms) if np.prod(ms) else np.zeros(ms, np.uint8)
+        yield dict(protos=torch.from_numpy(z[f"c{i}_protos"]), coefs=torch.from_numpy(z[f"c{i}_coefs"]), boxes=torch.from_numpy(z[f"c{i}_boxes"]),
+                   shape=(int(m[0]), int(m[1])), upsample=bool(m[2]), mask=torch.from_numpy(mask))
+
+
+def test_process_mask_oracle_matches_reference(golden_dir):
+    n = 0
+    for c in mask_cases(golden_dir):
+        got = post_ref.process_mask(c["protos"], c["coefs"], c["boxes"], c["shape"], upsample=c["upsample"])
+        assert got.shape == c["mask"].shape
+        # bit-identical at generation time; a different thread count may move a sum by an ulp and flip a pixel that sits at 0
+        assert float((got != c["mask"]).float().mean()) <= 1e-4 if got.numel() else True
+        n += 1
+    assert n == 6

@@ -100,3 +100,85 @@ extern "C" int ymk_tokens_to_rows(int32_t dtype, const void* x, int32_t ldx, flo
                            row_off, rows_total);
     return ymk_launch_status();
 }
+
+// ---- process_mask (ultralytics/utils/ops.py:477-528), one image per call ---------------------------------------------------
+// coefficients of the kept anchors: out[j][k] = mc[b][k][idx[j]]
+__global__ __launch_bounds__(256) void mask_coeff_gather_kernel(const float* mc, int nm, int A, int b, const int64_t* idx, int n, float* out) {
+    const int total = n * nm;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i / nm, k = i % nm;
+        out[i] = mc[((size_t)b * nm + k) * A + idx[j]];
+    }
+}
+// prototype-resolution masks: L[d][y][x] = sum_k coef[d][k] * proto[y][x][k] (prototypes NHWC, as the Proto module leaves them)
+template <typename T>
+__global__ __launch_bounds__(256) void mask_lowres_kernel(const T* proto, int ldp, const float* coef, int nm, int n, int mh, int mw, float* L) {
+    const int64_t total = (int64_t)n * mh * mw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i % ((int64_t)mh * mw);
+        const int d = (int)(i / ((int64_t)mh * mw));
+        const T* pr = proto + pix * ldp;
+        const float* c = coef + (size_t)d * nm;
+        float s = 0.f;
+        for (int k = 0; k < nm; ++k) s += c[k] * to_f32(pr[k]);
+        L[i] = s;
+    }
+}
+// binarised output: upsample == 0: crop at prototype resolution with the boxes scaled by (rw, rh); upsample != 0: bilinear
+// (align_corners = False, PyTorch's source-index rule) to H x W, then crop with the boxes as they are
+__global__ __launch_bounds__(256) void mask_finish_kernel(const float* L, const float* boxes, int ldb, int n, int mh, int mw, int H, int W,
+                                                          int upsample, float rw, float rh, uint8_t* out) {
+    const int64_t total = (int64_t)n * H * W;
+    const float sh = (float)mh / (float)H, sw = (float)mw / (float)W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W);
+        const int Y = (int)((i / W) % H);
+        const int d = (int)(i / ((int64_t)H * W));
+        const float* bx = boxes + (size_t)d * ldb;
+        float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+        if (!upsample) { x1 *= rw; y1 *= rh; x2 *= rw; y2 *= rh; }
+        const float fx = (float)X, fy = (float)Y;
+        uint8_t o = 0;
+        if (fx >= x1 && fx < x2 && fy >= y1 && fy < y2) {
+            const float* Ld = L + (size_t)d * mh * mw;
+            float v;
+            if (!upsample) {
+                v = Ld[Y * mw + X];
+            } else {
+                float ry = sh * (fy + 0.5f) - 0.5f, rx = sw * (fx + 0.5f) - 0.5f;
+                ry = ry < 0.f ? 0.f : ry;
+                rx = rx < 0.f ? 0.f : rx;
+                const int y0 = (int)ry, x0 = (int)rx;
+                const int y1i = y0 + (y0 < mh - 1 ? 1 : 0), x1i = x0 + (x0 < mw - 1 ? 1 : 0);
+                const float ly1 = ry - (float)y0, lx1 = rx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                v = ly0 * (lx0 * Ld[y0 * mw + x0] + lx1 * Ld[y0 * mw + x1i]) + ly1 * (lx0 * Ld[y1i * mw + x0] + lx1 * Ld[y1i * mw + x1i]);
+            }
+            o = v > 0.f ? 1 : 0;
+        }
+        out[i] = o;
+    }
+}
+
+extern "C" int ymk_mask_coeff_gather(const float* mc, int32_t nm, int32_t A, int32_t b, const int64_t* idx, int32_t n, float* out, void* stream) {
+    if (!mc || !idx || !out || nm < 1 || A < 1 || b < 0) return YMK_E_BADARG;
+    if (n <= 0) return YMK_OK;
+    hipLaunchKernelGGL(mask_coeff_gather_kernel, dim3((n * nm + 255) / 256), dim3(256), 0, (hipStream_t)stream, mc, nm, A, b, idx, n, out);
+    return ymk_launch_status();
+}
+extern "C" int ymk_process_mask(int32_t dtype, const void* protos, int32_t ldp, int32_t mh, int32_t mw, int32_t nm, const float* coefs,
+                                const float* boxes, int32_t ldb, int32_t n, int32_t H, int32_t W, int32_t upsample, float rw, float rh,
+                                float* lowres_ws, uint8_t* out, void* stream) {
+    if (!protos || !coefs || !boxes || !lowres_ws || !out || (dtype != YMK_F32 && dtype != YMK_BF16) || nm < 1 || ldp < nm || ldb < 4 ||
+        mh < 1 || mw < 1 || H < 1 || W < 1 || (!upsample && (H != mh || W != mw)))
+        return YMK_E_BADARG;
+    if (n <= 0) return YMK_OK;
+    const int64_t tl = (int64_t)n * mh * mw, tf = (int64_t)n * H * W;
+    const int bl = (int)((tl + 255) / 256 > 16384 ? 16384 : (tl + 255) / 256), bf = (int)((tf + 255) / 256 > 32768 ? 32768 : (tf + 255) / 256);
+    if (dtype == YMK_BF16)
+        hipLaunchKernelGGL(mask_lowres_kernel<bf16_t>, dim3(bl), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)protos, ldp, coefs, nm, n, mh, mw, lowres_ws);
+    else
+        hipLaunchKernelGGL(mask_lowres_kernel<float>, dim3(bl), dim3(256), 0, (hipStream_t)stream, (const float*)protos, ldp, coefs, nm, n, mh, mw, lowres_ws);
+    hipLaunchKernelGGL(mask_finish_kernel, dim3(bf), dim3(256), 0, (hipStream_t)stream, (const float*)lowres_ws, boxes, ldb, n, mh, mw, H, W, upsample, rw,
+                       rh, out);
+    return ymk_launch_status();
+}

@@ -56,3 +56,42 @@ def scale_boxes(img1_shape, boxes: torch.Tensor, img0_shape, ratio_pad=None, pad
         raise ValueError("scale_boxes: boxes [N, >=4]")
     scale_detections(img1_shape, boxes.unsqueeze(0), None, [img0_shape], None if ratio_pad is None else [ratio_pad], padding, xywh)
     return boxes
+
+
+def gather_mask_coefficients(mc: torch.Tensor, b: int, idx: torch.Tensor) -> torch.Tensor:
+    """Mask coefficients of the anchors NMS kept for image b: mc fp32 [B, nm, A] (Segment head), idx int64 [n] (the
+    `return_idxs` output of non_max_suppression) -> fp32 [n, nm]."""
+    ops._gate("process_mask")
+    ops.require_gpu(mc, "yolo_master_amd post-processing")
+    if mc.dtype != torch.float32 or not mc.is_contiguous() or idx.dtype != torch.int64 or not idx.is_contiguous():
+        raise ValueError("gather_mask_coefficients: contiguous fp32 [B, nm, A] coefficients, contiguous int64 indices")
+    n = idx.numel()
+    out = torch.empty((n, mc.shape[1]), dtype=torch.float32, device=mc.device)
+    check(lib.ymk_mask_coeff_gather(ops._p(mc), mc.shape[1], mc.shape[2], int(b), ops._p(idx), n, ops._p(out), ops._stream()), "mask_coeff_gather")
+    return out
+
+
+def process_mask(protos: torch.Tensor, masks_in: torch.Tensor, bboxes: torch.Tensor, shape, upsample: bool = False) -> torch.Tensor:
+    """ultralytics.utils.ops.process_mask for one image (utils/ops.py:500-528), with the prototypes in the layout the Proto
+    module leaves them: NHWC [mh, mw, nm] (a channel-dense view; the reference takes [nm, mh, mw]).  masks_in fp32 [n, nm],
+    bboxes fp32 [n, >=4] xyxy in network-input pixels, shape = (H, W) of the network input.  Returns uint8 [n, H, W] when
+    upsample else [n, mh, mw]."""
+    ops._gate("process_mask")
+    ops.require_gpu(protos, "yolo_master_amd post-processing")
+    if protos.dim() != 3 or protos.stride(2) != 1 or protos.stride(0) != protos.shape[1] * protos.stride(1):
+        raise ValueError("process_mask: prototypes are an NHWC [mh, mw, nm] view of one image")
+    mh, mw, nm = protos.shape
+    n = masks_in.shape[0]
+    H, W = (int(shape[0]), int(shape[1])) if upsample else (mh, mw)
+    out = torch.empty((n, H, W), dtype=torch.uint8, device=protos.device)
+    if n == 0:
+        return out
+    if masks_in.dtype != torch.float32 or not masks_in.is_contiguous() or tuple(masks_in.shape) != (n, nm):
+        raise ValueError("process_mask: contiguous fp32 [n, nm] coefficients")
+    if bboxes.dtype != torch.float32 or bboxes.dim() != 2 or bboxes.shape[0] != n or bboxes.stride(1) != 1:
+        raise ValueError("process_mask: fp32 [n, >=4] boxes")
+    ws = torch.empty((n * mh * mw,), dtype=torch.float32, device=protos.device)
+    check(lib.ymk_process_mask(ops.DT[protos.dtype], ops._p(protos), protos.stride(1), mh, mw, nm, ops._p(masks_in), ops._p(bboxes),
+                               bboxes.stride(0), n, H, W, int(bool(upsample)), float(torch.tensor(mw / shape[1], dtype=torch.float32)),
+                               float(torch.tensor(mh / shape[0], dtype=torch.float32)), ops._p(ws), ops._p(out), ops._stream()), "process_mask")
+    return out

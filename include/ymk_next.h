@@ -6,6 +6,10 @@
  * counted vmcnt, 1 = two stages with a plain barrier); bf16 only, Cin % 64 == 0, Cout % 64 == 0, otherwise YMK_E_BADARG.
  * ymk_conv2d itself dispatches to it only when the environment variable YMK_ENABLE has bit 0 set (bit 1 = two_stage):
  * its logic is verified on the CPU lane emulator (tests/test_hostemu_conv.py), its speed has not been measured.
+ * (2) The rows right after / beside the hot path: box rescaling, the Segment head's layout
+ * kernels and process_mask.  Each is pinned to golden vectors generated from the real reference and verified on the CPU lane
+ * emulator (tests/test_hostemu_post.py); the Python wrappers (yolo_master_amd/postprocess.py, ops.py) refuse to call them
+ * unless YMK_EXPERIMENTAL=1 until tests/test_gpu_next.py has passed on an MI355X.
  */
 #ifndef YMK_NEXT_H_
 #define YMK_NEXT_H_

@@ -8,8 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
 timeout -k 10 420 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_suite.log 2>&1; echo "gpu suite exit $?"; tail -3 gpurun_out/${TAG}_gpu_suite.log
-bash tools/gpu_cfg5.sh $TAG | tail -15
-YMK_EXPERIMENTAL=1 timeout -k 10 600 python -m pytest tests/test_gpu_next.py -m gpu -q -x > gpurun_out/${TAG}_next.log 2>&1; echo "next-core tests exit $?"; tail -5 gpurun_out/${TAG}_next.log
+bash tools/gpu_cfg5.sh $TAG | tail -60
 bash tools/gpu_probe.sh $TAG | tail -60
 for e in 1 3; do   # A/B of the opt-in core inside the same box: 1 = three LDS stages, 3 = two
   YMK_ENABLE=$e timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_enable$e.json 2>/dev/null

@@ -69,3 +69,28 @@ def test_segment_host_path_vs_reference(golden_dir, emu):
     with torch.inference_mode():
         (yy, pp), pr = head(feats)
     assert tuple(yy.shape) == (1, 4 + 80 + 32, 64 + 16 + 4) and tuple(pp.shape) == (1, 32, 16, 16) and "mask_coefficient" in pr
+
+
+def test_segmentation_model_api(golden_dir, emu):
+    """`SegmentationModel("yolo-master-seg-n.yaml")` (own YAML of the cfg directory) builds the same network as the
+    reference's seg YAML and returns the reference's eval structure."""
+    from yolo_master_amd.nn.tasks import DetectionModel, SegmentationModel
+
+    z, cfg, sd = _fixture(golden_dir)
+    m = SegmentationModel("yolo-master-seg-n.yaml")
+    keys = json.load(open(golden_dir / "keys_seg_n.json"))
+    assert list(m.state_dict().keys()) == list(keys.keys())
+    full = dict(m.state_dict())
+    full.update(sd)
+    m.load_state_dict(full)
+    m.eval()
+    with torch.inference_mode():
+        (ycat, proto), preds = m(torch.from_numpy(z["x"]))
+    ref_y, ref_p = torch.from_numpy(z["y"]), torch.from_numpy(z["proto"])
+    assert float((ycat[:, 4:] - ref_y[:, 4:]).abs().max()) <= 1e-4 * max(1.0, float(ref_y[:, 4:].abs().max()))
+    assert float((proto - ref_p).abs().max()) <= 1e-4 * max(1.0, float(ref_p.abs().max()))
+    import pytest
+
+    with pytest.raises(ValueError):
+        SegmentationModel("yolo-master-n.yaml")
+    assert isinstance(m, DetectionModel)

@@ -290,3 +290,19 @@ class DetectionModel(nn.Module):
             if isinstance(m, ES_MOE):
                 m.check_flags()
                 break
+
+
+class SegmentationModel(DetectionModel):
+    """YOLO-Master segmentation model on the ymk path (reference surface: nn/tasks.py:696-727).  `predict` returns the
+    reference's eval structure ((y with the mask-coefficient rows, prototypes NCHW fp32), preds); the device path for a
+    predictor is `_predict_once` + yolo_master_amd.postprocess (INTEGRATION.md)."""
+
+    def __init__(self, cfg="yolo-master-seg-s.yaml", ch=3, nc=None, verbose=False):
+        super().__init__(cfg, ch, nc, verbose)
+        if not isinstance(self.model[-1], Segment):
+            raise ValueError("SegmentationModel needs a model YAML that ends in a Segment head")
+
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        y, preds = super().predict(x, profile, visualize, augment, embed)
+        proto = ops.nhwc_to_nchw_f32(preds["proto"])
+        return (torch.cat([y, preds["mask_coefficient"]], 1), proto), preds   # concatenation: API compatibility only

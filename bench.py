@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scale", default="s")
+    ap.add_argument("--cfg", default=None, help="model YAML other than the v0 detector, e.g. yolo-master-moa-mot.yaml with --scale l "
+                    "--imgsz 1280 --batch 16 for BASELINE config 5 (needs YMK_EXPERIMENTAL=1 until its kernels are validated)")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -116,7 +118,16 @@ def main():
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
-    model = DetectionModel(f"yolo-master-{a.scale}.yaml")
+    if a.cfg is None:
+        model = DetectionModel(f"yolo-master-{a.scale}.yaml")
+    else:   # another model family at a scale its YAML may not list (config 5 = the moa-mot YAML at the L scale)
+        from yolo_master_amd.nn.tasks import yaml_model_load
+
+        cfg = yaml_model_load(a.cfg)
+        v0 = yaml_model_load("yolo-master.yaml")["scales"]
+        cfg.setdefault("scales", {}).setdefault(a.scale, v0[a.scale])
+        cfg["scale"] = a.scale
+        model = DetectionModel(cfg)
     if rank == 0:
         model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
     model.eval().to(dev)
@@ -224,15 +235,16 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "p50_ms_per_image": round(p50_ms / a.batch, 5),
-            "config": {"workload": f"YOLO-Master-{a.scale.upper()} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, "
-                                   f"bs={a.batch}/GPU, ES-MoE top-k=2 (BASELINE.json configs[2]{'/[3]' if world > 1 else ''})",
+            "config": {"workload": (f"YOLO-Master-{a.scale.upper()} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, "
+                                    f"bs={a.batch}/GPU, ES-MoE top-k=2 (BASELINE.json configs[2]{'/[3]' if world > 1 else ''})") if a.cfg is None else
+                                   f"{a.cfg} at scale {a.scale} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, bs={a.batch}/GPU (not the headline configuration)",
                        "global_batch": world * a.batch, "imgsz": a.imgsz, "parallelism": f"dp{world} (image shards, no data-path collective)",
                        "launch": "hipGraph" if graph is not None else "eager", "weights": "seeded random + BN calibration (no checkpoints offline)"},
             "roofline": roof,
             "families": fams,
             "cpu_baseline": None,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.cfg is None:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.scale)
             except Exception as e:  # never lose the measured line to the host-side baseline

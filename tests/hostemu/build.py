@@ -73,5 +73,20 @@ def build_probe(name: str = "conv256") -> Path | None:
     return exe
 
 
+def build_selftest() -> Path | None:
+    cxx = compiler()
+    if cxx is None:
+        return None
+    OUT.mkdir(exist_ok=True)
+    src, exe = HERE / "selftest" / "selftest.hip", OUT / "selftest_host"
+    txt = src.read_text()
+    txt = re.sub(r"\bextern\s+__shared__\s+(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(hostemu::dyn_lds);", txt)
+    txt = re.sub(r"\b__shared__\b", "static", txt)
+    u = OUT / "selftest_host.cpp"
+    u.write_text(txt)
+    subprocess.run([cxx, "-std=c++20", "-O1", "-Wno-everything", "-DYMK_HOST_EMU", f"-I{HERE}", str(u), "-o", str(exe)], check=True)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force=True))

@@ -25,6 +25,13 @@ int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void* w, const 
 int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
                           int32_t ldx2, const void* w, const float* bias, void* y, int32_t two_stage, void* stream);
 
+/* Routed-expert form of the same core (true sparse dispatch for the gated MoE's expert groups, moe/gated.py:1058-1076,
+ * moe/experts.py:235-269): d describes ONE expert's convolution (stride 1, no activation, no bias); w [E][Cout][Kpad]; idx int32
+ * [B][K] the routed experts; y slot-major: image j*B + b = conv(x[b], w[idx[b][j]]).  Only the routed filter banks run (the first
+ * implementation behind ops.expert_conv convolves with all E banks and gathers).  bf16, Cin % 64 == 0, Cout % 64 == 0. */
+int ymk_expert_conv_glds(const ymk_conv_desc* d, const void* x, const void* w, const int32_t* idx, int32_t K, int32_t E, void* y,
+                         int32_t two_stage, void* stream);
+
 /* The step after the hot path: scale_boxes + clip_boxes (ultralytics/utils/ops.py:119-205, called
  * per image by models/yolo/detect/predict.py:109-122), batched and in place over padded detections.
  * dets fp32 [B][max_det] rows of `ld` >= 4 floats (x1, y1, x2, y2, ...); counts int32 [B] valid rows per image (NULL = all);

@@ -9,7 +9,7 @@ import sys
 import pytest
 import torch
 
-from tests.test_hostemu_conv import CASES, CAT2_CASES, run_case, run_cat2_case
+from tests.test_hostemu_conv import CASES, CAT2_CASES, EXPERT_CASES, run_case, run_cat2_case, run_expert_case
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("YMK_EXPERIMENTAL") != "1", reason="opt-in kernels are not validated on hardware yet")]
@@ -31,6 +31,14 @@ def test_conv1x1_cat2_glds_direct(case):
     from yolo_master_amd import _lib
 
     run_cat2_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", EXPERT_CASES + [(4, 80, 80, 128, 256, 3, 8, [[0, 7], [3, 3], [5, 1], [2, 6]], 0)])
+def test_expert_conv_glds_direct(case):
+    from yolo_master_amd import _lib
+
+    run_expert_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
 
 

@@ -142,3 +142,41 @@ def test_conv1x1_cat2_glds_on_the_emulator(hostlib, case):
     fn = hostlib.ymk_conv1x1_cat2_glds
     fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_conv1x1_cat2_glds"]
     run_cat2_case(hostlib, case)
+
+
+EXPERT_CASES = [
+    # B, H, W, Cin, Cout, k, E, idx, two_stage
+    (2, 9, 7, 64, 64, 3, 4, [[2, 0], [1, 3]], 0),
+    (3, 17, 16, 128, 128, 3, 4, [[0, 1], [3, 3], [2, 0]], 1),         # image larger than one tile (272 pixels): tail tile per image
+    (2, 6, 5, 192, 64, 1, 16, [[15, 4, 9], [0, 15, 7]], 0),           # shared-inverted projections: 1x1, sixteen banks, three slots
+]
+
+
+def run_expert_case(lib, case, dev="cpu", stream=None):
+    from yolo_master_amd import _lib
+
+    B, H, W, Cin, Cout, k, E, idx, two = case
+    bf = torch.bfloat16
+    x = _rnd(B, H, W, Cin, seed=21).to(bf)
+    Kp = k * k * Cin
+    wp = (_rnd(E, Cout, Kp, seed=22) * Kp ** -0.5).to(bf)
+    it = torch.tensor(idx, dtype=torch.int32)
+    ref = emu_ops.expert_conv(x, wp, k, it)
+    K = it.shape[1]
+    out = torch.full((K * B, H, W, Cout), 7.0, dtype=bf, device=dev)
+    xd, wd, idd = x.to(dev), wp.to(dev), it.to(dev)
+    d = _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, B, H, W, Cin, Cout, k, 1, Cin, Cout, 0, Kp, _lib.ACT_NONE)
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    rc = lib.ymk_expert_conv_glds(C.byref(d), p(xd), p(wd), p(idd), K, E, p(out), two, stream)
+    assert rc == 0
+    err = float((out.float().cpu() - ref.float()).abs().max())
+    assert err <= 1.6e-2 * max(1.0, float(ref.float().abs().max())), f"max |d| {err:.3e}"
+
+
+@pytest.mark.parametrize("case", EXPERT_CASES)
+def test_expert_conv_glds_on_the_emulator(hostlib, case):
+    from yolo_master_amd import _lib
+
+    fn = hostlib.ymk_expert_conv_glds
+    fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_expert_conv_glds"]
+    run_expert_case(hostlib, case)

@@ -40,6 +40,10 @@ struct GldsArgs {
     // when up1), channels [C1, Cin) from x2; x2 == nullptr: single source
     const bf16_t* x2;
     int C1, ldx2, up1;
+    // routed experts (stride 1): w holds E filter banks [E][Cout][Kpad]; image b convolves with bank eidx[b*K + j] for slot j and
+    // writes image j*B + b of a slot-major output.  Tiles never straddle images.  eidx == nullptr: one filter bank.
+    const int32_t* eidx;
+    int K;
 };
 
 template <int BN, int STAGES>
@@ -64,7 +68,19 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int m0 = (bid / nt) * GLDS_BM, n0 = (bid % nt) * BN;
+    const int n0 = (bid % nt) * BN;
+    int m0 = (bid / nt) * GLDS_BM, Mlim = M, b_img = -1;
+    size_t out_base = 0;
+    const bf16_t* wbase = a.w;
+    if (a.eidx) {   // (slot, image, tile-in-image)
+        const int HW = a.Ho * a.Wo, tpi = (HW + GLDS_BM - 1) / GLDS_BM, r = bid / nt;
+        const int bj = r / tpi;
+        b_img = bj % a.B;
+        m0 = (r % tpi) * GLDS_BM;
+        Mlim = HW;
+        out_base = (size_t)bj * HW;
+        wbase = a.w + (size_t)a.eidx[b_img * a.K + bj / a.B] * a.Cout * a.Kpad;
+    }
     const int cpt = a.Cin >> 6;               // k-steps per filter tap
     const int nk = a.ks * a.ks * cpt;
     const int pad = a.ks >> 1;
@@ -80,13 +96,13 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         const int r = (j * 8 + wave) * 8 + lr;
         const int sc = (lc ^ (r & 7)) * 8;
         if (j < GW) {
-            wsrc[j] = a.w + (size_t)(n0 + r) * a.Kpad + sc;
+            wsrc[j] = wbase + (size_t)(n0 + r) * a.Kpad + sc;
         } else {
             const int p = m0 + r - BN;
             unsigned mask = 0;
             int off = 0, off2 = 0;
-            if (p < M) {
-                const int ox = p % a.Wo, oy = (p / a.Wo) % a.Ho, b = p / (a.Wo * a.Ho);
+            if (p < Mlim) {
+                const int ox = p % a.Wo, oy = (p / a.Wo) % a.Ho, b = b_img >= 0 ? b_img : p / (a.Wo * a.Ho);
                 const int iy0 = oy * a.stride - pad, ix0 = ox * a.stride - pad;
                 off = ((b * a.H + iy0) * a.W + ix0) * a.ldx + sc;
                 if (a.x2) {   // 1x1, stride 1: (oy, ox) is the pixel itself
@@ -188,15 +204,16 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     //      the end clamped to the last pixel) so that they overlap: one wait instead of one per fragment ---------------------
     f32x4 bv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(a.bias + n0 + ((wave % WN) * 4 + i) * 16 + fc * 4);
+    for (int i = 0; i < 4; ++i)
+        bv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + ((wave % WN) * 4 + i) * 16 + fc * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     u32x2 rr[4][TP];
     if (a.res) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const int p = min(m0 + ((wave / WN) * TP + j) * 16 + fr, M - 1);
-                rr[i][j] = load_raw4(a.res + (size_t)p * a.ldr + n0 + ((wave % WN) * 4 + i) * 16 + fc * 4);
+                const int p = min(m0 + ((wave / WN) * TP + j) * 16 + fr, Mlim - 1);
+                rr[i][j] = load_raw4(a.res + (out_base + p) * a.ldr + n0 + ((wave % WN) * 4 + i) * 16 + fc * 4);
             }
     }
 #pragma unroll
@@ -212,9 +229,9 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
                 unpack_raw4(rr[i][j], r0, r1, r2, r3);
                 v0 += r0; v1 += r1; v2 += r2; v3 += r3;
             }
-            if (p >= M) continue;
-            if (a.out_f32) store4(static_cast<float*>(a.y) + (size_t)p * a.ldy + co, v0, v1, v2, v3);
-            else store4(static_cast<bf16_t*>(a.y) + (size_t)p * a.ldy + co, v0, v1, v2, v3);
+            if (p >= Mlim) continue;
+            if (a.out_f32) store4(static_cast<float*>(a.y) + (out_base + p) * a.ldy + co, v0, v1, v2, v3);
+            else store4(static_cast<bf16_t*>(a.y) + (out_base + p) * a.ldy + co, v0, v1, v2, v3);
         }
     }
 }
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
 template <int BN, int STAGES>
 static int glds_launch(const GldsArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
-    const int grid = ((M + GLDS_BM - 1) / GLDS_BM) * (a.Cout / BN);
+    const int grid = (a.eidx ? a.K * a.B * ((a.Ho * a.Wo + GLDS_BM - 1) / GLDS_BM) : (M + GLDS_BM - 1) / GLDS_BM) * (a.Cout / BN);
     const size_t lds = (size_t)STAGES * (BN + GLDS_BM) * 8 * 16;
     static bool once = false;
     if (!once) {
@@ -253,7 +270,7 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
     a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.Kpad = d->Kpad; a.act = d->act;
     a.out_f32 = d->out_dtype == YMK_F32;
-    a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0;
+    a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = nullptr; a.K = 0;
     const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
     if (M <= 0) return YMK_OK;
     // 32-bit element offsets inside the kernel
@@ -275,10 +292,33 @@ extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int
     a.x = static_cast<const bf16_t*>(x1); a.w = static_cast<const bf16_t*>(w); a.bias = bias; a.res = nullptr; a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = 1; a.stride = 1;
     a.ldx = ldx1; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = d->act; a.out_f32 = 0;
-    a.x2 = static_cast<const bf16_t*>(x2); a.C1 = C1; a.ldx2 = ldx2; a.up1 = upsample1 ? 1 : 0;
+    a.x2 = static_cast<const bf16_t*>(x2); a.C1 = C1; a.ldx2 = ldx2; a.up1 = upsample1 ? 1 : 0; a.eidx = nullptr; a.K = 0;
     const int64_t M = (int64_t)a.B * a.H * a.W;
     if (M <= 0) return YMK_OK;
     if (M >= (1ll << 31) || (M + 2) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Cout % 128 == 0) return two_stage ? glds_launch<128, 2>(a, s) : glds_launch<128, 3>(a, s);
+    return two_stage ? glds_launch<64, 2>(a, s) : glds_launch<64, 3>(a, s);
+}
+
+// Routed-expert convolution (FusedExpertGroup moe/gated.py:1058-1076, SharedInvertedExpertGroup moe/experts.py:235-269) with
+// true sparse dispatch: only the filter banks the router picked run.  d describes ONE expert's convolution (Cout, Kpad of one
+// bank; stride 1; no activation); w [E][Cout][Kpad]; idx int32 [B][K]; y slot-major [K*B][Ho][Wo] rows of d->ldy.
+extern "C" int ymk_expert_conv_glds(const ymk_conv_desc* d, const void* x, const void* w, const int32_t* idx, int32_t K, int32_t E,
+                                    void* y, int32_t two_stage, void* stream) {
+    if (!d || !x || !w || !idx || !y || K < 1 || E < 1) return YMK_E_BADARG;
+    if (d->dtype != YMK_BF16 || d->out_dtype != YMK_BF16 || d->stride != 1 || (d->ksize != 1 && d->ksize != 3)) return YMK_E_BADARG;
+    if (d->Cin < 64 || d->Cin % 64 || d->Cout % 64 || d->ldx % 8 || d->ldy % 4 || d->Kpad != d->ksize * d->ksize * d->Cin ||
+        d->act != YMK_ACT_NONE)
+        return YMK_E_BADARG;
+    GldsArgs a;
+    a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(w); a.bias = nullptr; a.res = nullptr; a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = d->ksize; a.stride = 1;
+    a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = YMK_ACT_NONE; a.out_f32 = 0;
+    a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = idx; a.K = K;
+    const int64_t HW = (int64_t)d->H * d->W;
+    if (d->B <= 0 || HW <= 0) return YMK_OK;
+    if (((int64_t)d->B * HW + d->W + 2) * d->ldx >= (1ll << 31) || (int64_t)K * d->B * HW >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (d->Cout % 128 == 0) return two_stage ? glds_launch<128, 2>(a, s) : glds_launch<128, 3>(a, s);
     return two_stage ? glds_launch<64, 2>(a, s) : glds_launch<64, 3>(a, s);

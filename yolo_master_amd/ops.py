@@ -718,12 +718,18 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
     K = idx.shape[1]
     if idx.dtype != torch.int32 or tuple(idx.shape) != (B, K) or not idx.is_contiguous():
         raise ValueError("expert_conv: idx is a contiguous int32 [B, K] tensor")
-    zero_b = torch.zeros((E * Cout,), dtype=torch.float32, device=x.device)
-    f_all = conv2d(x, w_packed.reshape(E * Cout, Kp), zero_b, k, 1, False)
     if out is None:
         out = torch.empty((K * B, H, W, Cout), dtype=x.dtype, device=x.device)
     if not out.is_contiguous():
         raise ValueError("expert_conv: dense output")
+    if (int(os.environ.get("YMK_ENABLE", "0"), 0) & 4) and x.dtype == torch.bfloat16 and Cin % 64 == 0 and Cout % 64 == 0 and Kp == k * k * Cin:
+        # true sparse dispatch on the next tiled core (include/ymk_next.h): only the routed filter banks run
+        d = ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, B, H, W, Cin, Cout, k, 1, _nhwc(x)[4], Cout, 0, Kp, _lib.ACT_NONE)
+        check(lib.ymk_expert_conv_glds(C.byref(d), _p(x), _p(w_packed), _p(idx), K, E, _p(out),
+                                       1 if int(os.environ.get("YMK_ENABLE", "0"), 0) & 2 else 0, _stream()), "expert_conv_glds")
+        return out
+    zero_b = torch.zeros((E * Cout,), dtype=torch.float32, device=x.device)
+    f_all = conv2d(x, w_packed.reshape(E * Cout, Kp), zero_b, k, 1, False)
     check(lib.ymk_expert_gather(DT[x.dtype], _p(f_all), _nhwc(f_all)[4], _p(idx), B, H * W, Cout, K, E, _p(out), _stream()),
           "expert_gather")
     return out

@@ -142,3 +142,30 @@ def test_kernels_config5_L_scale_model(T):
     with torch.inference_mode():
         yb, _ = m._predict_once(x)
     assert bool(torch.isfinite(yb).all())
+
+
+def test_kernels_sparse_expert_dispatch_in_the_L_scale_gated_blocks(T, hostlib, monkeypatch):
+    """YMK_ENABLE bit 2: the routed experts of the gated blocks run through ymk_expert_conv_glds (only the routed filter banks)
+    instead of the all-experts convolution + gather.  bf16, L-scale widths (bottleneck 128 -> 4 / 8 banks of 256 couts, 3x3;
+    512 -> 16 banks, 1x1): both paths give the same block output up to bf16 rounding of the intermediate."""
+    from yolo_master_amd import _lib
+    from yolo_master_amd.nn.mixture import VisualEnhancedAdaptiveGateMoE
+
+    fn = hostlib.ymk_expert_conv_glds
+    fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_expert_conv_glds"]
+    for E in (4, 16):
+        torch.manual_seed(E)
+        m = VisualEnhancedAdaptiveGateMoE(512, 512, num_experts=E, top_k=2).eval()
+        m.ymk_dtype = torch.bfloat16
+        x = torch.randn(2, 512, 10, 12)
+        outs = []
+        for enable in ("0", "4"):
+            monkeypatch.setenv("YMK_ENABLE", enable)
+            before = emu_ops.CALLS.get("conv2d", 0)
+            with torch.inference_mode():
+                outs.append(m(x).float())
+            calls = emu_ops.CALLS.get("conv2d", 0) - before
+            outs.append(calls)
+        (dense, n_dense, sparse, n_sparse) = outs
+        assert n_sparse == n_dense - 1, "the all-experts convolution must be gone on the sparse path"
+        assert float((dense - sparse).abs().max()) <= 3e-2 * max(1.0, float(dense.abs().max()))

@@ -180,3 +180,30 @@ def test_expert_conv_glds_on_the_emulator(hostlib, case):
     fn = hostlib.ymk_expert_conv_glds
     fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_expert_conv_glds"]
     run_expert_case(hostlib, case)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_conv2d_glds_random_shapes(hostlib, seed):
+    """Seeded sweep over kernel size, stride, channel counts, map sizes (single pixels to several tiles), views, epilogue
+    options and both k-loops."""
+    import random
+
+    rng = random.Random(500 + seed)
+    k = rng.choice([1, 3])
+    case = (rng.randint(1, 3), rng.randint(1, 21), rng.randint(1, 21), rng.choice([64, 128, 192]), rng.choice([64, 128, 192, 256]), k,
+            rng.choice([1, 2]), rng.random() < 0.5, rng.random() < 0.5, rng.random() < 0.3, rng.choice([0, 8, 64]), rng.choice([0, 4, 64]),
+            rng.choice([0, 1]))
+    run_case(hostlib, case)
+    if seed % 4 == 0:   # and the virtual-concatenation / routed-expert forms on shapes drawn the same way
+        from yolo_master_amd import _lib
+
+        for name in ("ymk_conv1x1_cat2_glds", "ymk_expert_conv_glds"):
+            fn = getattr(hostlib, name)
+            fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT[name]
+        H, W = 2 * rng.randint(1, 8), 2 * rng.randint(1, 8)
+        run_cat2_case(hostlib, (rng.randint(1, 2), H, W, rng.choice([64, 128]), rng.choice([64, 192]), rng.choice([64, 128]), rng.random() < 0.5,
+                                rng.random() < 0.5, rng.choice([0, 8]), rng.choice([0, 64]), rng.choice([0, 64]), rng.choice([0, 1])))
+        B, E, K = rng.randint(1, 3), rng.choice([2, 5]), rng.randint(1, 2)
+        idx = [[rng.randrange(E) for _ in range(K)] for _ in range(B)]
+        run_expert_case(hostlib, (B, rng.randint(1, 18), rng.randint(1, 18), rng.choice([64, 128]), rng.choice([64, 128]), rng.choice([1, 3]), E, idx,
+                                  rng.choice([0, 1])))

@@ -48,6 +48,51 @@ def emu(monkeypatch):
     return emu_ops
 
 
+
+V0_OPS = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "esmoe_route", "esmoe_dw", "esmoe_pw",
+          "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32", "detect_decode",
+          "nms_batched"]
+
+
+@pytest.fixture(scope="session")
+def hostlib():
+    """libymk_hostemu.so: the config-5 / opt-in kernel sources compiled for the host by tests/hostemu (CPU lane emulator), bound
+    with the product's own ctypes tables."""
+    import ctypes as C
+
+    from tests.hostemu import build as hostemu_build
+    from yolo_master_amd import _lib
+
+    path = hostemu_build.build()
+    if path is None:
+        pytest.skip("no host clang++ to build the kernel emulation")
+    h = C.CDLL(str(path))
+    for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT}.items():
+        fn = getattr(h, name)
+        fn.restype, fn.argtypes = res, args
+    return h
+
+
+@pytest.fixture
+def T(hostlib, monkeypatch):
+    """tests/test_gpu_mixture.py re-targeted at the CPU: config-5 / opt-in entry points -> host-compiled kernels (the product's
+    wrappers call them through the same C-ABI), v0 entry points -> torch restatement (validated on the GPU already and not
+    under test there), tensors on the CPU."""
+    import tests.test_gpu_mixture as gpu_tests
+    from tests import emu_ops
+    from yolo_master_amd import ops, postprocess
+
+    monkeypatch.setenv("YMK_EXPERIMENTAL", "1")
+    monkeypatch.setattr(ops, "lib", hostlib)
+    monkeypatch.setattr(postprocess, "lib", hostlib)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
+    for name in V0_OPS:
+        monkeypatch.setattr(ops, name, getattr(emu_ops, name))
+    monkeypatch.setattr(gpu_tests, "DEV", "cpu")
+    return gpu_tests
+
+
 def pytest_runtest_logreport(report):
     """Append every failure (test id + traceback) to $YMK_TEST_FAILURE_LOG when set: lets a rare flake in a long
     unattended loop be identified afterwards."""

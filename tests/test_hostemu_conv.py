@@ -9,20 +9,6 @@ import pytest
 import torch
 
 from tests import emu_ops
-from tests.hostemu import build as hostemu_build
-
-
-@pytest.fixture(scope="module")
-def hostlib():
-    path = hostemu_build.build()
-    if path is None:
-        pytest.skip("no host clang++ to build the kernel emulation")
-    from yolo_master_amd import _lib
-
-    h = C.CDLL(str(path))
-    fn = h.ymk_conv2d_glds
-    fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_conv2d_glds"]
-    return h
 
 
 def _rnd(*shape, seed=0, scale=1.0):
@@ -137,10 +123,6 @@ def run_cat2_case(lib, case, dev="cpu", stream=None):
 
 @pytest.mark.parametrize("case", CAT2_CASES)
 def test_conv1x1_cat2_glds_on_the_emulator(hostlib, case):
-    from yolo_master_amd import _lib
-
-    fn = hostlib.ymk_conv1x1_cat2_glds
-    fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_conv1x1_cat2_glds"]
     run_cat2_case(hostlib, case)
 
 
@@ -175,10 +157,6 @@ def run_expert_case(lib, case, dev="cpu", stream=None):
 
 @pytest.mark.parametrize("case", EXPERT_CASES)
 def test_expert_conv_glds_on_the_emulator(hostlib, case):
-    from yolo_master_amd import _lib
-
-    fn = hostlib.ymk_expert_conv_glds
-    fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_expert_conv_glds"]
     run_expert_case(hostlib, case)
 
 
@@ -195,11 +173,6 @@ def test_conv2d_glds_random_shapes(hostlib, seed):
             rng.choice([0, 1]))
     run_case(hostlib, case)
     if seed % 4 == 0:   # and the virtual-concatenation / routed-expert forms on shapes drawn the same way
-        from yolo_master_amd import _lib
-
-        for name in ("ymk_conv1x1_cat2_glds", "ymk_expert_conv_glds"):
-            fn = getattr(hostlib, name)
-            fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT[name]
         H, W = 2 * rng.randint(1, 8), 2 * rng.randint(1, 8)
         run_cat2_case(hostlib, (rng.randint(1, 2), H, W, rng.choice([64, 128]), rng.choice([64, 192]), rng.choice([64, 128]), rng.random() < 0.5,
                                 rng.random() < 0.5, rng.choice([0, 8]), rng.choice([0, 64]), rng.choice([0, 64]), rng.choice([0, 1])))

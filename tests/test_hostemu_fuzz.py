@@ -7,7 +7,6 @@ import pytest
 import torch
 
 from tests import emu_ops
-from tests.test_hostemu_mixture import T, hostlib  # noqa: F401  (fixtures)
 
 TOL = {torch.float32: 3e-5, torch.bfloat16: 1.6e-2}
 
@@ -28,7 +27,7 @@ def _t(rng, shape, dtype, pad=0, scale=1.0):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_random_shapes(T, seed):  # noqa: F811
+def test_random_shapes(T, seed):
     from yolo_master_amd import ops
 
     rng = random.Random(1000 + seed)
@@ -79,7 +78,7 @@ def test_random_shapes(T, seed):  # noqa: F811
 
 
 @pytest.mark.parametrize("seed", range(16))
-def test_random_attention_shapes(T, seed):  # noqa: F811
+def test_random_attention_shapes(T, seed):
     from yolo_master_amd import ops
 
     rng = random.Random(2000 + seed)

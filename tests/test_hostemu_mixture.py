@@ -7,7 +7,6 @@ through the same ctypes tables and the same C-ABI as libymk, and the bodies of `
 with DEV = "cpu": every entry point against its contract restatement in fp32 and bf16, the 18 module fixtures of the
 real reference and the whole config-5 detector.  What this cannot see is anything hardware-specific (LDS capacity,
 launch limits, wave-level timing): that is what the GPU run of the same tests is for."""
-import ctypes as C
 import warnings
 
 import pytest
@@ -15,42 +14,6 @@ import torch
 
 from tests import emu_ops
 from tests.hostemu import build as hostemu_build
-
-V0_OPS = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "esmoe_route", "esmoe_dw", "esmoe_pw",
-          "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32", "detect_decode",
-          "nms_batched"]
-
-
-@pytest.fixture(scope="module")
-def hostlib():
-    path = hostemu_build.build()
-    if path is None:
-        pytest.skip("no host clang++ to build the kernel emulation")
-    from yolo_master_amd import _lib
-
-    h = C.CDLL(str(path))
-    for name, (res, args) in _lib.SYMBOLS_MIXTURE.items():
-        fn = getattr(h, name)
-        fn.restype, fn.argtypes = res, args
-    return h
-
-
-@pytest.fixture
-def T(hostlib, monkeypatch):
-    """tests/test_gpu_mixture.py re-targeted: mixture entry points -> host-compiled kernels, v0 entry points -> torch
-    restatement (they are validated on the GPU already and not under test here), tensors on the CPU."""
-    from yolo_master_amd import ops
-    import tests.test_gpu_mixture as gpu_tests
-
-    monkeypatch.setenv("YMK_EXPERIMENTAL", "1")
-    monkeypatch.setattr(ops, "lib", hostlib)
-    monkeypatch.setattr(ops, "_stream", lambda: None)
-    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
-    for name in V0_OPS:
-        monkeypatch.setattr(ops, name, getattr(emu_ops, name))
-    monkeypatch.setattr(gpu_tests, "DEV", "cpu")
-    return gpu_tests
-
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_kernels_norms_and_elementwise(T, dtype):
@@ -148,11 +111,8 @@ def test_kernels_sparse_expert_dispatch_in_the_L_scale_gated_blocks(T, hostlib, 
     """YMK_ENABLE bit 2: the routed experts of the gated blocks run through ymk_expert_conv_glds (only the routed filter banks)
     instead of the all-experts convolution + gather.  bf16, L-scale widths (bottleneck 128 -> 4 / 8 banks of 256 couts, 3x3;
     512 -> 16 banks, 1x1): both paths give the same block output up to bf16 rounding of the intermediate."""
-    from yolo_master_amd import _lib
     from yolo_master_amd.nn.mixture import VisualEnhancedAdaptiveGateMoE
 
-    fn = hostlib.ymk_expert_conv_glds
-    fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT["ymk_expert_conv_glds"]
     for E in (4, 16):
         torch.manual_seed(E)
         m = VisualEnhancedAdaptiveGateMoE(512, 512, num_experts=E, top_k=2).eval()

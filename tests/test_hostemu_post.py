@@ -1,26 +1,20 @@
 """ymk_scale_boxes (include/ymk_next.h, csrc/post.hip) on the CPU lane emulator through the product's own wrapper
 (yolo_master_amd/postprocess.py): bit-exact against the REAL reference's golden vectors, single image and batched."""
-import ctypes as C
-
 import numpy as np
 import pytest
 import torch
 
-from tests.hostemu import build as hostemu_build
 from tests.test_oracle_post import cases
 
 
 @pytest.fixture
-def post(monkeypatch):
-    path = hostemu_build.build()
-    if path is None:
-        pytest.skip("no host clang++ to build the kernel emulation")
-    from yolo_master_amd import _lib, ops, postprocess
+def post(hostlib, monkeypatch):
+    """yolo_master_amd.postprocess / ops wired to the host-compiled kernels (tests/conftest.py: hostlib)."""
+    from yolo_master_amd import ops, postprocess
 
-    h = C.CDLL(str(path))
-    h.ymk_scale_boxes.restype, h.ymk_scale_boxes.argtypes = _lib.SYMBOLS_NEXT["ymk_scale_boxes"]
     monkeypatch.setenv("YMK_EXPERIMENTAL", "1")
-    monkeypatch.setattr(postprocess, "lib", h)
+    monkeypatch.setattr(postprocess, "lib", hostlib)
+    monkeypatch.setattr(ops, "lib", hostlib)
     monkeypatch.setattr(ops, "_stream", lambda: None)
     monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
     return postprocess
@@ -86,20 +80,7 @@ def seg_kernel_checks(dev="cpu"):
         assert torch.equal(yd.cpu(), ref), dtype
 
 
-def test_segment_kernels_on_the_emulator(monkeypatch):
-    path = hostemu_build.build()
-    if path is None:
-        pytest.skip("no host clang++ to build the kernel emulation")
-    from yolo_master_amd import _lib, ops
-
-    h = C.CDLL(str(path))
-    for name in ("ymk_pixel_shuffle2", "ymk_tokens_to_rows"):
-        fn = getattr(h, name)
-        fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT[name]
-    monkeypatch.setenv("YMK_EXPERIMENTAL", "1")
-    monkeypatch.setattr(ops, "lib", h)
-    monkeypatch.setattr(ops, "_stream", lambda: None)
-    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
+def test_segment_kernels_on_the_emulator(post):
     seg_kernel_checks()
 
 
@@ -122,11 +103,6 @@ def mask_kernel_checks(golden_dir, dev="cpu"):
 
 
 def test_process_mask_on_the_emulator(post, golden_dir):
-    from yolo_master_amd import _lib
-
-    for name in ("ymk_process_mask", "ymk_mask_coeff_gather"):
-        fn = getattr(post.lib, name)
-        fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT[name]
     mask_kernel_checks(golden_dir)
 
 
@@ -137,13 +113,10 @@ def test_segmentation_predict_flow(post, emu, golden_dir):
 
     from oracle import nms_ref, post_ref
     from tests.helpers import fill_by_name
-    from yolo_master_amd import _lib, postprocess
+    from yolo_master_amd import postprocess
     from yolo_master_amd.nms import non_max_suppression
     from yolo_master_amd.nn.tasks import DetectionModel
 
-    for name in ("ymk_process_mask", "ymk_mask_coeff_gather"):
-        fn = getattr(post.lib, name)
-        fn.restype, fn.argtypes = _lib.SYMBOLS_NEXT[name]
     z = np.load(golden_dir / "fwd_seg_n.npz")
     cfg = json.loads(str(z["cfg"]))
     m = DetectionModel(cfg)

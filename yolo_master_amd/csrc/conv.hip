@@ -27,6 +27,8 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
 extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
                                      int32_t ldx2, const void* w, const float* bias, void* y, int32_t two_stage, void* stream);
 static int ymk_glds_min_tiles = [] { const char* e = getenv("YMK_GLDS_MIN_TILES"); return e ? atoi(e) : 192; }();
+// one workgroup per CU (144 KB of LDS): with fewer than four k-steps there is nothing to pipeline, the current kernels win
+static int ymk_glds_min_k = [] { const char* e = getenv("YMK_GLDS_MIN_K"); return e ? atoi(e) : 256; }();
 extern "C" int32_t ymk_conv2d_last_variant(void) { return ymk_last_variant; }
 
 template <typename T, bool PRECISE>
@@ -593,7 +595,7 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     }
     if ((ymk_enabled() & YMK_ON_CONV_GLDS) && d->dtype == YMK_BF16) {   // opt-in: next tiled core (include/ymk_next.h)
         const int64_t tiles = ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
-        if (d->Cout % 64 == 0 && tiles >= ymk_glds_min_tiles) {
+        if (d->Cout % 64 == 0 && tiles >= ymk_glds_min_tiles && d->Kpad >= ymk_glds_min_k) {
             const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 1 : 0, stream);
             if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; return rc; }
         }
@@ -625,7 +627,7 @@ extern "C" int ymk_conv1x1_cat2(const ymk_conv_desc* d, const void* x1, int32_t 
     if (a.M <= 0) return YMK_OK;
     if (a.M >= (1ll << 31) || (2ll * d->H * d->W + 4096) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31)) return YMK_E_BADARG;
     if ((ymk_enabled() & YMK_ON_CONV_GLDS) && d->dtype == YMK_BF16 && d->Cout % 64 == 0 &&
-        ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64)) >= ymk_glds_min_tiles) {   // opt-in: next tiled core
+        ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64)) >= ymk_glds_min_tiles && d->Kpad >= ymk_glds_min_k) {   // opt-in
         const int rc = ymk_conv1x1_cat2_glds(d, x1, C1, ldx1, upsample1, x2, ldx2, w, bias, y, (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 1 : 0, stream);
         if (rc != YMK_E_BADARG) return rc;
     }

@@ -116,8 +116,62 @@ def call_times(scale="s", B=64, dtype=torch.bfloat16, reps=3):
         print(f"{i:3d} {fam[:58]:58s} {shp:34s} {ms * 1e3:8.1f} us {nb / ms / 1e6:8.0f} GB/s {fl / ms / 1e9:8.1f} TF/s")
 
 
+def glds_ab(B=64, reps=20):
+    """Per-shape A/B of the opt-in tiled core (include/ymk_next.h) against what ymk_conv2d dispatches today, on the dense
+    convolutions of YOLO-Master-S at batch B (bf16, SiLU): median of `reps` event-timed launches each; results compared."""
+    import ctypes as C
+
+    from yolo_master_amd import _lib
+
+    lib = _lib.load()
+    shapes = [  # Cin, Cout, k, stride, input H = W
+        (128, 128, 3, 2, 160), (256, 256, 3, 2, 80), (128, 64, 3, 1, 80), (256, 512, 3, 2, 40), (256, 64, 3, 1, 40), (128, 128, 3, 2, 80),
+        (256, 256, 3, 2, 40), (384, 256, 1, 1, 40), (256, 128, 1, 1, 40), (512, 128, 1, 1, 80), (768, 256, 1, 1, 40), (64, 64, 1, 1, 160),
+        (128, 128, 3, 1, 40), (256, 64, 3, 1, 20)]
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    st = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2] * 1e3
+
+    print(f"{'shape':34s} {'today':>9s} {'glds s3':>9s} {'glds s2':>9s}   (us; TF/s of the best)")
+    for cin, cout, k, s, hw in shapes:
+        g = torch.Generator().manual_seed(cin + cout + k)
+        x = torch.randn(B, hw, hw, cin, generator=g).to(torch.bfloat16).to(DEV)
+        w = ops.pack_conv_weight(torch.randn(cout, cin, k, k, generator=g) * (k * k * cin) ** -0.5, torch.bfloat16).to(DEV)
+        bias = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+        ho = (hw + 2 * (k // 2) - k) // s + 1
+        ys = [torch.empty((B, ho, ho, cout), dtype=torch.bfloat16, device=DEV) for _ in range(3)]
+        d = _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, B, hw, hw, cin, cout, k, s, cin, cout, 0, w.shape[1], _lib.ACT_SILU)
+        t0 = timed(lambda: lib.ymk_conv2d(C.byref(d), p(x), p(w), p(bias), None, p(ys[0]), st))
+        var = lib.ymk_conv2d_last_variant()
+        res = []
+        for two, y in ((0, ys[1]), (1, ys[2])):
+            if lib.ymk_conv2d_glds(C.byref(d), p(x), p(w), p(bias), None, p(y), two, st) != 0:
+                res.append(float("nan"))
+                continue
+            res.append(timed(lambda: lib.ymk_conv2d_glds(C.byref(d), p(x), p(w), p(bias), None, p(y), two, st)))
+            torch.cuda.synchronize()
+            err = float((y.float() - ys[0].float()).abs().max())
+            if err > 0.05 * max(1.0, float(ys[0].float().abs().max())):
+                print(f"   MISMATCH two_stage={two}: max |d| {err:.3e}")
+        best = min([t0] + [r for r in res if r == r])
+        fl = 2.0 * B * ho * ho * cout * k * k * cin
+        print(f"{cin:4d}->{cout:<4d} k{k} s{s} in {hw:3d}^2 (v{var})        {t0:9.1f} {res[0]:9.1f} {res[1]:9.1f}   {fl / best / 1e6:7.1f}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "glds":
+        glds_ab()
+        sys.exit(0)
     if what in ("all", "err"):
         errors()
     if what in ("all", "time"):

@@ -17,3 +17,4 @@ timeout -k 5 120 tools/micro/conv256.bin > gpurun_out/${TAG}_conv256.log 2>&1; e
 timeout -k 5 120 tools/micro/gemm256.bin > gpurun_out/${TAG}_gemm256.log 2>&1; echo "gemm256 exit $?"
 cat gpurun_out/${TAG}_conv256.log
 tail -8 gpurun_out/${TAG}_gemm256.log
+timeout -k 5 240 python tools/gpu_diag.py glds > gpurun_out/${TAG}_glds_ab.log 2>&1; echo "glds per-shape A/B exit $?"; cat gpurun_out/${TAG}_glds_ab.log

@@ -230,7 +230,8 @@ def main():
     if rank == 0:
         total_images = world * a.batch * a.steps
         res = {
-            "metric": "images/sec @ 640x640 bs=64, YOLO-Master-S; per-image p50 latency",
+            "metric": "images/sec @ 640x640 bs=64, YOLO-Master-S; per-image p50 latency" if a.cfg is None else
+                      f"images/sec @ {a.imgsz}x{a.imgsz} bs={a.batch}, {a.cfg} scale {a.scale} (diagnostic run, not BASELINE's metric)",
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",

@@ -82,7 +82,6 @@ def T(hostlib, monkeypatch):
     from tests import emu_ops
     from yolo_master_amd import ops, postprocess
 
-    monkeypatch.setenv("YMK_EXPERIMENTAL", "1")
     monkeypatch.setattr(ops, "lib", hostlib)
     monkeypatch.setattr(postprocess, "lib", hostlib)
     monkeypatch.setattr(ops, "_stream", lambda: None)

@@ -2,11 +2,7 @@
 (a) the torch restatement of each entry point's contract (tests/emu_ops.py) on the same seeded inputs and
 (b) the REAL reference's golden vectors for the modules and the whole config-5 detector.
 
-These kernels were written after the round-1 GPU budget was spent and have not run on hardware yet, so the product keeps
-them switched off unless YMK_EXPERIMENTAL=1 — and so does this file: without that variable every test here is skipped
-(the driver's `pytest -m gpu` run must only report validated code).  First GPU job of the next round:
-
-    YMK_EXPERIMENTAL=1 python -m pytest tests/test_gpu_mixture.py -m gpu -q
+First hardware run: round 2 (profiles/r02_first_hw_run.log); part of the driver's `pytest -m gpu` run since then.
 """
 import os
 
@@ -16,8 +12,7 @@ import torch
 
 from tests import emu_ops
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("YMK_EXPERIMENTAL") != "1", reason="config-5 kernels are opt-in until validated")]
+pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = {torch.float32: 2e-5, torch.bfloat16: 1.6e-2}
 

@@ -1,7 +1,6 @@
 """Opt-in tiled convolution core (csrc/conv_glds.hip, include/ymk_next.h) on the GPU: the cases of
 tests/test_hostemu_conv.py through the real library, plus the library's own dispatch with YMK_ENABLE set.
-Skipped unless YMK_EXPERIMENTAL=1 (the kernel has only run on the CPU lane emulator so far); part of the first GPU job of
-the next round: `YMK_EXPERIMENTAL=1 python -m pytest tests/test_gpu_next.py -m gpu -q`."""
+First hardware run: round 2 (profiles/r02_first_hw_run.log)."""
 import os
 import subprocess
 import sys
@@ -11,8 +10,7 @@ import torch
 
 from tests.test_hostemu_conv import CASES, CAT2_CASES, EXPERT_CASES, run_case, run_cat2_case, run_expert_case
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("YMK_EXPERIMENTAL") != "1", reason="opt-in kernels are not validated on hardware yet")]
+pytestmark = pytest.mark.gpu
 
 BIG = [(4, 80, 80, 128, 128, 3, 2, True, False, False, 0, 0, 0), (4, 40, 40, 256, 256, 3, 2, True, True, False, 0, 0, 1),
        (2, 80, 80, 512, 128, 1, 1, True, False, False, 0, 128, 0), (8, 40, 40, 256, 64, 3, 1, True, False, True, 0, 0, 0)]
@@ -47,17 +45,17 @@ def test_model_with_the_new_core_enabled(enable):
     """The S detector at batch 8 with YMK_ENABLE set (read once per process -> subprocess): same detections as the default
     kernels on the median image (bf16; the two paths differ only in fp32 summation order)."""
     code = (
-        "import torch, json\\n"
-        "from yolo_master_amd.nn.tasks import DetectionModel\\n"
-        "from yolo_master_amd.weights import synth_state_dict, synth_input\\n"
-        "m = DetectionModel('yolo-master-s.yaml'); m.load_state_dict(synth_state_dict(m.state_dict(), seed=0))\\n"
-        "m = m.eval().to('cuda:0').set_compute_dtype(torch.bfloat16)\\n"
-        "with torch.inference_mode(): y, _ = m._predict_once(synth_input(8, 640, 640, seed=3).to('cuda:0'))\\n"
-        "torch.save(y.cpu(), __import__('sys').argv[1])\\n")
+        "import torch, json\n"
+        "from yolo_master_amd.nn.tasks import DetectionModel\n"
+        "from yolo_master_amd.weights import synth_state_dict, synth_input\n"
+        "m = DetectionModel('yolo-master-s.yaml'); m.load_state_dict(synth_state_dict(m.state_dict(), seed=0))\n"
+        "m = m.eval().to('cuda:0').set_compute_dtype(torch.bfloat16)\n"
+        "with torch.inference_mode(): y, _ = m._predict_once(synth_input(8, 640, 640, seed=3).to('cuda:0'))\n"
+        "torch.save(y.cpu(), __import__('sys').argv[1])\n")
     outs = []
     for tag, env in (("base", {}), ("glds", {"YMK_ENABLE": enable})):
         path = f"/tmp/ymk_next_{tag}_{enable}.pt"
-        subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=600)
+        subprocess.run([sys.executable, "-c", code, path], check=True, cwd=str(__import__('pathlib').Path(__file__).resolve().parent.parent), env={**os.environ, **env}, timeout=600)
         outs.append(torch.load(path))
     d = (outs[0] - outs[1]).abs()
     assert float(d[:, 4:].median()) < 2e-3 and float(d[:, :4].median()) < 0.5, (float(d[:, 4:].median()), float(d[:, :4].median()))

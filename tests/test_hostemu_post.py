@@ -12,7 +12,6 @@ def post(hostlib, monkeypatch):
     """yolo_master_amd.postprocess / ops wired to the host-compiled kernels (tests/conftest.py: hostlib)."""
     from yolo_master_amd import ops, postprocess
 
-    monkeypatch.setenv("YMK_EXPERIMENTAL", "1")
     monkeypatch.setattr(postprocess, "lib", hostlib)
     monkeypatch.setattr(ops, "lib", hostlib)
     monkeypatch.setattr(ops, "_stream", lambda: None)
@@ -45,11 +44,10 @@ def test_scale_detections_batched(post, golden_dir):
         assert torch.equal(dets[b, n:], before[b, n:]) and torch.equal(dets[b, :, 4:], before[b, :, 4:])   # nothing else touched
 
 
-def test_scale_boxes_is_opt_in(monkeypatch):
-    from yolo_master_amd import ops, postprocess
+def test_scale_boxes_has_no_cpu_path():
+    from yolo_master_amd import postprocess
 
-    monkeypatch.delenv("YMK_EXPERIMENTAL", raising=False)
-    with pytest.raises(ops.KernelNotBuilt):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         postprocess.scale_boxes((640, 640), torch.zeros(3, 4), (480, 640))
 
 

@@ -407,21 +407,10 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
 
 # ============================================================================= config-5 rows (MoA / MoT / gated MoE)
 # Entry points of include/ymk_mixture.h.  Their CONTRACT is fixed here — it is what nn/mixture.py is written against and
-# what tests/emu_ops.py restates for the CPU-side host tests.  Their HIP kernels (csrc/mixture.hip, csrc/mixattn.hip) are a
-# first, correctness-first implementation that compiles for gfx950 but was written after the round's GPU budget was
-# spent: it has NOT run on hardware yet.  Until tests/test_gpu_mixture.py has passed on an MI355X the wrappers refuse to
-# use them unless YMK_EXPERIMENTAL=1 is set — there is no CPU / PyTorch fallback either way.  Conventions as above: NHWC
-# views [B, H, W, C] with a pixel stride ld >= C, activations in the compute dtype, statistics / gates / router math fp32.
-class KernelNotBuilt(NotImplementedError):
-    pass
-
-
-def _gate(name: str):
-    if os.environ.get("YMK_EXPERIMENTAL") != "1":
-        raise KernelNotBuilt(f"libymk's kernel for `{name}` (config-5 row) has not been validated on hardware yet and is switched "
-                             "off; set YMK_EXPERIMENTAL=1 to run it. There is no CPU / PyTorch fallback")
-
-
+# what tests/emu_ops.py restates for the CPU-side host tests.  The HIP kernels (csrc/mixture.hip, csrc/mixattn.hip) are
+# validated on MI355X by tests/test_gpu_mixture.py (first hardware run: round 2, profiles/r02_first_hw_run.log).  There is
+# no CPU / PyTorch fallback: every wrapper goes through `_nhwc` -> `require_gpu`.  Conventions as above: NHWC views
+# [B, H, W, C] with a pixel stride ld >= C, activations in the compute dtype, statistics / gates / router math fp32.
 ACT_CODES = (False, True, "silu", "sigmoid", "gelu")   # conv / norm epilogues of the config-5 modules
 _ACT = {False: _lib.ACT_NONE, None: _lib.ACT_NONE, True: _lib.ACT_SILU, "silu": _lib.ACT_SILU, "sigmoid": _lib.ACT_SIGMOID,
         "gelu": _lib.ACT_GELU}
@@ -440,7 +429,6 @@ def conv2d_act(x, w_packed, bias, k: int, stride: int, act, out=None, residual=N
         return conv2d(x, w_packed, bias, k, stride, bool(act), out=out, residual=residual, out_dtype=out_dtype)
     if act not in ACT_CODES:
         raise ValueError(f"unknown activation {act!r}")
-    _gate(f"conv2d epilogue {act}")
     if residual is not None:
         raise NotImplementedError("conv2d_act: sigmoid / gelu epilogues take no residual")
     y = conv2d(x, w_packed, bias, k, stride, False, out=out, out_dtype=out_dtype)
@@ -455,7 +443,6 @@ def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, ou
     affine_rows int32 [B] choosing the row per image (FusedExpertGroup's per-expert affine, moe/gated.py:1058-1090).
     act in (False, "silu"); residual (same shape) is added after the activation (MoTBlock's out_norm(.) + x,
     mot/block.py:413-417).  x may be a channel slice (C channels of a wider buffer); any C >= 1; out may alias x."""
-    _gate("group_norm")
     B, H, W, Cc, ldx = _nhwc(x)
     out, ldy = _out_like(x, out, out_dtype)
     ldr = _nhwc(residual)[4] if residual is not None else 0
@@ -469,7 +456,6 @@ def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, ou
 
 def layer_norm(x, weight, bias, eps: float, out=None):
     """LayerNorm over the channel vector of every token (torch.nn.LayerNorm(C)), fp32 statistics."""
-    _gate("layer_norm")
     B, H, W, Cc, ldx = _nhwc(x)
     out, ldy = _out_like(x, out)
     check(lib.ymk_layer_norm(DT[x.dtype], _p(x), ldx, _p(out), ldy, B * H * W, Cc, _p(weight), _p(bias), float(eps), _stream()),
@@ -490,7 +476,6 @@ def _eltwise(op, a, b, alpha, out, what):
 def eltwise_mul(a, b, out=None, act_a=None):
     """out = act_a(a) * b, same shapes; act_a in (None, "sigmoid") (GLU of the MoT local expert: sigmoid(gate) * value,
     mot/experts.py:160-166)."""
-    _gate("eltwise_mul")
     if act_a not in (None, "sigmoid"):
         raise ValueError(act_a)
     return _eltwise(_lib.ELT_SIGMOID_MUL if act_a else _lib.ELT_MUL, a, b, 0.0, out, "eltwise_mul")
@@ -498,14 +483,12 @@ def eltwise_mul(a, b, out=None, act_a=None):
 
 def lerp(a, b, alpha: float, out=None):
     """out = (1 - alpha) * a + alpha * b (exact / linear attention blend, moa/heads.py:366-374)."""
-    _gate("lerp")
     return _eltwise(_lib.ELT_LERP, a, b, alpha, out, "lerp")
 
 
 def fma_gate(x, a, b, scale, out=None):
     """out = x + scale * a * b with scale a host float; b is a map [B,H,W,C] or a per-image channel gate [B,1,1,C] fp32
     (detail gate x*(1+s*g), context mixer x+s*c*gate, refinement x+s*r*g: moe/gated.py:1171-1218, hooks.py:60-68)."""
-    _gate("fma_gate")
     B, H, W, Cc, ldx = _nhwc(x)
     lda = _nhwc(a)[4]
     per_image = tuple(b.shape) == (B, 1, 1, Cc) and (H, W) != (1, 1)
@@ -523,7 +506,6 @@ def fma_gate(x, a, b, scale, out=None):
 
 def channel_gate(x, gate, out=None):
     """out = x * gate with gate fp32 [B,1,1,C] (squeeze-excite gate of the gated MoE, moe/gated.py:333-341)."""
-    _gate("channel_gate")
     B, H, W, Cc, ldx = _nhwc(x)
     if gate.dtype != torch.float32 or tuple(gate.shape) != (B, 1, 1, Cc) or not gate.is_contiguous():
         raise ValueError("channel_gate: gate is a contiguous fp32 [B,1,1,C] tensor")
@@ -535,7 +517,6 @@ def channel_gate(x, gate, out=None):
 def weighted_sum(weights, parts, out=None):
     """out = sum_e weights[..., e] * parts[e]; weights fp32 [B,H,W,>=E] per token or [B,1,1,>=E] per image
     (MoA head mix moa/block.py:230-262, MoT expert blend mot/block.py:360-417, gated expert mix)."""
-    _gate("weighted_sum")
     B, H, W, Cc, ldp = _nhwc(parts[0])
     E = len(parts)
     if not 1 <= E <= 4 or any(_nhwc(p_)[4] != ldp or p_.dtype != parts[0].dtype or p_.shape != parts[0].shape for p_ in parts):
@@ -554,7 +535,6 @@ def weighted_sum(weights, parts, out=None):
 def mean_upsampled(parts, out=None):
     """out = mean_i nearest_resize(parts[i] -> size of parts[0]) (F.interpolate mode="nearest": src = floor(dst * h / H));
     PyramidContextMixer.forward moe/gated.py:1209-1216."""
-    _gate("mean_upsampled")
     B, H, W, Cc, _ = _nhwc(parts[0])
     n = len(parts)
     if not 1 <= n <= 4:
@@ -570,7 +550,6 @@ def mean_upsampled(parts, out=None):
 
 def adaptive_avg_pool(x, Ho: int, Wo: int, out=None, out_dtype=None):
     """F.adaptive_avg_pool2d bins: rows [floor(i*H/Ho), ceil((i+1)*H/Ho))."""
-    _gate("adaptive_avg_pool")
     B, H, W, Cc, ldx = _nhwc(x)
     out, ldy = _out_like(x, out, out_dtype, (B, Ho, Wo, Cc))
     check(lib.ymk_adaptive_avg_pool(DT[x.dtype], _p(x), ldx, _p(out), DT[out.dtype], ldy, B, H, W, Cc, Ho, Wo, _stream()),
@@ -580,7 +559,6 @@ def adaptive_avg_pool(x, Ho: int, Wo: int, out=None, out_dtype=None):
 
 def avg_pool(x, k: int, out=None, out_dtype=None):
     """F.avg_pool2d(kernel_size=k, stride=k): floor(H/k) x floor(W/k) outputs, remainder rows/columns dropped."""
-    _gate("avg_pool")
     B, H, W, Cc, ldx = _nhwc(x)
     out, ldy = _out_like(x, out, out_dtype, (B, H // k, W // k, Cc))
     check(lib.ymk_avg_pool(DT[x.dtype], _p(x), ldx, _p(out), DT[out.dtype], ldy, B, H, W, Cc, k, _stream()), "avg_pool")
@@ -590,7 +568,6 @@ def avg_pool(x, k: int, out=None, out_dtype=None):
 def channel_stats(x, want_std: bool = False):
     """Per image and channel mean (and biased std) over H*W in fp32: returns [B,1,1,C] (or [B,1,1,2C] = [mean | std],
     DualStreamGateRouter's global stream moe/gated.py:133-139)."""
-    _gate("channel_stats")
     B, H, W, Cc, ldx = _nhwc(x)
     out = torch.empty((B, 1, 1, 2 * Cc if want_std else Cc), dtype=torch.float32, device=x.device)
     check(lib.ymk_channel_stats(DT[x.dtype], _p(x), ldx, _p(out), B, H * W, Cc, int(want_std), _stream()), "channel_stats")
@@ -610,7 +587,6 @@ def attention(q, k, v, heads: int, hd: int, scale: float, out=None):
     """softmax(q k^T * scale) v per (image, head).  q [B,Hq,Wq,heads*hd], k/v [B,Hk,Wk,heads*hd] channel-slice views
     (tokens row-major); any hd that is a multiple of 8.  MoA regional / global-exact heads (moa/heads.py:208-253,
     354-365), MoT local expert (mot/experts.py:150-156)."""
-    _gate("attention")
     B, Hq, Wq, Hk, Wk, ldq, ldk, ldv = _qkv_geometry(q, k, v, heads, hd, "attention")
     out, ldo = _out_like(q, out)
     check(lib.ymk_attention(DT[q.dtype], _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, Hq * Wq, Hk * Wk, heads, hd,
@@ -624,7 +600,6 @@ def window_attention(q, k, v, heads: int, hd: int, scale: float, win: int, shift
     carry the fp32 vectors pad_q / pad_k / pad_v [heads*hd] (None = zeros) and take part as keys; with shift > 0 the
     padded grid is rolled by -shift in both axes before the partition and rolled back after (no mask).
     moa/heads.py:83-117, mot/experts.py:237-325."""
-    _gate("window_attention")
     B, H, W, Hk, Wk, ldq, ldk, ldv = _qkv_geometry(q, k, v, heads, hd, "window_attention")
     if (Hk, Wk) != (H, W):
         raise ValueError("window_attention: q, k, v live on one map")
@@ -640,7 +615,6 @@ def window_attention(q, k, v, heads: int, hd: int, scale: float, win: int, shift
 def linear_attention(q, k, v, rf, heads: int, hd: int, out=None):
     """ReLU random-feature attention of _GlobalAttnHead._linear_attn (moa/heads.py:318-352), fp32 math:
     phi(t) = min(relu(t rf^T / sqrt(nb)) + 1e-6, 1e4); out = clamp(phi(q) (phi(k)^T v), +-1e4) / max(phi(q) sum phi(k), 1e-6)."""
-    _gate("linear_attention")
     B, H, W, Hk, Wk, ldq, ldk, ldv = _qkv_geometry(q, k, v, heads, hd, "linear_attention")
     if (Hk, Wk) != (H, W) or rf.dtype != torch.float32 or rf.shape[1] != hd or not rf.is_contiguous():
         raise ValueError("linear_attention: q, k, v on one map; rf a contiguous fp32 [nb, hd] matrix")
@@ -656,7 +630,6 @@ def deform_attention(v, off_logits, aw_logits, heads: int, hd: int, n_points: in
     """_DeformableTransformerExpert._deform_attn (mot/experts.py:381-459): per token and head, locations =
     clamp(ref + 0.25 * tanh(off_logits), -1, 1) around the token's own normalised position, weights = softmax over the
     points of aw_logits, bilinear samples of v's head slice (zeros padding), weighted sum.  Coordinates fp32."""
-    _gate("deform_attention")
     B, H, W, Cc, ldv = _nhwc(v)
     if off_logits.dtype != torch.float32 or aw_logits.dtype != torch.float32 or Cc != heads * hd:
         raise ValueError("deform_attention: fp32 offsets / weights, v [B,H,W,heads*hd]")
@@ -671,7 +644,6 @@ def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None):
     """Per-token softmax over the first n channels of fp32 logits scaled by inv_temp; with 0 < top_k < n the top_k
     largest are kept and renormalised (sum clamped at 1e-6), the rest set to 0 (mot/router.py:243-295, moa/router.py:50-62).
     Returns (weights fp32 [B,H,W,n], active int32 [B,n] = 1 where any token of the image gives expert e a nonzero weight)."""
-    _gate("token_softmax")
     B, H, W, Cc, ldl = _nhwc(logits)
     if logits.dtype != torch.float32 or Cc < n:
         raise ValueError("token_softmax: fp32 logits with at least n channels")
@@ -688,7 +660,6 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
     sigmoid(cplx_logit[b]), 0.3, 1.5) (1.0 when non-finite) keeps round(c * top_k) in [1, top_k] ranked experts and
     renormalises (clamp 1e-6).  Inputs fp32 [B,1,1,E] / [B,1,1,1]; returns (w fp32 [B,1,1,top_k], idx int32 [B,top_k], probs,
     rows int32 [top_k*B] = idx transposed: the expert of image j*B + b in expert_conv's slot-major output)."""
-    _gate("gated_route_decide")
     B, E = g_logits.shape[0], g_logits.shape[-1]
     for t in (g_logits, loc_logits, cplx_logit):
         if t.dtype != torch.float32 or t.shape[0] != B or t.shape[1:3] != (1, 1) or t.stride(3) != 1:
@@ -712,7 +683,6 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
     SharedInvertedExpertGroup (moe/experts.py:235-269).  First implementation: ALL experts' rows run as one ymk_conv2d
     (what the reference's fused convolution does) and the routed slices are gathered; the grouped-GEMM machinery of the
     ES-MoE stage (resident expert weights, only routed rows) replaces it once parity holds."""
-    _gate("expert_conv")
     B, H, W, Cin, _ = _nhwc(x)
     E, Cout, Kp = w_packed.shape
     K = idx.shape[1]
@@ -738,7 +708,6 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
 def channel_shuffle_cat(parts, groups: int, out=None):
     """Channel concatenation followed by _channel_shuffle (moe/gated.py:1333-1338) in one pass:
     out[..., j * groups + i] = cat(parts)[..., i * (C / groups) + j]."""
-    _gate("channel_shuffle_cat")
     if len(parts) != 2 or parts[0].dtype != parts[1].dtype or parts[0].shape[:3] != parts[1].shape[:3]:
         raise ValueError("channel_shuffle_cat: two maps of one size and dtype")
     a, b = parts
@@ -753,7 +722,6 @@ def channel_shuffle_cat(parts, groups: int, out=None):
 def pixel_shuffle2(t, out=None):
     """Depth-to-space by 2: t [B,H,W,4C] (phase-major channel slices) -> [B,2H,2W,C]; with the 4C-channel 1x1 convolution in
     front it is Proto's ConvTranspose2d(C, C, 2, 2) (nn/modules/block.py:101-107)."""
-    _gate("pixel_shuffle2")
     B, H, W, C4, ldt = _nhwc(t)
     Cc = C4 // 4
     out, ldo = _out_like(t, out, None, (B, 2 * H, 2 * W, Cc))
@@ -764,7 +732,6 @@ def pixel_shuffle2(t, out=None):
 def tokens_to_rows(x, y, a_off: int, row_off: int = 0):
     """y[b][row_off + c][a_off + p] = x[b][p][c] for an NHWC map x and an fp32 [B, rows, A] tensor y (mask coefficients of the
     Segment head in the reference's layout, nn/modules/head.py:341-349)."""
-    _gate("tokens_to_rows")
     B, H, W, Cc, ldx = _nhwc(x)
     if y.dtype != torch.float32 or not y.is_contiguous() or y.shape[0] != B:
         raise ValueError("tokens_to_rows: y is a contiguous fp32 [B, rows, A] tensor")

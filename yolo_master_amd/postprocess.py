@@ -37,7 +37,6 @@ def _params(img1_shape, img0_shapes, ratio_pads, device):
 def scale_detections(img1_shape, dets: torch.Tensor, counts: torch.Tensor | None, img0_shapes, ratio_pads=None, padding: bool = True,
                      xywh: bool = False) -> torch.Tensor:
     """dets fp32 [B, max_det, >=4] (as returned by nms_padded), rescaled in place image by image."""
-    ops._gate("scale_boxes")
     ops.require_gpu(dets, "yolo_master_amd post-processing")
     if dets.dtype != torch.float32 or dets.dim() != 3 or dets.stride(2) != 1 or dets.stride(0) != dets.shape[1] * dets.stride(1):
         raise ValueError("scale_detections: fp32 [B, max_det, >=4] detections with contiguous rows")
@@ -61,7 +60,6 @@ def scale_boxes(img1_shape, boxes: torch.Tensor, img0_shape, ratio_pad=None, pad
 def gather_mask_coefficients(mc: torch.Tensor, b: int, idx: torch.Tensor) -> torch.Tensor:
     """Mask coefficients of the anchors NMS kept for image b: mc fp32 [B, nm, A] (Segment head), idx int64 [n] (the
     `return_idxs` output of non_max_suppression) -> fp32 [n, nm]."""
-    ops._gate("process_mask")
     ops.require_gpu(mc, "yolo_master_amd post-processing")
     if mc.dtype != torch.float32 or not mc.is_contiguous() or idx.dtype != torch.int64 or not idx.is_contiguous():
         raise ValueError("gather_mask_coefficients: contiguous fp32 [B, nm, A] coefficients, contiguous int64 indices")
@@ -76,7 +74,6 @@ def process_mask(protos: torch.Tensor, masks_in: torch.Tensor, bboxes: torch.Ten
     module leaves them: NHWC [mh, mw, nm] (a channel-dense view; the reference takes [nm, mh, mw]).  masks_in fp32 [n, nm],
     bboxes fp32 [n, >=4] xyxy in network-input pixels, shape = (H, W) of the network input.  Returns uint8 [n, H, W] when
     upsample else [n, mh, mw]."""
-    ops._gate("process_mask")
     ops.require_gpu(protos, "yolo_master_amd post-processing")
     if protos.dim() != 3 or protos.stride(2) != 1 or protos.stride(0) != protos.shape[1] * protos.stride(1):
         raise ValueError("process_mask: prototypes are an NHWC [mh, mw, nm] view of one image")

@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scale", default="s")
     ap.add_argument("--cfg", default=None, help="model YAML other than the v0 detector, e.g. yolo-master-moa-mot.yaml with --scale l "
-                    "--imgsz 1280 --batch 16 for BASELINE config 5 (needs YMK_EXPERIMENTAL=1 until its kernels are validated)")
+                    "--imgsz 1280 --batch 16 for BASELINE config 5")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -139,23 +139,27 @@ def main():
         y, _ = model._predict_once(x)
         return nms_padded(y, 0.25, 0.7, max_det=300)
 
-    def step():
-        dets, counts, idx, status = local_step()
+    gathered = {}   # the three all_gather outputs, allocated once
+
+    def finish(local_out):
+        """What follows the rank-local work of a step: for N>1 the RCCL all_gather of the padded detections (outside the
+        captured graph: a collective is not part of the rank-local launch sequence)."""
+        dets, counts, idx, status = local_out
         if world > 1:
-            dets, counts, idx = gather_detections(dets, counts, idx)
-        return dets, counts
+            dets, counts, idx = gather_detections(dets, counts, idx, out=gathered)
+        return dets, counts, status
 
     with torch.inference_mode():
         for _ in range(max(a.warmup, 1)):
-            out = step()
+            out = finish(local_step())
         torch.cuda.synchronize()
         model.check_flags()
-        graph = None
-        if not a.no_graph and world == 1:
+        graph, static_out = None, None
+        if not a.no_graph:   # the rank-local step (forward + NMS) is one captured HIP graph at every N
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    out = step()
+                    static_out = local_step()
                 graph.replay()
                 torch.cuda.synchronize()
             except Exception as e:  # pragma: no cover
@@ -163,7 +167,14 @@ def main():
                     print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
-        run = graph.replay if graph is not None else step
+
+        def run():
+            if graph is not None:
+                graph.replay()
+                return finish(static_out)
+            return finish(local_step())
+
+        out = run()
 
         if world > 1:
             dist.barrier()
@@ -184,6 +195,11 @@ def main():
             elapsed = float(t.item())
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
         p50_ms = per_step[len(per_step) // 2]
+        from yolo_master_amd._lib import FLAG_NMS_OVERFLOW
+
+        model.check_flags()                       # device flag words of the timed steps, read once after the loop
+        if int(out[2].item()) & FLAG_NMS_OVERFLOW:
+            raise RuntimeError("bench: the NMS candidate buffer overflowed during the timed steps (results truncated)")
 
         # roofline leg: per-call HIP events around every op family (eager launches on this stream); the object
         # reported is the family with the largest share of the step, the rest go into "families"
@@ -229,15 +245,18 @@ def main():
 
     if rank == 0:
         total_images = world * a.batch * a.steps
+        headline = a.cfg is None and (a.scale, a.batch, a.imgsz, a.dtype) == ("s", 64, 640, "bf16")
+        cfgtag = ("BASELINE.json configs[2]" + ("/[3]" if world > 1 else "")) if headline else "not the headline configuration"
         res = {
-            "metric": "images/sec @ 640x640 bs=64, YOLO-Master-S; per-image p50 latency" if a.cfg is None else
-                      f"images/sec @ {a.imgsz}x{a.imgsz} bs={a.batch}, {a.cfg} scale {a.scale} (diagnostic run, not BASELINE's metric)",
+            "metric": "images/sec @ 640x640 bs=64, YOLO-Master-S; per-image p50 latency" if headline else
+                      f"images/sec @ {a.imgsz}x{a.imgsz} bs={a.batch}, {a.cfg or 'YOLO-Master-' + a.scale.upper()} scale {a.scale} {a.dtype} "
+                      "(diagnostic run, not BASELINE's metric)",
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "p50_ms_per_image": round(p50_ms / a.batch, 5),
             "config": {"workload": (f"YOLO-Master-{a.scale.upper()} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, "
-                                    f"bs={a.batch}/GPU, ES-MoE top-k=2 (BASELINE.json configs[2]{'/[3]' if world > 1 else ''})") if a.cfg is None else
+                                    f"bs={a.batch}/GPU, ES-MoE top-k=2 ({cfgtag})") if a.cfg is None else
                                    f"{a.cfg} at scale {a.scale} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, bs={a.batch}/GPU (not the headline configuration)",
                        "global_batch": world * a.batch, "imgsz": a.imgsz, "parallelism": f"dp{world} (image shards, no data-path collective)",
                        "launch": "hipGraph" if graph is not None else "eager", "weights": "seeded random + BN calibration (no checkpoints offline)"},

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YMK_ABI_VERSION 1
+#define YMK_ABI_VERSION 2
 
 /* error codes */
 #define YMK_OK 0
@@ -133,7 +133,12 @@ int ymk_dwconv2d(int32_t dtype, const void* x, const void* w, const float* bias,
  *   sel       int32 [B][top_k] expert id per slot in ascending expert order, -1 = unused
  *   csr_off   int32 [E+1]   expert -> range in csr_pair
  *   csr_pair  int32 [B*top_k] packed (b*top_k + slot), grouped by expert, b ascending
+ *   state     fp32 [E+1]    (nullable) the eval-time buffers ES_MOE keeps (modules.py:706-741, moe/loss.py:16-26):
+ *                           state[e] = expert_usage_counts[e] = mean over the batch of route_w[:, e],
+ *                           state[E] = load_balancing_loss = E * sum_e (u_e / max(sum u, 1e-6))^2
  *   flags     int32 [1]     YMK_FLAG_NONFINITE_* bits (atomicOr)
+ * dynamic_threshold > 0: prune the non-leading top-k experts below it; == 0: keep the whole top-k set (renormalised);
+ * < 0: the DENSE forward (use_sparse_inference=False, modules.py:648-656) — gate_w = route_w, nothing renormalised.
  * workspace: ymk_esmoe_route_workspace_bytes(B, C, H, W) (partial pooling sums).
  */
 size_t ymk_esmoe_route_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
@@ -141,8 +146,8 @@ int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t 
                     int32_t ldx, const float* w1 /*[hidden][C]*/, const float* b1,
                     const float* w2 /*[E][hidden]*/, const float* b2, int32_t hidden, int32_t E,
                     int32_t top_k, float dynamic_threshold, float* route_w, float* gate_w,
-                    int32_t* sel, int32_t* csr_off, int32_t* csr_pair, int32_t* flags,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    int32_t* sel, int32_t* csr_off, int32_t* csr_pair, float* state /*[E+1], nullable*/,
+                    int32_t* flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Depthwise stage of the retained experts, dispatched over the CSR pairs
  * (experts.py:283-292, modules.py:690-697).  dw_w is one blob holding every
@@ -209,11 +214,12 @@ int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int3
  * Detect decode: DFL softmax-expectation + dist2bbox(xywh) * stride + sigmoid
  * (Detect._inference head.py:173-194, DFL.forward block.py:81-84,
  *  make_anchors/dist2bbox utils/tal.py:398-423).
- * box_l / cls_l: fp32 NHWC logits of one level: [B][H_l*W_l][4*reg_max] / [..][nc].
+ * box_l / cls_l: fp32 NHWC logits of one level: [B][H_l*W_l][4*reg_max] / [..][ldc].
+ * ldc: row stride of cls_l in floats: nc, or 4*ceil(nc/4) when the class rows are padded to 16 bytes (nc % 4 != 0).
  * y: fp32 [B][4+nc][A_total]; this call fills anchors [a_off, a_off + H_l*W_l).
  * ------------------------------------------------------------------------ */
 int ymk_detect_decode(const float* box_l, const float* cls_l, float* y, int32_t B, int32_t Hl,
-                      int32_t Wl, int32_t reg_max, int32_t nc, float stride, int32_t a_off,
+                      int32_t Wl, int32_t reg_max, int32_t nc, int32_t ldc, float stride, int32_t a_off,
                       int32_t A_total, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -230,17 +236,20 @@ size_t ymk_nms_workspace_bytes(int32_t B, int32_t nc, int32_t A, int32_t multi_l
                                int32_t max_nms);
 int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A, float conf_thres,
                     float iou_thres, int32_t multi_label, int32_t agnostic, int32_t max_det,
-                    int32_t max_nms, float max_wh, float* out_dets, int32_t* out_counts,
-                    int32_t* out_idx, int32_t* status, void* workspace, size_t workspace_bytes,
-                    void* stream);
+                    int32_t max_nms, float max_wh, const uint8_t* class_keep /*[nc] or NULL*/,
+                    float* out_dets, int32_t* out_counts, int32_t* out_idx, int32_t* status,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* class_keep: the `classes=` filter of non_max_suppression (utils/nms.py:63,132): a candidate survives only when
+ * class_keep[its class] != 0; applied after the best-class choice of the single-label path, as the reference does. */
 
 /* Cluster-weighted box refinement (CW-NMS).  Not implemented in the reference's
  * Python; algorithm spec = examples/YOLO-Master-Cross-Platform-Edge-Deployment/
  * cpp/src/common.cpp:150-185 (fp64 accumulation, pool = top-3000 candidates).
  * Must be called right after ymk_nms_batched with the same workspace and the same
  * (B, nc, A, multi_label, max_nms) so that the workspace layout matches;
- * rewrites out_dets[..][0:4] in place, keep-set/order/scores/classes unchanged. */
-int ymk_cw_refine(int32_t B, int32_t nc, int32_t A, int32_t multi_label, int32_t max_nms, int32_t max_det,
+ * rewrites out_dets[..][0:4] in place, keep-set/order/scores/classes unchanged.
+ * agnostic != 0 (class-agnostic suppression was used): clusters ignore classes too (the spec defines only the per-class case). */
+int ymk_cw_refine(int32_t B, int32_t nc, int32_t A, int32_t multi_label, int32_t agnostic, int32_t max_nms, int32_t max_det,
                   float iou_thres, float sigma, int32_t pool_cap, float* out_dets,
                   const int32_t* out_counts, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -154,22 +154,28 @@ def stable_normalize(t, dim, eps=1e-6):
     return t / t.sum(dim=dim, keepdim=True).clamp_min(eps)
 
 
-def esmoe_route(sd, p, x, top_k=2, thr=0.4):
+def esmoe_route(sd, p, x, top_k=2, thr=0.4, hard_top_k=True, sparse=True):
     """DynamicRoutingLayer.forward + _hard_top_k (moe/routers.py:458-527) and the dispatch decision of
-    ES_MOE._sparse_forward (moe/modules.py:665-684).  Returns (route_w [B,E], gate_w [B,E], retained [B,E])."""
+    ES_MOE._sparse_forward (moe/modules.py:665-684).  Returns (route_w [B,E], gate_w [B,E], retained [B,E], logits).
+    hard_top_k=False: `top_k=None` modules, plain softmax (routers.py:477-479).  sparse=False (or top_k >= E): the dense
+    forward (modules.py:648-656) — every expert is summed with its routing weight, nothing is pruned or renormalised;
+    `retained` then marks the experts with a non-zero weight (the others contribute exactly 0)."""
     B = x.shape[0]
     pooled = F.adaptive_avg_pool2d(x, 1)
     h = F.silu(F.conv2d(pooled, sd[f"{p}.routing.routing_network.0.weight"], sd[f"{p}.routing.routing_network.0.bias"]))
     logits = F.conv2d(h, sd[f"{p}.routing.routing_network.2.weight"], sd[f"{p}.routing.routing_network.2.bias"])
     E = logits.shape[1]
     w = F.softmax(logits.reshape(B, E, -1).float().clamp(-30.0, 30.0), dim=1)
-    values, indices = torch.topk(w, top_k, dim=1)
-    values = stable_normalize(values, dim=1)
-    sparse = torch.zeros_like(w)
-    sparse.scatter_(1, indices, values)
-    route_w = sparse.view(B, E)
-    if top_k >= E:
-        return route_w, route_w.clone(), torch.ones(B, E, dtype=torch.bool), logits.view(B, E)
+    if hard_top_k:
+        values, indices = torch.topk(w, top_k, dim=1)
+        values = stable_normalize(values, dim=1)
+        sparse_w = torch.zeros_like(w)
+        sparse_w.scatter_(1, indices, values)
+        route_w = sparse_w.view(B, E)
+    else:
+        route_w, top_k = w.view(B, E), E
+    if top_k >= E or not sparse:
+        return route_w, route_w.clone(), route_w > 0, logits.view(B, E)
     importance = route_w  # mean over H*W of a spatially constant map (modules.py:668-669)
     topv, topi = torch.topk(importance, top_k, dim=1)
     keep = torch.ones_like(topi, dtype=torch.bool)
@@ -183,6 +189,17 @@ def esmoe_route(sd, p, x, top_k=2, thr=0.4):
     return route_w, gate_w, retained, logits.view(B, E)
 
 
+def esmoe_state(route_w, H=1, W=1):
+    """Eval-time buffers ES_MOE keeps (moe/modules.py:706-741, moe/loss.py:16-26): `expert_usage_counts` = mean routing
+    weight per expert over the batch (the weight map is spatially constant), `load_balancing_loss` = E * sum(u_n^2) with
+    u_n = usage / clamp_min(sum usage, 1e-6)."""
+    B, E = route_w.shape
+    usage = route_w.view(B, E, 1, 1).repeat(1, 1, H, W).mean(dim=(0, 2, 3))   # the reference averages the repeated map
+    un = usage.reshape(-1).float()
+    un = un / un.sum().clamp_min(1e-6)
+    return usage, E * torch.sum(un * un)
+
+
 def expert(sd, p, x):
     """DepthwiseSeparableConv.forward (moe/experts.py:291-296): DW -> PW -> BN -> SiLU (never BN-folded)."""
     k = sd[f"{p}.conv.depthwise.weight"].shape[-1]
@@ -191,24 +208,30 @@ def expert(sd, p, x):
     return F.silu(_bn(sd, f"{p}.conv.bn", y))
 
 
-def es_moe(sd, p, x, top_k=2, thr=0.4, info=None):
-    """ES_MOE.forward, eval + sparse (moe/modules.py:535-583, 659-704)."""
+def es_moe(sd, p, x, top_k=2, thr=0.4, info=None, sparse=True, hard_top_k=True):
+    """ES_MOE.forward, eval (moe/modules.py:535-583): sparse dispatch (:659-704) or the dense sum (:648-656)."""
     B, C, H, W = x.shape
-    route_w, gate_w, retained, logits = esmoe_route(sd, p, x, top_k, thr)
+    route_w, gate_w, retained, logits = esmoe_route(sd, p, x, top_k, thr, hard_top_k, sparse)
     E = route_w.shape[1]
     co = sd[f"{p}.norm.0.weight"].shape[0]
-    out = x.new_zeros(B, co, H, W)
-    for e in range(E):
-        idx = torch.where(retained[:, e])[0]
-        if idx.numel() == 0:
-            if CALIBRATE:
-                expert(sd, f"{p}.experts.{e}", x)  # give unselected experts sane statistics too
-            continue
-        eo = expert(sd, f"{p}.experts.{e}", x[idx])
-        out.index_add_(0, idx, eo * gate_w[idx, e].view(-1, 1, 1, 1))
+    if sparse and hard_top_k and top_k < E:
+        out = x.new_zeros(B, co, H, W)
+        for e in range(E):
+            idx = torch.where(retained[:, e])[0]
+            if idx.numel() == 0:
+                if CALIBRATE:
+                    expert(sd, f"{p}.experts.{e}", x)  # give unselected experts sane statistics too
+                continue
+            eo = expert(sd, f"{p}.experts.{e}", x[idx])
+            out.index_add_(0, idx, eo * gate_w[idx, e].view(-1, 1, 1, 1))
+    else:
+        out = 0
+        for e in range(E):
+            out = out + expert(sd, f"{p}.experts.{e}", x) * route_w[:, e].view(B, 1, 1, 1).repeat(1, 1, H, W)
     out = _bn(sd, f"{p}.norm.0", out)
     if info is not None:
-        info[p] = {"route_w": route_w, "gate_w": gate_w, "retained": retained, "logits": logits}
+        usage, lb = esmoe_state(route_w, H, W)
+        info[p] = {"route_w": route_w, "gate_w": gate_w, "retained": retained, "logits": logits, "usage": usage, "lb_loss": lb}
     return F.silu(out)
 
 

@@ -58,8 +58,9 @@ def nms_greedy(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
 
 
 def non_max_suppression(pred: np.ndarray, conf_thres=0.25, iou_thres=0.45, multi_label=False, agnostic=False,
-                        max_det=300, max_nms=30000, max_wh=7680, return_idxs=False):
-    """pred: [B, 4+nc, A] float32 (xywh + class scores).  Returns list of [n,6] (xyxy, conf, cls)."""
+                        max_det=300, max_nms=30000, max_wh=7680, return_idxs=False, classes=None):
+    """pred: [B, 4+nc, A] float32 (xywh + class scores).  Returns list of [n,6] (xyxy, conf, cls).
+    classes: keep only candidates of these class ids (utils/nms.py:63,131-136: after the best-class choice)."""
     pred = np.asarray(pred, f32)
     B, ch, A = pred.shape
     nc = ch - 4
@@ -85,6 +86,9 @@ def non_max_suppression(pred: np.ndarray, conf_thres=0.25, iou_thres=0.45, multi
             filt = conf > conf_thres
             x = np.concatenate((box, conf[:, None], j[:, None].astype(f32)), 1)[filt]
             xk = xk[filt]
+        if classes is not None:
+            filt = (x[:, 5:6] == np.asarray(classes, f32).reshape(1, -1)).any(1)
+            x, xk = x[filt], xk[filt]
         n = x.shape[0]
         if n == 0:
             outs.append(np.zeros((0, 6), f32)); idxs.append(np.zeros((0,), np.int64)); continue
@@ -98,9 +102,10 @@ def non_max_suppression(pred: np.ndarray, conf_thres=0.25, iou_thres=0.45, multi
     return (outs, idxs) if return_idxs else outs
 
 
-def cw_refine(cands: np.ndarray, keep: np.ndarray, iou_thres: float, sigma: float, pool_cap: int = 3000):
+def cw_refine(cands: np.ndarray, keep: np.ndarray, iou_thres: float, sigma: float, pool_cap: int = 3000, agnostic: bool = False):
     """CW-NMS refinement per common.cpp:150-185 (fp64).  cands: [n,6] (xyxy, conf, cls) — the
-    conf-filtered candidates of one image; keep: indices of the greedy survivors.  Returns [len(keep),4]."""
+    conf-filtered candidates of one image; keep: indices of the greedy survivors.  Returns [len(keep),4].
+    agnostic (not in the C++ spec, which only has per-class NMS): clusters ignore the class, like the suppression did."""
     c = cands.astype(np.float64)
     order = np.argsort(-cands[:, 4], kind="stable")[:pool_cap]
     out = np.zeros((len(keep), 4))
@@ -110,7 +115,7 @@ def cw_refine(cands: np.ndarray, keep: np.ndarray, iou_thres: float, sigma: floa
         sw = 0.0
         acc = np.zeros(4)
         for m in order:
-            if c[m, 5] != kc:
+            if not agnostic and c[m, 5] != kc:
                 continue
             mb = c[m, :4]
             iw = min(kb[2], mb[2]) - max(kb[0], mb[0]); ih = min(kb[3], mb[3]) - max(kb[1], mb[1])

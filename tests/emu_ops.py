@@ -146,6 +146,9 @@ def esmoe_route(x, w1, b1, w2, b2, top_k, thr, flags):
     if top_k >= E:
         retained = torch.ones(B, E, dtype=torch.bool)
         gate_w = route_w.clone()
+    elif thr < 0:      # dense forward over the top-k set
+        retained = route_w > 0
+        gate_w = route_w.clone()
     else:
         topv, topi = torch.topk(route_w, top_k, 1)
         keep = torch.ones_like(topi, dtype=torch.bool)
@@ -169,7 +172,9 @@ def esmoe_route(x, w1, b1, w2, b2, top_k, thr, flags):
             csr_pair[n] = p
             n += 1
     csr_off[E] = n
-    return route_w, gate_w, sel, csr_off, csr_pair
+    usage = route_w.mean(0)
+    un = usage / usage.sum().clamp_min(1e-6)
+    return route_w, gate_w, sel, csr_off, csr_pair, torch.cat([usage, (E * (un * un).sum()).view(1)])
 
 
 def esmoe_dw(x, dw_w, dw_off, ksizes, kmax, top_k, sel, csr_off, csr_pair):
@@ -276,12 +281,13 @@ def detect_decode(box_l, cls_l, y, stride, a_off, reg_max):
     return y
 
 
-def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, cw_sigma=None, cw_pool=3000):
+def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, cw_sigma=None, cw_pool=3000, class_keep=None):
     _count("nms_batched")
     assert cw_sigma is None, "CW refinement is checked on the GPU against oracle/_ref"
     B = y.shape[0]
+    classes = None if class_keep is None else torch.nonzero(class_keep).view(-1).tolist()
     outs, idxs = nms_ref.non_max_suppression(y.numpy(), conf, iou, multi_label, agnostic, max_det, max_nms, max_wh,
-                                             return_idxs=True)
+                                             return_idxs=True, classes=classes)
     dets = torch.zeros((B, max_det, 6), dtype=torch.float32)
     counts = torch.zeros((B,), dtype=torch.int32)
     idx = torch.zeros((B, max_det), dtype=torch.int32)

@@ -36,7 +36,7 @@ from ultralytics.nn.tasks import DetectionModel as RefModel  # noqa: E402
 from ultralytics.utils.nms import non_max_suppression as ref_nms  # noqa: E402
 
 from yolo_master_amd.nn.tasks import yaml_model_load  # noqa: E402
-from yolo_master_amd.weights import synth_input, synth_state_dict  # noqa: E402
+from yolo_master_amd.weights import CFG_DIR, synth_input, synth_state_dict  # noqa: E402
 
 assert "torchvision" not in sys.modules, "the reference must take its pure-torch TorchNMS path"
 REF_YAML = "/root/reference/ultralytics/cfg/models/master/v0/det/yolo-master-{}.yaml"
@@ -59,9 +59,14 @@ def has_ties(y, conf):
     return out
 
 
-def model_case(name, scale, B, H, W, seed, conf=0.25, iou=0.7, full_y=False):
+def model_case(name, scale, B, H, W, seed, conf=0.25, iou=0.7, full_y=False, calib="auto", n64=None, stable=False):
+    """calib: "auto" = the committed BatchNorm calibration (chaotic at 640 x 640, see tools/make_conditioned.py), or the
+    name of a cfg/*.npz override set ("cond_n.npz": the well-conditioned weights of the BASELINE-size fixtures).
+    n64: number of leading images evaluated in fp64 (all when None).  stable: also record, per image, whether the
+    reference's OWN discrete decisions survive an evaluation-order perturbation (BN folded vs unfolded, and fp64 on the
+    first n64 images): parity tests demand bit-exact kept indices on exactly those images."""
     ref = RefModel(REF_YAML.format(scale), ch=3, nc=80, verbose=False)
-    sd = synth_state_dict(ref.state_dict(), seed=0)
+    sd = synth_state_dict(ref.state_dict(), seed=0, calib=calib if calib == "auto" else str(CFG_DIR / calib))
     ref.load_state_dict(sd)
     ref.eval()
     x = synth_input(B, H, W, seed=seed)
@@ -86,8 +91,9 @@ def model_case(name, scale, B, H, W, seed, conf=0.25, iou=0.7, full_y=False):
     # tests can bound the HIP path by "as close to the exact result as the reference itself is".
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     taps64 = {}
+    n64 = B if n64 is None else min(n64, B)
     with torch.inference_mode():
-        y64, _, _ = model_ref.forward(cfg, sd64, x.double(), fused=False, taps=taps64)
+        y64, _, _ = model_ref.forward(cfg, sd64, x[:n64].double(), fused=False, taps=taps64)
     exact = all(torch.equal(taps[i], otaps[i]) for i in range(len(ref.model) - 1)) and torch.equal(y, oy)
     print(f"[{name}] oracle forward bit-exact vs reference: {exact}; max|dy| = {(y - oy).abs().max().item():.3e}")
     for i, rw in routes.items():
@@ -99,27 +105,50 @@ def model_case(name, scale, B, H, W, seed, conf=0.25, iou=0.7, full_y=False):
         print(f"[{name}] img {b}: cands={(y[b, 4:].amax(0) > conf).sum().item()} kept={len(keepi[b])} "
               f"ties={ties[b]} numpy-oracle NMS == reference: {same}")
         assert same or ties[b], "oracle NMS differs from the reference on a tie-free image"
-    rec = {"B": B, "H": H, "W": W, "seed": seed, "conf": conf, "iou": iou, "scale": ord(scale)}
+    rec = {"B": B, "H": H, "W": W, "seed": seed, "conf": conf, "iou": iou, "scale": ord(scale), "n64": n64}
+    if calib != "auto":
+        rec["calib"] = np.array(calib)
     for i in range(len(ref.model) - 1):
         idx = sample_idx(taps[i].numel(), NSAMP_LAYER, 1000 + i)
         rec[f"layer{i}_idx"] = idx.numpy().astype(np.int32)
         rec[f"layer{i}_val"] = taps[i].reshape(-1)[idx].numpy()
         rec[f"layer{i}_shape"] = np.array(taps[i].shape)
-        rec[f"layer{i}_val64"] = taps64[i].reshape(-1)[idx].numpy()
-        rec[f"layer{i}_noise"] = np.float64((taps[i].double() - taps64[i]).abs().max().item())
+        if n64 == B:
+            rec[f"layer{i}_val64"] = taps64[i].reshape(-1)[idx].numpy()
+        rec[f"layer{i}_noise"] = np.float64((taps[i][:n64].double() - taps64[i]).abs().max().item())
     if full_y:
         rec["y"] = y.numpy()
     idx = sample_idx(y.numel(), NSAMP_Y, 7)
     rec["y_idx"], rec["y_val"], rec["y_shape"] = idx.numpy().astype(np.int32), y.reshape(-1)[idx].numpy(), np.array(y.shape)
-    rec["y_val64"] = y64.reshape(-1)[idx].numpy()
-    rec["y_noise_box"] = np.float64((y[:, :4].double() - y64[:, :4]).abs().max().item())
-    rec["y_noise_cls"] = np.float64((y[:, 4:].double() - y64[:, 4:]).abs().max().item())
+    if n64 == B:
+        rec["y_val64"] = y64.reshape(-1)[idx].numpy()
+    rec["y_noise_box"] = np.float64((y[:n64, :4].double() - y64[:, :4]).abs().max().item())
+    rec["y_noise_cls"] = np.float64((y[:n64, 4:].double() - y64[:, 4:]).abs().max().item())
+    if stable:
+        with torch.inference_mode():
+            info_u = {}
+            yu, _, _ = model_ref.forward(cfg, sd, x, fused=False, moe_info=info_u)
+        ku = nms_ref.non_max_suppression(yu.numpy(), conf, iou, return_idxs=True)[1]
+        k64 = nms_ref.non_max_suppression(y64.float().numpy(), conf, iou, return_idxs=True)[1]
+        st = [np.array_equal(ku[b], keepi[b].numpy().reshape(-1)) and (b >= n64 or np.array_equal(k64[b], keepi[b].numpy().reshape(-1)))
+              for b in range(B)]
+        rst = [all(torch.equal(info[f"model.{i}"]["retained"][b], info_u[f"model.{i}"]["retained"][b]) for i in routes) for b in range(B)]
+        rec["stable"], rec["route_stable"] = np.array(st), np.array(rst)
+        rec["perturb_box"] = np.float64((y[:, :4] - yu[:, :4]).abs().max().item())
+        rec["perturb_cls"] = np.float64((y[:, 4:] - yu[:, 4:]).abs().max().item())
+        print(f"[{name}] decisions stable under BN-fold / fp64 perturbation (|dy| {rec['perturb_box']:.2e} px, {rec['perturb_cls']:.2e}): "
+              f"NMS {sum(st)}/{B} images, routing {sum(rst)}/{B}")
     print(f"[{name}] reference fp32 noise floor vs fp64: boxes {rec['y_noise_box']:.3e} px, scores {rec['y_noise_cls']:.3e}")
     for i, rw in routes.items():
         rec[f"route{i}_route_w"] = rw.numpy()
         rec[f"route{i}_gate_w"] = info[f"model.{i}"]["gate_w"].numpy()
         rec[f"route{i}_retained"] = info[f"model.{i}"]["retained"].numpy()
         rec[f"route{i}_logits"] = info[f"model.{i}"]["logits"].numpy()
+        # eval-time state the reference module holds after this forward (modules.py:706-741)
+        rec[f"route{i}_usage"] = ref.model[i].expert_usage_counts.numpy().copy()
+        rec[f"route{i}_lbloss"] = ref.model[i].load_balancing_loss.numpy().copy()
+        assert torch.equal(ref.model[i].expert_usage_counts, info[f"model.{i}"]["usage"])
+        assert torch.equal(ref.model[i].load_balancing_loss, info[f"model.{i}"]["lb_loss"])
     rec["ties"] = np.array(ties)
     for b in range(B):
         rec[f"nms{b}_dets"], rec[f"nms{b}_idx"] = dets[b].numpy(), keepi[b].numpy().reshape(-1).astype(np.int64)
@@ -157,12 +186,14 @@ def nms_case(name, make_y, **kw):
     args = dict(conf_thres=kw.get("conf_thres", 0.25), iou_thres=kw.get("iou_thres", 0.45),
                 multi_label=kw.get("multi_label", False), agnostic=kw.get("agnostic", False),
                 max_det=kw.get("max_det", 300), max_nms=kw.get("max_nms", 30000))
-    o = nms_ref.non_max_suppression(y.numpy(), return_idxs=True, **args)
+    o = nms_ref.non_max_suppression(y.numpy(), return_idxs=True, classes=kw.get("classes"), **args)
     ok = all(np.array_equal(o[1][b], keepi[b].numpy().reshape(-1)) and np.array_equal(o[0][b], dets[b].numpy())
              for b in range(y.shape[0]))
     print(f"[nms_{name}] seed={seed} kept/img={[len(k) for k in keepi]} numpy-oracle == reference: {ok}")
     assert ok
     rec = {"y": y.numpy(), **{f"arg_{k}": np.array(v) for k, v in args.items()}}
+    if kw.get("classes") is not None:
+        rec["arg_classes"] = np.array(kw["classes"])
     for b in range(y.shape[0]):
         rec[f"dets{b}"], rec[f"idx{b}"] = dets[b].numpy(), keepi[b].numpy().reshape(-1).astype(np.int64)
     np.savez_compressed(HERE / f"nms_{name}.npz", **rec)
@@ -170,6 +201,15 @@ def nms_case(name, make_y, **kw):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "baseline":   # BASELINE configs 2 and 3 at their full size, conditioned weights
+        model_case("n640_b32", "n", 32, 640, 640, seed=1, conf=0.5, calib="cond_n.npz", n64=2, stable=True)
+        model_case("s640_b64", "s", 64, 640, 640, seed=1, conf=0.5, calib="cond_s.npz", n64=1, stable=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "classes":    # the `classes=` filter (utils/nms.py:63,131-136), single- and multi-label
+        nms_case("classes", lambda s: synth_pred(3, 20, 1500, s, -3.0), conf_thres=0.25, iou_thres=0.7, classes=[1, 7, 19, 33])
+        nms_case("classes_multi", lambda s: synth_pred(2, 12, 800, s, -2.5), conf_thres=0.05, iou_thres=0.6, multi_label=True,
+                 classes=[0, 5])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "l":   # only the L-scale case (C3k blocks, gamma-residual A2C2f, mlp 1.2)
         model_case("l_tiny", "l", 1, 64, 64, seed=5, conf=0.002, full_y=True)
         sys.exit(0)

@@ -91,6 +91,12 @@ def test_host_graph_bf16_buffers(emu):
             assert t.dtype == torch.bfloat16, f"layer {i} buffer is {t.dtype}"
     for box, cls in preds["raw"]:
         assert box.dtype == torch.float32 and cls.dtype == torch.float32
+    # the reference's eval-mode preds surface (head.py:157-171): {"boxes", "scores", "feats"}, built on access
+    assert {"boxes", "scores", "feats"} <= set(preds.keys()) and "boxes" in preds and preds.get("nope") is None
+    A = y.shape[2]
+    assert tuple(preds["boxes"].shape) == (2, 64, A) and tuple(preds["scores"].shape) == (2, 80, A)
+    assert [tuple(f.shape[:2]) for f in preds["feats"]] == [(2, 64), (2, 128), (2, 128)] and len(preds["feats"]) == 3
+    assert torch.allclose(preds["scores"].sigmoid(), y[:, 4:], atol=1e-6)
     mf = _model("n", torch.float32)
     with torch.inference_mode():
         yf, _ = mf._predict_once(synth_input(2, 64, 96, seed=3))
@@ -118,5 +124,13 @@ def test_module_level_api_on_emulation(emu):
     sd = module_sd(moe, "model.0", seed=2)
     moe.eval()
     got = moe(x)
-    ref = model_ref.es_moe(sd, "model.0", x, top_k=2, thr=float(moe.dynamic_threshold))
+    info = {}
+    ref = model_ref.es_moe(sd, "model.0", x, top_k=2, thr=float(moe.dynamic_threshold), info=info)
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert torch.allclose(moe.expert_usage_counts, info["model.0"]["usage"], atol=1e-6)
+    assert torch.allclose(moe.load_balancing_loss, info["model.0"]["lb_loss"], atol=1e-5)
+    # dense forward over the router's top-k set (use_sparse_inference off): host logic vs the oracle's dense mode
+    moe.enable_sparse_inference(False)
+    got = moe(x)
+    ref = model_ref.es_moe(sd, "model.0", x, top_k=2, sparse=False)
     assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))

@@ -6,20 +6,20 @@ import torch
 
 from tests.helpers import load_npz
 
-CASES = ["n640", "n_ragged", "n_tiny", "s_small", "l_tiny"]
+CASES = ["n640", "n_ragged", "n_tiny", "s_small", "l_tiny", "n640_b32"]   # s640_b64 (config 3): same code path, 40 s on CPU
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_forward_restatement_matches_reference(case, golden_dir):
     from oracle import model_ref, nms_ref
     from yolo_master_amd.nn.tasks import DetectionModel, yaml_model_load
-    from yolo_master_amd.weights import synth_input, synth_state_dict
+    from yolo_master_amd.weights import CFG_DIR, synth_input, synth_state_dict
 
     z = load_npz(golden_dir / f"fwd_{case}.npz")
     scale = chr(int(z["scale"]))
     B, H, W, seed = int(z["B"]), int(z["H"]), int(z["W"]), int(z["seed"])
     cfg = yaml_model_load(f"yolo-master-{scale}.yaml")
-    sd = synth_state_dict(DetectionModel(cfg).state_dict(), seed=0)
+    sd = synth_state_dict(DetectionModel(cfg).state_dict(), seed=0, calib=str(CFG_DIR / str(z["calib"])) if "calib" in z else "auto")
     taps, info = {}, {}
     with torch.inference_mode():
         y, _, _ = model_ref.forward(cfg, sd, synth_input(B, H, W, seed=seed), taps=taps, moe_info=info)
@@ -46,14 +46,14 @@ def test_forward_restatement_matches_reference(case, golden_dir):
             assert len(a & r) >= 0.97 * max(len(a | r), 1), f"image {b}: kept sets differ beyond near-threshold flips"
 
 
-@pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one"])
+@pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one", "classes", "classes_multi"])
 def test_nms_restatement_matches_reference(case, golden_dir):
     from oracle import nms_ref
 
     z = load_npz(golden_dir / f"nms_{case}.npz")
     kw = dict(conf_thres=float(z["arg_conf_thres"]), iou_thres=float(z["arg_iou_thres"]),
               multi_label=bool(z["arg_multi_label"]), agnostic=bool(z["arg_agnostic"]), max_det=int(z["arg_max_det"]),
-              max_nms=int(z["arg_max_nms"]))
+              max_nms=int(z["arg_max_nms"]), classes=z["arg_classes"].tolist() if "arg_classes" in z else None)
     dets, idx = nms_ref.non_max_suppression(z["y"], return_idxs=True, **kw)
     for b in range(z["y"].shape[0]):
         assert np.array_equal(idx[b], z[f"idx{b}"]), f"{case} image {b}"
@@ -78,3 +78,22 @@ def test_cw_refine_properties():
     np.testing.assert_allclose(lonely[0], cands[0, :4].astype(np.float64), rtol=1e-12)
     # refined boxes stay inside the hull of their cluster
     assert (ref[:, 0] >= cands[:, 0].min() - 1e-6).all() and (ref[:, 2] <= cands[:, 2].max() + 1e-6).all()
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense", "disabled", "all", "k3of4"])
+def test_esmoe_modes_restatement_matches_reference(case, golden_dir):
+    """oracle.model_ref.es_moe in every dispatch mode + the eval-time state, against the real reference module's vectors."""
+    from oracle import model_ref
+
+    z = load_npz(golden_dir / f"esmoe_{case}.npz")
+    kw = {"sparse": {}, "dense": dict(sparse=False), "disabled": dict(sparse=False), "all": dict(top_k=4, hard_top_k=False, sparse=False),
+          "k3of4": dict(top_k=3, thr=0.2)}[case]
+    sd = {f"m.{k}": torch.from_numpy(z[f"sd::{k}"]) for k in z["keys"].tolist()}
+    info = {}
+    with torch.inference_mode():
+        y = model_ref.es_moe(sd, "m", torch.from_numpy(z["x"]), info=info, **kw)
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-5, atol=1e-6)
+    r = info["m"]
+    assert np.array_equal(r["retained"].numpy(), z["retained"])
+    np.testing.assert_allclose(r["usage"].numpy(), z["usage"], atol=1e-7)
+    np.testing.assert_allclose(float(r["lb_loss"]), float(z["lb_loss"]), atol=1e-6)

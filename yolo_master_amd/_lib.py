@@ -39,6 +39,8 @@ class ConvDesc(C.Structure):
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); must list every function declared in include/ymk.h
+ABI_VERSION = 2   # include/ymk.h YMK_ABI_VERSION
+
 SYMBOLS = {
     "ymk_abi_version": (C.c_int, []),
     "ymk_build_info": (C.c_char_p, []),
@@ -49,7 +51,7 @@ SYMBOLS = {
     "ymk_dwconv2d": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_esmoe_route_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "ymk_esmoe_route": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ymk_esmoe_dw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ymk_esmoe_pw": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
                                _vp, _i32, _vp]),
@@ -63,11 +65,11 @@ SYMBOLS = {
     "ymk_copy_channels": (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "ymk_scale_residual": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _i32, _vp]),
     "ymk_nhwc_to_nchw_f32": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "ymk_detect_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "ymk_detect_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "ymk_nms_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
-    "ymk_nms_batched": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
+    "ymk_nms_batched": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _sz, _vp]),
-    "ymk_cw_refine": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "ymk_cw_refine": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
 }
 
 # Config-5 rows (include/ymk_mixture.h): first implementation, compiled but not yet run on hardware — bound separately so
@@ -144,8 +146,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         except AttributeError as e:
             raise YmkLibraryError(f"{p} does not export {name}; rebuild libymk") from e
         fn.restype, fn.argtypes = res, args
-    if h.ymk_abi_version() != 1:
-        raise YmkLibraryError(f"{p}: ABI version {h.ymk_abi_version()} != 1")
+    if h.ymk_abi_version() != ABI_VERSION:
+        raise YmkLibraryError(f"{p}: ABI version {h.ymk_abi_version()} != {ABI_VERSION} (stale build: run python -m yolo_master_amd.build)")
     if path is None:
         _lib = h
     return h

@@ -179,7 +179,12 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     if constexpr (STAGES == 2) {
         issue(0);
         for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();   // drains the DMA (vmcnt(0)): stage kt&1 complete, the other one free
+            // my DMA pieces of k-step kt have landed and my fragment reads of k-step kt-1 are done: stated explicitly (a
+            // workgroup barrier alone is not required to wait for outstanding global->LDS transfers of OTHER waves' making)
+            __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(0));
+            GLDS_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();   // everyone's pieces landed: stage kt&1 complete, the other one free
+            GLDS_COMPILER_FENCE();
             if (kt + 1 < nk) issue((kt + 1) & 1);
             compute(kt & 1);
         }

@@ -151,7 +151,7 @@ extern "C" int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int3
 //   c = (x1y1 + x2y2)/2; wh = x2y2 - x1y1; box = (c, wh) * stride; score = sigmoid(cls).
 __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restrict__ box, const float* __restrict__ cls,
                                                            float* __restrict__ y, int Hl, int Wl, int reg_max, int nc,
-                                                           float stride, int a_off, int A) {
+                                                           int ldc, float stride, int a_off, int A) {
     extern __shared__ float sm[];  // cls tile [64][nc+1], dist [64][4], box tile [256][17] (reg_max == 16)
     const int HW = Hl * Wl;
     const int b = blockIdx.y;
@@ -162,8 +162,20 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
     float* sbox = sdist + 64 * 4;
     const int na = min(64, HW - a0);
     // class logits: coalesced read of na*nc floats (16-byte loads when the row length allows)
-    const float* cb = cls + ((size_t)b * HW + a0) * nc;
-    if ((nc & 3) == 0) {
+    const float* cb = cls + ((size_t)b * HW + a0) * ldc;
+    if (ldc != nc) {
+        // class rows padded to a 16-byte multiple (nc % 4 != 0: the tail conv writes ldc = 4*ceil(nc/4) channels)
+        const int q = ldc >> 2;
+        for (int i = t; i < na * q; i += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(cb)[i];
+            const int r = i / q, c = 4 * (i - r * q);
+            float* d = scls + r * (nc + 1) + c;
+            d[0] = v.x;   // c < nc always (ldc - nc < 4)
+            if (c + 1 < nc) d[1] = v.y;
+            if (c + 2 < nc) d[2] = v.z;
+            if (c + 3 < nc) d[3] = v.w;
+        }
+    } else if ((nc & 3) == 0) {
         for (int i = t; i < na * nc / 4; i += 256) {
             const f32x4 v = reinterpret_cast<const f32x4*>(cb)[i];
             const int r = (4 * i) / nc, c = 4 * i - r * nc;  // nc % 4 == 0: the four values share a row
@@ -234,9 +246,10 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
 }
 
 extern "C" int ymk_detect_decode(const float* box_l, const float* cls_l, float* y, int32_t B, int32_t Hl, int32_t Wl,
-                                 int32_t reg_max, int32_t nc, float stride, int32_t a_off, int32_t A_total,
+                                 int32_t reg_max, int32_t nc, int32_t ldc, float stride, int32_t a_off, int32_t A_total,
                                  void* stream) {
     if (!box_l || !cls_l || !y || reg_max < 1 || nc < 1) return YMK_E_BADARG;
+    if (ldc != nc && (ldc < nc || (ldc & 3) || ldc - nc >= 4)) return YMK_E_BADARG;
     const int HW = Hl * Wl;
     if (B <= 0 || HW <= 0) return YMK_OK;
     if (B > 65535 || a_off + HW > A_total) return YMK_E_BADARG;
@@ -244,6 +257,6 @@ extern "C" int ymk_detect_decode(const float* box_l, const float* cls_l, float* 
     if (shm > 64 * 1024) return YMK_E_BADARG;
     dim3 grid((HW + 63) / 64, B), blk(256);
     hipLaunchKernelGGL(detect_decode_kernel, grid, blk, shm, (hipStream_t)stream, box_l, cls_l, y, Hl, Wl, reg_max, nc,
-                       stride, a_off, A_total);
+                       ldc, stride, a_off, A_total);
     return ymk_launch_status();
 }

@@ -177,21 +177,25 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
         vsum = fmaxf(vsum, 1e-6f);
         for (int e = 0; e < E; ++e) rw[e] = 0.f;
         for (int k = 0; k < top_k; ++k) rw[idx[k]] = p[idx[k]] / vsum;
-        // sparse dispatch decision (modules.py:665-684): importance == rw (spatially constant)
+        // sparse dispatch decision (modules.py:665-684): importance == rw (spatially constant).
+        // thr < 0 selects the DENSE forward (modules.py:648-656; use_sparse_inference=False): every expert is summed with
+        // its routing weight, nothing pruned or renormalised — experts outside the top-k set have weight exactly 0 and
+        // are skipped (their term is 0 * finite).
+        const bool dense = top_k >= E || thr < 0.f;
         for (int e = 0; e < E; ++e) keep[e] = 0;
         if (top_k >= E) {
-            for (int e = 0; e < E; ++e) keep[e] = 1;  // dense path: every expert, unpruned
+            for (int e = 0; e < E; ++e) keep[e] = 1;  // every expert, unpruned
         } else {
             for (int k = 0; k < top_k; ++k)
                 keep[idx[k]] = (k == 0) || !(thr > 0.f) || (rw[idx[k]] >= thr);
         }
         float nsum = 0.f;
         for (int e = 0; e < E; ++e) nsum += keep[e] ? rw[e] : 0.f;
-        nsum = (top_k >= E) ? 1.0f : fmaxf(nsum, 1.1920929e-07f);
+        nsum = dense ? 1.0f : fmaxf(nsum, 1.1920929e-07f);
         int ns = 0;
         for (int e = 0; e < E; ++e) {
             route_w[b * E + e] = rw[e];
-            const float g = keep[e] ? ((top_k >= E) ? rw[e] : rw[e] / nsum) : 0.f;
+            const float g = keep[e] ? (dense ? rw[e] : rw[e] / nsum) : 0.f;
             gate_w[b * E + e] = g;
             if (keep[e] && ns < top_k) sel[b * top_k + ns++] = e;
         }
@@ -201,9 +205,30 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
 
 // stage 3: image->expert CSR permutation, one wavefront: per 64-image chunk and expert,
 // a ballot gives the member mask, popcount-of-lower-lanes the position inside the chunk.
+// The same wavefront produces the eval-time state ES_MOE keeps (modules.py:706-741, moe/loss.py:16-26):
+// state[e] = expert_usage_counts[e] = mean_b route_w[b][e], state[E] = load_balancing_loss = E * sum_e (u_e / max(sum u, 1e-6))^2.
 __global__ __launch_bounds__(64) void route_csr_kernel(const int* __restrict__ sel, int B, int E, int top_k,
-                                                      int* __restrict__ csr_off, int* __restrict__ csr_pair) {
+                                                      int* __restrict__ csr_off, int* __restrict__ csr_pair,
+                                                      const float* __restrict__ route_w, float* __restrict__ state) {
     const int lane = threadIdx.x;
+    if (state) {
+        float usum = 0.f, u2 = 0.f, u[RT_MAX_E];
+        for (int e = 0; e < E; ++e) {
+            float s = 0.f;
+            for (int b = lane; b < B; b += 64) s += route_w[b * E + e];   // fixed order: lane-strided, then butterfly
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            u[e] = s / (float)B;
+            usum += u[e];
+        }
+        const float den = fmaxf(usum, 1e-6f);
+        for (int e = 0; e < E; ++e) {
+            const float un = u[e] / den;
+            u2 += un * un;
+            if (lane == 0) state[e] = u[e];
+        }
+        if (lane == 0) state[E] = (float)E * u2;
+    }
     int cnt[RT_MAX_E];
     for (int e = 0; e < E; ++e) cnt[e] = 0;
     for (int b0 = 0; b0 < B; b0 += 64) {
@@ -240,7 +265,7 @@ extern "C" int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t 
                                int32_t ldx, const float* w1, const float* b1, const float* w2,
                                const float* b2, int32_t hidden, int32_t E, int32_t top_k,
                                float dynamic_threshold, float* route_w, float* gate_w, int32_t* sel,
-                               int32_t* csr_off, int32_t* csr_pair, int32_t* flags, void* workspace,
+                               int32_t* csr_off, int32_t* csr_pair, float* state, int32_t* flags, void* workspace,
                                size_t workspace_bytes, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !route_w || !gate_w || !sel || !csr_off || !csr_pair || !flags)
         return YMK_E_BADARG;
@@ -266,7 +291,7 @@ extern "C" int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t 
     const size_t shm = (size_t)(C + hidden + E + E * hidden) * sizeof(float);
     hipLaunchKernelGGL(route_finalize_kernel, dim3(B), blk, shm, s, part, nchunk, HW, C, w1, b1, w2, b2, hidden,
                        E, top_k, dynamic_threshold, route_w, gate_w, sel, flags);
-    hipLaunchKernelGGL(route_csr_kernel, dim3(1), dim3(64), 0, s, sel, B, E, top_k, csr_off, csr_pair);
+    hipLaunchKernelGGL(route_csr_kernel, dim3(1), dim3(64), 0, s, sel, B, E, top_k, csr_off, csr_pair, route_w, state);
     return ymk_launch_status();
 }
 

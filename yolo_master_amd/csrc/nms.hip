@@ -73,8 +73,10 @@ extern "C" size_t ymk_nms_workspace_bytes(int32_t B, int32_t nc, int32_t A, int3
 }
 
 // ---- 1. per-anchor candidate count (+ best class for single-label) ----------------
+// class_keep (nullable, [nc] bytes): the `classes=` filter (utils/nms.py:63,132) — applied to the candidate's class AFTER the
+// best-class choice of the single-label path, exactly where the reference filters its candidate rows.
 __global__ __launch_bounds__(256) void nms_count_kernel(const float* __restrict__ y, int nc, int A, float conf, int multi,
-                                                       NmsWs w) {
+                                                       const unsigned char* __restrict__ class_keep, NmsWs w) {
     __shared__ int wsum[4];
     const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
     int c = 0;
@@ -89,9 +91,9 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const float* __restrict_
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(k + q) * A];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) c += v[q] > conf;
+                for (int q = 0; q < 8; ++q) c += (v[q] > conf) && (!class_keep || class_keep[k + q]);
             }
-            for (; k < nc; ++k) c += p[(size_t)k * A] > conf;
+            for (; k < nc; ++k) c += (p[(size_t)k * A] > conf) && (!class_keep || class_keep[k]);
         } else {
             float best = p[0];
             int bi = 0;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const float* __restrict_
                 const float v = p[(size_t)k * A];
                 if (v > best) { best = v; bi = k; }
             }
-            c = best > conf;
+            c = (best > conf) && (!class_keep || class_keep[bi]);
             w.bconf[(size_t)b * A + a] = best;
             w.bcls[(size_t)b * A + a] = bi;
         }
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(NmsWs w, int* __restrict__
 
 // ---- 3. ordered compaction of candidates -------------------------------------------
 __global__ __launch_bounds__(256) void nms_emit_kernel(const float* __restrict__ y, int nc, int A, float conf, int multi,
-                                                      NmsWs w) {
+                                                      const unsigned char* __restrict__ class_keep, NmsWs w) {
     __shared__ int wsum[4];
     const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float* __restrict__
     if (multi) {
         for (int k = 0; k < nc; ++k) {
             const float v = yb[(size_t)(4 + k) * A];
-            if (v > conf) put(pos++, v, k);
+            if (v > conf && (!class_keep || class_keep[k])) put(pos++, v, k);
         }
     } else {
         put(pos, w.bconf[(size_t)b * A + a], w.bcls[(size_t)b * A + a]);
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, flo
 
 extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A, float conf_thres, float iou_thres,
                                int32_t multi_label, int32_t agnostic, int32_t max_det, int32_t max_nms, float max_wh,
-                               float* out_dets, int32_t* out_counts, int32_t* out_idx, int32_t* status,
+                               const uint8_t* class_keep, float* out_dets, int32_t* out_counts, int32_t* out_idx, int32_t* status,
                                void* workspace, size_t workspace_bytes, void* stream) {
     if (!y || !out_dets || !out_counts || !out_idx || !status || !workspace) return YMK_E_BADARG;
     if (B <= 0 || A <= 0 || nc <= 0 || max_det <= 0 || max_nms <= 0 || B > 65535 || max_det > NMS_MAXDET_CAP)
@@ -365,9 +367,9 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A,
     NmsWs w = nms_layout(workspace, B, nc, A, multi, max_nms);
     if (workspace_bytes < w.total) return YMK_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, w);
+    hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, w, status);
-    hipLaunchKernelGGL(nms_emit_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, w);
+    hipLaunchKernelGGL(nms_emit_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
     if (w.capc <= NMS_SORT_CAP && !(ymk_disabled() & YMK_OFF_NMS_SORT))
         hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, s, w);
     else
@@ -379,7 +381,9 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A,
 
 // ---- CW-NMS refinement (spec: examples/.../cpp/src/common.cpp:150-185) ----------------
 // One wavefront per kept detection: fp64 accumulation over the score-sorted pool.
-__global__ __launch_bounds__(64) void cw_refine_kernel(NmsWs w, int max_det, float thr, double sigma, int pool_cap,
+// agnostic: the cluster of a survivor is every pool member it overlaps, whatever its class (the suppression that produced
+// the survivors ignored classes too); the C++ spec only defines the per-class case.
+__global__ __launch_bounds__(64) void cw_refine_kernel(NmsWs w, int max_det, float thr, double sigma, int pool_cap, int agnostic,
                                                       float* __restrict__ dets, const int* __restrict__ counts) {
     const int b = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
     if (k >= counts[b]) return;
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(64) void cw_refine_kernel(NmsWs w, int max_det, flo
     const double ak = (kx2 - kx1) * (ky2 - ky1);
     double sw = 0, ax1 = 0, ay1 = 0, ax2 = 0, ay2 = 0;
     for (int m = lane; m < n; m += 64) {
-        if (w.scls[base + m] != ck) continue;
+        if (!agnostic && w.scls[base + m] != ck) continue;
         const double x1 = w.sbox[(base + m) * 4 + 0], y1 = w.sbox[(base + m) * 4 + 1];
         const double x2 = w.sbox[(base + m) * 4 + 2], y2 = w.sbox[(base + m) * 4 + 3];
         const double iw = fmin(kx2, x2) - fmax(kx1, x1), ih = fmin(ky2, y2) - fmax(ky1, y1);
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(64) void cw_refine_kernel(NmsWs w, int max_det, flo
     }
 }
 
-extern "C" int ymk_cw_refine(int32_t B, int32_t nc, int32_t A, int32_t multi_label, int32_t max_nms, int32_t max_det,
+extern "C" int ymk_cw_refine(int32_t B, int32_t nc, int32_t A, int32_t multi_label, int32_t agnostic, int32_t max_nms, int32_t max_det,
                                 float iou_thres, float sigma, int32_t pool_cap, float* out_dets,
                                 const int32_t* out_counts, void* workspace, size_t workspace_bytes, void* stream) {
     if (!out_dets || !out_counts || !workspace || B <= 0 || max_det <= 0 || max_det > NMS_MAXDET_CAP || !(sigma > 0.f))
@@ -426,6 +430,6 @@ extern "C" int ymk_cw_refine(int32_t B, int32_t nc, int32_t A, int32_t multi_lab
     NmsWs w = nms_layout(workspace, B, nc, A, multi, max_nms);
     if (workspace_bytes < w.total) return YMK_E_WORKSPACE;
     hipLaunchKernelGGL(cw_refine_kernel, dim3(max_det, B), dim3(64), 0, (hipStream_t)stream, w, max_det, iou_thres,
-                       (double)sigma, pool_cap, out_dets, out_counts);
+                       (double)sigma, pool_cap, agnostic ? 1 : 0, out_dets, out_counts);
     return ymk_launch_status();
 }

@@ -64,22 +64,30 @@ def broadcast_state_dict(module: torch.nn.Module, src: int = 0) -> None:
         module.repack()
 
 
-def gather_detections(dets: torch.Tensor, counts: torch.Tensor, idx: torch.Tensor | None = None):
+def gather_detections(dets: torch.Tensor, counts: torch.Tensor, idx: torch.Tensor | None = None, out: dict | None = None):
     """all_gather of per-rank padded detections.  dets [B_local, max_det, 6], counts [B_local].
     Every rank must hold the same B_local (pad the last shard).  Returns tensors with leading dim
-    world*B_local in rank order (i.e. the original batch order for contiguous shards)."""
+    world*B_local in rank order (i.e. the original batch order for contiguous shards).
+    out: a dict the caller keeps across batches — the gathered tensors are allocated in it on first use and reused
+    afterwards (a serving loop gathers into the same three buffers every batch: no allocator traffic per step)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return dets, counts, idx
     world = dist.get_world_size()
 
-    def ag(t):
+    def ag(name, t):
+        shape = (world * t.shape[0], *t.shape[1:])
+        buf = None if out is None else out.get(name)
+        if buf is None or tuple(buf.shape) != shape or buf.dtype != t.dtype or buf.device != t.device:
+            buf = torch.empty(shape, dtype=t.dtype, device=t.device)
+            if out is not None:
+                out[name] = buf
         if dist.get_backend() == "nccl":  # RCCL: one fused all_gather straight into the output tensor
-            out = torch.empty((world * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t.contiguous())
-            return out
+            dist.all_gather_into_tensor(buf, t.contiguous())
+            return buf
         src = t.contiguous().cpu()        # gloo (CPU tests / single-GPU functional runs)
         parts = [torch.empty_like(src) for _ in range(world)]
         dist.all_gather(parts, src)
-        return torch.cat(parts, 0).to(t.device)
+        buf.copy_(torch.cat(parts, 0))
+        return buf
 
-    return ag(dets), ag(counts), (ag(idx) if idx is not None else None)
+    return ag("dets", dets), ag("counts", counts), (ag("idx", idx) if idx is not None else None)

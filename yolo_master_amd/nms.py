@@ -21,16 +21,28 @@ from . import ops
 from ._lib import FLAG_NMS_OVERFLOW
 
 
+def class_keep_mask(classes, nc: int, device) -> torch.Tensor:
+    """`classes=[...]` (utils/nms.py:63) -> uint8 [nc] keep mask for the kernel; ids outside [0, nc) match nothing, as in
+    the reference's `(x[:, 5:6] == classes).any(1)`."""
+    keep = torch.zeros((nc,), dtype=torch.uint8)
+    for c in (classes.tolist() if torch.is_tensor(classes) else classes):
+        if float(c) == int(c) and 0 <= int(c) < nc:
+            keep[int(c)] = 1
+    return keep.to(device)
+
+
 def nms_padded(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, agnostic=False, multi_label=False,
-               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1):
+               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1, classes=None):
     """prediction: [B, 4+nc, A] fp32 on the GPU.  Returns (dets [B,max_det,6], counts [B], idx [B,max_det],
-    status [1]) without synchronising."""
+    status [1]) without synchronising.  classes: list of class ids or a ready uint8 [nc] device mask."""
     if prediction.dtype != torch.float32:
         prediction = prediction.float()
     prediction = prediction.contiguous()
     nc = prediction.shape[1] - 4
+    if classes is not None and not (torch.is_tensor(classes) and classes.dtype == torch.uint8):
+        classes = class_keep_mask(classes, nc, prediction.device)
     return ops.nms_batched(prediction, conf_thres, iou_thres, bool(multi_label) and nc > 1, bool(agnostic), max_det,
-                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None)
+                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None, class_keep=classes)
 
 
 def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float = 0.45, classes=None,
@@ -41,12 +53,12 @@ def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float =
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
-    if rotated or end2end or prediction.shape[-1] == 6 or labels or classes is not None:
-        raise NotImplementedError("ymk NMS covers the detect path: no rotated/end2end/autolabel/class-filter modes")
+    if rotated or end2end or prediction.shape[-1] == 6 or labels:
+        raise NotImplementedError("ymk NMS covers the detect path: no rotated/end2end/autolabel modes")
     if nc and nc != prediction.shape[1] - 4:
         raise NotImplementedError("ymk NMS: extra mask channels (segment) are not on the detect path")
     dets, counts, idx, status = nms_padded(prediction, conf_thres, iou_thres, agnostic, multi_label, max_det, max_nms,
-                                           max_wh, cluster, sigma)
+                                           max_wh, cluster, sigma, classes)
     n = counts.tolist()  # the one host sync of the post-processing step
     if int(status.item()) & FLAG_NMS_OVERFLOW:
         raise RuntimeError("ymk NMS: more than 2*max_nms multi-label candidates in one image (unsupported stress case)")

@@ -459,10 +459,16 @@ class _PlainConv:
 
     @staticmethod
     def pack(conv: nn.Conv2d, dtype, device):
+        """Output channels are zero-padded to a multiple of 4 (ymk_conv2d's 16-byte fp32 store granularity): `nc` / `nm`
+        are free ctor arguments of the reference (nc=1, 2, 3 ... datasets); callers slice the padded channels off."""
         if conv.kernel_size != (1, 1) or conv.groups != 1:
             raise NotImplementedError("Detect tail conv must be 1x1")
         w = conv.weight.detach().float().to(device)
         b = conv.bias.detach().float().to(device) if conv.bias is not None else torch.zeros(w.shape[0], device=device)
+        co = w.shape[0]
+        if co % 4:
+            w = torch.cat([w, w.new_zeros((4 - co % 4, *w.shape[1:]))], 0)
+            b = torch.cat([b, b.new_zeros(4 - co % 4)])
         return ops.pack_conv_weight(w, dtype), b.contiguous()
 
 
@@ -564,7 +570,7 @@ class Detect(YmkModule):
             hb = self._branch(self.cv2[i], f)
             box = ops.conv2d(hb, pk["box"][i][0], pk["box"][i][1], 1, 1, False, out_dtype=torch.float32)
             hc = self._branch(self.cv3[i], f)
-            cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)
+            cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)[..., : self.nc]
             ops.detect_decode(box, cls, y, float(self.stride[i]), offs[i], self.reg_max)
             raw[i] = (box, cls)
 
@@ -651,7 +657,7 @@ class Segment(Detect):
         a_off = 0
         for i, f in enumerate(feats):
             h = self.cv4[i][1]._run(self.cv4[i][0]._run(f))
-            c = ops.conv2d(h, pk["mask"][i][0], pk["mask"][i][1], 1, 1, False, out_dtype=torch.float32)
+            c = ops.conv2d(h, pk["mask"][i][0], pk["mask"][i][1], 1, 1, False, out_dtype=torch.float32)[..., : self.nm]
             ops.tokens_to_rows(c, mc, a_off)
             a_off += f.shape[1] * f.shape[2]
         self.last_mc, self.last_proto = mc, self.proto._run(feats[0])
@@ -880,10 +886,13 @@ class ES_MOE(YmkModule):
         pk = self._packed(x.device)
         if self._flags is None or self._flags.device != x.device:
             self._flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
-        dense = not self._eager_sparse_enabled()
-        top_k = self.num_experts if dense else self.top_k
-        route_w, gate_w, sel, csr_off, csr_pair = ops.esmoe_route(
-            x, pk["w1"], pk["b1"], pk["w2"], pk["b2"], top_k, float(self.dynamic_threshold), self._flags)
+        # Router width and dispatch are separate things (routers.py:477-487 vs modules.py:558-568): the router applies its
+        # hard top-k whenever `use_top_k` is set, also when the sparse dispatch is off; the dense forward then sums every
+        # expert with those (masked, renormalised) weights -> only the top-k set contributes.  top_k=None: plain softmax.
+        top_k = self.top_k if self.use_top_k else self.num_experts
+        thr = float(self.dynamic_threshold) if self._eager_sparse_enabled() else -1.0
+        route_w, gate_w, sel, csr_off, csr_pair, state = ops.esmoe_route(
+            x, pk["w1"], pk["b1"], pk["w2"], pk["b2"], top_k, thr, self._flags)
         if self.fuse_experts and ops.dwpw_supported(x.dtype, C, pk["kmax"]):
             # depthwise -> pointwise in one kernel: the stencil tile never leaves LDS
             y = ops.esmoe_experts_fused(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], pk["pw_w"], pk["pw_b"], pk["ns"],
@@ -891,11 +900,9 @@ class ES_MOE(YmkModule):
         else:
             dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair)
             y = ops.esmoe_pw(dw, B, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel, gate_w, out=out)
-        # eval-time state the reference keeps (modules.py:706-741): usage = mean routing weight
-        usage = route_w.mean(0)
-        self.expert_usage_counts = usage
-        un = usage / usage.sum().clamp_min(1e-6)
-        self.load_balancing_loss = self.num_experts * torch.sum(un * un)
+        # eval-time state the reference keeps (modules.py:706-741), computed by the router's last kernel: views, no arithmetic
+        self.expert_usage_counts = state[: self.num_experts]
+        self.load_balancing_loss = state[self.num_experts]
         self.last_route = {"route_w": route_w, "gate_w": gate_w, "sel": sel, "csr_off": csr_off, "csr_pair": csr_pair}
         return y
 

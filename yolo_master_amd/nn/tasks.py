@@ -244,7 +244,7 @@ class DetectionModel(nn.Module):
             self._flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
         ys = []
         cur = x
-        raw = None
+        raw = det_in = None
         for m in self.model:
             if m.f != -1:
                 cur = ys[m.f] if isinstance(m.f, int) else [cur if j == -1 else ys[j] for j in m.f]
@@ -267,6 +267,7 @@ class DetectionModel(nn.Module):
                 m.bind_flags(self._flags)
                 cur = m._run(cur)
             elif isinstance(m, Detect):
+                det_in = cur
                 cur, raw = m._run(cur)
             elif isinstance(m, nn.Sequential):
                 for mm in m:
@@ -279,7 +280,7 @@ class DetectionModel(nn.Module):
             if taps is not None:
                 taps[m.i] = cur.materialise() if isinstance(cur, VirtualCat) else cur
         det = self.model[-1]
-        preds = {"raw": raw, "feats": None}
+        preds = DetectPreds(raw, det_in, det.reg_max, det.nc)
         if isinstance(det, Segment):   # mask coefficients fp32 [B, nm, A] and prototypes NHWC [B, 2H0, 2W0, nm]
             preds["mask_coefficient"], preds["proto"] = det.last_mc, det.last_proto
         return cur, preds
@@ -290,6 +291,37 @@ class DetectionModel(nn.Module):
             if isinstance(m, ES_MOE):
                 m.check_flags()
                 break
+
+
+class DetectPreds(dict):
+    """The dict Detect returns beside y in eval mode (nn/modules/head.py:157-171): "boxes" [B, 4*reg_max, A] and "scores"
+    [B, nc, A] raw logits, "feats" = the head's input maps (NCHW-logical).  Nothing on the inference path reads them
+    (predict()/val() consume y), so the three reference keys are built on first access from the per-level NHWC logits
+    ("raw", what the decode kernel consumed) instead of being concatenated every step: layout changes only, no arithmetic."""
+
+    def __init__(self, raw, feats, reg_max, nc):
+        super().__init__(raw=raw)
+        self._lazy = {"boxes": lambda: self._cat(0, 4 * reg_max), "scores": lambda: self._cat(1, nc),
+                      "feats": lambda: [f.permute(0, 3, 1, 2) for f in feats]}
+
+    def _cat(self, which, width):
+        lv = [r[which] for r in self["raw"]]
+        return torch.cat([t.reshape(t.shape[0], -1, width) for t in lv], 1).permute(0, 2, 1)
+
+    def __missing__(self, key):
+        if key not in self._lazy:
+            raise KeyError(key)
+        self[key] = self._lazy[key]()
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._lazy if not dict.__contains__(self, k)]
 
 
 class SegmentationModel(DetectionModel):

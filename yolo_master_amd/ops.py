@@ -229,6 +229,8 @@ def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
 
 # ----------------------------------------------------------------------------- ES-MoE
 def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
+    """Router + dispatch decision + CSR + eval-time state (include/ymk.h ymk_esmoe_route).  thr < 0 = dense forward.
+    Returns (route_w [B,E], gate_w [B,E], sel [B,top_k], csr_off [E+1], csr_pair [B*top_k], state [E+1])."""
     B, H, W, Cc, ldx = _nhwc(x)
     hidden, E = w1.shape[0], w2.shape[0]
     dev = x.device
@@ -237,14 +239,15 @@ def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
     sel = torch.empty((B, top_k), dtype=torch.int32, device=dev)
     csr_off = torch.empty((E + 1,), dtype=torch.int32, device=dev)
     csr_pair = torch.empty((B * top_k,), dtype=torch.int32, device=dev)
+    state = torch.empty((E + 1,), dtype=torch.float32, device=dev)
     nbytes = lib.ymk_esmoe_route_workspace_bytes(B, Cc, H, W)
     ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
     e0 = TIMER.begin()
     check(lib.ymk_esmoe_route(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(w1), _p(b1), _p(w2), _p(b2), hidden, E, top_k,
-                              float(thr), _p(route_w), _p(gate_w), _p(sel), _p(csr_off), _p(csr_pair), _p(flags),
-                              _p(ws), nbytes, _stream()), "esmoe_route")
+                              float(thr), _p(route_w), _p(gate_w), _p(sel), _p(csr_off), _p(csr_pair), _p(state),
+                              _p(flags), _p(ws), nbytes, _stream()), "esmoe_route")
     TIMER.end(e0, "moe_route", B * H * W * Cc * x.element_size(), B * H * W * Cc, f"C{Cc} @{H}x{W}")
-    return route_w, gate_w, sel, csr_off, csr_pair
+    return route_w, gate_w, sel, csr_off, csr_pair, state
 
 
 def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_pair):
@@ -370,19 +373,22 @@ def nhwc_to_nchw_f32(x):
 
 # ----------------------------------------------------------------------------- detect / nms
 def detect_decode(box_l, cls_l, y, stride: float, a_off: int, reg_max: int):
+    """cls_l: fp32 [B, Hl, Wl, nc], dense or a view of rows padded to 4*ceil(nc/4) channels (tail conv with nc % 4 != 0)."""
     B, Hl, Wl, _, _ = _nhwc(box_l)
     nc = cls_l.shape[-1]
-    assert box_l.is_contiguous() and cls_l.is_contiguous() and box_l.dtype == torch.float32
+    ldc = _nhwc(cls_l)[4]
+    assert box_l.is_contiguous() and box_l.dtype == torch.float32 and cls_l.dtype == torch.float32 and y.shape[1] == 4 + nc
     e0 = TIMER.begin()
-    check(lib.ymk_detect_decode(_p(box_l), _p(cls_l), _p(y), B, Hl, Wl, reg_max, nc, float(stride), a_off, y.shape[2],
+    check(lib.ymk_detect_decode(_p(box_l), _p(cls_l), _p(y), B, Hl, Wl, reg_max, nc, ldc, float(stride), a_off, y.shape[2],
                                 _stream()), "detect_decode")
     TIMER.end(e0, "detect_decode", B * Hl * Wl * (4 * reg_max + nc + 4 + nc) * 4, B * Hl * Wl * (4 * reg_max * 4 + nc * 4))
     return y
 
 
 def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, max_det: int, max_nms: int,
-                max_wh: float, cw_sigma: float | None = None, cw_pool: int = 3000):
-    """Returns (dets [B,max_det,6], counts [B] int32, idx [B,max_det] int32, status [1] int32)."""
+                max_wh: float, cw_sigma: float | None = None, cw_pool: int = 3000, class_keep: torch.Tensor | None = None):
+    """Returns (dets [B,max_det,6], counts [B] int32, idx [B,max_det] int32, status [1] int32).
+    class_keep: uint8 [nc] on the GPU (the `classes=` filter, utils/nms.py:63,132) or None."""
     _need_gpu(y)
     assert y.dtype == torch.float32 and y.is_contiguous()
     B, ch, A = y.shape
@@ -395,11 +401,13 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
     idx = torch.zeros((B, max_det), dtype=torch.int32, device=dev)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
     e0 = TIMER.begin()
+    if class_keep is not None:
+        assert class_keep.dtype == torch.uint8 and class_keep.numel() == nc and class_keep.is_cuda and class_keep.is_contiguous()
     check(lib.ymk_nms_batched(_p(y), B, nc, A, float(conf), float(iou), int(multi_label), int(agnostic), max_det, max_nms,
-                              float(max_wh), _p(dets), _p(counts), _p(idx), _p(status), _p(ws), nbytes, _stream()),
+                              float(max_wh), _p(class_keep), _p(dets), _p(counts), _p(idx), _p(status), _p(ws), nbytes, _stream()),
           "nms_batched")
     if cw_sigma is not None:
-        check(lib.ymk_cw_refine(B, nc, A, int(multi_label), max_nms, max_det, float(iou), float(cw_sigma), cw_pool,
+        check(lib.ymk_cw_refine(B, nc, A, int(multi_label), int(agnostic), max_nms, max_det, float(iou), float(cw_sigma), cw_pool,
                                 _p(dets), _p(counts), _p(ws), nbytes, _stream()), "cw_refine")
     TIMER.end(e0, "nms", B * ch * A * 4 + B * max_det * 28, B * ch * A)
     return dets, counts, idx, status

@@ -300,7 +300,7 @@ def test_detect_head(dtype, nc):
     sd = module_sd(m)
     feats = [rnd(2, 64, 16, 20, seed=1), rnd(2, 128, 8, 10, seed=2), rnd(2, 128, 4, 5, seed=3)]
     with torch.inference_mode():
-        ref_y, ref_boxes, ref_scores = model_ref.detect(sd, "model.0", [_prep(f, dtype) for f in feats], [8, 16, 32])
+        ref_y, ref_boxes, ref_scores = model_ref.detect(sd, "model.0", [_prep(f, dtype) for f in feats], [8, 16, 32], nc=nc)
     from yolo_master_amd.nn.modules import set_compute_dtype
 
     m.eval().to(DEV)

@@ -211,6 +211,25 @@ int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int3
                          int32_t ldx, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Depthwise convolution on the matrix cores (bf16, odd k <= 9, C % 16 == 0): the same operations as ymk_dwconv2d /
+ * ymk_esmoe_dw (DWConv conv.py:185-199, AAttn.pe block.py:1688,1731, DepthwiseSeparableConv.depthwise
+ * experts.py:283-292), evaluated as banded (Toeplitz) GEMMs along x — one 16x16x32 MFMA per (channel, filter row,
+ * 16x16 output tile), see csrc/dwmfma.hip.  The filter is consumed as a table of MFMA A fragments built once at pack
+ * time: ymk_dw_toeplitz_pack turns the [k*k][C] bf16 filter of ymk_dwconv2d into ymk_dw_toeplitz_elems(C, k) bf16
+ * elements; ES-MoE concatenates the experts' tables in expert order.
+ * ------------------------------------------------------------------------ */
+int ymk_dw_mfma_supported(int32_t dtype, int32_t C, int32_t ksize);
+size_t ymk_dw_toeplitz_elems(int32_t C, int32_t ksize);
+int ymk_dw_toeplitz_pack(const void* w_packed /*bf16 [k*k][C]*/, int32_t C, int32_t ksize, void* out, void* stream);
+int ymk_dwconv2d_mfma(const void* x, const void* toeplitz, const float* bias, const void* residual, void* y,
+                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t ksize, int32_t ldx, int32_t ldy,
+                      int32_t ldr, int32_t act, void* stream);
+int ymk_esmoe_dw_mfma(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx, const void* toeplitz,
+                      const int32_t* ksizes /*device [E]*/, int32_t kmask /*host: bit (k-1)/2 per filter size present*/,
+                      int32_t E, int32_t top_k, const int32_t* csr_off, const int32_t* csr_pair, void* dw_out,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
  * Detect decode: DFL softmax-expectation + dist2bbox(xywh) * stride + sigmoid
  * (Detect._inference head.py:173-194, DFL.forward block.py:81-84,
  *  make_anchors/dist2bbox utils/tal.py:398-423).

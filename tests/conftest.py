@@ -67,7 +67,9 @@ def hostlib():
     if path is None:
         pytest.skip("no host clang++ to build the kernel emulation")
     h = C.CDLL(str(path))
-    for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT}.items():
+    dw = {k: v for k, v in _lib.SYMBOLS.items() if k in ("ymk_dw_mfma_supported", "ymk_dw_toeplitz_elems", "ymk_dw_toeplitz_pack",
+                                                         "ymk_dwconv2d_mfma", "ymk_esmoe_dw_mfma")}   # csrc/dwmfma.hip
+    for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT, **dw}.items():
         fn = getattr(h, name)
         fn.restype, fn.argtypes = res, args
     return h

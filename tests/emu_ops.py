@@ -177,7 +177,7 @@ def esmoe_route(x, w1, b1, w2, b2, top_k, thr, flags):
     return route_w, gate_w, sel, csr_off, csr_pair, torch.cat([usage, (E * (un * un).sum()).view(1)])
 
 
-def esmoe_dw(x, dw_w, dw_off, ksizes, kmax, top_k, sel, csr_off, csr_pair):
+def esmoe_dw(x, dw_w, dw_off, ksizes, kmax, top_k, sel, csr_off, csr_pair, toep=None, kmask=0):
     _count("esmoe_dw")
     B, H, W, C = x.shape
     assert kmax == int(ksizes.max())

@@ -840,7 +840,7 @@ class ES_MOE(YmkModule):
         E, C, Co = self.num_experts, self.in_channels, self.out_channels
         rn = self.routing.routing_network
         hidden = rn[0].out_channels
-        ks, dw_parts, dw_off, off = [], [], [], 0
+        ks, dw_parts, dw_off, off, toeps = [], [], [], 0, []
         pw_w = torch.zeros((E, Co, ops.kpad(C)), dtype=torch.float32, device=device)
         pw_b = torch.zeros((E, Co), dtype=torch.float32, device=device)
         for e, ex in enumerate(self.experts):
@@ -850,6 +850,7 @@ class ES_MOE(YmkModule):
                 raise NotImplementedError("ymk ES_MOE: experts are odd k<=15 stride-1 depthwise + pointwise")
             ks.append(k)
             w = ops.pack_dw_weight(cv.depthwise.weight.detach().float().to(device), dtype)
+            toeps.append(getattr(w, "toeplitz", None))
             dw_parts.append(w.reshape(-1))
             dw_off.append(off)
             off += w.numel()
@@ -866,6 +867,9 @@ class ES_MOE(YmkModule):
             "w2": rn[2].weight.detach().float().reshape(E, hidden).to(device).contiguous(),
             "b2": rn[2].bias.detach().float().to(device).contiguous(),
             "dw_w": torch.cat(dw_parts).contiguous(), "dw_off": torch.tensor(dw_off, **i32),
+            # the experts' filters as MFMA A fragments, expert-major (csrc/dwmfma.hip); None -> VALU stencil
+            "toep": torch.cat(toeps).contiguous() if toeps and all(t is not None for t in toeps) else None,
+            "kmask": sum({1 << (k // 2) for k in ks}),
             "ks": torch.tensor(ks, **i32), "kmax": max(ks), "pw_w": pw_w.to(dtype).contiguous(), "pw_b": pw_b.contiguous(),
             "ns": ns.detach().float().to(device).contiguous(), "nt": nt.detach().float().to(device).contiguous(),
         }
@@ -898,7 +902,7 @@ class ES_MOE(YmkModule):
             y = ops.esmoe_experts_fused(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], pk["pw_w"], pk["pw_b"], pk["ns"],
                                         pk["nt"], top_k, sel, gate_w, out=out)
         else:
-            dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair)
+            dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair, toep=pk["toep"], kmask=pk["kmask"])
             y = ops.esmoe_pw(dw, B, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel, gate_w, out=out)
         # eval-time state the reference keeps (modules.py:706-741), computed by the router's last kernel: views, no arithmetic
         self.expert_usage_counts = state[: self.num_experts]

@@ -129,10 +129,33 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cout_perm: torch.Tenso
     return out.to(dtype).contiguous()
 
 
+def dw_mfma_enabled() -> bool:
+    """YMK_ENABLE bit 8 routes bf16 depthwise convolutions (k = 3..9, C % 16 == 0) to the matrix-core kernels of
+    csrc/dwmfma.hip.  OFF by default: validated on MI355X (tests/test_gpu_kernels.py::test_dwconv_mfma*), but measured slower
+    than the VALU stencil except for 7x7 / 9x9 filters on the 160- and 40-pixel maps (0.6-1.16x; ES-MoE stage 0.56-0.86x):
+    its 16-channel tiles read the input in 32-byte pieces with a 2.25-3x halo, and the CU's load path saturates at about one
+    such request per two cycles (stage ablation in profiles/r02_dwmfma_ablation.txt)."""
+    return bool(int(os.environ.get("YMK_ENABLE", "0"), 0) & 8)
+
+
+def dw_toeplitz(w_packed: torch.Tensor, k: int, force: bool = False) -> torch.Tensor | None:
+    """MFMA A-fragment table of a packed depthwise filter ([k*k, C] bf16 on the GPU), built once at pack time by
+    ymk_dw_toeplitz_pack; None when the matrix-core kernel does not cover the case (dtype, k > 9, C % 16)."""
+    C_ = w_packed.shape[1]
+    if not (w_packed.is_cuda and (force or dw_mfma_enabled()) and w_packed.dtype in DT and lib.ymk_dw_mfma_supported(DT[w_packed.dtype], C_, k)):
+        return None
+    out = torch.empty((lib.ymk_dw_toeplitz_elems(C_, k),), dtype=torch.bfloat16, device=w_packed.device)
+    check(lib.ymk_dw_toeplitz_pack(_p(w_packed), C_, k, _p(out), _stream()), "dw_toeplitz_pack")
+    return out
+
+
 def pack_dw_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """[C, 1, k, k] -> [k*k, C]."""
+    """[C, 1, k, k] -> [k*k, C].  On the GPU in bf16 the result also carries `.toeplitz`, the same filter as MFMA A
+    fragments (dw_toeplitz): dwconv2d / esmoe_dw then run on the matrix cores."""
     c, _, kh, kw = w.shape
-    return w.reshape(c, kh * kw).t().contiguous().to(dtype)
+    wp = w.reshape(c, kh * kw).t().contiguous().to(dtype)
+    wp.toeplitz = dw_toeplitz(wp, kh) if kh == kw else None
+    return wp
 
 
 def fold_bn(w: torch.Tensor, bn_w, bn_b, bn_mean, bn_var, eps: float, conv_bias=None):
@@ -221,8 +244,13 @@ def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
     ldy = _nhwc(out)[4]
     ldr = _nhwc(residual)[4] if residual is not None else 0
     e0 = TIMER.begin()
-    check(lib.ymk_dwconv2d(DT[x.dtype], _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy,
-                           ldr, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d")
+    toep = getattr(w_packed, "toeplitz", None)
+    if toep is not None and x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16:
+        check(lib.ymk_dwconv2d_mfma(_p(x), _p(toep), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy, ldr,
+                                    _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d_mfma")
+    else:
+        check(lib.ymk_dwconv2d(DT[x.dtype], _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy,
+                               ldr, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d")
     TIMER.end(e0, "dwconv", B * H * W * Cc * x.element_size() * (3 if residual is not None else 2), 2 * B * H * W * Cc * k * k, f"C{Cc} k{k} @{H}x{W}")
     return out
 
@@ -250,13 +278,20 @@ def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
     return route_w, gate_w, sel, csr_off, csr_pair, state
 
 
-def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_pair):
+def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_pair, toep=None, kmask: int = 0):
+    """Depthwise stage of the retained (image, expert) pairs.  toep: the experts' Toeplitz tables concatenated in expert
+    order (bf16 only) + kmask (bit (k-1)/2 per filter size present) -> matrix-core kernels walking the image->expert CSR;
+    otherwise the VALU stencil per pair."""
     B, H, W, Cc, ldx = _nhwc(x)
     E = ksizes.numel()
     out = torch.empty((B * top_k, H, W, Cc), dtype=x.dtype, device=x.device)
     e0 = TIMER.begin()
-    check(lib.ymk_esmoe_dw(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), E, top_k, kmax, _p(sel),
-                           _p(csr_off), _p(csr_pair), _p(out), _stream()), "esmoe_dw")
+    if toep is not None and x.dtype == torch.bfloat16:
+        check(lib.ymk_esmoe_dw_mfma(_p(x), B, H, W, Cc, ldx, _p(toep), _p(ksizes), kmask, E, top_k, _p(csr_off), _p(csr_pair),
+                                    _p(out), _stream()), "esmoe_dw_mfma")
+    else:
+        check(lib.ymk_esmoe_dw(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), E, top_k, kmax, _p(sel),
+                               _p(csr_off), _p(csr_pair), _p(out), _stream()), "esmoe_dw")
     if e0 is not None:  # algorithmic traffic: every image read once, one plane written per retained (image, expert) pair
         e1 = TIMER.begin()
         cnt = (csr_off[1:] - csr_off[:-1]).cpu()

@@ -235,6 +235,27 @@ def test_a2c2f_block(area, hw, residual, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,heads,area", [(3, 1600, 4, 4),      # the detector's layer 8: 4 areas of 400 tokens (resident K/V)
+                                            (2, 400, 8, 1),       # layer 11
+                                            (2, 37 * 3, 2, 3),    # ragged: 37 tokens per area (one partial query / key tile)
+                                            (1, 1024, 1, 1),      # largest resident bf16 case, 4 key chunks
+                                            (1, 1100, 2, 1)])     # past the resident limit: streaming kernel
+def test_area_attn_kernel(dtype, B, N, heads, area):
+    """ymk_area_attn against softmax(q k^T / sqrt(32)) v per (image, area, head) in fp32 on the same (rounded) inputs."""
+    from yolo_master_amd import ops
+
+    Cq = heads * 32
+    qkv = _prep(rnd(B, N, 1, 3 * Cq, seed=31), dtype)             # [B, tokens, 1, Q|K|V]
+    dev = qkv.to(dtype).to(DEV)
+    out = ops.area_attn(dev, heads, area)
+    Na = N // area
+    q, k, v = (qkv[..., i * Cq:(i + 1) * Cq].reshape(B, area, Na, heads, 32).permute(0, 1, 3, 2, 4) for i in range(3))
+    att = torch.softmax((q @ k.transpose(-1, -2)) * 32 ** -0.5, -1) @ v                # [B, area, heads, Na, 32]
+    ref = att.permute(0, 1, 3, 2, 4).reshape(B, N, 1, Cq)
+    assert_close(out.float().cpu(), ref, dtype, f"area_attn N={N} heads={heads} area={area}", scale_aware=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_area_attention_long(dtype):
     """More than one 256-key chunk (online softmax across chunks): 24x24 = 576 tokens, area 1."""
     from oracle import model_ref

@@ -22,6 +22,7 @@ static int ymk_use_ws = 1;          // tools/micro can switch the streaming 1x1 
 static int ymk_ws_min_tiles = [] { const char* e = getenv("YMK_WS_MIN_TILES"); return e ? atoi(e) : 1024; }();
 extern "C" void ymk_debug_set_ws(int on) { ymk_use_ws = on; }
 static thread_local int ymk_last_variant = YMK_CONV_TILED;
+static thread_local int ymk_last_glds_stages = 0;
 extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
                                void* y, int32_t two_stage, void* stream);   // csrc/conv_glds.hip, include/ymk_next.h
 extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
@@ -29,7 +30,10 @@ extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int
 static int ymk_glds_min_tiles = [] { const char* e = getenv("YMK_GLDS_MIN_TILES"); return e ? atoi(e) : 192; }();
 // one workgroup per CU (144 KB of LDS): with fewer than four k-steps there is nothing to pipeline, the current kernels win
 static int ymk_glds_min_k = [] { const char* e = getenv("YMK_GLDS_MIN_K"); return e ? atoi(e) : 256; }();
-extern "C" int32_t ymk_conv2d_last_variant(void) { return ymk_last_variant; }
+// diagnostic (kernel naming in bench.py / tools): variant code, plus the LDS stage count << 8 for the LDS-DMA core
+extern "C" int32_t ymk_conv2d_last_variant(void) {
+    return ymk_last_variant == YMK_CONV_GLDS ? (ymk_last_variant | (ymk_last_glds_stages << 8)) : ymk_last_variant;
+}
 
 template <typename T, bool PRECISE>
 __device__ __forceinline__ float act_silu(float v) {
@@ -593,11 +597,22 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
         const bool done = d->dtype == YMK_F32 ? launch_conv3x3_tile<float>(a, s) : launch_conv3x3_tile<bf16_t>(a, s);
         if (done) { ymk_last_variant = YMK_CONV_SPATIAL_3X3; return ymk_launch_status(); }
     }
-    if ((ymk_enabled() & YMK_ON_CONV_GLDS) && d->dtype == YMK_BF16) {   // opt-in: next tiled core (include/ymk_next.h)
+    if (d->ksize == 3 && d->dtype == YMK_BF16 && !(ymk_disabled() & YMK_OFF_CONV_GLDS3) && !(ymk_enabled() & YMK_ON_CONV_GLDS)) {
+        // 3x3 with Cin >= 64 (the stride-2 down-sampling convs, the Detect / C3k 3x3s): LDS-DMA tiled core.  Measured faster than
+        // conv_igemm_kernel on every such shape of the S detector (profiles/r02a_glds_ab.log: 6-35 %), two LDS stages except
+        // for 128-wide cout tiles with >= 1024 tiles (128->128 s2 from 160x160), where the three-stage counted-vmcnt loop wins.
+        const int64_t tiles = ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
+        const bool three = d->Cout % 128 == 0 && tiles >= 1024;
+        if (d->Cout % 64 == 0) {
+            const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, three ? 0 : 1, stream);
+            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = three ? 3 : 2; return rc; }
+        }
+    }
+    if ((ymk_enabled() & YMK_ON_CONV_GLDS) && d->dtype == YMK_BF16) {   // opt-in for every shape: next tiled core (include/ymk_next.h)
         const int64_t tiles = ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
         if (d->Cout % 64 == 0 && tiles >= ymk_glds_min_tiles && d->Kpad >= ymk_glds_min_k) {
             const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 1 : 0, stream);
-            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; return rc; }
+            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 2 : 3; return rc; }
         }
     }
     ymk_last_variant = YMK_CONV_TILED;

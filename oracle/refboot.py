@@ -41,3 +41,20 @@ def boot():
     md.version = lambda n: "0.25.0" if n == "torchvision" else _v(n)
     os.environ.setdefault("YOLO_CONFIG_DIR", "/tmp")
     sys.path.insert(0, REF)
+
+
+def stub_torchvision():
+    """`predict()` / `val()` of the reference import torchvision (nn/autobackend.py:324-325, engine/predictor.py:274) and, once it
+    is in sys.modules, use `torchvision.ops.nms` (utils/nms.py:156-161).  Not installed here: a stub whose `ops.nms` is the
+    reference's own pure-torch TorchNMS.nms, i.e. the path the reference takes without torchvision."""
+    if "torchvision" in sys.modules:
+        return
+    tv = types.ModuleType("torchvision")
+    tv.__spec__ = importlib.machinery.ModuleSpec("torchvision", None)
+    tv.__version__ = "0.25.0"
+    tvops = types.ModuleType("torchvision.ops")
+    tv.ops = tvops
+    sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, tvops
+    from ultralytics.utils.nms import TorchNMS
+
+    tvops.nms = TorchNMS.nms

@@ -1,0 +1,97 @@
+"""BASELINE config 1 (plumbing): the REFERENCE's own `YOLO(yaml).predict(tensor)` with libymk hooked underneath by
+`yolo_master_amd.enable(model)` — module registry / layer loop / NMS hook / Results construction all the reference's code.
+
+Runs in the build container (needs /root/reference; the GPU box has no checkout).  No GPU here, so libymk's entry points are
+the torch restatement of the C-ABI contract (tests/emu_ops.py, the `emu` fixture): what is tested is the HOOKS — that the
+reference predictor walks through this package's graph, that the weights were taken from the reference's parameters, that
+the detections equal the un-hooked reference's — not kernel numerics (those are the -m gpu tests)."""
+import pytest
+import torch
+
+from oracle import refboot
+
+pytestmark = pytest.mark.skipif(not refboot.available(), reason="reference checkout not present")
+YAML = f"{refboot.REF}/ultralytics/cfg/models/master/v0/det/yolo-master-n.yaml"
+
+
+def _yolo():
+    refboot.boot()
+    refboot.stub_torchvision()
+    from ultralytics import YOLO
+
+    from yolo_master_amd.weights import synth_state_dict
+
+    m = YOLO(YAML, verbose=False)
+    m.model.load_state_dict(synth_state_dict(m.model.state_dict(), seed=0))
+    return m
+
+
+def test_predict_through_the_hooks(emu, monkeypatch):
+    import yolo_master_amd
+    from yolo_master_amd import dropin, ops
+    from yolo_master_amd.weights import synth_input
+
+    monkeypatch.setattr(ops, "device_ok", lambda t: True)     # CPU tensors go to the (emulated) libymk path
+    x = synth_input(2, 128, 128, seed=42)
+    kw = dict(conf=0.002, iou=0.7, verbose=False, device="cpu")
+    ref = _yolo().predict(x, **kw)                            # the untouched reference
+    m = _yolo()
+    assert yolo_master_amd.enable(m) is m
+    try:
+        got = m.predict(x, **kw)
+        st = dropin.stats(m)
+        assert st["calls"] >= 1 and st["nms_calls"] >= 1, st          # the batch (the reference skips warm-up on cpu); NMS hook used
+        assert emu.CALLS["conv2d_stem"] >= 1 and emu.CALLS["esmoe_route"] >= 4 and emu.CALLS["nms_batched"] >= 1
+        assert len(got) == len(ref) == 2
+        n = 0
+        for g, r in zip(got, ref):
+            gb, rb = g.boxes.data, r.boxes.data
+            assert gb.shape == rb.shape and gb.shape[0] > 0
+            assert torch.equal(gb[:, 5], rb[:, 5]), "classes differ"
+            assert float((gb[:, 4] - rb[:, 4]).abs().max()) <= 1e-4
+            assert float((gb[:, :4] - rb[:, :4]).abs().max()) <= 1e-2
+            assert g.orig_shape == r.orig_shape and g.names == r.names
+            n += gb.shape[0]
+        print(f"reference predict() through the libymk hooks: {n} detections identical in class, <= 1e-4 in score")
+        # training-mode / profiling calls are left to the reference
+        core = m.model
+        before = dropin.stats(m)["fallbacks"]
+        core._predict_once(x, profile=False, visualize=False, embed=[1])
+        assert dropin.stats(m)["fallbacks"] == before + 1
+    finally:
+        yolo_master_amd.disable(m)
+    import ultralytics.utils.nms as ref_nms
+
+    assert ref_nms.non_max_suppression.__module__ == "ultralytics.utils.nms", "disable() must restore the reference's NMS"
+    assert "_predict_once" not in m.model.__dict__
+
+
+def test_enable_refuses_a_fused_model(emu):
+    import yolo_master_amd
+
+    m = _yolo()
+    m.model.fuse(verbose=False)
+    with pytest.raises(RuntimeError, match="already fused"):
+        yolo_master_amd.enable(m)
+
+
+def test_val_style_nms_call_goes_through_the_hook(emu, monkeypatch):
+    """The validator's call shape (models/yolo/detect/val.py:116: multi_label, agnostic, max_det by keyword, nc=0)."""
+    import yolo_master_amd
+    from yolo_master_amd import dropin, ops
+    from yolo_master_amd.weights import synth_input
+
+    monkeypatch.setattr(ops, "device_ok", lambda t: True)
+    m = _yolo()
+    yolo_master_amd.enable(m)
+    try:
+        import ultralytics.utils.nms as ref_nms
+
+        with torch.inference_mode():
+            y, _ = m.model.eval()(synth_input(1, 64, 64, seed=3))
+        out = ref_nms.non_max_suppression(y, 0.05, 0.6, nc=0, multi_label=True, agnostic=False, max_det=100, end2end=False, rotated=False)
+        want = dropin._PATCHED["nms"](y.clone(), 0.05, 0.6, nc=0, multi_label=True, agnostic=False, max_det=100, max_time_img=10.0)
+        assert dropin.stats(m)["nms_calls"] >= 1
+        assert len(out) == 1 and out[0].shape == want[0].shape and torch.allclose(out[0], want[0], atol=1e-5)
+    finally:
+        yolo_master_amd.disable(m)

@@ -14,6 +14,10 @@ def __getattr__(name):  # lazy: importing the package must not require torch/lib
         from .nn import tasks
 
         return getattr(tasks, name)
+    if name in ("enable", "disable"):   # drop-in hooks under the reference's own YOLO / DetectionModel objects
+        from . import dropin
+
+        return getattr(dropin, name)
     if name == "non_max_suppression":
         from .nms import non_max_suppression
 

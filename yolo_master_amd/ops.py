@@ -91,6 +91,11 @@ def require_gpu(t: torch.Tensor, what: str = "yolo_master_amd ops") -> None:
         raise RuntimeError(f"{what} run on MI355X (HIP) only; got a CPU tensor. There is no CPU fallback.")
 
 
+def device_ok(t: torch.Tensor) -> bool:
+    """True when libymk can take this tensor (the drop-in hooks fall through to the reference otherwise)."""
+    return bool(t.is_cuda)
+
+
 def _need_gpu(t: torch.Tensor) -> None:
     require_gpu(t)
 

@@ -61,6 +61,15 @@ int ymk_process_mask(int32_t dtype, const void* protos, int32_t ldp, int32_t mh,
                      const float* boxes, int32_t ldb, int32_t n, int32_t H, int32_t W, int32_t upsample, float rw, float rh,
                      float* lowres_ws, uint8_t* out, void* stream);
 
+/* Predictor pre-processing on the device (the step before the path): LetterBox resize + pad (ultralytics/data/augment.py:1646-1830)
+ * + BGR->RGB + HWC->CHW + /255 (BasePredictor.preprocess, engine/predictor.py:155-178), one launch per batch.
+ * src: the batch's uint8 HWC 3-channel images packed back to back, image b at byte offset src_off[b] (device int64 [B]);
+ * geom: device int32 [B][6] = (src_h, src_w, new_h, new_w, top, left) as LetterBox.get_params computes them (host side:
+ * yolo_master_amd.preprocess.letterbox_params); dst: fp32 [B][3][H][W], padded with pad_value / 255 (114).
+ * The bilinear resize restates OpenCV's generic 8-bit INTER_LINEAR path (fixed point, see csrc/preproc.hip). */
+int ymk_letterbox_preprocess(const void* src, const int64_t* src_off, const int32_t* geom, float* dst, int32_t B, int32_t H,
+                             int32_t W, int32_t pad_value, int32_t swap_rb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,7 +69,7 @@ def hostlib():
     h = C.CDLL(str(path))
     dw = {k: v for k, v in _lib.SYMBOLS.items() if k in ("ymk_dw_mfma_supported", "ymk_dw_toeplitz_elems", "ymk_dw_toeplitz_pack",
                                                          "ymk_dwconv2d_mfma", "ymk_esmoe_dw_mfma")}   # csrc/dwmfma.hip
-    for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT, **dw}.items():
+    for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT, **dw}.items():   # SYMBOLS_NEXT includes csrc/preproc.hip
         fn = getattr(h, name)
         fn.restype, fn.argtypes = res, args
     return h

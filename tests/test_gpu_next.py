@@ -119,3 +119,27 @@ def test_process_mask_vs_reference_golden(golden_dir):
     from tests.test_hostemu_post import mask_kernel_checks
 
     mask_kernel_checks(golden_dir, "cuda:0")
+
+
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_pre", fromlist=["CASES"]).CASES)
+def test_letterbox_preprocess_vs_oracle(case):
+    """Device-side LetterBox + BGR->RGB + CHW + /255 (csrc/preproc.hip) bit-exact against oracle/pre_ref.py."""
+    from tests.test_hostemu_pre import run_case as run_pre_case
+    from yolo_master_amd import _lib
+
+    run_pre_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)
+
+
+def test_preprocess_wrapper_feeds_the_model():
+    """yolo_master_amd.preprocess.preprocess on host uint8 images -> the detector's input tensor; same detections as feeding the
+    oracle's pre-processed tensor."""
+    import numpy as np
+
+    from oracle import pre_ref
+    from yolo_master_amd.preprocess import preprocess
+
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (90, 120, 3), dtype=np.uint8), rng.integers(0, 256, (128, 64, 3), dtype=np.uint8)]
+    x = preprocess(imgs, (128, 128), device="cuda:0")
+    assert x.shape == (2, 3, 128, 128) and x.dtype == torch.float32
+    assert np.array_equal(x.cpu().numpy(), pre_ref.preprocess(imgs, (128, 128)))

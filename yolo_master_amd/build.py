@@ -18,10 +18,10 @@ OBJ = CSRC / "_obj"
 LIB = HERE / "libymk.so"
 ARCH = "gfx950"
 # files whose arithmetic must not be contracted into FMAs (bit-exact NMS / decode)
-NO_CONTRACT = {"nms.hip", "elementwise.hip", "post.hip"}
+NO_CONTRACT = {"nms.hip", "elementwise.hip", "post.hip", "preproc.hip"}
 SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "dwmfma.hip", "esmoe.hip", "dwpw.hip", "attn.hip", "elementwise.hip", "nms.hip",
            "mixture.hip", "mixattn.hip",   # config-5 rows, first implementation (include/ymk_mixture.h)
-           "conv_glds.hip", "post.hip"]    # opt-in: next tiled convolution core, box rescaling (include/ymk_next.h)
+           "conv_glds.hip", "post.hip", "preproc.hip"]    # opt-in: next tiled convolution core, box rescaling (include/ymk_next.h)
 HEADERS = ["ymk_common.h", "igemm.h", "../../include/ymk.h", "../../include/ymk_mixture.h", "../../include/ymk_next.h"]
 
 
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(s), "-o", str(o)]
         if src in NO_CONTRACT:
             cmd.insert(4, "-ffp-contract=off")
-        if src == "post.hip":   # bit-exact box rescaling divides by the gain: IEEE division (hipcc's default, stated explicitly)
+        if src in ("post.hip", "preproc.hip"):   # bit-exact box rescaling divides by the gain: IEEE division (hipcc's default, stated explicitly)
             cmd.insert(4, "-fhip-fp32-correctly-rounded-divide-sqrt")
         if verbose:
             print("[ymk build]", " ".join(cmd), flush=True)

@@ -61,6 +61,19 @@ int ymk_process_mask(int32_t dtype, const void* protos, int32_t ldp, int32_t mh,
                      const float* boxes, int32_t ldb, int32_t n, int32_t H, int32_t W, int32_t upsample, float rw, float rh,
                      float* lowres_ws, uint8_t* out, void* stream);
 
+/* Validation matching (the step after the path in val(): ultralytics/models/yolo/detect/val.py `_process_batch`).
+ * ymk_box_iou: utils/metrics.py:82-104, out[i][j] = IoU(box1[i], box2[j]) fp32 [N][M]; rows of ld1 / ld2 >= 4 floats (xyxy).
+ * ymk_match_predictions: BaseValidator.match_predictions (engine/validator.py:301-336, numpy path) for a whole batch:
+ *   dets fp32 [B][max_det][ldd >= 6] (xyxy, conf, cls — the padded output of ymk_nms_batched, in the labels' coordinate frame),
+ *   counts int32 [B] or NULL, labels fp32 [total_labels][5] = (cls, x1, y1, x2, y2) grouped by image, label_off int32 [B+1],
+ *   iouv fp32 [T] (T <= 16; torch.linspace(0.5, 0.95, 10)), eps of box_iou (1e-7);
+ *   correct uint8 [B][max_det][T] (rows past counts[b] are 0).  workspace: ymk_match_predictions_workspace_bytes(total_labels, T). */
+int ymk_box_iou(const float* box1, int32_t ld1, int32_t N, const float* box2, int32_t ld2, int32_t M, float eps, float* out, void* stream);
+size_t ymk_match_predictions_workspace_bytes(int32_t total_labels, int32_t T);
+int ymk_match_predictions(const float* dets, int32_t ldd, const int32_t* counts, int32_t B, int32_t max_det, const float* labels,
+                          const int32_t* label_off, int32_t total_labels, const float* iouv, int32_t T, float eps, uint8_t* correct,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Predictor pre-processing on the device (the step before the path): LetterBox resize + pad (ultralytics/data/augment.py:1646-1830)
  * + BGR->RGB + HWC->CHW + /255 (BasePredictor.preprocess, engine/predictor.py:155-178), one launch per batch.
  * src: the batch's uint8 HWC 3-channel images packed back to back, image b at byte offset src_off[b] (device int64 [B]);

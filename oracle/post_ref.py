@@ -72,3 +72,31 @@ def process_mask(protos: torch.Tensor, masks_in: torch.Tensor, bboxes: torch.Ten
         ratios = torch.tensor([[mw / shape[1], mh / shape[0], mw / shape[1], mh / shape[0]]])
         masks = crop_mask(masks, bboxes * ratios)
     return masks.gt(0.0).byte()
+
+
+# ---------------------------------------------------------------------------------- validation matching
+def box_iou(box1: np.ndarray, box2: np.ndarray, eps: float = 1e-7) -> np.ndarray:
+    """utils/metrics.py:82-104 in numpy fp32, same operation order: inter / (area1 + area2 - inter + eps)."""
+    a, b = np.asarray(box1, f32)[:, None, :4], np.asarray(box2, f32)[None, :, :4]
+    wh = np.clip(np.minimum(a[..., 2:], b[..., 2:]) - np.maximum(a[..., :2], b[..., :2]), 0, None).astype(f32)
+    inter = wh[..., 0] * wh[..., 1]
+    area1 = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area2 = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    return (inter / (area1 + area2 - inter + f32(eps))).astype(f32)
+
+
+def match_predictions(pred_classes: np.ndarray, true_classes: np.ndarray, iou: np.ndarray, iouv: np.ndarray) -> np.ndarray:
+    """BaseValidator.match_predictions (engine/validator.py:301-336), numpy path, restated line by line.  iou: [L labels, D detections].
+    Returns correct bool [D, T]."""
+    correct = np.zeros((pred_classes.shape[0], iouv.shape[0]), bool)
+    correct_class = true_classes[:, None] == pred_classes
+    iou = (np.asarray(iou, f32) * correct_class).astype(f32)
+    for i, threshold in enumerate(np.asarray(iouv, f32).tolist()):
+        matches = np.array(np.nonzero(iou >= f32(threshold))).T
+        if matches.shape[0]:
+            if matches.shape[0] > 1:
+                matches = matches[iou[matches[:, 0], matches[:, 1]].argsort()[::-1]]
+                matches = matches[np.unique(matches[:, 1], return_index=True)[1]]
+                matches = matches[np.unique(matches[:, 0], return_index=True)[1]]
+            correct[matches[:, 1].astype(int), i] = True
+    return correct

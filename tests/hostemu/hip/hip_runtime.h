@@ -105,6 +105,7 @@ static inline float __shfl_xor(float v, int mask) {
     return r;
 }
 static inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
+static inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 #define __expf(x) expf(x)   // glibc declares __expf itself
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

@@ -143,3 +143,10 @@ def test_preprocess_wrapper_feeds_the_model():
     x = preprocess(imgs, (128, 128), device="cuda:0")
     assert x.shape == (2, 3, 128, 128) and x.dtype == torch.float32
     assert np.array_equal(x.cpu().numpy(), pre_ref.preprocess(imgs, (128, 128)))
+
+
+def test_validation_matching_vs_reference_golden(golden_dir):
+    """box_iou + batched match_predictions on the GPU against the real reference's vectors (tests/golden/make_golden_match.py)."""
+    from tests.test_hostemu_post import match_kernel_checks
+
+    match_kernel_checks("cuda:0", golden_dir)

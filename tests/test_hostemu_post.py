@@ -145,3 +145,39 @@ def test_segmentation_predict_flow(post, emu, golden_dir):
         boxes = postprocess.scale_boxes((H, W), dets[b][:, :4].clone(), (2 * H + 3, 2 * W))
         assert np.allclose(boxes.numpy(), post_ref.scale_boxes((H, W), rd[b][:, :4], (2 * H + 3, 2 * W)), atol=2e-3)
     assert total > 0, "the fixture should keep some detections at this threshold"
+
+
+def match_kernel_checks(dev="cpu", golden_dir=None):
+    """ymk_box_iou / ymk_match_predictions (all fixture cases as ONE batch, padded like nms_padded's output) against the real
+    reference's vectors; shared with tests/test_gpu_next.py."""
+    from tests.test_oracle_post import match_cases
+    from yolo_master_amd import postprocess
+
+    cs = [c for c in match_cases(golden_dir) if not c["tied"]]
+    for c in cs:   # box_iou, bit-exact
+        if c["labels"].shape[0] and c["dets"].shape[0]:
+            got = postprocess.box_iou(torch.from_numpy(c["labels"][:, 1:].copy()).to(dev), torch.from_numpy(c["dets"][:, :4].copy()).to(dev))
+            assert np.array_equal(got.cpu().numpy(), c["iou"])
+    B, max_det, T = len(cs), 300, len(cs[0]["iouv"])
+    dets = torch.zeros((B, max_det, 6))
+    counts = torch.zeros((B,), dtype=torch.int32)
+    labels, off = [], [0]
+    for b, c in enumerate(cs):
+        n = c["dets"].shape[0]
+        dets[b, :n] = torch.from_numpy(c["dets"])
+        dets[b, n:, :4] = torch.tensor([10.0, 10.0, 200.0, 200.0])      # padding rows must not take part
+        counts[b] = n
+        labels.append(torch.from_numpy(c["labels"]))
+        off.append(off[-1] + c["labels"].shape[0])
+    labels = torch.cat(labels).contiguous()
+    got = postprocess.match_predictions(dets.to(dev), counts.to(dev), labels.to(dev), torch.tensor(off, dtype=torch.int32).to(dev),
+                                        torch.from_numpy(cs[0]["iouv"]).to(dev)).cpu().numpy()
+    assert got.shape == (B, max_det, T)
+    for b, c in enumerate(cs):
+        n = c["dets"].shape[0]
+        assert np.array_equal(got[b, :n], c["correct"]), f"image {b}: correct matrix differs from the reference"
+        assert not got[b, n:].any()
+
+
+def test_validation_matching_kernels_on_emulator(post, golden_dir):
+    match_kernel_checks("cpu", golden_dir)

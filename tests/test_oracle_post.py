@@ -53,3 +53,22 @@ def test_process_mask_oracle_matches_reference(golden_dir):
         assert float((got != c["mask"]).float().mean()) <= 1e-4 if got.numel() else True
         n += 1
     assert n == 6
+
+
+def match_cases(golden_dir):
+    z = np.load(golden_dir / "post_match.npz")
+    for i in range(int(z["n"])):
+        yield {"dets": z[f"c{i}_dets"], "labels": z[f"c{i}_labels"], "iou": z[f"c{i}_iou"], "correct": z[f"c{i}_correct"],
+               "tied": bool(z[f"c{i}_tied"]), "iouv": z["iouv"]}
+
+
+def test_validation_matching_restatement_matches_reference(golden_dir):
+    """oracle box_iou / match_predictions against vectors from the real reference (metrics.box_iou, BaseValidator.match_predictions)."""
+    n = 0
+    for c in match_cases(golden_dir):
+        iou = post_ref.box_iou(c["labels"][:, 1:], c["dets"][:, :4])
+        assert np.array_equal(iou, c["iou"])
+        got = post_ref.match_predictions(c["dets"][:, 5], c["labels"][:, 0], iou, c["iouv"])
+        assert np.array_equal(got, c["correct"])
+        n += 1
+    assert n >= 7

@@ -114,6 +114,9 @@ SYMBOLS_NEXT = {
     "ymk_process_mask": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
     "ymk_expert_conv_glds": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "ymk_scale_boxes": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_box_iou": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _f32, _vp, _vp]),
+    "ymk_match_predictions_workspace_bytes": (_sz, [_i32, _i32]),
+    "ymk_match_predictions": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _sz, _vp]),
     "ymk_letterbox_preprocess": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
 }
 ACT_SIGMOID, ACT_GELU = 2, 3

@@ -182,3 +182,109 @@ extern "C" int ymk_process_mask(int32_t dtype, const void* protos, int32_t ldp, 
                        rh, out);
     return ymk_launch_status();
 }
+
+// ---- Validation matching (the remainder): box_iou + match_predictions ---------------------------------------
+// box_iou (ultralytics/utils/metrics.py:82-104): iou[i][j] = inter / (area1_i + area2_j - inter + eps), fp32, the reference's
+// operation order (no FMA contraction in this file).  One thread per pair, rows of box1 as the slow index.
+__global__ __launch_bounds__(256) void box_iou_kernel(const float* __restrict__ b1, int ld1, const float* __restrict__ b2, int ld2, int N,
+                                                      int M, float eps, float* __restrict__ out) {
+    const int64_t total = (int64_t)N * M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* a = b1 + (i / M) * ld1;
+        const float* b = b2 + (i % M) * ld2;
+        const float w = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]), 0.f), h = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]), 0.f);
+        const float inter = w * h;
+        out[i] = inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter + eps);
+    }
+}
+extern "C" int ymk_box_iou(const float* box1, int32_t ld1, int32_t N, const float* box2, int32_t ld2, int32_t M, float eps, float* out,
+                           void* stream) {
+    if (!out || ld1 < 4 || ld2 < 4 || N < 0 || M < 0) return YMK_E_BADARG;
+    if (N == 0 || M == 0) return YMK_OK;
+    if (!box1 || !box2) return YMK_E_BADARG;
+    const int64_t total = (int64_t)N * M;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(box_iou_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, box1, ld1, box2, ld2, N, M, eps, out);
+    return ymk_launch_status();
+}
+
+// match_predictions (ultralytics/engine/validator.py:301-336, the numpy path) batched over images: one workgroup per image.
+// The reference, per IoU threshold t: pairs (label l, detection d) with iou[l][d] * (cls_l == cls_d) >= t, sorted by IoU descending;
+// np.unique over the detection column keeps each detection's best label (result ordered by detection index); np.unique over the label
+// column then keeps, per label, the FIRST of those — the lowest detection index, i.e. the most confident detection that chose it.
+// A detection's best label does not depend on t (it is the arg-max of its IoU column; t only decides whether the pair exists), so:
+//   best[d] = argmax_l iou[l][d] (class-matched);  first[l][t] = min { d : best[d] == l, iou_best[d] >= t };  correct[d][t] = first[best[d]][t] == d.
+// Equal IoUs of one detection with two labels (identical ground-truth boxes) are ordered by numpy's unstable argsort in the
+// reference — implementation-defined; here the higher label index wins (what a stable ascending sort, reversed, gives).
+#define MP_MAXT 16
+__global__ __launch_bounds__(256) void match_predictions_kernel(const float* __restrict__ dets, int ldd, const int* __restrict__ counts,
+                                                                int max_det, const float* __restrict__ labels,
+                                                                const int* __restrict__ label_off, const float* __restrict__ iouv,
+                                                                int T, float eps, unsigned char* __restrict__ correct, int* __restrict__ ws) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int D = counts ? min(counts[b], max_det) : max_det;
+    const int l0 = label_off[b], L = label_off[b + 1] - l0;
+    int* first = ws + (size_t)l0 * T;                       // [L][T], this image's slice of the workspace
+    for (int i = t; i < L * T; i += 256) first[i] = 0x7fffffff;
+    for (int i = t; i < max_det * T; i += 256) correct[((size_t)b * max_det) * T + i] = 0;
+    __syncthreads();
+    float thr[MP_MAXT];
+    for (int i = 0; i < T; ++i) thr[i] = iouv[i];
+    for (int d0 = 0; d0 < D; d0 += 256) {
+        const int d = d0 + t;
+        int best = -1;
+        float bi = 0.f;
+        if (d < D) {
+            const float* p = dets + ((size_t)b * max_det + d) * ldd;
+            const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3], pc = p[5];
+            const float ap = (x2 - x1) * (y2 - y1);
+            for (int l = 0; l < L; ++l) {
+                const float* g = labels + (size_t)(l0 + l) * 5;      // cls, x1, y1, x2, y2
+                if (g[0] != pc) continue;                            // iou * correct_class: wrong classes are exact zeros
+                const float w = fmaxf(fminf(g[3], x2) - fmaxf(g[1], x1), 0.f), h = fmaxf(fminf(g[4], y2) - fmaxf(g[2], y1), 0.f);
+                const float inter = w * h;
+                const float iou = inter / ((g[3] - g[1]) * (g[4] - g[2]) + ap - inter + eps);
+                if (iou >= bi && iou > 0.f) { bi = iou; best = l; }  // >=: the higher label index wins a tie
+            }
+            if (best >= 0)
+                for (int i = 0; i < T; ++i)
+                    if (bi >= thr[i]) atomicMin(&first[best * T + i], d);
+        }
+    }
+    __syncthreads();
+    // second pass: recompute nothing — a detection is correct at threshold i iff it is the first taker of its best label there.
+    for (int d0 = 0; d0 < D; d0 += 256) {
+        const int d = d0 + t;
+        if (d >= D) continue;
+        const float* p = dets + ((size_t)b * max_det + d) * ldd;
+        const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3], pc = p[5];
+        const float ap = (x2 - x1) * (y2 - y1);
+        int best = -1;
+        float bi = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const float* g = labels + (size_t)(l0 + l) * 5;
+            if (g[0] != pc) continue;
+            const float w = fmaxf(fminf(g[3], x2) - fmaxf(g[1], x1), 0.f), h = fmaxf(fminf(g[4], y2) - fmaxf(g[2], y1), 0.f);
+            const float inter = w * h;
+            const float iou = inter / ((g[3] - g[1]) * (g[4] - g[2]) + ap - inter + eps);
+            if (iou >= bi && iou > 0.f) { bi = iou; best = l; }
+        }
+        if (best >= 0)
+            for (int i = 0; i < T; ++i)
+                correct[((size_t)b * max_det + d) * T + i] = (bi >= thr[i] && first[best * T + i] == d) ? 1 : 0;
+    }
+}
+extern "C" size_t ymk_match_predictions_workspace_bytes(int32_t total_labels, int32_t T) {
+    return (size_t)(total_labels > 0 ? total_labels : 1) * (size_t)(T > 0 ? T : 1) * sizeof(int);
+}
+extern "C" int ymk_match_predictions(const float* dets, int32_t ldd, const int32_t* counts, int32_t B, int32_t max_det, const float* labels,
+                                     const int32_t* label_off, int32_t total_labels, const float* iouv, int32_t T, float eps,
+                                     uint8_t* correct, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dets || !label_off || !iouv || !correct || !workspace || ldd < 6 || T < 1 || T > MP_MAXT || max_det < 1) return YMK_E_BADARG;
+    if (total_labels > 0 && !labels) return YMK_E_BADARG;
+    if (workspace_bytes < ymk_match_predictions_workspace_bytes(total_labels, T)) return YMK_E_WORKSPACE;
+    if (B <= 0) return YMK_OK;
+    hipLaunchKernelGGL(match_predictions_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dets, ldd, counts, max_det, labels, label_off,
+                       iouv, T, eps, correct, (int*)workspace);
+    return ymk_launch_status();
+}

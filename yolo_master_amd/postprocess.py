@@ -92,3 +92,41 @@ def process_mask(protos: torch.Tensor, masks_in: torch.Tensor, bboxes: torch.Ten
                                bboxes.stride(0), n, H, W, int(bool(upsample)), float(torch.tensor(mw / shape[1], dtype=torch.float32)),
                                float(torch.tensor(mh / shape[0], dtype=torch.float32)), ops._p(ws), ops._p(out), ops._stream()), "process_mask")
     return out
+
+
+# ----------------------------------------------------------------------------- validation matching (val() after NMS)
+def box_iou(box1: torch.Tensor, box2: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    """ultralytics.utils.metrics.box_iou: fp32 [N, >=4] x [M, >=4] xyxy boxes on the GPU -> IoU [N, M]."""
+    ops.require_gpu(box1, "yolo_master_amd post-processing")
+    ops.require_gpu(box2, "yolo_master_amd post-processing")
+    if box1.dim() != 2 or box2.dim() != 2 or box1.stride(1) != 1 or box2.stride(1) != 1 or box1.dtype != torch.float32 or box2.dtype != torch.float32:
+        raise ValueError("box_iou: fp32 [N, >=4] boxes with contiguous rows")
+    N, M = box1.shape[0], box2.shape[0]
+    out = torch.empty((N, M), dtype=torch.float32, device=box1.device)
+    check(lib.ymk_box_iou(ops._p(box1), box1.stride(0) if N else 4, N, ops._p(box2), box2.stride(0) if M else 4, M, float(eps), ops._p(out),
+                          ops._stream()), "box_iou")
+    return out
+
+
+def match_predictions(dets: torch.Tensor, counts: torch.Tensor | None, labels: torch.Tensor, label_off: torch.Tensor, iouv: torch.Tensor,
+                      eps: float = 1e-7) -> torch.Tensor:
+    """BaseValidator.match_predictions (engine/validator.py:301-336) + the box_iou of DetectionValidator._process_batch for a batch.
+    dets fp32 [B, max_det, >=6] (xyxy, conf, cls; nms_padded's output scaled to the labels' frame), counts int32 [B] or None,
+    labels fp32 [sum L_b, 5] = (cls, x1, y1, x2, y2) grouped by image, label_off int32 [B + 1], iouv fp32 [T].
+    Returns correct bool [B, max_det, T] (rows past counts[b] False)."""
+    ops.require_gpu(dets, "yolo_master_amd post-processing")
+    if dets.dtype != torch.float32 or dets.dim() != 3 or dets.shape[2] < 6 or not dets.is_contiguous():
+        raise ValueError("match_predictions: contiguous fp32 [B, max_det, >=6] detections")
+    if labels.dtype != torch.float32 or (labels.numel() and (labels.dim() != 2 or labels.shape[1] != 5 or not labels.is_contiguous())):
+        raise ValueError("match_predictions: contiguous fp32 [total_labels, 5] labels (cls, x1, y1, x2, y2)")
+    B, max_det = dets.shape[:2]
+    T, total = int(iouv.numel()), int(labels.shape[0]) if labels.numel() else 0
+    if label_off.dtype != torch.int32 or label_off.numel() != B + 1:
+        raise ValueError("match_predictions: label_off int32 [B + 1]")
+    nbytes = lib.ymk_match_predictions_workspace_bytes(total, T)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dets.device)
+    correct = torch.empty((B, max_det, T), dtype=torch.uint8, device=dets.device)
+    check(lib.ymk_match_predictions(ops._p(dets), dets.stride(1), ops._p(counts), B, max_det, ops._p(labels) if total else None,
+                                    ops._p(label_off), total, ops._p(iouv.float().contiguous()), T, float(eps), ops._p(correct), ops._p(ws),
+                                    nbytes, ops._stream()), "match_predictions")
+    return correct.bool()

@@ -728,9 +728,10 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
     out[j*B:(j+1)*B] is the batch of slot j, a contiguous NHWC tensor);
     w_packed [E][Cout][Kpad] in the compute dtype, idx int32 [B][K].  The selected slices of FusedExpertGroup's grouped
     3x3 (moe/gated.py:1058-1076; grouped weights expanded to dense rows at pack time) and the expert projections of
-    SharedInvertedExpertGroup (moe/experts.py:235-269).  First implementation: ALL experts' rows run as one ymk_conv2d
-    (what the reference's fused convolution does) and the routed slices are gathered; the grouped-GEMM machinery of the
-    ES-MoE stage (resident expert weights, only routed rows) replaces it once parity holds."""
+    SharedInvertedExpertGroup (moe/experts.py:235-269).  bf16 with Cin, Cout multiples of 64: TRUE sparse dispatch on the LDS-DMA
+    tiled core (ymk_expert_conv_glds: tiles per (slot, image), the routed filter bank chosen on the device) — only the routed
+    experts' MACs run (validated on MI355X, tests/test_gpu_next.py::test_expert_conv_glds_direct; YMK_DISABLE bit 512 switches
+    it off).  Other shapes / fp32: all experts' rows as one ymk_conv2d (what the reference's fused convolution does) + a gather."""
     B, H, W, Cin, _ = _nhwc(x)
     E, Cout, Kp = w_packed.shape
     K = idx.shape[1]
@@ -740,11 +741,11 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
         out = torch.empty((K * B, H, W, Cout), dtype=x.dtype, device=x.device)
     if not out.is_contiguous():
         raise ValueError("expert_conv: dense output")
-    if (int(os.environ.get("YMK_ENABLE", "0"), 0) & 4) and x.dtype == torch.bfloat16 and Cin % 64 == 0 and Cout % 64 == 0 and Kp == k * k * Cin:
-        # true sparse dispatch on the next tiled core (include/ymk_next.h): only the routed filter banks run
+    if not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 512) and x.dtype == torch.bfloat16 and Cin % 64 == 0 and Cout % 64 == 0 and Kp == k * k * Cin:
+        # true sparse dispatch on the LDS-DMA tiled core (include/ymk_next.h): only the routed filter banks run
         d = ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, B, H, W, Cin, Cout, k, 1, _nhwc(x)[4], Cout, 0, Kp, _lib.ACT_NONE)
         check(lib.ymk_expert_conv_glds(C.byref(d), _p(x), _p(w_packed), _p(idx), K, E, _p(out),
-                                       1 if int(os.environ.get("YMK_ENABLE", "0"), 0) & 2 else 0, _stream()), "expert_conv_glds")
+                                       1, _stream()), "expert_conv_glds")   # two LDS stages: the faster loop on every 3x3 shape measured
         return out
     zero_b = torch.zeros((E * Cout,), dtype=torch.float32, device=x.device)
     f_all = conv2d(x, w_packed.reshape(E * Cout, Kp), zero_b, k, 1, False)

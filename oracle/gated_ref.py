@@ -177,3 +177,93 @@ def visual_enhanced_moe(sd, p, x, num_experts=4, top_k=2, split_ratio=0.5, num_g
     cat = context_mixer(sd, f"{p}.context_mixer", cat, num_groups)                  # post_fusion hooks, declaration order
     cat = refine(sd, p, cat, num_groups)
     return _gn(sd, f"{p}.bn", F.conv2d(cat, sd[f"{p}.proj.weight"]), num_groups) + x
+
+
+# ---------------------------------------------------------------------------------- v0_12 / v0_15 members of the family
+def dual_stream_router_v2(sd, p, x, top_k, temperature, pool_scale=4):
+    """DualStreamGateRouterV2.forward, eval (gated.py:217-262): as dual_stream_router with LayerNorm over the concatenated
+    [mean, std] statistics before the global Linear, and the learnable `expert_prior` added to the blended logits."""
+    B, C, H, W = x.shape
+    xf = x.float()
+    mean = xf.mean(dim=[2, 3])
+    std = xf.std(dim=[2, 3], unbiased=False) if H * W > 1 else torch.zeros_like(mean)
+    stats = F.layer_norm(torch.cat([mean, std], dim=1), (2 * C,), sd[f"{p}.stat_norm.weight"], sd[f"{p}.stat_norm.bias"], 1e-5)
+    g = F.linear(stats, sd[f"{p}.global_fc.weight"])
+    xl = F.avg_pool2d(xf, kernel_size=pool_scale, stride=pool_scale) if (H > pool_scale and W > pool_scale) else xf
+    h = F.silu(_gn(sd, f"{p}.local_conv.1", _dw3(xl, sd[f"{p}.local_conv.0.weight"]), 8))
+    h = F.silu(_gn(sd, f"{p}.local_conv.4", F.conv2d(h, sd[f"{p}.local_conv.3.weight"]), 4))
+    loc = F.conv2d(h, sd[f"{p}.local_conv.6.weight"], sd[f"{p}.local_conv.6.bias"]).mean(dim=[2, 3])
+    a = torch.sigmoid(sd[f"{p}.alpha"])
+    logits = a * g + (1 - a) * loc
+    logits = (logits + sd[f"{p}.expert_prior"].view(1, -1)).clamp(-30.0, 30.0)
+    probs = F.softmax(logits / max(float(temperature), 1e-3), dim=1)
+    tw, ti = torch.topk(probs, top_k, dim=1)
+    tw = tw / (tw.sum(dim=1, keepdim=True) + 1e-6)
+    return tw.to(x.dtype).view(B, top_k, 1, 1), ti.view(B, top_k, 1, 1), probs
+
+
+def plain_fused_experts(sd, p, x, weights, indices, num_experts, num_groups=8):
+    """FusedExpertGroup.forward (gated.py:1058-1090) on the dynamic half directly (no bottleneck): grouped 3x3 for all experts,
+    gather top-k, affine-free GroupNorm, the routed expert's affine row, SiLU, weighted sum."""
+    wf = sd[f"{p}.fused_conv.weight"]
+    groups = x.shape[1] // wf.shape[1]
+    B, _, H, W = x.shape
+    E, OC = num_experts, wf.shape[0] // num_experts
+    k = weights.shape[1]
+    f = F.conv2d(x, wf, None, 1, 1, 1, groups).view(B, E, OC, H, W)
+    idx = indices.view(B, k)
+    sel = torch.gather(f, 1, idx.view(B, k, 1, 1, 1).expand(B, k, OC, H, W))
+    ws = sd[f"{p}.expert_norm_weight"][idx].to(f.dtype)
+    bs = sd[f"{p}.expert_norm_bias"][idx].to(f.dtype)
+    n = F.group_norm(sel.reshape(B * k, OC, H, W), safe_groups(OC, num_groups), None, None, 1e-5).view(B, k, OC, H, W)
+    n = F.silu(n * ws.view(B, k, OC, 1, 1) + bs.view(B, k, OC, 1, 1))
+    return (n * weights.view(B, k, 1, 1, 1)).sum(dim=1)
+
+
+def cross_path_gate(sd, p, s, d):
+    """CrossPathGate.forward (gated.py:2398-2428): gate = 0.5 + tanh(gate_scale) * 0.5 * sigmoid(MLP(GAP(cat[s, d]))); the first
+    Cs / next Cd entries scale the static / dynamic outputs; returns their concatenation."""
+    cs, cd = s.shape[1], d.shape[1]
+    g = F.adaptive_avg_pool2d(torch.cat([s, d], dim=1), 1).flatten(1)
+    raw = F.linear(F.silu(F.linear(g, sd[f"{p}.gate_net.2.weight"])), sd[f"{p}.gate_net.4.weight"], sd[f"{p}.gate_net.4.bias"])
+    gate = 0.5 + torch.tanh(sd[f"{p}.gate_scale"]) * 0.5 * torch.sigmoid(raw)
+    return torch.cat([s * gate[:, :cs].unsqueeze(-1).unsqueeze(-1), d * gate[:, cs: cs + cd].unsqueeze(-1).unsqueeze(-1)], dim=1)
+
+
+def optimal_hybrid_moe(sd, p, x, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, temperature=1.2, shuffle_groups=2,
+                       cross_gate=False, info=None):
+    """OptimalHybridGateMoE.forward (v0_12, gated.py:1953-2008) and, with cross_gate=True, GatedFusionMoE.forward (v0_15,
+    gated.py:2630-2693), eval: SE-gated split, static DW+PW path, complexity-gated top-k routing (router V2), fused or
+    shared-inverted experts, [cross-path gate,] channel shuffle, residual DW refinement x + tanh(s) * GN(DW3x3(x)) * SE(x),
+    1x1 projection, GroupNorm, + x."""
+    B, C, H, W = x.shape
+    dyn = int(C * split_ratio)
+    st = C - dyn
+    g = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    g = torch.sigmoid(F.linear(F.silu(F.linear(g, sd[f"{p}.se_gate.2.weight"])), sd[f"{p}.se_gate.4.weight"], sd[f"{p}.se_gate.4.bias"]))
+    xs = x[:, :st] * g[:, :st].unsqueeze(-1).unsqueeze(-1)
+    xd = x[:, st:] * g[:, st:].unsqueeze(-1).unsqueeze(-1)
+    s = F.silu(_bn(sd, f"{p}.static_net.1", _dw3(xs, sd[f"{p}.static_net.0.weight"])))
+    s = F.silu(_bn(sd, f"{p}.static_net.4", F.conv2d(s, sd[f"{p}.static_net.3.weight"])))
+    cplx = torch.sigmoid(F.conv2d(F.adaptive_avg_pool2d(xd, 1), sd[f"{p}.complexity_estimator.1.weight"],
+                                  sd[f"{p}.complexity_estimator.1.bias"])).mean()
+    cplx = torch.tensor(1.0) if (torch.isnan(cplx) or torch.isinf(cplx)) else cplx.clamp(0.3, 1.5)
+    w, idx, probs = dual_stream_router_v2(sd, f"{p}.routing", xd, top_k, temperature)
+    w = complexity_gate(w, cplx)
+    if info is not None:
+        info[p] = {"weights": w, "indices": idx, "probs": probs, "complexity": cplx}
+    if f"{p}.fused_experts.shared_feature.0.weight" in sd:
+        d = shared_inverted_experts(sd, f"{p}.fused_experts", xd, w, idx)
+    else:
+        d = plain_fused_experts(sd, f"{p}.fused_experts", xd, w, idx, num_experts, num_groups)
+    cat = cross_path_gate(sd, f"{p}.cross_gate", s, d) if cross_gate else torch.cat([s, d], dim=1)
+    oc = cat.shape[1]
+    sg = shuffle_groups if oc % shuffle_groups == 0 else 1
+    if sg > 1:
+        cat = cat.view(B, sg, oc // sg, H, W).transpose(1, 2).reshape(B, oc, H, W)
+    if f"{p}.refine_dw.0.weight" in sd:                                  # _apply_refine (gated.py:1947-1950)
+        r = _gn(sd, f"{p}.refine_dw.1", _dw3(cat, sd[f"{p}.refine_dw.0.weight"]), num_groups)
+        gg = F.silu(F.conv2d(F.adaptive_avg_pool2d(cat, 1), sd[f"{p}.refine_gate.1.weight"]))
+        gg = torch.sigmoid(F.conv2d(gg, sd[f"{p}.refine_gate.3.weight"], sd[f"{p}.refine_gate.3.bias"]))
+        cat = cat + torch.tanh(sd[f"{p}.refine_scale"]) * (r * gg)
+    return _gn(sd, f"{p}.bn", F.conv2d(cat, sd[f"{p}.proj.weight"]), num_groups) + x

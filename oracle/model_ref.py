@@ -336,6 +336,11 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
             from . import gated_ref
             cur = gated_ref.visual_enhanced_moe(sd, p, cur, num_experts=args[1], top_k=args[2],
                                                 split_ratio=args[3] if len(args) > 3 else 0.5, info=moe_info)
+        elif m in ("OptimalHybridGateMoE", "GatedFusionMoE"):   # v0_12 / v0_15 rows: [c2, num_experts, top_k, split_ratio]
+            from . import gated_ref
+            cur = gated_ref.optimal_hybrid_moe(sd, p, cur, num_experts=args[1], top_k=args[2],
+                                               split_ratio=args[3] if len(args) > 3 else 0.5, cross_gate=m == "GatedFusionMoE",
+                                               info=moe_info)
         elif m == "C2fMoA":                          # [c2, num_heads, mlp_ratio, temperature, shortcut]
             from . import moa_ref
             cur = moa_ref.c2f_moa(sd, p, cur, num_heads=args[1] if len(args) > 1 else 6,

@@ -26,6 +26,10 @@ from ultralytics.nn.tasks import DetectionModel as RefModel  # noqa: E402
 
 YAML = Path(refboot.REF) / "ultralytics/cfg/models/master/v0_10/det/yolo-master-moa-mot-n.yaml"
 NS = 256
+TAG = "cfg5"
+if len(sys.argv) > 1 and sys.argv[1] == "v15":   # the v0_15 generation: GatedFusionMoE backbone on the v0 neck / head
+    YAML = Path(refboot.REF) / "ultralytics/cfg/models/master/v0_15/det/yolo-master-n.yaml"
+    TAG = "v15"
 
 
 def sample_idx(n, k, seed):
@@ -43,7 +47,7 @@ if __name__ == "__main__":
     ref.load_state_dict(sd)
     ref.eval()
     g = torch.Generator().manual_seed(55)
-    x = torch.rand(2, 3, 192, 160, generator=g)
+    x = torch.rand(2, 3, 192, 160, generator=g) if TAG == "cfg5" else torch.rand(3, 3, 128, 96, generator=g)
     taps = {}
     for m in ref.model:
         m.register_forward_hook(lambda mod, i, o, idx=m.i: taps.__setitem__(idx, o))
@@ -60,9 +64,9 @@ if __name__ == "__main__":
     worst = max((float((taps[i] - otaps[i]).abs().max()) if torch.is_tensor(taps[i]) else 0.0) for i in range(n - 1))
     exact = all(torch.equal(taps[i], otaps[i]) for i in range(n - 1)) and torch.equal(y, oy)
     mags = [round(float(taps[i].abs().max()), 2) for i in range(n - 1)]
-    print(f"[cfg5] {n} layers, {sum(v.numel() for v in sd.values()) / 1e6:.2f} M values; oracle bit-exact vs reference: {exact}; "
+    print(f"[{TAG}] {n} layers, {sum(v.numel() for v in sd.values()) / 1e6:.2f} M values; oracle bit-exact vs reference: {exact}; "
           f"worst layer |d| {worst:.3e}; max|dy| {(y - oy).abs().max().item():.3e}")
-    print("[cfg5] per-layer max |activation|:", mags)
+    print(f"[{TAG}] per-layer max |activation|:", mags)
     assert exact
     rec = {"x": x.numpy(), "spec": np.array(json.dumps(gen)), "cfg": np.array(json.dumps({k: cfg[k] for k in ("nc", "backbone", "head")})),
            "y_shape": np.array(y.shape)}
@@ -76,6 +80,6 @@ if __name__ == "__main__":
     for k, v in info.items():
         if "indices" in v:
             rec[f"route::{k}"] = v["indices"].numpy().astype(np.int16)
-    np.savez_compressed(HERE / "fwd_cfg5.npz", **rec)
-    json.dump({k: list(v.shape) for k, v in sd0.items()}, open(HERE / "keys_cfg5.json", "w"))   # ordered: the drop-in contract
-    print("[cfg5] wrote", (HERE / "fwd_cfg5.npz").stat().st_size, "bytes")
+    np.savez_compressed(HERE / f"fwd_{TAG}.npz", **rec)
+    json.dump({k: list(v.shape) for k, v in sd0.items()}, open(HERE / f"keys_{TAG}.json", "w"))   # ordered: the drop-in contract
+    print(f"[{TAG}] wrote", (HERE / f"fwd_{TAG}.npz").stat().st_size, "bytes")

@@ -18,7 +18,32 @@ from oracle import gated_ref, refboot  # noqa: E402
 refboot.boot()
 from make_golden_moa import seeded_fill  # noqa: E402
 
-from ultralytics.nn.modules.moe.gated import VisualEnhancedAdaptiveGateMoE  # noqa: E402
+from ultralytics.nn.modules.moe.gated import GatedFusionMoE, OptimalHybridGateMoE, VisualEnhancedAdaptiveGateMoE  # noqa: E402
+
+
+def case_v2(name, cls, C, x, seed, tweak=None, **kw):
+    """OptimalHybridGateMoE (v0_12) / GatedFusionMoE (v0_15) -> gated2_<name>.npz."""
+    m = cls(C, C, **kw)
+    sd = seeded_fill(m, seed)
+    if tweak:
+        tweak(sd)
+        m.load_state_dict(sd)
+    m.eval()
+    info = {}
+    with torch.inference_mode():
+        y = m(x)
+        oy = gated_ref.optimal_hybrid_moe({f"m.{k}": v for k, v in sd.items()}, "m", x, info=info, cross_gate=cls is GatedFusionMoE,
+                                          **{k: v for k, v in kw.items() if k in ("num_experts", "top_k", "split_ratio")})
+    exact = torch.equal(y, oy)
+    r = info["m"]
+    print(f"[gated2_{name}] {cls.__name__} x {tuple(x.shape)}; oracle bit-exact vs reference: {exact}; max|dy| {(y - oy).abs().max().item():.3e}; "
+          f"|y| max {y.abs().max().item():.3f}; complexity {float(r['complexity']):.3f}; experts {r['indices'].view(x.shape[0], -1).tolist()}")
+    assert exact
+    rec = {"x": x.numpy(), "y": y.numpy(), "keys": np.array(list(sd.keys())), "weights": r["weights"].numpy(),
+           "indices": r["indices"].numpy(), "complexity": np.float32(r["complexity"]), "cls": np.array(cls.__name__),
+           "kw": np.array(repr(kw))}
+    rec.update({f"sd::{k}": v.numpy() for k, v in sd.items()})
+    np.savez_compressed(HERE / f"gated2_{name}.npz", **rec)
 
 
 def case(name, C, x, seed, tweak=None, **kw):
@@ -48,6 +73,7 @@ def case(name, C, x, seed, tweak=None, **kw):
 if __name__ == "__main__":
     torch.set_num_threads(4)
     g = torch.Generator().manual_seed(777)
+    V2_ONLY = len(sys.argv) > 1 and sys.argv[1] == "v2"
 
     def varied(B, C, H, W):   # images with different channel statistics so that the router separates them
         x = torch.randn(B, C, H, W, generator=g)
@@ -60,6 +86,21 @@ if __name__ == "__main__":
     def low_complexity(sd):    # complexity clamps to 0.3 -> round(0.6) = 1 expert kept of the top-2
         sd["complexity_estimator.1.bias"] = torch.tensor([-20.0])
 
+    def live_gates(sd):        # the reference initialises gate_scale = 0 and refine_scale = 0.1: make both paths matter
+        high_complexity(sd)
+        if "cross_gate.gate_scale" in sd:
+            sd["cross_gate.gate_scale"] = torch.tensor(0.8)
+        sd["refine_scale"] = torch.tensor(0.6)
+        sd["routing.expert_prior"] = torch.randn(sd["routing.expert_prior"].shape, generator=torch.Generator().manual_seed(3)) * 0.5
+
+    case_v2("opt_base", OptimalHybridGateMoE, 128, varied(3, 128, 12, 16), 11, tweak=live_gates)
+    case_v2("opt_e16", OptimalHybridGateMoE, 128, varied(3, 128, 8, 8), 12, tweak=live_gates, num_experts=16, top_k=2, split_ratio=0.375)
+    case_v2("fus_base", GatedFusionMoE, 128, varied(4, 128, 12, 16), 13, tweak=live_gates)
+    case_v2("fus_small", GatedFusionMoE, 128, varied(2, 128, 4, 3), 14, tweak=live_gates, num_experts=8, top_k=2)
+    case_v2("fus_e16", GatedFusionMoE, 128, varied(3, 128, 8, 10), 15, tweak=live_gates, num_experts=16, top_k=2, split_ratio=0.375)
+    case_v2("fus_keep1", GatedFusionMoE, 128, varied(2, 128, 9, 9), 16, tweak=lambda sd: (live_gates(sd), low_complexity(sd)))
+    if V2_ONLY:
+        sys.exit(0)
     case("base", 64, varied(4, 64, 16, 20), 1, tweak=high_complexity)
     case("small", 64, varied(3, 64, 4, 3), 2, tweak=high_complexity)                   # map not larger than the router pool
     case("keep1", 64, varied(2, 64, 12, 12), 3, tweak=low_complexity)

@@ -239,7 +239,8 @@ def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
         assert np.array_equal(m.last_route["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
 
 
-def test_config5_model_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("tag", ["cfg5", "v15"])
+def test_config5_model_vs_reference_golden(tag, golden_dir):
     import json
     import warnings
 
@@ -247,13 +248,15 @@ def test_config5_model_vs_reference_golden(golden_dir):
     from yolo_master_amd import ops
     from yolo_master_amd.nn.tasks import DetectionModel
 
-    z = np.load(golden_dir / "fwd_cfg5.npz")
+    from tests.test_host_mixture import MODEL_FIXTURES
+
+    z = np.load(golden_dir / f"fwd_{tag}.npz")
     cfg = json.loads(str(z["cfg"]))
     sd = fill_by_name(json.loads(str(z["spec"])), seed=5, gain=1.0)
     sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = DetectionModel("yolo-master-moa-mot-n.yaml")
+        m = DetectionModel(MODEL_FIXTURES[tag])
     m.load_state_dict(sd)
     m.eval().to(DEV)
     taps = {}
@@ -268,3 +271,11 @@ def test_config5_model_vs_reference_golden(golden_dir):
         ref = z[f"layer{i}_val"]
         err = float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max())))
         assert err <= 1e-3, f"layer {i} ({(cfg['backbone'] + cfg['head'])[i][2]}): scaled max error {err:.3e}"
+
+
+@pytest.mark.parametrize("name", __import__("tests.test_host_mixture", fromlist=["GATED2_CASES"]).GATED2_CASES)
+def test_gated_v12_v15_vs_reference_golden(name, golden_dir):
+    """OptimalHybridGateMoE / GatedFusionMoE (moe/gated.py:1846-2008, 2564-2693) on the GPU, fp32, against the real reference."""
+    from tests.test_host_mixture import run_gated2_case
+
+    run_gated2_case(name, golden_dir, dev=DEV, dtype=torch.float32, rtol=2e-4)

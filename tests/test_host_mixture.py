@@ -139,20 +139,60 @@ def test_gated_moe_host_vs_reference(name, golden_dir, emu):
     assert emu.CALLS["expert_conv"] == 1 and emu.CALLS["gated_route_decide"] == 1 and emu.CALLS["channel_shuffle_cat"] == 1
 
 
-def test_config5_model_host_vs_reference(golden_dir, emu):
-    """The whole config-5 detector (v0_10 moa-mot YAML: gated-MoE backbone, C2fMoT / C2fMoA neck, Detect) through the
-    product's graph walk, against the real reference model's per-layer samples and routing decisions."""
+GATED2_CASES = ["opt_base", "opt_e16", "fus_base", "fus_small", "fus_e16", "fus_keep1"]
+
+
+def run_gated2_case(name, golden_dir, dev="cpu", dtype=torch.float32, rtol=5e-5):
+    """OptimalHybridGateMoE (v0_12) / GatedFusionMoE (v0_15) against the real reference's vectors; shared with the GPU test."""
+    from yolo_master_amd.nn import mixture
+
+    z, sd = _load(golden_dir, "gated2", name)
+    cls = getattr(mixture, str(z["cls"]))
+    kw = eval(str(z["kw"]), {"__builtins__": {}}, {"dict": dict})
+    m = _prep(cls(128, 128, **kw), sd)
+    assert m.expert_backend == ("shared_inverted" if kw.get("num_experts", 4) > 8 else "fused")
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    if dev != "cpu":
+        from yolo_master_amd.nn.modules import set_compute_dtype
+
+        m = m.to(dev)
+        set_compute_dtype(m, dtype)
+    with torch.inference_mode():
+        got = m(x.to(dev))
+    B = x.shape[0]
+    r = m.last_route
+    assert np.array_equal(r["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
+    assert float(np.abs(r["weights"].reshape(B, -1).cpu().numpy() - z["weights"].reshape(B, -1)).max()) <= 1e-5
+    _close(got.float().cpu(), y, f"gated2_{name}", rtol=rtol)
+    return m
+
+
+@pytest.mark.parametrize("name", GATED2_CASES)
+def test_gated_v12_v15_host_vs_reference(name, golden_dir, emu):
+    run_gated2_case(name, golden_dir)
+    assert emu.CALLS["expert_conv"] == 1 and emu.CALLS["gated_route_decide"] == 1 and emu.CALLS["channel_shuffle_cat"] == 1
+    assert emu.CALLS["layer_norm"] == 1
+
+
+MODEL_FIXTURES = {"cfg5": "yolo-master-moa-mot-n.yaml", "v15": "yolo-master-v15-n.yaml"}
+
+
+@pytest.mark.parametrize("tag", list(MODEL_FIXTURES))
+def test_config5_model_host_vs_reference(tag, golden_dir, emu):
+    """Whole detectors of the gated-MoE generations through the product's graph walk, against the real reference model's
+    per-layer samples and routing decisions: config 5 (v0_10 moa-mot YAML: VisualEnhancedAdaptiveGateMoE backbone, C2fMoT /
+    C2fMoA neck) and the v0_15 YAML (GatedFusionMoE backbone on the v0 neck / head)."""
     import json
 
     from tests.helpers import fill_by_name
     from yolo_master_amd import ops
     from yolo_master_amd.nn.tasks import DetectionModel
 
-    z = np.load(golden_dir / "fwd_cfg5.npz")
+    z = np.load(golden_dir / f"fwd_{tag}.npz")
     cfg = json.loads(str(z["cfg"]))
     sd = fill_by_name(json.loads(str(z["spec"])), seed=5, gain=1.0)
     sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
-    m = DetectionModel("yolo-master-moa-mot-n.yaml")
+    m = DetectionModel(MODEL_FIXTURES[tag])
     m.load_state_dict(sd)
     m.eval()
     taps = {}

@@ -53,3 +53,19 @@ def test_gated_structural_properties(golden_dir):
     sd0 = dict(sd)
     sd0["m.detail_gate.detail_scale"] = torch.tensor(0.0)
     assert torch.equal(gated_ref.detail_gate(sd0, "m.detail_gate", xd), xd)
+
+
+@pytest.mark.parametrize("name", ["opt_base", "opt_e16", "fus_base", "fus_small", "fus_e16", "fus_keep1"])
+def test_v12_v15_restatement_matches_reference(name, golden_dir):
+    """oracle optimal_hybrid_moe (OptimalHybridGateMoE v0_12 / GatedFusionMoE v0_15) against the real reference's vectors."""
+    import numpy as np
+
+    z = np.load(golden_dir / f"gated2_{name}.npz")
+    sd = {f"m.{k}": torch.from_numpy(z[f"sd::{k}"]) for k in z["keys"].tolist()}
+    kw = eval(str(z["kw"]), {"__builtins__": {}}, {"dict": dict})
+    info = {}
+    with torch.inference_mode():
+        y = gated_ref.optimal_hybrid_moe(sd, "m", torch.from_numpy(z["x"]), info=info, cross_gate=str(z["cls"]) == "GatedFusionMoE",
+                                         **{k: v for k, v in kw.items() if k in ("num_experts", "top_k", "split_ratio")})
+    assert np.array_equal(info["m"]["indices"].numpy(), z["indices"])
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-5, atol=1e-5)

@@ -367,6 +367,213 @@ class VisualEnhancedAdaptiveGateMoE(YmkModule):
         return ops.group_norm(ops.conv2d(cat, *pk["proj"], 1, 1, False), gs(oc, ng), *pk["bn"], 1e-5, residual=x, out=out)
 
 
+class DualStreamGateRouterV2(DualStreamGateRouter):
+    """moe/gated.py:181-215: LayerNorm over the [mean, std] statistics + a learnable per-expert prior on the logits."""
+
+    def __init__(self, in_channels, num_experts, top_k, temperature=1.0, local_reduction=16, pool_scale=4, noise_std=0.1):
+        super().__init__(in_channels, num_experts, top_k, temperature, local_reduction, pool_scale)
+        self.stat_norm = nn.LayerNorm(2 * in_channels)
+        self.expert_prior = nn.Parameter(torch.zeros(num_experts))
+        self.register_buffer("_noise_progress", torch.tensor(0.0), persistent=False)
+
+
+class CrossPathGate(nn.Module):
+    """moe/gated.py:2347-2396 (parameters; the arithmetic is in GatedFusionMoE._run)."""
+
+    def __init__(self, static_channels, dynamic_channels, out_channels, num_groups=8, drop_prob=0.1):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self.static_channels, self.dynamic_channels, self.out_channels = static_channels, dynamic_channels, out_channels
+        stat_dim = static_channels + dynamic_channels
+        hidden = max(stat_dim // 4, 8)
+        self.gate_net = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(stat_dim, hidden, bias=False), nn.SiLU(),
+                                      nn.Linear(hidden, out_channels * 2, bias=True))
+        self.gate_scale = nn.Parameter(torch.tensor(0.0))
+        self.drop_scale = nn.Parameter(torch.tensor(1.0))
+
+
+class OptimalHybridGateMoE(YmkModule):
+    """v0_12 gated MoE (moe/gated.py:1846-2008; chain AdaptiveGateMoE :268 -> HybridAdaptiveGateMoE :1277 -> HybridAdaptiveGateMoEv2
+    :1389): SE-gated channel split, static DW+PW path, DualStreamGateRouterV2 + batch-level complexity gate, fused (E <= 8) or
+    shared-inverted experts, channel shuffle, residual DW refinement, 1x1 projection + GroupNorm + x.  Eval forward on libymk."""
+
+    cross = False
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, refine=True, refine_reduction=8):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_experts, self.top_k, self.num_groups = num_experts, top_k, num_groups
+        self.initial_temperature, self.final_temperature = initial_temperature, final_temperature
+        self.dynamic_channels = int(in_channels * split_ratio)
+        self.static_channels = in_channels - self.dynamic_channels
+        self.out_dynamic = int(out_channels * split_ratio)
+        self.out_static = out_channels - self.out_dynamic
+        self.shuffle_groups = shuffle_groups if out_channels % shuffle_groups == 0 else 1
+        se_hidden = max(in_channels // 4, 4)
+        self.se_gate = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(in_channels, se_hidden, bias=False),
+                                     nn.SiLU(), nn.Linear(se_hidden, in_channels, bias=True), nn.Sigmoid())
+        sc = self.static_channels
+        self.static_net = nn.Sequential(
+            nn.Conv2d(sc, sc, 3, padding=1, groups=sc, bias=False), nn.BatchNorm2d(sc), nn.SiLU(),
+            nn.Conv2d(sc, self.out_static, 1, bias=False), nn.BatchNorm2d(self.out_static), nn.SiLU())
+        self.routing = DualStreamGateRouterV2(self.dynamic_channels, num_experts, top_k, temperature=initial_temperature)
+        if num_experts <= fused_expert_threshold:
+            self.expert_backend = "fused"
+            self.fused_experts = FusedExpertGroup(self.dynamic_channels, self.out_dynamic, num_experts, num_groups, top_k=top_k)
+        else:
+            self.expert_backend = "shared_inverted"
+            self.fused_experts = SharedInvertedExpertGroup(self.dynamic_channels, self.out_dynamic, num_experts, top_k=top_k)
+        self.complexity_estimator = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(self.dynamic_channels, 1, 1), nn.Sigmoid())
+        self.proj = nn.Conv2d(out_channels, out_channels, 1, bias=False)
+        self.bn = _gn(out_channels, num_groups)
+        self.refine = refine
+        if refine:
+            refine_hidden = max(out_channels // refine_reduction, 8)
+            self.refine_dw = nn.Sequential(nn.Conv2d(out_channels, out_channels, 3, padding=1, groups=out_channels, bias=False),
+                                           _gn(out_channels, num_groups))
+            self.refine_gate = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(out_channels, refine_hidden, 1, bias=False), nn.SiLU(),
+                                             nn.Conv2d(refine_hidden, out_channels, 1, bias=True), nn.Sigmoid())
+            self.refine_scale = nn.Parameter(torch.tensor(0.1))
+
+    def _pack(self, dtype, device):
+        import math
+
+        f32 = torch.float32
+        dyn = self.dynamic_channels
+        se, rt = self.se_gate, self.routing
+        if dyn % 8 or self.static_channels % 8 or self.out_dynamic % 8 or self.out_static % 8:
+            raise NotImplementedError(f"ymk {type(self).__name__}: split {self.static_channels}+{dyn} breaks the 16-byte channel-vector rule")
+        E4, red = _ceil(self.num_experts, 4), rt.local_conv[3].out_channels
+        rp = _ceil(red, 4)
+        sn = self.static_net
+        dw_w, dw_b = ops.fold_bn(sn[0].weight.detach().float().to(device), sn[1].weight.float().to(device), sn[1].bias.float().to(device),
+                                 sn[1].running_mean.float().to(device), sn[1].running_var.float().to(device), sn[1].eps)
+        pw_w, pw_b = ops.fold_bn(sn[3].weight.detach().float().to(device), sn[4].weight.float().to(device), sn[4].bias.float().to(device),
+                                 sn[4].running_mean.float().to(device), sn[4].running_var.float().to(device), sn[4].eps)
+        alpha = float(torch.sigmoid(rt.alpha.detach().float()))
+        gw, gb = _pack_conv(rt.global_fc, f32, device, pad_cout_to=E4)
+        # expert_prior is added to the blended logits alpha * g + (1 - alpha) * l: folded into the global stream as prior / alpha
+        gb = gb.clone()
+        gb[: self.num_experts] = rt.expert_prior.detach().float().to(device) / alpha
+        pk = {
+            "se0": _pack_conv(se[2], f32, device), "se1": _pack_conv(se[4], f32, device),
+            "st_dw": (ops.pack_dw_weight(dw_w, dtype), dw_b.contiguous()), "st_pw": (ops.pack_conv_weight(pw_w, dtype), pw_b.contiguous()),
+            "cplx": _pack_conv(self.complexity_estimator[1], f32, device, pad_cout_to=4),
+            "sn": _pack_norm(rt.stat_norm, device), "gfc": (gw, gb.contiguous()),
+            "lc0": _pack_dw(rt.local_conv[0], f32, device), "lc1": _pack_norm(rt.local_conv[1], device),
+            "lc3": _pack_conv(rt.local_conv[3], f32, device, pad_cout_to=rp), "lc4": _pack_norm(rt.local_conv[4], device),
+            "lc_red": red, "lc_rp": rp,
+            "lc6": _pack_conv(rt.local_conv[6], f32, device, pad_cout_to=E4, pad_cin_to=rp), "alpha": float(rt.alpha), "inv_temp": 1.0 / rt.temperature,
+            "proj": _pack_conv(self.proj, dtype, device), "bn": _pack_norm(self.bn, device),
+        }
+        if self.refine:
+            pk.update({"rd0": _pack_dw(self.refine_dw[0], dtype, device), "rd1": _pack_norm(self.refine_dw[1], device),
+                       "rg1": _pack_conv(self.refine_gate[1], f32, device), "rg3": _pack_conv(self.refine_gate[3], f32, device),
+                       "rf_s": math.tanh(float(self.refine_scale))})
+        fe = self.fused_experts
+        E, OC = self.num_experts, self.out_dynamic
+        if self.expert_backend == "fused":
+            fc = fe.fused_conv
+            w = fc.weight.detach().float().to(device)                       # [E*OC, dyn/g, 3, 3], grouped
+            cin, g = fc.in_channels, fc.groups
+            cg, og = cin // g, (E * OC) // g
+            dense = w.new_zeros((E * OC, cin, 3, 3))
+            for grp in range(g):                                             # grouped filter bank -> dense rows (only routed rows run)
+                dense[grp * og:(grp + 1) * og, grp * cg:(grp + 1) * cg] = w[grp * og:(grp + 1) * og]
+            pk["ew"] = ops.pack_conv_weight(dense, dtype).reshape(E, OC, -1).contiguous()
+            pk["en"] = (fe.expert_norm_weight.detach().float().to(device).contiguous(), fe.expert_norm_bias.detach().float().to(device).contiguous())
+        else:
+            sf = fe.shared_feature
+            pk["sf0"], pk["sf1"] = _pack_conv(sf[0], dtype, device), _pack_norm(sf[1], device)
+            pk["sf3"], pk["sf4"], pk["sf_k"] = _pack_dw(sf[3], dtype, device), _pack_norm(sf[4], device), sf[3].kernel_size[0]
+            pk["ew"] = torch.stack([_pack_conv(p[0], dtype, device)[0] for p in fe.expert_projections]).contiguous()
+            pk["en"] = (torch.stack([p[1].weight.detach().float() for p in fe.expert_projections]).to(device).contiguous(),
+                        torch.stack([p[1].bias.detach().float() for p in fe.expert_projections]).to(device).contiguous())
+        if self.cross:
+            cg_ = self.cross_gate
+            oc = self.out_static + self.out_dynamic
+            c = 0.5 * math.tanh(float(cg_.gate_scale))
+            # gate = 0.5 + c * sigmoid(raw): an affine map of the sigmoid, applied as a diagonal 1x1 convolution over its first oc entries
+            diag = torch.zeros((oc, oc, 1, 1), device=device)
+            diag[torch.arange(oc), torch.arange(oc), 0, 0] = c
+            pk.update({"cg0": _pack_conv(cg_.gate_net[2], f32, device), "cg1": _pack_conv(cg_.gate_net[4], f32, device),
+                       "cg_aff": (ops.pack_conv_weight(diag, f32), torch.full((oc,), 0.5, device=device))})
+        return pk
+
+    def _fuse_paths(self, s, d, pk):
+        """[static | dynamic] -> channel-shuffled concatenation (gated.py:1333-1338)."""
+        return ops.channel_shuffle_cat([s, d], self.shuffle_groups)
+
+    def _run(self, x, out=None):
+        B, H, W, C = x.shape
+        pk = self._packed(x.device)
+        st, dyn, ng, k = self.static_channels, self.dynamic_channels, self.num_groups, self.top_k
+        gs = get_safe_groups
+        gate = ops.conv2d_act(ops.conv2d(ops.channel_stats(x), *pk["se0"], 1, 1, True), *pk["se1"], 1, 1, "sigmoid")
+        xg = ops.channel_gate(x, gate)
+        xs, xd = xg[..., :st], xg[..., st:]
+        s = ops.conv2d(ops.dwconv2d(xs, *pk["st_dw"], 3, True), *pk["st_pw"], 1, 1, True)
+        cplx = ops.conv2d(ops.channel_stats(xd), *pk["cplx"], 1, 1, False)[..., :1]
+        E = self.num_experts
+        stats = ops.layer_norm(ops.channel_stats(xd, want_std=True), *pk["sn"], 1e-5)
+        g_logits = ops.conv2d(stats, *pk["gfc"], 1, 1, False)[..., :E]
+        ps = self.routing.pool_scale
+        xl = ops.avg_pool(xd, ps if (H > ps and W > ps) else 1, out_dtype=torch.float32)
+        h = ops.group_norm(ops.dwconv2d(xl, pk["lc0"], None, 3, False), gs(dyn, 8), *pk["lc1"], 1e-5, act="silu")
+        h = ops.conv2d(h, *pk["lc3"], 1, 1, False)
+        red, rp = pk["lc_red"], pk["lc_rp"]
+        hn = h if red == rp else torch.zeros(h.shape, dtype=h.dtype, device=h.device)
+        ops.group_norm(h[..., :red], gs(red, 4), *pk["lc4"], 1e-5, act="silu", out=hn[..., :red])
+        loc = ops.channel_stats(ops.conv2d(hn, *pk["lc6"], 1, 1, False))[..., :E]
+        w, idx, probs, rows = ops.gated_route_decide(g_logits, loc, pk["alpha"], pk["inv_temp"], k, cplx)
+        self.last_route = {"weights": w, "indices": idx, "probs": probs}
+        OC = self.out_dynamic
+        if self.expert_backend == "fused":
+            f = ops.expert_conv(xd, pk["ew"], 3, idx)
+            f = ops.group_norm(f, gs(OC, ng), *pk["en"], 1e-5, act="silu", affine_rows=rows)
+        else:
+            hs = ops.group_norm(ops.conv2d(xd, *pk["sf0"], 1, 1, False), gs(pk["sf0"][0].shape[0], 8), *pk["sf1"], 1e-5, act="silu")
+            hs = ops.group_norm(ops.dwconv2d(hs, pk["sf3"], None, pk["sf_k"], False), gs(hs.shape[-1], 8), *pk["sf4"], 1e-5, act="silu")
+            f = ops.group_norm(ops.expert_conv(hs, pk["ew"], 1, idx), gs(OC, 8), *pk["en"], 1e-5, affine_rows=rows)
+        d = ops.weighted_sum(w, [f[j * B:(j + 1) * B] for j in range(k)])
+        cat = self._fuse_paths(s, d, pk)
+        oc = cat.shape[-1]
+        if self.refine:   # x + tanh(scale) * GN(DW3x3(x)) * SE(x)   (gated.py:1947-1950)
+            r = ops.group_norm(ops.dwconv2d(cat, pk["rd0"], None, 3, False), gs(oc, ng), *pk["rd1"], 1e-5)
+            g = ops.conv2d_act(ops.conv2d(ops.channel_stats(cat), *pk["rg1"], 1, 1, True), *pk["rg3"], 1, 1, "sigmoid")
+            cat = ops.fma_gate(cat, r, g, pk["rf_s"])
+        return ops.group_norm(ops.conv2d(cat, *pk["proj"], 1, 1, False), gs(oc, ng), *pk["bn"], 1e-5, residual=x, out=out)
+
+
+class GatedFusionMoE(OptimalHybridGateMoE):
+    """v0_15 gated MoE (moe/gated.py:2564-2693): OptimalHybridGateMoE with a content-aware CrossPathGate between the two paths and
+    the channel shuffle (stochastic depth is training-only)."""
+
+    cross = True
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, refine=True, refine_reduction=8, drop_prob=0.05):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold, shuffle_groups, refine,
+                         refine_reduction)
+        self.cross_gate = CrossPathGate(self.out_static, self.out_dynamic, out_channels, num_groups=num_groups, drop_prob=drop_prob)
+
+    def _fuse_paths(self, s, d, pk):
+        """CrossPathGate.forward (gated.py:2398-2428): gate = 0.5 + tanh(scale) / 2 * sigmoid(MLP(GAP [s | d])) per image and channel,
+        applied to both paths before the shuffle."""
+        cs, cd = self.out_static, self.out_dynamic
+        B = s.shape[0]
+        stats = torch.empty((B, 1, 1, cs + cd), dtype=torch.float32, device=s.device)
+        ops.copy_channels(ops.channel_stats(s), stats[..., :cs])
+        ops.copy_channels(ops.channel_stats(d), stats[..., cs:])
+        sig = ops.conv2d_act(ops.conv2d(stats, *pk["cg0"], 1, 1, True), *pk["cg1"], 1, 1, "sigmoid")     # [B,1,1,2*out_channels]
+        gate = ops.conv2d(sig[..., : cs + cd], *pk["cg_aff"], 1, 1, False)
+        return ops.channel_shuffle_cat([ops.channel_gate(s, gate[..., :cs]), ops.channel_gate(d, gate[..., cs:])], self.shuffle_groups)
+
+
 # ----------------------------------------------------------------------------------------- MoA
 class _MoARouter(nn.Module):
     """moa/router.py:29-48."""
@@ -828,5 +1035,6 @@ class C2fMoT(YmkModule):
         return self.cv2._run(cat, out=out)
 
 
-MIXTURE_BOUNDARY_MODULES = {"VisualEnhancedAdaptiveGateMoE": VisualEnhancedAdaptiveGateMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
+MIXTURE_BOUNDARY_MODULES = {"VisualEnhancedAdaptiveGateMoE": VisualEnhancedAdaptiveGateMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE,
+                            "GatedFusionMoE": GatedFusionMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
 MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

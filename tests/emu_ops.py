@@ -371,7 +371,7 @@ def fma_gate(x, a, b, scale, out=None):
 
 def channel_gate(x, gate, out=None):
     _count("channel_gate")
-    assert gate.dtype == torch.float32 and tuple(gate.shape) == (x.shape[0], 1, 1, x.shape[3])
+    assert gate.dtype == torch.float32 and tuple(gate.shape) == (x.shape[0], 1, 1, x.shape[3]) and gate.is_contiguous()   # as ops.channel_gate
     return _put(x.float() * gate, out, x.dtype)
 
 

@@ -571,7 +571,8 @@ class GatedFusionMoE(OptimalHybridGateMoE):
         ops.copy_channels(ops.channel_stats(d), stats[..., cs:])
         sig = ops.conv2d_act(ops.conv2d(stats, *pk["cg0"], 1, 1, True), *pk["cg1"], 1, 1, "sigmoid")     # [B,1,1,2*out_channels]
         gate = ops.conv2d(sig[..., : cs + cd], *pk["cg_aff"], 1, 1, False)
-        return ops.channel_shuffle_cat([ops.channel_gate(s, gate[..., :cs]), ops.channel_gate(d, gate[..., cs:])], self.shuffle_groups)
+        gs_, gd_ = gate[..., :cs].contiguous(), gate[..., cs:].contiguous()     # channel_gate takes dense [B,1,1,C] gates (two tiny copies)
+        return ops.channel_shuffle_cat([ops.channel_gate(s, gs_), ops.channel_gate(d, gd_)], self.shuffle_groups)
 
 
 # ----------------------------------------------------------------------------------------- MoA

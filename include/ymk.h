@@ -211,6 +211,15 @@ int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int3
                          int32_t ldx, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Fused two-layer 1x1 MLP with residual (bf16): y = x + W2 * SiLU(W1 * x + b1) + b2 per token — ABlock's `x + mlp(x)`
+ * (nn/modules/block.py:1772-1797) as ONE kernel: the hidden tensor stays in LDS.  Same operands as two ymk_conv2d calls
+ * (packed [Cout][Kpad] bf16 weights with the BN folded, fp32 biases).  (C, hidden) in {(64,128), (128,256), (256,512)}.
+ * ------------------------------------------------------------------------ */
+int ymk_mlp_fused_supported(int32_t dtype, int32_t C, int32_t hidden);
+int ymk_mlp_fused(const void* x, int32_t ldx, const void* w1, int32_t k1pad, const float* b1, const void* w2, int32_t k2pad,
+                  const float* b2, void* y, int32_t ldy, int64_t M, int32_t C, int32_t hidden, void* stream);
+
+/* ------------------------------------------------------------------------
  * Depthwise convolution on the matrix cores (bf16, odd k <= 9, C % 16 == 0): the same operations as ymk_dwconv2d /
  * ymk_esmoe_dw (DWConv conv.py:185-199, AAttn.pe block.py:1688,1731, DepthwiseSeparableConv.depthwise
  * experts.py:283-292), evaluated as banded (Toeplitz) GEMMs along x — one 16x16x32 MFMA per (channel, filter row,

@@ -121,6 +121,17 @@ def dwpw_supported(dtype, C, kmax):
     return False
 
 
+def mlp_fused_supported(dtype, C, hidden):
+    return dtype == torch.bfloat16 and (C, hidden) in ((64, 128), (128, 256), (256, 512))
+
+
+def mlp_fused(x, w1, b1, w2, b2, out=None):
+    """include/ymk.h `ymk_mlp_fused`: y = x + W2 SiLU(W1 x + b1) + b2, the hidden tile rounded to the activation type."""
+    _count("mlp_fused")
+    h = conv2d(x, w1, b1, 1, 1, True)
+    return conv2d(h, w2, b2, 1, 1, False, out=out, residual=x)
+
+
 def dwconv_pwconv(x, dw_w, dw_b, k, dw_act, pw_w, pw_b, pw_act, out=None):
     _count("dwconv_pwconv")
     h = dwconv2d(x, dw_w, dw_b, k, dw_act)
@@ -557,7 +568,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "esmoe_route", "esmoe_dw",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "weighted_sum",

@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
 CSRC = ROOT / "yolo_master_amd" / "csrc"
 OUT = HERE / "_build"
-SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "dwmfma.hip", "preproc.hip"]
+SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "dwmfma.hip", "preproc.hip", "mlp.hip"]
 
 
 def compiler():
@@ -42,6 +42,7 @@ def build(force: bool = False) -> Path | None:
         txt = re.sub(r"\bextern\s+__shared__\s+(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(hostemu::dyn_lds);", txt)
         txt = re.sub(r"\b__shared__\b", "static", txt)
         txt = txt.replace('#include "ymk_common.h"', f'#include "{CSRC / "ymk_common.h"}"')
+        txt = txt.replace('#include "igemm.h"', f'#include "{CSRC / "igemm.h"}"')
         txt = txt.replace('#include "../../include/ymk_mixture.h"', f'#include "{ROOT / "include" / "ymk_mixture.h"}"')
         u = OUT / (s.stem + "_host.cpp")
         u.write_text(txt)

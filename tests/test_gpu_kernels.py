@@ -177,6 +177,16 @@ def test_dwconv_mfma_equals_valu_path():
     assert float(d.max()) <= 2.0 ** -7 * float(y_v.float().abs().max()) and float((d > 0).float().mean()) < 0.2
 
 
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_mlp", fromlist=["CASES"]).CASES + [(128, 256, 102400, 0, 0), (256, 512, 25600, 0, 0)])
+def test_mlp_fused(case):
+    """Fused ABlock MLP kernel (csrc/mlp.hip) through the C-ABI against the two-GEMM composition in fp32 (incl. the detector's sizes)."""
+    from tests.test_hostemu_mlp import run_case
+    from yolo_master_amd import _lib
+
+    run_case(_lib.load(), case, dev=DEV, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------- layout kernels
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_kernels(dtype):

@@ -48,8 +48,9 @@ def test_kernels_modules_vs_reference_golden(T, fam, name, ctor, golden_dir):
         T.test_modules_vs_reference_golden(fam, name, ctor, golden_dir)
 
 
-def test_kernels_config5_model_vs_reference_golden(T, golden_dir):
-    T.test_config5_model_vs_reference_golden(golden_dir)
+@pytest.mark.parametrize("tag", ["cfg5", "v15"])
+def test_kernels_config5_model_vs_reference_golden(T, tag, golden_dir):
+    T.test_config5_model_vs_reference_golden(tag, golden_dir)
 
 
 def test_conv256_probe_on_the_emulator():
@@ -108,8 +109,8 @@ def test_kernels_config5_L_scale_model(T):
 
 
 def test_kernels_sparse_expert_dispatch_in_the_L_scale_gated_blocks(T, hostlib, monkeypatch):
-    """YMK_ENABLE bit 2: the routed experts of the gated blocks run through ymk_expert_conv_glds (only the routed filter banks)
-    instead of the all-experts convolution + gather.  bf16, L-scale widths (bottleneck 128 -> 4 / 8 banks of 256 couts, 3x3;
+    """The routed experts of the gated blocks run through ymk_expert_conv_glds (only the routed filter banks); YMK_DISABLE bit 512
+    puts the all-experts convolution + gather back.  bf16, L-scale widths (bottleneck 128 -> 4 / 8 banks of 256 couts, 3x3;
     512 -> 16 banks, 1x1): both paths give the same block output up to bf16 rounding of the intermediate."""
     from yolo_master_amd.nn.mixture import VisualEnhancedAdaptiveGateMoE
 
@@ -119,8 +120,8 @@ def test_kernels_sparse_expert_dispatch_in_the_L_scale_gated_blocks(T, hostlib, 
         m.ymk_dtype = torch.bfloat16
         x = torch.randn(2, 512, 10, 12)
         outs = []
-        for enable in ("0", "4"):
-            monkeypatch.setenv("YMK_ENABLE", enable)
+        for off in ("512", "0"):
+            monkeypatch.setenv("YMK_DISABLE", off)
             before = emu_ops.CALLS.get("conv2d", 0)
             with torch.inference_mode():
                 outs.append(m(x).float())

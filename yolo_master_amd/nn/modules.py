@@ -402,8 +402,12 @@ class ABlock(YmkModule):
 
     def _run(self, x, out=None):
         x1 = self.attn._run(x, residual=x)              # x + attn(x)
-        h = self.mlp[0]._run(x1)
-        return self.mlp[1]._run(h, out=out, residual=x1)  # x + mlp(x)
+        m0, m1 = self.mlp[0], self.mlp[1]
+        if ops.mlp_fused_supported(x1.dtype, x1.shape[-1], m0.conv.out_channels) and _is_silu(m0.act) and not _is_silu(m1.act):
+            p0, p1 = m0._packed(x1.device), m1._packed(x1.device)   # x + mlp(x) as one kernel: the hidden tensor never leaves the CU
+            return ops.mlp_fused(x1, p0["w"], p0["b"], p1["w"], p1["b"], out=out)
+        h = m0._run(x1)
+        return m1._run(h, out=out, residual=x1)  # x + mlp(x)
 
 
 class A2C2f(YmkModule):
@@ -525,7 +529,9 @@ class Detect(YmkModule):
         return {"box": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv2],
                 "cls": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv3]}
 
-    level_streams = False  # levels 1.. on side HIP streams: measured slower (10.8 vs 10.1 ms/step, contention) -> off
+    # levels 1.. on side HIP streams (fork / join, also valid under graph capture): measured slower in round 1 (10.8 vs 10.1 ms/step,
+    # contention) -> off; YMK_ENABLE bit 16 switches it on for A/B runs
+    level_streams = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 16)
 
     def _side_streams(self, device, n):
         st = self.__dict__.setdefault("_ymk_streams", {})

@@ -352,6 +352,26 @@ def dwconv_pwconv(x, dw_w, dw_b, k: int, dw_act: bool, pw_w, pw_b, pw_act: bool,
     return out
 
 
+def mlp_fused_supported(dtype, C: int, hidden: int) -> bool:
+    """YMK_DISABLE bit 1024 switches the fused ABlock MLP off (-> two 1x1 convolutions) for A/B runs."""
+    return dtype in DT and bool(lib.ymk_mlp_fused_supported(DT[dtype], C, hidden)) and not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 1024)
+
+
+def mlp_fused(x, w1, b1, w2, b2, out=None):
+    """y = x + W2 * SiLU(W1 * x + b1) + b2 per token (ABlock's x + mlp(x)), one kernel: x / y NHWC bf16 views, w1 [hidden][Kpad],
+    w2 [C][Kpad] packed bf16 (BN folded), fp32 biases."""
+    B, H, W, Cc, ldx = _nhwc(x)
+    hidden = w1.shape[0]
+    if out is None:
+        out = new_act(B, H, W, Cc, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_mlp_fused(_p(x), ldx, _p(w1), w1.shape[1], _p(b1), _p(w2), w2.shape[1], _p(b2), _p(out), ldy, B * H * W, Cc, hidden,
+                            _stream()), "mlp_fused")
+    TIMER.end(e0, "mlp_fused", (2 * B * H * W * Cc + 2 * Cc * hidden) * x.element_size(), 4 * B * H * W * Cc * hidden, f"{Cc}->{hidden}->{Cc} @{H}x{W}")
+    return out
+
+
 # ----------------------------------------------------------------------------- attention
 def area_attn(qkv, heads: int, area: int, out=None):
     B, H, W, C3, ldq = _nhwc(qkv)

@@ -142,41 +142,74 @@ def refine(sd, p, x, num_groups=8):
     return x + sd[f"{p}.refine_scale"].tanh() * r * g
 
 
-def visual_enhanced_moe(sd, p, x, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, temperature=1.2,
-                        shuffle_groups=2, info=None):
-    """run_visual_hybrid_moe_forward for VisualEnhancedAdaptiveGateMoE, eval (_gated_visual.py:32-75)."""
+def adaptive_gate_chain(sd, p, x, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, temperature=1.2, shuffle_groups=2,
+                        hooks=None, info=None, complexity_after_hooks=True):
+    """Eval forward of every member of the AdaptiveGateMoE inheritance chain (gated.py:268-1764): AdaptiveGateMoE v0_4 (:530-580;
+    shared-inverted experts, no shuffle), FusedAdaptiveGateMoE v0_5 (:1232-1274; FusedExpertGroup), HybridAdaptiveGateMoE v0_6
+    (:1340-1386; fused for E <= 8 else shared-inverted, channel shuffle), HybridAdaptiveGateMoEv2 v0_11 (:1389-1452; router V2),
+    LowRankHybridAdaptiveGateMoE v0_7 (:1455-1508; bottlenecked fused experts), Refined v0_8 / DetailAware v0_9 / ContextRefined /
+    VisualEnhanced v0_10 (:1511-1764, `run_visual_hybrid_moe_forward`, _gated_visual.py:32-75, with the router hooks
+    detail -> pre_route, context / refine -> post_fusion in declaration order).
+
+    The members differ only in which sub-modules exist, so the state dict decides: `routing.stat_norm` -> router V2,
+    `fused_experts.shared_feature` / `.bottleneck` / `.fused_conv` -> expert backend, `detail_gate` / `context_mixer` /
+    `feature_refiner` -> hooks (`hooks` overrides the order for AdaptiveGateMoE(router_hooks=[...])).  `shuffle_groups` is 1 for
+    v0_4 / v0_5 (their forward has no _channel_shuffle) and `temperature` is the router's eval temperature (1.0 for v0_4 / v0_5).
+    The complexity score reads the dynamic half after the pre-route hooks in `run_visual_hybrid_moe_forward` (_gated_visual.py:47-53)
+    and before them in AdaptiveGateMoE.forward (gated.py:548-552): `complexity_after_hooks`."""
     B, C, H, W = x.shape
     dyn = int(C * split_ratio)
     st = C - dyn
+    if hooks is None:
+        hooks = [h for h, key in (("detail", f"{p}.detail_gate.detail_scale"), ("context", f"{p}.context_mixer.context_scale"),
+                                  ("refine", f"{p}.feature_refiner.0.weight")) if key in sd]
     # SE gate (gated.py:333-341): GAP -> Linear (no bias) -> SiLU -> Linear -> sigmoid
     g = F.adaptive_avg_pool2d(x, 1).flatten(1)
     g = torch.sigmoid(F.linear(F.silu(F.linear(g, sd[f"{p}.se_gate.2.weight"])), sd[f"{p}.se_gate.4.weight"], sd[f"{p}.se_gate.4.bias"]))
     xs = x[:, :st] * g[:, :st].unsqueeze(-1).unsqueeze(-1)
     xd = x[:, st:] * g[:, st:].unsqueeze(-1).unsqueeze(-1)
-    xd = detail_gate(sd, f"{p}.detail_gate", xd, num_groups)                       # pre_route hook
     # static path (gated.py:344-353): DW3x3 -> BN -> SiLU -> 1x1 -> BN -> SiLU
     s = F.silu(_bn(sd, f"{p}.static_net.1", _dw3(xs, sd[f"{p}.static_net.0.weight"])))
     s = F.silu(_bn(sd, f"{p}.static_net.4", F.conv2d(s, sd[f"{p}.static_net.3.weight"])))
-    # complexity score (gated.py:373-377, 455-460)
-    cplx = torch.sigmoid(F.conv2d(F.adaptive_avg_pool2d(xd, 1), sd[f"{p}.complexity_estimator.1.weight"],
-                                  sd[f"{p}.complexity_estimator.1.bias"])).mean()
-    cplx = torch.tensor(1.0) if (torch.isnan(cplx) or torch.isinf(cplx)) else cplx.clamp(0.3, 1.5)
-    w, idx, probs = dual_stream_router(sd, f"{p}.routing", xd, top_k, temperature)
+    def complexity(t):   # gated.py:373-377, 455-460
+        c = torch.sigmoid(F.conv2d(F.adaptive_avg_pool2d(t, 1), sd[f"{p}.complexity_estimator.1.weight"],
+                                   sd[f"{p}.complexity_estimator.1.bias"])).mean()
+        return torch.tensor(1.0) if (torch.isnan(c) or torch.isinf(c)) else c.clamp(0.3, 1.5)
+
+    cplx = None if complexity_after_hooks else complexity(xd)
+    for h in hooks:                                                                 # pre_route hooks
+        if h == "detail":
+            xd = detail_gate(sd, f"{p}.detail_gate", xd, num_groups)
+    if cplx is None:
+        cplx = complexity(xd)
+    router = dual_stream_router_v2 if f"{p}.routing.stat_norm.weight" in sd else dual_stream_router
+    w, idx, probs = router(sd, f"{p}.routing", xd, top_k, temperature)
     w = complexity_gate(w, cplx)
     if info is not None:
         info[p] = {"weights": w, "indices": idx, "probs": probs, "complexity": cplx}
-    if f"{p}.fused_experts.shared_feature.0.weight" in sd:   # more experts than fused_expert_threshold (gated.py:1318-1331)
+    if f"{p}.fused_experts.shared_feature.0.weight" in sd:   # AdaptiveGateMoE, or more experts than fused_expert_threshold (:1318-1331)
         d = shared_inverted_experts(sd, f"{p}.fused_experts", xd, w, idx)
-    else:
+    elif f"{p}.fused_experts.bottleneck.0.weight" in sd:
         d = fused_experts(sd, f"{p}.fused_experts", xd, w, idx, num_experts, num_groups)
+    else:
+        d = plain_fused_experts(sd, f"{p}.fused_experts", xd, w, idx, num_experts, num_groups)
     cat = torch.cat([s, d], dim=1)
     oc = cat.shape[1]
     sg = shuffle_groups if oc % shuffle_groups == 0 else 1
     if sg > 1:                                                                      # _channel_shuffle (gated.py:1333-1338)
         cat = cat.view(B, sg, oc // sg, H, W).transpose(1, 2).reshape(B, oc, H, W)
-    cat = context_mixer(sd, f"{p}.context_mixer", cat, num_groups)                  # post_fusion hooks, declaration order
-    cat = refine(sd, p, cat, num_groups)
+    for h in hooks:                                                                 # post_fusion hooks, declaration order
+        if h == "context":
+            cat = context_mixer(sd, f"{p}.context_mixer", cat, num_groups)
+        elif h == "refine":
+            cat = refine(sd, p, cat, num_groups)
     return _gn(sd, f"{p}.bn", F.conv2d(cat, sd[f"{p}.proj.weight"]), num_groups) + x
+
+
+def visual_enhanced_moe(sd, p, x, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, temperature=1.2,
+                        shuffle_groups=2, info=None):
+    """run_visual_hybrid_moe_forward for VisualEnhancedAdaptiveGateMoE, eval (_gated_visual.py:32-75)."""
+    return adaptive_gate_chain(sd, p, x, num_experts, top_k, split_ratio, num_groups, temperature, shuffle_groups, info=info)
 
 
 # ---------------------------------------------------------------------------------- v0_12 / v0_15 members of the family

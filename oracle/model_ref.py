@@ -336,6 +336,14 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
             from . import gated_ref
             cur = gated_ref.visual_enhanced_moe(sd, p, cur, num_experts=args[1], top_k=args[2],
                                                 split_ratio=args[3] if len(args) > 3 else 0.5, info=moe_info)
+        elif m in ("AdaptiveGateMoE", "FusedAdaptiveGateMoE", "HybridAdaptiveGateMoE", "HybridAdaptiveGateMoEv2", "LowRankHybridAdaptiveGateMoE",
+                   "RefinedLowRankHybridAdaptiveGateMoE", "DetailAwareLowRankHybridAdaptiveGateMoE",
+                   "ContextRefinedLowRankHybridAdaptiveGateMoE"):      # v0_4 ... v0_9 / v0_11 rows: [c2, num_experts, top_k, split_ratio]
+            from . import gated_ref
+            plain = m in ("AdaptiveGateMoE", "FusedAdaptiveGateMoE")    # constructor default temperature 1.0, no channel shuffle
+            cur = gated_ref.adaptive_gate_chain(sd, p, cur, num_experts=args[1], top_k=args[2], split_ratio=args[3] if len(args) > 3 else 0.5,
+                                                temperature=1.0 if plain else 1.2, shuffle_groups=1 if plain else 2,
+                                                complexity_after_hooks=not plain, info=moe_info)
         elif m in ("OptimalHybridGateMoE", "GatedFusionMoE"):   # v0_12 / v0_15 rows: [c2, num_experts, top_k, split_ratio]
             from . import gated_ref
             cur = gated_ref.optimal_hybrid_moe(sd, p, cur, num_experts=args[1], top_k=args[2],

@@ -30,6 +30,9 @@ TAG = "cfg5"
 if len(sys.argv) > 1 and sys.argv[1] == "v15":   # the v0_15 generation: GatedFusionMoE backbone on the v0 neck / head
     YAML = Path(refboot.REF) / "ultralytics/cfg/models/master/v0_15/det/yolo-master-n.yaml"
     TAG = "v15"
+if len(sys.argv) > 1 and sys.argv[1] in ("v04", "v05", "v06", "v07", "v08", "v09"):   # earlier generations of the gated family (one class each)
+    TAG = sys.argv[1]
+    YAML = Path(refboot.REF) / f"ultralytics/cfg/models/master/v0_{int(TAG[1:])}/det/yolo-master-n.yaml"
 
 
 def sample_idx(n, k, seed):
@@ -68,7 +71,7 @@ if __name__ == "__main__":
           f"worst layer |d| {worst:.3e}; max|dy| {(y - oy).abs().max().item():.3e}")
     print(f"[{TAG}] per-layer max |activation|:", mags)
     assert exact
-    rec = {"x": x.numpy(), "spec": np.array(json.dumps(gen)), "cfg": np.array(json.dumps({k: cfg[k] for k in ("nc", "backbone", "head")})),
+    rec = {"x": x.numpy(), "spec": np.array(json.dumps(gen)), "cfg": np.array(json.dumps({"scale": "n", **{k: cfg[k] for k in ("nc", "scales", "backbone", "head")}})),
            "y_shape": np.array(y.shape)}
     for k, v in fixed.items():
         rec[f"fixed::{k}"] = v.numpy()

@@ -18,7 +18,38 @@ from oracle import gated_ref, refboot  # noqa: E402
 refboot.boot()
 from make_golden_moa import seeded_fill  # noqa: E402
 
+from ultralytics.nn.modules.moe import gated as ref_gated  # noqa: E402
 from ultralytics.nn.modules.moe.gated import GatedFusionMoE, OptimalHybridGateMoE, VisualEnhancedAdaptiveGateMoE  # noqa: E402
+
+
+def case_chain(name, cls_name, C, x, seed, tweak=None, **kw):
+    """Earlier members of the AdaptiveGateMoE chain (v0_4 ... v0_9, v0_11) -> gated3_<name>.npz (python make_golden_gated.py chain)."""
+    cls = getattr(ref_gated, cls_name)
+    m = cls(C, C, **kw)
+    sd = seeded_fill(m, seed)
+    if tweak:
+        tweak(sd)
+        m.load_state_dict(sd)
+    m.eval()
+    plain = cls_name in ("AdaptiveGateMoE", "FusedAdaptiveGateMoE")      # their forward: no channel shuffle, complexity before the hooks
+    okw = dict(num_experts=kw.get("num_experts", 4), top_k=kw.get("top_k", 2), split_ratio=kw.get("split_ratio", 0.5),
+               temperature=float(m.routing.temperature), shuffle_groups=1 if plain else 2, complexity_after_hooks=not plain,
+               hooks=list(kw["router_hooks"]) if kw.get("router_hooks") else None)
+    info = {}
+    with torch.inference_mode():
+        y = m(x)
+        oy = gated_ref.adaptive_gate_chain({f"m.{k}": v for k, v in sd.items()}, "m", x, info=info, **okw)
+    exact = torch.equal(y, oy)
+    r = info["m"]
+    print(f"[gated3_{name}] {cls_name} x {tuple(x.shape)} backend {getattr(m, 'expert_backend', 'shared_inverted')} hooks {m.router_hook_names}; "
+          f"oracle bit-exact vs reference: {exact}; max|dy| {(y - oy).abs().max().item():.3e}; |y| max {y.abs().max().item():.3f}; "
+          f"complexity {float(r['complexity']):.3f}; experts {r['indices'].view(x.shape[0], -1).tolist()}")
+    assert exact
+    rec = {"x": x.numpy(), "y": y.numpy(), "keys": np.array(list(sd.keys())), "weights": r["weights"].numpy(),
+           "indices": r["indices"].numpy(), "complexity": np.float32(r["complexity"]), "cls": np.array(cls_name),
+           "kw": np.array(repr(kw)), "okw": np.array(repr(okw))}
+    rec.update({f"sd::{k}": v.numpy() for k, v in sd.items()})
+    np.savez_compressed(HERE / f"gated3_{name}.npz", **rec)
 
 
 def case_v2(name, cls, C, x, seed, tweak=None, **kw):
@@ -93,6 +124,27 @@ if __name__ == "__main__":
         sd["refine_scale"] = torch.tensor(0.6)
         sd["routing.expert_prior"] = torch.randn(sd["routing.expert_prior"].shape, generator=torch.Generator().manual_seed(3)) * 0.5
 
+    if len(sys.argv) > 1 and sys.argv[1] == "chain":
+        def live(sd):          # both routed experts kept; hook scales away from their near-identity initial values
+            high_complexity(sd)
+            for k in ("refine_scale", "detail_gate.detail_scale", "context_mixer.context_scale"):
+                if k in sd:
+                    sd[k] = torch.tensor(0.7)
+            if "routing.expert_prior" in sd:
+                sd["routing.expert_prior"] = torch.randn(sd["routing.expert_prior"].shape, generator=torch.Generator().manual_seed(5)) * 0.5
+
+        case_chain("agm", "AdaptiveGateMoE", 64, varied(3, 64, 12, 16), 21, tweak=live)
+        case_chain("agm_hooks", "AdaptiveGateMoE", 64, varied(3, 64, 10, 10), 22, tweak=live, router_hooks=["refine", "detail"])
+        case_chain("agm_keep1", "AdaptiveGateMoE", 64, varied(2, 64, 6, 5), 23, tweak=low_complexity, num_experts=8)
+        case_chain("fused", "FusedAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 24, tweak=live)
+        case_chain("hyb", "HybridAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 25, tweak=live)
+        case_chain("hyb_e16", "HybridAdaptiveGateMoE", 64, varied(3, 64, 8, 8), 26, tweak=live, num_experts=16, top_k=2)
+        case_chain("hyb2", "HybridAdaptiveGateMoEv2", 64, varied(3, 64, 12, 16), 27, tweak=live, split_ratio=0.375)
+        case_chain("lowrank", "LowRankHybridAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 28, tweak=live)
+        case_chain("refined", "RefinedLowRankHybridAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 29, tweak=live)
+        case_chain("detail", "DetailAwareLowRankHybridAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 30, tweak=live)
+        case_chain("ctxref", "ContextRefinedLowRankHybridAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 31, tweak=live)
+        sys.exit(0)
     case_v2("opt_base", OptimalHybridGateMoE, 128, varied(3, 128, 12, 16), 11, tweak=live_gates)
     case_v2("opt_e16", OptimalHybridGateMoE, 128, varied(3, 128, 8, 8), 12, tweak=live_gates, num_experts=16, top_k=2, split_ratio=0.375)
     case_v2("fus_base", GatedFusionMoE, 128, varied(4, 128, 12, 16), 13, tweak=live_gates)

@@ -239,7 +239,7 @@ def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
         assert np.array_equal(m.last_route["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
 
 
-@pytest.mark.parametrize("tag", ["cfg5", "v15"])
+@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06"])
 def test_config5_model_vs_reference_golden(tag, golden_dir):
     import json
     import warnings
@@ -256,7 +256,7 @@ def test_config5_model_vs_reference_golden(tag, golden_dir):
     sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = DetectionModel(MODEL_FIXTURES[tag])
+        m = DetectionModel(MODEL_FIXTURES[tag] or cfg)
     m.load_state_dict(sd)
     m.eval().to(DEV)
     taps = {}
@@ -271,6 +271,15 @@ def test_config5_model_vs_reference_golden(tag, golden_dir):
         ref = z[f"layer{i}_val"]
         err = float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max())))
         assert err <= 1e-3, f"layer {i} ({(cfg['backbone'] + cfg['head'])[i][2]}): scaled max error {err:.3e}"
+
+
+@pytest.mark.parametrize("name", __import__("tests.test_host_mixture", fromlist=["GATED3_CASES"]).GATED3_CASES)
+def test_gated_chain_vs_reference_golden(name, golden_dir):
+    """AdaptiveGateMoE (v0_4) ... ContextRefinedLowRankHybridAdaptiveGateMoE, HybridAdaptiveGateMoEv2 (v0_11) (moe/gated.py:268-1700)
+    on the GPU, fp32, against the real reference."""
+    from tests.test_host_mixture import run_gated3_case
+
+    run_gated3_case(name, golden_dir, dev=DEV, dtype=torch.float32, rtol=2e-4)
 
 
 @pytest.mark.parametrize("name", __import__("tests.test_host_mixture", fromlist=["GATED2_CASES"]).GATED2_CASES)

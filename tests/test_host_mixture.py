@@ -174,14 +174,54 @@ def test_gated_v12_v15_host_vs_reference(name, golden_dir, emu):
     assert emu.CALLS["layer_norm"] == 1
 
 
-MODEL_FIXTURES = {"cfg5": "yolo-master-moa-mot-n.yaml", "v15": "yolo-master-v15-n.yaml"}
+GATED3_CASES = ["agm", "agm_hooks", "agm_keep1", "fused", "hyb", "hyb_e16", "hyb2", "lowrank", "refined", "detail", "ctxref"]
+
+
+def run_gated3_case(name, golden_dir, dev="cpu", dtype=torch.float32, rtol=5e-5):
+    """The earlier generations of the gated family (AdaptiveGateMoE v0_4 ... ContextRefined, HybridAdaptiveGateMoEv2 v0_11;
+    moe/gated.py:268-1700) against the real reference's vectors; shared with the GPU test."""
+    from yolo_master_amd.nn import mixture
+
+    z, sd = _load(golden_dir, "gated3", name)
+    cls = getattr(mixture, str(z["cls"]))
+    kw = eval(str(z["kw"]), {"__builtins__": {}}, {"dict": dict})
+    m = _prep(cls(64, 64, **kw), sd)
+    assert list(m.state_dict().keys()) == z["keys"].tolist(), "state_dict keys / order differ from the reference's"
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    if dev != "cpu":
+        from yolo_master_amd.nn.modules import set_compute_dtype
+
+        m = m.to(dev)
+        set_compute_dtype(m, dtype)
+    with torch.inference_mode():
+        got = m(x.to(dev))
+    B = x.shape[0]
+    r = m.last_route
+    assert np.array_equal(r["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
+    assert float(np.abs(r["weights"].reshape(B, -1).cpu().numpy() - z["weights"].reshape(B, -1)).max()) <= 1e-5
+    _close(got.float().cpu(), y, f"gated3_{name}", rtol=rtol)
+    return m
+
+
+@pytest.mark.parametrize("name", GATED3_CASES)
+def test_gated_chain_host_vs_reference(name, golden_dir, emu):
+    m = run_gated3_case(name, golden_dir)
+    assert emu.CALLS["expert_conv"] == 1 and emu.CALLS["gated_route_decide"] == 1 and emu.CALLS["channel_shuffle_cat"] == 1
+    assert emu.CALLS.get("layer_norm", 0) == (1 if name == "hyb2" else 0)
+    assert m.expert_backend == {"agm": "shared_inverted", "agm_hooks": "shared_inverted", "agm_keep1": "shared_inverted", "fused": "fused",
+                                "hyb": "fused", "hyb_e16": "shared_inverted", "hyb2": "fused"}.get(name, "low_rank_fused")
+
+
+MODEL_FIXTURES = {"cfg5": "yolo-master-moa-mot-n.yaml", "v15": "yolo-master-v15-n.yaml",
+                  "v04": None, "v06": None}    # None: the reference YAML's dict as stored in the fixture (generations v0_4 / v0_6, n scale)
 
 
 @pytest.mark.parametrize("tag", list(MODEL_FIXTURES))
 def test_config5_model_host_vs_reference(tag, golden_dir, emu):
     """Whole detectors of the gated-MoE generations through the product's graph walk, against the real reference model's
     per-layer samples and routing decisions: config 5 (v0_10 moa-mot YAML: VisualEnhancedAdaptiveGateMoE backbone, C2fMoT /
-    C2fMoA neck) and the v0_15 YAML (GatedFusionMoE backbone on the v0 neck / head)."""
+    C2fMoA neck), the v0_15 YAML (GatedFusionMoE backbone on the v0 neck / head) and the v0_4 / v0_6 YAMLs (AdaptiveGateMoE /
+    HybridAdaptiveGateMoE with 4, 8 and 16 experts: shared-inverted and fused backends)."""
     import json
 
     from tests.helpers import fill_by_name
@@ -192,7 +232,7 @@ def test_config5_model_host_vs_reference(tag, golden_dir, emu):
     cfg = json.loads(str(z["cfg"]))
     sd = fill_by_name(json.loads(str(z["spec"])), seed=5, gain=1.0)
     sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
-    m = DetectionModel(MODEL_FIXTURES[tag])
+    m = DetectionModel(MODEL_FIXTURES[tag] or cfg)
     m.load_state_dict(sd)
     m.eval()
     taps = {}

@@ -69,3 +69,19 @@ def test_v12_v15_restatement_matches_reference(name, golden_dir):
                                          **{k: v for k, v in kw.items() if k in ("num_experts", "top_k", "split_ratio")})
     assert np.array_equal(info["m"]["indices"].numpy(), z["indices"])
     np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["agm", "agm_hooks", "agm_keep1", "fused", "hyb", "hyb_e16", "hyb2", "lowrank", "refined", "detail", "ctxref"])
+def test_chain_restatement_matches_reference(name, golden_dir):
+    """oracle adaptive_gate_chain (AdaptiveGateMoE v0_4 ... ContextRefined, HybridAdaptiveGateMoEv2 v0_11) against the real
+    reference's vectors (tests/golden/make_golden_gated.py chain)."""
+    import numpy as np
+
+    z = np.load(golden_dir / f"gated3_{name}.npz")
+    sd = {f"m.{k}": torch.from_numpy(z[f"sd::{k}"]) for k in z["keys"].tolist()}
+    okw = eval(str(z["okw"]), {"__builtins__": {}}, {"dict": dict})
+    info = {}
+    with torch.inference_mode():
+        y = gated_ref.adaptive_gate_chain(sd, "m", torch.from_numpy(z["x"]), info=info, **okw)
+    assert np.array_equal(info["m"]["indices"].numpy(), z["indices"])
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-5, atol=1e-5)

@@ -116,7 +116,7 @@ def call_times(scale="s", B=64, dtype=torch.bfloat16, reps=3):
         print(f"{i:3d} {fam[:58]:58s} {shp:34s} {ms * 1e3:8.1f} us {nb / ms / 1e6:8.0f} GB/s {fl / ms / 1e9:8.1f} TF/s")
 
 
-def glds_ab(B=64, reps=20):
+def glds_ab(B=64, reps=20, extra=False):
     """Per-shape A/B of the opt-in tiled core (include/ymk_next.h) against what ymk_conv2d dispatches today, on the dense
     convolutions of YOLO-Master-S at batch B (bf16, SiLU): median of `reps` event-timed launches each; results compared."""
     import ctypes as C
@@ -128,6 +128,9 @@ def glds_ab(B=64, reps=20):
         (128, 128, 3, 2, 160), (256, 256, 3, 2, 80), (128, 64, 3, 1, 80), (256, 512, 3, 2, 40), (256, 64, 3, 1, 40), (128, 128, 3, 2, 80),
         (256, 256, 3, 2, 40), (384, 256, 1, 1, 40), (256, 128, 1, 1, 40), (512, 128, 1, 1, 80), (768, 256, 1, 1, 40), (64, 64, 1, 1, 160),
         (128, 128, 3, 1, 40), (256, 64, 3, 1, 20)]
+    if extra:   # the shapes the spatial-tile 3x3 kernel and the 128x128 tiled 1x1 kernel serve today
+        shapes = [(64, 64, 3, 1, 80), (64, 64, 3, 1, 40), (64, 64, 3, 1, 20), (256, 768, 1, 1, 20), (768, 512, 1, 1, 20), (512, 256, 1, 1, 20),
+                  (256, 256, 1, 1, 20), (384, 256, 1, 1, 20), (256, 128, 1, 1, 20), (128, 128, 1, 1, 20), (128, 64, 1, 1, 40), (64, 64, 1, 1, 80)]
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
     st = torch.cuda.current_stream().cuda_stream
 
@@ -171,6 +174,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "glds":
         glds_ab()
+    if what == "glds2":
+        glds_ab(extra=True)
         sys.exit(0)
     if what in ("all", "err"):
         errors()

@@ -593,7 +593,11 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
         const bool done = d->dtype == YMK_F32 ? launch_conv1x1_ws<float>(a, s) : launch_conv1x1_ws<bf16_t>(a, s);
         if (done) { ymk_last_variant = YMK_CONV_STREAM_1X1; return ymk_launch_status(); }
     }
-    if (d->ksize == 3 && ymk_use_ws && !(ymk_disabled() & YMK_OFF_CONV_STREAM)) {  // small-Cin stride-1 3x3: spatial-tile kernel (LDS-staged im2col)
+    // 64 -> 64 3x3 on the small maps (C3k bottlenecks at 40x40 / 20x20): the LDS-DMA tiled core is 0-22 % faster than the
+    // spatial-tile kernel up to ~100k output pixels (gpu_diag.py glds2: 29.6 -> 23.1 us at 64 x 40 x 40), slower above
+    const bool small64 = d->dtype == YMK_BF16 && d->Cin == 64 && d->Cout == 64 && d->stride == 1 && a.M <= 102400 &&
+                         !(ymk_disabled() & YMK_OFF_CONV_GLDS3);
+    if (d->ksize == 3 && ymk_use_ws && !small64 && !(ymk_disabled() & YMK_OFF_CONV_STREAM)) {  // small-Cin stride-1 3x3: spatial-tile kernel (LDS-staged im2col)
         const bool done = d->dtype == YMK_F32 ? launch_conv3x3_tile<float>(a, s) : launch_conv3x3_tile<bf16_t>(a, s);
         if (done) { ymk_last_variant = YMK_CONV_SPATIAL_3X3; return ymk_launch_status(); }
     }

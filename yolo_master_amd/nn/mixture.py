@@ -198,14 +198,40 @@ class PyramidContextMixer(nn.Module):
         self.context_scale = nn.Parameter(torch.tensor(0.1))
 
 
-class VisualEnhancedAdaptiveGateMoE(YmkModule):
-    """moe/gated.py:1703-1764 (end of the AdaptiveGateMoE chain :268-1701)."""
+class AdaptiveGateMoE(YmkModule):
+    """v0_4 gated MoE and the base of the chain (moe/gated.py:268-640): SE-gated channel split, static DW+PW path, dual-stream
+    router + batch-level complexity gate, routed experts, 1x1 projection + GroupNorm + x.  The later generations only swap the
+    expert backend, add the channel shuffle and attach hooks (detail before routing; context / refine after the fusion), so they
+    are this class with other settings:
+
+        class (YAML generation)                         experts                          shuffle  hooks              forward
+        AdaptiveGateMoE (v0_4)                          shared-inverted                  no       router_hooks=...   :530-580
+        FusedAdaptiveGateMoE (v0_5)                     fused                            no       -                  (inherited)
+        HybridAdaptiveGateMoE (v0_6)                    fused (E <= 8) / shared-inv.     yes      -                  :1340-1386
+        HybridAdaptiveGateMoEv2 (v0_11)                 as v0_6, DualStreamGateRouterV2  yes      -                  (inherited)
+        LowRankHybridAdaptiveGateMoE (v0_7)             low-rank fused / shared-inv.     yes      -                  (inherited)
+        RefinedLowRankHybridAdaptiveGateMoE (v0_8)      "                                yes      refine             _gated_visual.py:32-75
+        DetailAwareLowRankHybridAdaptiveGateMoE (v0_9)  "                                yes      detail             "
+        ContextRefinedLowRankHybridAdaptiveGateMoE      "                                yes      context, refine    "
+        VisualEnhancedAdaptiveGateMoE (v0_10)           "                                yes      detail, context, refine  "
+
+    The complexity score reads the dynamic half before the hooks in AdaptiveGateMoE.forward (:548-552) and after the detail gate
+    in `run_visual_hybrid_moe_forward` (_gated_visual.py:47-53): `_complexity_after_hooks`."""
+
+    _backend_rule = "shared_inverted"     # "shared_inverted" | "fused" | "hybrid" | "low_rank_hybrid"
+    _shuffle = False
+    _router_v2 = False
+    _hooks = ()
+    _complexity_after_hooks = False
+    _default_temperature = 1.0
 
     def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8,
-                 initial_temperature=1.2, final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0,
-                 entropy_loss_coeff=0.01, fused_expert_threshold=8, shuffle_groups=2, bottleneck_ratio=0.5,
-                 refine_reduction=8, detail_reduction=8):
+                 initial_temperature=None, final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0,
+                 entropy_loss_coeff=0.01, router_hooks=None, detail_reduction=8, refine_reduction=8, *, fused_expert_threshold=8,
+                 shuffle_groups=2, bottleneck_ratio=0.5):
         super().__init__()
+        if initial_temperature is None:
+            initial_temperature = self._default_temperature
         self.in_channels, self.out_channels = in_channels, out_channels
         self.num_experts, self.top_k, self.num_groups = num_experts, top_k, num_groups
         self.initial_temperature, self.final_temperature = initial_temperature, final_temperature
@@ -213,7 +239,7 @@ class VisualEnhancedAdaptiveGateMoE(YmkModule):
         self.static_channels = in_channels - self.dynamic_channels
         self.out_dynamic = int(out_channels * split_ratio)
         self.out_static = out_channels - self.out_dynamic
-        self.shuffle_groups = shuffle_groups if out_channels % shuffle_groups == 0 else 1
+        self.shuffle_groups = (shuffle_groups if out_channels % shuffle_groups == 0 else 1) if self._shuffle else 1
         se_hidden = max(in_channels // 4, 4)
         self.se_gate = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(in_channels, se_hidden, bias=False),
                                      nn.SiLU(), nn.Linear(se_hidden, in_channels, bias=True), nn.Sigmoid())
@@ -221,8 +247,13 @@ class VisualEnhancedAdaptiveGateMoE(YmkModule):
         self.static_net = nn.Sequential(
             nn.Conv2d(sc, sc, 3, padding=1, groups=sc, bias=False), nn.BatchNorm2d(sc), nn.SiLU(),
             nn.Conv2d(sc, self.out_static, 1, bias=False), nn.BatchNorm2d(self.out_static), nn.SiLU())
-        self.routing = DualStreamGateRouter(self.dynamic_channels, num_experts, top_k, temperature=initial_temperature)
-        if num_experts <= fused_expert_threshold:
+        router = DualStreamGateRouterV2 if self._router_v2 else DualStreamGateRouter
+        self.routing = router(self.dynamic_channels, num_experts, top_k, temperature=initial_temperature)
+        rule, few = self._backend_rule, num_experts <= fused_expert_threshold
+        if rule == "fused" or (rule == "hybrid" and few):
+            self.expert_backend = "fused"
+            self.fused_experts = FusedExpertGroup(self.dynamic_channels, self.out_dynamic, num_experts, num_groups, top_k=top_k)
+        elif rule == "low_rank_hybrid" and few:
             self.expert_backend = "low_rank_fused"
             self.fused_experts = LowRankFusedExpertGroup(self.dynamic_channels, self.out_dynamic, num_experts, num_groups,
                                                          top_k=top_k, bottleneck_ratio=bottleneck_ratio)
@@ -232,26 +263,43 @@ class VisualEnhancedAdaptiveGateMoE(YmkModule):
         self.complexity_estimator = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(self.dynamic_channels, 1, 1), nn.Sigmoid())
         self.proj = nn.Conv2d(out_channels, out_channels, 1, bias=False)
         self.bn = _gn(out_channels, num_groups)
-        refine_hidden = max(out_channels // refine_reduction, 8)
-        self.feature_refiner = nn.Sequential(
-            nn.Conv2d(out_channels, out_channels, 3, padding=1, groups=out_channels, bias=False), _gn(out_channels, num_groups),
-            nn.SiLU())
-        self.feature_gate = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(out_channels, refine_hidden, 1, bias=False), nn.SiLU(),
-                                          nn.Conv2d(refine_hidden, out_channels, 1, bias=True), nn.Sigmoid())
-        self.refine_scale = nn.Parameter(torch.tensor(0.1))
-        self.context_mixer = PyramidContextMixer(out_channels, num_groups)
-        self.detail_gate = VisualDetailGate(self.dynamic_channels, num_groups, detail_reduction)
-        self.router_hook_names = ("detail", "context", "refine")
+        hooks = tuple(self._hooks)
+        if router_hooks is not None:      # AdaptiveGateMoE(router_hooks=[...]) (gated.py:388-438): names in application order
+            alias = {"feature_refinement": "refine"}
+            names = [router_hooks] if isinstance(router_hooks, str) else list(router_hooks)
+            hooks = tuple(alias.get(str(h).strip().lower(), str(h).strip().lower()) for h in names)
+            if len(set(hooks)) != len(hooks) or any(h not in ("detail", "context", "refine") for h in hooks):
+                raise KeyError(f"unknown or repeated router hook in {names}; available=['context', 'detail', 'feature_refinement', 'refine']")
+        # learnable hook modules, in the reference's registration order of each class (state_dict key order)
+        for h in self._hook_registration_order(hooks):
+            if h == "refine":
+                refine_hidden = max(out_channels // refine_reduction, 8)
+                self.feature_refiner = nn.Sequential(
+                    nn.Conv2d(out_channels, out_channels, 3, padding=1, groups=out_channels, bias=False), _gn(out_channels, num_groups),
+                    nn.SiLU())
+                self.feature_gate = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(out_channels, refine_hidden, 1, bias=False), nn.SiLU(),
+                                                  nn.Conv2d(refine_hidden, out_channels, 1, bias=True), nn.Sigmoid())
+                self.refine_scale = nn.Parameter(torch.tensor(0.1))
+            elif h == "context":
+                self.context_mixer = PyramidContextMixer(out_channels, num_groups)
+            elif h == "detail":
+                self.detail_gate = VisualDetailGate(self.dynamic_channels, num_groups, detail_reduction)
+        self.router_hook_names = hooks
+
+    def _hook_registration_order(self, hooks):
+        if self._hooks:                      # subclasses: refine (v0_8 __init__) before context before detail (gated.py:1545-1560, 1693, 1751)
+            return [h for h in ("refine", "context", "detail") if h in hooks]
+        return [h for h in ("detail", "context", "refine") if h in hooks]    # configure_router_hooks (gated.py:415-435)
 
     # -- packing ---------------------------------------------------------------------------------------------------
     def _pack(self, dtype, device):
         import math
 
         f32 = torch.float32
-        dyn, ng = self.dynamic_channels, self.num_groups
-        se, rt, dg, cm = self.se_gate, self.routing, self.detail_gate, self.context_mixer
-        if dyn % 8 or self.static_channels % 8:
-            raise NotImplementedError(f"ymk VisualEnhancedAdaptiveGateMoE: split {self.static_channels}+{dyn} breaks the 16-byte channel-vector rule")
+        dyn = self.dynamic_channels
+        se, rt = self.se_gate, self.routing
+        if dyn % 8 or self.static_channels % 8 or self.out_dynamic % 8 or self.out_static % 8:
+            raise NotImplementedError(f"ymk {type(self).__name__}: split {self.static_channels}+{dyn} breaks the 16-byte channel-vector rule")
         E4, red = _ceil(self.num_experts, 4), rt.local_conv[3].out_channels
         rp = _ceil(red, 4)
         sn = self.static_net
@@ -259,76 +307,99 @@ class VisualEnhancedAdaptiveGateMoE(YmkModule):
                                  sn[1].running_mean.float().to(device), sn[1].running_var.float().to(device), sn[1].eps)
         pw_w, pw_b = ops.fold_bn(sn[3].weight.detach().float().to(device), sn[4].weight.float().to(device), sn[4].bias.float().to(device),
                                  sn[4].running_mean.float().to(device), sn[4].running_var.float().to(device), sn[4].eps)
-        hp = torch.full((9, dyn), -1.0 / 9.0, device=device)      # x - avg_pool3x3(x) (zero padded, count_include_pad) as one stencil
-        hp[4] += 1.0
+        gw, gb = _pack_conv(rt.global_fc, f32, device, pad_cout_to=E4)
         pk = {
             "se0": _pack_conv(se[2], f32, device), "se1": _pack_conv(se[4], f32, device),
-            "hp": hp.to(dtype).contiguous(),
-            "dg0": _pack_dw(dg.detail_filter[0], dtype, device), "dg1": _pack_norm(dg.detail_filter[1], device),
-            "dg3": _pack_conv(dg.detail_filter[3], dtype, device), "dg5": _pack_conv(dg.detail_filter[5], dtype, device),
-            "dg_s": math.tanh(float(dg.detail_scale)),
             "st_dw": (ops.pack_dw_weight(dw_w, dtype), dw_b.contiguous()), "st_pw": (ops.pack_conv_weight(pw_w, dtype), pw_b.contiguous()),
             "cplx": _pack_conv(self.complexity_estimator[1], f32, device, pad_cout_to=4),
-            "gfc": _pack_conv(rt.global_fc, f32, device, pad_cout_to=E4),
             "lc0": _pack_dw(rt.local_conv[0], f32, device), "lc1": _pack_norm(rt.local_conv[1], device),
             "lc3": _pack_conv(rt.local_conv[3], f32, device, pad_cout_to=rp), "lc4": _pack_norm(rt.local_conv[4], device),
             "lc_red": red, "lc_rp": rp,
             "lc6": _pack_conv(rt.local_conv[6], f32, device, pad_cout_to=E4, pad_cin_to=rp), "alpha": float(rt.alpha), "inv_temp": 1.0 / rt.temperature,
-            "cm0": _pack_dw(cm.local_context[0], dtype, device), "cm1": _pack_norm(cm.local_context[1], device),
-            "cmp": [(_pack_conv(p[0], dtype, device), _pack_norm(p[1], device)) for p in cm.pool_projections],
-            "cmg": _pack_conv(cm.context_gate[0], dtype, device), "cm_s": math.tanh(float(cm.context_scale)),
-            "fr0": _pack_dw(self.feature_refiner[0], dtype, device), "fr1": _pack_norm(self.feature_refiner[1], device),
-            "fg1": _pack_conv(self.feature_gate[1], f32, device), "fg3": _pack_conv(self.feature_gate[3], f32, device),
-            "rf_s": math.tanh(float(self.refine_scale)),
             "proj": _pack_conv(self.proj, dtype, device), "bn": _pack_norm(self.bn, device),
         }
+        if self._router_v2:
+            # expert_prior is added to the blended logits alpha * g + (1 - alpha) * l (gated.py:217-262): folded into the global
+            # stream's bias as prior / alpha
+            gb = gb.clone()
+            gb[: self.num_experts] = rt.expert_prior.detach().float().to(device) / float(torch.sigmoid(rt.alpha.detach().float()))
+            pk["sn"] = _pack_norm(rt.stat_norm, device)
+        pk["gfc"] = (gw, gb.contiguous())
+        if "detail" in self.router_hook_names:
+            dg = self.detail_gate
+            hp = torch.full((9, dyn), -1.0 / 9.0, device=device)      # x - avg_pool3x3(x) (zero padded, count_include_pad) as one stencil
+            hp[4] += 1.0
+            pk.update({"hp": hp.to(dtype).contiguous(),
+                       "dg0": _pack_dw(dg.detail_filter[0], dtype, device), "dg1": _pack_norm(dg.detail_filter[1], device),
+                       "dg3": _pack_conv(dg.detail_filter[3], dtype, device), "dg5": _pack_conv(dg.detail_filter[5], dtype, device),
+                       "dg_s": math.tanh(float(dg.detail_scale))})
+        if "context" in self.router_hook_names:
+            cm = self.context_mixer
+            pk.update({"cm0": _pack_dw(cm.local_context[0], dtype, device), "cm1": _pack_norm(cm.local_context[1], device),
+                       "cmp": [(_pack_conv(q[0], dtype, device), _pack_norm(q[1], device)) for q in cm.pool_projections],
+                       "cmg": _pack_conv(cm.context_gate[0], dtype, device), "cm_s": math.tanh(float(cm.context_scale))})
+        if "refine" in self.router_hook_names:
+            pk.update({"fr0": _pack_dw(self.feature_refiner[0], dtype, device), "fr1": _pack_norm(self.feature_refiner[1], device),
+                       "fg1": _pack_conv(self.feature_gate[1], f32, device), "fg3": _pack_conv(self.feature_gate[3], f32, device),
+                       "rf_s": math.tanh(float(self.refine_scale))})
         fe = self.fused_experts
         E, OC = self.num_experts, self.out_dynamic
-        if self.expert_backend == "low_rank_fused":
-            pk["bt0"] = _pack_conv(fe.bottleneck[0], dtype, device)
-            pk["bt1"] = _pack_norm(fe.bottleneck[1], device)
-            fc = fe.fused.fused_conv
-            w = fc.weight.detach().float().to(device)                       # [E*OC, bc/g, 3, 3], grouped
-            bc, g = fc.in_channels, fc.groups
-            cg, og = bc // g, (E * OC) // g
-            dense = w.new_zeros((E * OC, bc, 3, 3))
+        if self.expert_backend in ("low_rank_fused", "fused"):
+            if self.expert_backend == "low_rank_fused":
+                pk["bt0"] = _pack_conv(fe.bottleneck[0], dtype, device)
+                pk["bt1"] = _pack_norm(fe.bottleneck[1], device)
+                fe = fe.fused
+            fc = fe.fused_conv
+            w = fc.weight.detach().float().to(device)                       # [E*OC, cin/g, 3, 3], grouped
+            cin, g = fc.in_channels, fc.groups
+            cg, og = cin // g, (E * OC) // g
+            dense = w.new_zeros((E * OC, cin, 3, 3))
             for grp in range(g):                                             # expand the grouped filter bank to dense rows:
                 dense[grp * og:(grp + 1) * og, grp * cg:(grp + 1) * cg] = w[grp * og:(grp + 1) * og]   # only the routed experts' rows run
             pk["ew"] = ops.pack_conv_weight(dense, dtype).reshape(E, OC, -1).contiguous()
-            pk["en"] = (fe.fused.expert_norm_weight.detach().float().to(device).contiguous(),
-                        fe.fused.expert_norm_bias.detach().float().to(device).contiguous())
+            pk["en"] = (fe.expert_norm_weight.detach().float().to(device).contiguous(),
+                        fe.expert_norm_bias.detach().float().to(device).contiguous())
         else:
             sf = fe.shared_feature
             pk["sf0"], pk["sf1"] = _pack_conv(sf[0], dtype, device), _pack_norm(sf[1], device)
             pk["sf3"], pk["sf4"], pk["sf_k"] = _pack_dw(sf[3], dtype, device), _pack_norm(sf[4], device), sf[3].kernel_size[0]
-            pk["ew"] = torch.stack([_pack_conv(p[0], dtype, device)[0] for p in fe.expert_projections]).contiguous()
-            pk["en"] = (torch.stack([p[1].weight.detach().float() for p in fe.expert_projections]).to(device).contiguous(),
-                        torch.stack([p[1].bias.detach().float() for p in fe.expert_projections]).to(device).contiguous())
+            pk["ew"] = torch.stack([_pack_conv(q[0], dtype, device)[0] for q in fe.expert_projections]).contiguous()
+            pk["en"] = (torch.stack([q[1].weight.detach().float() for q in fe.expert_projections]).to(device).contiguous(),
+                        torch.stack([q[1].bias.detach().float() for q in fe.expert_projections]).to(device).contiguous())
         return pk
 
     # -- execution -------------------------------------------------------------------------------------------------
     def _run(self, x, out=None):
-        """run_visual_hybrid_moe_forward, eval (moe/_gated_visual.py:32-75; pieces: moe/gated.py:124-166 router, :333-353
-        SE gate + static path, :455-492 complexity gate, :1058-1146 fused experts, :1171-1218 detail gate / context mixer,
-        hooks.py:60-68 refinement; moe/experts.py:235-269 shared-inverted experts)."""
+        """AdaptiveGateMoE.forward / HybridAdaptiveGateMoE.forward / run_visual_hybrid_moe_forward, eval (moe/gated.py:530-580,
+        :1340-1386, moe/_gated_visual.py:32-75; pieces: gated.py:124-166 router, :217-262 router V2, :333-353 SE gate + static path,
+        :455-492 complexity gate, :1058-1146 fused experts, :1171-1218 detail gate / context mixer, hooks.py:60-68 refinement;
+        moe/experts.py:235-269 shared-inverted experts)."""
         B, H, W, C = x.shape
         pk = self._packed(x.device)
         st, dyn, ng, k = self.static_channels, self.dynamic_channels, self.num_groups, self.top_k
         gs = get_safe_groups
+        hooks = self.router_hook_names
         # squeeze-excite gate over all channels, then the static / dynamic split
         gate = ops.conv2d_act(ops.conv2d(ops.channel_stats(x), *pk["se0"], 1, 1, True), *pk["se1"], 1, 1, "sigmoid")
         xg = ops.channel_gate(x, gate)
         xs, xd = xg[..., :st], xg[..., st:]
-        # detail gate on the dynamic half (pre-route hook)
-        h = ops.dwconv2d(ops.dwconv2d(xd, pk["hp"], None, 3, False), pk["dg0"], None, 3, False)
-        h = ops.conv2d(ops.group_norm(h, gs(dyn, ng), *pk["dg1"], 1e-5, act="silu"), *pk["dg3"], 1, 1, True)
-        xd = ops.fma_gate(xd, xd, ops.conv2d_act(h, *pk["dg5"], 1, 1, "sigmoid"), pk["dg_s"])
+        cplx = None
+        if not self._complexity_after_hooks:
+            cplx = ops.conv2d(ops.channel_stats(xd), *pk["cplx"], 1, 1, False)[..., :1]
+        if "detail" in hooks:   # detail gate on the dynamic half (pre-route hook)
+            h = ops.dwconv2d(ops.dwconv2d(xd, pk["hp"], None, 3, False), pk["dg0"], None, 3, False)
+            h = ops.conv2d(ops.group_norm(h, gs(dyn, ng), *pk["dg1"], 1e-5, act="silu"), *pk["dg3"], 1, 1, True)
+            xd = ops.fma_gate(xd, xd, ops.conv2d_act(h, *pk["dg5"], 1, 1, "sigmoid"), pk["dg_s"])
         # static path: DW3x3+BN+SiLU -> 1x1+BN+SiLU (BN folded)
         s = ops.conv2d(ops.dwconv2d(xs, *pk["st_dw"], 3, True), *pk["st_pw"], 1, 1, True)
         # routing: global statistics stream + pooled local stream, decision tail with the batch-level complexity gate
-        cplx = ops.conv2d(ops.channel_stats(xd), *pk["cplx"], 1, 1, False)[..., :1]
+        if cplx is None:
+            cplx = ops.conv2d(ops.channel_stats(xd), *pk["cplx"], 1, 1, False)[..., :1]
         E = self.num_experts
-        g_logits = ops.conv2d(ops.channel_stats(xd, want_std=True), *pk["gfc"], 1, 1, False)[..., :E]
+        stats = ops.channel_stats(xd, want_std=True)
+        if self._router_v2:
+            stats = ops.layer_norm(stats, *pk["sn"], 1e-5)
+        g_logits = ops.conv2d(stats, *pk["gfc"], 1, 1, False)[..., :E]
         ps = self.routing.pool_scale
         xl = ops.avg_pool(xd, ps if (H > ps and W > ps) else 1, out_dtype=torch.float32)
         h = ops.group_norm(ops.dwconv2d(xl, pk["lc0"], None, 3, False), gs(dyn, 8), *pk["lc1"], 1e-5, act="silu")
@@ -341,8 +412,10 @@ class VisualEnhancedAdaptiveGateMoE(YmkModule):
         self.last_route = {"weights": w, "indices": idx, "probs": probs}   # rows: expert of image j*B + b in the slot-major expert batch
         # routed experts: only the selected experts' filter rows run
         OC = self.out_dynamic
-        if self.expert_backend == "low_rank_fused":
-            hb = ops.group_norm(ops.conv2d(xd, *pk["bt0"], 1, 1, False), gs(pk["bt0"][0].shape[0], ng), *pk["bt1"], 1e-5, act="silu")
+        if self.expert_backend in ("low_rank_fused", "fused"):
+            hb = xd
+            if self.expert_backend == "low_rank_fused":
+                hb = ops.group_norm(ops.conv2d(xd, *pk["bt0"], 1, 1, False), gs(pk["bt0"][0].shape[0], ng), *pk["bt1"], 1e-5, act="silu")
             f = ops.expert_conv(hb, pk["ew"], 3, idx)
             f = ops.group_norm(f, gs(OC, ng), *pk["en"], 1e-5, act="silu", affine_rows=rows)
         else:
@@ -352,19 +425,116 @@ class VisualEnhancedAdaptiveGateMoE(YmkModule):
         d = ops.weighted_sum(w, [f[j * B:(j + 1) * B] for j in range(k)])
         cat = ops.channel_shuffle_cat([s, d], self.shuffle_groups)
         oc = cat.shape[-1]
-        # pyramid context mixer (post-fusion hook 1)
-        ctx = [ops.group_norm(ops.dwconv2d(cat, pk["cm0"], None, 3, False), gs(oc, ng), *pk["cm1"], 1e-5, act="silu")]
-        for (pw, pn), sc in zip(pk["cmp"], self.context_mixer.pool_scales):
-            hh, ww = max(1, H // sc), max(1, W // sc)
-            pooled = cat if (hh, ww) == (H, W) else ops.adaptive_avg_pool(cat, hh, ww)
-            ctx.append(ops.group_norm(ops.conv2d(pooled, *pw, 1, 1, False), gs(oc, ng), *pn, 1e-5, act="silu"))
-        c = ops.mean_upsampled(ctx)
-        cat = ops.fma_gate(cat, c, ops.conv2d_act(c, *pk["cmg"], 1, 1, "sigmoid"), pk["cm_s"])
-        # feature refinement (post-fusion hook 2)
-        r = ops.group_norm(ops.dwconv2d(cat, pk["fr0"], None, 3, False), gs(oc, ng), *pk["fr1"], 1e-5, act="silu")
-        g = ops.conv2d_act(ops.conv2d(ops.channel_stats(cat), *pk["fg1"], 1, 1, True), *pk["fg3"], 1, 1, "sigmoid")
-        cat = ops.fma_gate(cat, r, g, pk["rf_s"])
+        for hook in hooks:      # post-fusion hooks in declaration order
+            if hook == "context":   # pyramid context mixer
+                ctx = [ops.group_norm(ops.dwconv2d(cat, pk["cm0"], None, 3, False), gs(oc, ng), *pk["cm1"], 1e-5, act="silu")]
+                for (pw, pn), sc in zip(pk["cmp"], self.context_mixer.pool_scales):
+                    hh, ww = max(1, H // sc), max(1, W // sc)
+                    pooled = cat if (hh, ww) == (H, W) else ops.adaptive_avg_pool(cat, hh, ww)
+                    ctx.append(ops.group_norm(ops.conv2d(pooled, *pw, 1, 1, False), gs(oc, ng), *pn, 1e-5, act="silu"))
+                c = ops.mean_upsampled(ctx)
+                cat = ops.fma_gate(cat, c, ops.conv2d_act(c, *pk["cmg"], 1, 1, "sigmoid"), pk["cm_s"])
+            elif hook == "refine":  # feature refinement
+                r = ops.group_norm(ops.dwconv2d(cat, pk["fr0"], None, 3, False), gs(oc, ng), *pk["fr1"], 1e-5, act="silu")
+                g = ops.conv2d_act(ops.conv2d(ops.channel_stats(cat), *pk["fg1"], 1, 1, True), *pk["fg3"], 1, 1, "sigmoid")
+                cat = ops.fma_gate(cat, r, g, pk["rf_s"])
         return ops.group_norm(ops.conv2d(cat, *pk["proj"], 1, 1, False), gs(oc, ng), *pk["bn"], 1e-5, residual=x, out=out)
+
+
+class FusedAdaptiveGateMoE(AdaptiveGateMoE):
+    """v0_5 (moe/gated.py:1232-1274): every expert in one grouped 3x3 filter bank (FusedExpertGroup), otherwise v0_4."""
+
+    _backend_rule = "fused"
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.0,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff)
+
+
+class HybridAdaptiveGateMoE(AdaptiveGateMoE):
+    """v0_6 (moe/gated.py:1277-1386): fused experts up to `fused_expert_threshold`, shared-inverted above; channel shuffle of the
+    concatenated paths before the projection."""
+
+    _backend_rule = "hybrid"
+    _shuffle = True
+    _default_temperature = 1.2
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, **later):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold=fused_expert_threshold,
+                         shuffle_groups=shuffle_groups, **later)
+        self.fused_expert_threshold = fused_expert_threshold
+
+
+class HybridAdaptiveGateMoEv2(HybridAdaptiveGateMoE):
+    """v0_11 (moe/gated.py:1389-1452): v0_6 with DualStreamGateRouterV2 (LayerNorm on the statistics, learnable expert prior)."""
+
+    _router_v2 = True
+
+
+class LowRankHybridAdaptiveGateMoE(HybridAdaptiveGateMoE):
+    """v0_7 (moe/gated.py:1455-1508): the fused backend behind a shared 1x1 bottleneck (LowRankFusedExpertGroup)."""
+
+    _backend_rule = "low_rank_hybrid"
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, bottleneck_ratio=0.5, **later):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold, shuffle_groups,
+                         bottleneck_ratio=bottleneck_ratio, **later)
+        self.bottleneck_ratio = bottleneck_ratio
+
+
+class RefinedLowRankHybridAdaptiveGateMoE(LowRankHybridAdaptiveGateMoE):
+    """v0_8 (moe/gated.py:1511-1585): + gated residual depthwise refinement after the fusion."""
+
+    _hooks = ("refine",)
+    _complexity_after_hooks = True
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, bottleneck_ratio=0.5, refine_reduction=8, **later):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold, shuffle_groups,
+                         bottleneck_ratio, refine_reduction=refine_reduction, **later)
+
+
+class DetailAwareLowRankHybridAdaptiveGateMoE(LowRankHybridAdaptiveGateMoE):
+    """v0_9 (moe/gated.py:1588-1642): + high-frequency detail gate on the dynamic half before routing."""
+
+    _hooks = ("detail",)
+    _complexity_after_hooks = True
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, bottleneck_ratio=0.5, detail_reduction=8):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold, shuffle_groups,
+                         bottleneck_ratio, detail_reduction=detail_reduction)
+
+
+class ContextRefinedLowRankHybridAdaptiveGateMoE(RefinedLowRankHybridAdaptiveGateMoE):
+    """moe/gated.py:1645-1700: pyramid context mixer, then the v0_8 refinement."""
+
+    _hooks = ("context", "refine")
+
+
+class VisualEnhancedAdaptiveGateMoE(ContextRefinedLowRankHybridAdaptiveGateMoE):
+    """v0_10, the end of the chain (moe/gated.py:1703-1764): detail gate before routing, context mixer and refinement after the
+    fusion — the backbone block of the shipped MoA / MoT YAMLs (BASELINE config 5)."""
+
+    _hooks = ("detail", "context", "refine")
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, bottleneck_ratio=0.5, refine_reduction=8, detail_reduction=8):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold, shuffle_groups,
+                         bottleneck_ratio, refine_reduction, detail_reduction=detail_reduction)
 
 
 class DualStreamGateRouterV2(DualStreamGateRouter):
@@ -1036,6 +1206,9 @@ class C2fMoT(YmkModule):
         return self.cv2._run(cat, out=out)
 
 
-MIXTURE_BOUNDARY_MODULES = {"VisualEnhancedAdaptiveGateMoE": VisualEnhancedAdaptiveGateMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE,
+GATED_CHAIN = (AdaptiveGateMoE, FusedAdaptiveGateMoE, HybridAdaptiveGateMoE, HybridAdaptiveGateMoEv2, LowRankHybridAdaptiveGateMoE,
+               RefinedLowRankHybridAdaptiveGateMoE, DetailAwareLowRankHybridAdaptiveGateMoE, ContextRefinedLowRankHybridAdaptiveGateMoE,
+               VisualEnhancedAdaptiveGateMoE)    # YAML generations v0_4 ... v0_11 (one class per generation)
+MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "OptimalHybridGateMoE": OptimalHybridGateMoE,
                             "GatedFusionMoE": GatedFusionMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
 MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

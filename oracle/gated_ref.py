@@ -235,6 +235,39 @@ def dual_stream_router_v2(sd, p, x, top_k, temperature, pool_scale=4):
     return tw.to(x.dtype).view(B, top_k, 1, 1), ti.view(B, top_k, 1, 1), probs
 
 
+def multi_head_router_v3(sd, p, x, top_k, temperature, pool_scale=4):
+    """MultiHeadRouterV3.forward, eval (gated.py:2108-2190): the LayerNorm-ed [mean, std] statistics feed one full-width Linear
+    (`global_proj`, weight sigmoid(global_weight)) and `num_heads` Linears over consecutive `head_dim` slices of the (zero padded or
+    truncated) statistics, mixed by normalised sigmoid(head_alpha); the blend with the local stream, the prior, the clamp, softmax
+    and top-k are DualStreamGateRouterV2's."""
+    B, C, H, W = x.shape
+    xf = x.float()
+    mean = xf.mean(dim=[2, 3])
+    std = xf.std(dim=[2, 3], unbiased=False) if H * W > 1 else torch.zeros_like(mean)
+    stats = F.layer_norm(torch.cat([mean, std], dim=1), (2 * C,), sd[f"{p}.stat_norm.weight"], sd[f"{p}.stat_norm.bias"], 1e-5)
+    nh = sd[f"{p}.head_alpha"].numel()
+    hd = sd[f"{p}.heads.0.weight"].shape[1]
+    hw = torch.sigmoid(sd[f"{p}.head_alpha"])
+    hw = hw / (hw.sum() + 1e-6)
+    gw = torch.sigmoid(sd[f"{p}.global_weight"])
+    sp = F.pad(stats, (0, hd * nh - stats.shape[1])) if stats.shape[1] < hd * nh else stats[:, : hd * nh]
+    chunks = sp.view(B, nh, hd)
+    hl = gw * F.linear(stats, sd[f"{p}.global_proj.weight"])
+    for i in range(nh):
+        hl = hl + (1 - gw) * hw[i] * F.linear(chunks[:, i, :], sd[f"{p}.heads.{i}.weight"])
+    xl = F.avg_pool2d(xf, kernel_size=pool_scale, stride=pool_scale) if (H > pool_scale and W > pool_scale) else xf
+    h = F.silu(_gn(sd, f"{p}.local_conv.1", _dw3(xl, sd[f"{p}.local_conv.0.weight"]), 8))
+    h = F.silu(_gn(sd, f"{p}.local_conv.4", F.conv2d(h, sd[f"{p}.local_conv.3.weight"]), 4))
+    loc = F.conv2d(h, sd[f"{p}.local_conv.6.weight"], sd[f"{p}.local_conv.6.bias"]).mean(dim=[2, 3])
+    a = torch.sigmoid(sd[f"{p}.alpha"])
+    logits = a * hl + (1 - a) * loc
+    logits = (logits + sd[f"{p}.expert_prior"].view(1, -1)).clamp(-30.0, 30.0)
+    probs = F.softmax(logits / max(float(temperature), 1e-3), dim=1)
+    tw, ti = torch.topk(probs, top_k, dim=1)
+    tw = tw / (tw.sum(dim=1, keepdim=True) + 1e-6)
+    return tw.to(x.dtype).view(B, top_k, 1, 1), ti.view(B, top_k, 1, 1), probs
+
+
 def plain_fused_experts(sd, p, x, weights, indices, num_experts, num_groups=8):
     """FusedExpertGroup.forward (gated.py:1058-1090) on the dynamic half directly (no bottleneck): grouped 3x3 for all experts,
     gather top-k, affine-free GroupNorm, the routed expert's affine row, SiLU, weighted sum."""
@@ -281,7 +314,8 @@ def optimal_hybrid_moe(sd, p, x, num_experts=4, top_k=2, split_ratio=0.5, num_gr
     cplx = torch.sigmoid(F.conv2d(F.adaptive_avg_pool2d(xd, 1), sd[f"{p}.complexity_estimator.1.weight"],
                                   sd[f"{p}.complexity_estimator.1.bias"])).mean()
     cplx = torch.tensor(1.0) if (torch.isnan(cplx) or torch.isinf(cplx)) else cplx.clamp(0.3, 1.5)
-    w, idx, probs = dual_stream_router_v2(sd, f"{p}.routing", xd, top_k, temperature)
+    router = multi_head_router_v3 if f"{p}.routing.heads.0.weight" in sd else dual_stream_router_v2   # MultiHeadRouterMoE (v0_13, :2430-2496)
+    w, idx, probs = router(sd, f"{p}.routing", xd, top_k, temperature)
     w = complexity_gate(w, cplx)
     if info is not None:
         info[p] = {"weights": w, "indices": idx, "probs": probs, "complexity": cplx}

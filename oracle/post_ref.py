@@ -100,3 +100,19 @@ def match_predictions(pred_classes: np.ndarray, true_classes: np.ndarray, iou: n
                 matches = matches[np.unique(matches[:, 0], return_index=True)[1]]
             correct[matches[:, 1].astype(int), i] = True
     return correct
+
+
+def batch_stats(dets_per_image, labels_per_image, iouv):
+    """DetectionValidator.update_metrics' per-image record (models/yolo/detect/val.py:176-192 + _process_batch :313-327), restated:
+    dets [n, 6] (xyxy, conf, cls), labels [L, 5] (cls, xyxy).  Returns the list of dicts handed to `metrics.update_stats`."""
+    out = []
+    for d, l in zip(dets_per_image, labels_per_image):
+        d, l = np.asarray(d, f32).reshape(-1, 6), np.asarray(l, f32).reshape(-1, 5)
+        if l.shape[0] == 0 or d.shape[0] == 0:
+            tp = np.zeros((d.shape[0], len(iouv)), bool)
+        else:
+            tp = match_predictions(d[:, 5], l[:, 0], box_iou(l[:, 1:], d[:, :4]), iouv)
+        no_pred = d.shape[0] == 0
+        out.append({"tp": tp, "target_cls": l[:, 0], "target_img": np.unique(l[:, 0]), "conf": np.zeros(0) if no_pred else d[:, 4],
+                    "pred_cls": np.zeros(0) if no_pred else d[:, 5]})
+    return out

@@ -112,7 +112,8 @@ if __name__ == "__main__":
 
     def high_complexity(sd):   # complexity -> 1.0: both routed experts kept with their softmax weights
         sd["complexity_estimator.1.bias"] = torch.tensor([20.0])
-        sd["routing.global_fc.weight"] = sd["routing.global_fc.weight"] * 4.0
+        if "routing.global_fc.weight" in sd:
+            sd["routing.global_fc.weight"] = sd["routing.global_fc.weight"] * 4.0
 
     def low_complexity(sd):    # complexity clamps to 0.3 -> round(0.6) = 1 expert kept of the top-2
         sd["complexity_estimator.1.bias"] = torch.tensor([-20.0])
@@ -144,6 +145,20 @@ if __name__ == "__main__":
         case_chain("refined", "RefinedLowRankHybridAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 29, tweak=live)
         case_chain("detail", "DetailAwareLowRankHybridAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 30, tweak=live)
         case_chain("ctxref", "ContextRefinedLowRankHybridAdaptiveGateMoE", 64, varied(3, 64, 12, 16), 31, tweak=live)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "v13":    # MultiHeadRouterMoE (v0_13) -> gated2_mh_*.npz
+        def live13(sd):
+            live_gates(sd)
+            g13 = torch.Generator().manual_seed(13)
+            sd["routing.global_proj.weight"] = sd["routing.global_proj.weight"] * 4.0
+            for k in [k for k in sd if k.startswith("routing.heads.")]:
+                sd[k] = sd[k] * 4.0
+            sd["routing.head_alpha"] = torch.randn(sd["routing.head_alpha"].shape, generator=g13)
+            sd["routing.global_weight"] = torch.tensor(0.4)
+
+        case_v2("mh_base", ref_gated.MultiHeadRouterMoE, 128, varied(3, 128, 12, 16), 41, tweak=live13)
+        case_v2("mh_e16", ref_gated.MultiHeadRouterMoE, 128, varied(3, 128, 8, 8), 42, tweak=live13, num_experts=16, top_k=2, split_ratio=0.375)
+        case_v2("mh_h3", ref_gated.MultiHeadRouterMoE, 128, varied(2, 128, 6, 7), 43, tweak=live13, num_experts=6, top_k=3, num_heads=3)
         sys.exit(0)
     case_v2("opt_base", OptimalHybridGateMoE, 128, varied(3, 128, 12, 16), 11, tweak=live_gates)
     case_v2("opt_e16", OptimalHybridGateMoE, 128, varied(3, 128, 8, 8), 12, tweak=live_gates, num_experts=16, top_k=2, split_ratio=0.375)

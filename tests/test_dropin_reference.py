@@ -95,3 +95,44 @@ def test_val_style_nms_call_goes_through_the_hook(emu, monkeypatch):
         assert len(out) == 1 and out[0].shape == want[0].shape and torch.allclose(out[0], want[0], atol=1e-5)
     finally:
         yolo_master_amd.disable(m)
+
+
+def test_validator_matching_goes_through_the_hook(hostlib, monkeypatch, golden_dir):
+    """`model.val()`'s per-image matching (DetectionValidator._process_batch, models/yolo/detect/val.py:313-327) under the hook:
+    the reference validator object, the host-compiled ymk_match_predictions underneath, equal to the reference's own result on
+    the real-reference fixture cases."""
+    import numpy as np
+
+    import yolo_master_amd
+    from tests.test_oracle_post import match_cases
+    from yolo_master_amd import dropin, ops, postprocess
+
+    monkeypatch.setattr(postprocess, "lib", hostlib)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
+    monkeypatch.setattr(ops, "device_ok", lambda t: True)
+    m = _yolo()
+    yolo_master_amd.enable(m)
+    try:
+        from ultralytics.models.yolo.detect.val import DetectionValidator
+
+        v = DetectionValidator.__new__(DetectionValidator)
+        v.iouv = torch.linspace(0.5, 0.95, 10)
+        v.niou = 10
+        n = 0
+        for c in match_cases(golden_dir):
+            if c["tied"]:
+                continue
+            d, l = torch.from_numpy(c["dets"].copy()), torch.from_numpy(c["labels"].copy())
+            preds = {"bboxes": d[:, :4], "conf": d[:, 4], "cls": d[:, 5]}
+            batch = {"bboxes": l[:, 1:], "cls": l[:, 0]}
+            got = v._process_batch(preds, batch)["tp"]
+            want = dropin._PATCHED["process_batch"](v, preds, batch)["tp"]
+            assert got.dtype == want.dtype == bool and got.shape == want.shape and np.array_equal(got, want)
+            n += 1
+        assert n >= 4 and dropin.stats(m)["match_calls"] >= 3
+    finally:
+        yolo_master_amd.disable(m)
+    from ultralytics.models.yolo.detect.val import DetectionValidator as V2
+
+    assert V2._process_batch.__module__ == "ultralytics.models.yolo.detect.val", "disable() must restore the validator"

@@ -139,7 +139,7 @@ def test_gated_moe_host_vs_reference(name, golden_dir, emu):
     assert emu.CALLS["expert_conv"] == 1 and emu.CALLS["gated_route_decide"] == 1 and emu.CALLS["channel_shuffle_cat"] == 1
 
 
-GATED2_CASES = ["opt_base", "opt_e16", "fus_base", "fus_small", "fus_e16", "fus_keep1"]
+GATED2_CASES = ["opt_base", "opt_e16", "fus_base", "fus_small", "fus_e16", "fus_keep1", "mh_base", "mh_e16", "mh_h3"]   # mh: MultiHeadRouterMoE (v0_13)
 
 
 def run_gated2_case(name, golden_dir, dev="cpu", dtype=torch.float32, rtol=5e-5):

@@ -177,6 +177,17 @@ def match_kernel_checks(dev="cpu", golden_dir=None):
         n = c["dets"].shape[0]
         assert np.array_equal(got[b, :n], c["correct"]), f"image {b}: correct matrix differs from the reference"
         assert not got[b, n:].any()
+    # per-image validation records (update_metrics): batched product path vs the restatement of the reference's per-image loop
+    from oracle import post_ref
+
+    stats = postprocess.batch_stats(dets.to(dev), counts.to(dev), labels.to(dev), torch.tensor(off, dtype=torch.int32).to(dev),
+                                    torch.from_numpy(cs[0]["iouv"]).to(dev))
+    want = post_ref.batch_stats([c["dets"] for c in cs], [c["labels"] for c in cs], cs[0]["iouv"])
+    assert len(stats) == len(want) == B
+    for b, (g, w) in enumerate(zip(stats, want)):
+        for key in ("tp", "conf", "pred_cls", "target_cls", "target_img"):
+            assert g[key].shape == w[key].shape and np.array_equal(g[key], w[key]), f"image {b}: {key}"
+        assert np.array_equal(g["tp"], cs[b]["correct"].reshape(g["tp"].shape))
 
 
 def test_validation_matching_kernels_on_emulator(post, golden_dir):

@@ -17,8 +17,9 @@ What `enable` does (every hook falls through to the reference's own code for CPU
      (nn/modules/head.py:157-171).  The weights are a snapshot taken at `enable()` time (the reference folds Conv+BN in
      place when its predictor starts): call `disable()` + `enable()` again after loading other weights;
   3. patches `ultralytics.utils.nms.non_max_suppression` (called as `nms.non_max_suppression(...)` by the detect
-     predictor and validators, models/yolo/detect/predict.py:54, val.py:116) and `ultralytics.utils.ops.scale_boxes`
-     (predict.py:122) with the libymk versions for GPU tensors.
+     predictor and validators, models/yolo/detect/predict.py:54, val.py:116), `ultralytics.utils.ops.scale_boxes`
+     (predict.py:122) and `DetectionValidator._process_batch` (box_iou + match_predictions of `model.val()`,
+     models/yolo/detect/val.py:313-327) with the libymk versions for GPU tensors.
 
 `disable(model)` restores everything.  The hooks are per model instance (2) and per process (3)."""
 from __future__ import annotations
@@ -117,7 +118,8 @@ def disable(model):
 def stats(model) -> dict:
     """How often the hooks ran (tests / diagnostics)."""
     s = getattr(_reference_core(model), _STATE_ATTR, None) or {}
-    return {"calls": s.get("calls", 0), "fallbacks": s.get("fallbacks", 0), "nms_calls": _PATCHED.get("_nms_calls", 0)}
+    return {"calls": s.get("calls", 0), "fallbacks": s.get("fallbacks", 0), "nms_calls": _PATCHED.get("_nms_calls", 0),
+            "match_calls": _PATCHED.get("_match_calls", 0)}
 
 
 def _patch_process():
@@ -149,6 +151,25 @@ def _patch_process():
 
     ref_nms.non_max_suppression = non_max_suppression
     ref_ops.scale_boxes = scale_boxes
+    try:
+        from ultralytics.models.yolo.detect.val import DetectionValidator
+    except Exception:      # a trimmed reference install without the validators: the predictor hooks above still apply
+        return
+    orig_pb = DetectionValidator._process_batch
+    _PATCHED.update(val_cls=DetectionValidator, process_batch=orig_pb, _match_calls=0)
+
+    def _process_batch(self, preds, batch):
+        pb, pc, tb, tc = preds["bboxes"], preds["cls"], batch["bboxes"], batch["cls"]
+        if tc.shape[0] == 0 or pc.shape[0] == 0 or not (ops.device_ok(pb) and ops.device_ok(tb)):
+            return orig_pb(self, preds, batch)
+        _PATCHED["_match_calls"] += 1
+        dets = torch.cat([pb.float(), preds["conf"].float().view(-1, 1), pc.float().view(-1, 1)], 1).unsqueeze(0).contiguous()
+        labels = torch.cat([tc.float().view(-1, 1), tb.float()], 1).contiguous()
+        off = torch.tensor([0, labels.shape[0]], dtype=torch.int32, device=dets.device)
+        correct = postprocess.match_predictions(dets, None, labels, off, self.iouv.to(dets.device))
+        return {"tp": correct[0].cpu().numpy()}
+
+    DetectionValidator._process_batch = _process_batch
 
 
 def _unpatch_process():
@@ -157,3 +178,6 @@ def _unpatch_process():
     ref_nms, ref_ops = sys.modules["ultralytics.utils.nms"], sys.modules["ultralytics.utils.ops"]
     ref_nms.non_max_suppression, ref_ops.scale_boxes = _PATCHED.pop("nms"), _PATCHED.pop("scale")
     _PATCHED.pop("_nms_calls", None)
+    if "val_cls" in _PATCHED:
+        _PATCHED.pop("val_cls")._process_batch = _PATCHED.pop("process_batch")
+        _PATCHED.pop("_match_calls", None)

@@ -623,7 +623,9 @@ class OptimalHybridGateMoE(YmkModule):
         pw_w, pw_b = ops.fold_bn(sn[3].weight.detach().float().to(device), sn[4].weight.float().to(device), sn[4].bias.float().to(device),
                                  sn[4].running_mean.float().to(device), sn[4].running_var.float().to(device), sn[4].eps)
         alpha = float(torch.sigmoid(rt.alpha.detach().float()))
-        gw, gb = _pack_conv(rt.global_fc, f32, device, pad_cout_to=E4)
+        lin = nn.Linear(2 * dyn, self.num_experts, bias=False)
+        lin.weight = nn.Parameter(self._global_weight(rt).detach().float(), requires_grad=False)
+        gw, gb = _pack_conv(lin, f32, device, pad_cout_to=E4)
         # expert_prior is added to the blended logits alpha * g + (1 - alpha) * l: folded into the global stream as prior / alpha
         gb = gb.clone()
         gb[: self.num_experts] = rt.expert_prior.detach().float().to(device) / alpha
@@ -671,6 +673,10 @@ class OptimalHybridGateMoE(YmkModule):
             pk.update({"cg0": _pack_conv(cg_.gate_net[2], f32, device), "cg1": _pack_conv(cg_.gate_net[4], f32, device),
                        "cg_aff": (ops.pack_conv_weight(diag, f32), torch.full((oc,), 0.5, device=device))})
         return pk
+
+    def _global_weight(self, rt):
+        """[E][2 * dyn] matrix of the router's global stream over the normalised statistics."""
+        return rt.global_fc.weight
 
     def _fuse_paths(self, s, d, pk):
         """[static | dynamic] -> channel-shuffled concatenation (gated.py:1333-1338)."""
@@ -743,6 +749,61 @@ class GatedFusionMoE(OptimalHybridGateMoE):
         gate = ops.conv2d(sig[..., : cs + cd], *pk["cg_aff"], 1, 1, False)
         gs_, gd_ = gate[..., :cs].contiguous(), gate[..., cs:].contiguous()     # channel_gate takes dense [B,1,1,C] gates (two tiny copies)
         return ops.channel_shuffle_cat([ops.channel_gate(s, gs_), ops.channel_gate(d, gd_)], self.shuffle_groups)
+
+
+class MultiHeadRouterV3(nn.Module):
+    """moe/gated.py:2026-2106 (parameters; the arithmetic is folded at pack time, see MultiHeadRouterMoE)."""
+
+    def __init__(self, in_channels, num_experts, top_k, temperature=1.0, num_heads=4, local_reduction=16, pool_scale=4, noise_std=0.1,
+                 expert_dropout=0.1):
+        super().__init__()
+        self.num_experts, self.top_k = num_experts, top_k
+        self.temperature = max(float(temperature), 1e-3)
+        self.pool_scale = pool_scale
+        self.num_heads = max(1, min(num_heads, num_experts))
+        stat_dim = 2 * in_channels
+        self.stat_norm = nn.LayerNorm(stat_dim)
+        self._head_dim = max(stat_dim // self.num_heads, 4)
+        self.heads = nn.ModuleList([nn.Linear(self._head_dim, num_experts, bias=False) for _ in range(self.num_heads)])
+        self.global_proj = nn.Linear(stat_dim, num_experts, bias=False)
+        self.head_alpha = nn.Parameter(torch.ones(self.num_heads) / self.num_heads)
+        self.global_weight = nn.Parameter(torch.tensor(0.1))
+        self.expert_prior = nn.Parameter(torch.zeros(num_experts))
+        reduced = max(in_channels // local_reduction, 4)
+        self.local_conv = nn.Sequential(
+            nn.Conv2d(in_channels, in_channels, 3, padding=1, groups=in_channels, bias=False), _gn(in_channels, 8), nn.SiLU(),
+            nn.Conv2d(in_channels, reduced, 1, bias=False), _gn(reduced, 4), nn.SiLU(), nn.Conv2d(reduced, num_experts, 1, bias=True))
+        self.alpha = nn.Parameter(torch.tensor(0.5))
+        self.register_buffer("_noise_progress", torch.tensor(0.0), persistent=False)
+
+
+class MultiHeadRouterMoE(OptimalHybridGateMoE):
+    """v0_13 gated MoE (moe/gated.py:2430-2496): OptimalHybridGateMoE routed by MultiHeadRouterV3 (:2108-2190).  Every head and the
+    full-width projection are linear in the same normalised statistics vector, so the router's global stream is ONE [E][2 * dyn]
+    matrix, built at pack time: sigmoid(global_weight) * W_global + (1 - sigmoid(global_weight)) * sum_i hw_i * W_i placed on head
+    i's slice (hw = sigmoid(head_alpha) / (sum + 1e-6); slices beyond the statistics are padding, statistics beyond the slices are
+    not read by any head).  Everything after it is the v0_12 path."""
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, refine=True, refine_reduction=8, num_heads=4, expert_dropout=0.05):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold, shuffle_groups, refine,
+                         refine_reduction)
+        self.routing = MultiHeadRouterV3(self.dynamic_channels, num_experts, top_k, temperature=initial_temperature, num_heads=num_heads,
+                                         expert_dropout=expert_dropout)
+
+    def _global_weight(self, rt):
+        gw = torch.sigmoid(rt.global_weight.detach().float())
+        hw = torch.sigmoid(rt.head_alpha.detach().float())
+        hw = hw / (hw.sum() + 1e-6)
+        w = gw * rt.global_proj.weight.detach().float()
+        sd_, hd = w.shape[1], rt._head_dim
+        for i, h in enumerate(rt.heads):
+            lo, hi = i * hd, min((i + 1) * hd, sd_)
+            if lo < hi:
+                w[:, lo:hi] += (1 - gw) * hw[i] * h.weight.detach().float()[:, : hi - lo]
+        return w
 
 
 # ----------------------------------------------------------------------------------------- MoA
@@ -1209,6 +1270,6 @@ class C2fMoT(YmkModule):
 GATED_CHAIN = (AdaptiveGateMoE, FusedAdaptiveGateMoE, HybridAdaptiveGateMoE, HybridAdaptiveGateMoEv2, LowRankHybridAdaptiveGateMoE,
                RefinedLowRankHybridAdaptiveGateMoE, DetailAwareLowRankHybridAdaptiveGateMoE, ContextRefinedLowRankHybridAdaptiveGateMoE,
                VisualEnhancedAdaptiveGateMoE)    # YAML generations v0_4 ... v0_11 (one class per generation)
-MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "OptimalHybridGateMoE": OptimalHybridGateMoE,
+MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE,
                             "GatedFusionMoE": GatedFusionMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
 MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

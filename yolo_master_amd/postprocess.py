@@ -130,3 +130,28 @@ def match_predictions(dets: torch.Tensor, counts: torch.Tensor | None, labels: t
                                     ops._p(label_off), total, ops._p(iouv.float().contiguous()), T, float(eps), ops._p(correct), ops._p(ws),
                                     nbytes, ops._stream()), "match_predictions")
     return correct.bool()
+
+
+def batch_stats(dets: torch.Tensor, counts: torch.Tensor, labels: torch.Tensor, label_off: torch.Tensor, iouv: torch.Tensor) -> list[dict]:
+    """The per-image statistics DetectionValidator.update_metrics hands to `metrics.update_stats`
+    (models/yolo/detect/val.py:176-192, with _process_batch :313-327), for a whole batch: one matching launch and ONE
+    device -> host copy instead of B x (IoU, matching, three `.cpu()` calls).  Arguments as `match_predictions`.
+    Returns, per image, {"tp": bool [n, T], "conf": fp32 [n], "pred_cls": fp32 [n], "target_cls": fp32 [L], "target_img": unique
+    target classes} as numpy arrays (n = counts[b]; empty predictions give `np.zeros(0)` for conf / pred_cls as the reference does)."""
+    import numpy as np
+
+    correct = match_predictions(dets, counts, labels, label_off, iouv)
+    B, max_det, T = correct.shape
+    # one staging buffer: [B, max_det, T + 2] = tp columns, conf, cls
+    pack = torch.cat([correct.to(torch.float32), dets[:, :, 4:6]], dim=2).cpu().numpy()
+    n_all = counts.cpu().numpy()
+    lab = labels.cpu().numpy() if labels.numel() else np.zeros((0, 5), np.float32)
+    off = label_off.cpu().numpy()
+    out = []
+    for b in range(B):
+        n = int(n_all[b])
+        cls = lab[off[b]:off[b + 1], 0]
+        no_pred = n == 0
+        out.append({"tp": pack[b, :n, :T] > 0.5, "conf": np.zeros(0) if no_pred else pack[b, :n, T].copy(),
+                    "pred_cls": np.zeros(0) if no_pred else pack[b, :n, T + 1].copy(), "target_cls": cls.copy(), "target_img": np.unique(cls)})
+    return out

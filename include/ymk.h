@@ -104,6 +104,16 @@ int ymk_conv2d_stem_nchw(const float* x_nchw, const float* w, const float* wt_kc
                          int32_t Cout, int32_t ksize, int32_t stride, int32_t ldy, int32_t act,
                          void* stream);
 
+/* Stem + the convolution after it as ONE kernel (bf16 activations): layer 0 `Conv(3, C0, 3, 2)` + SiLU and layer 1
+ * `Conv(C0, C1, 3, 2)` + SiLU of the YOLO-Master YAMLs (conv.py:80-89, walked by nn/tasks.py:182-218), for (C0, C1) = (32, 64)
+ * (the S width).  The stem's output — the largest tensor of the network — stays in LDS (csrc/stem2.hip): same arithmetic as
+ * ymk_conv2d_stem_nchw (fp32 matrix cores, bf16 rounding of the stem map) followed by ymk_conv2d.
+ * x fp32 [B][3][H][W] (16-byte aligned, W % 4 == 0); wt0 = the stem's wt_kco [27][C0] fp32, b0 fp32 [C0];
+ * w1 bf16 [C1][k1pad] packed as for ymk_conv2d (K = (ky, kx, c)), b1 fp32 [C1]; y bf16 [B][H2][W2][ldy]. */
+int ymk_stem_pair_supported(int32_t dtype, int32_t Cin, int32_t C0, int32_t C1, int32_t k0, int32_t s0, int32_t k1, int32_t s1);
+int ymk_stem_pair(const float* x_nchw, int32_t B, int32_t H, int32_t W, const float* wt0, const float* b0, int32_t C0,
+                  const void* w1, int32_t k1pad, const float* b1, int32_t C1, void* y, int32_t ldy, void* stream);
+
 /* ------------------------------------------------------------------------
  * Depthwise k x k convolution (stride 1, pad k/2, k odd <= 15) + bias + act
  * + residual.  Replaces DWConv (conv.py:185-199; Detect cv3 head.py:111-118),

@@ -121,6 +121,17 @@ def dwpw_supported(dtype, C, kmax):
     return False
 
 
+def stem_pair_supported(dtype, cin, c0, c1, k0, s0, k1, s1):
+    return dtype == torch.bfloat16 and (cin, c0, c1, k0, s0, k1, s1) == (3, 32, 64, 3, 2, 3, 2)
+
+
+def stem_pair(x_nchw, wt0, b0, w1, b1, out=None):
+    """include/ymk.h `ymk_stem_pair`: the stem (fp32 operands, bf16 map) followed by the next 3x3/s2 convolution."""
+    _count("stem_pair")
+    h = conv2d_stem(x_nchw, wt0.t().contiguous(), b0, 3, 2, True, torch.bfloat16)
+    return conv2d(h, w1, b1, 3, 2, True, out=out)
+
+
 def mlp_fused_supported(dtype, C, hidden):
     return dtype == torch.bfloat16 and (C, hidden) in ((64, 128), (128, 256), (256, 512))
 
@@ -568,7 +579,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "esmoe_route", "esmoe_dw",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "weighted_sum",

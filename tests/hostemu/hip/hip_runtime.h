@@ -32,10 +32,11 @@ enum { hipSuccess = 0 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 
 // Lanes are FIBERS of one OS thread (ucontext): the scheduler resumes every unfinished lane of the workgroup in turn and
-// a lane runs until its next barrier (or its end).  One such pass is one "phase"; since all lanes of a workgroup (of a
-// wave) execute the same sequence of workgroup (wave) barriers, every lane is at the same barrier when a phase ends, so
-// "yield to the scheduler" IS the barrier.  Kernels whose lanes skip a barrier other lanes take are not supported (and
-// would be broken on the GPU as well).
+// a lane runs until it has to wait.  Two kinds of rendezvous, each with its own arrival counter and generation number:
+// `block_sync` (__syncthreads / s_barrier: every unfinished lane of the workgroup) and `wave_sync` (the exchange points of
+// __shfl_xor and of the matrix-core builtins: the 64 lanes of one wave).  Waves may therefore execute different numbers of
+// wave-level exchanges between two workgroup barriers (a wave with fewer MFMA steps than its neighbours), as on the GPU.
+// Kernels whose lanes skip a barrier other lanes take are not supported (and would be broken on the GPU as well).
 namespace hostemu {
 constexpr unsigned MAX_LANES = 512;           // the largest workgroup any emulated kernel uses
 constexpr size_t STACK = 128 * 1024;
@@ -52,10 +53,30 @@ inline float xch[MAX_LANES];                  // shuffle exchange, one slot per 
 alignas(16) inline float dyn_lds[40960];     // dynamic LDS of `extern __shared__` kernels (160 KB: one CU's LDS)
 inline std::function<void()> job;
 
+inline unsigned n_alive = 0, blk_arrived = 0, blk_gen = 0;
+inline unsigned wave_arrived[MAX_LANES / 64], wave_gen[MAX_LANES / 64], wave_alive[MAX_LANES / 64];
 inline void yield() { swapcontext(&fibers[cur].ctx, &sched); }
+inline void block_sync() {
+    const unsigned g = blk_gen;
+    ++blk_arrived;
+    while (blk_gen == g) {
+        if (blk_arrived >= n_alive) { blk_arrived = 0; ++blk_gen; break; }   // the last lane to arrive (or lanes finished meanwhile) opens it
+        yield();
+    }
+}
+inline void wave_sync() {
+    const unsigned w = cur / 64, g = wave_gen[w];
+    ++wave_arrived[w];
+    while (wave_gen[w] == g) {
+        if (wave_arrived[w] >= wave_alive[w]) { wave_arrived[w] = 0; ++wave_gen[w]; break; }   // lanes that returned do not take part
+        yield();
+    }
+}
 inline void entry() {
     job();
     fibers[cur].done = true;
+    --n_alive;
+    --wave_alive[cur / 64];
     swapcontext(&fibers[cur].ctx, &sched);
 }
 template <typename F>
@@ -77,6 +98,9 @@ void launch(F&& body, dim3 grid, dim3 block) {
                     fibers[t].done = false;
                     makecontext(&fibers[t].ctx, entry, 0);
                 }
+                n_alive = block.x;
+                blk_arrived = 0;
+                for (unsigned w = 0; w < MAX_LANES / 64; ++w) { wave_arrived[w] = 0; wave_alive[w] = 64; }
                 for (unsigned alive = block.x; alive;) {   // one pass = one phase between barriers
                     alive = 0;
                     for (unsigned t = 0; t < block.x; ++t) {
@@ -95,13 +119,13 @@ void launch(F&& body, dim3 grid, dim3 block) {
 #define blockDim hostemu::g_blockDim
 #define gridDim hostemu::g_gridDim
 
-static inline void __syncthreads() { hostemu::yield(); }
+static inline void __syncthreads() { hostemu::block_sync(); }
 static inline float __shfl_xor(float v, int mask) {
     const unsigned t = hostemu::cur;
     hostemu::xch[t] = v;
-    hostemu::yield();                                                    // every lane of the wave has written
+    hostemu::wave_sync();                                                    // every lane of the wave has written
     const float r = hostemu::xch[(t & ~63u) | ((t ^ (unsigned)mask) & 63u)];
-    hostemu::yield();                                                    // every lane has read before the next write
+    hostemu::wave_sync();                                                    // every lane has read before the next write
     return r;
 }
 static inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
@@ -129,14 +153,29 @@ static inline hostemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hostemu_bf16
         hostemu::mfma_a[t][e] = (float)a[e];
         hostemu::mfma_b[t][e] = (float)b[e];
     }
-    hostemu::yield();
+    hostemu::wave_sync();
     for (int r = 0; r < 4; ++r) {
         const unsigned i = (l / 16) * 4 + r, j = l % 16;
         float s = 0.f;
         for (unsigned k = 0; k < 32; ++k) s += hostemu::mfma_a[w0 + (k / 8) * 16 + i][k % 8] * hostemu::mfma_b[w0 + (k / 8) * 16 + j][k % 8];
         c[r] += s;
     }
-    hostemu::yield();
+    hostemu::wave_sync();
+    return c;
+}
+// v_mfma_f32_16x16x4_f32: lane l holds A[l % 16][l / 16], B[l / 16][l % 16]; D as above.
+static inline hostemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hostemu_f32x4 c, int, int, int) {
+    const unsigned t = hostemu::cur, w0 = t & ~63u, l = t & 63u;
+    hostemu::mfma_a[t][0] = a;
+    hostemu::mfma_b[t][0] = b;
+    hostemu::wave_sync();
+    for (int r = 0; r < 4; ++r) {
+        const unsigned i = (l / 16) * 4 + r, j = l % 16;
+        float s = 0.f;
+        for (unsigned k = 0; k < 4; ++k) s += hostemu::mfma_a[w0 + k * 16 + i][0] * hostemu::mfma_b[w0 + k * 16 + j][0];
+        c[r] += s;
+    }
+    hostemu::wave_sync();
     return c;
 }
 // LDS-DMA: 16 bytes per lane from the lane's global address to (wave-uniform LDS base) + lane * 16.  Completes at once
@@ -146,7 +185,7 @@ static inline void hostemu_global_load_lds16(const void* g, void* lds_base) {
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hostemu_global_load_lds16((const void*)(g), (void*)(l))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
-static inline void __builtin_amdgcn_s_barrier() { hostemu::yield(); }
+static inline void __builtin_amdgcn_s_barrier() { hostemu::block_sync(); }
 
 // the slice of the HIP runtime API the probes' main() uses
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost };

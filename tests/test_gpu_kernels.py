@@ -501,3 +501,27 @@ def test_cw_refine(agnostic):
         assert np.array_equal(got[:, 4:], plain[b].cpu().numpy()[:, 4:]), "CW-NMS must not change scores/classes"
         assert np.abs(got[:, :4] - ref).max() <= 1e-4, f"CW-NMS boxes differ: {np.abs(got[:, :4] - ref).max()}"
         assert np.abs(got[:, :4] - plain[b].cpu().numpy()[:, :4]).max() > 1e-3, "refinement had no effect"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_stem2", fromlist=["CASES"]).CASES + [(4, 640, 640), (2, 320, 324)])
+def test_stem_pair(case):
+    """Fused stem + row-1 convolution (csrc/stem2.hip) vs the two-layer composition in torch, and — at the S detector's own
+    size — bit-for-bit against the unfused libymk pair it replaces (ymk_conv2d_stem_nchw -> ymk_conv2d)."""
+    from tests.test_hostemu_stem2 import run_case
+    from yolo_master_amd import _lib, ops
+
+    got = run_case(_lib.load(), case, dev="cuda:0", stream=None)
+    torch.cuda.synchronize()
+    B, H, W = case
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.rand(B, 3, H, W, generator=g)
+    w0 = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    b0 = torch.randn(32, generator=g) * 0.3
+    w1 = torch.randn(64, 32, 3, 3, generator=g) * (9 * 32) ** -0.5
+    b1 = torch.randn(64, generator=g) * 0.2
+    wk = w0.permute(0, 2, 3, 1).reshape(32, 27).contiguous().cuda()
+    h = ops.conv2d_stem(x.cuda(), wk, b0.cuda(), 3, 2, True, torch.bfloat16, wt=wk.t().contiguous())
+    y = ops.conv2d(h, ops.pack_conv_weight(w1, torch.bfloat16).cuda(), b1.cuda(), 3, 2, True)
+    d = (y.float().cpu() - got).abs()
+    assert float(d.max()) == 0.0, f"fused vs unfused libymk pair: max |d| {float(d.max()):.3e} ({int((d > 0).sum())} elements)"

@@ -134,3 +134,28 @@ def test_module_level_api_on_emulation(emu):
     got = moe(x)
     ref = model_ref.es_moe(sd, "model.0", x, top_k=2, sparse=False)
     assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_host_graph_fuses_the_stem_pair_at_the_s_width(emu):
+    """bf16, S scale (rows 0 / 1 = 3 -> 32 -> 64, both 3x3 stride 2): the graph walk hands both rows to ONE entry point
+    (ymk_stem_pair) and produces what the two separate rows produce; with `taps` (per-layer outputs wanted), in fp32, or at
+    another width it keeps the two rows."""
+    from yolo_master_amd.weights import synth_input
+
+    x = synth_input(1, 64, 96, seed=5)
+    m = _model("s", torch.bfloat16)
+    with torch.inference_mode():
+        emu.CALLS.clear()
+        y, _ = m._predict_once(x)
+        assert emu.CALLS["stem_pair"] == 1 and emu.CALLS.get("conv2d_stem", 0) == 1   # (the emulation of the pair calls the stem once)
+        emu.CALLS.clear()
+        taps = {}
+        yt, _ = m._predict_once(x, taps=taps)
+        assert emu.CALLS.get("stem_pair", 0) == 0 and 0 in taps and 1 in taps
+    assert torch.equal(y, yt)
+    for scale, dt in (("n", torch.bfloat16), ("s", torch.float32)):
+        mm = _model(scale, dt)
+        with torch.inference_mode():
+            emu.CALLS.clear()
+            mm._predict_once(x)
+        assert emu.CALLS.get("stem_pair", 0) == 0

@@ -23,7 +23,7 @@ import yaml
 from .. import ops
 from .mixture import MIXTURE_BOUNDARY_MODULES, MIXTURE_BOUNDARY_REPEAT
 from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DWConv, LazyUpsample, Segment,
-                      VirtualCat, YmkModule, set_compute_dtype)
+                      VirtualCat, YmkModule, _is_silu, set_compute_dtype)
 
 CFG_DIR = Path(__file__).resolve().parent.parent / "cfg"
 
@@ -233,6 +233,21 @@ class DetectionModel(nn.Module):
             raise NotImplementedError("ymk DetectionModel.predict: augment/visualize/embed are not on the hot path")
         return self._predict_once(x)
 
+    def _stem_pair_ok(self):
+        """Rows 0 and 1 are `Conv(3, C0, 3, 2)` -> `Conv(C0, C1, 3, 2)`, SiLU both, nothing else reads row 0, and libymk has the
+        fused kernel for these widths in the compute dtype."""
+        if len(self.model) < 3:
+            return False
+        m0, m1 = self.model[0], self.model[1]
+        if not (type(m0) is Conv and type(m1) is Conv and m1.f == -1 and 0 not in self.save):
+            return False
+        c0, c1 = m0.conv, m1.conv
+        if not (c0.in_channels <= 4 and _is_silu(m0.act) and _is_silu(m1.act) and c1.groups == 1 and c0.kernel_size[0] == c0.kernel_size[1]
+                and c1.kernel_size[0] == c1.kernel_size[1]):
+            return False
+        return ops.stem_pair_supported(m1.ymk_dtype, c0.in_channels, c0.out_channels, c1.out_channels, c0.kernel_size[0], c0.stride[0],
+                                       c1.kernel_size[0], c1.stride[0])
+
     def _predict_once(self, x, taps=None):
         """Graph walk on NHWC buffers (reference loop: tasks.py:182-218).  x: NCHW fp32 [B,3,H,W] on GPU.
         Returns (y [B,4+nc,A] fp32, preds dict) like Detect in eval mode.  ``taps``: optional dict that
@@ -245,9 +260,21 @@ class DetectionModel(nn.Module):
         ys = []
         cur = x
         raw = det_in = None
+        skip = -1
         for m in self.model:
+            if m.i == skip:      # produced together with the previous layer (fused stem pair)
+                ys.append(cur if m.i in self.save else None)
+                continue
             if m.f != -1:
                 cur = ys[m.f] if isinstance(m.f, int) else [cur if j == -1 else ys[j] for j in m.f]
+            if m.i == 0 and taps is None and self._stem_pair_ok():
+                # rows 0 + 1 as one kernel: the stem map (the largest tensor of the network) never leaves the CU (csrc/stem2.hip)
+                m1 = self.model[1]
+                p0, p1 = m._packed(x.device), m1._packed(x.device)
+                cur = ops.stem_pair(cur, p0["wt"], p0["b"], p1["w"], p1["b"])
+                ys.append(None)
+                skip = 1
+                continue
             if isinstance(m, Conv):
                 if isinstance(cur, LazyUpsample):
                     cur = cur.materialise()

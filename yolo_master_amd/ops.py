@@ -242,6 +242,30 @@ def conv2d_stem(x_nchw, w, bias, k: int, stride: int, act: bool, dtype: torch.dt
     return out
 
 
+def stem_pair_supported(dtype, cin: int, c0: int, c1: int, k0: int, s0: int, k1: int, s1: int) -> bool:
+    """YMK_DISABLE bit 2048 switches the fused stem + row-1 kernel off (-> conv2d_stem + conv2d) for A/B runs."""
+    return dtype in DT and bool(lib.ymk_stem_pair_supported(DT[dtype], cin, c0, c1, k0, s0, k1, s1)) and \
+        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 2048)
+
+
+def stem_pair(x_nchw, wt0, b0, w1, b1, out=None):
+    """Layer 0 (stem 3x3/s2 + SiLU) and layer 1 (3x3/s2 + SiLU) as one kernel (include/ymk.h ymk_stem_pair): x fp32 NCHW, wt0 the
+    stem's transposed fp32 weights [27][C0], w1 the next convolution's packed bf16 weights; returns layer 1's NHWC bf16 output."""
+    _need_gpu(x_nchw)
+    x_nchw = x_nchw.contiguous().float()
+    B, _, H, W = x_nchw.shape
+    C0, C1 = wt0.shape[1], w1.shape[0]
+    H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+    if out is None:
+        out = new_act(B, H2, W2, C1, torch.bfloat16, x_nchw.device)
+    ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_stem_pair(_p(x_nchw), B, H, W, _p(wt0), _p(b0), C0, _p(w1), w1.shape[1], _p(b1), C1, _p(out), ldy, _stream()), "stem_pair")
+    TIMER.end(e0, "stem_pair", B * 3 * H * W * 4 + B * H2 * W2 * C1 * 2, 2 * B * (H1 * W1 * C0 * 27 + H2 * W2 * C1 * 9 * C0), f"3->{C0}->{C1} @{H}x{W}")
+    return out
+
+
 def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
     B, H, W, Cc, ldx = _nhwc(x)
     if out is None:

@@ -15,6 +15,16 @@
 //   row 1   implicit GEMM from that tile: one 3x3 tap = one 32-deep MFMA step (C0 = 32), the wave's weight fragments resident in
 //           registers for the whole kernel; bias + SiLU, one NHWC bf16 store.
 // Halo cost: 585 stem pixels per 512 consumed (1.14x stem arithmetic); the input window overlap is served by L2.
+//
+// Stem arithmetic, two variants (SPLIT template parameter):
+//   false  fp32 matrix cores (v_mfma_f32_16x16x4_f32), exactly stem_rows_kernel's sequence: bit-identical to the unfused pair, but
+//          16 x 32-cycle MFMAs per 16 pixels make the stem phase the longest of the kernel (stage ablation: 25 % of its time);
+//   true   (default) each fp32 operand is split into two bf16 parts, v = hi + lo with hi = bf16(v), lo = bf16(v - hi), and the product
+//          is accumulated in fp32 as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (3 x 16-cycle MFMAs per 16 pixels x 16 couts;
+//          K = 27 fits one 32-deep step).  Dropped: lo*lo and the parts' own rounding, <= 2^-16 relative per product — 100x below
+//          the bf16 rounding the stem map gets anyway (about 0.3 % of its values move by one bf16 ulp against the fp32 variant).
+//          The image is split once, when the window is staged: an LDS word is (hi << 16) | lo.
+// YMK_DISABLE bit 4096 selects the fp32 variant.
 #include "ymk_common.h"
 
 #define S2_TH 4
@@ -53,7 +63,14 @@ struct Stem2Args {
     int B, H, W, H1, W1, H2, W2, k1pad, ldy, tiles_x, tiles_y;
 };
 
-template <int C0, int C1>
+// fp32 -> (hi << 16) | lo, both parts bf16 (round to nearest even)
+__device__ __forceinline__ uint32_t s2_split(float v) {
+    const uint32_t hi = pack_bf16x2(v, 0.f) & 0xffffu;
+    const float r = v - __uint_as_float(hi << 16);
+    return (hi << 16) | (pack_bf16x2(r, 0.f) & 0xffffu);
+}
+
+template <int C0, int C1, bool SPLIT>
 __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
     static_assert(C0 == 32 && C1 == 64, "tile shapes are written for the S width (32 -> 64)");
     constexpr int TM0 = C0 / 16;            // stem cout fragments
@@ -67,11 +84,13 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
     const int ntile = a.B * a.tiles_y * a.tiles_x;
 
     // ---- resident operands ----------------------------------------------------------------------------------------------------
-    u32x4 af0[TM0][2];     // stem weights: k = kk * 16 + fc * 4 + v
-    int off0[8];           // ... and the LDS offset of that tap relative to the lane's pixel base
+    // stem weights and the LDS offset of each tap relative to the lane's pixel base.  fp32 variant: k = kk * 16 + fc * 4 + v
+    // (four 16x16x4 steps per u32x4); split variant: k = fc * 8 + e, af0[i][0] = hi parts, af0[i][1] = lo parts (8 bf16 each)
+    u32x4 af0[TM0][2];
+    int off0[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int k = (q >> 2) * 16 + fc * 4 + (q & 3);
+        const int k = SPLIT ? fc * 8 + q : (q >> 2) * 16 + fc * 4 + (q & 3);
         const int kc = k < 27 ? k : 0;
         const int tap = kc / 3, c = kc - tap * 3;
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -79,7 +98,15 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
 #pragma unroll
         for (int i = 0; i < TM0; ++i) {
             const float wv = k < 27 ? a.wt0[k * C0 + i * 16 + fr] : 0.f;
-            reinterpret_cast<float*>(&af0[i][q >> 2])[q & 3] = wv;
+            if (SPLIT) {
+                const uint32_t w2 = s2_split(wv);
+                uint32_t* h = reinterpret_cast<uint32_t*>(&af0[i][0]) + (q >> 1);
+                uint32_t* l = reinterpret_cast<uint32_t*>(&af0[i][1]) + (q >> 1);
+                if (q & 1) { *h |= w2 & 0xffff0000u; *l |= w2 << 16; }
+                else { *h = w2 >> 16; *l = w2 & 0xffffu; }
+            } else {
+                reinterpret_cast<float*>(&af0[i][q >> 2])[q & 3] = wv;
+            }
         }
     }
     f32x4 bv0[TM0];
@@ -129,7 +156,12 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
             const int i = t + l * S2_NT;
             if (i < 3 * S2_IR * S2_IC4) {
                 const int rr = i / S2_IC4, q = i - rr * S2_IC4;
-                *reinterpret_cast<u32x4*>(sIn + rr * S2_IP + q * 4) = stg[l];
+                u32x4 v = stg[l];
+                if (SPLIT) {
+                    v.x = s2_split(__uint_as_float(v.x)); v.y = s2_split(__uint_as_float(v.y));
+                    v.z = s2_split(__uint_as_float(v.z)); v.w = s2_split(__uint_as_float(v.w));
+                }
+                *reinterpret_cast<u32x4*>(sIn + rr * S2_IP + q * 4) = v;
             }
         }
         __syncthreads();   // A: window visible; every wave has finished the previous tile's row-1 phase (stem tile free)
@@ -142,15 +174,34 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
             const int u = pc / S2_SC, s = pc - u * S2_SC;
             const float* base = sIn + (2 * u) * S2_IP + 2 * s;
             u32x4 bf[2];
+            if (SPLIT) {
+                uint32_t w[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) reinterpret_cast<float*>(&bf[q >> 2])[q & 3] = base[off0[q]];
+                for (int q = 0; q < 8; ++q) w[q] = reinterpret_cast<const uint32_t*>(base)[off0[q]];
+                uint32_t* h = reinterpret_cast<uint32_t*>(&bf[0]);
+                uint32_t* l = reinterpret_cast<uint32_t*>(&bf[1]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h[q] = (w[2 * q] >> 16) | (w[2 * q + 1] & 0xffff0000u);
+                    l[q] = (w[2 * q] & 0xffffu) | (w[2 * q + 1] << 16);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) reinterpret_cast<float*>(&bf[q >> 2])[q & 3] = base[off0[q]];
+            }
             const int sy = 2 * oy0 - 1 + u, sx = 2 * ox0 - 1 + s;
             const bool inside = (unsigned)sy < (unsigned)a.H1 && (unsigned)sx < (unsigned)a.W1;
 #pragma unroll
             for (int i = 0; i < TM0; ++i) {
                 f32x4 acc = bv0[i];
-                s2_mma_f32(acc, af0[i][0], bf[0]);
-                s2_mma_f32(acc, af0[i][1], bf[1]);
+                if (SPLIT) {
+                    s2_mma_bf16(acc, af0[i][1], bf[0]);   // lo * hi
+                    s2_mma_bf16(acc, af0[i][0], bf[1]);   // hi * lo
+                    s2_mma_bf16(acc, af0[i][0], bf[0]);   // hi * hi
+                } else {
+                    s2_mma_f32(acc, af0[i][0], bf[0]);
+                    s2_mma_f32(acc, af0[i][1], bf[1]);
+                }
                 u32x2 o = {0u, 0u};   // outside the stem map: row 1's zero padding
                 if (inside) {
                     o.x = pack_bf16x2(silu_f(acc.x), silu_f(acc.y));
@@ -225,10 +276,15 @@ extern "C" int ymk_stem_pair(const float* x, int32_t B, int32_t H, int32_t W, co
 #endif
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pair_kernel<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pair_kernel<32, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)S2_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pair_kernel<32, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)S2_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((stem_pair_kernel<32, 64>), dim3(grid), dim3(S2_NT), S2_LDS_BYTES, (hipStream_t)stream, a);
+    if (ymk_disabled() & 4096u)
+        hipLaunchKernelGGL((stem_pair_kernel<32, 64, false>), dim3(grid), dim3(S2_NT), S2_LDS_BYTES, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((stem_pair_kernel<32, 64, true>), dim3(grid), dim3(S2_NT), S2_LDS_BYTES, (hipStream_t)stream, a);
     return ymk_launch_status();
 }

@@ -114,6 +114,16 @@ int ymk_stem_pair_supported(int32_t dtype, int32_t Cin, int32_t C0, int32_t C1, 
 int ymk_stem_pair(const float* x_nchw, int32_t B, int32_t H, int32_t W, const float* wt0, const float* b0, int32_t C0,
                   const void* w1, int32_t k1pad, const float* b1, int32_t C1, void* y, int32_t ldy, void* stream);
 
+/* C3k2 block with one plain Bottleneck as ONE kernel (bf16; c1 = 64, c2 = 128, hidden c = 32: YOLO-Master-S row 2 on the 160 x 160
+ * map): y = cv2([a | b | b + m.cv2(m.cv1(b))]) with [a | b] = cv1(x), every Conv = convolution + folded BN + SiLU
+ * (C2f.forward / C3k2, nn/modules/block.py:293-325, 1074-1111; Bottleneck :462-486).  The three intermediates stay in LDS
+ * (csrc/c3k2f.hip).  Weights packed as for ymk_conv2d: w1 [64][k1pad] (1x1), wa [16][kapad] (3x3, 32 -> 16), wb [32][kbpad]
+ * (3x3, 16 -> 32), w2 [128][k2pad] (1x1 over 96), fp32 biases.  x [B][H][W][ldx] (64 channels), y [B][H][W][ldy] (128). */
+int ymk_c3k2_fused_supported(int32_t dtype, int32_t c1, int32_t c2, int32_t c, int32_t n, int32_t c3k, int32_t shortcut);
+int ymk_c3k2_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, const void* w1, int32_t k1pad, const float* b1,
+                   const void* wa, int32_t kapad, const float* ba, const void* wb, int32_t kbpad, const float* bb, const void* w2,
+                   int32_t k2pad, const float* b2, void* y, int32_t ldy, void* stream);
+
 /* ------------------------------------------------------------------------
  * Depthwise k x k convolution (stride 1, pad k/2, k odd <= 15) + bias + act
  * + residual.  Replaces DWConv (conv.py:185-199; Detect cv3 head.py:111-118),

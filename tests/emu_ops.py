@@ -132,6 +132,20 @@ def stem_pair(x_nchw, wt0, b0, w1, b1, out=None):
     return conv2d(h, w1, b1, 3, 2, True, out=out)
 
 
+def c3k2_fused_supported(dtype, c1, c2, c, n, c3k, shortcut):
+    return dtype == torch.bfloat16 and (c1, c2, c, n) == (64, 128, 32, 1) and not c3k and bool(shortcut)
+
+
+def c3k2_fused(x, p1, pa, pb, p2, out=None):
+    """include/ymk.h `ymk_c3k2_fused`: cv1 -> Bottleneck(3x3, 3x3, + residual) -> cv2 over [a | b | m], each stage rounded to bf16."""
+    _count("c3k2_fused")
+    y1 = conv2d(x, p1[0], p1[1], 1, 1, True)
+    b = y1[..., 32:]
+    h = conv2d(b, pa[0], pa[1], 3, 1, True)
+    m = conv2d(h, pb[0], pb[1], 3, 1, True, residual=b)
+    return conv2d(torch.cat([y1, m], -1), p2[0], p2[1], 1, 1, True, out=out)
+
+
 def mlp_fused_supported(dtype, C, hidden):
     return dtype == torch.bfloat16 and (C, hidden) in ((64, 128), (128, 256), (256, 512))
 
@@ -579,7 +593,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "esmoe_route", "esmoe_dw",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "weighted_sum",

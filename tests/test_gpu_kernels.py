@@ -558,3 +558,26 @@ def test_stem_pair_fp32_variant_is_bit_identical_to_the_unfused_pair():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
                        cwd=str(Path(__file__).resolve().parent.parent))
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_c3k2f", fromlist=["CASES"]).CASES + [(4, 160, 160), (2, 80, 96)])
+def test_c3k2_fused(case):
+    """Fused C3k2 block (csrc/c3k2f.hip) vs the four-convolution composition in torch (inside run_case) and vs the unfused libymk
+    convolutions it replaces (same stage roundings: differences are isolated bf16 ulps where a stage rounds the other way)."""
+    from tests.test_hostemu_c3k2f import operands, run_case
+    from yolo_master_amd import _lib, ops
+
+    got = run_case(_lib.load(), case, dev="cuda:0", stream=None)
+    torch.cuda.synchronize()
+    x, ws, bs, packed = operands(case)
+    xd, pk, bd = x.cuda(), [w.cuda() for w in packed], [b.cuda() for b in bs]
+    y1 = ops.conv2d(xd, pk[0], bd[0], 1, 1, True)
+    b = y1[..., 32:]
+    h = ops.conv2d(b, pk[1], bd[1], 3, 1, True)
+    m = ops.conv2d(h, pk[2], bd[2], 3, 1, True, residual=b)
+    y = ops.conv2d(torch.cat([y1, m], -1), pk[3], bd[3], 1, 1, True).float().cpu()
+    d = (y - got).abs()
+    scale = max(1.0, float(y.abs().max()))
+    assert float(d.max()) <= 4e-2 * scale and float(d.mean()) <= 2e-4 * scale, f"max {float(d.max()):.3e} mean {float(d.mean()):.3e}"
+    print(f"fused vs unfused libymk: {int((d > 0).sum())} of {d.numel()} elements differ, max {float(d.max()):.3e}")

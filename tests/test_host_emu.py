@@ -148,6 +148,7 @@ def test_host_graph_fuses_the_stem_pair_at_the_s_width(emu):
         emu.CALLS.clear()
         y, _ = m._predict_once(x)
         assert emu.CALLS["stem_pair"] == 1 and emu.CALLS.get("conv2d_stem", 0) == 1   # (the emulation of the pair calls the stem once)
+        assert emu.CALLS["c3k2_fused"] == 1                                            # row 2 (64 -> 128, c = 32) as one entry point
         emu.CALLS.clear()
         taps = {}
         yt, _ = m._predict_once(x, taps=taps)

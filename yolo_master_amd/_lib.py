@@ -57,6 +57,8 @@ SYMBOLS = {
                                _vp, _i32, _vp]),
     "ymk_stem_pair_supported": (C.c_int, [_i32] * 8),
     "ymk_stem_pair": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "ymk_c3k2_fused_supported": (C.c_int, [_i32] * 7),
+    "ymk_c3k2_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "ymk_mlp_fused_supported": (C.c_int, [_i32, _i32, _i32]),
     "ymk_mlp_fused": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ymk_dw_mfma_supported": (C.c_int, [_i32, _i32, _i32]),

@@ -282,6 +282,17 @@ class C2f(YmkModule):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
+    def _fusable(self, x):
+        m0 = self.m[0]
+        convs = (self.cv1, m0.cv1, m0.cv2, self.cv2)
+        if not all(_is_silu(q.act) and q.conv.groups == 1 and q.conv.stride == (1, 1) for q in convs):
+            return False
+        if (self.cv1.conv.kernel_size, m0.cv1.conv.kernel_size, m0.cv2.conv.kernel_size, self.cv2.conv.kernel_size) != ((1, 1), (3, 3), (3, 3), (1, 1)):
+            return False
+        if m0.cv1.conv.out_channels * 2 != self.c:
+            return False
+        return ops.c3k2_fused_supported(x.dtype, self.cv1.conv.in_channels, self.cv2.conv.out_channels, self.c, 1, False, m0.add)
+
     def _run(self, x, out=None):
         # chunk(2)/cat are free: cv1 and every block write their slice of one buffer
         if isinstance(x, VirtualCat):
@@ -292,6 +303,11 @@ class C2f(YmkModule):
             ref = x
             B, H, W, _ = x.shape
         c, n = self.c, len(self.m)
+        if torch.is_tensor(x) and n == 1 and type(self.m[0]) is Bottleneck and self._fusable(x):
+            # the whole block as one kernel: cv1's output, the bottleneck's hidden map and its result stay in LDS (csrc/c3k2f.hip)
+            m0 = self.m[0]
+            pk = [q._packed(x.device) for q in (self.cv1, m0.cv1, m0.cv2, self.cv2)]
+            return ops.c3k2_fused(x, *[(q["w"], q["b"]) for q in pk], out=out)
         cat = ops.new_act(B, H, W, (2 + n) * c, ref.dtype, ref.device)
         if isinstance(x, VirtualCat):
             pk = self.cv1._packed(ref.device)

@@ -266,6 +266,27 @@ def stem_pair(x_nchw, wt0, b0, w1, b1, out=None):
     return out
 
 
+def c3k2_fused_supported(dtype, c1: int, c2: int, c: int, n: int, c3k: bool, shortcut: bool) -> bool:
+    """YMK_DISABLE bit 8192 switches the fused C3k2 block off (-> its four convolutions) for A/B runs."""
+    return dtype in DT and bool(lib.ymk_c3k2_fused_supported(DT[dtype], c1, c2, c, n, int(bool(c3k)), int(bool(shortcut)))) and \
+        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 8192)
+
+
+def c3k2_fused(x, p1, pa, pb, p2, out=None):
+    """C3k2 (c3k = False, n = 1, c = 32) as one kernel (include/ymk.h ymk_c3k2_fused).  p1 / pa / pb / p2 = (packed bf16 weights, fp32
+    bias) of cv1, m[0].cv1, m[0].cv2, cv2; x / out NHWC bf16 views."""
+    B, H, W, Cin, ldx = _nhwc(x)
+    Cout = p2[0].shape[0]
+    if out is None:
+        out = new_act(B, H, W, Cout, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_c3k2_fused(_p(x), ldx, B, H, W, _p(p1[0]), p1[0].shape[1], _p(p1[1]), _p(pa[0]), pa[0].shape[1], _p(pa[1]), _p(pb[0]),
+                             pb[0].shape[1], _p(pb[1]), _p(p2[0]), p2[0].shape[1], _p(p2[1]), _p(out), ldy, _stream()), "c3k2_fused")
+    TIMER.end(e0, "c3k2_fused", B * H * W * (Cin + Cout) * 2, 2 * B * H * W * (64 * 64 + 288 * 16 + 144 * 32 + 96 * 128), f"{Cin}->{Cout} @{H}x{W}")
+    return out
+
+
 def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
     B, H, W, Cc, ldx = _nhwc(x)
     if out is None:

@@ -123,6 +123,14 @@ int ymk_c3k2_fused_supported(int32_t dtype, int32_t c1, int32_t c2, int32_t c, i
 int ymk_c3k2_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, const void* w1, int32_t k1pad, const float* b1,
                    const void* wa, int32_t kapad, const float* ba, const void* wb, int32_t kbpad, const float* bb, const void* w2,
                    int32_t k2pad, const float* b2, void* y, int32_t ldy, void* stream);
+/* ... and, for a consumer that starts with a global average pool of y (the ES-MoE router of the next YAML row,
+ * moe/routers.py:458-527): gap_part fp32 [B][ymk_c3k2_fused_pool_chunks(H, W)][128] receives the per-tile channel sums of the
+ * stored (bf16) values, in a fixed order — feed it to ymk_esmoe_route_pooled instead of re-reading y.  flags (may be NULL):
+ * YMK_FLAG_NONFINITE_INPUT when a sum is not finite. */
+int32_t ymk_c3k2_fused_pool_chunks(int32_t H, int32_t W);
+int ymk_c3k2_fused_pooled(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, const void* w1, int32_t k1pad, const float* b1,
+                          const void* wa, int32_t kapad, const float* ba, const void* wb, int32_t kbpad, const float* bb, const void* w2,
+                          int32_t k2pad, const float* b2, void* y, int32_t ldy, float* gap_part, int32_t* flags, void* stream);
 
 /* ------------------------------------------------------------------------
  * Depthwise k x k convolution (stride 1, pad k/2, k odd <= 15) + bias + act
@@ -168,6 +176,12 @@ int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t 
                     int32_t top_k, float dynamic_threshold, float* route_w, float* gate_w,
                     int32_t* sel, int32_t* csr_off, int32_t* csr_pair, float* state /*[E+1], nullable*/,
                     int32_t* flags, void* workspace, size_t workspace_bytes, void* stream);
+/* The same router on per-chunk channel sums a producer kernel already wrote (ymk_c3k2_fused_pooled): part fp32 [B][nchunk][C], any
+ * partition of each image's H * W pixels into nchunk chunks.  Skips the read of x; everything else as ymk_esmoe_route. */
+int ymk_esmoe_route_pooled(const float* part, int32_t nchunk, int32_t B, int32_t H, int32_t W, int32_t C, const float* w1,
+                           const float* b1, const float* w2, const float* b2, int32_t hidden, int32_t E, int32_t top_k,
+                           float dynamic_threshold, float* route_w, float* gate_w, int32_t* sel, int32_t* csr_off,
+                           int32_t* csr_pair, float* state, int32_t* flags, void* stream);
 
 /* Depthwise stage of the retained experts, dispatched over the CSR pairs
  * (experts.py:283-292, modules.py:690-697).  dw_w is one blob holding every

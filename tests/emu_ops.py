@@ -136,7 +136,7 @@ def c3k2_fused_supported(dtype, c1, c2, c, n, c3k, shortcut):
     return dtype == torch.bfloat16 and (c1, c2, c, n) == (64, 128, 32, 1) and not c3k and bool(shortcut)
 
 
-def c3k2_fused(x, p1, pa, pb, p2, out=None):
+def c3k2_fused(x, p1, pa, pb, p2, out=None, pool=True):
     """include/ymk.h `ymk_c3k2_fused`: cv1 -> Bottleneck(3x3, 3x3, + residual) -> cv2 over [a | b | m], each stage rounded to bf16."""
     _count("c3k2_fused")
     y1 = conv2d(x, p1[0], p1[1], 1, 1, True)

@@ -133,6 +133,7 @@ static inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 #define __expf(x) expf(x)   // glibc declares __expf itself
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+using std::isfinite;
 using std::max;
 using std::min;
 

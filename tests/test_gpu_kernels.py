@@ -581,3 +581,32 @@ def test_c3k2_fused(case):
     scale = max(1.0, float(y.abs().max()))
     assert float(d.max()) <= 4e-2 * scale and float(d.mean()) <= 2e-4 * scale, f"max {float(d.max()):.3e} mean {float(d.mean()):.3e}"
     print(f"fused vs unfused libymk: {int((d > 0).sum())} of {d.numel()} elements differ, max {float(d.max()):.3e}")
+
+
+@pytest.mark.gpu
+def test_esmoe_route_from_the_producers_pooled_sums():
+    """ymk_esmoe_route_pooled on the per-tile channel sums c3k2_fused leaves (`out.gap_part`) = ymk_esmoe_route reading the map:
+    same retained experts, routing weights equal to fp32 summation-order noise."""
+    from tests.test_hostemu_c3k2f import operands
+    from yolo_master_amd import ops
+
+    x, ws, bs, packed = operands((6, 40, 64))
+    pk, bd = [w.cuda() for w in packed], [b.cuda() for b in bs]
+    y = ops.c3k2_fused(x.cuda(), *[(w, b) for w, b in zip(pk, bd)])
+    assert y.gap_part.shape == (6, 5 * 2, 128)
+    g = torch.Generator().manual_seed(1)
+    w1, b1 = (torch.randn(32, 128, generator=g) * 0.5).cuda(), (torch.randn(32, generator=g) * 0.1).cuda()
+    w2, b2 = (torch.randn(4, 32, generator=g) * 0.8).cuda(), (torch.randn(4, generator=g) * 0.1).cuda()
+    flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pooled = ops.esmoe_route(y, w1, b1, w2, b2, 2, 0.3, flags)
+    plain = ops.esmoe_route(y.clone(), w1, b1, w2, b2, 2, 0.3, flags)      # a copy carries no partials: stage 1 reads the map
+    torch.cuda.synchronize()
+    assert int(flags.item()) == 0, f"flags {int(flags.item())}"
+    dw = float((pooled[0] - plain[0]).abs().max())
+    assert dw <= 1e-5, f"routing weights differ by {dw:.3e}"
+    assert torch.equal(pooled[2], plain[2]), f"retained experts differ:\n{pooled[2].tolist()}\n{plain[2].tolist()}"
+    assert torch.equal(pooled[3], plain[3]) and torch.equal(pooled[4], plain[4]), "CSR differs"
+    assert float((pooled[1] - plain[1]).abs().max()) <= 1e-5
+    y.gap_part[0, 0, 5] = float("nan")                                     # a non-finite sum must raise the router's input flag
+    ops.esmoe_route(y, w1, b1, w2, b2, 2, 0.3, flags)
+    assert int(flags.item()) & 1

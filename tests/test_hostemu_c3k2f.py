@@ -56,10 +56,22 @@ def run_case(lib, case, dev="cpu", stream=None):
     yb = torch.full((B, H, W, 128 + 8), 7.0, dtype=bf, device=dev)
     pk, bd = [w.to(dev) for w in packed], [b.to(dev) for b in bs]
     assert lib.ymk_c3k2_fused_supported(1, 64, 128, 32, 1, 0, 1) and not lib.ymk_c3k2_fused_supported(1, 128, 256, 64, 1, 0, 1)
-    rc = lib.ymk_c3k2_fused(_p(xd), xd.stride(2), B, H, W, _p(pk[0]), pk[0].shape[1], _p(bd[0]), _p(pk[1]), pk[1].shape[1], _p(bd[1]),
-                            _p(pk[2]), pk[2].shape[1], _p(bd[2]), _p(pk[3]), pk[3].shape[1], _p(bd[3]), _p(yb), yb.stride(2), stream)
+    nchunk = lib.ymk_c3k2_fused_pool_chunks(H, W)
+    assert nchunk == -(-H // 8) * -(-W // 32)
+    part = torch.full((B, nchunk, 128), 9.0, dtype=torch.float32, device=dev)
+    rc = lib.ymk_c3k2_fused_pooled(_p(xd), xd.stride(2), B, H, W, _p(pk[0]), pk[0].shape[1], _p(bd[0]), _p(pk[1]), pk[1].shape[1], _p(bd[1]),
+                                   _p(pk[2]), pk[2].shape[1], _p(bd[2]), _p(pk[3]), pk[3].shape[1], _p(bd[3]), _p(yb), yb.stride(2), _p(part),
+                                   None, stream)
     assert rc == 0
     got = yb[..., :128].float().cpu()
+    # pooled partials: their sum over the chunks is the channel sum of the STORED output (what a global average pool of y reads)
+    pooled = part.sum(1).cpu()
+    want = got.double().sum((1, 2))
+    assert float((pooled.double() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), "pooled partials != channel sums of y"
+    y2 = torch.full_like(yb, 7.0)     # the entry point without pooling writes the same map
+    assert lib.ymk_c3k2_fused(_p(xd), xd.stride(2), B, H, W, _p(pk[0]), pk[0].shape[1], _p(bd[0]), _p(pk[1]), pk[1].shape[1], _p(bd[1]),
+                              _p(pk[2]), pk[2].shape[1], _p(bd[2]), _p(pk[3]), pk[3].shape[1], _p(bd[3]), _p(y2), y2.stride(2), stream) == 0
+    assert torch.equal(y2.cpu(), yb.cpu())
     err = (got - ref).abs()
     scale = max(1.0, float(ref.abs().max()))
     # a stage's bf16 rounding may land on the other side of a boundary (fast SiLU, summation order): isolated one-ulp effects downstream

@@ -54,6 +54,8 @@ struct C3k2fArgs {
     const float *b1, *ba, *bb, *b2;
     bf16_t* y;                             // [B][H][W][ldy], 128 channels
     int B, H, W, ldx, ldy, k1pad, kapad, kbpad, k2pad, tiles_x, tiles_y;
+    float* gap_part;                       // [B][tiles_y * tiles_x][128] per-tile channel sums of y (or null)
+    int* flags;                            // YMK_FLAG_NONFINITE_INPUT is raised when a sum is not finite (or null)
 };
 
 __global__ __launch_bounds__(CF_NT) void c3k2_fused_kernel(C3k2fArgs a) {
@@ -93,47 +95,56 @@ __global__ __launch_bounds__(CF_NT) void c3k2_fused_kernel(C3k2fArgs a) {
     for (int s = 0; s < 3; ++s) af2[s] = *reinterpret_cast<const u32x4*>(a.w2 + (size_t)(wave * 16 + fr) * a.k2pad + s * 32 + fc * 8);
     const f32x4 bv2 = *reinterpret_cast<const f32x4*>(a.b2 + wave * 16 + fc * 4);
 
+    // phase-1 operands of a tile: the wave's pixel groups' x fragments, straight from global into registers.  Loaded one tile ahead:
+    // the next tile's requests are issued as soon as this tile's phase 1 has consumed the registers and land during phases 2-4.
+    constexpr int NG1 = CF_NY / 16;                              // 27 pixel groups
+    constexpr int NR1 = (NG1 + CF_NT / 64 - 1) / (CF_NT / 64);   // rounds per wave (4)
+    u32x4 bx[NR1][2];
+    unsigned inmask = 0;
+    auto xload = [&](int tile) {
+        const int txi = tile % a.tiles_x, r0 = tile / a.tiles_x;
+        const int tyi = r0 % a.tiles_y, b = r0 / a.tiles_y;
+        const bf16_t* xb = a.x + (size_t)b * a.H * a.W * a.ldx;
+        inmask = 0;
+#pragma unroll
+        for (int r = 0; r < NR1; ++r) {
+            const int g = wave + r * (CF_NT / 64);
+            const int p = (g < NG1 ? g : 0) * 16 + fr;
+            const int u = p / CF_YC, s = p - u * CF_YC;
+            const int iy = tyi * CF_TH - 2 + u, ix = txi * CF_TW - 2 + s;
+            const bool in = g < NG1 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            bx[r][0] = bx[r][1] = u32x4{0u, 0u, 0u, 0u};
+            if (in) {
+                const bf16_t* px = xb + ((size_t)iy * a.W + ix) * a.ldx + fc * 8;
+                bx[r][0] = *reinterpret_cast<const u32x4*>(px);
+                bx[r][1] = *reinterpret_cast<const u32x4*>(px + 32);
+                inmask |= 1u << r;
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntile) xload(blockIdx.x);
+
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int txi = tile % a.tiles_x, r0 = tile / a.tiles_x;
         const int tyi = r0 % a.tiles_y, b = r0 / a.tiles_y;
         const int oy0 = tyi * CF_TH, ox0 = txi * CF_TW;
-        const bf16_t* xb = a.x + (size_t)b * a.H * a.W * a.ldx;
 
         // ---- phase 1: y1 = SiLU(cv1 x) on the tile + 2 ------------------------------------------------------------------------------------
-        {
-            constexpr int NG = CF_NY / 16;                         // 27 pixel groups
-            constexpr int NR = (NG + CF_NT / 64 - 1) / (CF_NT / 64);   // rounds per wave (4)
-            u32x4 bx[NR][2];
-            bool in[NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {                         // every load of the wave in flight before the first MFMA
-                const int g = wave + r * (CF_NT / 64);
-                const int p = (g < NG ? g : 0) * 16 + fr;
-                const int u = p / CF_YC, s = p - u * CF_YC;
-                const int iy = oy0 - 2 + u, ix = ox0 - 2 + s;
-                in[r] = g < NG && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                bx[r][0] = bx[r][1] = u32x4{0u, 0u, 0u, 0u};
-                if (in[r]) {
-                    const bf16_t* px = xb + ((size_t)iy * a.W + ix) * a.ldx + fc * 8;
-                    bx[r][0] = *reinterpret_cast<const u32x4*>(px);
-                    bx[r][1] = *reinterpret_cast<const u32x4*>(px + 32);
-                }
-            }
+        for (int r = 0; r < NR1; ++r) {
+            const int g = wave + r * (CF_NT / 64);
+            if (g >= NG1) break;
+            const int p = g * 16 + fr;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int g = wave + r * (CF_NT / 64);
-                if (g >= NG) break;
-                const int p = g * 16 + fr;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 acc = bv1[i];
-                    cf_mma(acc, af1[i][0], bx[r][0]);
-                    cf_mma(acc, af1[i][1], bx[r][1]);
-                    const u32x2 o = in[r] ? cf_pack_silu(acc) : u32x2{0u, 0u};   // outside the map: the 3x3's zero padding
-                    *reinterpret_cast<u32x2*>(sY + p * CF_YP + (i * 16 + fc * 4) * 2) = o;
-                }
+            for (int i = 0; i < 4; ++i) {
+                f32x4 acc = bv1[i];
+                cf_mma(acc, af1[i][0], bx[r][0]);
+                cf_mma(acc, af1[i][1], bx[r][1]);
+                const u32x2 o = ((inmask >> r) & 1u) ? cf_pack_silu(acc) : u32x2{0u, 0u};   // outside the map: the 3x3's zero padding
+                *reinterpret_cast<u32x2*>(sY + p * CF_YP + (i * 16 + fc * 4) * 2) = o;
             }
         }
+        if (tile + (int)gridDim.x < ntile) xload(tile + gridDim.x);
         __syncthreads();
 
         // ---- phase 2: h = SiLU(3x3 over b) on the tile + 1 ---------------------------------------------------------------------------------
@@ -184,6 +195,7 @@ __global__ __launch_bounds__(CF_NT) void c3k2_fused_kernel(C3k2fArgs a) {
         __syncthreads();
 
         // ---- phase 4: y = SiLU(cv2 [a | b | m]): this wave = couts [wave * 16, +16), every pixel of the tile ---------------------------------
+        f32x4 gsum = {0.f, 0.f, 0.f, 0.f};   // channel sums of the STORED (bf16) values over this lane's pixels: the consumer's average pool
 #pragma unroll 1
         for (int j0 = 0; j0 < 16; j0 += 4) {
             f32x4 acc[4];
@@ -200,9 +212,22 @@ __global__ __launch_bounds__(CF_NT) void c3k2_fused_kernel(C3k2fArgs a) {
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = j0 + jj, r = j >> 1, xx = (j & 1) * 16 + fr;
                 const int oy = oy0 + r, ox = ox0 + xx;
-                if (oy < a.H && ox < a.W)
-                    store4(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4, silu_f(acc[jj].x), silu_f(acc[jj].y),
-                           silu_f(acc[jj].z), silu_f(acc[jj].w));
+                if (oy < a.H && ox < a.W) {
+                    const u32x2 o = cf_pack_silu(acc[jj]);
+                    *reinterpret_cast<u32x2*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = o;
+                    gsum.x += bf16lo(o.x); gsum.y += bf16hi(o.x); gsum.z += bf16lo(o.y); gsum.w += bf16hi(o.y);
+                }
+            }
+        }
+        if (a.gap_part) {   // fixed order: the lane's 16 pixels in tile order, then the 16 lanes of a channel quadruple pairwise
+#pragma unroll
+            for (int msk = 1; msk < 16; msk <<= 1) {
+                gsum.x += __shfl_xor(gsum.x, msk); gsum.y += __shfl_xor(gsum.y, msk);
+                gsum.z += __shfl_xor(gsum.z, msk); gsum.w += __shfl_xor(gsum.w, msk);
+            }
+            if (fr == 0) {
+                *reinterpret_cast<f32x4*>(a.gap_part + ((size_t)b * a.tiles_y * a.tiles_x + tyi * a.tiles_x + txi) * 128 + wave * 16 + fc * 4) = gsum;
+                if (a.flags && !(isfinite(gsum.x) && isfinite(gsum.y) && isfinite(gsum.z) && isfinite(gsum.w))) atomicOr(a.flags, YMK_FLAG_NONFINITE_INPUT);
             }
         }
         __syncthreads();   // the tiles are free for the next iteration
@@ -213,19 +238,23 @@ extern "C" int ymk_c3k2_fused_supported(int32_t dtype, int32_t c1, int32_t c2, i
     return dtype == YMK_BF16 && c1 == 64 && c2 == 128 && c == 32 && n == 1 && !c3k && shortcut;
 }
 
-extern "C" int ymk_c3k2_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, const void* w1, int32_t k1pad, const float* b1,
-                              const void* wa, int32_t kapad, const float* ba, const void* wb, int32_t kbpad, const float* bb, const void* w2,
-                              int32_t k2pad, const float* b2, void* y, int32_t ldy, void* stream) {
+extern "C" int32_t ymk_c3k2_fused_pool_chunks(int32_t H, int32_t W) { return ((H + CF_TH - 1) / CF_TH) * ((W + CF_TW - 1) / CF_TW); }
+
+extern "C" int ymk_c3k2_fused_pooled(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, const void* w1, int32_t k1pad, const float* b1,
+                                     const void* wa, int32_t kapad, const float* ba, const void* wb, int32_t kbpad, const float* bb,
+                                     const void* w2, int32_t k2pad, const float* b2, void* y, int32_t ldy, float* gap_part, int32_t* flags,
+                                     void* stream) {
     if (!x || !w1 || !b1 || !wa || !ba || !wb || !bb || !w2 || !b2 || !y) return YMK_E_BADARG;
     if (ldx % 8 || ldx < 64 || ldy % 4 || ldy < 128 || k1pad < 64 || kapad < 288 || kbpad < 160 || k2pad < 96 || (k1pad | kapad | kbpad | k2pad) % 8)
         return YMK_E_BADARG;
-    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return YMK_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7) || ((uintptr_t)gap_part & 15)) return YMK_E_BADARG;
     if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
     C3k2fArgs a;
     a.x = (const bf16_t*)x; a.w1 = (const bf16_t*)w1; a.wa = (const bf16_t*)wa; a.wb = (const bf16_t*)wb; a.w2 = (const bf16_t*)w2;
     a.b1 = b1; a.ba = ba; a.bb = bb; a.b2 = b2; a.y = (bf16_t*)y;
     a.B = B; a.H = H; a.W = W; a.ldx = ldx; a.ldy = ldy; a.k1pad = k1pad; a.kapad = kapad; a.kbpad = kbpad; a.k2pad = k2pad;
     a.tiles_x = (W + CF_TW - 1) / CF_TW; a.tiles_y = (H + CF_TH - 1) / CF_TH;
+    a.gap_part = gap_part; a.flags = flags;
     const int64_t ntile = (int64_t)B * a.tiles_x * a.tiles_y;
     if (ntile >= (1ll << 31) || (int64_t)B * H * W * (ldx > ldy ? ldx : ldy) >= (1ll << 40)) return YMK_E_BADARG;
 #ifdef YMK_MAX_BLOCKS
@@ -240,4 +269,10 @@ extern "C" int ymk_c3k2_fused(const void* x, int32_t ldx, int32_t B, int32_t H, 
     }
     hipLaunchKernelGGL(c3k2_fused_kernel, dim3(grid), dim3(CF_NT), CF_LDS_BYTES, (hipStream_t)stream, a);
     return ymk_launch_status();
+}
+
+extern "C" int ymk_c3k2_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, const void* w1, int32_t k1pad, const float* b1,
+                              const void* wa, int32_t kapad, const float* ba, const void* wb, int32_t kbpad, const float* bb, const void* w2,
+                              int32_t k2pad, const float* b2, void* y, int32_t ldy, void* stream) {
+    return ymk_c3k2_fused_pooled(x, ldx, B, H, W, w1, k1pad, b1, wa, kapad, ba, wb, kbpad, bb, w2, k2pad, b2, y, ldy, nullptr, nullptr, stream);
 }

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void route_finalize_kernel(
             for (int q = 0; q < 16; ++q) s += v[q];
         }
         for (; k < nchunk; ++k) s += pp[(size_t)k * C];
+        if (!isfinite(s)) atomicOr(flags, YMK_FLAG_NONFINITE_INPUT);   // (partials written by a producer kernel carry no flag of their own)
         pooled[c] = s / (float)HW;
     }
     __syncthreads();
@@ -291,6 +292,25 @@ extern "C" int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t 
     const size_t shm = (size_t)(C + hidden + E + E * hidden) * sizeof(float);
     hipLaunchKernelGGL(route_finalize_kernel, dim3(B), blk, shm, s, part, nchunk, HW, C, w1, b1, w2, b2, hidden,
                        E, top_k, dynamic_threshold, route_w, gate_w, sel, flags);
+    hipLaunchKernelGGL(route_csr_kernel, dim3(1), dim3(64), 0, s, sel, B, E, top_k, csr_off, csr_pair, route_w, state);
+    return ymk_launch_status();
+}
+
+// The router on per-chunk channel sums the PRODUCER of x already wrote (ymk_c3k2_fused_pooled): stage 1 — a full read of x — is skipped.
+// part fp32 [B][nchunk][C]: any partition of each image's pixels into nchunk chunks (sum over chunks = sum over H * W pixels).
+extern "C" int ymk_esmoe_route_pooled(const float* part, int32_t nchunk, int32_t B, int32_t H, int32_t W, int32_t C, const float* w1,
+                                      const float* b1, const float* w2, const float* b2, int32_t hidden, int32_t E, int32_t top_k,
+                                      float dynamic_threshold, float* route_w, float* gate_w, int32_t* sel, int32_t* csr_off,
+                                      int32_t* csr_pair, float* state, int32_t* flags, void* stream) {
+    if (!part || !w1 || !b1 || !w2 || !b2 || !route_w || !gate_w || !sel || !csr_off || !csr_pair || !flags) return YMK_E_BADARG;
+    if (nchunk < 1 || C % 4 || E < 1 || E > RT_MAX_E || top_k < 1 || top_k > E || hidden < 1 || hidden > RT_MAX_HID) return YMK_E_BADARG;
+    const int HW = H * W;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    if (B > 65535) return YMK_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t shm = (size_t)(C + hidden + E + E * hidden) * sizeof(float);
+    hipLaunchKernelGGL(route_finalize_kernel, dim3(B), dim3(256), shm, s, part, nchunk, HW, C, w1, b1, w2, b2, hidden, E, top_k,
+                       dynamic_threshold, route_w, gate_w, sel, flags);
     hipLaunchKernelGGL(route_csr_kernel, dim3(1), dim3(64), 0, s, sel, B, E, top_k, csr_off, csr_pair, route_w, state);
     return ymk_launch_status();
 }

@@ -272,18 +272,23 @@ def c3k2_fused_supported(dtype, c1: int, c2: int, c: int, n: int, c3k: bool, sho
         not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 8192)
 
 
-def c3k2_fused(x, p1, pa, pb, p2, out=None):
-    """C3k2 (c3k = False, n = 1, c = 32) as one kernel (include/ymk.h ymk_c3k2_fused).  p1 / pa / pb / p2 = (packed bf16 weights, fp32
-    bias) of cv1, m[0].cv1, m[0].cv2, cv2; x / out NHWC bf16 views."""
+def c3k2_fused(x, p1, pa, pb, p2, out=None, pool=True):
+    """C3k2 (c3k = False, n = 1, c = 32) as one kernel (include/ymk.h ymk_c3k2_fused_pooled).  p1 / pa / pb / p2 = (packed bf16 weights,
+    fp32 bias) of cv1, m[0].cv1, m[0].cv2, cv2; x / out NHWC bf16 views.  pool: the kernel also leaves the per-tile channel sums of its
+    output in `out.gap_part` (fp32 [B, chunks, 128]) — an ES-MoE router consuming `out` pools those instead of re-reading the map."""
     B, H, W, Cin, ldx = _nhwc(x)
     Cout = p2[0].shape[0]
     if out is None:
         out = new_act(B, H, W, Cout, x.dtype, x.device)
     ldy = _nhwc(out)[4]
+    part = torch.empty((B, lib.ymk_c3k2_fused_pool_chunks(H, W), Cout), dtype=torch.float32, device=x.device) if pool else None
     e0 = TIMER.begin()
-    check(lib.ymk_c3k2_fused(_p(x), ldx, B, H, W, _p(p1[0]), p1[0].shape[1], _p(p1[1]), _p(pa[0]), pa[0].shape[1], _p(pa[1]), _p(pb[0]),
-                             pb[0].shape[1], _p(pb[1]), _p(p2[0]), p2[0].shape[1], _p(p2[1]), _p(out), ldy, _stream()), "c3k2_fused")
+    check(lib.ymk_c3k2_fused_pooled(_p(x), ldx, B, H, W, _p(p1[0]), p1[0].shape[1], _p(p1[1]), _p(pa[0]), pa[0].shape[1], _p(pa[1]), _p(pb[0]),
+                                    pb[0].shape[1], _p(pb[1]), _p(p2[0]), p2[0].shape[1], _p(p2[1]), _p(out), ldy, _p(part), None, _stream()),
+          "c3k2_fused")
     TIMER.end(e0, "c3k2_fused", B * H * W * (Cin + Cout) * 2, 2 * B * H * W * (64 * 64 + 288 * 16 + 144 * 32 + 96 * 128), f"{Cin}->{Cout} @{H}x{W}")
+    if pool:
+        out.gap_part = part
     return out
 
 
@@ -318,13 +323,20 @@ def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
     csr_off = torch.empty((E + 1,), dtype=torch.int32, device=dev)
     csr_pair = torch.empty((B * top_k,), dtype=torch.int32, device=dev)
     state = torch.empty((E + 1,), dtype=torch.float32, device=dev)
-    nbytes = lib.ymk_esmoe_route_workspace_bytes(B, Cc, H, W)
-    ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
+    part = getattr(x, "gap_part", None)   # per-chunk channel sums left by the kernel that produced x (c3k2_fused)
     e0 = TIMER.begin()
-    check(lib.ymk_esmoe_route(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(w1), _p(b1), _p(w2), _p(b2), hidden, E, top_k,
-                              float(thr), _p(route_w), _p(gate_w), _p(sel), _p(csr_off), _p(csr_pair), _p(state),
-                              _p(flags), _p(ws), nbytes, _stream()), "esmoe_route")
-    TIMER.end(e0, "moe_route", B * H * W * Cc * x.element_size(), B * H * W * Cc, f"C{Cc} @{H}x{W}")
+    if part is not None and part.dtype == torch.float32 and part.dim() == 3 and part.shape[0] == B and part.shape[2] == Cc and part.is_contiguous():
+        check(lib.ymk_esmoe_route_pooled(_p(part), part.shape[1], B, H, W, Cc, _p(w1), _p(b1), _p(w2), _p(b2), hidden, E, top_k, float(thr),
+                                         _p(route_w), _p(gate_w), _p(sel), _p(csr_off), _p(csr_pair), _p(state), _p(flags), _stream()),
+              "esmoe_route_pooled")
+        TIMER.end(e0, "moe_route", part.numel() * 4, B * H * W * Cc, f"C{Cc} @{H}x{W} pooled")
+    else:
+        nbytes = lib.ymk_esmoe_route_workspace_bytes(B, Cc, H, W)
+        ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
+        check(lib.ymk_esmoe_route(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(w1), _p(b1), _p(w2), _p(b2), hidden, E, top_k,
+                                  float(thr), _p(route_w), _p(gate_w), _p(sel), _p(csr_off), _p(csr_pair), _p(state),
+                                  _p(flags), _p(ws), nbytes, _stream()), "esmoe_route")
+        TIMER.end(e0, "moe_route", B * H * W * Cc * x.element_size(), B * H * W * Cc, f"C{Cc} @{H}x{W}")
     return route_w, gate_w, sel, csr_off, csr_pair, state
 
 

@@ -25,13 +25,38 @@ struct DwTile {
     static constexpr int TH = TW == 40 ? 16 : 32;
     static constexpr int CB = 16;                             // channels per workgroup
     static constexpr int CPP = CB * (int)sizeof(T) / 16;      // 16-byte chunks per staged pixel (2 bf16 / 4 fp32)
-    static constexpr int PSB = CB * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16);  // padded LDS pixel stride (bytes)
     static constexpr int NCG = CB / 4;                        // 4-channel groups
     static constexpr int STRIPS = TW / DW_R;                  // x-strips per tile row
+    // LDS pixel stride (bytes).  bf16: a thread's 4 channels are one ds_read_b64, serviced 32 lanes at a time over 64 four-byte
+    // banks = (4 channel groups) x (x-strips) x (rows of the half wave); with pitch 32 (40-wide tiles: 4 strips, 2 rows) / 48
+    // (20-wide: 2 strips, 4 rows) and the row pitch below those 32 addresses cover the 64 banks exactly once.  The 40-byte
+    // pitch used before was 2-way conflicted on every stencil size (SQ_LDS_BANK_CONFLICT in profiles/r01_sq_pass2.json).
+    static constexpr int PSB = sizeof(T) == 2 ? (TW == 40 ? 32 : 48) : CB * (int)sizeof(T) + 16;
+    static constexpr int conflicts(int rp) {   // largest number of distinct addresses on one bank within a 32-lane group
+        int worst = 0;
+        for (int bank = 0; bank < 64; ++bank) {
+            int n = 0;
+            for (int l = 0; l < 32; ++l) {
+                const int cg = l % NCG, strip = (l / NCG) % STRIPS, y = l / (NCG * STRIPS);
+                const int d = (y * rp + strip * DW_R * PSB + cg * 8) / 4;
+                n += (d % 64 == bank) || ((d + 1) % 64 == bank);
+            }
+            worst = n > worst ? n : worst;
+        }
+        return worst;
+    }
+    static constexpr int row_pitch(int K) {    // bytes between staged rows
+        const int base = (TW + K - 1) * PSB;
+        if (sizeof(T) != 2) return base;
+        int best = base, bc = conflicts(base);
+        for (int extra = 8; extra <= 128 && bc > 1; extra += 8)
+            if (conflicts(base + extra) < bc) { bc = conflicts(base + extra); best = base + extra; }
+        return best;
+    }
     static constexpr int ROWL = 256 / (NCG * STRIPS);         // row lanes
     static_assert(TH == ROWL, "one output row per thread");
     static constexpr size_t lds_bytes(int K) {
-        return (size_t)(TH + K - 1) * (TW + K - 1) * PSB + (size_t)K * K * CB * sizeof(float);
+        return (size_t)(TH + K - 1) * row_pitch(K) + (size_t)K * K * CB * sizeof(float);
     }
 };
 
@@ -80,7 +105,8 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
     const int t = threadIdx.x;
     const int tiles_x = (W + TW - 1) / TW;
     const int c0 = cb * D::CB;
-    float* wsm = reinterpret_cast<float*>(smem + (size_t)HT * WT * D::PSB);
+    constexpr int RP = D::row_pitch(K);
+    float* wsm = reinterpret_cast<float*>(smem + (size_t)HT * RP);
 
     // filter block once: channel j of each 4-group at its register-quadruple position (see lds_ld4)
     for (int i = t; i < K * K * D::CB; i += 256) {
@@ -121,7 +147,8 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
         for (int l = 0; l < NL; ++l) {
             const int i = t + l * 256;
             if (i < HT * WT * CPP) {
-                u32x2* d = reinterpret_cast<u32x2*>(smem + (size_t)(i / CPP) * D::PSB + (i % CPP) * 16);
+                const int pix = i / CPP, hy = pix / WT;
+                u32x2* d = reinterpret_cast<u32x2*>(smem + (size_t)hy * RP + (pix - hy * WT) * D::PSB + (i % CPP) * 16);
                 d[0] = u32x2{stg[l].x, stg[l].y};
                 d[1] = u32x2{stg[l].z, stg[l].w};
             }
@@ -143,7 +170,7 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
                 const f32x4 t4 = *reinterpret_cast<const f32x4*>(wsm + (ky * K + kx) * D::CB + cg * 4);
                 wr[kx][0] = f32x2{t4.x, t4.y}; wr[kx][1] = f32x2{t4.z, t4.w};
             }
-            const char* row = smem + ((size_t)(y + ky) * WT + x0) * D::PSB + cg * 4 * sizeof(T);
+            const char* row = smem + (size_t)(y + ky) * RP + x0 * D::PSB + cg * 4 * sizeof(T);
 #pragma unroll
             for (int j = 0; j < DW_R + K - 1; ++j) {
                 f32x2 va, vb;

@@ -7,11 +7,10 @@ registration order, so reference checkpoints of the v0_10 moa / mot YAMLs load u
 dumped from the real reference).
 
 Host path: every module has its `_pack` (BN folds, grouped filters expanded to dense rows, channel padding to the
-kernels' vector width, constant vectors for window-padding tokens, host scalars) and `_run` (NHWC dataflow over libymk
-entry points).  It is written against the entry-point contracts in `ops.py`; the config-5 half of those contracts has no
-HIP kernel yet, so on a GPU box the first such call raises `ops.KernelNotBuilt` — there is no CPU or PyTorch fallback.
-The dataflow itself is verified on the CPU: with the entry points emulated (tests/emu_ops.py, test infrastructure) the
-modules and the whole config-5 detector reproduce the REAL reference's golden vectors (tests/test_host_mixture.py).
+kernels' vector width, constant vectors for window-padding tokens, host scalars) and `_run` (NHWC dataflow over libymk entry
+points, include/ymk_mixture.h).  There is no CPU or PyTorch fallback.  Validated on MI355X against the REAL reference's golden
+vectors (tests/test_gpu_mixture.py); the dataflow alone is also checked on the CPU with the entry points emulated
+(tests/emu_ops.py, test infrastructure) and with the kernel sources compiled for the host (tests/hostemu).
 
 Reference: ultralytics/nn/modules/moe/gated.py:82-1764, moe/experts.py:183-269, moe/_gated_visual.py:32-75,
 moa/{block,heads,router,wrappers}.py, mot/{block,experts,router,wrappers}.py.  Parameter containers are plain torch.nn
@@ -864,10 +863,9 @@ class _GlobalAttnHead(nn.Module):
 
 
 class MoABlock(YmkModule):
-    """moa/block.py:21-278 (eval, dense soft routing).  Host orchestration over libymk entry points; the kernels behind
-    the config-5 entry points (ops.py, second half) are next-round work, so on a GPU box the first of them raises
-    ``ops.KernelNotBuilt`` — the dataflow itself is checked on the CPU against the real reference's golden vectors
-    (tests/test_host_mixture.py)."""
+    """moa/block.py:21-278 (eval, dense soft routing).  Host orchestration over libymk entry points (include/ymk_mixture.h);
+    checked on MI355X (tests/test_gpu_mixture.py) and, dataflow only, on the CPU (tests/test_host_mixture.py) against the real
+    reference's golden vectors."""
 
     NUM_GROUPS = 3
 

@@ -4,7 +4,7 @@
 tensor); ``scale_detections`` is the batched form over the padded output of ``nms_padded`` (what
 ``DetectionPredictor.construct_result`` does per image, models/yolo/detect/predict.py:109-122).  The letterbox parameters
 are computed on the host with the reference's own arithmetic (Python doubles, round-half-even); the arithmetic on the boxes
-runs in libymk (``ymk_scale_boxes``, include/ymk_next.h) — opt-in (YMK_EXPERIMENTAL=1) until it has run on hardware; there is
+runs in libymk (``ymk_scale_boxes``, include/ymk_next.h; validated on MI355X, tests/test_gpu_next.py); there is
 no CPU / PyTorch fallback."""
 from __future__ import annotations
 

@@ -132,6 +132,16 @@ int ymk_c3k2_fused_pooled(const void* x, int32_t ldx, int32_t B, int32_t H, int3
                           const void* wa, int32_t kapad, const float* ba, const void* wb, int32_t kbpad, const float* bb, const void* w2,
                           int32_t k2pad, const float* b2, void* y, int32_t ldy, float* gap_part, int32_t* flags, void* stream);
 
+/* Detect class branch of one pyramid level as ONE kernel (bf16 in, fp32 logits out): DWConv3x3 -> Conv1x1 -> DWConv3x3 -> Conv1x1 ->
+ * Conv2d 1x1 (+bias) (head.py:111-118, non-legacy `cv3[i]`), c3 = 128, cin = 128 or 256.  The four intermediate maps stay in LDS
+ * (csrc/detcls.hip).  dw1 [9][cin] / dw2 [9][128] packed as for ymk_dwconv2d, pw1 [128][k1pad] / pw2 [128][k2pad] / w3 [ncpad][k3pad]
+ * as for ymk_conv2d, fp32 biases (BN folded); ncpad = nc rounded up to a multiple of 4 (padded rows zero); y fp32 [B][H][W][ldy]. */
+int ymk_detect_cls_fused_supported(int32_t dtype, int32_t cin, int32_t c3, int32_t nc);
+int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, int32_t cin, const void* dw1, const float* bd1,
+                         const void* pw1, int32_t k1pad, const float* bp1, const void* dw2, const float* bd2, const void* pw2,
+                         int32_t k2pad, const float* bp2, const void* w3, int32_t k3pad, const float* b3, int32_t ncpad, float* y,
+                         int32_t ldy, void* stream);
+
 /* ------------------------------------------------------------------------
  * Depthwise k x k convolution (stride 1, pad k/2, k odd <= 15) + bias + act
  * + residual.  Replaces DWConv (conv.py:185-199; Detect cv3 head.py:111-118),

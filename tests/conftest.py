@@ -49,7 +49,7 @@ def emu(monkeypatch):
 
 
 
-V0_OPS = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "esmoe_route", "esmoe_dw",
+V0_OPS = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "esmoe_route", "esmoe_dw",
           "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32", "detect_decode",
           "nms_batched"]
 
@@ -68,7 +68,7 @@ def hostlib():
         pytest.skip("no host clang++ to build the kernel emulation")
     h = C.CDLL(str(path))
     dw = {k: v for k, v in _lib.SYMBOLS.items() if k in ("ymk_dw_mfma_supported", "ymk_dw_toeplitz_elems", "ymk_dw_toeplitz_pack",
-                                                         "ymk_dwconv2d_mfma", "ymk_esmoe_dw_mfma", "ymk_mlp_fused_supported", "ymk_mlp_fused", "ymk_stem_pair_supported", "ymk_stem_pair", "ymk_c3k2_fused_supported", "ymk_c3k2_fused", "ymk_c3k2_fused_pool_chunks", "ymk_c3k2_fused_pooled")}   # csrc/dwmfma.hip, mlp.hip, stem2.hip
+                                                         "ymk_dwconv2d_mfma", "ymk_esmoe_dw_mfma", "ymk_mlp_fused_supported", "ymk_mlp_fused", "ymk_stem_pair_supported", "ymk_stem_pair", "ymk_c3k2_fused_supported", "ymk_c3k2_fused", "ymk_c3k2_fused_pool_chunks", "ymk_c3k2_fused_pooled", "ymk_detect_cls_fused_supported", "ymk_detect_cls_fused")}   # csrc/dwmfma.hip, mlp.hip, stem2.hip
     for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT, **dw}.items():   # SYMBOLS_NEXT includes csrc/preproc.hip
         fn = getattr(h, name)
         fn.restype, fn.argtypes = res, args

@@ -146,6 +146,20 @@ def c3k2_fused(x, p1, pa, pb, p2, out=None, pool=True):
     return conv2d(torch.cat([y1, m], -1), p2[0], p2[1], 1, 1, True, out=out)
 
 
+def detect_cls_fused_supported(dtype, cin, c3, nc):
+    return dtype == torch.bfloat16 and cin in (128, 256) and c3 == 128 and 1 <= nc <= 128
+
+
+def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None):
+    """include/ymk.h `ymk_detect_cls_fused`: DW3x3 -> 1x1 -> DW3x3 -> 1x1 (each + SiLU, rounded to bf16) -> 1x1 + bias, fp32 logits."""
+    _count("detect_cls_fused")
+    h = dwconv2d(x, d1[0], d1[1], 3, True)
+    h = conv2d(h, p1[0], p1[1], 1, 1, True)
+    h = dwconv2d(h, d2[0], d2[1], 3, True)
+    h = conv2d(h, p2[0], p2[1], 1, 1, True)
+    return conv2d(h, w3[0], w3[1], 1, 1, False, out=out, out_dtype=torch.float32)
+
+
 def mlp_fused_supported(dtype, C, hidden):
     return dtype == torch.bfloat16 and (C, hidden) in ((64, 128), (128, 256), (256, 512))
 
@@ -593,7 +607,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "esmoe_route", "esmoe_dw",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "weighted_sum",

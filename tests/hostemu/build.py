@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
 CSRC = ROOT / "yolo_master_amd" / "csrc"
 OUT = HERE / "_build"
-SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "dwmfma.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip"]
+SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "dwmfma.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip"]
 
 
 def compiler():

@@ -611,3 +611,25 @@ def test_esmoe_route_from_the_producers_pooled_sums():
     y.gap_part[0, 0, 5] = float("nan")                                     # a non-finite sum must raise the router's input flag
     ops.esmoe_route(y, w1, b1, w2, b2, 2, 0.3, flags)
     assert int(flags.item()) & 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_detcls", fromlist=["CASES"]).CASES + [(4, 80, 80, 128, 80), (3, 40, 40, 256, 80), (2, 20, 20, 256, 80)])
+def test_detect_cls_fused(case):
+    """Fused Detect class branch (csrc/detcls.hip) vs the five-convolution composition in torch (inside run_case) and vs the unfused
+    libymk kernels it replaces (same stage roundings; isolated bf16-ulp effects where a stage rounds the other way)."""
+    from tests.test_hostemu_detcls import operands, run_case
+    from yolo_master_amd import _lib, ops
+
+    got = run_case(_lib.load(), case, dev="cuda:0", stream=None)
+    torch.cuda.synchronize()
+    x, w, b, packed = operands(case)
+    pk, bd = {k: v.cuda() for k, v in packed.items()}, {k: v.cuda() for k, v in b.items()}
+    h = ops.dwconv2d(x.cuda(), pk["d1"], bd["d1"], 3, True)
+    h = ops.conv2d(h, pk["p1"], bd["p1"], 1, 1, True)
+    h = ops.dwconv2d(h, pk["d2"], bd["d2"], 3, True)
+    h = ops.conv2d(h, pk["p2"], bd["p2"], 1, 1, True)
+    y = ops.conv2d(h, pk["w3"], bd["w3"], 1, 1, False, out_dtype=torch.float32).cpu()
+    d = (y - got).abs()
+    scale = max(1.0, float(y.abs().max()))
+    assert float(d.max()) <= 4e-2 * scale and float(d.mean()) <= 3e-4 * scale, f"max {float(d.max()):.3e} mean {float(d.mean()):.3e}"

@@ -1,0 +1,69 @@
+"""Fused Detect class branch (csrc/detcls.hip: DWConv3x3 -> Conv1x1 -> DWConv3x3 -> Conv1x1 -> Conv2d 1x1, one kernel) on the CPU lane
+emulator against the five-convolution composition it replaces (torch fp32 arithmetic on bf16 operands, every stage rounded to bf16).
+Map sizes exercise the borders; nc values the padded / partial last fragment.  Shared with the GPU test."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+CASES = [(1, 8, 16, 128, 80), (1, 5, 7, 128, 3), (2, 11, 21, 256, 80), (1, 9, 33, 128, 20)]   # B, H, W, Cin, nc
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def operands(case):
+    from yolo_master_amd import ops
+
+    B, H, W, Cin, nc = case
+    g = torch.Generator().manual_seed(H * 100 + W + nc)
+    bf = torch.bfloat16
+    x = torch.randn(B, H, W, Cin, generator=g).to(bf)
+    ncpad = (nc + 3) // 4 * 4
+    w = {"d1": torch.randn(Cin, 1, 3, 3, generator=g) * 0.4, "p1": torch.randn(128, Cin, 1, 1, generator=g) * Cin ** -0.5,
+         "d2": torch.randn(128, 1, 3, 3, generator=g) * 0.4, "p2": torch.randn(128, 128, 1, 1, generator=g) * 128 ** -0.5,
+         "w3": torch.cat([torch.randn(nc, 128, 1, 1, generator=g) * 128 ** -0.5, torch.zeros(ncpad - nc, 128, 1, 1)])}
+    b = {k: torch.randn(v.shape[0], generator=g) * 0.3 for k, v in w.items()}
+    b["w3"][nc:] = 0
+    packed = {k: (ops.pack_dw_weight(v, bf) if k[0] == "d" else ops.pack_conv_weight(v, bf)) for k, v in w.items()}
+    return x, w, b, packed
+
+
+def reference(x, w, b):
+    bf = torch.bfloat16
+    t = x.float().permute(0, 3, 1, 2)
+    for k in ("d1", "p1", "d2", "p2"):
+        wk = w[k].to(bf).float()
+        t = F.conv2d(t, wk, b[k], 1, 1, 1, t.shape[1]) if k[0] == "d" else F.conv2d(t, wk, b[k])
+        t = F.silu(t).to(bf).float()
+    return F.conv2d(t, w["w3"].to(bf).float(), b["w3"]).permute(0, 2, 3, 1)
+
+
+def run_case(lib, case, dev="cpu", stream=None):
+    B, H, W, Cin, nc = case
+    x, w, b, packed = operands(case)
+    ref = reference(x, w, b)
+    ncpad = (nc + 3) // 4 * 4
+    xd = x.to(dev)
+    yb = torch.full((B, H, W, ncpad + 4), 7.0, dtype=torch.float32, device=dev)
+    pk = {k: v.to(dev) for k, v in packed.items()}
+    bd = {k: v.to(dev) for k, v in b.items()}
+    assert lib.ymk_detect_cls_fused_supported(1, Cin, 128, nc) and not lib.ymk_detect_cls_fused_supported(1, 64, 128, nc)
+    rc = lib.ymk_detect_cls_fused(_p(xd), xd.stride(2), B, H, W, Cin, _p(pk["d1"]), _p(bd["d1"]), _p(pk["p1"]), pk["p1"].shape[1], _p(bd["p1"]),
+                                  _p(pk["d2"]), _p(bd["d2"]), _p(pk["p2"]), pk["p2"].shape[1], _p(bd["p2"]), _p(pk["w3"]), pk["w3"].shape[1],
+                                  _p(bd["w3"]), ncpad, _p(yb), yb.stride(2), stream)
+    assert rc == 0
+    got = yb[..., :ncpad].cpu()
+    err = (got - ref).abs()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float(err.max()) <= 4e-2 * scale, f"{case}: max err {float(err.max()):.3e}"
+    assert float(err.mean()) <= 3e-3 * scale, f"{case}: mean err {float(err.mean()):.3e}"
+    assert bool((yb[..., ncpad:].cpu() == 7.0).all()), "bytes between pixels were touched"
+    return got
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_detect_cls_fused_on_emulator(case, hostlib):
+    run_case(hostlib, case)

@@ -19,7 +19,7 @@ LIB = HERE / "libymk.so"
 ARCH = "gfx950"
 # files whose arithmetic must not be contracted into FMAs (bit-exact NMS / decode)
 NO_CONTRACT = {"nms.hip", "elementwise.hip", "post.hip", "preproc.hip"}
-SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "dwmfma.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "esmoe.hip", "dwpw.hip", "attn.hip", "elementwise.hip", "nms.hip",
+SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "dwmfma.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip", "esmoe.hip", "dwpw.hip", "attn.hip", "elementwise.hip", "nms.hip",
            "mixture.hip", "mixattn.hip",   # config-5 rows, first implementation (include/ymk_mixture.h)
            "conv_glds.hip", "post.hip", "preproc.hip"]    # opt-in: next tiled convolution core, box rescaling (include/ymk_next.h)
 HEADERS = ["ymk_common.h", "igemm.h", "../../include/ymk.h", "../../include/ymk_mixture.h", "../../include/ymk_next.h"]

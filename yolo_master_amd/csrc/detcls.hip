@@ -1,0 +1,234 @@
+// Detect class branch as ONE kernel (bf16): DWConv3x3 -> Conv1x1 -> DWConv3x3 -> Conv1x1 -> Conv2d 1x1 (+bias) -> fp32 class logits
+// (ultralytics/nn/modules/head.py:111-118: `cv3[i] = Sequential(Sequential(DWConv(x, x, 3), Conv(x, c3, 1)),
+// Sequential(DWConv(c3, c3, 3), Conv(c3, c3, 1)), Conv2d(c3, nc, 1))`, every Conv / DWConv = convolution + folded BN + SiLU), for
+// c3 = 128 and x = 128 or 256 input channels (the three pyramid levels of YOLO-Master-S / -N ...: c3 = max(ch[0], min(nc, 100))).
+//
+// As five kernels a level writes and re-reads four [B, H, W, 128] maps; here a persistent 8-wave workgroup owns an 8 x 16 pixel tile
+// and keeps them in LDS (121 KB): HBM sees the level's input once (with a 2-pixel halo, served by L2) and the logits once.
+//   stage   x on the tile + 2, in 128-channel chunks (zero outside the map = DWConv's padding)
+//   dw1     3x3 stencil on the tile + 1 (VALU, 4 channels x 11-12 pixels per thread), bias, SiLU -> LDS
+//   pw1     1x1 (K = x channels, accumulated over the chunks) on the tile + 1: each wave owns 16 output channels, its weight rows
+//           resident as MFMA A fragments; bias, SiLU, ZERO outside the map (the second DWConv's padding) -> LDS
+//   dw2     3x3 on the tile -> LDS;  pw2  1x1 128 -> 128 -> LDS;  out  1x1 128 -> nc (+ bias), fp32 store
+// Arithmetic per stage as the unfused kernels' (bf16 operands, fp32 accumulation, one rounding to bf16 per stage).
+#include "ymk_common.h"
+
+#define DC_TH 8
+#define DC_TW 16
+#define DC_XR (DC_TH + 4)
+#define DC_XC (DC_TW + 4)
+#define DC_NX (DC_XR * DC_XC)        // 240 input pixels of a tile
+#define DC_MR (DC_TH + 2)
+#define DC_MC (DC_TW + 2)
+#define DC_NMID (DC_MR * DC_MC)      // 180 pixels of the first pair's maps
+#define DC_NP (DC_TH * DC_TW)        // 128 tile pixels
+#define DC_PITCH 288                 // LDS pitch of a 128-channel pixel (bytes): 256 + 32, conflict-free b128 fragment reads
+#define DC_NT 512
+#define DC_A_BYTES (DC_NX * DC_PITCH)        // region A: x chunk, then pw1's map, then pw2's map
+#define DC_B_BYTES (DC_NMID * DC_PITCH)      // region B: dw1's map, then dw2's map
+#define DC_LDS_BYTES (DC_A_BYTES + DC_B_BYTES)
+
+typedef __bf16 dc_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void dc_mma(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dc_bf16x8, a), __builtin_bit_cast(dc_bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ u32x2 dc_pack_silu(const f32x4& v) {
+    u32x2 o;
+    o.x = pack_bf16x2(silu_f(v.x), silu_f(v.y));
+    o.y = pack_bf16x2(silu_f(v.z), silu_f(v.w));
+    return o;
+}
+
+struct DetClsArgs {
+    const bf16_t* x;                         // [B][H][W][ldx], CIN channels
+    const bf16_t *dw1, *pw1, *dw2, *pw2, *w3;   // dw: [9][C]; pw1 [128][k1pad]; pw2 [128][k2pad]; w3 [ncpad][k3pad]
+    const float *bd1, *bp1, *bd2, *bp2, *b3;
+    float* y;                                // [B][H][W][ldy] fp32 logits (ncpad channels written)
+    int B, H, W, ldx, ldy, k1pad, k2pad, k3pad, ncpad, tiles_x, tiles_y;
+};
+
+// 3x3 depthwise stencil + bias + SiLU for this thread's 4 channels: output pixels s, s + 16, ... < npix of an (orow x ocol) map read
+// from an input tile of row length icol whose origin is one pixel up / left of the output map's
+template <int CTOT>
+__device__ __forceinline__ void dc_dw3(const char* in, int icol, char* out, int npix, int ocol, const bf16_t* w, int coff, const float* bias,
+                                       int cg, int s) {
+    float wt[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const u32x2 q = *reinterpret_cast<const u32x2*>(w + (size_t)tap * CTOT + coff + cg * 4);
+        wt[tap][0] = bf16lo(q.x); wt[tap][1] = bf16hi(q.x); wt[tap][2] = bf16lo(q.y); wt[tap][3] = bf16hi(q.y);
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + coff + cg * 4);
+    for (int p = s; p < npix; p += DC_NT / 32) {
+        const int u = p / ocol, v = p - u * ocol;
+        f32x4 acc = bv;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const u32x2 q = *reinterpret_cast<const u32x2*>(in + ((u + ky) * icol + v + kx) * DC_PITCH + cg * 8);
+            acc.x = __builtin_fmaf(bf16lo(q.x), wt[tap][0], acc.x);
+            acc.y = __builtin_fmaf(bf16hi(q.x), wt[tap][1], acc.y);
+            acc.z = __builtin_fmaf(bf16lo(q.y), wt[tap][2], acc.z);
+            acc.w = __builtin_fmaf(bf16hi(q.y), wt[tap][3], acc.w);
+        }
+        *reinterpret_cast<u32x2*>(out + p * DC_PITCH + cg * 8) = dc_pack_silu(acc);
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
+    constexpr int NCH = CIN / 128;            // 128-channel chunks of the input
+    constexpr int NF1 = (DC_NMID + 15) / 16;   // 12 pixel fragments of the first pair's maps
+    extern __shared__ u32x4 dc_smem[];
+    char* sA = reinterpret_cast<char*>(dc_smem);
+    char* sB = sA + DC_A_BYTES;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int cg = t & 31, sl = t >> 5;        // stencil stages: 4-channel group x pixel slot
+    const int ntile = a.B * a.tiles_y * a.tiles_x;
+
+    // resident pointwise weights: this wave's 16 output channels
+    u32x4 af1[NCH * 4], af2[4], af3[4];
+#pragma unroll
+    for (int s = 0; s < NCH * 4; ++s) af1[s] = *reinterpret_cast<const u32x4*>(a.pw1 + (size_t)(wave * 16 + fr) * a.k1pad + s * 32 + fc * 8);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        af2[s] = *reinterpret_cast<const u32x4*>(a.pw2 + (size_t)(wave * 16 + fr) * a.k2pad + s * 32 + fc * 8);
+        af3[s] = u32x4{0u, 0u, 0u, 0u};
+        if (wave * 16 + fr < a.ncpad) af3[s] = *reinterpret_cast<const u32x4*>(a.w3 + (size_t)(wave * 16 + fr) * a.k3pad + s * 32 + fc * 8);
+    }
+    const f32x4 bv1 = *reinterpret_cast<const f32x4*>(a.bp1 + wave * 16 + fc * 4);
+    const f32x4 bv2 = *reinterpret_cast<const f32x4*>(a.bp2 + wave * 16 + fc * 4);
+    f32x4 bv3 = {0.f, 0.f, 0.f, 0.f};
+    if (wave * 16 + fc * 4 < a.ncpad) bv3 = *reinterpret_cast<const f32x4*>(a.b3 + wave * 16 + fc * 4);
+
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int txi = tile % a.tiles_x, r0 = tile / a.tiles_x;
+        const int tyi = r0 % a.tiles_y, b = r0 / a.tiles_y;
+        const int oy0 = tyi * DC_TH, ox0 = txi * DC_TW;
+        const bf16_t* xb = a.x + (size_t)b * a.H * a.W * a.ldx;
+
+        f32x4 acc1[NF1];
+#pragma unroll
+        for (int j = 0; j < NF1; ++j) acc1[j] = bv1;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {   // (unrolled: the fragment array is indexed by ch)
+            // ---- stage: x chunk on the tile + 2 -> region A -----------------------------------------------------------------------------
+            {
+                constexpr int NL = (DC_NX * 16 + DC_NT - 1) / DC_NT;   // 16-byte pieces per thread (8)
+                u32x4 v[NL];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int i = t + l * DC_NT;
+                    const int px = i >> 4, q = i & 15;
+                    const int u = px / DC_XC, w = px - u * DC_XC;
+                    const int iy = oy0 - 2 + u, ix = ox0 - 2 + w;
+                    v[l] = u32x4{0u, 0u, 0u, 0u};
+                    if (px < DC_NX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                        v[l] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.ldx + ch * 128 + q * 8);
+                }
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int i = t + l * DC_NT;
+                    if ((i >> 4) < DC_NX) *reinterpret_cast<u32x4*>(sA + (i >> 4) * DC_PITCH + (i & 15) * 16) = v[l];
+                }
+            }
+            __syncthreads();
+            // ---- dw1: region A -> region B (tile + 1) -------------------------------------------------------------------------------------
+            dc_dw3<CIN>(sA, DC_XC, sB, DC_NMID, DC_MC, a.dw1, ch * 128, a.bd1, cg, sl);
+            __syncthreads();
+            // ---- pw1: K chunk ch ----------------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < NF1; ++j) {
+                int px = j * 16 + fr;
+                px = px < DC_NMID ? px : 0;
+                const char* pb = sB + px * DC_PITCH + fc * 16;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dc_mma(acc1[j], af1[ch * 4 + s], *reinterpret_cast<const u32x4*>(pb + s * 64));
+            }
+            if (ch + 1 < NCH) __syncthreads();   // region A / B are restaged for the next chunk
+        }
+        // pw1 epilogue -> region A (the x chunk is dead: every wave is past its dw1)
+#pragma unroll
+        for (int j = 0; j < NF1; ++j) {
+            const int px = j * 16 + fr;
+            if (px < DC_NMID) {
+                const int u = px / DC_MC, v = px - u * DC_MC;
+                const int my = oy0 - 1 + u, mx = ox0 - 1 + v;
+                const bool inside = (unsigned)my < (unsigned)a.H && (unsigned)mx < (unsigned)a.W;
+                *reinterpret_cast<u32x2*>(sA + px * DC_PITCH + (wave * 16 + fc * 4) * 2) = inside ? dc_pack_silu(acc1[j]) : u32x2{0u, 0u};
+            }
+        }
+        __syncthreads();
+        // ---- dw2: region A (tile + 1) -> region B (tile) -------------------------------------------------------------------------------------
+        dc_dw3<128>(sA, DC_MC, sB, DC_NP, DC_TW, a.dw2, 0, a.bd2, cg, sl);
+        __syncthreads();
+        // ---- pw2: region B -> region A ----------------------------------------------------------------------------------------------------------
+        {
+            f32x4 acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] = bv2;
+                const char* pb = sB + (j * 16 + fr) * DC_PITCH + fc * 16;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dc_mma(acc[j], af2[s], *reinterpret_cast<const u32x4*>(pb + s * 64));
+            }
+            // region A still holds pw1's map, which dw2 of OTHER waves may be reading: they are past the barrier above, so it is free
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<u32x2*>(sA + (j * 16 + fr) * DC_PITCH + (wave * 16 + fc * 4) * 2) = dc_pack_silu(acc[j]);
+        }
+        __syncthreads();
+        // ---- out: 1x1 128 -> nc, fp32 logits -------------------------------------------------------------------------------------------------------
+        if (wave * 16 < a.ncpad) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 acc = bv3;
+                const char* pb = sA + (j * 16 + fr) * DC_PITCH + fc * 16;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dc_mma(acc, af3[s], *reinterpret_cast<const u32x4*>(pb + s * 64));
+                const int oy = oy0 + j, ox = ox0 + fr;   // fragment j = tile row j (16 pixels)
+                if (oy < a.H && ox < a.W && wave * 16 + fc * 4 < a.ncpad)
+                    *reinterpret_cast<f32x4*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = acc;
+            }
+        }
+        __syncthreads();   // region A is restaged by the next tile
+    }
+}
+
+extern "C" int ymk_detect_cls_fused_supported(int32_t dtype, int32_t cin, int32_t c3, int32_t nc) {
+    return dtype == YMK_BF16 && (cin == 128 || cin == 256) && c3 == 128 && nc >= 1 && nc <= 128;
+}
+
+extern "C" int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, int32_t cin, const void* dw1, const float* bd1,
+                                    const void* pw1, int32_t k1pad, const float* bp1, const void* dw2, const float* bd2, const void* pw2,
+                                    int32_t k2pad, const float* bp2, const void* w3, int32_t k3pad, const float* b3, int32_t ncpad, float* y,
+                                    int32_t ldy, void* stream) {
+    if (!x || !dw1 || !bd1 || !pw1 || !bp1 || !dw2 || !bd2 || !pw2 || !bp2 || !w3 || !b3 || !y) return YMK_E_BADARG;
+    if (!ymk_detect_cls_fused_supported(YMK_BF16, cin, 128, ncpad) || ncpad % 4 || ldx % 8 || ldx < cin || ldy % 4 || ldy < ncpad ||
+        k1pad < cin || k2pad < 128 || k3pad < 128 || (k1pad | k2pad | k3pad) % 8)
+        return YMK_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return YMK_E_BADARG;
+    if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
+    DetClsArgs a;
+    a.x = (const bf16_t*)x; a.dw1 = (const bf16_t*)dw1; a.pw1 = (const bf16_t*)pw1; a.dw2 = (const bf16_t*)dw2; a.pw2 = (const bf16_t*)pw2;
+    a.w3 = (const bf16_t*)w3; a.bd1 = bd1; a.bp1 = bp1; a.bd2 = bd2; a.bp2 = bp2; a.b3 = b3; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.ldx = ldx; a.ldy = ldy; a.k1pad = k1pad; a.k2pad = k2pad; a.k3pad = k3pad; a.ncpad = ncpad;
+    a.tiles_x = (W + DC_TW - 1) / DC_TW; a.tiles_y = (H + DC_TH - 1) / DC_TH;
+    const int64_t ntile = (int64_t)B * a.tiles_x * a.tiles_y;
+    if (ntile >= (1ll << 31)) return YMK_E_BADARG;
+#ifdef YMK_MAX_BLOCKS
+    const unsigned grid = (unsigned)(ntile < YMK_MAX_BLOCKS ? ntile : YMK_MAX_BLOCKS);
+#else
+    const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);   // one persistent workgroup per CU (121 KB of LDS)
+#endif
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
+        attr_set = true;
+    }
+    if (cin == 128) hipLaunchKernelGGL(detect_cls_kernel<128>, dim3(grid), dim3(DC_NT), DC_LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(detect_cls_kernel<256>, dim3(grid), dim3(DC_NT), DC_LDS_BYTES, (hipStream_t)stream, a);
+    return ymk_launch_status();
+}

@@ -573,6 +573,17 @@ class Detect(YmkModule):
                 x = m._run(x)
         return x
 
+    def _cls_fusable(self, i, f):
+        seq = self.cv3[i]
+        if self.legacy or len(seq) != 3 or not all(isinstance(seq[j], nn.Sequential) and len(seq[j]) == 2 for j in (0, 1)):
+            return False
+        d1, p1, d2, p2 = seq[0][0], seq[0][1], seq[1][0], seq[1][1]
+        ok = all(isinstance(m, DWConv) and m.conv.kernel_size == (3, 3) and m.conv.stride == (1, 1) and m.conv.groups == m.conv.in_channels
+                 and _is_silu(m.act) for m in (d1, d2))
+        ok = ok and all(type(m) is Conv and m.conv.kernel_size == (1, 1) and m.conv.groups == 1 and _is_silu(m.act) for m in (p1, p2))
+        return ok and ops.detect_cls_fused_supported(f.dtype, d1.conv.in_channels, p1.conv.out_channels, self.nc) and \
+            p2.conv.out_channels == p1.conv.out_channels
+
     def _run(self, feats):
         """feats: list of NHWC maps.  Returns (y [B, 4+nc, A] fp32, raw) with raw = per-level
         (box_logits [B,H,W,4*reg_max], cls_logits [B,H,W,nc]) fp32 NHWC tensors."""
@@ -591,8 +602,15 @@ class Detect(YmkModule):
         def level(i, f):
             hb = self._branch(self.cv2[i], f)
             box = ops.conv2d(hb, pk["box"][i][0], pk["box"][i][1], 1, 1, False, out_dtype=torch.float32)
-            hc = self._branch(self.cv3[i], f)
-            cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)[..., : self.nc]
+            if self._cls_fusable(i, f):
+                # the class branch of the level as one kernel: its four [B, H, W, 128] intermediates stay in LDS (csrc/detcls.hip)
+                s0, s1 = self.cv3[i][0], self.cv3[i][1]
+                q = [m._packed(f.device) for m in (s0[0], s0[1], s1[0], s1[1])]
+                cls = ops.detect_cls_fused(f, (q[0]["w"], q[0]["b"]), (q[1]["w"], q[1]["b"]), (q[2]["w"], q[2]["b"]), (q[3]["w"], q[3]["b"]),
+                                           pk["cls"][i])[..., : self.nc]
+            else:
+                hc = self._branch(self.cv3[i], f)
+                cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)[..., : self.nc]
             ops.detect_decode(box, cls, y, float(self.stride[i]), offs[i], self.reg_max)
             raw[i] = (box, cls)
 

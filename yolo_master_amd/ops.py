@@ -292,6 +292,29 @@ def c3k2_fused(x, p1, pa, pb, p2, out=None, pool=True):
     return out
 
 
+def detect_cls_fused_supported(dtype, cin: int, c3: int, nc: int) -> bool:
+    """YMK_DISABLE bit 16384 switches the fused Detect class branch off (-> its five convolutions) for A/B runs."""
+    return dtype in DT and bool(lib.ymk_detect_cls_fused_supported(DT[dtype], cin, c3, nc)) and \
+        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 16384)
+
+
+def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None):
+    """One pyramid level's Detect class branch as one kernel (include/ymk.h ymk_detect_cls_fused).  d1 / d2 = (packed depthwise weights
+    [9][C], fp32 bias), p1 / p2 = (packed 1x1 weights, fp32 bias), w3 = (packed [ncpad][Kpad], fp32 bias); returns fp32 [B, H, W, ncpad]."""
+    B, H, W, Cin, ldx = _nhwc(x)
+    ncpad = w3[0].shape[0]
+    if out is None:
+        out = torch.empty((B, H, W, ncpad), dtype=torch.float32, device=x.device)
+    ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_detect_cls_fused(_p(x), ldx, B, H, W, Cin, _p(d1[0]), _p(d1[1]), _p(p1[0]), p1[0].shape[1], _p(p1[1]), _p(d2[0]), _p(d2[1]),
+                                   _p(p2[0]), p2[0].shape[1], _p(p2[1]), _p(w3[0]), w3[0].shape[1], _p(w3[1]), ncpad, _p(out), ldy, _stream()),
+          "detect_cls_fused")
+    TIMER.end(e0, "detect_cls_fused", B * H * W * (Cin * 2 + ncpad * 4), 2 * B * H * W * (9 * Cin + Cin * 128 + 9 * 128 + 128 * 128 + 128 * ncpad),
+              f"{Cin}->128->{ncpad} @{H}x{W}")
+    return out
+
+
 def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
     B, H, W, Cc, ldx = _nhwc(x)
     if out is None:

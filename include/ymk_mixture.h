@@ -101,6 +101,12 @@ int ymk_gated_route_decide(const float* g, int32_t ldg, const float* loc, int32_
 int ymk_expert_gather(int32_t dtype, const void* f_all, int32_t ldf, const int32_t* idx, int32_t B, int32_t HW,
                       int32_t OC, int32_t K, int32_t E, void* out, void* stream);
 
+/* Per-image expert depthwise 3x3 with a per-expert dilation (DiversifiedExpertGroup.dw_layers, moe/gated.py:2265-2278): out[(j*B + b)]
+ * = dw3x3(x[b]; w[idx[b][j]], dilation dil[idx[b][j]], zero padding = dilation), slot-major like ymk_expert_gather; w [E][9][C] in
+ * the compute dtype, dil int32 [E], idx int32 [B][K]; no bias, no activation (a GroupNorm follows). */
+int ymk_expert_dw3(int32_t dtype, const void* x, int32_t ldx, const void* w, const int32_t* dil, const int32_t* idx, int32_t B,
+                   int32_t H, int32_t W, int32_t C, int32_t K, int32_t E, void* out, void* stream);
+
 /* out[..][j*groups + i] = cat(a, b)[..][i*(C/groups) + j], C = Ca + Cb (_channel_shuffle, moe/gated.py:1333-1338). */
 int ymk_channel_shuffle_cat(int32_t dtype, const void* a, int32_t lda, int32_t Ca, const void* b, int32_t ldb, int32_t Cb,
                             int32_t groups, void* y, int32_t ldy, int64_t npix, void* stream);

@@ -286,6 +286,27 @@ def plain_fused_experts(sd, p, x, weights, indices, num_experts, num_groups=8):
     return (n * weights.view(B, k, 1, 1, 1)).sum(dim=1)
 
 
+def diversified_experts(sd, p, x, weights, indices, num_groups=8):
+    """DiversifiedExpertGroup.forward, eager path (gated.py:2296-2330): shared 1x1 expand -> GN -> SiLU once; every ACTIVE expert
+    (ascending index) runs its own dilated depthwise 3x3 (dilation 1 + i // 2) -> GN -> SiLU and its 1x1 projection -> GN on the images
+    that routed to it with a positive weight; weighted index_add_ in that order."""
+    B, _, H, W = x.shape
+    k = weights.shape[1]
+    h = F.silu(_gn(sd, f"{p}.shared_expand.1", F.conv2d(x, sd[f"{p}.shared_expand.0.weight"]), num_groups))
+    idx = indices.reshape(B, -1)[:, :k].to(torch.long)
+    w = weights.reshape(B, -1)[:, :k]
+    valid = w > 0.0
+    out = x.new_zeros(B, sd[f"{p}.expert_projections.0.0.weight"].shape[0], H, W)
+    for e in torch.unique(idx[valid]).to(torch.long).tolist():
+        d = 1 + e // 2
+        f = F.conv2d(h, sd[f"{p}.dw_layers.{e}.0.weight"], None, 1, d, d, h.shape[1])
+        f = F.silu(_gn(sd, f"{p}.dw_layers.{e}.1", f, num_groups))
+        bi, ki = torch.where((idx == e) & valid)
+        eo = _gn(sd, f"{p}.expert_projections.{e}.1", F.conv2d(f[bi], sd[f"{p}.expert_projections.{e}.0.weight"]), num_groups)
+        out.index_add_(0, bi, (eo * w[bi, ki].view(-1, 1, 1, 1).to(eo.dtype)).to(out.dtype))
+    return out
+
+
 def cross_path_gate(sd, p, s, d):
     """CrossPathGate.forward (gated.py:2398-2428): gate = 0.5 + tanh(gate_scale) * 0.5 * sigmoid(MLP(GAP(cat[s, d]))); the first
     Cs / next Cd entries scale the static / dynamic outputs; returns their concatenation."""
@@ -319,7 +340,9 @@ def optimal_hybrid_moe(sd, p, x, num_experts=4, top_k=2, split_ratio=0.5, num_gr
     w = complexity_gate(w, cplx)
     if info is not None:
         info[p] = {"weights": w, "indices": idx, "probs": probs, "complexity": cplx}
-    if f"{p}.fused_experts.shared_feature.0.weight" in sd:
+    if f"{p}.fused_experts.shared_expand.0.weight" in sd:            # DiversifiedExpertMoE (v0_14, :2499-2561)
+        d = diversified_experts(sd, f"{p}.fused_experts", xd, w, idx, num_groups)
+    elif f"{p}.fused_experts.shared_feature.0.weight" in sd:
         d = shared_inverted_experts(sd, f"{p}.fused_experts", xd, w, idx)
     else:
         d = plain_fused_experts(sd, f"{p}.fused_experts", xd, w, idx, num_experts, num_groups)

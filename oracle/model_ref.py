@@ -344,7 +344,7 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
             cur = gated_ref.adaptive_gate_chain(sd, p, cur, num_experts=args[1], top_k=args[2], split_ratio=args[3] if len(args) > 3 else 0.5,
                                                 temperature=1.0 if plain else 1.2, shuffle_groups=1 if plain else 2,
                                                 complexity_after_hooks=not plain, info=moe_info)
-        elif m in ("OptimalHybridGateMoE", "GatedFusionMoE", "MultiHeadRouterMoE"):   # v0_12 / v0_15 rows: [c2, num_experts, top_k, split_ratio]
+        elif m in ("OptimalHybridGateMoE", "GatedFusionMoE", "MultiHeadRouterMoE", "DiversifiedExpertMoE"):   # v0_12 / v0_15 rows: [c2, num_experts, top_k, split_ratio]
             from . import gated_ref
             cur = gated_ref.optimal_hybrid_moe(sd, p, cur, num_experts=args[1], top_k=args[2],
                                                split_ratio=args[3] if len(args) > 3 else 0.5, cross_gate=m == "GatedFusionMoE",

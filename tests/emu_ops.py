@@ -584,6 +584,22 @@ def expert_conv(x, w_packed, k, idx, out=None):
     return _put(torch.cat(ys).permute(0, 2, 3, 1), out, x.dtype)
 
 
+def expert_dw3(x, w, dil, idx, out=None):
+    """include/ymk_mixture.h `ymk_expert_dw3`."""
+    _count("expert_dw3")
+    B, H, W, C = x.shape
+    K = idx.shape[1]
+    xn = x.float().permute(0, 3, 1, 2)
+    ys = []
+    for j in range(K):
+        for b in range(B):
+            e = int(idx[b, j])
+            d = int(dil[e])
+            wk = w[e].float().t().reshape(C, 1, 3, 3)
+            ys.append(F.conv2d(xn[b:b + 1], wk, None, 1, d, d, C))
+    return _put(torch.cat(ys).permute(0, 2, 3, 1), out, x.dtype)
+
+
 def channel_shuffle_cat(parts, groups, out=None):
     _count("channel_shuffle_cat")
     cat = torch.cat(parts, -1)
@@ -612,5 +628,5 @@ EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported
             "detect_decode", "nms_batched",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",
-            "linear_attention", "deform_attention", "token_softmax", "gated_route_decide", "expert_conv", "channel_shuffle_cat",
+            "linear_attention", "deform_attention", "token_softmax", "gated_route_decide", "expert_conv", "expert_dw3", "channel_shuffle_cat",
             "pixel_shuffle2", "tokens_to_rows"]

@@ -160,6 +160,12 @@ if __name__ == "__main__":
         case_v2("mh_e16", ref_gated.MultiHeadRouterMoE, 128, varied(3, 128, 8, 8), 42, tweak=live13, num_experts=16, top_k=2, split_ratio=0.375)
         case_v2("mh_h3", ref_gated.MultiHeadRouterMoE, 128, varied(2, 128, 6, 7), 43, tweak=live13, num_experts=6, top_k=3, num_heads=3)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "v14":    # DiversifiedExpertMoE (v0_14) -> gated2_div_*.npz
+        case_v2("div_base", ref_gated.DiversifiedExpertMoE, 128, varied(3, 128, 12, 16), 51, tweak=live_gates)
+        case_v2("div_e16", ref_gated.DiversifiedExpertMoE, 128, varied(3, 128, 20, 18), 52, tweak=live_gates, num_experts=16, top_k=2, split_ratio=0.375)
+        case_v2("div_k3", ref_gated.DiversifiedExpertMoE, 128, varied(2, 128, 6, 7), 53, tweak=live_gates, num_experts=6, top_k=3)
+        case_v2("div_keep1", ref_gated.DiversifiedExpertMoE, 128, varied(2, 128, 9, 9), 54, tweak=lambda sd: (live_gates(sd), low_complexity(sd)))
+        sys.exit(0)
     case_v2("opt_base", OptimalHybridGateMoE, 128, varied(3, 128, 12, 16), 11, tweak=live_gates)
     case_v2("opt_e16", OptimalHybridGateMoE, 128, varied(3, 128, 8, 8), 12, tweak=live_gates, num_experts=16, top_k=2, split_ratio=0.375)
     case_v2("fus_base", GatedFusionMoE, 128, varied(4, 128, 12, 16), 13, tweak=live_gates)

@@ -139,7 +139,8 @@ def test_gated_moe_host_vs_reference(name, golden_dir, emu):
     assert emu.CALLS["expert_conv"] == 1 and emu.CALLS["gated_route_decide"] == 1 and emu.CALLS["channel_shuffle_cat"] == 1
 
 
-GATED2_CASES = ["opt_base", "opt_e16", "fus_base", "fus_small", "fus_e16", "fus_keep1", "mh_base", "mh_e16", "mh_h3"]   # mh: MultiHeadRouterMoE (v0_13)
+GATED2_CASES = ["opt_base", "opt_e16", "fus_base", "fus_small", "fus_e16", "fus_keep1", "mh_base", "mh_e16", "mh_h3",          # mh: MultiHeadRouterMoE (v0_13)
+                "div_base", "div_e16", "div_k3", "div_keep1"]                                                       # div: DiversifiedExpertMoE (v0_14)
 
 
 def run_gated2_case(name, golden_dir, dev="cpu", dtype=torch.float32, rtol=5e-5):
@@ -150,7 +151,7 @@ def run_gated2_case(name, golden_dir, dev="cpu", dtype=torch.float32, rtol=5e-5)
     cls = getattr(mixture, str(z["cls"]))
     kw = eval(str(z["kw"]), {"__builtins__": {}}, {"dict": dict})
     m = _prep(cls(128, 128, **kw), sd)
-    assert m.expert_backend == ("shared_inverted" if kw.get("num_experts", 4) > 8 else "fused")
+    assert m.expert_backend == ("diversified" if name.startswith("div") else "shared_inverted" if kw.get("num_experts", 4) > 8 else "fused")
     x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
     if dev != "cpu":
         from yolo_master_amd.nn.modules import set_compute_dtype
@@ -171,7 +172,7 @@ def run_gated2_case(name, golden_dir, dev="cpu", dtype=torch.float32, rtol=5e-5)
 def test_gated_v12_v15_host_vs_reference(name, golden_dir, emu):
     run_gated2_case(name, golden_dir)
     assert emu.CALLS["expert_conv"] == 1 and emu.CALLS["gated_route_decide"] == 1 and emu.CALLS["channel_shuffle_cat"] == 1
-    assert emu.CALLS["layer_norm"] == 1
+    assert emu.CALLS["layer_norm"] == 1 and emu.CALLS.get("expert_dw3", 0) == (1 if name.startswith("div") else 0)
 
 
 GATED3_CASES = ["agm", "agm_hooks", "agm_keep1", "fused", "hyb", "hyb_e16", "hyb2", "lowrank", "refined", "detail", "ctxref"]

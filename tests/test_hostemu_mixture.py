@@ -53,6 +53,15 @@ def test_kernels_config5_model_vs_reference_golden(T, tag, golden_dir):
     T.test_config5_model_vs_reference_golden(tag, golden_dir)
 
 
+@pytest.mark.parametrize("name", ["div_base", "div_e16", "mh_base", "opt_base"])
+def test_kernels_gated_v12_to_v15(T, name, golden_dir):
+    """OptimalHybridGateMoE / MultiHeadRouterMoE / DiversifiedExpertMoE (per-expert dilated depthwise: ymk_expert_dw3) through the
+    host-compiled kernels against the real reference's vectors."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        T.test_gated_v12_v15_vs_reference_golden(name, golden_dir)
+
+
 def test_conv256_probe_on_the_emulator():
     """The next tiled-GEMM core's design probe (tools/micro/conv256.hip: 256-pixel tiles, LDS-DMA staging with source-side
     swizzle, zero page for border taps, 2- and 3-stage k-loops, XCD tile order) with the matrix core, the LDS-DMA and the

@@ -55,7 +55,7 @@ def test_gated_structural_properties(golden_dir):
     assert torch.equal(gated_ref.detail_gate(sd0, "m.detail_gate", xd), xd)
 
 
-@pytest.mark.parametrize("name", ["opt_base", "opt_e16", "fus_base", "fus_small", "fus_e16", "fus_keep1", "mh_base", "mh_e16", "mh_h3"])
+@pytest.mark.parametrize("name", ["opt_base", "opt_e16", "fus_base", "fus_small", "fus_e16", "fus_keep1", "mh_base", "mh_e16", "mh_h3", "div_base", "div_e16", "div_k3", "div_keep1"])
 def test_v12_v15_restatement_matches_reference(name, golden_dir):
     """oracle optimal_hybrid_moe (OptimalHybridGateMoE v0_12 / GatedFusionMoE v0_15) against the real reference's vectors."""
     import numpy as np

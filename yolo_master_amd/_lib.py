@@ -108,6 +108,7 @@ SYMBOLS_MIXTURE = {
     "ymk_token_softmax": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "ymk_gated_route_decide": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ymk_expert_gather": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ymk_expert_dw3": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ymk_channel_shuffle_cat": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i64, _vp]),
     "ymk_attention": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "ymk_window_attention": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32,

@@ -353,6 +353,30 @@ __global__ __launch_bounds__(256) void expert_gather_kernel(int dt, const void* 
         stv(out, dt, i, ldv(f, dt, ((int64_t)b * HW + px) * ldf + (int64_t)idx[b * K + j] * OC + c));
     }
 }
+// out[(j*B + b)][y][x][c] = sum_taps w[e][tap][c] * x[b][y + (ky-1)*d][x + (kx-1)*d][c], e = idx[b][j], d = dil[e] (zero padding)
+__global__ __launch_bounds__(256) void expert_dw3_kernel(int dt, const void* x, int ldx, const void* w, const int32_t* dil, const int32_t* idx,
+                                                          int B, int H, int W, int C, int K, void* out) {
+    const int64_t total = (int64_t)K * B * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int xx = (int)(p % W);
+        p /= W;
+        const int yy = (int)(p % H);
+        p /= H;
+        const int b = (int)(p % B);
+        const int j = (int)(p / B);
+        const int e = idx[b * K + j];
+        const int d = dil[e];
+        float acc = 0.f;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = yy + (tap / 3 - 1) * d, ix = xx + (tap % 3 - 1) * d;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                acc = fmaf(ldv(x, dt, (((int64_t)b * H + iy) * W + ix) * ldx + c), ldv(w, dt, ((int64_t)e * 9 + tap) * C + c), acc);
+        }
+        stv(out, dt, i, acc);
+    }
+}
 __global__ __launch_bounds__(256) void shuffle_cat_kernel(int dt, const void* a, int lda, int Ca, const void* b, int ldb, int Cb,
                                                            int groups, void* y, int ldy, int64_t npix) {
     const int C = Ca + Cb, cpg = C / groups;
@@ -949,6 +973,14 @@ extern "C" int ymk_expert_gather(int32_t dtype, const void* f_all, int32_t ldf, 
         return ymk_launch_status();
     }
     LAUNCH(expert_gather_kernel, (int64_t)K * B * HW * OC, dtype, f_all, ldf, idx, B, HW, OC, K, out);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_expert_dw3(int32_t dtype, const void* x, int32_t ldx, const void* w, const int32_t* dil, const int32_t* idx, int32_t B,
+                              int32_t H, int32_t W, int32_t C, int32_t K, int32_t E, void* out, void* stream) {
+    if (!x || !w || !dil || !idx || !out || bad_dt(dtype) || C < 1 || K < 1 || E < 1 || ldx < C) return YMK_E_BADARG;
+    if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
+    LAUNCH(expert_dw3_kernel, (int64_t)K * B * H * W * C, dtype, x, ldx, w, dil, idx, B, H, W, C, K, out);
     return ymk_launch_status();
 }
 

@@ -655,6 +655,15 @@ class OptimalHybridGateMoE(YmkModule):
                 dense[grp * og:(grp + 1) * og, grp * cg:(grp + 1) * cg] = w[grp * og:(grp + 1) * og]
             pk["ew"] = ops.pack_conv_weight(dense, dtype).reshape(E, OC, -1).contiguous()
             pk["en"] = (fe.expert_norm_weight.detach().float().to(device).contiguous(), fe.expert_norm_bias.detach().float().to(device).contiguous())
+        elif self.expert_backend == "diversified":
+            pk["sx0"], pk["sx1"] = _pack_conv(fe.shared_expand[0], dtype, device), _pack_norm(fe.shared_expand[1], device)
+            pk["dww"] = torch.stack([_pack_dw(q[0], dtype, device) for q in fe.dw_layers]).contiguous()           # [E][9][hidden]
+            pk["dwd"] = torch.tensor([q[0].dilation[0] for q in fe.dw_layers], dtype=torch.int32, device=device)
+            pk["dwn"] = (torch.stack([q[1].weight.detach().float() for q in fe.dw_layers]).to(device).contiguous(),
+                         torch.stack([q[1].bias.detach().float() for q in fe.dw_layers]).to(device).contiguous())
+            pk["ew"] = torch.stack([_pack_conv(q[0], dtype, device)[0] for q in fe.expert_projections]).contiguous()
+            pk["en"] = (torch.stack([q[1].weight.detach().float() for q in fe.expert_projections]).to(device).contiguous(),
+                        torch.stack([q[1].bias.detach().float() for q in fe.expert_projections]).to(device).contiguous())
         else:
             sf = fe.shared_feature
             pk["sf0"], pk["sf1"] = _pack_conv(sf[0], dtype, device), _pack_norm(sf[1], device)
@@ -708,6 +717,12 @@ class OptimalHybridGateMoE(YmkModule):
         if self.expert_backend == "fused":
             f = ops.expert_conv(xd, pk["ew"], 3, idx)
             f = ops.group_norm(f, gs(OC, ng), *pk["en"], 1e-5, act="silu", affine_rows=rows)
+        elif self.expert_backend == "diversified":   # DiversifiedExpertGroup (gated.py:2296-2330): per-expert dilated DW3x3 between expand and projection
+            hs = ops.group_norm(ops.conv2d(xd, *pk["sx0"], 1, 1, False), gs(pk["sx0"][0].shape[0], ng), *pk["sx1"], 1e-5, act="silu")
+            hd = ops.expert_dw3(hs, pk["dww"], pk["dwd"], idx)                                                   # [k * B, H, W, hidden], slot-major
+            hd = ops.group_norm(hd, gs(hd.shape[-1], ng), *pk["dwn"], 1e-5, act="silu", affine_rows=rows)
+            f = ops.expert_conv(hd, pk["ew"], 1, rows.view(-1, 1).contiguous())                                 # image n of the slot-major batch -> its own expert
+            f = ops.group_norm(f, gs(OC, ng), *pk["en"], 1e-5, affine_rows=rows)
         else:
             hs = ops.group_norm(ops.conv2d(xd, *pk["sf0"], 1, 1, False), gs(pk["sf0"][0].shape[0], 8), *pk["sf1"], 1e-5, act="silu")
             hs = ops.group_norm(ops.dwconv2d(hs, pk["sf3"], None, pk["sf_k"], False), gs(hs.shape[-1], 8), *pk["sf4"], 1e-5, act="silu")
@@ -803,6 +818,42 @@ class MultiHeadRouterMoE(OptimalHybridGateMoE):
             if lo < hi:
                 w[:, lo:hi] += (1 - gw) * hw[i] * h.weight.detach().float()[:, : hi - lo]
         return w
+
+
+class DiversifiedExpertGroup(nn.Module):
+    """moe/gated.py:2214-2294 (parameters; the arithmetic is in OptimalHybridGateMoE._run, backend "diversified")."""
+
+    def __init__(self, in_channels, out_channels, num_experts, expand_ratio=2.0, top_k=2, weight_threshold=0.0, num_groups=8):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_experts, self.top_k = in_channels, out_channels, num_experts, top_k
+        hidden = max(1, int(in_channels * expand_ratio))
+        self.shared_expand = nn.Sequential(nn.Conv2d(in_channels, hidden, 1, bias=False), _gn(hidden, num_groups), nn.SiLU())
+        self.dw_layers = nn.ModuleList()
+        self.dw_dilations = nn.ParameterList()
+        for i in range(num_experts):
+            d = 1 + (i // 2)
+            self.dw_layers.append(nn.Sequential(nn.Conv2d(hidden, hidden, 3, padding=d, dilation=d, groups=hidden, bias=False),
+                                                _gn(hidden, num_groups), nn.SiLU()))
+            self.dw_dilations.append(nn.Parameter(torch.tensor(float(d))))
+        self.expert_projections = nn.ModuleList(nn.Sequential(nn.Conv2d(hidden, out_channels, 1, bias=False), _gn(out_channels, num_groups))
+                                                for _ in range(num_experts))
+
+
+class DiversifiedExpertMoE(OptimalHybridGateMoE):
+    """v0_14 gated MoE (moe/gated.py:2499-2561): OptimalHybridGateMoE whose experts are a shared 1x1 expansion, a per-expert DILATED
+    depthwise 3x3 (dilation 1 + i // 2) and a per-expert 1x1 projection, for every expert count.  The depthwise stage runs per routed
+    (image, slot) pair with the expert's own filter and dilation (ymk_expert_dw3); the projection is the sparse expert convolution over
+    the slot-major batch."""
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, refine=True, refine_reduction=8):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold, shuffle_groups, refine,
+                         refine_reduction)
+        self.expert_backend = "diversified"
+        self.fused_experts = DiversifiedExpertGroup(self.dynamic_channels, self.out_dynamic, num_experts, expand_ratio=2.0, top_k=top_k,
+                                                    weight_threshold=0.0, num_groups=num_groups)
 
 
 # ----------------------------------------------------------------------------------------- MoA
@@ -1268,6 +1319,6 @@ class C2fMoT(YmkModule):
 GATED_CHAIN = (AdaptiveGateMoE, FusedAdaptiveGateMoE, HybridAdaptiveGateMoE, HybridAdaptiveGateMoEv2, LowRankHybridAdaptiveGateMoE,
                RefinedLowRankHybridAdaptiveGateMoE, DetailAwareLowRankHybridAdaptiveGateMoE, ContextRefinedLowRankHybridAdaptiveGateMoE,
                VisualEnhancedAdaptiveGateMoE)    # YAML generations v0_4 ... v0_11 (one class per generation)
-MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE,
+MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
                             "GatedFusionMoE": GatedFusionMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
 MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

@@ -823,6 +823,19 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
     return w, idx, probs, rows
 
 
+def expert_dw3(x, w, dil, idx, out=None):
+    """Per-image expert depthwise 3x3 with per-expert dilation, slot-major (include/ymk_mixture.h ymk_expert_dw3): x NHWC [B, H, W, C],
+    w [E, 9, C] in x's dtype, dil int32 [E], idx int32 [B, K] -> [K * B, H, W, C] (DiversifiedExpertGroup.dw_layers, gated.py:2265-2278)."""
+    B, H, W, Cc, ldx = _nhwc(x)
+    E, K = w.shape[0], idx.shape[1]
+    if idx.dtype != torch.int32 or tuple(idx.shape) != (B, K) or not idx.is_contiguous() or dil.dtype != torch.int32 or w.dtype != x.dtype:
+        raise ValueError("expert_dw3: idx int32 [B, K] contiguous, dil int32 [E], w in the activation dtype")
+    if out is None:
+        out = torch.empty((K * B, H, W, Cc), dtype=x.dtype, device=x.device)
+    check(lib.ymk_expert_dw3(DT[x.dtype], _p(x), ldx, _p(w), _p(dil), _p(idx), B, H, W, Cc, K, E, _p(out), _stream()), "expert_dw3")
+    return out
+
+
 def expert_conv(x, w_packed, k: int, idx, out=None):
     """Per-image expert convolution, slot-major: out[j*B + b] = conv_kxk(x[b], w_packed[idx[b, j]]) (no bias, no activation;
     out[j*B:(j+1)*B] is the batch of slot j, a contiguous NHWC tensor);

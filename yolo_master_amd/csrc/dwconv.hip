@@ -45,18 +45,22 @@ struct DwTile {
         }
         return worst;
     }
+    static constexpr size_t wbytes(int K) { return (size_t)K * K * CB * (sizeof(T) == 2 ? 2 : 4); }   // filter block in LDS (bf16 stays bf16)
+    static constexpr int resident_with(int K, int rp) { return (int)(163840 / ((size_t)(TH + K - 1) * rp + wbytes(K))); }
     static constexpr int row_pitch(int K) {    // bytes between staged rows
         const int base = (TW + K - 1) * PSB;
         if (sizeof(T) != 2) return base;
         int best = base, bc = conflicts(base);
         for (int extra = 8; extra <= 128 && bc > 1; extra += 8)
             if (conflicts(base + extra) < bc) { bc = conflicts(base + extra); best = base + extra; }
-        return best;
+        // ... unless the padding costs a resident workgroup (16 x 40 tile, k = 9: four workgroups per CU only without it)
+        return resident_with(K, best) < resident_with(K, base) ? base : best;
     }
+    static constexpr int resident(int K) { return resident_with(K, row_pitch(K)); }   // workgroups per CU by LDS
     static constexpr int ROWL = 256 / (NCG * STRIPS);         // row lanes
     static_assert(TH == ROWL, "one output row per thread");
     static constexpr size_t lds_bytes(int K) {
-        return (size_t)(TH + K - 1) * row_pitch(K) + (size_t)K * K * CB * sizeof(float);
+        return (size_t)(TH + K - 1) * row_pitch(K) + wbytes(K);
     }
 };
 
@@ -107,11 +111,17 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
     const int c0 = cb * D::CB;
     constexpr int RP = D::row_pitch(K);
     float* wsm = reinterpret_cast<float*>(smem + (size_t)HT * RP);
+    T* wsb = reinterpret_cast<T*>(smem + (size_t)HT * RP);
+    // With four workgroups resident per CU (bf16, k <= 9: 16 waves hide each other's staging) the next tile's halo is NOT prefetched
+    // into registers: that prefetch holds 36 registers through the arithmetic and caps the kernel at three waves per SIMD.
+    constexpr bool PREFETCH = D::resident(K) < 4;
 
-    // filter block once: channel j of each 4-group at its register-quadruple position (see lds_ld4)
+    // filter block once.  fp32: channel j of each 4-group at its register-quadruple position (see lds_ld4); bf16: as stored, widened
+    // at use with the same shifts / masks as the activations
     for (int i = t; i < K * K * D::CB; i += 256) {
         const int tap = i / D::CB, c = i - tap * D::CB;
-        wsm[tap * D::CB + (c & ~3) + DwPair<T>::pos[c & 3]] = (c0 + c) < C ? to_f32(w[(size_t)tap * C + c0 + c]) : 0.f;
+        if constexpr (sizeof(T) == 2) wsb[i] = (c0 + c) < C ? w[(size_t)tap * C + c0 + c] : (T)0;
+        else wsm[tap * D::CB + (c & ~3) + DwPair<T>::pos[c & 3]] = (c0 + c) < C ? to_f32(w[(size_t)tap * C + c0 + c]) : 0.f;
     }
     // halo staging: all global loads of a thread are issued back to back into registers
     u32x4 stg[NL];
@@ -140,8 +150,9 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
         bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
     }
 
-    if (st0 < st1) gload(st0);
+    if (PREFETCH && st0 < st1) gload(st0);
     for (int st = st0; st < st1; ++st) {
+        if (!PREFETCH) gload(st);
         __syncthreads();  // the previous tile's LDS reads are finished
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -154,7 +165,7 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
             }
         }
         __syncthreads();  // halo (and, first pass, the filter block) visible
-        if (st + 1 < st1) gload(st + 1);  // in flight during the arithmetic below
+        if (PREFETCH && st + 1 < st1) gload(st + 1);  // in flight during the arithmetic below
 
         const int ty0 = (st / tiles_x) * TH, tx0 = (st % tiles_x) * TW;
         const int gy = ty0 + y;
@@ -167,8 +178,14 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
             f32x2 wr[K][2];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(wsm + (ky * K + kx) * D::CB + cg * 4);
-                wr[kx][0] = f32x2{t4.x, t4.y}; wr[kx][1] = f32x2{t4.z, t4.w};
+                if constexpr (sizeof(T) == 2) {
+                    const u32x2 t2 = *reinterpret_cast<const u32x2*>(wsb + (ky * K + kx) * D::CB + cg * 4);
+                    wr[kx][0] = __builtin_bit_cast(f32x2, t2 << 16);
+                    wr[kx][1] = __builtin_bit_cast(f32x2, t2 & 0xffff0000u);
+                } else {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(wsm + (ky * K + kx) * D::CB + cg * 4);
+                    wr[kx][0] = f32x2{t4.x, t4.y}; wr[kx][1] = f32x2{t4.z, t4.w};
+                }
             }
             const char* row = smem + (size_t)(y + ky) * RP + x0 * D::PSB + cg * 4 * sizeof(T);
 #pragma unroll

@@ -148,18 +148,20 @@ def test_conv_kernel_names_match_the_committed_profiles():
     import bench
     from yolo_master_amd import ops
 
-    prof = json.load(open(Path(__file__).parent.parent / "profiles" / "r01_pmc_FETCH_SIZE.json"))["kernels"]
+    latest = sorted((Path(__file__).parent.parent / "profiles").glob("*_pmc_FETCH_SIZE.json"))[-1]   # the one bench.pmc_traffic reads
+    prof = json.load(open(latest))["kernels"]
     bf = torch.bfloat16
     names = [
         ops.conv_kernel_name(0, bf, 256, 128, 1, 256, True),              # tiled 1x1, 128x128 tile
         ops.conv_kernel_name(0, bf, 64, 64, 1, 64, False),                # tiled 1x1, 64x256 tile
-        ops.conv_kernel_name(0, bf, 128, 128, 3, 1152, False),            # tiled 3x3
+        ops.conv_kernel_name(3 | (2 << 8), bf, 256, 256, 3, 2304, False),  # LDS-DMA tiled 3x3, 128 couts, two stages
+        ops.conv_kernel_name(3 | (2 << 8), bf, 128, 64, 3, 1152, False),  # ... 64 couts
         ops.conv_kernel_name(1, bf, 96, 128, 1, 128, False),              # streaming 1x1, 2 K groups
-        ops.conv_kernel_name(2, bf, 64, 64, 3, 576, True),                # spatial tile 3x3 with residual prefetch
+        ops.conv_kernel_name(2, bf, 32, 32, 3, 320, True),                # spatial tile 3x3 with residual prefetch
         ops.conv_kernel_name(0, bf, 512, 128, 1, 512, False, dual=True),  # cat2
     ]
     for n in names:
-        assert n in prof, f"{n!r} is not a kernel name of the committed profile"
+        assert n in prof, f"{n!r} is not a kernel name of the committed profile {latest.name}"
         assert bench.pmc_traffic(n) > 0
     assert ops.conv_kernel_name(0, torch.float32, 16, 8, 3, 192, False) == "conv_igemm_kernel<float, 16, 256, 1, 4, 3, false>"
     assert bench.pmc_traffic("moe_dw") > 0 and bench.pmc_traffic("nms") is None   # prefix families / multi-kernel ops

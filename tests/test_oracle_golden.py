@@ -43,7 +43,7 @@ def test_forward_restatement_matches_reference(case, golden_dir):
             np.testing.assert_allclose(dets[b], z[f"nms{b}_dets"], rtol=1e-4, atol=1e-4)
         else:   # ulp-level differences in y may flip a near-threshold IoU / score decision: compare the kept sets
             a, r = set(idx[b].tolist()), set(z[f"nms{b}_idx"].tolist())
-            assert len(a & r) >= 0.97 * max(len(a | r), 1), f"image {b}: kept sets differ beyond near-threshold flips"
+            assert len(a & r) >= 0.97 * len(a | r), f"image {b}: kept sets differ beyond near-threshold flips"   # (both empty: equal)
 
 
 @pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one", "classes", "classes_multi"])

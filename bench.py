@@ -34,6 +34,10 @@ FAMILY_KERNEL = {
 }
 
 
+VALU_FAMILIES = ("moe_dw", "dwconv")   # depthwise stencils (csrc/dwconv.hip)
+VALU_PEAK_TMACS = 64.0
+
+
 def pmc_traffic(family: str):
     """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_*.json, collected by tools/gpu_profile.sh on the same workload): 2*FETCH_SIZE (gfx950 counts
@@ -232,6 +236,11 @@ def main():
                              alg_gflop_per_launch=round(flops / n / 1e9, 3), achieved_gbs=round(gbs, 1),
                              achieved_tflops=round(tfl, 2))
                     r["traffic"] = pmc_traffic(fam)
+                    if fam in VALU_FAMILIES:
+                        # stencil kernels have no matrix contraction: neither HBM nor MFMA is their limit; the honest third axis is
+                        # the fp32 VALU rate (64 T MAC/s measured on MI355X for v_fma / v_pk_fma / v_dot2c, tools/micro/valu_rate.hip)
+                        r["valu"] = {"achieved": round(tfl / 2, 2), "peak": VALU_PEAK_TMACS, "unit": "TMAC/s",
+                                     "frac": round(tfl / 2 / VALU_PEAK_TMACS, 4)}
                     return r
 
                 if agg:

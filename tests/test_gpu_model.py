@@ -32,7 +32,10 @@ def test_forward_vs_reference_golden(case, golden_dir):
     the same graph, and the reference's own round-off distance to fp64 ("noise").  fp32 evaluation orders differ
     (oneDNN vs MFMA fma chains), and a 26-layer network amplifies that: at 640x640 the reference itself is 0.33 px
     / 1.5e-3 away from the exact result, at the small sizes ~1e-4 px / 1e-7.  The HIP path must be as close to the
-    exact (fp64) result as the reference is, within a factor 3, plus the 1e-4 (abs + rel) the north star names."""
+    exact (fp64) result as the reference is, within a factor 3, plus the 1e-4 (abs + rel) the north star names.
+    (These are the round-1 fixtures on UNconditioned seeded weights, kept as regression vectors; the stated bar without any
+    noise allowance is enforced on conditioned weights by tests/test_gpu_baseline_configs.py — BASELINE config 2 at full size —
+    and by test_forward_vs_oracle_fresh_inputs below.)"""
     from yolo_master_amd import ops
     from yolo_master_amd.nms import non_max_suppression
     from yolo_master_amd.weights import synth_input
@@ -107,34 +110,45 @@ def test_forward_vs_reference_golden(case, golden_dir):
 
 
 def test_forward_vs_oracle_fresh_inputs():
-    """Fresh seed (not in any fixture), batch 5, non-square: HIP fp32 vs the oracle on the same input."""
+    """Fresh seed (not in any fixture), batch 5, non-square, conditioned synthetic weights (tools/make_conditioned.py): HIP fp32 vs
+    the oracle (bit-identical to the real reference on every fixture) on the same input at the stated bar, no noise allowance:
+    routing identical, scores <= 1e-4, boxes <= 1e-4 DFL bins; NMS on the oracle's y exact; end to end at most two near-threshold flips per image."""
     from oracle import model_ref, nms_ref
     from yolo_master_amd.nms import non_max_suppression
-    from yolo_master_amd.nn.tasks import yaml_model_load
+    from yolo_master_amd.nn.tasks import CFG_DIR, DetectionModel, yaml_model_load
     from yolo_master_amd.weights import synth_input, synth_state_dict
 
-    from yolo_master_amd.nn.tasks import DetectionModel
-
-    sd = synth_state_dict(DetectionModel("yolo-master-n.yaml").state_dict(), seed=0)
-    m = _model("n")
-    x = synth_input(5, 320, 448, seed=99)
+    sd = synth_state_dict(DetectionModel("yolo-master-n.yaml").state_dict(), seed=0, calib=str(CFG_DIR / "cond_n.npz"))
+    m = DetectionModel("yolo-master-n.yaml")
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    H, W = 320, 448
+    x = synth_input(5, H, W, seed=99)
     info = {}
     with torch.inference_mode():
         oy, _, _ = model_ref.forward(yaml_model_load("yolo-master-n.yaml"), sd, x, moe_info=info)
         y, _ = m._predict_once(x.to(DEV))
-        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-        y64, _, _ = model_ref.forward(yaml_model_load("yolo-master-n.yaml"), sd64, x.double(), fused=False)
+    m.check_flags()
     for i in (3, 6, 9, 12):
         assert torch.equal((m.model[i].last_route["gate_w"] > 0).cpu(), info[f"model.{i}"]["retained"])
-    noise = (oy.double() - y64).abs()
-    err = (y.cpu().double() - y64).abs()
-    assert float(err[:, 4:].max()) <= 3 * float(noise[:, 4:].max()) + 1e-4
-    assert float(err[:, :4].max()) <= 3 * float(noise[:, :4].max()) + 1e-4 + 1e-4 * float(y64[:, :4].abs().max())
-    # NMS kernel on the oracle's y: exact
+    err = (y.cpu() - oy).abs()
+    strides = torch.cat([torch.full(((H // s) * (W // s),), float(s)) for s in (8, 16, 32)])
+    bins = float((err[:, :4] / strides).max())
+    assert float(err[:, 4:].max()) <= 1e-4, f"scores {float(err[:, 4:].max()):.3e}"
+    assert bins <= 1e-4, f"boxes {bins:.3e} bins ({float(err[:, :4].max()):.3e} px)"
+    # NMS kernel on the oracle's y: exact; end to end: same kept anchors and classes
     ref, ref_idx = nms_ref.non_max_suppression(oy.numpy(), 0.1, 0.7, return_idxs=True)
     got, got_idx = non_max_suppression(oy.to(DEV), 0.1, 0.7, return_idxs=True)
+    e2e, e2e_idx = non_max_suppression(y, 0.1, 0.7, return_idxs=True)
+    flips = 0
     for b in range(5):
         assert np.array_equal(got_idx[b].cpu().numpy(), ref_idx[b]) and np.array_equal(got[b].cpu().numpy(), ref[b])
+        # end to end: y differs from the oracle's by ~1e-6, so one of the ~10^5 IoU / score comparisons of an image may sit on the other
+        # side of its threshold: at most two anchors may differ, everything else identical
+        a_, r_ = set(e2e_idx[b].cpu().numpy().tolist()), set(ref_idx[b].tolist())
+        assert len(a_ ^ r_) <= 2, f"image {b}: end-to-end kept anchors differ in {len(a_ ^ r_)} places"
+        flips += len(a_ ^ r_)
+    print(f"fresh inputs: scores {float(err[:, 4:].max()):.3e}, boxes {bins:.3e} bins, kept {[len(r) for r in ref_idx]}, end-to-end flips {flips}")
 
 
 def test_bf16_model_tracks_fp32():

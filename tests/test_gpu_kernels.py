@@ -283,7 +283,8 @@ def test_area_attention_long(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("fused,cin,hw", [(True, 64, (14, 18)), (False, 64, (14, 18)), (True, 128, (14, 18)),
-                                          (False, 256, (14, 18)),    # streaming pointwise stage, 2 cout tiles, 4 K groups
+                                          (False, 256, (14, 18)),    # table-driven pointwise stage, 2 cout tiles, 4 K groups
+                                          (False, 192, (14, 18)),    # cout not a multiple of 128: the older streaming kernel
                                           (False, 128, (88, 88))])   # more (image, tile) items than workgroups, ragged last tile
 def test_esmoe_block(dtype, fused, cin, hw):
     from oracle import model_ref

@@ -1,4 +1,5 @@
-// VALU issue-rate probe: v_fma_f32, v_pk_fma_f32, v_dot2c_f32_bf16 — MACs per clock per CU with every SIMD saturated.
+// VALU issue-rate probe: v_fma_f32, v_pk_fma_f32, v_dot2c_f32_bf16, the transcendentals and a whole SiLU — lane-results per second with
+// every SIMD saturated (8 workgroups of 4 waves per CU, 8 independent chains per lane).
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/valu_rate.hip -o tools/micro/valu_rate.bin && tools/micro/valu_rate.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -21,6 +22,10 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned seed) {
             if (MODE == 0) a[i] = __builtin_fmaf(a[i], fx, fy);
             if (MODE == 1) p[i] = __builtin_elementwise_fma(p[i], px, py);
             if (MODE == 2) a[i] = __builtin_amdgcn_fdot2_f32_bf16(x, y, a[i], false);
+            if (MODE == 3) a[i] = __builtin_amdgcn_exp2f(a[i]);
+            if (MODE == 4) a[i] = __builtin_amdgcn_rcpf(a[i]);
+            if (MODE == 5) a[i] = a[i] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[i] * -1.4426950408889634f));   // silu_f
+            if (MODE == 6) a[i] = a[i] + fy;
         }
     }
     float s = 0.f;
@@ -51,5 +56,9 @@ int main() {
     run<0>("v_fma_f32", 1);
     run<1>("v_pk_fma_f32", 2);
     run<2>("v_dot2c_f32_bf16", 2);
+    run<3>("v_exp_f32", 1);
+    run<4>("v_rcp_f32", 1);
+    run<5>("silu_f (5 ops)", 1);
+    run<6>("v_add_f32", 1);
     return 0;
 }

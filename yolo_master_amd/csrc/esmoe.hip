@@ -636,6 +636,324 @@ __global__ __launch_bounds__(512) void moe_pw_stream_kernel(MoePwArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Lean streaming pointwise stage (Cout % 128 == 0, K == Kpad <= 4 x 128 bytes, E <= 8).
+// Same work list, tile shape and arithmetic as moe_pw_stream_kernel, but that kernel spent ~1100 instructions per wave and
+// step (index decode with divisions and dependent LDS reads, 64-bit address arithmetic, tail masks) around 32 MFMAs: with two
+// waves per SIMD it was issue-bound at ~6 us per step (tools ablation: 4 us per step with loads, stores, MFMA and SiLU all
+// removed).  Here every workgroup decodes its steps ONCE, in parallel, into an LDS table of 16-byte descriptors
+// {activation row, output row, expert | first | last, gate weight}; the loop body reads one descriptor, addresses with a
+// uniform base + a per-lane constant, keeps up to four expert weight tiles resident in LDS (an image that kept two experts
+// alternates between them tile after tile), prefetches the next weight tile together with the next activations, starts the
+// accumulators at the expert bias, and stages rows at a 32-byte-padded pitch (conflict-free ds_read_b128 without a swizzle).
+// Weight rows are staged in the order that leaves a lane with EIGHT consecutive output channels after its two MFMA row
+// blocks (16-byte stores, 64 contiguous bytes per pixel and wave instead of 32).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pwl_store8(float* p, const float (&v)[8]) {
+    store4(p, v[0], v[1], v[2], v[3]);
+    store4(p + 4, v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void pwl_store8(bf16_t* p, const float (&v)[8]) { store_vec_f32(p, v); }
+#define PWL_MAXSTEP 512
+#define PWL_MAXE 8
+__host__ __device__ constexpr int pwl_slots(int kg) { return kg == 1 ? 4 : kg == 2 ? 2 : 1; }
+__host__ __device__ constexpr int pwl_pitch(int kg) { return kg * 8 + 2; }   // u32x4 per staged row
+
+template <typename T, int KG>
+__global__ __launch_bounds__(512) void moe_pw_lean_kernel(MoePwArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int RP = pwl_pitch(KG);
+    constexpr int NSLOT = pwl_slots(KG);
+    constexpr int TILE = 128 * RP;
+    constexpr bool PRECISE = sizeof(T) == 4;
+    extern __shared__ u32x4 pwl_dyn[];
+    u32x4* const sWall = pwl_dyn;
+    u32x4* const sA = pwl_dyn + NSLOT * TILE;
+    int* const s_sel = reinterpret_cast<int*>(sA);   // the two prologue tables live in the (not yet used) activation tile
+    int* const s_pref = s_sel + PWS_MAXSEL;
+    __shared__ int4 s_step[PWL_MAXSTEP];
+    __shared__ float s_bias[PWL_MAXE * 128];
+    __shared__ float s_norm[256];
+    __shared__ int s_wsum[8];
+    __shared__ int s_rng[2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wco = wave >> 1, wpx = wave & 1;   // 8 waves: 4 (cout, 32 each) x 2 (pixels, 64 each)
+    const int srow = t >> 3, cq = t & 7;         // 64 staged rows per pass
+    const int fr = lane & 15, fc = lane >> 4;
+    const int ncot = a.Cout >> 7;
+    const int tail = a.HW & 127;                 // rows of the last tile of an image (0: whole)
+    int ct, j;   // cout tiles of one pixel range sit on the same XCD (shared L2 for the activation tile)
+    if (gridDim.x % (8 * ncot) == 0) {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        ct = q % ncot; j = (q / ncot) * 8 + xcd;
+    } else {
+        ct = blockIdx.x % ncot; j = blockIdx.x / ncot;
+    }
+    const int co0 = ct * 128;
+    const int nblk = gridDim.x / ncot;
+    const int tiles = a.tiles;
+
+    for (int i = t; i < a.B * a.top_k; i += 512) s_sel[i] = a.sel[i];
+    for (int i = t; i < a.E * 128; i += 512) s_bias[i] = a.pw_b[(size_t)(i >> 7) * a.Cout + co0 + (i & 127)];
+    if (t < 256) s_norm[t] = t < 128 ? a.nscale[co0 + t] : a.nshift[co0 + t - 128];
+    __syncthreads();
+    {   // exclusive prefix of the steps per image (an image without a retained expert still owns one, empty, step): two images per thread
+        int c[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int b = 2 * t + q;
+            int nv = 0;
+            if (b < a.B) {
+                for (int k = 0; k < a.top_k; ++k) nv += s_sel[b * a.top_k + k] >= 0;
+                nv = nv > 0 ? nv : 1;
+            }
+            c[q] = nv;
+        }
+        const int own = c[0] + c[1];
+        int inc = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += v;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int ex = inc - own;
+        for (int w = 0; w < wave; ++w) ex += s_wsum[w];
+        if (2 * t < a.B) s_pref[2 * t] = ex;
+        if (2 * t + 1 < a.B) s_pref[2 * t + 1] = ex + c[0];
+        if (2 * t == a.B - 1 || 2 * t + 1 == a.B - 1) s_pref[a.B] = ex + own;
+    }
+    __syncthreads();
+    {   // this workgroup's range of steps, cut at whole (image, tile) items
+        const int total = s_pref[a.B] * tiles;
+        const int per = (total + nblk - 1) / nblk;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int target = (j + q) * per;
+            if (target >= total) {
+                if (t == 0) s_rng[q] = total;
+            } else {
+                for (int b = t; b < a.B; b += 512) {
+                    const int lo = s_pref[b] * tiles, hi = s_pref[b + 1] * tiles;
+                    if (lo <= target && target < hi) {
+                        const int c = s_pref[b + 1] - s_pref[b];
+                        s_rng[q] = lo + (target - lo + c - 1) / c * c;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int g0 = s_rng[0];
+    const int n = s_rng[1] - g0;
+    if (n <= 0) return;
+    for (int i = t; i < n; i += 512) {   // n <= PWL_MAXSTEP (launcher)
+        const int g = g0 + i;
+        int lo = 0, hi = a.B - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_pref[mid] * tiles <= g) lo = mid; else hi = mid - 1;
+        }
+        const int b = lo, c = s_pref[b + 1] - s_pref[b];
+        const int local = g - s_pref[b] * tiles;
+        const int tile = local / c, k = local - tile * c;
+        const int pair = b * a.top_k + ((tile & 1) ? c - 1 - k : k);   // the expert left in LDS by one tile is the first the next tile needs
+        const int e = s_sel[pair];
+        int4 d;
+        d.x = pair * a.HW + tile * 128;
+        d.y = b * a.HW + tile * 128;
+        d.z = (e & 0xffff) | (k == 0 ? 0x10000 : 0) | (k == c - 1 ? 0x20000 : 0) | (tail && tile == tiles - 1 ? 0x40000 : 0);
+        d.w = e >= 0 ? __float_as_int(a.gate[b * a.E + e]) : 0;
+        s_step[i] = d;
+    }
+    __syncthreads();   // s_sel / s_pref are dead from here on: the activation tile may be written
+
+    const T* const dw = reinterpret_cast<const T*>(a.dw);
+    const T* const pw = reinterpret_cast<const T*>(a.pw_w) + (size_t)co0 * a.Kpad;
+    T* const yb = reinterpret_cast<T*>(a.y) + co0;
+    const int w_off = srow * a.Kpad + cq * VEC;
+    const int st_off = srow * RP + cq;                // LDS: row srow (+64), chunk g * 8 + cq
+    // weight row c of a wave's 32 = f2 * 8 + q * 4 + f0 goes to MFMA row block q, row f2 * 4 + f0
+    const int sw_off = ((srow & ~31) + ((srow >> 2) & 1) * 16 + ((srow >> 3) & 3) * 4 + (srow & 3)) * RP + cq;
+    const int fa_off = ((wco * 2) * 16 + fr) * RP + fc;   // weight fragment rows (wco*2 + i) * 16 + fr
+    const int fb_off = ((wpx * 4) * 16 + fr) * RP + fc;   // pixel fragment rows (wpx*4 + jj) * 16 + fr
+    const int o_off = ((wpx * 4) * 16 + fr) * a.ldy + wco * 32 + fc * 8;
+    auto fetch = [&](int i) {
+        const int4 d = s_step[i];
+        int4 r;
+        r.x = __builtin_amdgcn_readfirstlane(d.x); r.y = __builtin_amdgcn_readfirstlane(d.y);
+        r.z = __builtin_amdgcn_readfirstlane(d.z); r.w = __builtin_amdgcn_readfirstlane(d.w);
+        return r;
+    };
+    auto expert_of = [](const int4& d) { return (int)(short)(d.z & 0xffff); };
+
+    u32x4 ra[2][KG], rw[2][KG];
+    auto gload = [&](const int4& d) {
+        const T* xin = dw + (size_t)d.x * a.C + cq * VEC;
+        const int last_row = ((d.z & 0x40000) ? tail : 128) - 1;   // rows past the image repeat its last row (never stored)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = min(srow + i * 64, last_row);
+#pragma unroll
+            for (int g = 0; g < KG; ++g) ra[i][g] = *reinterpret_cast<const u32x4*>(xin + r * a.C + g * 8 * VEC);
+        }
+    };
+    auto wload = [&](int e) {
+        const T* wt = pw + (size_t)e * a.Cout * a.Kpad;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+                rw[i][g] = *reinterpret_cast<const u32x4*>(wt + w_off + i * 64 * a.Kpad + g * 8 * VEC);
+    };
+    int slot_e[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) slot_e[q] = -1;
+    int mru = 0;
+    // slot of expert e; a miss picks a victim (never the slot of the step before), loads the tile into rw and reports it pending
+    auto claim = [&](int e, bool& pend) {
+        int sl = -1;
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) if (slot_e[q] == e) sl = q;
+        pend = sl < 0;
+        if (pend) {
+            sl = NSLOT == 1 ? 0 : (mru + 1) % NSLOT;
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) if (q == sl) slot_e[q] = e;
+            wload(e);
+        }
+        mru = sl;
+        return sl;
+    };
+
+    int4 cur = fetch(0);
+    bool pend = false;
+    int cslot = 0;
+    if (expert_of(cur) >= 0) { gload(cur); cslot = claim(expert_of(cur), pend); }
+    f32x4 part[2][4];
+    for (int i = 0; i < n; ++i) {
+        __syncthreads();   // the previous step's fragment reads are finished
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < KG; ++g) sA[st_off + q * 64 * RP + g * 8] = ra[q][g];
+        if (pend) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int g = 0; g < KG; ++g) sWall[cslot * TILE + sw_off + q * 64 * RP + g * 8] = rw[q][g];
+        }
+        __syncthreads();
+        int4 nx = cur;
+        int nslot = cslot;
+        pend = false;
+        if (i + 1 < n) {
+            nx = fetch(i + 1);
+            if (expert_of(nx) >= 0) { gload(nx); nslot = claim(expert_of(nx), pend); }
+        }
+        const int e = expert_of(cur);
+        const bool first = cur.z & 0x10000, last = cur.z & 0x20000;
+        if (e >= 0) {
+            const u32x4* sW = sWall + cslot * TILE;
+            const float gw = __int_as_float(cur.w);
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(s_bias + e * 128 + wco * 32 + fc * 8 + q * 4);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[q][jj] = bv;
+            }
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 af[2], bfr[4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) af[q] = sW[fa_off + q * 16 * RP + g * 8 + kk * 4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) bfr[jj] = sA[fb_off + jj * 16 * RP + g * 8 + kk * 4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) mma16<T>(acc[q][jj], af[q], bfr[jj]);
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (PRECISE ? silu_exact(acc[q][jj][r]) : silu_f(acc[q][jj][r])) * gw;
+                    if (first) part[q][jj] = v; else part[q][jj] += v;
+                }
+        } else if (first) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) part[q][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (last) {  // trailing ES_MOE.norm: BatchNorm(eval) + SiLU
+            T* const yo = yb + (size_t)cur.y * a.ldy;
+            const int rows = (cur.z & 0x40000) ? tail : 128;
+            f32x4 sc[2], sh[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                sc[q] = *reinterpret_cast<const f32x4*>(s_norm + wco * 32 + fc * 8 + q * 4);
+                sh[q] = *reinterpret_cast<const f32x4*>(s_norm + 128 + wco * 32 + fc * 8 + q * 4);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = part[q][jj][r] * sc[q][r] + sh[q][r];
+                        v[q * 4 + r] = PRECISE ? silu_exact(u) : silu_f(u);
+                    }
+                if ((wpx * 4 + jj) * 16 + fr < rows) pwl_store8(yo + o_off + jj * 16 * a.ldy, v);
+            }
+        }
+        cur = nx; cslot = nslot;
+    }
+}
+
+template <typename T>
+static bool launch_pw_lean(MoePwArgs a, hipStream_t s) {
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    const int kg = a.Kpad / BK;
+    if (ymk_disabled() & (YMK_OFF_MOE_STREAM | YMK_OFF_MOE_LEAN)) return false;
+    if (a.Kpad % BK || kg < 1 || kg > 4 || a.C != a.Kpad || a.Cout % 128 || a.E > PWL_MAXE || a.B > PWS_MAXB ||
+        (int64_t)a.B * a.top_k > PWS_MAXSEL || (int64_t)a.B * a.top_k * a.HW >= (1ll << 31) ||
+        (a.ldy * sizeof(T)) % 16 || reinterpret_cast<uintptr_t>(a.y) % 16)   // 16-byte output stores
+        return false;
+    const int ncot = a.Cout / 128;
+    a.tiles = (a.HW + 127) / 128;
+    int64_t nblk = 256 / ncot;
+    if (nblk < 1) nblk = 1;
+    if (nblk > (int64_t)a.B * a.tiles) nblk = (int64_t)a.B * a.tiles;
+    // the step table holds one workgroup's share: at most ceil(all steps / workgroups) rounded up to a whole (image, tile) item
+    if (ceil_div64((int64_t)a.B * a.top_k * a.tiles, nblk) + a.top_k > PWL_MAXSTEP) return false;
+    dim3 grid((unsigned)(nblk * ncot)), blk(512);
+    auto lds = [](int g) { return (size_t)(pwl_slots(g) + 1) * 128 * pwl_pitch(g) * sizeof(u32x4); };
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_pw_lean_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_pw_lean_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(2));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_pw_lean_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(3));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_pw_lean_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(4));
+        attr_set = true;
+    }
+    switch (kg) {
+        case 1: hipLaunchKernelGGL((moe_pw_lean_kernel<T, 1>), grid, blk, lds(1), s, a); break;
+        case 2: hipLaunchKernelGGL((moe_pw_lean_kernel<T, 2>), grid, blk, lds(2), s, a); break;
+        case 3: hipLaunchKernelGGL((moe_pw_lean_kernel<T, 3>), grid, blk, lds(3), s, a); break;
+        default: hipLaunchKernelGGL((moe_pw_lean_kernel<T, 4>), grid, blk, lds(4), s, a); break;
+    }
+    return true;
+}
+
 template <typename T>
 static bool launch_pw_stream(MoePwArgs a, hipStream_t s) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
@@ -662,6 +980,7 @@ static bool launch_pw_stream(MoePwArgs a, hipStream_t s) {
 template <typename T>
 static int launch_pw(MoePwArgs a, hipStream_t s) {
     dim3 blk(256);
+    if (launch_pw_lean<T>(a, s)) return ymk_launch_status();
     if (launch_pw_stream<T>(a, s)) return ymk_launch_status();
     if (a.Cout > 64) {
         a.tiles = (a.HW + 127) / 128;

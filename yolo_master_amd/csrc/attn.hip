@@ -10,7 +10,7 @@
 // accumulator layout is applied identically to the V^T operand).
 #include "igemm.h"
 
-#define AT_KC 256
+#define AT_KC 256   // streaming kernel: keys per staged chunk
 #define AT_NT 256   // threads per workgroup: 4 waves x 16 queries (512 measured ~5% slower on the A2C2f layers)
 
 // WPE: waves per SIMD the register allocation is held to (left alone the compiler takes ~280 registers and one
@@ -190,12 +190,126 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 // arithmetic (score tiles, exp2-domain online softmax in 256-key chunks, P fed to the second MFMA from registers) is the
 // streaming kernel's, so the two agree to rounding.  Used whenever K + V^T fit the LDS (Na <= 1024 bf16 / 512 fp32).
 // ---------------------------------------------------------------------------------------------------------------------
+// max over the lanes that share (lane & 15): the two cross-row steps as register swaps (v_permlane16/32_swap: no LDS round trip)
+__device__ __forceinline__ float at_rowgroup_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float at_rowgroup_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// One chunk of NP pairs of 16-key tiles (32 NP keys from c0) against a wave's 16 queries: score tiles, online-softmax update,
+// P V.  Every loop bound is a compile-time constant, so the whole chunk is ONE basic block: the per-tile `if (tk < ntile)`
+// guards this replaces put a branch, an LDS round trip and an MFMA latency in series 25 times per query tile (113 branches in
+// the kernel; a SIMD with three waves was busy a third of the time).  `valid` < 32 NP only in the last chunk: keys past it
+// (zero padding / the rows after K) get -inf in the last pair, which is where a ragged end falls by construction.
+template <typename T, int NP>
+__device__ __forceinline__ void at_chunk(const T* __restrict__ sK, const T* __restrict__ sVt, int VP, int c0, int valid,
+                                         const u32x4* qf, f32x4 (&o)[2], float& mrun, float& lrun, float scale, int fi, int g) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int NF = sizeof(T) == 2 ? 1 : 2;
+    constexpr bool PRECISE = sizeof(T) == 4;
+    constexpr int NTILE = 2 * NP;
+    const float c2 = scale * 1.4426950408889634f;
+    f32x4 sacc[NTILE];
+    // all K fragments of the chunk are requested before the first MFMA, and all V fragments before the softmax arithmetic: left to
+    // itself the compiler waited for every LDS read right before its use (27 waits per chunk, ~100 cycles each, in series)
+    u32x4 kf[NTILE][NF];
+#pragma unroll
+    for (int tk = 0; tk < NTILE; ++tk)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) kf[tk][f] = *reinterpret_cast<const u32x4*>(&sK[(c0 + tk * 16 + fi) * 32 + f * 16 + g * VEC]);
+#pragma unroll
+    for (int tk = 0; tk < NTILE; ++tk) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < NF; ++f) mma16<T>(acc, kf[tk][f], qf[f]);
+        if (PRECISE) acc *= scale;
+        sacc[tk] = acc;
+    }
+    u32x4 va[sizeof(T) == 2 ? NP : 1][2];
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const T* vr = &sVt[(dt * 16 + fi) * VP + c0 + g * 4];
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + (2 * u) * 16);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(vr + (2 * u + 1) * 16);
+                va[u][dt] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+    }
+    if (valid < 32 * NP) {   // wave-uniform
+#pragma unroll
+        for (int tk = NTILE - 2; tk < NTILE; ++tk) {
+            const int key0 = tk * 16 + g * 4;
+            sacc[tk].x = key0 + 0 < valid ? sacc[tk].x : -INFINITY;
+            sacc[tk].y = key0 + 1 < valid ? sacc[tk].y : -INFINITY;
+            sacc[tk].z = key0 + 2 < valid ? sacc[tk].z : -INFINITY;
+            sacc[tk].w = key0 + 3 < valid ? sacc[tk].w : -INFINITY;
+        }
+    }
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int tk = 0; tk < NTILE; ++tk) cmax = fmaxf(cmax, fmaxf(fmaxf(sacc[tk].x, sacc[tk].y), fmaxf(sacc[tk].z, sacc[tk].w)));
+    cmax = at_rowgroup_max(cmax);
+    const float mnew = fmaxf(mrun, cmax);
+    const float resc = PRECISE ? expf(mrun - mnew) : __builtin_amdgcn_exp2f((mrun - mnew) * c2);
+    const float nmc = -mnew * c2;
+    mrun = mnew;
+    o[0] *= resc;
+    o[1] *= resc;
+    float lsum = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NTILE; ++tk) {
+        f32x4 p = sacc[tk];
+        if (PRECISE) {
+            p.x = expf(p.x - mnew); p.y = expf(p.y - mnew); p.z = expf(p.z - mnew); p.w = expf(p.w - mnew);
+        } else {
+            p.x = __builtin_amdgcn_exp2f(fmaf(p.x, c2, nmc)); p.y = __builtin_amdgcn_exp2f(fmaf(p.y, c2, nmc));
+            p.z = __builtin_amdgcn_exp2f(fmaf(p.z, c2, nmc)); p.w = __builtin_amdgcn_exp2f(fmaf(p.w, c2, nmc));
+        }
+        lsum += (p.x + p.y) + (p.z + p.w);
+        sacc[tk] = p;
+    }
+    lrun = lrun * resc + lsum;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            u32x4 pb;
+            pb.x = pack_bf16x2(sacc[2 * u].x, sacc[2 * u].y);
+            pb.y = pack_bf16x2(sacc[2 * u].z, sacc[2 * u].w);
+            pb.z = pack_bf16x2(sacc[2 * u + 1].x, sacc[2 * u + 1].y);
+            pb.w = pack_bf16x2(sacc[2 * u + 1].z, sacc[2 * u + 1].w);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) mma16<T>(o[dt], va[u][dt], pb);
+        }
+    } else {
+#pragma unroll
+        for (int tk = 0; tk < NTILE; ++tk) {
+            u32x4 pb;
+            pb.x = __float_as_uint(sacc[tk].x); pb.y = __float_as_uint(sacc[tk].y);
+            pb.z = __float_as_uint(sacc[tk].z); pb.w = __float_as_uint(sacc[tk].w);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const u32x4 va = *reinterpret_cast<const u32x4*>(&sVt[(dt * 16 + fi) * VP + c0 + tk * 16 + g * 4]);
+                mma16<T>(o[dt], va, pb);
+            }
+        }
+    }
+}
+
 template <typename T, int WPE>
 __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void area_attn_resident_kernel(
     const T* __restrict__ qkv, int ldq, T* __restrict__ out, int ldo, int N, int Na, int heads, int area, float scale) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int NF = sizeof(T) == 2 ? 1 : 2;
-    constexpr bool PRECISE = sizeof(T) == 4;
     constexpr int CPR = 32 / VEC;              // 16-byte chunks per 32-wide head row
     extern __shared__ __attribute__((aligned(16))) char at_smem[];
     const int Nk = (Na + 31) & ~31;            // keys incl. zero padding (the P V product walks 32 keys at a time)
@@ -214,133 +328,138 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     const T* base = qkv + (size_t)b * N * ldq;
 
     // ---- stage every key / value of the head once: K row-major, V transposed ------------------------------------------------
-    for (int i0 = 0; i0 < Nk * CPR; i0 += AT_NT * 4) {
-        u32x4 kreg[4], vreg[4];
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {          // four independent loads per thread in flight
-            const int i = i0 + t + l * AT_NT;
-            const int key = i / CPR, ch = i % CPR;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (key < Na) {
-                const T* p = base + (size_t)(tok0 + key) * ldq + h * 32 + ch * VEC;
-                kv = *reinterpret_cast<const u32x4*>(p + Cq);
-                vv = *reinterpret_cast<const u32x4*>(p + 2 * Cq);
-            }
-            kreg[l] = kv; vreg[l] = vv;
-        }
+    auto kload = [&](int i0, u32x4 (&kreg)[4]) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const int i = i0 + t + l * AT_NT;
             const int key = i / CPR, ch = i % CPR;
-            if (key < Nk) {
-                if (key < Nr) *reinterpret_cast<u32x4*>(&sK[key * 32 + ch * VEC]) = kreg[l];
-                const T* ve = reinterpret_cast<const T*>(&vreg[l]);
+            u32x4 kv = {0u, 0u, 0u, 0u};
+            if (key < Na) kv = *reinterpret_cast<const u32x4*>(base + (size_t)(tok0 + key) * ldq + h * 32 + ch * VEC + Cq);
+            kreg[l] = kv;
+        }
+    };
+    auto kstore = [&](int i0, const u32x4 (&kreg)[4]) {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) sVt[(ch * VEC + q) * VP + key] = ve[q];
+        for (int l = 0; l < 4; ++l) {
+            const int i = i0 + t + l * AT_NT;
+            if (i < Nr * CPR) *reinterpret_cast<u32x4*>(&sK[(size_t)i * VEC]) = kreg[l];
+        }
+    };
+    // V^T (bf16) as (key, key + 1) words: a thread takes the same 8 channels of two consecutive keys and stores 8 dwords; the 32 lanes of
+    // a store group hold 32 consecutive key pairs of ONE channel chunk, i.e. 32 consecutive dwords of each V^T row (the 2-byte stores
+    // this replaces were 8-way conflicted and twice as many)
+    auto vload = [&](int i0, u32x4 (&v0)[4], u32x4 (&v1)[4]) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int i = i0 + t + l * AT_NT;
+            const int kp = (i & 31) + ((i >> 7) << 5), ch = (i >> 5) & 3, key = 2 * kp;
+            u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+            const T* p = base + (size_t)(tok0 + key) * ldq + h * 32 + ch * VEC + 2 * Cq;
+            if (key < Na) a = *reinterpret_cast<const u32x4*>(p);
+            if (key + 1 < Na) c = *reinterpret_cast<const u32x4*>(p + ldq);
+            v0[l] = a; v1[l] = c;
+        }
+    };
+    auto vstore = [&](int i0, const u32x4 (&v0)[4], const u32x4 (&v1)[4]) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int i = i0 + t + l * AT_NT;
+            const int kp = (i & 31) + ((i >> 7) << 5), ch = (i >> 5) & 3;
+            if (kp < Nk / 2) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(sVt) + kp;
+                const int vp2 = VP / 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    d[(ch * 8 + 2 * q) * vp2] = (v0[l][q] & 0xffffu) | (v1[l][q] << 16);
+                    d[(ch * 8 + 2 * q + 1) * vp2] = (v0[l][q] >> 16) | (v1[l][q] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    if (sizeof(T) == 2 && Na <= 512) {
+        // the whole head in ONE round trip: 8 K + 8 V loads per thread in flight (three dependent round trips in the loops below)
+        u32x4 ka[4], kb[4], v0[4], v1[4];
+        kload(0, ka);
+        kload(AT_NT * 4, kb);
+        vload(0, v0, v1);
+        kstore(0, ka);
+        kstore(AT_NT * 4, kb);
+        vstore(0, v0, v1);
+    } else {
+        for (int i0 = 0; i0 < Nr * CPR; i0 += AT_NT * 4) {
+            u32x4 kreg[4];
+            kload(i0, kreg);
+            kstore(i0, kreg);
+        }
+    }
+    if (sizeof(T) == 2 && Na <= 512) {
+    } else if constexpr (sizeof(T) == 2) {
+        for (int i0 = 0; i0 < (Nk / 2) * CPR; i0 += AT_NT * 4) {
+            u32x4 v0[4], v1[4];
+            vload(i0, v0, v1);
+            vstore(i0, v0, v1);
+        }
+    } else {
+        for (int i0 = 0; i0 < Nk * CPR; i0 += AT_NT * 4) {
+            u32x4 vreg[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int i = i0 + t + l * AT_NT;
+                const int key = i / CPR, ch = i % CPR;
+                u32x4 vv = {0u, 0u, 0u, 0u};
+                if (key < Na) vv = *reinterpret_cast<const u32x4*>(base + (size_t)(tok0 + key) * ldq + h * 32 + ch * VEC + 2 * Cq);
+                vreg[l] = vv;
+            }
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int i = i0 + t + l * AT_NT;
+                const int key = i / CPR, ch = i % CPR;
+                if (key < Nk) {
+                    const T* ve = reinterpret_cast<const T*>(&vreg[l]);
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) sVt[(ch * VEC + q) * VP + key] = ve[q];
+                }
             }
         }
     }
     __syncthreads();
 
-    const float c2 = scale * 1.4426950408889634f;
-    for (int q0 = wave * 16; q0 < Na; q0 += (AT_NT / 64) * 16) {
-        u32x4 qf[NF];
+    // chunks of at most 7 key-tile pairs (8 spills at three waves per SIMD), as equal as they come (Na = 400: 13 pairs -> 7 + 6)
+    const int npair = Nk / 32;
+    const int nchunk = (npair + 6) / 7;
+    const int cbase = npair / nchunk, cextra = npair % nchunk;
+    u32x4 qf[NF], qn[NF];
+    auto qload = [&](int q0, u32x4 (&q)[NF]) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            qf[f] = u32x4{0u, 0u, 0u, 0u};
+            q[f] = u32x4{0u, 0u, 0u, 0u};
             if (q0 + fi < Na)
-                qf[f] = *reinterpret_cast<const u32x4*>(base + (size_t)(tok0 + q0 + fi) * ldq + h * 32 + f * 16 + g * VEC);
+                q[f] = *reinterpret_cast<const u32x4*>(base + (size_t)(tok0 + q0 + fi) * ldq + h * 32 + f * 16 + g * VEC);
         }
+    };
+    qload(wave * 16, qn);
+    for (int q0 = wave * 16; q0 < Na; q0 += (AT_NT / 64) * 16) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) qf[f] = qn[f];
+        qload(q0 + (AT_NT / 64) * 16, qn);   // the next tile's queries arrive during this tile (a global round trip per tile otherwise)
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float mrun = -INFINITY, lrun = 0.f;
-        for (int c0 = 0; c0 < Na; c0 += AT_KC) {
-            const int kc = min(AT_KC, Na - c0);
-            const int ntile = ((kc + 31) & ~31) / 16;
-            f32x4 sacc[AT_KC / 16];
-            float cmax = -INFINITY;
-#pragma unroll
-            for (int tk = 0; tk < AT_KC / 16; ++tk) {
-                if (tk < ntile) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        const u32x4 kf = *reinterpret_cast<const u32x4*>(&sK[(c0 + tk * 16 + fi) * 32 + f * 16 + g * VEC]);
-                        mma16<T>(acc, kf, qf[f]);
-                    }
-                    if (PRECISE) acc *= scale;
-                    if (tk * 16 + 16 > kc) {  // wave-uniform: only the zero-padded tail tiles
-                        const int key0 = tk * 16 + g * 4;
-                        acc.x = key0 + 0 < kc ? acc.x : -INFINITY;
-                        acc.y = key0 + 1 < kc ? acc.y : -INFINITY;
-                        acc.z = key0 + 2 < kc ? acc.z : -INFINITY;
-                        acc.w = key0 + 3 < kc ? acc.w : -INFINITY;
-                    }
-                    cmax = fmaxf(cmax, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
-                    sacc[tk] = acc;
-                }
+        int c0 = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            const int np = cbase + (c < cextra ? 1 : 0);
+            const int valid = Na - c0;   // >= 32 np except in the last chunk
+            switch (np) {
+                case 1: at_chunk<T, 1>(sK, sVt, VP, c0, valid, qf, o, mrun, lrun, scale, fi, g); break;
+                case 2: at_chunk<T, 2>(sK, sVt, VP, c0, valid, qf, o, mrun, lrun, scale, fi, g); break;
+                case 3: at_chunk<T, 3>(sK, sVt, VP, c0, valid, qf, o, mrun, lrun, scale, fi, g); break;
+                case 4: at_chunk<T, 4>(sK, sVt, VP, c0, valid, qf, o, mrun, lrun, scale, fi, g); break;
+                case 5: at_chunk<T, 5>(sK, sVt, VP, c0, valid, qf, o, mrun, lrun, scale, fi, g); break;
+                case 6: at_chunk<T, 6>(sK, sVt, VP, c0, valid, qf, o, mrun, lrun, scale, fi, g); break;
+                default: at_chunk<T, 7>(sK, sVt, VP, c0, valid, qf, o, mrun, lrun, scale, fi, g); break;
             }
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-            const float mnew = fmaxf(mrun, cmax);
-            const float resc = PRECISE ? expf(mrun - mnew) : __builtin_amdgcn_exp2f((mrun - mnew) * c2);
-            const float nmc = -mnew * c2;
-            mrun = mnew;
-            lrun *= resc;
-            o[0] *= resc;
-            o[1] *= resc;
-            float lsum = 0.f;
-#pragma unroll
-            for (int tk = 0; tk < AT_KC / 16; ++tk) {
-                if (tk < ntile) {
-                    f32x4 p = sacc[tk];
-                    if (PRECISE) {
-                        p.x = expf(p.x - mnew); p.y = expf(p.y - mnew); p.z = expf(p.z - mnew); p.w = expf(p.w - mnew);
-                    } else {
-                        p.x = __builtin_amdgcn_exp2f(fmaf(p.x, c2, nmc)); p.y = __builtin_amdgcn_exp2f(fmaf(p.y, c2, nmc));
-                        p.z = __builtin_amdgcn_exp2f(fmaf(p.z, c2, nmc)); p.w = __builtin_amdgcn_exp2f(fmaf(p.w, c2, nmc));
-                    }
-                    lsum += (p.x + p.y) + (p.z + p.w);
-                    sacc[tk] = p;
-                }
-            }
-            lrun += lsum;
-            if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                for (int u = 0; u < AT_KC / 32; ++u) {
-                    if (2 * u < ntile) {
-                        u32x4 pb;
-                        pb.x = pack_bf16x2(sacc[2 * u].x, sacc[2 * u].y);
-                        pb.y = pack_bf16x2(sacc[2 * u].z, sacc[2 * u].w);
-                        pb.z = pack_bf16x2(sacc[2 * u + 1].x, sacc[2 * u + 1].y);
-                        pb.w = pack_bf16x2(sacc[2 * u + 1].z, sacc[2 * u + 1].w);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const T* vr = &sVt[(dt * 16 + fi) * VP + c0 + g * 4];
-                            const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + (2 * u) * 16);
-                            const u32x2 hi = *reinterpret_cast<const u32x2*>(vr + (2 * u + 1) * 16);
-                            const u32x4 va = {lo.x, lo.y, hi.x, hi.y};
-                            mma16<T>(o[dt], va, pb);
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int tk = 0; tk < AT_KC / 16; ++tk) {
-                    if (tk < ntile) {
-                        u32x4 pb;
-                        pb.x = __float_as_uint(sacc[tk].x); pb.y = __float_as_uint(sacc[tk].y);
-                        pb.z = __float_as_uint(sacc[tk].z); pb.w = __float_as_uint(sacc[tk].w);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const u32x4 va = *reinterpret_cast<const u32x4*>(&sVt[(dt * 16 + fi) * VP + c0 + tk * 16 + g * 4]);
-                            mma16<T>(o[dt], va, pb);
-                        }
-                    }
-                }
-            }
+            c0 += 32 * np;
         }
-        lrun += __shfl_xor(lrun, 16);
-        lrun += __shfl_xor(lrun, 32);
+        lrun = at_rowgroup_sum(lrun);
         if (q0 + fi < Na) {
             const float inv = 1.0f / lrun;
             T* op = out + (size_t)(b * (size_t)N + tok0 + q0 + fi) * ldo + h * 32 + g * 4;

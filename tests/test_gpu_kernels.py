@@ -473,6 +473,11 @@ def test_nms_all_anchors_candidates():
     wh = torch.rand(B, 2, A, generator=g) * 60 + 2
     cls = torch.rand(B, nc, A, generator=g) * 0.5 + 0.3
     _nms_compare(torch.cat([xy, wh, cls], 1), conf_thres=0.25, iou_thres=0.7)
+    # the same load with 17 distinct scores: the radix index sort (more than 1024 candidates) must keep equal scores in anchor order
+    _nms_compare(torch.cat([xy, wh, (cls * 32).round() / 32], 1), conf_thres=0.25, iou_thres=0.7)
+    # ... and with scores spread over many binades (no digit is skipped)
+    wide = torch.rand(B, nc, A, generator=g) ** 8 * 0.9 + 0.002
+    _nms_compare(torch.cat([xy, wh, wide], 1), conf_thres=0.001, iou_thres=0.6, max_det=100)
 
 
 @pytest.mark.parametrize("agnostic", [False, True])

@@ -222,11 +222,147 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w) {
 // The 64-bit keys are unique (the low word carries the candidate index), so any correct sort yields exactly the
 // permutation of the counting rank above; this one is O(n log^2 n) instead of O(n^2).
 #define NMS_SORT_CAP 16384
-__global__ __launch_bounds__(1024) void nms_sort_kernel(NmsWs w) {
+
+// ---- 4c. same order again by a stable LSD radix sort of candidate INDICES (4-bit digits of the inverted score bits) -----------
+// The bitonic network needs log^2 passes over the keys (105 stages at 16384 elements, 155 us for the batch-64 step with one
+// workgroup per image); here a pass is: every thread takes 16 consecutive positions, counts its digits in registers (16 8-bit
+// counters in two 64-bit registers — thread-private, so the order inside the thread is kept without atomics), the 16 digit
+// channels are scanned across the workgroup as eight registers of two 16-bit fields (values <= 16384 never carry), and every
+// index is scattered to  digit base + earlier threads' count + own earlier count.  Digits on which all keys agree are skipped
+// (scores in (conf, 1) share their top bits).  LDS: 64 KB of keys (fixed) + two 32 KB index buffers, inside the bitonic
+// kernel's 128 KB; the consumed source slots of a thread hold its 16 scanned bases (dynamic indexing without a register tree).
+#define NMS_RADIX_MIN 1024   // below: the bitonic network is as fast
+#define YMK_OFF_NMS_RADIX 65536u
+__device__ __forceinline__ void nms_radix_sort(const NmsWs& w, int b, int n, unsigned* lds) {
+    unsigned* key = lds;                                                       // [NMS_SORT_CAP]
+    unsigned short* buf0 = reinterpret_cast<unsigned short*>(lds + NMS_SORT_CAP);   // [2][NMS_SORT_CAP]
+    __shared__ unsigned wtot[16][8];
+    __shared__ unsigned wbase[16][8];
+    __shared__ unsigned red[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sc = w.cscore + (size_t)b * w.capc;
+    unsigned orv = 0u, andv = ~0u;
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned k = ~__float_as_uint(sc[i]);   // ascending on the inverted bits = descending score
+        key[i] = k; orv |= k; andv &= k;
+    }
+    for (int i = tid; i < NMS_SORT_CAP / 2; i += 1024) reinterpret_cast<unsigned*>(buf0)[i] = (unsigned)(2 * i) | ((unsigned)(2 * i + 1) << 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { orv |= __shfl_xor(orv, o); andv &= __shfl_xor(andv, o); }
+    if (lane == 0) { red[0][wave] = orv; red[1][wave] = andv; }
+    __syncthreads();
+    unsigned diff;
+    {
+        unsigned o2 = 0u, a2 = ~0u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { o2 |= red[0][q]; a2 &= red[1][q]; }
+        diff = o2 ^ a2;
+    }
+    int cur = 0;
+    const int p0 = tid * 16;
+    for (int shift = 0; shift < 32; shift += 4) {
+        if (((diff >> shift) & 15u) == 0u) continue;   // every key has the same digit here: the pass would be the identity
+        unsigned short* src = buf0 + cur * NMS_SORT_CAP;
+        unsigned short* dst = buf0 + (cur ^ 1) * NMS_SORT_CAP;
+        const u32x4 r0 = *reinterpret_cast<const u32x4*>(src + p0), r1 = *reinterpret_cast<const u32x4*>(src + p0 + 8);
+        const unsigned raw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        unsigned long long clo = 0ull, chi = 0ull;
+        unsigned meta[16];   // index | digit << 16 | own earlier count << 20
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned idx = (raw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            unsigned m = idx;
+            if (p0 + k < n) {
+                const unsigned d = (key[idx] >> shift) & 15u;
+                const unsigned sh = (d & 7u) * 8u;
+                const unsigned long long sel = (d & 8u) ? chi : clo;
+                m |= (d << 16) | ((unsigned)((sel >> sh) & 0xffull) << 20);
+                const unsigned long long one = 1ull << sh;
+                if (d & 8u) chi += one; else clo += one;
+            }
+            meta[k] = m;
+        }
+        unsigned c2[8], in2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long sel = j < 4 ? clo : chi;
+            const unsigned pairbits = (unsigned)(sel >> ((j & 3) * 16)) & 0xffffu;   // digits 2j (low byte), 2j + 1 (high byte)
+            c2[j] = (pairbits & 0xffu) | ((pairbits >> 8) << 16);
+            in2[j] = c2[j];
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned v = __shfl_up(in2[j], o);
+                if (lane >= o) in2[j] += v;
+            }
+        if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wtot[wave][j] = in2[j];
+        }
+        __syncthreads();
+        if (wave == 0) {   // 16 wave totals -> exclusive base of every (wave, digit): digit base + earlier waves
+            unsigned tt[8], ti[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { tt[j] = lane < 16 ? wtot[lane][j] : 0u; ti[j] = tt[j]; }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned v = __shfl_up(ti[j], o);
+                    if (lane >= o) ti[j] += v;
+                }
+            unsigned acc = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned tot = __shfl(ti[j], 15);
+                const unsigned lo = acc; acc += tot & 0xffffu;
+                const unsigned hi = acc; acc += tot >> 16;
+                if (lane < 16) wbase[lane][j] = (lo | (hi << 16)) + ti[j] - tt[j];
+            }
+        }
+        __syncthreads();
+        {   // this thread's 16 bases into its own (consumed) source slots
+            u32x4 b0, b1;
+            b0.x = wbase[wave][0] + in2[0] - c2[0]; b0.y = wbase[wave][1] + in2[1] - c2[1];
+            b0.z = wbase[wave][2] + in2[2] - c2[2]; b0.w = wbase[wave][3] + in2[3] - c2[3];
+            b1.x = wbase[wave][4] + in2[4] - c2[4]; b1.y = wbase[wave][5] + in2[5] - c2[5];
+            b1.z = wbase[wave][6] + in2[6] - c2[6]; b1.w = wbase[wave][7] + in2[7] - c2[7];
+            *reinterpret_cast<u32x4*>(src + p0) = b0;
+            *reinterpret_cast<u32x4*>(src + p0 + 8) = b1;
+        }
+        __threadfence_block();   // the 2-byte reads below alias the 16-byte stores above (same thread, same wave: in order once emitted in order)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (p0 + k < n) {
+                const unsigned m = meta[k];
+                const unsigned r = (unsigned)src[p0 + ((m >> 16) & 15u)] + (m >> 20);
+                dst[r] = (unsigned short)(m & 0xffffu);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const unsigned short* fin = buf0 + cur * NMS_SORT_CAP;
+    const int mo = n < w.ns ? n : w.ns;
+    for (int r = tid; r < mo; r += 1024) {
+        const int i = fin[r];
+        const size_t s = (size_t)b * w.capc + i, d = (size_t)b * w.ns + r;
+        *reinterpret_cast<f32x4*>(w.sbox + d * 4) = *reinterpret_cast<const f32x4*>(w.cbox + s * 4);
+        w.sscore[d] = sc[i]; w.scls[d] = w.ccls[s]; w.sanchor[d] = w.canchor[s];
+    }
+}
+
+__global__ __launch_bounds__(1024) void nms_sort_kernel(NmsWs w, int radix) {
     __shared__ unsigned long long key[NMS_SORT_CAP];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = w.ncand[b];
     if (n <= 0) return;
+    if (n > NMS_RADIX_MIN && radix) {   // workgroup-uniform
+        nms_radix_sort(w, b, n, reinterpret_cast<unsigned*>(key));
+        return;
+    }
     int np = 64;
     while (np < n) np <<= 1;
     const float* sc = w.cscore + (size_t)b * w.capc;
@@ -371,7 +507,7 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A,
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, w, status);
     hipLaunchKernelGGL(nms_emit_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
     if (w.capc <= NMS_SORT_CAP && !(ymk_disabled() & YMK_OFF_NMS_SORT))
-        hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, s, w);
+        hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, s, w, (ymk_disabled() & YMK_OFF_NMS_RADIX) ? 0 : 1);
     else
         hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w);
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det,

@@ -14,6 +14,9 @@
 // Reference semantics: DWConv (ultralytics/nn/modules/conv.py:185-199), AAttn.pe
 // (nn/modules/block.py:1688,1731), DepthwiseSeparableConv.depthwise (nn/modules/moe/experts.py:283-292)
 // dispatched per retained (image, expert) pair as in ES_MOE._sparse_forward (moe/modules.py:690-697).
+#ifndef DW_ABLATE
+#define DW_ABLATE 0   // tools/micro/dwv_ablate.sh builds stage-ablated copies of this file (bits: 1 no global loads, 2 no LDS staging writes, 4 no FMA loop, 8 no global stores)
+#endif
 #include "ymk_common.h"
 
 #define DW_R 10   // consecutive output pixels per thread
@@ -114,7 +117,11 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
     T* wsb = reinterpret_cast<T*>(smem + (size_t)HT * RP);
     // With four workgroups resident per CU (bf16, k <= 9: 16 waves hide each other's staging) the next tile's halo is NOT prefetched
     // into registers: that prefetch holds 36 registers through the arithmetic and caps the kernel at three waves per SIMD.
+#ifdef DW_FORCE_PREFETCH
+    constexpr bool PREFETCH = true;
+#else
     constexpr bool PREFETCH = D::resident(K) < 4;
+#endif
 
     // filter block once.  fp32: channel j of each 4-group at its register-quadruple position (see lds_ld4); bf16: as stored, widened
     // at use with the same shifts / masks as the activations
@@ -134,7 +141,7 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
             const int hy = pix / WT, hx = pix - hy * WT;
             const int iy = ty0 - P + hy, ix = tx0 - P + hx;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (i < HT * WT * CPP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + q * VEC < C)
+            if (!(DW_ABLATE & 1) && i < HT * WT * CPP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + q * VEC < C)
                 v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * ldx + c0 + q * VEC);
             stg[l] = v;
         }
@@ -157,7 +164,7 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const int i = t + l * 256;
-            if (i < HT * WT * CPP) {
+            if (!(DW_ABLATE & 2) && i < HT * WT * CPP) {
                 const int pix = i / CPP, hy = pix / WT;
                 u32x2* d = reinterpret_cast<u32x2*>(smem + (size_t)hy * RP + (pix - hy * WT) * D::PSB + (i % CPP) * 16);
                 d[0] = u32x2{stg[l].x, stg[l].y};
@@ -174,7 +181,7 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
 #pragma unroll
         for (int r = 0; r < DW_R; ++r) { acc[r][0] = f32x2{0.f, 0.f}; acc[r][1] = f32x2{0.f, 0.f}; }
 #pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
+        for (int ky = 0; ky < ((DW_ABLATE & 4) ? 1 : K); ++ky) {
             f32x2 wr[K][2];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
@@ -219,7 +226,7 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
                 load4(rb + pix * ep.ldr + c0 + cg * 4, r0, r1, r2, r3);
                 v[0] = r0 + v[0]; v[1] = r1 + v[1]; v[2] = r2 + v[2]; v[3] = r3 + v[3];
             }
-            store4(ob + pix * ldy + c0 + cg * 4, v[0], v[1], v[2], v[3]);
+            if (!(DW_ABLATE & 8) || v[0] == 12345.f) store4(ob + pix * ldy + c0 + cg * 4, v[0], v[1], v[2], v[3]);
         }
     }
 }

@@ -83,7 +83,8 @@ int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, const float
 #define YMK_CONV_TILED       0  /* tiled implicit GEMM (any shape)                                   */
 #define YMK_CONV_STREAM_1X1  1  /* weight-stationary persistent streaming 1x1 (large M, Kpad <= 256) */
 #define YMK_CONV_SPATIAL_3X3 2  /* spatial-tile 3x3 with LDS-staged im2col (stride 1, Cin 16/32/64)  */
-#define YMK_CONV_GLDS        3  /* LDS-DMA tiled core (ymk_next.h): bf16 3x3 with Cin >= 64; every shape with YMK_ENABLE bit 0 */
+#define YMK_CONV_GLDS        3  /* LDS-DMA tiled core (ymk_next.h): bf16 3x3 with Cin >= 64; every shape with YMK_ENABLE bit 0;
+                                * LDS stages in bits 8-15 and pixel-tile height in bits 16+ of the returned value              */
 int32_t ymk_conv2d_last_variant(void);
 
 /* 1x1 convolution over the channel concatenation [x1 | x2] without materialising it; with upsample1 != 0 the

@@ -47,7 +47,7 @@ def build(force: bool = False) -> Path | None:
         u = OUT / (s.stem + "_host.cpp")
         u.write_text(txt)
         units.append(str(u))
-    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DYMK_HOST_EMU", "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(lib)]
+    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DGLDS_SMALL_BELOW_DEFAULT=3", "-DYMK_HOST_EMU", "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(lib)]
     subprocess.run(cmd, check=True)
     return lib
 

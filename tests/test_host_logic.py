@@ -154,8 +154,9 @@ def test_conv_kernel_names_match_the_committed_profiles():
     names = [
         ops.conv_kernel_name(0, bf, 256, 128, 1, 256, True),              # tiled 1x1, 128x128 tile
         ops.conv_kernel_name(0, bf, 64, 64, 1, 64, False),                # tiled 1x1, 64x256 tile
-        ops.conv_kernel_name(3 | (2 << 8), bf, 256, 256, 3, 2304, False),  # LDS-DMA tiled 3x3, 128 couts, two stages
-        ops.conv_kernel_name(3 | (2 << 8), bf, 128, 64, 3, 1152, False),  # ... 64 couts
+        ops.conv_kernel_name(3 | (2 << 8) | (128 << 16), bf, 256, 256, 3, 2304, False),  # LDS-DMA tiled 3x3, 128 couts, two stages, 128-pixel tiles
+        ops.conv_kernel_name(3 | (2 << 8) | (128 << 16), bf, 128, 64, 3, 1152, False),  # ... 64 couts
+        ops.conv_kernel_name(3 | (2 << 8) | (256 << 16), bf, 256, 64, 3, 2304, False),  # ... 256-pixel tiles (mid-size launches)
         ops.conv_kernel_name(1, bf, 96, 128, 1, 128, False),              # streaming 1x1, 2 K groups
         ops.conv_kernel_name(2, bf, 32, 32, 3, 320, True),                # spatial tile 3x3 with residual prefetch
         ops.conv_kernel_name(0, bf, 512, 128, 1, 512, False, dual=True),  # cat2

@@ -27,12 +27,13 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
                                void* y, int32_t two_stage, void* stream);   // csrc/conv_glds.hip, include/ymk_next.h
 extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
                                      int32_t ldx2, const void* w, const float* bias, void* y, int32_t two_stage, void* stream);
+int ymk_glds_last_tile();   // csrc/conv_glds.hip: pixel-tile height of the thread's last LDS-DMA launch
 static int ymk_glds_min_tiles = [] { const char* e = getenv("YMK_GLDS_MIN_TILES"); return e ? atoi(e) : 192; }();
 // one workgroup per CU (144 KB of LDS): with fewer than four k-steps there is nothing to pipeline, the current kernels win
 static int ymk_glds_min_k = [] { const char* e = getenv("YMK_GLDS_MIN_K"); return e ? atoi(e) : 256; }();
 // diagnostic (kernel naming in bench.py / tools): variant code, plus the LDS stage count << 8 for the LDS-DMA core
 extern "C" int32_t ymk_conv2d_last_variant(void) {
-    return ymk_last_variant == YMK_CONV_GLDS ? (ymk_last_variant | (ymk_last_glds_stages << 8)) : ymk_last_variant;
+    return ymk_last_variant == YMK_CONV_GLDS ? (ymk_last_variant | (ymk_last_glds_stages << 8) | (ymk_glds_last_tile() << 16)) : ymk_last_variant;
 }
 
 template <typename T, bool PRECISE>
@@ -603,10 +604,10 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     }
     if (d->ksize == 3 && d->dtype == YMK_BF16 && !(ymk_disabled() & YMK_OFF_CONV_GLDS3) && !(ymk_enabled() & YMK_ON_CONV_GLDS)) {
         // 3x3 with Cin >= 64 (the stride-2 down-sampling convs, the Detect / C3k 3x3s): LDS-DMA tiled core.  Measured faster than
-        // conv_igemm_kernel on every such shape of the S detector (profiles/r02a_glds_ab.log: 6-35 %), two LDS stages except
-        // for 128-wide cout tiles with >= 1024 tiles (128->128 s2 from 160x160), where the three-stage counted-vmcnt loop wins.
-        const int64_t tiles = ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
-        const bool three = d->Cout % 128 == 0 && tiles >= 1024;
+        // conv_igemm_kernel on every such shape of the S detector (profiles/r02a_glds_ab.log: 6-35 %), two LDS stages: with the
+        // 128-pixel tiles the core now takes (two or three workgroups per CU) the three-stage counted-vmcnt loop no longer wins
+        // anywhere (profiles/r02_glds_tile_ab.txt).  YMK_GLDS_THREE_STAGE=1 brings it back for A/B runs.
+        static const bool three = [] { const char* e = getenv("YMK_GLDS_THREE_STAGE"); return e && atoi(e) != 0; }();
         if (d->Cout % 64 == 0) {
             const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, three ? 0 : 1, stream);
             if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = three ? 3 : 2; return rc; }

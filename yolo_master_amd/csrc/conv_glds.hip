@@ -23,7 +23,14 @@ typedef void* glds_lptr;
 #define GLDS_COMPILER_FENCE() ((void)0)
 #endif
 
-#define GLDS_BM 256
+#define GLDS_BM 256   // pixels per tile (default); GLDS_BM_SMALL for launches that would leave CUs without a second workgroup
+#define GLDS_BM_SMALL 128
+#ifndef GLDS_SMALL_BELOW_DEFAULT
+#define GLDS_SMALL_BELOW_DEFAULT (-1)   // no override: the measured rule of glds_launch
+#endif
+#ifndef GLDS_ABLATE
+#define GLDS_ABLATE 0   // tools/micro/glds_ablate.sh: 1 no fragment reads / MFMA, 2 no DMA after the prologue, 4 no workgroup barrier, 8 no MFMA only
+#endif
 // s_waitcnt immediate (gfx9 family): vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
 #define GLDS_WAITCNT_VM(n) (0x0F70 | ((n) & 15) | ((((n) >> 4) & 3) << 14))
 
@@ -46,15 +53,15 @@ struct GldsArgs {
     int K;
 };
 
-template <int BN, int STAGES>
+template <int BN, int STAGES, int BM = GLDS_BM>
 __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
-    constexpr int ROWS = BN + GLDS_BM;        // staged rows per k-step: weights first, then pixels
+    constexpr int ROWS = BN + BM;        // staged rows per k-step: weights first, then pixels
     constexpr int STAGE_U4 = ROWS * 8;        // 16-byte slots per stage
     constexpr int G = ROWS / 64;              // global_load_lds instructions per wave per k-step (6 or 5)
     constexpr int GW = BN / 64;               // of which weight rows
     constexpr int WN = BN / 64;               // waves along couts (64 couts per wave)
     constexpr int WM = 8 / WN;                // waves along pixels
-    constexpr int TP = GLDS_BM / WM / 16;     // 16-pixel fragments per wave (4 or 2)
+    constexpr int TP = BM / WM / 16;          // 16-pixel fragments per wave (4 or 2; 2 or 1 with 128-pixel tiles)
     extern __shared__ u32x4 smem[];           // STAGES * STAGE_U4
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -69,14 +76,14 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int n0 = (bid % nt) * BN;
-    int m0 = (bid / nt) * GLDS_BM, Mlim = M, b_img = -1;
+    int m0 = (bid / nt) * BM, Mlim = M, b_img = -1;
     size_t out_base = 0;
     const bf16_t* wbase = a.w;
     if (a.eidx) {   // (slot, image, tile-in-image)
-        const int HW = a.Ho * a.Wo, tpi = (HW + GLDS_BM - 1) / GLDS_BM, r = bid / nt;
+        const int HW = a.Ho * a.Wo, tpi = (HW + BM - 1) / BM, r = bid / nt;
         const int bj = r / tpi;
         b_img = bj % a.B;
-        m0 = (r % tpi) * GLDS_BM;
+        m0 = (r % tpi) * BM;
         Mlim = HW;
         out_base = (size_t)bj * HW;
         wbase = a.w + (size_t)a.eidx[b_img * a.K + bj / a.B] * a.Cout * a.Kpad;
@@ -132,9 +139,16 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         for (int j = 0; j < G; ++j) {
             u32x4* dst = smem + stage * STAGE_U4 + (j * 8 + wave) * 64;   // wave-uniform; the lane lands at + lane * 16 B
             const bf16_t* s;
-            if (j < GW) s = wsrc[j] + it_k * 64;
-            else if (second) s = pmask[j - GW] ? a.x2 + (poff2[j - GW] + (it_k - k1) * 64) : zsrc;
-            else s = ((pmask[j - GW] >> it_tap_bit) & 1u) ? a.x + (poff[j - GW] + tapoff) : zsrc;
+            if (j < GW) {
+                s = wsrc[j] + it_k * 64;
+            } else {
+                // pixel address or the zero page, selected with mask arithmetic: written as `cond ? p : zsrc` the compiler built a
+                // divergent branch per load (ten per k-step, in a loop whose useful content is 16 MFMAs per wave)
+                const bool ok = second ? pmask[j - GW] != 0u : ((pmask[j - GW] >> it_tap_bit) & 1u) != 0u;
+                const bf16_t* p = second ? a.x2 + (poff2[j - GW] + (it_k - k1) * 64) : a.x + (poff[j - GW] + tapoff);
+                const uintptr_t pa = reinterpret_cast<uintptr_t>(p), za = reinterpret_cast<uintptr_t>(zsrc);
+                s = reinterpret_cast<const bf16_t*>(za ^ ((pa ^ za) & ((uintptr_t)0 - (uintptr_t)ok)));
+            }
             __builtin_amdgcn_global_load_lds((glds_gptr)s, (glds_lptr)dst, 16, 0, 0);
         }
         ++it_k;
@@ -152,6 +166,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int stage) {
+        if (GLDS_ABLATE & 1) return;
         const u32x4* sW = smem + stage * STAGE_U4;
         const u32x4* sX = sW + BN * 8;
 #pragma unroll
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
+                    if (GLDS_ABLATE & 8) acc[i][j].x += __uint_as_float(af[i].x ^ bfr[j].y); else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(glds_bf16x8, af[i]),
                                                                        __builtin_bit_cast(glds_bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
         }
@@ -183,9 +199,9 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
             // workgroup barrier alone is not required to wait for outstanding global->LDS transfers of OTHER waves' making)
             __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(0));
             GLDS_WAIT_LGKM0();
-            __builtin_amdgcn_s_barrier();   // everyone's pieces landed: stage kt&1 complete, the other one free
+            if (!(GLDS_ABLATE & 4)) __builtin_amdgcn_s_barrier();   // everyone's pieces landed: stage kt&1 complete, the other one free
             GLDS_COMPILER_FENCE();
-            if (kt + 1 < nk) issue((kt + 1) & 1);
+            if (kt + 1 < nk && !(GLDS_ABLATE & 2)) issue((kt + 1) & 1);
             compute(kt & 1);
         }
     } else {
@@ -196,9 +212,9 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
             if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(G));   // my pieces of k-step kt have landed
             else __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(0));
             GLDS_WAIT_LGKM0();                  // my fragment reads of k-step kt-1 are done (WAR on stage nxt)
-            __builtin_amdgcn_s_barrier();       // everyone's pieces landed, everyone's reads done
+            if (!(GLDS_ABLATE & 4)) __builtin_amdgcn_s_barrier();       // everyone's pieces landed, everyone's reads done
             GLDS_COMPILER_FENCE();
-            if (kt + 2 < nk) issue(nxt);
+            if (kt + 2 < nk && !(GLDS_ABLATE & 2)) issue(nxt);
             compute(cur);
             cur = cur == 2 ? 0 : cur + 1;
             nxt = nxt == 2 ? 0 : nxt + 1;
@@ -241,19 +257,44 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     }
 }
 
-template <int BN, int STAGES>
-static int glds_launch(const GldsArgs& a, hipStream_t s) {
+template <int BN, int STAGES, int BM>
+static int glds_launch_bm(const GldsArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
-    const int grid = (a.eidx ? a.K * a.B * ((a.Ho * a.Wo + GLDS_BM - 1) / GLDS_BM) : (M + GLDS_BM - 1) / GLDS_BM) * (a.Cout / BN);
-    const size_t lds = (size_t)STAGES * (BN + GLDS_BM) * 8 * 16;
+    const int grid = (a.eidx ? a.K * a.B * ((a.Ho * a.Wo + BM - 1) / BM) : (M + BM - 1) / BM) * (a.Cout / BN);
+    const size_t lds = (size_t)STAGES * (BN + BM) * 8 * 16;
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute((const void*)conv_glds_kernel<BN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_glds_kernel<BN, STAGES, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return YMK_E_LAUNCH;
         once = true;
     }
-    hipLaunchKernelGGL((conv_glds_kernel<BN, STAGES>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_glds_kernel<BN, STAGES, BM>), dim3(grid), dim3(512), lds, s, a);
     return ymk_launch_status();
+}
+
+// Tile height: 128 pixels when the 256-pixel launch would have fewer than `glds_small_below` workgroups (default: always), else 256.
+// A 128-cout x 256-pixel tile of two 49 KB stages leaves room for ONE workgroup per CU: its DMA wait, barrier and MFMA phases run one
+// after the other (stage ablation, tools/micro/glds_ablate.sh: the MFMAs are 6 % of 128->128 s2 at 160^2, the DMA 36 %); with
+// 128-pixel tiles two (128 couts) or three (64 couts) workgroups share a CU and overlap them.  Same arithmetic, bit-identical output.
+// pixel-tile height of the calling thread's last launch (ymk_conv2d_last_variant reports it in bits 16+: profilers' kernel names)
+static thread_local int glds_last_tile = 0;
+int ymk_glds_last_tile() { return glds_last_tile; }
+
+static int glds_small_below() {   // YMK_GLDS_SMALL_BELOW=<n>: 128-pixel tiles iff the 256-pixel launch has fewer than n workgroups (A/B runs); unset: the rule below
+    static const int v = [] { const char* e = getenv("YMK_GLDS_SMALL_BELOW"); return e ? atoi(e) : GLDS_SMALL_BELOW_DEFAULT; }();
+    return v;
+}
+template <int BN, int STAGES>
+static int glds_launch(const GldsArgs& a, hipStream_t s) {
+    const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+    const int64_t grid256 = (a.eidx ? (int64_t)a.K * a.B * ((a.Ho * a.Wo + GLDS_BM - 1) / GLDS_BM) : (M + GLDS_BM - 1) / GLDS_BM) * (a.Cout / BN);
+    // measured rule (profiles/r02_glds_tile_ab.txt): 128-cout tiles always; 64-cout tiles when the launch is small (under one
+    // 256-pixel workgroup per CU) or large (>= 1024), not in between (256 -> 64 at 40^2: 69 vs 78 us)
+    bool small = BN == 128 || grid256 < 256 || grid256 >= 1024;
+    if (glds_small_below() >= 0) small = grid256 < glds_small_below();
+    glds_last_tile = small ? GLDS_BM_SMALL : GLDS_BM;
+    if (small) return glds_launch_bm<BN, STAGES, GLDS_BM_SMALL>(a, s);
+    return glds_launch_bm<BN, STAGES, GLDS_BM>(a, s);
 }
 
 // Same arguments and result as ymk_conv2d; returns YMK_E_BADARG for shapes outside this kernel's domain (the caller then

@@ -159,7 +159,7 @@ def test_conv_kernel_names_match_the_committed_profiles():
         ops.conv_kernel_name(3 | (2 << 8) | (256 << 16), bf, 256, 64, 3, 2304, False),  # ... 256-pixel tiles (mid-size launches)
         ops.conv_kernel_name(1, bf, 96, 128, 1, 128, False),              # streaming 1x1, 2 K groups
         ops.conv_kernel_name(2, bf, 32, 32, 3, 320, True),                # spatial tile 3x3 with residual prefetch
-        ops.conv_kernel_name(0, bf, 512, 128, 1, 512, False, dual=True),  # cat2
+        ops.conv_kernel_name(3 | (2 << 8) | (128 << 16), bf, 512, 128, 1, 512, False, dual=True),  # cat2 (on the LDS-DMA core)
     ]
     for n in names:
         assert n in prof, f"{n!r} is not a kernel name of the committed profile {latest.name}"

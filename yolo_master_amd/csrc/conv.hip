@@ -613,11 +613,18 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
             if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = three ? 3 : 2; return rc; }
         }
     }
-    if ((ymk_enabled() & YMK_ON_CONV_GLDS) && d->dtype == YMK_BF16) {   // opt-in for every shape: next tiled core (include/ymk_next.h)
+    // The tiled 1x1 shapes (K >= 256, Cout a multiple of 128, at least 192 tiles of 256 pixels): with 128-pixel tiles and the two-stage
+    // loop the LDS-DMA core is 0-20 % faster than conv_igemm_kernel on 15 of the 17 such launches of the S detector and equal on the
+    // rest (profiles/r02_glds_tile_ab.txt; with 256-pixel tiles it was slower, which is why it was opt-in before).
+    // YMK_ENABLE bit 0 still routes EVERY shape the core accepts here (bit 1: with the two-stage loop).
+    const bool glds_all = (ymk_enabled() & YMK_ON_CONV_GLDS) != 0;
+    const bool glds_1x1 = d->ksize == 1 && d->Cout % 128 == 0 && !(ymk_disabled() & YMK_OFF_CONV_GLDS1);
+    if ((glds_all || glds_1x1) && d->dtype == YMK_BF16) {
         const int64_t tiles = ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
         if (d->Cout % 64 == 0 && tiles >= ymk_glds_min_tiles && d->Kpad >= ymk_glds_min_k) {
-            const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 1 : 0, stream);
-            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 2 : 3; return rc; }
+            const bool two = glds_all ? (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) != 0 : true;
+            const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, two ? 1 : 0, stream);
+            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = two ? 2 : 3; return rc; }
         }
     }
     ymk_last_variant = YMK_CONV_TILED;
@@ -646,11 +653,17 @@ extern "C" int ymk_conv1x1_cat2(const ymk_conv_desc* d, const void* x1, int32_t 
     a.M = (int64_t)d->B * d->H * d->W;
     if (a.M <= 0) return YMK_OK;
     if (a.M >= (1ll << 31) || (2ll * d->H * d->W + 4096) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31)) return YMK_E_BADARG;
-    if ((ymk_enabled() & YMK_ON_CONV_GLDS) && d->dtype == YMK_BF16 && d->Cout % 64 == 0 &&
-        ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64)) >= ymk_glds_min_tiles && d->Kpad >= ymk_glds_min_k) {   // opt-in
-        const int rc = ymk_conv1x1_cat2_glds(d, x1, C1, ldx1, upsample1, x2, ldx2, w, bias, y, (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) ? 1 : 0, stream);
-        if (rc != YMK_E_BADARG) return rc;
+    // same rule as the tiled 1x1 shapes of ymk_conv2d: the LDS-DMA core with 128-pixel tiles and the two-stage loop is 5-8 % faster on
+    // the four cat2 launches of the S detector (118 -> 112, 79 -> 72, 57 -> 52, 27 -> 25 us)
+    const bool glds_all = (ymk_enabled() & YMK_ON_CONV_GLDS) != 0;
+    const bool glds_1x1 = d->Cout % 128 == 0 && !(ymk_disabled() & YMK_OFF_CONV_GLDS1);
+    if ((glds_all || glds_1x1) && d->dtype == YMK_BF16 && d->Cout % 64 == 0 &&
+        ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64)) >= ymk_glds_min_tiles && d->Kpad >= ymk_glds_min_k) {
+        const bool two = glds_all ? (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) != 0 : true;
+        const int rc = ymk_conv1x1_cat2_glds(d, x1, C1, ldx1, upsample1, x2, ldx2, w, bias, y, two ? 1 : 0, stream);
+        if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = two ? 2 : 3; return rc; }
     }
+    ymk_last_variant = YMK_CONV_TILED;
     return d->dtype == YMK_F32 ? launch_conv_dual<float>(a, (hipStream_t)stream) : launch_conv_dual<bf16_t>(a, (hipStream_t)stream);
 }
 

@@ -114,6 +114,7 @@ static inline int ymk_launch_status() {
 #define YMK_OFF_RES_PREFETCH 16u  // register prefetch of residual operands in the spatial-tile 3x3 kernel
 #define YMK_OFF_STEM_ROWS 32u     // LDS-staged stem rows -> direct gathers from the image
 #define YMK_OFF_MOE_LEAN 32768u    // table-driven ES-MoE pointwise stage -> moe_pw_stream_kernel
+#define YMK_OFF_CONV_GLDS1 131072u  // tiled bf16 1x1 convolutions (K >= 256, Cout % 128 == 0) on the LDS-DMA core -> conv_igemm_kernel
 #define YMK_OFF_CONV_GLDS3 128u   // bf16 3x3 convolutions with Cin >= 64 on the LDS-DMA tiled core -> conv_igemm_kernel
 static inline unsigned ymk_disabled() {
     static const unsigned m = [] {

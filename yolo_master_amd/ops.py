@@ -65,7 +65,7 @@ def conv_kernel_name(variant: int, dtype, cin: int, cout: int, k: int, kpad: int
     committed rocprof / PMC summaries refer to the same kernel."""
     t = "unsigned short" if dtype == torch.bfloat16 else "float"
     es = 2 if dtype == torch.bfloat16 else 4
-    if dual:
+    if dual and variant & 0xff != 3:
         return f"conv_igemm_kernel<{t}, {_tile(cout)}, 1, true>"
     if variant & 0xff == 3:   # LDS-DMA tiled core (default for bf16 3x3 with Cin >= 64; YMK_ENABLE bit 0: every shape); stages in bits 8+
         return f"conv_glds_kernel<{128 if cout % 128 == 0 else 64}, {(variant >> 8) & 0xff}, {(variant >> 16) or 256}>"   # pixel-tile height in bits 16+
@@ -219,7 +219,7 @@ def conv1x1_cat2(x1, up1: bool, x2, w_packed, bias, act: bool, out=None):
     check(lib.ymk_conv1x1_cat2(C.byref(d), _p(x1), C1, ld1, int(up1), _p(x2), ld2, _p(w_packed), _p(bias), _p(out), _stream()),
           "conv1x1_cat2")
     es = x2.element_size()
-    TIMER.end(e0, conv_kernel_name(0, x2.dtype, C1 + C2, Cout, 1, Kp, False, dual=True),
+    TIMER.end(e0, conv_kernel_name(lib.ymk_conv2d_last_variant(), x2.dtype, C1 + C2, Cout, 1, Kp, False, dual=True),
               (B1 * H1 * W1 * C1 + B * H * W * C2 + Cout * (C1 + C2) + B * H * W * Cout) * es,
               2 * B * H * W * Cout * (C1 + C2), f"{C1}+{C2}->{Cout} @{H}x{W}{' up' if up1 else ''}")
     return out

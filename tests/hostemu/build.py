@@ -16,7 +16,8 @@ HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
 CSRC = ROOT / "yolo_master_amd" / "csrc"
 OUT = HERE / "_build"
-SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "dwmfma.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip"]
+SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "dwmfma.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip",
+           "esmoe.hip", "attn.hip", "nms.hip"]
 
 
 def compiler():
@@ -39,7 +40,8 @@ def build(force: bool = False) -> Path | None:
     units = []
     for s in srcs:
         txt = s.read_text()
-        txt = re.sub(r"\bextern\s+__shared__\s+(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(hostemu::dyn_lds);", txt)
+        txt = re.sub(r"__attribute__\(\(amdgpu_waves_per_eu\([^;{]*?\)\)\)\s*(?=void)", "", txt)   # occupancy hint of GPU kernels
+        txt = re.sub(r"\bextern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(hostemu::dyn_lds);", txt)
         txt = re.sub(r"\b__shared__\b", "static", txt)
         txt = txt.replace('#include "ymk_common.h"', f'#include "{CSRC / "ymk_common.h"}"')
         txt = txt.replace('#include "igemm.h"', f'#include "{CSRC / "igemm.h"}"')

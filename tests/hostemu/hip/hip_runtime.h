@@ -26,6 +26,7 @@ struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+struct int4 { int x, y, z, w; };
 typedef void* hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
@@ -38,7 +39,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 // wave-level exchanges between two workgroup barriers (a wave with fewer MFMA steps than its neighbours), as on the GPU.
 // Kernels whose lanes skip a barrier other lanes take are not supported (and would be broken on the GPU as well).
 namespace hostemu {
-constexpr unsigned MAX_LANES = 512;           // the largest workgroup any emulated kernel uses
+constexpr unsigned MAX_LANES = 1024;          // the largest workgroup any emulated kernel uses (the NMS ordering kernels)
 constexpr size_t STACK = 128 * 1024;
 struct Fiber {
     ucontext_t ctx;
@@ -49,7 +50,7 @@ inline ucontext_t sched;
 inline char* stacks = nullptr;
 inline unsigned cur = 0;
 inline dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
-inline float xch[MAX_LANES];                  // shuffle exchange, one slot per lane
+inline uint64_t xch[MAX_LANES];               // shuffle exchange, one (up to 64-bit) slot per lane
 alignas(16) inline float dyn_lds[40960];     // dynamic LDS of `extern __shared__` kernels (160 KB: one CU's LDS)
 inline std::function<void()> job;
 
@@ -120,17 +121,74 @@ void launch(F&& body, dim3 grid, dim3 block) {
 #define gridDim hostemu::g_gridDim
 
 static inline void __syncthreads() { hostemu::block_sync(); }
-static inline float __shfl_xor(float v, int mask) {
-    const unsigned t = hostemu::cur;
-    hostemu::xch[t] = v;
-    hostemu::wave_sync();                                                    // every lane of the wave has written
-    const float r = hostemu::xch[(t & ~63u) | ((t ^ (unsigned)mask) & 63u)];
-    hostemu::wave_sync();                                                    // every lane has read before the next write
+// Wave-level exchanges: every lane publishes its 32-bit value, the wave meets, every lane reads the lane it asked for, the
+// wave meets again (so the slot can be reused).  A source lane that has already returned reads as the asking lane's own value.
+namespace hostemu {
+template <typename T, typename F>
+inline T exchange(T v, F&& src_lane) {
+    static_assert(sizeof(T) <= 8, "32- and 64-bit exchanges");
+    const unsigned t = cur;
+    std::memcpy(&xch[t], &v, sizeof(T));
+    wave_sync();
+    const unsigned s = (t & ~63u) | ((unsigned)src_lane(t & 63u) & 63u);
+    T r = v;
+    if (!fibers[s].done) std::memcpy(&r, &xch[s], sizeof(T));
+    wave_sync();
+    return r;
+}
+}  // namespace hostemu
+template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { return hostemu::exchange(v, [&](unsigned l) { return l ^ (unsigned)mask; }); }
+template <typename T> static inline T __shfl_up(T v, unsigned delta, int = 64) { return hostemu::exchange(v, [&](unsigned l) { return l >= delta ? l - delta : l; }); }
+template <typename T> static inline T __shfl_down(T v, unsigned delta, int = 64) { return hostemu::exchange(v, [&](unsigned l) { return l + delta < 64 ? l + delta : l; }); }
+template <typename T> static inline T __shfl(T v, int lane, int = 64) { return hostemu::exchange(v, [&](unsigned) { return (unsigned)lane; }); }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
+static inline int __builtin_amdgcn_readfirstlane(int v) {   // the lowest lane of the wave that is still running
+    const unsigned w0 = hostemu::cur & ~63u;
+    return hostemu::exchange(v, [&](unsigned) { unsigned l = 0; while (l < 63 && hostemu::fibers[w0 + l].done) ++l; return l; });
+}
+static inline unsigned long long __ballot(int pred) {
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64; ++l) {   // 64 rounds of a one-bit exchange (test infrastructure: clarity over speed)
+        const int b = hostemu::exchange(pred ? 1 : 0, [&](unsigned) { return l; });
+        const bool alive = !hostemu::fibers[(hostemu::cur & ~63u) + l].done;
+        if (alive && b) m |= 1ull << l;
+    }
+    return m;
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline void __threadfence_block() {}
+static inline void __builtin_amdgcn_wave_barrier() { hostemu::wave_sync(); }
+// v_permlane16_swap / v_permlane32_swap (gfx950): rows of 16 lanes; swap odd rows of the first operand with even rows of the second /
+// the upper half of the first with the lower half of the second.  Returns {new first, new second}.
+typedef unsigned hostemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline hostemu_u32x2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+    const unsigned row = (hostemu::cur & 63u) >> 4;
+    const unsigned pa = hostemu::exchange(a, [&](unsigned l) { return l ^ 16u; });   // partner row's first operand
+    const unsigned pb = hostemu::exchange(b, [&](unsigned l) { return l ^ 16u; });
+    hostemu_u32x2 r;
+    r.x = (row & 1u) ? pb : a;     // odd rows of a receive the even row below them of b
+    r.y = (row & 1u) ? b : pa;     // even rows of b receive the odd row above them of a
+    return r;
+}
+static inline hostemu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+    const unsigned hi = (hostemu::cur & 63u) >> 5;
+    const unsigned pa = hostemu::exchange(a, [&](unsigned l) { return l ^ 32u; });
+    const unsigned pb = hostemu::exchange(b, [&](unsigned l) { return l ^ 32u; });
+    hostemu_u32x2 r;
+    r.x = hi ? pb : a;
+    r.y = hi ? b : pa;
     return r;
 }
 static inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
 static inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __expf(x) expf(x)   // glibc declares __expf itself
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 using std::isfinite;

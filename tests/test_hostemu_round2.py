@@ -1,0 +1,100 @@
+"""The three kernels rewritten in the second half of round 2, on the CPU lane emulator (tests/hostemu: unmodified kernel sources
+compiled for the host, lanes as fibers) through the product's own wrappers: the table-driven ES-MoE pointwise stage
+(`moe_pw_lean_kernel`, csrc/esmoe.hip) and the streaming kernel it falls back to, the branch-free resident area attention
+(csrc/attn.hip: compile-time chunks, register-swap reductions, packed V^T staging) and the radix ordering of NMS candidates
+(csrc/nms.hip).  Logic only (indexing, tables, reductions, barriers): speed and occupancy are the GPU tests' business."""
+import numpy as np
+import pytest
+import torch
+
+from tests import emu_ops
+
+
+@pytest.fixture
+def host_ops(hostlib, monkeypatch):
+    from yolo_master_amd import ops
+
+    monkeypatch.setattr(ops, "lib", hostlib)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
+    return ops
+
+
+def _rnd(*shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+PW_CASES = [
+    # dtype, B, H, W, C, Cout, sel
+    (torch.bfloat16, 3, 14, 18, 128, 128, [[0, 2], [1, -1], [-1, -1]]),     # two K groups; ragged last tile; one / two / no expert
+    (torch.bfloat16, 2, 16, 16, 256, 256, [[3, 1], [2, -1]]),                # four K groups, two cout tiles, one weight slot
+    (torch.bfloat16, 5, 8, 16, 64, 128, [[0, 1], [1, 0], [2, 3], [3, -1], [0, 2]]),   # one K group, four resident weight tiles
+    (torch.float32, 2, 10, 13, 64, 128, [[1, 3], [0, -1]]),                  # fp32: two K groups of 32
+    (torch.bfloat16, 2, 12, 12, 192, 192, [[0, 1], [2, -1]]),                # cout not a multiple of 128: the older streaming kernel
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=lambda c: f"{str(c[0])[6:]}-{c[4]}to{c[5]}-{c[2]}x{c[3]}")
+def test_esmoe_pointwise_stage(case, host_ops):
+    dtype, B, H, W, C, Cout, sel = case
+    E, top_k = 4, 2
+    sel = torch.tensor(sel, dtype=torch.int32)
+    dw_out = _rnd(B * top_k, H, W, C, seed=1).to(dtype)
+    vec = 8 if dtype == torch.bfloat16 else 4
+    kp = (C + 63) // 64 * 64
+    pw_w = torch.zeros(E, Cout, kp, dtype=dtype)
+    pw_w[:, :, :C] = _rnd(E, Cout, C, seed=2, scale=C ** -0.5).to(dtype)
+    pw_b, nscale, nshift = _rnd(E, Cout, seed=3, scale=0.3), 1.0 + _rnd(Cout, seed=4, scale=0.1), _rnd(Cout, seed=5, scale=0.2)
+    gate = torch.zeros(B, E)
+    for b in range(B):
+        for k in range(top_k):
+            if sel[b, k] >= 0:
+                gate[b, sel[b, k]] = 0.3 + 0.5 * torch.rand(1, generator=torch.Generator().manual_seed(10 * b + k)).item()
+    ref = emu_ops.esmoe_pw(dw_out, B, H, W, pw_w, pw_b, nscale, nshift, top_k, sel, gate)
+    out = torch.full((B, H, W, Cout + 8), 7.0, dtype=dtype)[..., :Cout]   # a view with a row pitch: ldy != Cout
+    got = host_ops.esmoe_pw(dw_out, B, H, W, pw_w, pw_b, nscale, nshift, top_k, sel, gate, out=out)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert torch.allclose(got.float(), ref.float(), atol=tol, rtol=tol), float((got.float() - ref.float()).abs().max())
+    assert bool((out.storage_offset() == 0)) and torch.all(out.as_strided((B, H, W, 8), out.stride(), Cout) == 7.0), "wrote past the channel range"
+
+
+ATTN_CASES = [
+    # dtype, B, N, heads, area
+    (torch.bfloat16, 1, 400, 2, 1),    # the detector's 400 keys: 13 key-tile pairs -> chunks of 7 + 6, -inf mask in the last pair
+    (torch.bfloat16, 2, 144, 1, 2),    # 72 keys per area: one chunk of three pairs, ragged
+    (torch.bfloat16, 1, 32, 1, 1),     # a single pair, no mask
+    (torch.float32, 1, 48, 2, 1),      # fp32 path of the same code (per-tile P V)
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: f"{str(c[0])[6:]}-N{c[2]}-h{c[3]}-a{c[4]}")
+def test_area_attention(case, host_ops):
+    dtype, B, N, heads, area = case
+    qkv = _rnd(B, 1, N, 3 * heads * 32, seed=7, scale=0.8).to(dtype)
+    ref = emu_ops.area_attn(qkv, heads, area)
+    got = host_ops.area_attn(qkv, heads, area)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert torch.allclose(got.float(), ref.float(), atol=tol, rtol=tol), float((got.float() - ref.float()).abs().max())
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_nms_radix_ordering(ties, host_ops):
+    """More than 1024 candidates per image -> the radix index sort; kept anchors and detections bit-exact against the oracle,
+    with heavy score ties (17 distinct scores) and without."""
+    from oracle import nms_ref
+    from yolo_master_amd.nms import non_max_suppression
+
+    g = torch.Generator().manual_seed(31)
+    B, nc, A = 2, 3, 1700
+    xy = torch.rand(B, 2, A, generator=g) * 600 + 20
+    wh = torch.rand(B, 2, A, generator=g) * 50 + 4
+    cls = torch.rand(B, nc, A, generator=g) * 0.6 + 0.2
+    cls[1, :, 1100:] *= 0.1                      # the second image stays under 1024 candidates... or not: both paths in one launch
+    if ties:
+        cls = (cls * 16).round() / 16
+    y = torch.cat([xy, wh, cls], 1)
+    ref, ref_idx = nms_ref.non_max_suppression(y.numpy(), 0.25, 0.6, return_idxs=True, max_det=60)
+    got, got_idx = non_max_suppression(y, 0.25, 0.6, return_idxs=True, max_det=60)
+    for b in range(B):
+        assert np.array_equal(got_idx[b].numpy(), ref_idx[b]), f"image {b}: kept anchors differ"
+        assert np.array_equal(got[b].numpy(), ref[b]), f"image {b}: detections differ"

@@ -613,15 +613,17 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
             if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = three ? 3 : 2; return rc; }
         }
     }
-    // The tiled 1x1 shapes (K >= 256, Cout a multiple of 128, at least 192 tiles of 256 pixels): with 128-pixel tiles and the two-stage
+    // The tiled 1x1 shapes (K >= 256 and Cout a multiple of 128, or Cout a multiple of 64; at least 192 tiles of 256 pixels): with 128-pixel tiles and the two-stage
     // loop the LDS-DMA core is 0-20 % faster than conv_igemm_kernel on 15 of the 17 such launches of the S detector and equal on the
     // rest (profiles/r02_glds_tile_ab.txt; with 256-pixel tiles it was slower, which is why it was opt-in before).
     // YMK_ENABLE bit 0 still routes EVERY shape the core accepts here (bit 1: with the two-stage loop).
     const bool glds_all = (ymk_enabled() & YMK_ON_CONV_GLDS) != 0;
-    const bool glds_1x1 = d->ksize == 1 && d->Cout % 128 == 0 && !(ymk_disabled() & YMK_OFF_CONV_GLDS1);
+    // (64-cout tiles: from K = 64 — 64->64 at 80^2 40 -> 32 us, 128->64 at 40^2 16 -> 15 us against the 64 x 256 tiled kernel)
+    const bool glds_1x1 = d->ksize == 1 && d->Cout % 64 == 0 && !(ymk_disabled() & YMK_OFF_CONV_GLDS1);
     if ((glds_all || glds_1x1) && d->dtype == YMK_BF16) {
         const int64_t tiles = ceil_div64(a.M, 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
-        if (d->Cout % 64 == 0 && tiles >= ymk_glds_min_tiles && d->Kpad >= ymk_glds_min_k) {
+        const int min_k = (glds_all || d->Cout % 128 == 0) ? ymk_glds_min_k : 64;
+        if (d->Cout % 64 == 0 && tiles >= ymk_glds_min_tiles && d->Kpad >= min_k) {
             const bool two = glds_all ? (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) != 0 : true;
             const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, two ? 1 : 0, stream);
             if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = two ? 2 : 3; return rc; }

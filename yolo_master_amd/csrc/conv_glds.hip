@@ -103,7 +103,11 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         const int r = (j * 8 + wave) * 8 + lr;
         const int sc = (lc ^ (r & 7)) * 8;
         if (j < GW) {
-            wsrc[j] = wbase + (size_t)(n0 + r) * a.Kpad + sc;
+            // LDS row r = MFMA row block i = (r >> 4) & 3, row fr = r & 15 of a wave's 64 couts.  It is filled with cout
+            // (i >> 1) * 32 + (fr >> 2) * 8 + (i & 1) * 4 + (fr & 3): after the MFMAs a lane then holds EIGHT consecutive couts per
+            // block pair (16-byte stores, 64 contiguous bytes per pixel and wave) instead of four (csrc/esmoe.hip does the same)
+            const int rc = (r & ~63) + ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
+            wsrc[j] = wbase + (size_t)(n0 + rc) * a.Kpad + sc;
         } else {
             const int p = m0 + r - BN;
             unsigned mask = 0;
@@ -221,12 +225,13 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         }
     }
 
-    // ---- epilogue: bias, activation, residual, 4 consecutive couts per lane.  All operand loads are issued first (rows past
-    //      the end clamped to the last pixel) so that they overlap: one wait instead of one per fragment ---------------------
+    // ---- epilogue: bias, activation, residual; 8 consecutive couts per lane and block pair (see the staging map).  All operand
+    //      loads are issued first (rows past the end clamped to the last pixel) so that they overlap: one wait instead of one per
+    //      fragment -------------------------------------------------------------------------------------------------------------
+    auto cout_of = [&](int i) { return n0 + (wave % WN) * 64 + (i >> 1) * 32 + fc * 8 + (i & 1) * 4; };
     f32x4 bv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        bv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + ((wave % WN) * 4 + i) * 16 + fc * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) bv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cout_of(i)) : f32x4{0.f, 0.f, 0.f, 0.f};
     u32x2 rr[4][TP];
     if (a.res) {
 #pragma unroll
@@ -234,25 +239,44 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 const int p = min(m0 + ((wave / WN) * TP + j) * 16 + fr, Mlim - 1);
-                rr[i][j] = load_raw4(a.res + (out_base + p) * a.ldr + n0 + ((wave % WN) * 4 + i) * 16 + fc * 4);
+                rr[i][j] = load_raw4(a.res + (out_base + p) * a.ldr + cout_of(i));
             }
     }
+    // 16-byte stores need the row pitch and the base to allow them (a channel-slice view of a concatenation buffer may not)
+    const bool wide = !a.out_f32 && (a.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int co = n0 + ((wave % WN) * 4 + i) * 16 + fc * 4;
+    for (int h = 0; h < 2; ++h) {
+        const int co = cout_of(2 * h);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int p = m0 + ((wave / WN) * TP + j) * 16 + fr;
-            float v0 = acc[i][j].x + bv[i].x, v1 = acc[i][j].y + bv[i].y, v2 = acc[i][j].z + bv[i].z, v3 = acc[i][j].w + bv[i].w;
-            if (a.act == YMK_ACT_SILU) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
-            if (a.res) {
-                float r0, r1, r2, r3;
-                unpack_raw4(rr[i][j], r0, r1, r2, r3);
-                v0 += r0; v1 += r1; v2 += r2; v3 += r3;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = 2 * h + q;
+                float v0 = acc[i][j].x + bv[i].x, v1 = acc[i][j].y + bv[i].y, v2 = acc[i][j].z + bv[i].z, v3 = acc[i][j].w + bv[i].w;
+                if (a.act == YMK_ACT_SILU) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                if (a.res) {
+                    float r0, r1, r2, r3;
+                    unpack_raw4(rr[i][j], r0, r1, r2, r3);
+                    v0 += r0; v1 += r1; v2 += r2; v3 += r3;
+                }
+                v[q * 4 + 0] = v0; v[q * 4 + 1] = v1; v[q * 4 + 2] = v2; v[q * 4 + 3] = v3;
             }
             if (p >= Mlim) continue;
-            if (a.out_f32) store4(static_cast<float*>(a.y) + (out_base + p) * a.ldy + co, v0, v1, v2, v3);
-            else store4(static_cast<bf16_t*>(a.y) + (out_base + p) * a.ldy + co, v0, v1, v2, v3);
+            if (a.out_f32) {
+                float* yo = static_cast<float*>(a.y) + (out_base + p) * a.ldy + co;
+                store4(yo, v[0], v[1], v[2], v[3]);
+                store4(yo + 4, v[4], v[5], v[6], v[7]);
+            } else {
+                bf16_t* yo = static_cast<bf16_t*>(a.y) + (out_base + p) * a.ldy + co;
+                if (wide) {
+                    store_vec_f32(yo, v);
+                } else {
+                    store4(yo, v[0], v[1], v[2], v[3]);
+                    store4(yo + 4, v[4], v[5], v[6], v[7]);
+                }
+            }
         }
     }
 }

@@ -158,7 +158,14 @@ static int ymk_ablate = 0;
 // stored, so the HBM latency of a tile is hidden behind the previous tile's MFMA + epilogue instead of being
 // exposed once per tile, and the k-loop has no barriers (both operands are complete in LDS).
 // ---------------------------------------------------------------------------
-template <typename T, int KG>
+// eight consecutive channels in one 16-byte store (bf16); the fp32 overload is never taken (`wide` is bf16-only) but must compile
+__device__ __forceinline__ void ws_store8(bf16_t* p, const float (&v)[8]) { store_vec_f32(p, v); }
+__device__ __forceinline__ void ws_store8(float* p, const float (&v)[8]) {
+    store4(p, v[0], v[1], v[2], v[3]);
+    store4(p + 4, v[4], v[5], v[6], v[7]);
+}
+
+template <typename T, int KG, bool PERM>
 __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int BK = 8 * VEC;            // elements per 128-byte K group
@@ -178,17 +185,23 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     const T* wt = reinterpret_cast<const T*>(a.w) + (size_t)co0 * a.Kpad;
     auto swz = [](int row, int c) { return (c & ~7) | ((c & 7) ^ (row & 7)); };
 
-    // weights: once per workgroup
+    // weights: once per workgroup.  With whole 64-cout groups, LDS row r = MFMA row block i = (r >> 4) & 3, row fr = r & 15 of a wave's 64
+    // couts is filled with cout (i >> 1) * 32 + (fr >> 2) * 8 + (i & 1) * 4 + (fr & 3): a lane then holds EIGHT consecutive couts per block
+    // pair after the MFMAs (16-byte stores, 64 contiguous bytes per pixel and wave; csrc/conv_glds.hip, csrc/esmoe.hip do the same)
+    constexpr bool perm = PERM;   // launcher: Cout % 64 == 0
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = srow + i * 32;
+        const int rc = perm ? (r & ~63) + ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3) : r;
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (co0 + r < a.Cout) v = *reinterpret_cast<const u32x4*>(wt + (size_t)r * a.Kpad + g * BK + cq * VEC);
+            if (co0 + rc < a.Cout) v = *reinterpret_cast<const u32x4*>(wt + (size_t)rc * a.Kpad + g * BK + cq * VEC);
             sW[r * RS + swz(r, g * 8 + cq)] = v;
         }
     }
+    auto cout_of = [&](int i) { return perm ? co0 + wco * 64 + (i >> 1) * 32 + fc * 8 + (i & 1) * 4 : co0 + (wco * 4 + i) * 16 + fc * 4; };
+    const bool wide = PERM && sizeof(T) == 2 && (a.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
     u32x4 ra[4][KG];
     auto gload = [&](int64_t tile) {
 #pragma unroll
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     f32x4 bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int co = co0 + (wco * 4 + i) * 16 + fc * 4;
+        const int co = cout_of(i);
         bv[i] = co < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const bool silu = a.act == YMK_ACT_SILU;
@@ -249,25 +262,33 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
                     for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
             }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = co0 + (wco * 4 + i) * 16 + fc * 4;
-            if (co >= a.Cout) continue;
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = tile * 128 + (wpx * 4 + j) * 16 + fr;
+            if (m >= a.M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t m = tile * 128 + (wpx * 4 + j) * 16 + fr;
-                if (m >= a.M) continue;
-                float v[4];
+            for (int h = 0; h < 2; ++h) {
+                float v[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][j][r] + bv[i][r];
-                    if (silu) v[r] = act_silu<T, PRECISE>(v[r]);
+                for (int q = 0; q < 2; ++q) {
+                    const int i = 2 * h + q, co = cout_of(i);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[q * 4 + r] = acc[i][j][r] + bv[i][r];
+                        if (silu) v[q * 4 + r] = act_silu<T, PRECISE>(v[q * 4 + r]);
+                    }
+                    if (a.res && co < a.Cout) {
+                        float r0, r1, r2, r3;
+                        load4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co, r0, r1, r2, r3);
+                        v[q * 4 + 0] += r0; v[q * 4 + 1] += r1; v[q * 4 + 2] += r2; v[q * 4 + 3] += r3;
+                    }
                 }
-                if (a.res) {
-                    float r0, r1, r2, r3;
-                    load4(reinterpret_cast<const T*>(a.res) + m * a.ldr + co, r0, r1, r2, r3);
-                    v[0] = r0 + v[0]; v[1] = r1 + v[1]; v[2] = r2 + v[2]; v[3] = r3 + v[3];
+                T* yo = reinterpret_cast<T*>(a.y) + m * a.ldy;
+                if (wide) {
+                    if (cout_of(2 * h) < a.Cout) ws_store8(yo + cout_of(2 * h), v);   // whole 64-cout groups: the lane's eight couts are in or out together
+                } else {
+                    if (cout_of(2 * h) < a.Cout) store4(yo + cout_of(2 * h), v[0], v[1], v[2], v[3]);
+                    if (cout_of(2 * h + 1) < a.Cout) store4(yo + cout_of(2 * h + 1), v[4], v[5], v[6], v[7]);
                 }
-                store4(reinterpret_cast<T*>(a.y) + m * a.ldy + co, v[0], v[1], v[2], v[3]);
             }
         }
     }
@@ -287,11 +308,20 @@ static bool launch_conv1x1_ws(ConvArgs a, hipStream_t s) {
     if (nblk_px < 1) nblk_px = 1;
     if (nblk_px > ntiles) nblk_px = (int)ntiles;
     dim3 grid(nblk_px * a.ncot), blk(256);
-    switch (kg) {
-        case 1: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 1>), grid, blk, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 2>), grid, blk, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 3>), grid, blk, 0, s, a); break;
-        default: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 4>), grid, blk, 0, s, a); break;
+    if (a.Cout % 64 == 0) {   // whole 64-cout groups: weight rows permuted for 16-byte stores
+        switch (kg) {
+            case 1: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 1, true>), grid, blk, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 2, true>), grid, blk, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 3, true>), grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 4, true>), grid, blk, 0, s, a); break;
+        }
+    } else {
+        switch (kg) {
+            case 1: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 1, false>), grid, blk, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 2, false>), grid, blk, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 3, false>), grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 4, false>), grid, blk, 0, s, a); break;
+        }
     }
     return true;
 }

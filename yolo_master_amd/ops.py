@@ -70,7 +70,7 @@ def conv_kernel_name(variant: int, dtype, cin: int, cout: int, k: int, kpad: int
     if variant & 0xff == 3:   # LDS-DMA tiled core (default for bf16 3x3 with Cin >= 64; YMK_ENABLE bit 0: every shape); stages in bits 8+
         return f"conv_glds_kernel<{128 if cout % 128 == 0 else 64}, {(variant >> 8) & 0xff}, {(variant >> 16) or 256}>"   # pixel-tile height in bits 16+
     if variant == 1:
-        return f"conv1x1_ws_kernel<{t}, {kpad * es // 128}>"
+        return f"conv1x1_ws_kernel<{t}, {kpad * es // 128}, {'true' if cout % 64 == 0 else 'false'}>"   # whole 64-cout groups: permuted rows
     if variant == 2:
         prefetch = residual and not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 16)
         return f"conv3x3_tile_kernel<{t}, {cin}, {32 if cout <= 32 else 64}, {'true' if prefetch else 'false'}>"

@@ -118,10 +118,13 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
-            af1[i][tap] = *reinterpret_cast<const u32x4*>(a.w1 + (size_t)(ch * 32 + i * 16 + fr) * a.k1pad + tap * C0 + fc * 8);
+            // MFMA row fr of block i holds cout (fr >> 2) * 8 + i * 4 + (fr & 3) of the wave's 32: after the MFMAs a lane owns the EIGHT
+            // consecutive couts fc * 8 ... + 7 of its pixel (one 16-byte store instead of two 8-byte ones)
+            af1[i][tap] = *reinterpret_cast<const u32x4*>(a.w1 + (size_t)(ch * 32 + (fr >> 2) * 8 + i * 4 + (fr & 3)) * a.k1pad + tap * C0 + fc * 8);
     f32x4 bv1[2];
+    const bool wide = (a.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;   // 16-byte output stores possible
 #pragma unroll
-    for (int i = 0; i < 2; ++i) bv1[i] = *reinterpret_cast<const f32x4*>(a.b1 + ch * 32 + i * 16 + fc * 4);
+    for (int i = 0; i < 2; ++i) bv1[i] = *reinterpret_cast<const f32x4*>(a.b1 + ch * 32 + fc * 8 + i * 4);
 
     // ---- input window: global -> registers -> LDS -----------------------------------------------------------------------------
     u32x4 stg[NLD];
@@ -239,10 +242,18 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
             for (int pf = 0; pf < 2; ++pf) {
                 const int ox = ox0 + pf * 16 + fr;
                 if (ox < a.W2) {
+                    float v8[8];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const f32x4 v = acc1[i][pf] + bv1[i];
-                        store4(yrow + (size_t)ox * a.ldy + ch * 32 + i * 16 + fc * 4, silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+                        v8[i * 4 + 0] = silu_f(v.x); v8[i * 4 + 1] = silu_f(v.y); v8[i * 4 + 2] = silu_f(v.z); v8[i * 4 + 3] = silu_f(v.w);
+                    }
+                    bf16_t* yo = yrow + (size_t)ox * a.ldy + ch * 32 + fc * 8;
+                    if (wide) {
+                        store_vec_f32(yo, v8);
+                    } else {
+                        store4(yo, v8[0], v8[1], v8[2], v8[3]);
+                        store4(yo + 4, v8[4], v8[5], v8[6], v8[7]);
                     }
                 }
             }

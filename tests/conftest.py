@@ -82,10 +82,13 @@ def hostlib():
     path = hostemu_build.build()
     if path is None:
         pytest.skip("no host clang++ to build the kernel emulation")
+    import os
+    os.environ.setdefault("YMK_WS_MIN_TILES", "2")   # read when the library is loaded: lets the tiny emulator shapes reach the streaming 1x1 kernel
     h = C.CDLL(str(path))
     dw = {k: v for k, v in _lib.SYMBOLS.items() if k in ("ymk_dw_mfma_supported", "ymk_dw_toeplitz_elems", "ymk_dw_toeplitz_pack",
                                                          "ymk_dwconv2d_mfma", "ymk_esmoe_dw_mfma", "ymk_mlp_fused_supported", "ymk_mlp_fused", "ymk_stem_pair_supported", "ymk_stem_pair", "ymk_c3k2_fused_supported", "ymk_c3k2_fused", "ymk_c3k2_fused_pool_chunks", "ymk_c3k2_fused_pooled", "ymk_detect_cls_fused_supported", "ymk_detect_cls_fused",
-                                                         "ymk_esmoe_pw", "ymk_area_attn", "ymk_nms_workspace_bytes", "ymk_nms_batched")}   # csrc/dwmfma.hip, mlp.hip, stem2.hip, ..., esmoe.hip, attn.hip, nms.hip
+                                                         "ymk_esmoe_pw", "ymk_area_attn", "ymk_nms_workspace_bytes", "ymk_nms_batched",
+                                                         "ymk_conv2d", "ymk_conv2d_last_variant", "ymk_dwconv2d")}   # csrc/dwmfma.hip, mlp.hip, stem2.hip, ..., esmoe.hip, attn.hip, nms.hip
     for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT, **dw}.items():   # SYMBOLS_NEXT includes csrc/preproc.hip
         fn = getattr(h, name)
         fn.restype, fn.argtypes = res, args

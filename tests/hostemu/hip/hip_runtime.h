@@ -256,6 +256,7 @@ static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+template <typename K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 static inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

@@ -30,6 +30,8 @@ CONV_CASES = [
     (torch.bfloat16, 1, 16, 16, 64, 80, 1, 1, True, False, 0, 1),      # Cout not a multiple of 64: natural row order
     (torch.float32, 1, 16, 16, 64, 128, 1, 1, True, True, 0, 1),       # fp32 streaming 1x1 (two K groups of 32)
     (torch.bfloat16, 8, 64, 64, 32, 32, 3, 1, True, True, 0, 2),       # spatial-tile 3x3 (128 tiles), residual prefetch
+    (torch.bfloat16, 8, 64, 64, 32, 64, 3, 1, True, False, 0, 2),      # ... four cout row blocks
+    (torch.bfloat16, 8, 64, 64, 16, 32, 3, 1, False, True, 4, 2),      # ... paired taps (Cin 16), padded output pitch
     (torch.float32, 2, 9, 11, 16, 24, 3, 2, True, False, 0, 0),        # tiled implicit GEMM, strided, ragged
     (torch.bfloat16, 2, 7, 9, 64, 64, 1, 1, False, True, 0, 0),        # tiled 1x1 below every threshold
 ]

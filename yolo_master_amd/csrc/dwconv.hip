@@ -237,13 +237,17 @@ struct DwGeom {
     int ncb, nsp, spt, nrun;
 };
 template <typename T>
-static DwGeom dw_geom(int H, int W, int C, int tw, int64_t planes) {
+static DwGeom dw_geom(int H, int W, int C, int tw, int64_t planes, bool prefetch) {
     const int th = tw == 40 ? 16 : 32;
     DwGeom g;
     g.ncb = (C + 15) / 16;
     g.nsp = ((H + th - 1) / th) * ((W + tw - 1) / tw);
-    // tiles per workgroup: as long as the launch keeps >= ~8k workgroups, at most 8 (prefetch needs >= 2 to pay)
-    int64_t spt = (int64_t)g.nsp * g.ncb * planes / 8192;
+    // with the register prefetch of the next halo (fewer than four workgroups per CU) a workgroup needs a run of tiles for it to pay: as
+    // long as the launch keeps >= ~8k workgroups, at most 8.  Without it ONE tile per workgroup is faster (ES-MoE layers 3 / 4: 471 -> 435,
+    // 230 -> 207 us): the dispatcher balances short workgroups better than a static run does.  YMK_DW_WG_TARGET overrides (A/B runs).
+    static const int64_t target_env = [] { const char* e = getenv("YMK_DW_WG_TARGET"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    const int64_t target = target_env > 0 ? target_env : prefetch ? 8192 : ((int64_t)1 << 40);
+    int64_t spt = (int64_t)g.nsp * g.ncb * planes / target;
     g.spt = (int)(spt < 1 ? 1 : spt > 8 ? 8 : spt);
     g.nrun = (g.nsp + g.spt - 1) / g.spt;
     return g;
@@ -287,7 +291,8 @@ static void launch_dw_k(const DwArgs& a, int nrun, hipStream_t s) {
 
 template <typename T, int TW>
 static int launch_dw_tw(DwArgs a, int k, hipStream_t s) {
-    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, a.B);
+    const bool prefetch = k <= 15 && DwTile<T, TW>::resident(k) < 4;
+    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, a.B, prefetch);
     a.ncb = g.ncb; a.nsp = g.nsp; a.spt = g.spt;
     switch (k) {
         case 1: launch_dw_k<T, 1, TW>(a, g.nrun, s); break;
@@ -379,7 +384,7 @@ static int launch_moe_dw_k(MoeDwArgs a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set = true;
     }
-    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, (int64_t)a.B * a.top_k);
+    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, (int64_t)a.B * a.top_k, DwTile<T, TW>::resident(KMAX) < 4);
     a.ncb = g.ncb; a.nsp = g.nsp; a.spt = g.spt;
     hipLaunchKernelGGL((moe_dw_kernel<T, TW, KMAX>), dim3(g.nrun * g.ncb, a.B * a.top_k), dim3(256), shm, s, a);
     return ymk_launch_status();

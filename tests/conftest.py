@@ -92,6 +92,10 @@ def hostlib():
     for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT, **dw}.items():   # SYMBOLS_NEXT includes csrc/preproc.hip
         fn = getattr(h, name)
         fn.restype, fn.argtypes = res, args
+    for name, (res, args) in _lib.SYMBOLS.items():   # every v0 entry point the host build has as well (whole-model runs on the emulator)
+        if hasattr(h, name):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
     return h
 
 

@@ -63,7 +63,7 @@ def _cpu_threads(request):
     import torch
 
     name = request.module.__name__.rsplit(".", 1)[-1]
-    want = 8 if name in ("test_oracle_golden", "test_host_emu", "test_oracle_nms") else 4
+    want = 8 if name in ("test_oracle_golden", "test_host_emu", "test_oracle_nms", "test_oracle_cfg5_l") else 4
     n = torch.get_num_threads()
     torch.set_num_threads(want)
     yield

@@ -93,3 +93,32 @@ def fill_by_name(spec: dict, seed: int = 0, gain: float = 1.0) -> dict:
                 fan_in *= d
             out[k] = torch.randn(shape, generator=g) * (gain / max(fan_in, 1) ** 0.5)
     return out
+
+
+def condition_bn(sd: dict) -> dict:
+    """In place: the conditioning of tools/make_conditioned.py applied by NAME to every BatchNorm of a state_dict (a prefix that owns a
+    `running_mean`): weight ~ U(0.4, 0.6), bias ~ N(1.0, 0.3), each from a generator seeded by crc32(prefix).  Pre-activations get a
+    positive mean, SiLU works in its near-linear range and fp32 evaluation-order noise is no longer amplified layer after layer (the
+    plain name-seeded L-scale config-5 network differs from its own fp64 evaluation by 12 % after the first A2C2f).  The matching
+    running statistics are calibrated by the fixture generator and stored in the fixture."""
+    import zlib
+
+    for k in [k for k in sd if k.endswith(".running_mean")]:
+        p = k[: -len(".running_mean")]
+        g = torch.Generator().manual_seed((zlib.crc32(p.encode()) ^ 0x5EED) & 0x7FFFFFFF)
+        sd[p + ".weight"] = torch.rand(sd[p + ".weight"].shape, generator=g) * 0.2 + 0.4
+        sd[p + ".bias"] = torch.randn(sd[p + ".bias"].shape, generator=g) * 0.3 + 1.0
+    return sd
+
+
+def cfg5_imbalance(sd: dict, alpha_image: float, alpha_token: float) -> dict:
+    """The expert-imbalance knob of BASELINE config 5: a copy of `sd` with expert 0's logit raised in every router —
+    the gated blocks' local stream (`routing.local_conv.6.bias`, moe/gated.py:124-166; the blend scales it by 1 - sigmoid(alpha_param))
+    and the per-token MoT / MoA routers (`router.router.3.bias`, mot/router.py:243-295, moa/router.py:29-62)."""
+    out = {k: v.clone() for k, v in sd.items()}
+    for k in out:
+        if k.endswith("routing.local_conv.6.bias"):
+            out[k][0] += alpha_image
+        elif k.endswith("router.router.3.bias"):
+            out[k][0] += alpha_token
+    return out

@@ -199,11 +199,7 @@ def main():
             elapsed = float(t.item())
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
         p50_ms = per_step[len(per_step) // 2]
-        from yolo_master_amd._lib import FLAG_NMS_OVERFLOW
-
         model.check_flags()                       # device flag words of the timed steps, read once after the loop
-        if int(out[2].item()) & FLAG_NMS_OVERFLOW:
-            raise RuntimeError("bench: the NMS candidate buffer overflowed during the timed steps (results truncated)")
 
         # roofline leg: per-call HIP events around every op family (eager launches on this stream); the object
         # reported is the family with the largest share of the step, the rest go into "families"

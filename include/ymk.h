@@ -41,7 +41,13 @@ extern "C" {
 
 /* dtypes of activations / packed weights */
 #define YMK_F32 0
-#define YMK_BF16 1
+#define YMK_H16 1   /* the library's 16-bit element type: bfloat16 in libymk.so, IEEE binary16 in libymk_f16.so — the SAME sources and
+                     * the SAME ABI compiled with -DYMK_H16_F16 (v_mfma_f32_16x16x32_f16, RNE float<->half conversions); the reference's
+                     * reduced-precision mode is fp16 (`half=True`: engine/predictor.py:174,415, nn/backends/pytorch.py:67).
+                     * ymk_h16_format() tells which one a loaded library is. */
+#define YMK_BF16 YMK_H16
+#define YMK_H16_FORMAT_BF16 1
+#define YMK_H16_FORMAT_F16 2
 
 /* activation codes for fused epilogues */
 #define YMK_ACT_NONE 0
@@ -50,11 +56,12 @@ extern "C" {
 /* device flag bits (int32 words written with atomicOr by kernels) */
 #define YMK_FLAG_NONFINITE_INPUT 1  /* router input contains NaN/Inf  (routers.py:51)  */
 #define YMK_FLAG_NONFINITE_LOGITS 2 /* router logits contain NaN/Inf  (routers.py:467) */
-#define YMK_FLAG_NMS_OVERFLOW 4     /* more than max_nms candidates in one image       */
+#define YMK_FLAG_NMS_OVERFLOW 4     /* reserved (ABI 2 raised it above 2*max_nms candidates; since round 3 any count is selected on device) */
 
 int ymk_abi_version(void);
 /* human readable build string (arch, compiler) — static storage */
 const char* ymk_build_info(void);
+int ymk_h16_format(void);   /* YMK_H16_FORMAT_BF16 | YMK_H16_FORMAT_F16 */
 
 /* ------------------------------------------------------------------------
  * Convolution (implicit GEMM on MFMA) + folded-BN bias + SiLU + residual.

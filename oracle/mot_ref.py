@@ -40,6 +40,13 @@ def sdpa(q, k, v, scale):
 
 
 # ---------------------------------------------------------------------------------- router
+# Tie resolution for parity tests: {router prefix: bool [B, E, H, W]} — the selected experts per token are taken from the mask
+# instead of this evaluation's own top-k (weights still come from this evaluation's probabilities).  Used when another fp32
+# evaluation order resolved a near-tie between two experts' logits (gap < 1e-4) the other way: both resolutions are valid results
+# of the reference algorithm, and everything downstream is then compared under the same resolution (tests/test_gpu_mixture.py).
+FORCE_SELECT: dict = {}
+
+
 def mot_router(sd, p, x, top_k=2):
     """_MoTRouter.forward, spatial, eval (mot/router.py:243-295): 1x1 -> GN(<=4) -> SiLU -> 1x1(+bias) in fp32,
     softmax(logits / T) with the persistent `temperature` buffer, hard top-k, stable_normalize over the selected
@@ -52,6 +59,9 @@ def mot_router(sd, p, x, top_k=2):
     E = w.shape[1]
     if top_k < E:
         vals, idx = w.topk(top_k, dim=1)
+        if p in FORCE_SELECT:
+            idx = torch.where(FORCE_SELECT[p], w, torch.full_like(w, -1.0)).topk(top_k, dim=1).indices   # the forced set, ranked by this evaluation's probabilities
+            vals = w.gather(1, idx)
         den = vals.sum(dim=1, keepdim=True).clamp_min(_fp_floor(1e-6, vals.dtype))   # stable_normalize (_numeric.py:85-90)
         w = torch.zeros_like(w).scatter_(1, idx, vals / den)
     else:

@@ -47,20 +47,28 @@ def letterbox_params(shape, new_shape=(640, 640), auto=False, scale_fill=False, 
             "right": int(right), "ratio": (float(ratio[0]), float(ratio[1]))}
 
 
-def _coef(dsize: int, ssize: int):
-    """Per destination index: first tap and the two 11-bit coefficients (OpenCV resize.cpp, linear kernel)."""
+def _coef(dsize: int, ssize: int, vertical: bool = False):
+    """Per destination index: the two taps and the two 11-bit coefficients (OpenCV resize.cpp, linear kernel).  Horizontal: at the
+    borders the tap moves inside and the fraction is zeroed (`if (sx < 0) fx = 0, sx = 0; if (sx >= ssize.width - 1) fx = 0, sx =
+    ssize.width - 1`).  Vertical: the fraction is kept and resizeGeneric_Invoker clamps the ROW INDICES (`clip(yofs[dy] + k, 0,
+    ssize.height)`), so with both rows equal the two products round separately (first / last rows of upscaled images can be one LSB
+    lower than with a zeroed fraction)."""
     scale = 1.0 / (dsize / ssize)
     d = np.arange(dsize, dtype=np.float64)
     f = ((d + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int32)
     f = f - s.astype(np.float32)
-    lo = s < 0
-    f[lo], s[lo] = 0.0, 0
-    hi = s >= ssize - 1
-    f[hi], s[hi] = 0.0, ssize - 1
+    if vertical:
+        s0, s1 = np.clip(s, 0, ssize - 1), np.clip(s + 1, 0, ssize - 1)
+    else:
+        lo = s < 0
+        f[lo], s[lo] = 0.0, 0
+        hi = s >= ssize - 1
+        f[hi], s[hi] = 0.0, ssize - 1
+        s0, s1 = s, np.minimum(s + 1, ssize - 1)
     a0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int32)
     a1 = np.rint(f * np.float32(2048.0)).astype(np.int32)
-    return s, a0, a1
+    return s0, s1, a0, a1
 
 
 def resize_linear_u8(img: np.ndarray, dsize) -> np.ndarray:
@@ -73,9 +81,8 @@ def resize_linear_u8(img: np.ndarray, dsize) -> np.ndarray:
     if sh == 2 * dh and sw == 2 * dw:   # exact 2x downscale -> 2x2 area average, rounded
         s = img.astype(np.int32)
         return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
-    sx, ax0, ax1 = _coef(dw, sw)
-    sy, by0, by1 = _coef(dh, sh)
-    sx1, sy1 = np.minimum(sx + 1, sw - 1), np.minimum(sy + 1, sh - 1)
+    sx, sx1, ax0, ax1 = _coef(dw, sw)
+    sy, sy1, by0, by1 = _coef(dh, sh, vertical=True)
     s = img.astype(np.int32)
     h = s[:, sx] * ax0[None, :, None] + s[:, sx1] * ax1[None, :, None]          # [sh, dw, c], scale 2^11
     h0, h1 = h[sy], h[sy1]

@@ -122,3 +122,25 @@ def cfg5_imbalance(sd: dict, alpha_image: float, alpha_token: float) -> dict:
         elif k.endswith("router.router.3.bias"):
             out[k][0] += alpha_token
     return out
+
+
+def dense_pred(B: int, nc: int, A: int, seed: int, frame: float = 640.0) -> torch.Tensor:
+    """A dense-scene prediction tensor y [B, 4 + nc, A] for the validator's NMS settings (conf 0.001, multi_label): EVERY (anchor,
+    class) pair is a candidate (A * nc per image: 672 000 at 8400 x 80) and all scores of an image are distinct float32 values (a
+    random permutation of an arithmetic sequence in (0.001, 0.999)), because the reference's unstable argsort leaves the order of
+    equal scores undefined.  Boxes cluster around a few hundred objects so that greedy suppression has work.  Regenerated from the
+    seed on both sides (numpy Generator: the stream is platform independent); the fixture stores only the reference's result."""
+    rng = np.random.default_rng(seed)
+    y = np.empty((B, 4 + nc, A), np.float32)
+    for b in range(B):
+        k = max(A // 24, 1)
+        centres = rng.uniform(40, frame - 40, (k, 2))
+        sizes = rng.uniform(24, 140, (k, 2))
+        pick = rng.integers(0, k, A)
+        y[b, 0:2] = (centres[pick] + rng.normal(0, 5, (A, 2))).T
+        y[b, 2:4] = (sizes[pick] * rng.uniform(0.85, 1.15, (A, 2))).T
+        n = nc * A
+        s = (rng.permutation(n).astype(np.float64) + 1.0) / (n + 2.0) * 0.997 + 0.0015
+        y[b, 4:] = s.astype(np.float32).reshape(nc, A)
+        assert len(np.unique(y[b, 4:])) == n
+    return torch.from_numpy(y)

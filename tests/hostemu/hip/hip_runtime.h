@@ -187,6 +187,7 @@ static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f
 static inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
 static inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __expf(x) expf(x)   // glibc declares __expf itself
@@ -256,6 +257,7 @@ static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 template <typename K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 static inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }

@@ -26,12 +26,17 @@ def _yolo():
     return m
 
 
-def test_predict_through_the_hooks(emu, monkeypatch):
+def test_predict_through_the_hooks(emu, hostlib, monkeypatch):
     import yolo_master_amd
-    from yolo_master_amd import dropin, ops
+    from yolo_master_amd import dropin, ops, postprocess
     from yolo_master_amd.weights import synth_input
 
     monkeypatch.setattr(ops, "device_ok", lambda t: True)     # CPU tensors go to the (emulated) libymk path
+    monkeypatch.setattr(postprocess, "lib", hostlib)          # scale_boxes hook: csrc/post.hip compiled for the host (lane emulator)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    scale_calls = []
+    real_scale = postprocess.scale_boxes
+    monkeypatch.setattr(postprocess, "scale_boxes", lambda *a, **k: (scale_calls.append(1), real_scale(*a, **k))[1])
     x = synth_input(2, 128, 128, seed=42)
     kw = dict(conf=0.002, iou=0.7, verbose=False, device="cpu")
     ref = _yolo().predict(x, **kw)                            # the untouched reference
@@ -42,6 +47,7 @@ def test_predict_through_the_hooks(emu, monkeypatch):
         st = dropin.stats(m)
         assert st["calls"] >= 1 and st["nms_calls"] >= 1, st          # the batch (the reference skips warm-up on cpu); NMS hook used
         assert emu.CALLS["conv2d_stem"] >= 1 and emu.CALLS["esmoe_route"] >= 4 and emu.CALLS["nms_batched"] >= 1
+        assert len(scale_calls) >= 2, "the predictor's scale_boxes(pred[:, :4]) (a row-stride-6 view) must reach libymk's kernel"
         assert len(got) == len(ref) == 2
         n = 0
         for g, r in zip(got, ref):
@@ -136,3 +142,61 @@ def test_validator_matching_goes_through_the_hook(hostlib, monkeypatch, golden_d
     from ultralytics.models.yolo.detect.val import DetectionValidator as V2
 
     assert V2._process_batch.__module__ == "ultralytics.models.yolo.detect.val", "disable() must restore the validator"
+
+
+def test_copies_traces_and_foreign_nms_modes_take_the_reference_path(emu, monkeypatch):
+    """Hook hygiene (round-2 advisor findings): (1) a `copy.deepcopy` of an enabled model — what the reference's Exporter and
+    ModelEMA make — must not run the ORIGINAL's weight snapshot nor look at the original's training flag: its hook is bound to the
+    copy and falls through to the reference until `enable(copy)`; (2) a second enabled model keeps the process-wide patches alive
+    when the first is disabled; (3) NMS modes outside the detect path are recognised when passed POSITIONALLY and go to the
+    reference's implementation instead of raising."""
+    import copy
+
+    import yolo_master_amd
+    from yolo_master_amd import dropin, ops
+    from yolo_master_amd.weights import synth_input
+
+    monkeypatch.setattr(ops, "device_ok", lambda t: True)
+    x = synth_input(1, 64, 64, seed=3)
+    m, m2 = _yolo(), _yolo()
+    yolo_master_amd.enable(m)
+    yolo_master_amd.enable(m2)
+    try:
+        import ultralytics.utils.nms as ref_nms
+
+        core = m.model.eval()
+        with torch.inference_mode():
+            y, _ = core(x)
+        y = y.clone()                                      # a normal tensor: the reference's NMS writes into its input
+        calls = dropin.stats(m)["calls"]
+        assert calls >= 1
+        dup = copy.deepcopy(core)
+        assert dup._predict_once.__self__ is dup, "the hook of a copy must be bound to the copy"
+        with torch.inference_mode():
+            y_dup, _ = dup(x)                              # reference path of the copy (its own parameters)
+        assert dropin.stats(m)["calls"] == calls, "a deep copy must not run the original's libymk snapshot"
+        assert torch.allclose(y_dup, y, atol=1e-3)
+        dup.train()                                        # the copy's flag is the one its hook reads
+        assert core.training is False
+        yolo_master_amd.enable(dup.eval())                 # a copy can be enabled on its own
+        with torch.inference_mode():
+            dup(x)
+        assert dropin.stats(dup)["calls"] == 1
+        yolo_master_amd.disable(dup)
+        # (2) refcount of the process-wide patches
+        yolo_master_amd.disable(m)
+        assert ref_nms.non_max_suppression.__module__ != "ultralytics.utils.nms", "m2 still relies on the NMS hook"
+        # (3) positional foreign modes: classes, agnostic, multi_label, labels=[...] (autolabelling) -> reference implementation
+        before = dropin.stats(m2)["nms_calls"]
+        lab = [torch.zeros((0, 5))]
+        out = ref_nms.non_max_suppression(y.clone(), 0.05, 0.6, None, False, False, lab)
+        want = dropin._PATCHED["nms"](y.clone(), 0.05, 0.6, None, False, False, lab)
+        assert dropin.stats(m2)["nms_calls"] == before and torch.equal(out[0], want[0])
+        out = ref_nms.non_max_suppression(y, 0.05, 0.6, None, False, True)      # positional multi_label: on the libymk path
+        assert dropin.stats(m2)["nms_calls"] == before + 1 and out[0].shape[1] == 6
+    finally:
+        yolo_master_amd.disable(m2)
+        yolo_master_amd.disable(m)
+    import ultralytics.utils.nms as ref_nms
+
+    assert ref_nms.non_max_suppression.__module__ == "ultralytics.utils.nms"

@@ -451,6 +451,36 @@ def test_nms_golden(case, golden_dir):
         assert np.array_equal(got[b].cpu().numpy(), z[f"dets{b}"]), f"{case} image {b}: detections differ"
 
 
+DENSE_KW = {"val640": dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300),
+            "single1280": dict(conf_thres=0.001, iou_thres=0.7, max_det=300)}
+
+
+@pytest.mark.parametrize("case", list(DENSE_KW))
+def test_nms_dense_scene_vs_reference_golden(case, golden_dir):
+    """The validator's NMS settings on a dense scene: 672 000 multi-label candidates per image (val640) / 33 600 best-class
+    candidates (single1280) against max_nms = 30 000 — the reference sorts them all and truncates (utils/nms.py:142-146); libymk
+    selects the same 30 000 by a radix select on the score bits.  Kept anchors and detections bit-exact vs the REAL reference
+    (tests/golden/make_golden_nms_dense.py), plus a tie stress against the oracle (quantised scores: hundreds of candidates share
+    the threshold score and only the first few in anchor-major order may pass)."""
+    from oracle import nms_ref
+    from tests.helpers import dense_pred
+    from yolo_master_amd.nms import nms_padded, non_max_suppression
+    from yolo_master_amd._lib import FLAG_NMS_OVERFLOW
+
+    z = np.load(golden_dir / "nms_dense.npz")
+    B, nc, A, seed = [int(v) for v in z[f"{case}::recipe"]]
+    y = dense_pred(B, nc, A, seed, frame=float(seed))
+    got, idx = non_max_suppression(y.to(DEV), return_idxs=True, **DENSE_KW[case])
+    for b in range(B):
+        assert np.array_equal(idx[b].cpu().numpy(), z[f"{case}::idx{b}"]), f"{case} image {b}: kept indices differ"
+        assert np.array_equal(got[b].cpu().numpy(), z[f"{case}::dets{b}"]), f"{case} image {b}: detections differ"
+    status = nms_padded(y.to(DEV), **DENSE_KW[case])[3]
+    assert not int(status.item()) & FLAG_NMS_OVERFLOW, "no candidate count may overflow any more"
+    yq = y[:1].clone()
+    yq[:, 4:] = (yq[:, 4:] * 512).round() / 512          # ~1300 candidates per distinct score
+    _nms_compare(yq, **DENSE_KW[case])
+
+
 def test_nms_random_and_ties():
     g = torch.Generator().manual_seed(21)
     B, nc, A = 4, 80, 8400

@@ -309,33 +309,75 @@ def load_cfg5_l(golden_dir, setting="base"):
     return z, cfg, rcp, sd, x
 
 
+def _cfg5_module(m, name):
+    mod = m
+    for part in name.split("."):
+        mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+    return mod
+
+
 def check_cfg5_routes(m, z, tag):
     """Every discrete routing decision against the reference's: exact wherever the reference's own logit gap to the next expert is
     at least 1e-4 (the fixture lists the few per-token decisions below that as `close`: an evaluation-order difference of 1e-6 may
-    resolve those ties either way).  Returns the number of close decisions that resolved differently."""
-    flips = 0
+    resolve those ties either way).  Returns {MoT block name: bool mask [B, E, H, W] of the product's selection} for the blocks in
+    which a close decision resolved differently (empty: identical routing everywhere)."""
+    flipped = {}
     for key in [f for f in z.files if f.startswith(f"{tag}::route::")]:
         name = key[len(f"{tag}::route::"):]
-        mod = m
-        for part in name.split("."):
-            mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
         ref = z[key].astype(np.int64)
-        r = mod.last_route
+        r = _cfg5_module(m, name).last_route
         B, k = ref.shape[:2]
         if "indices" in r:                                # gated block: ranked experts per image
             got = r["indices"].cpu().numpy().reshape(ref.shape).astype(np.int64)
-            same = (got == ref).reshape(B, k, -1).all(1)
-        else:                                             # MoT block: selected experts per token
-            w = r["weights"].permute(0, 3, 1, 2).cpu()
-            sel = torch.zeros_like(w, dtype=torch.bool).scatter_(1, torch.from_numpy(ref), True)
-            same = ((w > 0) == sel).all(1).reshape(B, -1).numpy()
+            assert np.array_equal(got, ref), f"{name}: routed experts differ from the reference"
+            continue
+        w = r["weights"].permute(0, 3, 1, 2).cpu()        # MoT block: selected experts per token
+        sel = torch.zeros_like(w, dtype=torch.bool).scatter_(1, torch.from_numpy(ref), True)
+        same = ((w > 0) == sel).all(1).reshape(B, -1).numpy()
         close = z[f"{tag}::close::{name}"]
         ok = same.copy()
         if len(close):
             ok[close[:, 0], close[:, 1]] = True
         assert ok.all(), f"{name}: {int((~ok).sum())} routing decisions differ from the reference outside its close calls"
-        flips += int((~same).sum())
-    return flips
+        if not same.all():
+            flipped[name] = w > 0
+    return flipped
+
+
+def oracle_under_the_products_tie_resolution(m, cfg, sd, x, names, margin):
+    """The reference algorithm (oracle, bit-exact vs the real reference at this size) re-evaluated with the product's resolution of
+    the near-ties: the first block (execution order) whose selection differs is forced to the product's, everything downstream is
+    recomputed, and the comparison repeats until no selection differs; a difference is only accepted where the ORACLE's own logit
+    gap is below `margin`.  Returns (y, taps) of that evaluation."""
+    from oracle import model_ref, mot_ref
+
+    mot_ref.FORCE_SELECT.clear()
+    try:
+        for _ in range(6):
+            taps, info = {}, {}
+            with torch.inference_mode():
+                y, _, _ = model_ref.forward(cfg, sd, x, fused=False, taps=taps, moe_info=info)
+            first = None
+            for name in names:                            # execution order
+                w = _cfg5_module(m, name).last_route["weights"].permute(0, 3, 1, 2).cpu() > 0
+                ind = info[name]["indices"]
+                sel = torch.zeros_like(w).scatter_(1, ind, True)
+                diff = (w != sel).any(1)
+                if not diff.any():
+                    continue
+                lg = info[name]["logits"].float()
+                srt = lg.sort(dim=1, descending=True).values
+                k = ind.shape[1]
+                gap = srt[:, k - 1] - srt[:, k]
+                assert float(gap[diff].max()) < margin, f"{name}: the product selects other experts where the reference's logit gap is {float(gap[diff].max()):.2e}"
+                first = (name, w)
+                break
+            if first is None:
+                return y, taps
+            mot_ref.FORCE_SELECT[first[0] + ".router"] = first[1]
+        raise AssertionError("tie resolution did not converge")
+    finally:
+        mot_ref.FORCE_SELECT.clear()
 
 
 @pytest.mark.parametrize("setting", ["base", "imb"])
@@ -344,9 +386,14 @@ def test_config5_at_its_own_configuration(setting, golden_dir):
     1280, fp32, against the REAL reference (tests/golden/make_golden_cfg5_l.py): every layer and y within 1e-4 (layers: of the layer's
     scale; class scores: absolute; boxes: 1e-4 DFL bins = pixels / stride, as for config 2), routed experts per image and per token
     identical, NMS kept anchor indices and classes identical, Cluster-Weighted boxes (sigma 0.1, pinned to the reference's C++)
-    within 1e-4 bins of the coarsest level.  `imb` = the expert-imbalance stress (all images / >= 90 % of the tokens on expert 0)."""
+    within 1e-4 bins of the coarsest level.  `imb` = the expert-imbalance stress (all images / >= 90 % of the tokens on expert 0).
+
+    Per-token routing has ~150 000 top-k decisions per forward; a handful have logit gaps of 1e-6 ... 1e-8 (the fixture lists those
+    under 1e-4), which two correct fp32 evaluations may resolve differently.  When that happens the comparison switches from the
+    committed vectors to the oracle re-evaluated under the product's resolution of exactly those ties (full tensors, same bars)."""
     import warnings
 
+    from oracle import nms_ref
     from yolo_master_amd.nms import non_max_suppression
     from yolo_master_amd.nn.tasks import DetectionModel
 
@@ -360,45 +407,63 @@ def test_config5_at_its_own_configuration(setting, golden_dir):
     with torch.inference_mode():
         y, _ = m._predict_once(x.to(DEV), taps=taps)
     m.check_flags()
-    flips = check_cfg5_routes(m, z, setting)
-    n = len(cfg["backbone"]) + len(cfg["head"])
-    worst = 0.0
-    if setting == "base":
-        for i in range(n - 1):
-            t = taps[i]
-            if not torch.is_tensor(t):
-                t = t.materialise()
-            got = ops_nchw(t).reshape(-1)[torch.from_numpy(z[f"base::layer{i}_idx"])].numpy()
-            ref = z[f"base::layer{i}_val"]
-            err = float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max())))
-            worst = max(worst, err)
-            assert err <= 1e-4 or flips, f"layer {i} ({(cfg['backbone'] + cfg['head'])[i][2]}): scaled max error {err:.3e}"
+    flipped = check_cfg5_routes(m, z, setting)
+    rows = cfg["backbone"] + cfg["head"]
+    n = len(rows)
     B, ch, A = y.shape
     img = rcp["img"]
     stride_of = torch.cat([torch.full(((img // s) ** 2,), float(s)) for s in (8, 16, 32)])
-    yi = torch.from_numpy(z[f"{setting}::y_idx"])
-    got, ref = y.cpu().reshape(-1)[yi], torch.from_numpy(z[f"{setting}::y_val"])
-    row, anchor = (yi // A) % ch, yi % A
-    is_box = row < 4
-    e_box = float(((got - ref).abs() / stride_of[anchor])[is_box].max())
-    e_cls = float((got - ref).abs()[~is_box].max())
-    print(f"config 5 @ L, {img}^2 [{setting}]: worst layer {worst:.2e}, boxes {e_box:.2e} bins, scores {e_cls:.2e}, close-call flips {flips}")
-    if not flips:
-        assert e_box <= 1e-4 and e_cls <= 1e-4, (e_box, e_cls)
+    worst = 0.0
+    if not flipped:                                       # the committed vectors of the real reference
+        if setting == "base":
+            for i in range(n - 1):
+                t = taps[i] if torch.is_tensor(taps[i]) else taps[i].materialise()
+                got = ops_nchw(t).reshape(-1)[torch.from_numpy(z[f"base::layer{i}_idx"])].numpy()
+                ref = z[f"base::layer{i}_val"]
+                err = float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max())))
+                worst = max(worst, err)
+                assert err <= 1e-4, f"layer {i} ({rows[i][2]}): scaled max error {err:.3e}"
+        yi = torch.from_numpy(z[f"{setting}::y_idx"])
+        got, ref = y.cpu().reshape(-1)[yi], torch.from_numpy(z[f"{setting}::y_val"])
+        row, anchor = (yi // A) % ch, yi % A
+        e_box = float(((got - ref).abs() / stride_of[anchor])[row < 4].max())
+        e_cls = float((got - ref).abs()[row >= 4].max())
+        ref_nms = [(z[f"{setting}::nms_det{b}"], z[f"{setting}::nms_idx{b}"], z[f"{setting}::cw_box{b}"]) for b in range(B)]
+    else:                                                 # the reference algorithm under the product's resolution of the listed ties
+        names = [k[len(f"{setting}::route::"):] for k in z.files if k.startswith(f"{setting}::route::") and ".m." in k]
+        oy, otaps = oracle_under_the_products_tie_resolution(m, cfg, sd, x, names, rcp["margin"])
+        for i in range(n - 1):
+            t = taps[i] if torch.is_tensor(taps[i]) else taps[i].materialise()
+            err = float((ops_nchw(t) - otaps[i]).abs().max() / max(1.0, float(otaps[i].abs().max())))
+            worst = max(worst, err)
+            assert err <= 1e-4, f"layer {i} ({rows[i][2]}): scaled max error {err:.3e} (full tensor, ties resolved as the product did)"
+        d = (y.cpu() - oy).abs()
+        e_box, e_cls = float((d[:, :4] / stride_of).max()), float(d[:, 4:].max())
+        dets_o, idx_o = nms_ref.non_max_suppression(oy.numpy(), rcp["conf"], rcp["iou"], return_idxs=True)
+        ref_nms = []
+        for b in range(B):
+            yb = oy[b].numpy()
+            conf, cls = yb[4:].max(0), yb[4:].argmax(0)
+            mk = conf > np.float32(rcp["conf"])
+            cands = np.concatenate([nms_ref.xywh2xyxy(yb[:4].T.copy())[mk], conf[mk, None], cls[mk, None].astype(np.float32)], 1).astype(np.float32)
+            pos = {int(a): j for j, a in enumerate(np.arange(A)[mk])}
+            keep = np.array([pos[int(a)] for a in idx_o[b]], np.int64)
+            ref_nms.append((dets_o[b], idx_o[b], nms_ref.cw_refine(cands, keep, rcp["iou"], rcp["sigma"])))
+    print(f"config 5 @ L, {img}^2 [{setting}]: worst layer {worst:.2e}, boxes {e_box:.2e} bins, scores {e_cls:.2e}; "
+          f"near-ties resolved differently in {sorted(flipped)}")
+    assert e_box <= 1e-4 and e_cls <= 1e-4, (e_box, e_cls)
     dets, idx = non_max_suppression(y, rcp["conf"], rcp["iou"], return_idxs=True)
     cw, _ = non_max_suppression(y, rcp["conf"], rcp["iou"], return_idxs=True, cluster=True, sigma=rcp["sigma"])
     for b in range(B):
-        ref_det, ref_idx = z[f"{setting}::nms_det{b}"], z[f"{setting}::nms_idx{b}"]
-        if flips and not np.array_equal(idx[b].cpu().numpy(), ref_idx):
-            continue                                      # a resolved tie moved a score across a neighbour's: reported above, not a defect
+        ref_det, ref_idx, ref_cw = ref_nms[b]
         assert np.array_equal(idx[b].cpu().numpy(), ref_idx), f"image {b}: NMS kept anchors differ"
         d = dets[b].cpu().numpy()
         assert np.array_equal(d[:, 5], ref_det[:, 5]), f"image {b}: classes differ"
-        s = stride_of[torch.from_numpy(ref_idx)].numpy()
+        s = stride_of[torch.from_numpy(np.asarray(ref_idx))].numpy()
         assert float((np.abs(d[:, :4] - ref_det[:, :4]).max(1) / s).max()) <= 1e-4 and float(np.abs(d[:, 4] - ref_det[:, 4]).max()) <= 1e-4
         c = cw[b].cpu().numpy()
         assert np.array_equal(c[:, 4:], d[:, 4:]), "Cluster-Weighted refinement must leave survivors, scores and classes untouched"
-        e_cw = float(np.abs(c[:, :4] - z[f"{setting}::cw_box{b}"]).max())
+        e_cw = float(np.abs(c[:, :4] - ref_cw).max())
         assert e_cw <= 32 * 1e-4, f"image {b}: Cluster-Weighted boxes off by {e_cw:.3e} px"
         assert float(np.abs(c[:, :4] - d[:, :4]).max()) > 1.0, "the fixture's clusters move boxes by tens of pixels"
 

@@ -98,3 +98,36 @@ def test_nms_radix_ordering(ties, host_ops):
     for b in range(B):
         assert np.array_equal(got_idx[b].numpy(), ref_idx[b]), f"image {b}: kept anchors differ"
         assert np.array_equal(got[b].numpy(), ref[b]), f"image {b}: detections differ"
+
+
+@pytest.mark.parametrize("mode", ["multi", "multi_ties", "single", "classes", "mixed_batch"])
+def test_nms_selects_the_top_max_nms_candidates(mode, host_ops):
+    """More candidates than `max_nms` (utils/nms.py:142-146 keeps the max_nms best by score, whatever their number): the radix select
+    on the score bits (csrc/nms.hip, three histogram levels) + threshold-aware compaction, bit-exact against the oracle's
+    sort-and-truncate.  `multi_ties`: 33 distinct scores, so the threshold value itself is shared by hundreds of candidates and only
+    the first few (anchor-major order, what the stable sort keeps) may pass; `mixed_batch`: one image over the cap, one under it."""
+    from oracle import nms_ref
+    from yolo_master_amd.nms import non_max_suppression
+
+    g = torch.Generator().manual_seed(77)
+    B, nc, A = 2, 6, 900
+    xy = torch.rand(B, 2, A, generator=g) * 600 + 20
+    wh = torch.rand(B, 2, A, generator=g) * 60 + 8
+    cls = torch.rand(B, nc, A, generator=g) * 0.9 + 0.05
+    kw = dict(conf_thres=0.01, iou_thres=0.6, multi_label=mode != "single", max_det=80, max_nms=700)
+    if mode == "multi_ties":
+        cls = (cls * 32).round() / 32
+    if mode == "single":
+        kw["max_nms"] = 300                      # 900 best-class candidates > 300
+    if mode == "classes":
+        kw["classes"] = [0, 2, 5]
+    if mode == "mixed_batch":
+        cls[1] *= 0.05                           # image 1: ~500 candidates above conf, under the cap
+    y = torch.cat([xy, wh, cls], 1)
+    ref, ref_idx = nms_ref.non_max_suppression(y.numpy(), return_idxs=True, **kw)
+    got, got_idx = non_max_suppression(y, return_idxs=True, **kw)
+    ncand = [(int((cls[b] > 0.01).sum()) if mode != "single" else int((cls[b].amax(0) > 0.01).sum())) for b in range(B)]
+    assert ncand[0] > kw["max_nms"], ncand
+    for b in range(B):
+        assert np.array_equal(got_idx[b].numpy(), ref_idx[b]), f"{mode} image {b}: kept anchors differ ({ncand[b]} candidates)"
+        assert np.array_equal(got[b].numpy(), ref[b]), f"{mode} image {b}: detections differ"

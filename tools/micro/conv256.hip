@@ -34,7 +34,7 @@ typedef void* lptr_t;
 #define WAIT_LGKM0() ((void)0)
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 template <typename T> inline void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
-template <> inline void mma16<bf16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
+template <> inline void mma16<h16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 #endif
@@ -50,9 +50,9 @@ struct ConvGeom {
 #define WAITCNT_VM(n) (0x0F70 | ((n) & 15) | ((((n) >> 4) & 3) << 14))
 
 template <int BN, int STAGES, bool XCD>
-__global__ __launch_bounds__(512) void conv256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
-                                                       const float* __restrict__ bias, bf16_t* __restrict__ Y,
-                                                       const bf16_t* __restrict__ zero_page, ConvGeom g) {
+__global__ __launch_bounds__(512) void conv256_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ Wt,
+                                                       const float* __restrict__ bias, h16_t* __restrict__ Y,
+                                                       const h16_t* __restrict__ zero_page, ConvGeom g) {
     constexpr int ROWS = BN + C_BM;          // staged rows per k-step: weights first, then pixels
     constexpr int STAGE_U4 = ROWS * 8;       // 16-byte slots per stage
     constexpr int G = ROWS / 64;             // global_load_lds instructions per wave per k-step (6 or 5)
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void conv256_kernel(const bf16_t* __restrict__
 
     // ---- staging map --------------------------------------------------------------------------------------
     const int lr = lane >> 3, lc = lane & 7;
-    const bf16_t* wsrc[GW];
+    const h16_t* wsrc[GW];
     int poff[G - GW];        // element offset of the tap-(0,0) input pixel (+ swizzled chunk) for this lane's pixel rows
     unsigned pmask[G - GW];  // bit (ky*3+kx): tap inside the image
 #pragma unroll
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void conv256_kernel(const bf16_t* __restrict__
             pmask[j - GW] = mask;
         }
     }
-    const bf16_t* zsrc = zero_page + lc * 8;
+    const h16_t* zsrc = zero_page + lc * 8;
     // k-step cursor of the NEXT tile to issue (uniform)
     int it_tap_bit = 0, it_ky = 0, it_kx = 0, it_c = 0, it_k = 0;
     auto issue = [&](int stage) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void conv256_kernel(const bf16_t* __restrict__
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             u32x4* dst = smem + stage * STAGE_U4 + (j * 8 + wave) * 64;   // wave-uniform; lane lands at + lane * 16 B
-            const bf16_t* s;
+            const h16_t* s;
             if (j < GW) s = wsrc[j] + it_k * 64;
             else s = ((pmask[j - GW] >> it_tap_bit) & 1u) ? X + (poff[j - GW] + tapoff) : zsrc;
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void conv256_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < TP; ++j) mma16<bf16_t>(acc[i][j], af[i], bfr[j]);
+                for (int j = 0; j < TP; ++j) mma16<h16_t>(acc[i][j], af[i], bfr[j]);
         }
     };
 
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void conv256_kernel(const bf16_t* __restrict__
     }
 }
 
-__global__ void naive_conv_kernel(const bf16_t* X, const bf16_t* Wt, const float* bias, float* Yr, ConvGeom g, const int* pix,
+__global__ void naive_conv_kernel(const h16_t* X, const h16_t* Wt, const float* bias, float* Yr, ConvGeom g, const int* pix,
                                   int npix) {
     const int i = blockIdx.x, n = threadIdx.x + blockIdx.y * blockDim.x;
     if (i >= npix || n >= g.Cout) return;
@@ -210,9 +210,9 @@ __global__ void naive_conv_kernel(const bf16_t* X, const bf16_t* Wt, const float
         for (int kx = 0; kx < g.ks; ++kx) {
             const int iy = oy * g.stride - pad + ky, ix = ox * g.stride - pad + kx;
             if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) continue;
-            const bf16_t* xr = X + ((size_t)(b * g.H + iy) * g.W + ix) * g.ldx;
-            const bf16_t* wr = Wt + (size_t)n * g.Kpad + (ky * g.ks + kx) * g.Cin;
-            for (int c = 0; c < g.Cin; ++c) s += bf16_to_f32(xr[c]) * bf16_to_f32(wr[c]);
+            const h16_t* xr = X + ((size_t)(b * g.H + iy) * g.W + ix) * g.ldx;
+            const h16_t* wr = Wt + (size_t)n * g.Kpad + (ky * g.ks + kx) * g.Cin;
+            for (int c = 0; c < g.Cin; ++c) s += h16_to_f32(xr[c]) * h16_to_f32(wr[c]);
         }
     s += bias[n];
     Yr[(size_t)i * g.Cout + n] = s / (1.0f + expf(-s));
@@ -237,7 +237,7 @@ static float timeit(F&& f, int reps = 20) {
 }
 
 template <int BN, int STAGES, bool XCD>
-static int launch(const bf16_t* x, const bf16_t* w, const float* b, bf16_t* y, const bf16_t* zp, const ConvGeom& g) {
+static int launch(const h16_t* x, const h16_t* w, const float* b, h16_t* y, const h16_t* zp, const ConvGeom& g) {
     const int M = g.B * g.Ho * g.Wo;
     const int grid = ((M + C_BM - 1) / C_BM) * (g.Cout / BN);
     const size_t lds = (size_t)STAGES * (BN + C_BM) * 8 * 16;
@@ -252,7 +252,7 @@ static int launch(const bf16_t* x, const bf16_t* w, const float* b, bf16_t* y, c
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-typedef int (*launch_fn)(const bf16_t*, const bf16_t*, const float*, bf16_t*, const bf16_t*, const ConvGeom&);
+typedef int (*launch_fn)(const h16_t*, const h16_t*, const float*, h16_t*, const h16_t*, const ConvGeom&);
 struct Variant { const char* name; int bn; launch_fn fn; };
 
 int main(int argc, char** argv) {
@@ -283,7 +283,7 @@ int main(int argc, char** argv) {
         {"bn128 s3 xcd  ", 128, launch<128, 3, true>},  {"bn64  s2      ", 64, launch<64, 2, false>},
         {"bn64  s3      ", 64, launch<64, 3, false>},   {"bn64  s3 xcd  ", 64, launch<64, 3, true>},
     };
-    bf16_t* zp;
+    h16_t* zp;
     hipMalloc(&zp, 256); hipMemset(zp, 0, 256);
     int bad = 0;
     for (int si = 0; si < nshape; ++si) {
@@ -295,15 +295,15 @@ int main(int argc, char** argv) {
         g.Kpad = sh.ks * sh.ks * sh.Cin;   // multiple of 64 by construction
         const int M = g.B * g.Ho * g.Wo;
         const size_t nx = (size_t)sh.B * sh.H * sh.W * sh.Cin, nw = (size_t)sh.Cout * g.Kpad, ny = (size_t)M * sh.Cout;
-        std::vector<bf16_t> hx(nx), hw(nw);
+        std::vector<h16_t> hx(nx), hw(nw);
         std::vector<float> hb(sh.Cout);
         uint32_t s = 12345u + si;
         auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 9) & 0xffff) / 65536.0f - 0.5f; };
-        for (auto& v : hx) { float f = rnd(); v = (bf16_t)(__builtin_bit_cast(uint32_t, f) >> 16); }
+        for (auto& v : hx) { float f = rnd(); v = (h16_t)(__builtin_bit_cast(uint32_t, f) >> 16); }
         const float wscale = 2.0f / sqrtf((float)g.Kpad);
-        for (auto& v : hw) { float f = rnd() * wscale; v = (bf16_t)(__builtin_bit_cast(uint32_t, f) >> 16); }
+        for (auto& v : hw) { float f = rnd() * wscale; v = (h16_t)(__builtin_bit_cast(uint32_t, f) >> 16); }
         for (auto& v : hb) v = rnd() * 0.2f;
-        bf16_t *x, *w, *y, *y2; float *b, *yr; int* pix;
+        h16_t *x, *w, *y, *y2; float *b, *yr; int* pix;
         hipMalloc(&x, nx * 2); hipMalloc(&w, nw * 2); hipMalloc(&y, ny * 2); hipMalloc(&y2, ny * 2); hipMalloc(&b, sh.Cout * 4);
         hipMemcpy(x, hx.data(), nx * 2, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice);
         hipMemcpy(b, hb.data(), sh.Cout * 4, hipMemcpyHostToDevice);
@@ -322,8 +322,8 @@ int main(int argc, char** argv) {
         const double flops = 2.0 * M * sh.Cout * g.Kpad, bytes = 2.0 * (nx / (double)(sh.stride == 2 && sh.ks == 1 ? 4 : 1) + nw + ny);
         printf("shape %d: %d->%d k%d s%d in %dx%d out %dx%d  M %d K %d  (%.2f GFLOP, %.1f MB)\n", si, sh.Cin, sh.Cout, sh.ks, sh.stride,
                sh.H, sh.W, g.Ho, g.Wo, M, g.Kpad, flops / 1e9, bytes / 1e6);
-        std::vector<bf16_t> hy(ny);
-        auto check = [&](const bf16_t* dev) {
+        std::vector<h16_t> hy(ny);
+        auto check = [&](const h16_t* dev) {
             hipMemcpy(hy.data(), dev, ny * 2, hipMemcpyDeviceToHost);
             double maxerr = 0;
             for (int i = 0; i < npix; ++i)

@@ -39,7 +39,7 @@ int main() {
         const int Ho = (sh.H + 2 * (sh.k / 2) - sh.k) / sh.s + 1, Wo = (sh.W + 2 * (sh.k / 2) - sh.k) / sh.s + 1;
         const size_t nout = (size_t)sh.B * Ho * Wo * sh.Cout;
         const int K = sh.k * sh.k * sh.Cin, Kpad = (K + 63) / 64 * 64;
-        bf16_t *x, *w, *y; float* bias;
+        h16_t *x, *w, *y; float* bias;
         hipMalloc(&x, nin * 2); hipMalloc(&y, nout * 2); hipMalloc(&w, (size_t)sh.Cout * Kpad * 2); hipMalloc(&bias, sh.Cout * 4);
         hipMemset(x, 0x3c, nin * 2); hipMemset(w, 0x3c, (size_t)sh.Cout * Kpad * 2); hipMemset(bias, 0, sh.Cout * 4);
         ymk_conv_desc d{YMK_BF16, YMK_BF16, sh.B, sh.H, sh.W, sh.Cin, sh.Cout, sh.k, sh.s, sh.Cin, sh.Cout, 0, Kpad, YMK_ACT_SILU};

@@ -22,8 +22,8 @@
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__global__ __launch_bounds__(512) void gemm256_glds_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
-                                                            const float* __restrict__ bias, bf16_t* __restrict__ Y, int M,
+__global__ __launch_bounds__(512) void gemm256_glds_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ Wt,
+                                                            const float* __restrict__ bias, h16_t* __restrict__ Y, int M,
                                                             int N, int K) {
     __shared__ u32x4 smem[2 * G_STAGE_U4];   // 96 KB
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512) void gemm256_glds_kernel(const bf16_t* __restr
 
     // staging map: k-step = 48 wave-instructions of 8 rows; wave w issues row blocks rb = j*8 + w, j = 0..5
     const int lr = lane >> 3, lc = lane & 7;
-    const bf16_t* src[6];
+    const h16_t* src[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int r = (j * 8 + wave) * 8 + lr;                 // staged row 0..383
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512) void gemm256_glds_kernel(const bf16_t* __restr
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma16<bf16_t>(acc[i][j], af[i], bfr[j]);
+                for (int j = 0; j < 4; ++j) mma16<h16_t>(acc[i][j], af[i], bfr[j]);
         }
     }
 #pragma unroll
@@ -93,13 +93,13 @@ __global__ __launch_bounds__(512) void gemm256_glds_kernel(const bf16_t* __restr
     }
 }
 
-__global__ void naive_kernel(const bf16_t* X, const bf16_t* Wt, const float* bias, float* Yr, int N, int K, const int* rows,
+__global__ void naive_kernel(const h16_t* X, const h16_t* Wt, const float* bias, float* Yr, int N, int K, const int* rows,
                              int nrows) {
     const int i = blockIdx.x, n = threadIdx.x + blockIdx.y * blockDim.x;
     if (i >= nrows || n >= N) return;
     const size_t m = rows[i];
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s += bf16_to_f32(X[m * K + k]) * bf16_to_f32(Wt[(size_t)n * K + k]);
+    for (int k = 0; k < K; ++k) s += h16_to_f32(X[m * K + k]) * h16_to_f32(Wt[(size_t)n * K + k]);
     s += bias[n];
     Yr[(size_t)i * N + n] = s / (1.0f + expf(-s));
 }
@@ -125,15 +125,15 @@ int main(int argc, char** argv) {
     for (int si = 0; si < nshape && si < 6; ++si) {
         const Shape sh = shapes[si];
         const size_t nx = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, ny = (size_t)sh.M * sh.N;
-        std::vector<bf16_t> hx(nx), hw(nw);
+        std::vector<h16_t> hx(nx), hw(nw);
         std::vector<float> hb(sh.N);
         uint32_t s = 12345u;
         auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 9) & 0xffff) / 65536.0f - 0.5f; };
-        for (auto& v : hx) { float f = rnd(); v = (bf16_t)(__builtin_bit_cast(uint32_t, f) >> 16); }
+        for (auto& v : hx) { float f = rnd(); v = (h16_t)(__builtin_bit_cast(uint32_t, f) >> 16); }
         const float wscale = 2.0f / sqrtf((float)sh.K);
-        for (auto& v : hw) { float f = rnd() * wscale; v = (bf16_t)(__builtin_bit_cast(uint32_t, f) >> 16); }
+        for (auto& v : hw) { float f = rnd() * wscale; v = (h16_t)(__builtin_bit_cast(uint32_t, f) >> 16); }
         for (auto& v : hb) v = rnd() * 0.2f;
-        bf16_t *x, *w, *y, *y2; float *b, *yr; int* rows;
+        h16_t *x, *w, *y, *y2; float *b, *yr; int* rows;
         hipMalloc(&x, nx * 2); hipMalloc(&w, nw * 2); hipMalloc(&y, ny * 2); hipMalloc(&y2, ny * 2); hipMalloc(&b, sh.N * 4);
         hipMemcpy(x, hx.data(), nx * 2, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice);
         hipMemcpy(b, hb.data(), sh.N * 4, hipMemcpyHostToDevice);
@@ -148,7 +148,7 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(gemm256_glds_kernel, grid, dim3(512), 0, 0, x, w, b, y, sh.M, sh.N, sh.K);
         hipLaunchKernelGGL(naive_kernel, dim3(nrows, (sh.N + 127) / 128), dim3(128), 0, 0, x, w, b, yr, sh.N, sh.K, rows, nrows);
         if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
-        std::vector<bf16_t> hy(ny);
+        std::vector<h16_t> hy(ny);
         std::vector<float> hyr((size_t)nrows * sh.N);
         hipMemcpy(hy.data(), y, ny * 2, hipMemcpyDeviceToHost);
         hipMemcpy(hyr.data(), yr, hyr.size() * 4, hipMemcpyDeviceToHost);

@@ -16,6 +16,9 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = CSRC / "_obj"
 LIB = HERE / "libymk.so"
+# The same sources compiled a second time with the 16-bit element format = IEEE binary16 (-DYMK_H16_F16, csrc/ymk_common.h): same
+# C-ABI, loaded side by side by _lib.py for torch.float16 tensors (the reference's `half=True` mode).
+VARIANTS = {"bf16": (OBJ, LIB, []), "f16": (CSRC / "_obj_f16", HERE / "libymk_f16.so", ["-DYMK_H16_F16"])}
 ARCH = "gfx950"
 # files whose arithmetic must not be contracted into FMAs (bit-exact NMS / decode)
 NO_CONTRACT = {"nms.hip", "elementwise.hip", "post.hip", "preproc.hip"}
@@ -32,31 +35,49 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libymk cannot be built (ROCm toolchain required)")
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
+def _compile_cmd(hipcc: str, src: str, obj: Path, defs: list) -> list:
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *defs, "-c", str(CSRC / src), "-o", str(obj)]
+    if src in NO_CONTRACT:
+        cmd.insert(4, "-ffp-contract=off")
+    if src in ("post.hip", "preproc.hip"):   # bit-exact box rescaling divides by the gain: IEEE division (hipcc's default, stated explicitly)
+        cmd.insert(4, "-fhip-fp32-correctly-rounded-divide-sqrt")
+    return cmd
+
+
+def build(force: bool = False, verbose: bool = True, variants=("bf16", "f16")) -> Path:
+    """Compile what is stale (objects are cached by mtime against their source and the shared headers) for every variant, up to
+    $YMK_BUILD_JOBS (default: all cores) hipcc processes at a time, then link each variant's shared object."""
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = _hipcc()
-    OBJ.mkdir(exist_ok=True)
     hdr_m = max((CSRC / h).resolve().stat().st_mtime for h in HEADERS)
-    objs, rebuilt = [], False
-    for src in SOURCES:
-        s = CSRC / src
-        o = OBJ / (src.replace(".hip", ".o"))
-        objs.append(str(o))
-        if not force and o.exists() and o.stat().st_mtime >= max(s.stat().st_mtime, hdr_m):
-            continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(s), "-o", str(o)]
-        if src in NO_CONTRACT:
-            cmd.insert(4, "-ffp-contract=off")
-        if src in ("post.hip", "preproc.hip"):   # bit-exact box rescaling divides by the gain: IEEE division (hipcc's default, stated explicitly)
-            cmd.insert(4, "-fhip-fp32-correctly-rounded-divide-sqrt")
+    jobs, relink = [], set()
+    for v in variants:
+        obj_dir, lib, defs = VARIANTS[v]
+        obj_dir.mkdir(exist_ok=True)
+        for src in SOURCES:
+            o = obj_dir / src.replace(".hip", ".o")
+            if not force and o.exists() and o.stat().st_mtime >= max((CSRC / src).stat().st_mtime, hdr_m):
+                continue
+            jobs.append(_compile_cmd(hipcc, src, o, defs))
+            relink.add(v)
+        if force or not lib.exists():
+            relink.add(v)
+
+    def run(cmd):
         if verbose:
             print("[ymk build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        rebuilt = True
-    if rebuilt or force or not LIB.exists():
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *objs]
-        if verbose:
-            print("[ymk build]", " ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("YMK_BUILD_JOBS", os.cpu_count() or 4))) as ex:
+            list(ex.map(run, jobs))
+    for v in variants:
+        obj_dir, lib, _ = VARIANTS[v]
+        if v in relink:
+            # -Bsymbolic + hidden-by-default template instantiations are not needed: ctypes loads each library RTLD_LOCAL, so the two
+            # variants' identically named symbols never meet
+            run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", str(lib), *[str(obj_dir / s.replace(".hip", ".o")) for s in SOURCES]])
     return LIB
 
 

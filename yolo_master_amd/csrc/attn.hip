@@ -140,10 +140,10 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             for (int u = 0; u < AT_KC / 32; ++u) {
                 if (2 * u < ntile) {
                     u32x4 pb;
-                    pb.x = pack_bf16x2(sacc[2 * u].x, sacc[2 * u].y);
-                    pb.y = pack_bf16x2(sacc[2 * u].z, sacc[2 * u].w);
-                    pb.z = pack_bf16x2(sacc[2 * u + 1].x, sacc[2 * u + 1].y);
-                    pb.w = pack_bf16x2(sacc[2 * u + 1].z, sacc[2 * u + 1].w);
+                    pb.x = pack_h16x2(sacc[2 * u].x, sacc[2 * u].y);
+                    pb.y = pack_h16x2(sacc[2 * u].z, sacc[2 * u].w);
+                    pb.z = pack_h16x2(sacc[2 * u + 1].x, sacc[2 * u + 1].y);
+                    pb.w = pack_h16x2(sacc[2 * u + 1].z, sacc[2 * u + 1].w);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
                         const T* vr = &sVt[(dt * 16 + fi) * VPAD + g * 4];
@@ -283,10 +283,10 @@ __device__ __forceinline__ void at_chunk(const T* __restrict__ sK, const T* __re
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             u32x4 pb;
-            pb.x = pack_bf16x2(sacc[2 * u].x, sacc[2 * u].y);
-            pb.y = pack_bf16x2(sacc[2 * u].z, sacc[2 * u].w);
-            pb.z = pack_bf16x2(sacc[2 * u + 1].x, sacc[2 * u + 1].y);
-            pb.w = pack_bf16x2(sacc[2 * u + 1].z, sacc[2 * u + 1].w);
+            pb.x = pack_h16x2(sacc[2 * u].x, sacc[2 * u].y);
+            pb.y = pack_h16x2(sacc[2 * u].z, sacc[2 * u].w);
+            pb.z = pack_h16x2(sacc[2 * u + 1].x, sacc[2 * u + 1].y);
+            pb.w = pack_h16x2(sacc[2 * u + 1].z, sacc[2 * u + 1].w);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) mma16<T>(o[dt], va[u][dt], pb);
         }
@@ -474,11 +474,11 @@ static int launch_attn_resident(const T* qkv, int ldq, T* out, int ldo, int B, i
                                 hipStream_t s) {
     const int Nk = (Na + 31) & ~31, Nr = (Na + 15) & ~15;
     const size_t shm = ((size_t)Nr * 32 + (size_t)32 * (Nk + 16 / sizeof(T))) * sizeof(T);
-    static bool attr_set = false;
-    if (shm > 64 * 1024 && !attr_set) {
+    static YmkOncePerDevice attr_once;
+    if (shm > 64 * 1024 && attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&area_attn_resident_kernel<T, WPE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_once.done();
     }
     hipLaunchKernelGGL((area_attn_resident_kernel<T, WPE>), dim3((unsigned)((size_t)B * area * heads)), dim3(AT_NT), shm, s, qkv, ldq,
                        out, ldo, N, Na, heads, area, scale);
@@ -500,7 +500,7 @@ extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* 
     hipStream_t s = (hipStream_t)stream;
     if (!(ymk_disabled() & YMK_OFF_ATTN_RESIDENT) && (int64_t)B * area * heads < (1ll << 31)) {
         if (dtype == YMK_BF16 && Na <= 1024)
-            return launch_attn_resident<bf16_t, 3>((const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, B, N, Na, heads, area, scale, s);
+            return launch_attn_resident<h16_t, 3>((const h16_t*)qkv, ldq, (h16_t*)out, ldo, B, N, Na, heads, area, scale, s);
         if (dtype == YMK_F32 && Na <= 512)
             return launch_attn_resident<float, 1>((const float*)qkv, ldq, (float*)out, ldo, B, N, Na, heads, area, scale, s);
     }
@@ -508,7 +508,7 @@ extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* 
         hipLaunchKernelGGL((area_attn_kernel<float, 1>), grid, blk, 0, s, (const float*)qkv, ldq, (float*)out, ldo, N, Na,
                            heads, area, scale);
     else if (dtype == YMK_BF16)
-        hipLaunchKernelGGL((area_attn_kernel<bf16_t, 3>), grid, blk, 0, s, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, Na, heads, area,
+        hipLaunchKernelGGL((area_attn_kernel<h16_t, 3>), grid, blk, 0, s, (const h16_t*)qkv, ldq, (h16_t*)out, ldo, N, Na, heads, area,
                            scale);   // 3 waves per SIMD measured best (4: small spill, 1: 2x slower)
     else
         return YMK_E_BADARG;

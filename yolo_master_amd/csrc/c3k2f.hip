@@ -39,20 +39,20 @@
 
 typedef __bf16 cf_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void cf_mma(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cf_bf16x8, a), __builtin_bit_cast(cf_bf16x8, b), acc, 0, 0, 0);
+    acc = mfma16x16x32_h16(a, b, acc);
 }
 __device__ __forceinline__ u32x2 cf_pack_silu(const f32x4& v) {
     u32x2 o;
-    o.x = pack_bf16x2(silu_f(v.x), silu_f(v.y));
-    o.y = pack_bf16x2(silu_f(v.z), silu_f(v.w));
+    o.x = pack_h16x2(silu_f(v.x), silu_f(v.y));
+    o.y = pack_h16x2(silu_f(v.z), silu_f(v.w));
     return o;
 }
 
 struct C3k2fArgs {
-    const bf16_t* x;                       // [B][H][W][ldx], 64 channels
-    const bf16_t *w1, *wa, *wb, *w2;       // packed [Cout][Kpad] (K = (ky, kx, cin)): 64 x 64, 16 x 288, 32 x 144, 128 x 96
+    const h16_t* x;                       // [B][H][W][ldx], 64 channels
+    const h16_t *w1, *wa, *wb, *w2;       // packed [Cout][Kpad] (K = (ky, kx, cin)): 64 x 64, 16 x 288, 32 x 144, 128 x 96
     const float *b1, *ba, *bb, *b2;
-    bf16_t* y;                             // [B][H][W][ldy], 128 channels
+    h16_t* y;                             // [B][H][W][ldy], 128 channels
     int B, H, W, ldx, ldy, k1pad, kapad, kbpad, k2pad, tiles_x, tiles_y;
     float* gap_part;                       // [B][tiles_y * tiles_x][128] per-tile channel sums of y (or null)
     int* flags;                            // YMK_FLAG_NONFINITE_INPUT is raised when a sum is not finite (or null)
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(CF_NT) void c3k2_fused_kernel(C3k2fArgs a) {
     auto xload = [&](int tile) {
         const int txi = tile % a.tiles_x, r0 = tile / a.tiles_x;
         const int tyi = r0 % a.tiles_y, b = r0 / a.tiles_y;
-        const bf16_t* xb = a.x + (size_t)b * a.H * a.W * a.ldx;
+        const h16_t* xb = a.x + (size_t)b * a.H * a.W * a.ldx;
         inmask = 0;
 #pragma unroll
         for (int r = 0; r < NR1; ++r) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(CF_NT) void c3k2_fused_kernel(C3k2fArgs a) {
             const bool in = g < NG1 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             bx[r][0] = bx[r][1] = u32x4{0u, 0u, 0u, 0u};
             if (in) {
-                const bf16_t* px = xb + ((size_t)iy * a.W + ix) * a.ldx + fc * 8;
+                const h16_t* px = xb + ((size_t)iy * a.W + ix) * a.ldx + fc * 8;
                 bx[r][0] = *reinterpret_cast<const u32x4*>(px);
                 bx[r][1] = *reinterpret_cast<const u32x4*>(px + 32);
                 inmask |= 1u << r;
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(CF_NT) void c3k2_fused_kernel(C3k2fArgs a) {
                 const int r = 2 * rq + (j >> 1), xx = (j & 1) * 16 + fr;
                 const u32x2 rb = *reinterpret_cast<const u32x2*>(sY + ((r + 2) * CF_YC + xx + 2) * CF_YP + 64 + (cfb * 16 + fc * 4) * 2);
                 u32x2 o;
-                o.x = pack_bf16x2(bf16lo(rb.x) + silu_f(acc[j].x), bf16hi(rb.x) + silu_f(acc[j].y));
-                o.y = pack_bf16x2(bf16lo(rb.y) + silu_f(acc[j].z), bf16hi(rb.y) + silu_f(acc[j].w));
+                o.x = pack_h16x2(h16lo(rb.x) + silu_f(acc[j].x), h16hi(rb.x) + silu_f(acc[j].y));
+                o.y = pack_h16x2(h16lo(rb.y) + silu_f(acc[j].z), h16hi(rb.y) + silu_f(acc[j].w));
                 *reinterpret_cast<u32x2*>(sM + (r * CF_TW + xx) * CF_MP + (cfb * 16 + fc * 4) * 2) = o;
             }
         }
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(CF_NT) void c3k2_fused_kernel(C3k2fArgs a) {
                 if (oy < a.H && ox < a.W) {
                     const u32x2 o = cf_pack_silu(acc[jj]);
                     *reinterpret_cast<u32x2*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = o;
-                    gsum.x += bf16lo(o.x); gsum.y += bf16hi(o.x); gsum.z += bf16lo(o.y); gsum.w += bf16hi(o.y);
+                    gsum.x += h16lo(o.x); gsum.y += h16hi(o.x); gsum.z += h16lo(o.y); gsum.w += h16hi(o.y);
                 }
             }
         }
@@ -250,8 +250,8 @@ extern "C" int ymk_c3k2_fused_pooled(const void* x, int32_t ldx, int32_t B, int3
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7) || ((uintptr_t)gap_part & 15)) return YMK_E_BADARG;
     if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
     C3k2fArgs a;
-    a.x = (const bf16_t*)x; a.w1 = (const bf16_t*)w1; a.wa = (const bf16_t*)wa; a.wb = (const bf16_t*)wb; a.w2 = (const bf16_t*)w2;
-    a.b1 = b1; a.ba = ba; a.bb = bb; a.b2 = b2; a.y = (bf16_t*)y;
+    a.x = (const h16_t*)x; a.w1 = (const h16_t*)w1; a.wa = (const h16_t*)wa; a.wb = (const h16_t*)wb; a.w2 = (const h16_t*)w2;
+    a.b1 = b1; a.ba = ba; a.bb = bb; a.b2 = b2; a.y = (h16_t*)y;
     a.B = B; a.H = H; a.W = W; a.ldx = ldx; a.ldy = ldy; a.k1pad = k1pad; a.kapad = kapad; a.kbpad = kbpad; a.k2pad = k2pad;
     a.tiles_x = (W + CF_TW - 1) / CF_TW; a.tiles_y = (H + CF_TH - 1) / CF_TH;
     a.gap_part = gap_part; a.flags = flags;
@@ -262,10 +262,10 @@ extern "C" int ymk_c3k2_fused_pooled(const void* x, int32_t ldx, int32_t B, int3
 #else
     const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);   // one persistent workgroup per CU
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
+    static YmkOncePerDevice attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c3k2_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES);
-        attr_set = true;
+        attr_once.done();
     }
     hipLaunchKernelGGL(c3k2_fused_kernel, dim3(grid), dim3(CF_NT), CF_LDS_BYTES, (hipStream_t)stream, a);
     return ymk_launch_status();

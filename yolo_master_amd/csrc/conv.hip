@@ -159,7 +159,7 @@ static int ymk_ablate = 0;
 // exposed once per tile, and the k-loop has no barriers (both operands are complete in LDS).
 // ---------------------------------------------------------------------------
 // eight consecutive channels in one 16-byte store (bf16); the fp32 overload is never taken (`wide` is bf16-only) but must compile
-__device__ __forceinline__ void ws_store8(bf16_t* p, const float (&v)[8]) { store_vec_f32(p, v); }
+__device__ __forceinline__ void ws_store8(h16_t* p, const float (&v)[8]) { store_vec_f32(p, v); }
 __device__ __forceinline__ void ws_store8(float* p, const float (&v)[8]) {
     store4(p, v[0], v[1], v[2], v[3]);
     store4(p + 4, v[4], v[5], v[6], v[7]);
@@ -621,7 +621,7 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     if ((2ll * d->H * d->W + 4096) * d->ldx >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (d->ksize == 1 && d->stride == 1 && ymk_use_ws && !(ymk_disabled() & YMK_OFF_CONV_STREAM)) {  // large-M short-K 1x1: weight-stationary streaming kernel
-        const bool done = d->dtype == YMK_F32 ? launch_conv1x1_ws<float>(a, s) : launch_conv1x1_ws<bf16_t>(a, s);
+        const bool done = d->dtype == YMK_F32 ? launch_conv1x1_ws<float>(a, s) : launch_conv1x1_ws<h16_t>(a, s);
         if (done) { ymk_last_variant = YMK_CONV_STREAM_1X1; return ymk_launch_status(); }
     }
     // 64 -> 64 3x3 on the small maps (C3k bottlenecks at 40x40 / 20x20): the LDS-DMA tiled core is 0-22 % faster than the
@@ -629,7 +629,7 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     const bool small64 = d->dtype == YMK_BF16 && d->Cin == 64 && d->Cout == 64 && d->stride == 1 && a.M <= 102400 &&
                          !(ymk_disabled() & YMK_OFF_CONV_GLDS3);
     if (d->ksize == 3 && ymk_use_ws && !small64 && !(ymk_disabled() & YMK_OFF_CONV_STREAM)) {  // small-Cin stride-1 3x3: spatial-tile kernel (LDS-staged im2col)
-        const bool done = d->dtype == YMK_F32 ? launch_conv3x3_tile<float>(a, s) : launch_conv3x3_tile<bf16_t>(a, s);
+        const bool done = d->dtype == YMK_F32 ? launch_conv3x3_tile<float>(a, s) : launch_conv3x3_tile<h16_t>(a, s);
         if (done) { ymk_last_variant = YMK_CONV_SPATIAL_3X3; return ymk_launch_status(); }
     }
     if (d->ksize == 3 && d->dtype == YMK_BF16 && !(ymk_disabled() & YMK_OFF_CONV_GLDS3) && !(ymk_enabled() & YMK_ON_CONV_GLDS)) {
@@ -662,7 +662,7 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
     ymk_last_variant = YMK_CONV_TILED;
     if (d->dtype == YMK_F32)
         return d->ksize == 1 ? launch_conv<float, 1>(a, s) : launch_conv<float, 3>(a, s);
-    return d->ksize == 1 ? launch_conv<bf16_t, 1>(a, s) : launch_conv<bf16_t, 3>(a, s);
+    return d->ksize == 1 ? launch_conv<h16_t, 1>(a, s) : launch_conv<h16_t, 3>(a, s);
 }
 
 // 1x1 conv over the channel concatenation [x1 (optionally 2x nearest-upsampled) | x2] without materialising it:
@@ -696,7 +696,7 @@ extern "C" int ymk_conv1x1_cat2(const ymk_conv_desc* d, const void* x1, int32_t 
         if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = two ? 2 : 3; return rc; }
     }
     ymk_last_variant = YMK_CONV_TILED;
-    return d->dtype == YMK_F32 ? launch_conv_dual<float>(a, (hipStream_t)stream) : launch_conv_dual<bf16_t>(a, (hipStream_t)stream);
+    return d->dtype == YMK_F32 ? launch_conv_dual<float>(a, (hipStream_t)stream) : launch_conv_dual<h16_t>(a, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1041,14 +1041,14 @@ extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float*
             if (!(ymk_disabled() & YMK_OFF_STEM_ROWS)) {  // LDS-staged rows when the geometry allows
 #define YMK_STEM_R(CO)                                                                                              \
     (f ? launch_stem_rows<float, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s)         \
-       : launch_stem_rows<bf16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
+       : launch_stem_rows<h16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
                 const bool done = Cout == 16 ? YMK_STEM_R(16) : Cout == 32 ? YMK_STEM_R(32) : YMK_STEM_R(64);
 #undef YMK_STEM_R
                 if (done) return ymk_launch_status();
             }
 #define YMK_STEM_M(CO)                                                                                              \
     (f ? launch_stem_mfma<float, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s)         \
-       : launch_stem_mfma<bf16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
+       : launch_stem_mfma<h16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
             if (Cout == 16) YMK_STEM_M(16);
             else if (Cout == 32) YMK_STEM_M(32);
             else YMK_STEM_M(64);
@@ -1057,7 +1057,7 @@ extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float*
         }
 #define YMK_STEM(CO)                                                                                                \
     (f ? launch_stem_px<float, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s)           \
-       : launch_stem_px<bf16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
+       : launch_stem_px<h16_t, CO>(x, wt_kco, bias, y, B, Cin, H, W, Ho, Wo, ksize, stride, ldy, act, s))
         if (Cout == 16) YMK_STEM(16);
         else if (Cout == 32) YMK_STEM(32);
         else YMK_STEM(64);
@@ -1068,7 +1068,7 @@ extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float*
         hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(256), shm, s, x, w, bias, (float*)y, B,
                            Cin, H, W, Ho, Wo, Cout, ksize, stride, ldy, act);
     else if (out_dtype == YMK_BF16)
-        hipLaunchKernelGGL(stem_kernel<bf16_t>, dim3(blocks), dim3(256), shm, s, x, w, bias, (bf16_t*)y,
+        hipLaunchKernelGGL(stem_kernel<h16_t>, dim3(blocks), dim3(256), shm, s, x, w, bias, (h16_t*)y,
                            B, Cin, H, W, Ho, Wo, Cout, ksize, stride, ldy, act);
     else
         return YMK_E_BADARG;

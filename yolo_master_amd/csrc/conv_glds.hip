@@ -37,15 +37,15 @@ typedef void* glds_lptr;
 __device__ u32x4 ymk_glds_zero_page[8];   // 128 bytes of zeros: the source of out-of-image taps and tail rows
 
 struct GldsArgs {
-    const bf16_t* x;
-    const bf16_t* w;
+    const h16_t* x;
+    const h16_t* w;
     const float* bias;
-    const bf16_t* res;
+    const h16_t* res;
     void* y;
     int B, H, W, Ho, Wo, Cin, Cout, ks, stride, ldx, ldy, ldr, Kpad, act, out_f32;
     // virtual concatenation (1x1 only): channels [0, C1) come from x (a [B][H/2][W/2] map read through a nearest 2x upsample
     // when up1), channels [C1, Cin) from x2; x2 == nullptr: single source
-    const bf16_t* x2;
+    const h16_t* x2;
     int C1, ldx2, up1;
     // routed experts (stride 1): w holds E filter banks [E][Cout][Kpad]; image b convolves with bank eidx[b*K + j] for slot j and
     // writes image j*B + b of a slot-major output.  Tiles never straddle images.  eidx == nullptr: one filter bank.
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     const int n0 = (bid % nt) * BN;
     int m0 = (bid / nt) * BM, Mlim = M, b_img = -1;
     size_t out_base = 0;
-    const bf16_t* wbase = a.w;
+    const h16_t* wbase = a.w;
     if (a.eidx) {   // (slot, image, tile-in-image)
         const int HW = a.Ho * a.Wo, tpi = (HW + BM - 1) / BM, r = bid / nt;
         const int bj = r / tpi;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
 
     // ---- staging map: lane (lr, lc) of wave-instruction q stages chunk lc ^ (row & 7) of row q*8 + lr ----------------
     const int lr = lane >> 3, lc = lane & 7;
-    const bf16_t* wsrc[GW];
+    const h16_t* wsrc[GW];
     int poff[G - GW];         // element offset of the tap-(0,0) input pixel (+ swizzled chunk) for this lane's pixel rows
     int poff2[G - GW];        // the same pixel in the second source of a virtual concatenation
     unsigned pmask[G - GW];   // bit (ky*3+kx): tap inside the image
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
             pmask[j - GW] = mask;
         }
     }
-    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(ymk_glds_zero_page) + lc * 8;
+    const h16_t* zsrc = reinterpret_cast<const h16_t*>(ymk_glds_zero_page) + lc * 8;
     int it_tap_bit = 0, it_ky = 0, it_kx = 0, it_c = 0, it_k = 0;   // cursor of the NEXT k-step to issue (uniform)
     const int k1 = a.x2 ? a.C1 >> 6 : 0;   // k-steps served by the first source of a virtual concatenation
     auto issue = [&](int stage) {
@@ -142,16 +142,16 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             u32x4* dst = smem + stage * STAGE_U4 + (j * 8 + wave) * 64;   // wave-uniform; the lane lands at + lane * 16 B
-            const bf16_t* s;
+            const h16_t* s;
             if (j < GW) {
                 s = wsrc[j] + it_k * 64;
             } else {
                 // pixel address or the zero page, selected with mask arithmetic: written as `cond ? p : zsrc` the compiler built a
                 // divergent branch per load (ten per k-step, in a loop whose useful content is 16 MFMAs per wave)
                 const bool ok = second ? pmask[j - GW] != 0u : ((pmask[j - GW] >> it_tap_bit) & 1u) != 0u;
-                const bf16_t* p = second ? a.x2 + (poff2[j - GW] + (it_k - k1) * 64) : a.x + (poff[j - GW] + tapoff);
+                const h16_t* p = second ? a.x2 + (poff2[j - GW] + (it_k - k1) * 64) : a.x + (poff[j - GW] + tapoff);
                 const uintptr_t pa = reinterpret_cast<uintptr_t>(p), za = reinterpret_cast<uintptr_t>(zsrc);
-                s = reinterpret_cast<const bf16_t*>(za ^ ((pa ^ za) & ((uintptr_t)0 - (uintptr_t)ok)));
+                s = reinterpret_cast<const h16_t*>(za ^ ((pa ^ za) & ((uintptr_t)0 - (uintptr_t)ok)));
             }
             __builtin_amdgcn_global_load_lds((glds_gptr)s, (glds_lptr)dst, 16, 0, 0);
         }
@@ -191,8 +191,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
                     if (GLDS_ABLATE & 8) acc[i][j].x += __uint_as_float(af[i].x ^ bfr[j].y); else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(glds_bf16x8, af[i]),
-                                                                       __builtin_bit_cast(glds_bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16x16x32_h16(af[i], bfr[j], acc[i][j]);
         }
     };
 
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
                 store4(yo, v[0], v[1], v[2], v[3]);
                 store4(yo + 4, v[4], v[5], v[6], v[7]);
             } else {
-                bf16_t* yo = static_cast<bf16_t*>(a.y) + (out_base + p) * a.ldy + co;
+                h16_t* yo = static_cast<h16_t*>(a.y) + (out_base + p) * a.ldy + co;
                 if (wide) {
                     store_vec_f32(yo, v);
                 } else {
@@ -286,11 +285,11 @@ static int glds_launch_bm(const GldsArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
     const int grid = (a.eidx ? a.K * a.B * ((a.Ho * a.Wo + BM - 1) / BM) : (M + BM - 1) / BM) * (a.Cout / BN);
     const size_t lds = (size_t)STAGES * (BN + BM) * 8 * 16;
-    static bool once = false;
-    if (!once) {
+    static YmkOncePerDevice once;
+    if (once.need()) {
         if (hipFuncSetAttribute((const void*)conv_glds_kernel<BN, STAGES, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return YMK_E_LAUNCH;
-        once = true;
+        once.done();
     }
     hipLaunchKernelGGL((conv_glds_kernel<BN, STAGES, BM>), dim3(grid), dim3(512), lds, s, a);
     return ymk_launch_status();
@@ -333,8 +332,8 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
     if (d->act != YMK_ACT_NONE && d->act != YMK_ACT_SILU) return YMK_E_BADARG;
     const int pad = d->ksize / 2;
     GldsArgs a;
-    a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(w); a.bias = bias;
-    a.res = static_cast<const bf16_t*>(residual); a.y = y;
+    a.x = static_cast<const h16_t*>(x); a.w = static_cast<const h16_t*>(w); a.bias = bias;
+    a.res = static_cast<const h16_t*>(residual); a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = d->ksize; a.stride = d->stride;
     a.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
     a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
@@ -359,10 +358,10 @@ extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int
     if (d->Kpad != d->Cin || (d->act != YMK_ACT_NONE && d->act != YMK_ACT_SILU)) return YMK_E_BADARG;
     if (upsample1 && ((d->H & 1) || (d->W & 1))) return YMK_E_BADARG;
     GldsArgs a;
-    a.x = static_cast<const bf16_t*>(x1); a.w = static_cast<const bf16_t*>(w); a.bias = bias; a.res = nullptr; a.y = y;
+    a.x = static_cast<const h16_t*>(x1); a.w = static_cast<const h16_t*>(w); a.bias = bias; a.res = nullptr; a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = 1; a.stride = 1;
     a.ldx = ldx1; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = d->act; a.out_f32 = 0;
-    a.x2 = static_cast<const bf16_t*>(x2); a.C1 = C1; a.ldx2 = ldx2; a.up1 = upsample1 ? 1 : 0; a.eidx = nullptr; a.K = 0;
+    a.x2 = static_cast<const h16_t*>(x2); a.C1 = C1; a.ldx2 = ldx2; a.up1 = upsample1 ? 1 : 0; a.eidx = nullptr; a.K = 0;
     const int64_t M = (int64_t)a.B * a.H * a.W;
     if (M <= 0) return YMK_OK;
     if (M >= (1ll << 31) || (M + 2) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
@@ -382,7 +381,7 @@ extern "C" int ymk_expert_conv_glds(const ymk_conv_desc* d, const void* x, const
         d->act != YMK_ACT_NONE)
         return YMK_E_BADARG;
     GldsArgs a;
-    a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(w); a.bias = nullptr; a.res = nullptr; a.y = y;
+    a.x = static_cast<const h16_t*>(x); a.w = static_cast<const h16_t*>(w); a.bias = nullptr; a.res = nullptr; a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = d->ksize; a.stride = 1;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = YMK_ACT_NONE; a.out_f32 = 0;
     a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = idx; a.K = K;

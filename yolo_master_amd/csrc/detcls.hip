@@ -30,18 +30,18 @@
 
 typedef __bf16 dc_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void dc_mma(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dc_bf16x8, a), __builtin_bit_cast(dc_bf16x8, b), acc, 0, 0, 0);
+    acc = mfma16x16x32_h16(a, b, acc);
 }
 __device__ __forceinline__ u32x2 dc_pack_silu(const f32x4& v) {
     u32x2 o;
-    o.x = pack_bf16x2(silu_f(v.x), silu_f(v.y));
-    o.y = pack_bf16x2(silu_f(v.z), silu_f(v.w));
+    o.x = pack_h16x2(silu_f(v.x), silu_f(v.y));
+    o.y = pack_h16x2(silu_f(v.z), silu_f(v.w));
     return o;
 }
 
 struct DetClsArgs {
-    const bf16_t* x;                         // [B][H][W][ldx], CIN channels
-    const bf16_t *dw1, *pw1, *dw2, *pw2, *w3;   // dw: [9][C]; pw1 [128][k1pad]; pw2 [128][k2pad]; w3 [ncpad][k3pad]
+    const h16_t* x;                         // [B][H][W][ldx], CIN channels
+    const h16_t *dw1, *pw1, *dw2, *pw2, *w3;   // dw: [9][C]; pw1 [128][k1pad]; pw2 [128][k2pad]; w3 [ncpad][k3pad]
     const float *bd1, *bp1, *bd2, *bp2, *b3;
     float* y;                                // [B][H][W][ldy] fp32 logits (ncpad channels written)
     int B, H, W, ldx, ldy, k1pad, k2pad, k3pad, ncpad, tiles_x, tiles_y;
@@ -50,13 +50,13 @@ struct DetClsArgs {
 // 3x3 depthwise stencil + bias + SiLU for this thread's 4 channels: output pixels s, s + 16, ... < npix of an (orow x ocol) map read
 // from an input tile of row length icol whose origin is one pixel up / left of the output map's
 template <int CTOT>
-__device__ __forceinline__ void dc_dw3(const char* in, int icol, char* out, int npix, int ocol, const bf16_t* w, int coff, const float* bias,
+__device__ __forceinline__ void dc_dw3(const char* in, int icol, char* out, int npix, int ocol, const h16_t* w, int coff, const float* bias,
                                        int cg, int s) {
     float wt[9][4];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const u32x2 q = *reinterpret_cast<const u32x2*>(w + (size_t)tap * CTOT + coff + cg * 4);
-        wt[tap][0] = bf16lo(q.x); wt[tap][1] = bf16hi(q.x); wt[tap][2] = bf16lo(q.y); wt[tap][3] = bf16hi(q.y);
+        wt[tap][0] = h16lo(q.x); wt[tap][1] = h16hi(q.x); wt[tap][2] = h16lo(q.y); wt[tap][3] = h16hi(q.y);
     }
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + coff + cg * 4);
     for (int p = s; p < npix; p += DC_NT / 32) {
@@ -66,10 +66,10 @@ __device__ __forceinline__ void dc_dw3(const char* in, int icol, char* out, int 
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const u32x2 q = *reinterpret_cast<const u32x2*>(in + ((u + ky) * icol + v + kx) * DC_PITCH + cg * 8);
-            acc.x = __builtin_fmaf(bf16lo(q.x), wt[tap][0], acc.x);
-            acc.y = __builtin_fmaf(bf16hi(q.x), wt[tap][1], acc.y);
-            acc.z = __builtin_fmaf(bf16lo(q.y), wt[tap][2], acc.z);
-            acc.w = __builtin_fmaf(bf16hi(q.y), wt[tap][3], acc.w);
+            acc.x = __builtin_fmaf(h16lo(q.x), wt[tap][0], acc.x);
+            acc.y = __builtin_fmaf(h16hi(q.x), wt[tap][1], acc.y);
+            acc.z = __builtin_fmaf(h16lo(q.y), wt[tap][2], acc.z);
+            acc.w = __builtin_fmaf(h16hi(q.y), wt[tap][3], acc.w);
         }
         *reinterpret_cast<u32x2*>(out + p * DC_PITCH + cg * 8) = dc_pack_silu(acc);
     }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
         const int txi = tile % a.tiles_x, r0 = tile / a.tiles_x;
         const int tyi = r0 % a.tiles_y, b = r0 / a.tiles_y;
         const int oy0 = tyi * DC_TH, ox0 = txi * DC_TW;
-        const bf16_t* xb = a.x + (size_t)b * a.H * a.W * a.ldx;
+        const h16_t* xb = a.x + (size_t)b * a.H * a.W * a.ldx;
 
         f32x4 acc1[NF1];
 #pragma unroll
@@ -211,8 +211,8 @@ extern "C" int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return YMK_E_BADARG;
     if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
     DetClsArgs a;
-    a.x = (const bf16_t*)x; a.dw1 = (const bf16_t*)dw1; a.pw1 = (const bf16_t*)pw1; a.dw2 = (const bf16_t*)dw2; a.pw2 = (const bf16_t*)pw2;
-    a.w3 = (const bf16_t*)w3; a.bd1 = bd1; a.bp1 = bp1; a.bd2 = bd2; a.bp2 = bp2; a.b3 = b3; a.y = y;
+    a.x = (const h16_t*)x; a.dw1 = (const h16_t*)dw1; a.pw1 = (const h16_t*)pw1; a.dw2 = (const h16_t*)dw2; a.pw2 = (const h16_t*)pw2;
+    a.w3 = (const h16_t*)w3; a.bd1 = bd1; a.bp1 = bp1; a.bd2 = bd2; a.bp2 = bp2; a.b3 = b3; a.y = y;
     a.B = B; a.H = H; a.W = W; a.ldx = ldx; a.ldy = ldy; a.k1pad = k1pad; a.k2pad = k2pad; a.k3pad = k3pad; a.ncpad = ncpad;
     a.tiles_x = (W + DC_TW - 1) / DC_TW; a.tiles_y = (H + DC_TH - 1) / DC_TH;
     const int64_t ntile = (int64_t)B * a.tiles_x * a.tiles_y;
@@ -222,11 +222,11 @@ extern "C" int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32
 #else
     const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);   // one persistent workgroup per CU (121 KB of LDS)
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
+    static YmkOncePerDevice attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
-        attr_set = true;
+        attr_once.done();
     }
     if (cin == 128) hipLaunchKernelGGL(detect_cls_kernel<128>, dim3(grid), dim3(DC_NT), DC_LDS_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(detect_cls_kernel<256>, dim3(grid), dim3(DC_NT), DC_LDS_BYTES, (hipStream_t)stream, a);

@@ -70,17 +70,16 @@ struct DwTile {
 // lds_ld4 returns channels as two register pairs: fp32 (c0,c1),(c2,c3); bf16 (c0,c2),(c1,c3).
 template <typename T> struct DwPair;  // position of channel j (0..3) inside the (a.x, a.y, b.x, b.y) quadruple
 template <> struct DwPair<float> { static constexpr int pos[4] = {0, 1, 2, 3}; };
-template <> struct DwPair<bf16_t> { static constexpr int pos[4] = {0, 2, 1, 3}; };
+template <> struct DwPair<h16_t> { static constexpr int pos[4] = {0, 2, 1, 3}; };
 __device__ __forceinline__ void lds_ld4(const char* p, f32x2& a, f32x2& b, float) {
     const f32x4 t = *reinterpret_cast<const f32x4*>(p);
     a = f32x2{t.x, t.y}; b = f32x2{t.z, t.w};
 }
 // bf16: the two packed words (c0,c1),(c2,c3) are widened with VECTOR shifts/masks so that the results land in
 // register pairs directly: a = (c0, c2), b = (c1, c3) (channel pairing differs from fp32: see DwPair)
-__device__ __forceinline__ void lds_ld4(const char* p, f32x2& a, f32x2& b, bf16_t) {
+__device__ __forceinline__ void lds_ld4(const char* p, f32x2& a, f32x2& b, h16_t) {
     const u32x2 t = *reinterpret_cast<const u32x2*>(p);
-    a = __builtin_bit_cast(f32x2, t << 16);
-    b = __builtin_bit_cast(f32x2, t & 0xffff0000u);
+    h16x4_widen(t, a, b);
 }
 
 // consecutive logical workgroups (the channel blocks of one run of tiles, then the next run) execute on the same
@@ -187,8 +186,7 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
             for (int kx = 0; kx < K; ++kx) {
                 if constexpr (sizeof(T) == 2) {
                     const u32x2 t2 = *reinterpret_cast<const u32x2*>(wsb + (ky * K + kx) * D::CB + cg * 4);
-                    wr[kx][0] = __builtin_bit_cast(f32x2, t2 << 16);
-                    wr[kx][1] = __builtin_bit_cast(f32x2, t2 & 0xffff0000u);
+                    h16x4_widen(t2, wr[kx][0], wr[kx][1]);
                 } else {
                     const f32x4 t4 = *reinterpret_cast<const f32x4*>(wsm + (ky * K + kx) * D::CB + cg * 4);
                     wr[kx][0] = f32x2{t4.x, t4.y}; wr[kx][1] = f32x2{t4.z, t4.w};
@@ -280,11 +278,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
 template <typename T, int K, int TW>
 static void launch_dw_k(const DwArgs& a, int nrun, hipStream_t s) {
     const size_t shm = DwTile<T, TW>::lds_bytes(K);
-    static bool attr_set = false;
-    if (!attr_set && shm > 64 * 1024) {
+    static YmkOncePerDevice attr_once;
+    if (attr_once.need() && shm > 64 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_kernel<T, K, TW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set = true;
+        attr_once.done();
     }
     hipLaunchKernelGGL((dwconv_kernel<T, K, TW>), dim3(nrun * a.ncb, a.B), dim3(256), shm, s, a);
 }
@@ -325,7 +323,7 @@ extern "C" int ymk_dwconv2d(int32_t dtype, const void* x, const void* w, const f
     if (!x || !w || !y || ldx % vec || ldy % 4 || (residual && ldr % 4)) return YMK_E_BADARG;
     DwArgs a{x, w, bias, residual, y, B, H, W, C, ldx, ldy, ldr, act, 0, 0, 0};
     if (dtype == YMK_F32) return launch_dw<float>(a, ksize, (hipStream_t)stream);
-    if (dtype == YMK_BF16) return launch_dw<bf16_t>(a, ksize, (hipStream_t)stream);
+    if (dtype == YMK_BF16) return launch_dw<h16_t>(a, ksize, (hipStream_t)stream);
     return YMK_E_BADARG;
 }
 
@@ -378,11 +376,11 @@ __global__ __launch_bounds__(256) void moe_dw_kernel(MoeDwArgs a) {
 template <typename T, int TW, int KMAX>
 static int launch_moe_dw_k(MoeDwArgs a, hipStream_t s) {
     const size_t shm = DwTile<T, TW>::lds_bytes(KMAX);
-    static bool attr_set = false;
-    if (shm > 64 * 1024 && !attr_set) {
+    static YmkOncePerDevice attr_once;
+    if (shm > 64 * 1024 && attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_dw_kernel<T, TW, KMAX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set = true;
+        attr_once.done();
     }
     const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, (int64_t)a.B * a.top_k, DwTile<T, TW>::resident(KMAX) < 4);
     a.ncb = g.ncb; a.nsp = g.nsp; a.spt = g.spt;
@@ -420,6 +418,6 @@ extern "C" int ymk_esmoe_dw(int32_t dtype, const void* x, int32_t B, int32_t H, 
     if ((int64_t)B * top_k > 65535) return YMK_E_BADARG;
     MoeDwArgs a{x, dw_w, dw_off, ksizes, sel, dw_out, B, H, W, C, ldx, E, top_k, 0, 0, 0};
     if (dtype == YMK_F32) return launch_moe_dw<float>(a, kmax, (hipStream_t)stream);
-    if (dtype == YMK_BF16) return launch_moe_dw<bf16_t>(a, kmax, (hipStream_t)stream);
+    if (dtype == YMK_BF16) return launch_moe_dw<h16_t>(a, kmax, (hipStream_t)stream);
     return YMK_E_BADARG;
 }

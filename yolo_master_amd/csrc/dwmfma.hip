@@ -58,18 +58,18 @@ extern "C" size_t ymk_dw_toeplitz_elems(int32_t C, int32_t k) {
 
 // fragment (c, ky), lane l = (m = l & 15, j = l >> 4), element i: A[m][kk = 8j + i] = w[ky][kx = kk - 8 - m + pad][c]
 // (LDS column kk of an M tile is image column x_tile - 8 + kk; output column m is x_tile + m)
-__global__ __launch_bounds__(256) void dw_toeplitz_pack_kernel(const bf16_t* __restrict__ w, int C, int k,
-                                                              bf16_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void dw_toeplitz_pack_kernel(const h16_t* __restrict__ w, int C, int k,
+                                                              h16_t* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)C * k * 64) return;
     const int lane = (int)(idx & 63);
     const int ky = (int)((idx >> 6) % k), c = (int)((idx >> 6) / k);
     const int m = lane & 15, j = lane >> 4, pad = k / 2;
-    bf16_t v[8];
+    h16_t v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int kx = 8 * j + i - 8 - m + pad;
-        v[i] = (kx >= 0 && kx < k) ? w[(size_t)(ky * k + kx) * C + c] : (bf16_t)0;
+        v[i] = (kx >= 0 && kx < k) ? w[(size_t)(ky * k + kx) * C + c] : (h16_t)0;
     }
     u32x4 o;
     o.x = v[0] | ((uint32_t)v[1] << 16); o.y = v[2] | ((uint32_t)v[3] << 16);
@@ -81,19 +81,19 @@ extern "C" int ymk_dw_toeplitz_pack(const void* w_packed, int32_t C, int32_t k, 
     if (!w_packed || !out || ymk_dw_toeplitz_elems(C, k) == 0) return YMK_E_BADARG;
     const int64_t n = (int64_t)C * k * 64;
     hipLaunchKernelGGL(dw_toeplitz_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)w_packed, C, k, (bf16_t*)out);
+                       (const h16_t*)w_packed, C, k, (h16_t*)out);
     return ymk_launch_status();
 }
 
 struct DwmArgs {
-    const bf16_t* x;
-    const bf16_t* toep;      // Toeplitz fragments: expert-major, then [c][ky][64 lanes][8]
+    const h16_t* x;
+    const h16_t* toep;      // Toeplitz fragments: expert-major, then [c][ky][64 lanes][8]
     const int* ksizes;       // [E] (device) or null: single filter of size k_single
     const int* csr_off;      // [E+1] (device) or null: every image once
     const int* csr_pair;     // [..] pair = b * top_k + slot
-    bf16_t* out;
+    h16_t* out;
     const float* bias;       // [C] or null
-    const bf16_t* res;       // residual view or null
+    const h16_t* res;       // residual view or null
     int B, H, W, C, ldx, ldo, ldr, act, E, top_k, tiles_x, tiles_y, k_single, G;
 };
 
@@ -124,7 +124,7 @@ static inline uint32_t dwm_perm(uint32_t s0, uint32_t s1, uint32_t sel) {   // v
 // operations per memory instruction — the first version recomputed its 64-bit addresses per item and was VALU-bound at
 // 24 VALU instructions per MFMA (profiles/r02_dwmfma_v1_pmc.txt).
 template <int K>
-__device__ __forceinline__ void dwm_segment(const DwmArgs& a, const bf16_t* __restrict__ toep_e, int csr_base, int i0,
+__device__ __forceinline__ void dwm_segment(const DwmArgs& a, const h16_t* __restrict__ toep_e, int csr_base, int i0,
                                             int i1, int chunk, char* smem) {
     constexpr int P = K / 2, R = DWM_TH + K - 1;
     constexpr int NMT = K >= 7 ? 1 : 2, TW = 16 * NMT, PAIRS = (TW + 16) / 2;
@@ -256,8 +256,7 @@ __device__ __forceinline__ void dwm_segment(const DwmArgs& a, const bf16_t* __re
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
                     const u32x4 bf = *reinterpret_cast<const u32x4*>(bp + cc * DWM_PLANE + ky * DWM_PITCH + mt * 32);
-                    acc[cc][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dwm_bf16x8, A[cc][ky]),
-                                                                          __builtin_bit_cast(dwm_bf16x8, bf), acc[cc][mt], 0, 0, 0);
+                    acc[cc][mt] = mfma16x16x32_h16(A[cc][ky], bf, acc[cc][mt]);
                 }
 
         // ---- epilogue, stage 1: lane (n, j) holds output columns 16 mt + 4 j + i of row n for its 4 channels: bias / SiLU in
@@ -291,11 +290,11 @@ __device__ __forceinline__ void dwm_segment(const DwmArgs& a, const bf16_t* __re
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                     if (rb) {
                         float r[8];
-                        load_vec_f32(reinterpret_cast<const bf16_t*>(rb + roff + it * 8 * ldr * 2), r);
+                        load_vec_f32(reinterpret_cast<const h16_t*>(rb + roff + it * 8 * ldr * 2), r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r[e];
                     }
-                    if (!(DWM_ABLATE & 8) || v[0] == 1234.5f) store_vec_f32(reinterpret_cast<bf16_t*>(ob + ooff + it * 8 * ldo * 2), v);
+                    if (!(DWM_ABLATE & 8) || v[0] == 1234.5f) store_vec_f32(reinterpret_cast<h16_t*>(ob + ooff + it * 8 * ldo * 2), v);
                 }
             }
         }
@@ -373,7 +372,7 @@ extern "C" int ymk_dwconv2d_mfma(const void* x, const void* toep, const float* b
                                  int32_t ldr, int32_t act, void* stream) {
     if (!x || !toep || !y || !ymk_dw_mfma_supported(YMK_BF16, C, ksize)) return YMK_E_BADARG;
     if (act != YMK_ACT_NONE && act != YMK_ACT_SILU) return YMK_E_BADARG;
-    DwmArgs a{(const bf16_t*)x, (const bf16_t*)toep, nullptr, nullptr, nullptr, (bf16_t*)y, bias, (const bf16_t*)residual,
+    DwmArgs a{(const h16_t*)x, (const h16_t*)toep, nullptr, nullptr, nullptr, (h16_t*)y, bias, (const h16_t*)residual,
               B, H, W, C, ldx, ldy, ldr, act, 1, 1, 0, 0, ksize, 1};
     return dwm_launch(a, B, 1 << (ksize / 2), (hipStream_t)stream);
 }
@@ -383,7 +382,7 @@ extern "C" int ymk_esmoe_dw_mfma(const void* x, int32_t B, int32_t H, int32_t W,
                                  const int32_t* csr_pair, void* dw_out, void* stream) {
     if (!x || !toep || !ksizes || !csr_off || !csr_pair || !dw_out || E < 1 || E > 16 || top_k < 1) return YMK_E_BADARG;
     if (kmask <= 0 || (kmask & ~30)) return YMK_E_BADARG;   // filter sizes 3, 5, 7, 9 only
-    DwmArgs a{(const bf16_t*)x, (const bf16_t*)toep, ksizes, csr_off, csr_pair, (bf16_t*)dw_out, nullptr, nullptr,
+    DwmArgs a{(const h16_t*)x, (const h16_t*)toep, ksizes, csr_off, csr_pair, (h16_t*)dw_out, nullptr, nullptr,
               B, H, W, C, ldx, C, 0, YMK_ACT_NONE, E, top_k, 0, 0, 0, 1};
     return dwm_launch(a, (int64_t)B * top_k, kmask, (hipStream_t)stream);
 }

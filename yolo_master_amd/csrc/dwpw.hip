@@ -53,14 +53,15 @@ __device__ __forceinline__ void fp_ld4(const char* p, fp_f32x2& a, fp_f32x2& b, 
     const f32x4 t = *reinterpret_cast<const f32x4*>(p);
     a = fp_f32x2{t.x, t.y}; b = fp_f32x2{t.z, t.w};
 }
-__device__ __forceinline__ void fp_ld4(const char* p, fp_f32x2& a, fp_f32x2& b, bf16_t) {  // (c0,c2),(c1,c3)
+__device__ __forceinline__ void fp_ld4(const char* p, fp_f32x2& a, fp_f32x2& b, h16_t) {  // (c0,c2),(c1,c3)
     const u32x2 t = *reinterpret_cast<const u32x2*>(p);
-    a = __builtin_bit_cast(fp_f32x2, t << 16);
-    b = __builtin_bit_cast(fp_f32x2, t & 0xffff0000u);
+    f32x2 a2, b2;
+    h16x4_widen(t, a2, b2);
+    a = fp_f32x2{a2.x, a2.y}; b = fp_f32x2{b2.x, b2.y};
 }
 template <typename T> struct FpPair;
 template <> struct FpPair<float> { static constexpr int pos[4] = {0, 1, 2, 3}; };
-template <> struct FpPair<bf16_t> { static constexpr int pos[4] = {0, 2, 1, 3}; };
+template <> struct FpPair<h16_t> { static constexpr int pos[4] = {0, 2, 1, 3}; };
 
 // byte offset of element (px, c) inside the swizzled [128][C] GEMM operand tile
 template <typename T>
@@ -297,7 +298,7 @@ static int launch_dwpw(DwPwArgs a, hipStream_t s) {
 
 extern "C" int ymk_dwpw_supported(int32_t dtype, int32_t C, int32_t kmax) {
     if (kmax < 3 || kmax > 9 || (kmax & 1) == 0) return 0;
-    if (dtype == YMK_BF16) return C % 64 == 0 && FpGeo<bf16_t>::lds_bytes(C, kmax) <= 160 * 1024;
+    if (dtype == YMK_BF16) return C % 64 == 0 && FpGeo<h16_t>::lds_bytes(C, kmax) <= 160 * 1024;
     if (dtype == YMK_F32) return C % 32 == 0 && FpGeo<float>::lds_bytes(C, kmax) <= 160 * 1024;
     return 0;
 }
@@ -312,7 +313,7 @@ extern "C" int ymk_esmoe_experts_fused(int32_t dtype, const void* x, int32_t B, 
     DwPwArgs a{x, dw_w, dw_off, ksizes, nullptr, pw_w, pw_b, norm_scale, norm_shift, sel, gate_w, y,
                B, H, W, C, Cout, Kpad, E, top_k, 0, YMK_ACT_NONE, YMK_ACT_SILU, ldx, ldy, 0, 0, kmax};
     if (dtype == YMK_F32) return launch_dwpw<float>(a, (hipStream_t)stream);
-    if (dtype == YMK_BF16) return launch_dwpw<bf16_t>(a, (hipStream_t)stream);
+    if (dtype == YMK_BF16) return launch_dwpw<h16_t>(a, (hipStream_t)stream);
     return YMK_E_BADARG;
 }
 
@@ -324,6 +325,6 @@ extern "C" int ymk_dwconv_pwconv(int32_t dtype, const void* x, int32_t B, int32_
     DwPwArgs a{x, dw_w, nullptr, nullptr, dw_bias, pw_w, pw_b, nullptr, nullptr, nullptr, nullptr, y,
                B, H, W, C, Cout, Kpad, 1, 1, ksize, dw_act, pw_act, ldx, ldy, 0, 0, ksize};
     if (dtype == YMK_F32) return launch_dwpw<float>(a, (hipStream_t)stream);
-    if (dtype == YMK_BF16) return launch_dwpw<bf16_t>(a, (hipStream_t)stream);
+    if (dtype == YMK_BF16) return launch_dwpw<h16_t>(a, (hipStream_t)stream);
     return YMK_E_BADARG;
 }

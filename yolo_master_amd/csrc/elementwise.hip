@@ -33,8 +33,8 @@ extern "C" int ymk_upsample2x(int32_t dtype, const void* x, void* y, int32_t B, 
         hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
                            (float*)y, B, H, W, C, ldx, ldy);
     else
-        hipLaunchKernelGGL(upsample2x_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ldx, ldy);
+        hipLaunchKernelGGL(upsample2x_kernel<h16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const h16_t*)x, (h16_t*)y, B, H, W, C, ldx, ldy);
     return ymk_launch_status();
 }
 
@@ -63,8 +63,8 @@ extern "C" int ymk_copy_channels(int32_t dtype, const void* x, void* y, int64_t 
         hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, (float*)y, npix, C, ldx, ldy);
     else
-        hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (bf16_t*)y, npix, C, ldx, ldy);
+        hipLaunchKernelGGL(copy_channels_kernel<h16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const h16_t*)x, (h16_t*)y, npix, C, ldx, ldy);
     return ymk_launch_status();
 }
 
@@ -105,8 +105,8 @@ extern "C" int ymk_scale_residual(int32_t dtype, const void* y, const float* gam
         hipLaunchKernelGGL(scale_residual_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)y,
                            gamma, (const float*)residual, (float*)out, npix, C, ldy, ldr, ldo);
     else
-        hipLaunchKernelGGL(scale_residual_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
-                           gamma, (const bf16_t*)residual, (bf16_t*)out, npix, C, ldy, ldr, ldo);
+        hipLaunchKernelGGL(scale_residual_kernel<h16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const h16_t*)y,
+                           gamma, (const h16_t*)residual, (h16_t*)out, npix, C, ldy, ldr, ldo);
     return ymk_launch_status();
 }
 
@@ -138,7 +138,7 @@ extern "C" int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int3
     if (dtype == YMK_F32)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)x, y, HW, C, ldx);
     else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)x, y, HW, C,
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<h16_t>, grid, blk, 0, (hipStream_t)stream, (const h16_t*)x, y, HW, C,
                            ldx);
     return ymk_launch_status();
 }

@@ -286,7 +286,7 @@ extern "C" int ymk_esmoe_route(int32_t dtype, const void* x, int32_t B, int32_t 
     if (dtype == YMK_F32)
         hipLaunchKernelGGL(gap_partial_kernel<float>, g1, blk, 0, s, (const float*)x, HW, C, ldx, cpix, part, flags);
     else if (dtype == YMK_BF16)
-        hipLaunchKernelGGL(gap_partial_kernel<bf16_t>, g1, blk, 0, s, (const bf16_t*)x, HW, C, ldx, cpix, part, flags);
+        hipLaunchKernelGGL(gap_partial_kernel<h16_t>, g1, blk, 0, s, (const h16_t*)x, HW, C, ldx, cpix, part, flags);
     else
         return YMK_E_BADARG;
     const size_t shm = (size_t)(C + hidden + E + E * hidden) * sizeof(float);
@@ -653,7 +653,7 @@ __device__ __forceinline__ void pwl_store8(float* p, const float (&v)[8]) {
     store4(p, v[0], v[1], v[2], v[3]);
     store4(p + 4, v[4], v[5], v[6], v[7]);
 }
-__device__ __forceinline__ void pwl_store8(bf16_t* p, const float (&v)[8]) { store_vec_f32(p, v); }
+__device__ __forceinline__ void pwl_store8(h16_t* p, const float (&v)[8]) { store_vec_f32(p, v); }
 #define PWL_MAXSTEP 512
 #define PWL_MAXE 8
 __host__ __device__ constexpr int pwl_slots(int kg) { return kg == 1 ? 4 : kg == 2 ? 2 : 1; }
@@ -937,13 +937,13 @@ static bool launch_pw_lean(MoePwArgs a, hipStream_t s) {
     if (ceil_div64((int64_t)a.B * a.top_k * a.tiles, nblk) + a.top_k > PWL_MAXSTEP) return false;
     dim3 grid((unsigned)(nblk * ncot)), blk(512);
     auto lds = [](int g) { return (size_t)(pwl_slots(g) + 1) * 128 * pwl_pitch(g) * sizeof(u32x4); };
-    static bool attr_set = false;
-    if (!attr_set) {
+    static YmkOncePerDevice attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_pw_lean_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(1));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_pw_lean_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(2));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_pw_lean_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(3));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_pw_lean_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(4));
-        attr_set = true;
+        attr_once.done();
     }
     switch (kg) {
         case 1: hipLaunchKernelGGL((moe_pw_lean_kernel<T, 1>), grid, blk, lds(1), s, a); break;
@@ -1008,5 +1008,5 @@ extern "C" int ymk_esmoe_pw(int32_t dtype, const void* dw_out, int32_t B, int32_
     if (C % vec || Cout % 4 || ldy % 4 || Kpad % 64 || Kpad < C || Cout > 32 * 1024) return YMK_E_BADARG;
     if (B <= 0 || H * W <= 0) return YMK_OK;
     MoePwArgs a{dw_out, pw_w, pw_b, norm_scale, norm_shift, sel, gate_w, y, B, H * W, C, Cout, Kpad, E, top_k, ldy, 0};
-    return dtype == YMK_F32 ? launch_pw<float>(a, (hipStream_t)stream) : launch_pw<bf16_t>(a, (hipStream_t)stream);
+    return dtype == YMK_F32 ? launch_pw<float>(a, (hipStream_t)stream) : launch_pw<h16_t>(a, (hipStream_t)stream);
 }

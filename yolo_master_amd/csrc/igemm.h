@@ -24,9 +24,8 @@ template <typename T>
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
 
 template <>
-__device__ __forceinline__ void mma16<bf16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                  __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+__device__ __forceinline__ void mma16<h16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = mfma16x16x32_h16(a, b, acc);   // v_mfma_f32_16x16x32_bf16 / _f16 by the build's 16-bit format
 }
 template <>
 __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u32x4& b) {

@@ -8,10 +8,10 @@
 namespace {
 
 __device__ __forceinline__ float ldv(const void* p, int dt, int64_t i) {
-    return dt == YMK_BF16 ? bf16_to_f32(static_cast<const bf16_t*>(p)[i]) : static_cast<const float*>(p)[i];
+    return dt == YMK_BF16 ? h16_to_f32(static_cast<const h16_t*>(p)[i]) : static_cast<const float*>(p)[i];
 }
 __device__ __forceinline__ void stv(void* p, int dt, int64_t i, float v) {
-    if (dt == YMK_BF16) static_cast<bf16_t*>(p)[i] = f32_to_bf16(v);
+    if (dt == YMK_BF16) static_cast<h16_t*>(p)[i] = f32_to_h16(v);
     else static_cast<float*>(p)[i] = v;
 }
 inline bool bad_dt(int dt) { return dt != YMK_F32 && dt != YMK_BF16; }

@@ -8,10 +8,10 @@
 namespace {
 
 __device__ __forceinline__ float ldv(const void* p, int dt, int64_t i) {
-    return dt == YMK_BF16 ? bf16_to_f32(static_cast<const bf16_t*>(p)[i]) : static_cast<const float*>(p)[i];
+    return dt == YMK_BF16 ? h16_to_f32(static_cast<const h16_t*>(p)[i]) : static_cast<const float*>(p)[i];
 }
 __device__ __forceinline__ void stv(void* p, int dt, int64_t i, float v) {
-    if (dt == YMK_BF16) static_cast<bf16_t*>(p)[i] = f32_to_bf16(v);
+    if (dt == YMK_BF16) static_cast<h16_t*>(p)[i] = f32_to_h16(v);
     else static_cast<float*>(p)[i] = v;
 }
 __device__ __forceinline__ float act_f(float v, int act) {
@@ -739,7 +739,7 @@ extern "C" int ymk_activation(int32_t dtype, void* x, int32_t ldx, int64_t npix,
     if (npix <= 0 || act == YMK_ACT_NONE) return YMK_OK;
     const int V = vecw(dtype);
     if (C % V == 0 && ldx % V == 0 && al16(x)) {
-        if (dtype == YMK_BF16) LAUNCH(activation_vec_kernel<bf16_t>, npix * (C / V), (bf16_t*)x, ldx, npix, C, act);
+        if (dtype == YMK_BF16) LAUNCH(activation_vec_kernel<h16_t>, npix * (C / V), (h16_t*)x, ldx, npix, C, act);
         else LAUNCH(activation_vec_kernel<float>, npix * (C / V), (float*)x, ldx, npix, C, act);
         return ymk_launch_status();
     }
@@ -760,7 +760,7 @@ extern "C" int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y
     const bool vin = C % V == 0 && ldx % V == 0 && al16(x);
     if (vin && (C / groups) % V == 0) {   // statistics: whole vectors inside a group
         if (dtype == YMK_BF16)
-            hipLaunchKernelGGL(gn_stats_vec_kernel<bf16_t>, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, HW, C, groups, eps, stats_ws);
+            hipLaunchKernelGGL(gn_stats_vec_kernel<h16_t>, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, HW, C, groups, eps, stats_ws);
         else
             hipLaunchKernelGGL(gn_stats_vec_kernel<float>, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, HW, C, groups, eps, stats_ws);
     } else {
@@ -769,7 +769,7 @@ extern "C" int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y
     if (vin && out_dtype == dtype && ldy % V == 0 && al16(y) && (!residual || (ldr % V == 0 && al16(residual)))) {
         const int64_t total = (int64_t)B * HW * (C / V);
         if (dtype == YMK_BF16)
-            LAUNCH(gn_apply_vec_kernel<bf16_t>, total, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (const bf16_t*)residual, ldr, B, HW, C, groups, weight,
+            LAUNCH(gn_apply_vec_kernel<h16_t>, total, (const h16_t*)x, ldx, (h16_t*)y, ldy, (const h16_t*)residual, ldr, B, HW, C, groups, weight,
                    bias, affine_rows, act, (const float*)stats_ws);
         else
             LAUNCH(gn_apply_vec_kernel<float>, total, (const float*)x, ldx, (float*)y, ldy, (const float*)residual, ldr, B, HW, C, groups, weight,
@@ -787,7 +787,7 @@ extern "C" int ymk_layer_norm(int32_t dtype, const void* x, int32_t ldx, void* y
     if (npix <= 0) return YMK_OK;
     const int V = vecw(dtype);
     if (C % V == 0 && ldx % V == 0 && ldy % V == 0 && al16(x) && al16(y)) {
-        if (dtype == YMK_BF16) LAUNCH(ln_vec_kernel<bf16_t>, npix * 64, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, npix, C, weight, bias, eps);
+        if (dtype == YMK_BF16) LAUNCH(ln_vec_kernel<h16_t>, npix * 64, (const h16_t*)x, ldx, (h16_t*)y, ldy, npix, C, weight, bias, eps);
         else LAUNCH(ln_vec_kernel<float>, npix * 64, (const float*)x, ldx, (float*)y, ldy, npix, C, weight, bias, eps);
         return ymk_launch_status();
     }
@@ -802,7 +802,7 @@ extern "C" int ymk_eltwise(int32_t op, int32_t dtype, const void* a, int32_t lda
     if (npix <= 0) return YMK_OK;
     const int V = vecw(dtype);
     if (C % V == 0 && lda % V == 0 && ldb % V == 0 && ldy % V == 0 && al16(a) && al16(b) && al16(y)) {
-        if (dtype == YMK_BF16) LAUNCH(eltwise_vec_kernel<bf16_t>, npix * (C / V), op, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)y, ldy, npix, C, alpha);
+        if (dtype == YMK_BF16) LAUNCH(eltwise_vec_kernel<h16_t>, npix * (C / V), op, (const h16_t*)a, lda, (const h16_t*)b, ldb, (h16_t*)y, ldy, npix, C, alpha);
         else LAUNCH(eltwise_vec_kernel<float>, npix * (C / V), op, (const float*)a, lda, (const float*)b, ldb, (float*)y, ldy, npix, C, alpha);
         return ymk_launch_status();
     }
@@ -821,8 +821,8 @@ extern "C" int ymk_fma_gate(int32_t dtype, const void* x, int32_t ldx, const voi
         (b_per_image || (b_dtype == dtype && ldb % V == 0 && al16(b)))) {
         const int64_t total = (int64_t)B * HW * (C / V);
         if (dtype == YMK_BF16)
-            LAUNCH(gate_vec_kernel<bf16_t>, total, (const bf16_t*)x, ldx, (const bf16_t*)a, lda, b_per_image ? nullptr : (const bf16_t*)b, ldb,
-                   b_per_image ? (const float*)b : nullptr, scale, (bf16_t*)y, ldy, B, HW, C);
+            LAUNCH(gate_vec_kernel<h16_t>, total, (const h16_t*)x, ldx, (const h16_t*)a, lda, b_per_image ? nullptr : (const h16_t*)b, ldb,
+                   b_per_image ? (const float*)b : nullptr, scale, (h16_t*)y, ldy, B, HW, C);
         else
             LAUNCH(gate_vec_kernel<float>, total, (const float*)x, ldx, (const float*)a, lda, b_per_image ? nullptr : (const float*)b, ldb,
                    b_per_image ? (const float*)b : nullptr, scale, (float*)y, ldy, B, HW, C);
@@ -840,7 +840,7 @@ extern "C" int ymk_channel_gate(int32_t dtype, const void* x, int32_t ldx, const
     if (C % V == 0 && ldx % V == 0 && ldy % V == 0 && al16(x) && al16(y)) {
         const int64_t total = (int64_t)B * HW * (C / V);
         if (dtype == YMK_BF16)
-            LAUNCH(gate_vec_kernel<bf16_t>, total, (const bf16_t*)x, ldx, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, gate, 0.f, (bf16_t*)y, ldy, B, HW, C);
+            LAUNCH(gate_vec_kernel<h16_t>, total, (const h16_t*)x, ldx, (const h16_t*)nullptr, 0, (const h16_t*)nullptr, 0, gate, 0.f, (h16_t*)y, ldy, B, HW, C);
         else
             LAUNCH(gate_vec_kernel<float>, total, (const float*)x, ldx, (const float*)nullptr, 0, (const float*)nullptr, 0, gate, 0.f, (float*)y, ldy, B, HW, C);
         return ymk_launch_status();
@@ -862,7 +862,7 @@ extern "C" int ymk_weighted_sum(int32_t dtype, const float* w, int32_t ldw, int3
     for (int e = 0; e < E; ++e) vok = vok && al16(parts.p[e]);
     if (vok) {
         const int64_t total = (int64_t)B * HW * (C / V);
-        if (dtype == YMK_BF16) LAUNCH(weighted_sum_vec_kernel<bf16_t>, total, w, ldw, w_per_image, E, parts, ldp, (bf16_t*)y, ldy, B, HW, C);
+        if (dtype == YMK_BF16) LAUNCH(weighted_sum_vec_kernel<h16_t>, total, w, ldw, w_per_image, E, parts, ldp, (h16_t*)y, ldy, B, HW, C);
         else LAUNCH(weighted_sum_vec_kernel<float>, total, w, ldw, w_per_image, E, parts, ldp, (float*)y, ldy, B, HW, C);
         return ymk_launch_status();
     }
@@ -885,7 +885,7 @@ extern "C" int ymk_mean_upsampled(int32_t dtype, int32_t n, const void* p0, cons
     for (int j = 0; j < n; ++j) vok = vok && a.ld[j] % V == 0 && al16(a.p[j]);
     if (vok) {
         const int64_t total = (int64_t)B * H * W * (C / V);
-        if (dtype == YMK_BF16) LAUNCH(mean_upsampled_vec_kernel<bf16_t>, total, n, a, (bf16_t*)y, ldy, B, H, W, C);
+        if (dtype == YMK_BF16) LAUNCH(mean_upsampled_vec_kernel<h16_t>, total, n, a, (h16_t*)y, ldy, B, H, W, C);
         else LAUNCH(mean_upsampled_vec_kernel<float>, total, n, a, (float*)y, ldy, B, H, W, C);
         return ymk_launch_status();
     }
@@ -902,8 +902,8 @@ extern "C" int ymk_adaptive_avg_pool(int32_t dtype, const void* x, int32_t ldx, 
     if (C % V == 0 && ldx % V == 0 && ldy % V == 0 && al16(x) && al16(y) && (out_dtype == dtype || out_dtype == YMK_F32)) {
         const int64_t total = (int64_t)B * Ho * Wo * (C / V);
         if (dtype == YMK_F32) LAUNCH((pool_vec_kernel<float, float>), total, (const float*)x, ldx, (float*)y, ldy, B, H, W, C, Ho, Wo, 0);
-        else if (out_dtype == YMK_BF16) LAUNCH((pool_vec_kernel<bf16_t, bf16_t>), total, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, H, W, C, Ho, Wo, 0);
-        else LAUNCH((pool_vec_kernel<bf16_t, float>), total, (const bf16_t*)x, ldx, (float*)y, ldy, B, H, W, C, Ho, Wo, 0);
+        else if (out_dtype == YMK_BF16) LAUNCH((pool_vec_kernel<h16_t, h16_t>), total, (const h16_t*)x, ldx, (h16_t*)y, ldy, B, H, W, C, Ho, Wo, 0);
+        else LAUNCH((pool_vec_kernel<h16_t, float>), total, (const h16_t*)x, ldx, (float*)y, ldy, B, H, W, C, Ho, Wo, 0);
         return ymk_launch_status();
     }
     LAUNCH(pool_kernel, (int64_t)B * Ho * Wo * C, dtype, x, ldx, y, out_dtype, ldy, B, H, W, C, Ho, Wo, 0);
@@ -918,8 +918,8 @@ extern "C" int ymk_avg_pool(int32_t dtype, const void* x, int32_t ldx, void* y, 
     if (C % V == 0 && ldx % V == 0 && ldy % V == 0 && al16(x) && al16(y) && (out_dtype == dtype || out_dtype == YMK_F32)) {
         const int64_t total = (int64_t)B * (H / k) * (W / k) * (C / V);
         if (dtype == YMK_F32) LAUNCH((pool_vec_kernel<float, float>), total, (const float*)x, ldx, (float*)y, ldy, B, H, W, C, (H / k), (W / k), k);
-        else if (out_dtype == YMK_BF16) LAUNCH((pool_vec_kernel<bf16_t, bf16_t>), total, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, H, W, C, (H / k), (W / k), k);
-        else LAUNCH((pool_vec_kernel<bf16_t, float>), total, (const bf16_t*)x, ldx, (float*)y, ldy, B, H, W, C, (H / k), (W / k), k);
+        else if (out_dtype == YMK_BF16) LAUNCH((pool_vec_kernel<h16_t, h16_t>), total, (const h16_t*)x, ldx, (h16_t*)y, ldy, B, H, W, C, (H / k), (W / k), k);
+        else LAUNCH((pool_vec_kernel<h16_t, float>), total, (const h16_t*)x, ldx, (float*)y, ldy, B, H, W, C, (H / k), (W / k), k);
         return ymk_launch_status();
     }
     LAUNCH(pool_kernel, (int64_t)B * (H / k) * (W / k) * C, dtype, x, ldx, y, out_dtype, ldy, B, H, W, C, H / k, W / k, k);
@@ -933,7 +933,7 @@ extern "C" int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, floa
     const int V = vecw(dtype);
     if (C % V == 0 && ldx % V == 0 && al16(x)) {
         const dim3 grid((C / V + 15) / 16, B);
-        if (dtype == YMK_BF16) hipLaunchKernelGGL(channel_stats_vec_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, out, HW, C, want_std);
+        if (dtype == YMK_BF16) hipLaunchKernelGGL(channel_stats_vec_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, out, HW, C, want_std);
         else hipLaunchKernelGGL(channel_stats_vec_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, out, HW, C, want_std);
         return ymk_launch_status();
     }
@@ -993,7 +993,7 @@ extern "C" int ymk_channel_shuffle_cat(int32_t dtype, const void* a, int32_t lda
     const int V = vecw(dtype);
     if (groups == 2 && Ca == Cb && Ca % (V / 2) == 0 && ldy % V == 0 && al16(y)) {   // the gated block's case: even / odd interleave
         const int64_t total = npix * (Ca / (V / 2));
-        if (dtype == YMK_BF16) LAUNCH(shuffle2_vec_kernel<bf16_t>, total, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, Ca, (bf16_t*)y, ldy, npix);
+        if (dtype == YMK_BF16) LAUNCH(shuffle2_vec_kernel<h16_t>, total, (const h16_t*)a, lda, (const h16_t*)b, ldb, Ca, (h16_t*)y, ldy, npix);
         else LAUNCH(shuffle2_vec_kernel<float>, total, (const float*)a, lda, (const float*)b, ldb, Ca, (float*)y, ldy, npix);
         return ymk_launch_status();
     }

@@ -18,13 +18,13 @@
 
 typedef __bf16 mlp_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void mlp_mma(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mlp_bf16x8, a), __builtin_bit_cast(mlp_bf16x8, b), acc, 0, 0, 0);
+    acc = mfma16x16x32_h16(a, b, acc);
 }
 
 #define MLP_BM 64
 
 struct MlpArgs {
-    const bf16_t* x; const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2; bf16_t* y;
+    const h16_t* x; const h16_t* w1; const float* b1; const h16_t* w2; const float* b2; h16_t* y;
     int M, C, Hd, ldx, ldy, k1pad, k2pad;
 };
 
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(MlpArgs a) {
     const int fr = lane & 15, fc = lane >> 4;
     const int ntiles = (a.M + MLP_BM - 1) / MLP_BM;
 
-    const bf16_t* w1row = a.w1 + (size_t)(wave * HT * 16 + fr) * a.k1pad + fc * 8;
-    const bf16_t* w2row = a.w2 + (size_t)(wave * CT * 16 + fr) * a.k2pad + fc * 8;
+    const h16_t* w1row = a.w1 + (size_t)(wave * HT * 16 + fr) * a.k1pad + fc * 8;
+    const h16_t* w2row = a.w2 + (size_t)(wave * CT * 16 + fr) * a.k2pad + fc * 8;
     u32x4 af1[C / 32][HT], af2[PERSIST ? Hd / 32 : 1][PERSIST ? CT : 1];
     f32x4 bias1[HT], bias2[CT];
     auto load_w1 = [&]() {
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(MlpArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 v = acc[i][j] + bias1[i];
                     u32x2 o;
-                    o.x = pack_bf16x2(silu_f(v.x), silu_f(v.y));
-                    o.y = pack_bf16x2(silu_f(v.z), silu_f(v.w));
+                    o.x = pack_h16x2(silu_f(v.x), silu_f(v.y));
+                    o.y = pack_h16x2(silu_f(v.z), silu_f(v.w));
                     *reinterpret_cast<u32x2*>(sH + (j * 16 + fr) * HP + h * 2) = o;
                 }
             }
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(MlpArgs a) {
                     if (m < a.M) {
                         const u32x2 r = *reinterpret_cast<const u32x2*>(sX + (j * 16 + fr) * XP + c * 2);     // residual: the staged x
                         const f32x4 v = acc[i][j] + bias2[i];
-                        store4(a.y + (size_t)m * a.ldy + c, v.x + bf16lo(r.x), v.y + bf16hi(r.x), v.z + bf16lo(r.y), v.w + bf16hi(r.y));
+                        store4(a.y + (size_t)m * a.ldy + c, v.x + h16lo(r.x), v.y + h16hi(r.x), v.z + h16lo(r.y), v.w + h16hi(r.y));
                     }
                 }
             }
@@ -179,10 +179,10 @@ extern "C" int ymk_mlp_fused_supported(int32_t dtype, int32_t C, int32_t hidden)
 extern "C" int ymk_mlp_fused(const void* x, int32_t ldx, const void* w1, int32_t k1pad, const float* b1, const void* w2, int32_t k2pad,
                              const float* b2, void* y, int32_t ldy, int64_t M, int32_t C, int32_t hidden, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || !ymk_mlp_fused_supported(YMK_BF16, C, hidden)) return YMK_E_BADARG;
-    if (ldx % 8 || ldy % 4 || k1pad < C || k2pad < hidden || k1pad % 8 || k2pad % 8 || ldx < C || ldy < C) return YMK_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7) || ldx % 8 || ldy % 4 || k1pad < C || k2pad < hidden || k1pad % 8 || k2pad % 8 || ldx < C || ldy < C) return YMK_E_BADARG;
     if (M <= 0) return YMK_OK;
     if (M >= (1ll << 31)) return YMK_E_BADARG;
-    MlpArgs a{(const bf16_t*)x, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (bf16_t*)y, (int)M, C, hidden, ldx, ldy, k1pad, k2pad};
+    MlpArgs a{(const h16_t*)x, (const h16_t*)w1, b1, (const h16_t*)w2, b2, (h16_t*)y, (int)M, C, hidden, ldx, ldy, k1pad, k2pad};
     const unsigned ntiles = (unsigned)((M + MLP_BM - 1) / MLP_BM);
     // persistent variants: as many workgroups as are resident at once (C = 128 holds 128 fragment registers: one per CU)
     const unsigned slots = C == 128 ? 256u : 768u;

@@ -4,7 +4,8 @@
 //   order: score descending (ties: lower candidate index first), cap max_nms (:142-146)
 //   boxes + cls*max_wh (:148-154); greedy: drop j when !(IoU(i,j) <= thr) (:300); [:max_det] (:162)
 // Pipeline (all per-image work runs batched over B):
-//   count -> scan -> emit (ordered compaction) -> rank (counting sort, stable)
+//   count -> scan -> [top-max_nms selection: 3-level radix select on the score bits, only for images with more candidates
+//   than max_nms] -> emit (ordered compaction) -> rank (counting sort, stable)
 //   -> chunked greedy suppression against the kept list (one workgroup per image, no n^2 mask).
 // Compile with -ffp-contract=off: IoU arithmetic must round exactly like the reference.
 #include "ymk_common.h"
@@ -26,6 +27,15 @@ struct NmsWs {
     int* scls;       // [B][ns]
     int* sanchor;    // [B][ns]
     int* keep_pos;   // [B][max_det_cap]
+    // top-max_nms selection (images with more than max_nms candidates; utils/nms.py:142-146 keeps the max_nms best by score)
+    int* sel;            // [B] 1: this image selects by threshold key
+    unsigned* thr_key;   // [B] score bits T: every candidate with bits > T is taken, and the first eq_take (anchor-major order) with bits == T
+    int* n_gt;           // [B] candidates with bits > T
+    int* eq_take;        // [B]
+    int* need;           // [B] running: how many still to take inside the current prefix
+    unsigned* hist;      // [B][2048]
+    int* blocksum_e;     // [B][NBLK] per-block counts of bits == T
+    int* blockoff_e;     // [B][NBLK]
     int nblk, capc, ns, nw;
     size_t total;
 };
@@ -36,9 +46,8 @@ static NmsWs nms_layout(void* base, int B, int nc, int A, int multi, int max_nms
     NmsWs w;
     w.nblk = (A + 255) / 256;
     const int64_t full = multi ? (int64_t)A * nc : (int64_t)A;
-    const int64_t capm = (int64_t)max_nms * 2;
-    w.capc = (int)(multi ? (full < capm ? full : capm) : full);
-    w.ns = w.capc < max_nms ? w.capc : max_nms;
+    w.capc = (int)(full < (int64_t)max_nms ? full : (int64_t)max_nms);   // never more than max_nms rows reach the ordering stage
+    w.ns = w.capc;
     w.nw = (w.ns + 63) / 64;
     size_t off = 0;
     char* p = (char*)base;
@@ -63,6 +72,14 @@ static NmsWs nms_layout(void* base, int B, int nc, int A, int multi, int max_nms
     w.scls = (int*)take((size_t)B * w.ns * 4);
     w.sanchor = (int*)take((size_t)B * w.ns * 4);
     w.keep_pos = (int*)take((size_t)B * NMS_MAXDET_CAP * 4);
+    w.sel = (int*)take((size_t)B * 4);
+    w.thr_key = (unsigned*)take((size_t)B * 4);
+    w.n_gt = (int*)take((size_t)B * 4);
+    w.eq_take = (int*)take((size_t)B * 4);
+    w.need = (int*)take((size_t)B * 4);
+    w.hist = (unsigned*)take((size_t)B * 2048 * 4);
+    w.blocksum_e = (int*)take((size_t)B * w.nblk * 4);
+    w.blockoff_e = (int*)take((size_t)B * w.nblk * 4);
     w.total = off;
     return w;
 }
@@ -141,31 +158,180 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(NmsWs w, int* __restrict__
         run += __shfl(inc, 63);
     }
     if (lane == 0) {
-        if (run > w.capc) atomicOr(status, YMK_FLAG_NMS_OVERFLOW);
-        const int n = run < w.capc ? run : w.capc;
+        // more candidates than the ordering stage takes (max_nms, utils/nms.py:142-146): the image goes through the radix select
+        const int over = run > w.capc;
+        const int n = over ? w.capc : run;
         w.ncand[b] = n;
-        w.nsort[b] = n < w.ns ? n : w.ns;
+        w.nsort[b] = n;
+        w.sel[b] = over;
+        w.thr_key[b] = 0u;       // bits > 0: every candidate (scores that pass conf >= 0 are positive)
+        w.n_gt[b] = 0;
+        w.eq_take[b] = 0;
+        w.need[b] = w.capc;
+    }
+    for (int i = lane; i < 2048; i += 64) w.hist[(size_t)b * 2048 + i] = 0u;
+}
+
+// ---- 2b. top-max_nms selection: radix select of the threshold key ------------------------------------------------------------
+// The reference sorts ALL candidates by score and keeps the first max_nms (utils/nms.py:142-146; with conf 0.001 and multi_label a
+// dense 640^2 image has up to 672 000 (anchor, class) pairs).  Instead of ordering them all: find the score bit pattern T with
+// #{bits > T} < max_nms <= #{bits >= T} by three histogram levels over the 32 key bits (11 + 11 + 10), then emit every candidate
+// above T and the first (max_nms - #{bits > T}) candidates equal to T in anchor-major order — the order the stable sort would give them.
+// Level l histograms the candidates whose higher bits equal the prefix found so far.  Images with <= max_nms candidates skip all of it.
+__device__ __forceinline__ int nms_level_shift(int level) { return level == 0 ? 21 : (level == 1 ? 10 : 0); }
+
+__global__ __launch_bounds__(256) void nms_hist_kernel(const float* __restrict__ y, int nc, int A, float conf, int multi,
+                                                      const unsigned char* __restrict__ class_keep, NmsWs w, int level) {
+    __shared__ unsigned h[2048];
+    const int b = blockIdx.y;
+    if (!w.sel[b]) return;   // workgroup-uniform
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0u;
+    __syncthreads();
+    const int shift = nms_level_shift(level);
+    const unsigned prefix = w.thr_key[b];
+    const int hs = level == 0 ? 32 : (level == 1 ? 21 : 10);   // bits above this position must match the prefix
+    const unsigned mask = level == 2 ? 1023u : 2047u;
+    auto add = [&](float v) {
+        const unsigned k = __float_as_uint(v);
+        if (hs < 32 && (k >> hs) != (prefix >> hs)) return;
+        atomicAdd(&h[(k >> shift) & mask], 1u);
+    };
+    if (a < A) {
+        if (multi) {
+            const float* p = y + ((size_t)b * (4 + nc) + 4) * A + a;
+            for (int k = 0; k < nc; ++k) {
+                const float v = p[(size_t)k * A];
+                if (v > conf && (!class_keep || class_keep[k])) add(v);
+            }
+        } else if (w.cnt[(size_t)b * A + a]) add(w.bconf[(size_t)b * A + a]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256)
+        if (h[i]) atomicAdd(&w.hist[(size_t)b * 2048 + i], h[i]);
+}
+
+__global__ __launch_bounds__(256) void nms_pick_kernel(NmsWs w, int level) {
+    __shared__ unsigned h[2048];
+    __shared__ unsigned wtot[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!w.sel[b]) return;
+    unsigned* gh = w.hist + (size_t)b * 2048;
+    for (int i = tid; i < 2048; i += 256) { h[i] = gh[i]; gh[i] = 0u; }   // cleared for the next level
+    __syncthreads();
+    // thread t owns bins [2047 - 8t - 7, 2047 - 8t]: walking threads upward walks the bins from the top down
+    unsigned own = 0u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) own += h[2047 - (tid * 8 + q)];
+    unsigned inc = own;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    unsigned above = inc - own;   // candidates in the bins above this thread's range
+    for (int k = 0; k < wave; ++k) above += wtot[k];
+    const unsigned need = (unsigned)w.need[b];
+    if (above < need && need <= above + own) {   // exactly one thread: the threshold bin is in its range
+        unsigned acc = above;
+        int t = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int bin = 2047 - (tid * 8 + q);
+            const unsigned c = h[bin];
+            if (acc < need && need <= acc + c) { t = bin; break; }
+            acc += c;
+        }
+        w.thr_key[b] |= (unsigned)t << nms_level_shift(level);
+        w.n_gt[b] += (int)acc;
+        w.need[b] = (int)(need - acc);
+        if (level == 2) w.eq_take[b] = (int)(need - acc);
+    }
+}
+
+// per-anchor counts against the threshold: low 16 bits #{bits > T}, high 16 bits #{bits == T} (nc < 65536)
+__global__ __launch_bounds__(256) void nms_count2_kernel(const float* __restrict__ y, int nc, int A, float conf, int multi,
+                                                        const unsigned char* __restrict__ class_keep, NmsWs w) {
+    __shared__ int wsum[4], wsum_e[4];
+    const int b = blockIdx.y;
+    if (!w.sel[b]) return;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const unsigned T = w.thr_key[b];
+    int c = 0;
+    if (a < A) {
+        if (multi) {
+            const float* p = y + ((size_t)b * (4 + nc) + 4) * A + a;
+            for (int k = 0; k < nc; ++k) {
+                const float v = p[(size_t)k * A];
+                if (v > conf && (!class_keep || class_keep[k])) {
+                    const unsigned key = __float_as_uint(v);
+                    c += key > T ? 1 : (key == T ? 65536 : 0);
+                }
+            }
+        } else if (w.cnt[(size_t)b * A + a]) {
+            const unsigned key = __float_as_uint(w.bconf[(size_t)b * A + a]);
+            c = key > T ? 1 : (key == T ? 65536 : 0);
+        }
+        w.cnt[(size_t)b * A + a] = c;
+    }
+    int s = c & 0xffff, e = (int)((unsigned)c >> 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); e += __shfl_xor(e, o); }
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = s; wsum_e[threadIdx.x >> 6] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w.blocksum[b * w.nblk + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        w.blocksum_e[b * w.nblk + blockIdx.x] = wsum_e[0] + wsum_e[1] + wsum_e[2] + wsum_e[3];
+    }
+}
+
+__global__ __launch_bounds__(64) void nms_scan2_kernel(NmsWs w) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (!w.sel[b]) return;
+    int run = 0, run_e = 0;
+    for (int i0 = 0; i0 < w.nblk; i0 += 64) {
+        const int i = i0 + lane;
+        const int v = i < w.nblk ? w.blocksum[b * w.nblk + i] : 0;
+        const int e = i < w.nblk ? w.blocksum_e[b * w.nblk + i] : 0;
+        int inc = v, ince = e;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(inc, o), ne = __shfl_up(ince, o);
+            if (lane >= o) { inc += n; ince += ne; }
+        }
+        if (i < w.nblk) { w.blockoff[b * w.nblk + i] = run + inc - v; w.blockoff_e[b * w.nblk + i] = run_e + ince - e; }
+        run += __shfl(inc, 63);
+        run_e += __shfl(ince, 63);
     }
 }
 
 // ---- 3. ordered compaction of candidates -------------------------------------------
 __global__ __launch_bounds__(256) void nms_emit_kernel(const float* __restrict__ y, int nc, int A, float conf, int multi,
                                                       const unsigned char* __restrict__ class_keep, NmsWs w) {
-    __shared__ int wsum[4];
+    __shared__ int wsum[4], wsum_e[4];
     const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sel = w.sel[b];
+    // per-anchor counts.  An image that selects (more than max_nms candidates) holds them packed: low 16 bits = candidates above
+    // its threshold key, high 16 bits = candidates equal to it; any other image holds its plain candidate count (T = 0: all above).
     const int c = a < A ? w.cnt[(size_t)b * A + a] : 0;
-    int inc = c;
+    const int cg = sel ? (c & 0xffff) : c, ce = sel ? (int)((unsigned)c >> 16) : 0;
+    int inc = cg, ince = ce;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const int n = __shfl_up(inc, o);
-        if (lane >= o) inc += n;
+        const int n = __shfl_up(inc, o), ne = __shfl_up(ince, o);
+        if (lane >= o) { inc += n; ince += ne; }
     }
-    if (lane == 63) wsum[wv] = inc;
+    if (lane == 63) { wsum[wv] = inc; wsum_e[wv] = ince; }
     __syncthreads();
-    int pos = w.blockoff[b * w.nblk + blockIdx.x] + inc - c;
-    for (int k = 0; k < wv; ++k) pos += wsum[k];
+    int pos = w.blockoff[b * w.nblk + blockIdx.x] + inc - cg;
+    int pos_e = sel ? w.blockoff_e[b * w.nblk + blockIdx.x] + ince - ce : 0;
+    for (int k = 0; k < wv; ++k) { pos += wsum[k]; pos_e += wsum_e[k]; }
     if (c == 0) return;
+    const unsigned T = w.thr_key[b];
+    const int n_gt = w.n_gt[b], eq_take = w.eq_take[b];
     const float* yb = y + (size_t)b * (4 + nc) * A + a;
     const float cx = yb[0], cy = yb[(size_t)A], bw = yb[2 * (size_t)A], bh = yb[3 * (size_t)A];
     const float hw = bw / 2.0f, hh = bh / 2.0f;  // xywh2xyxy (utils/ops.py:248-264)
@@ -176,13 +342,20 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float* __restrict__
         w.cbox[o * 4 + 0] = x1; w.cbox[o * 4 + 1] = y1; w.cbox[o * 4 + 2] = x2; w.cbox[o * 4 + 3] = y2;
         w.cscore[o] = score; w.ccls[o] = cls; w.canchor[o] = a;
     };
+    // Rows above the threshold fill [0, n_gt) in anchor-major order, the taken rows equal to it [n_gt, n_gt + eq_take): equal
+    // scores never straddle the two ranges, so "lower row first" in the ordering stage is still "lower candidate index first".
+    auto route = [&](float v, int cls) {
+        const unsigned key = __float_as_uint(v);
+        if (key > T) put(pos++, v, cls);
+        else if (key == T) { if (pos_e < eq_take) put(n_gt + pos_e, v, cls); ++pos_e; }
+    };
     if (multi) {
         for (int k = 0; k < nc; ++k) {
             const float v = yb[(size_t)(4 + k) * A];
-            if (v > conf && (!class_keep || class_keep[k])) put(pos++, v, k);
+            if (v > conf && (!class_keep || class_keep[k])) route(v, k);
         }
     } else {
-        put(pos, w.bconf[(size_t)b * A + a], w.bcls[(size_t)b * A + a]);
+        route(w.bconf[(size_t)b * A + a], w.bcls[(size_t)b * A + a]);
     }
 }
 
@@ -505,6 +678,15 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A,
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, w, status);
+    const int64_t full = multi ? (int64_t)A * nc : (int64_t)A;
+    if (full > (int64_t)max_nms) {   // an image CAN hold more candidates than max_nms: selection kernels (no-ops for images that do not)
+        for (int level = 0; level < 3; ++level) {
+            hipLaunchKernelGGL(nms_hist_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w, level);
+            hipLaunchKernelGGL(nms_pick_kernel, dim3(B), dim3(256), 0, s, w, level);
+        }
+        hipLaunchKernelGGL(nms_count2_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
+        hipLaunchKernelGGL(nms_scan2_kernel, dim3(B), dim3(64), 0, s, w);
+    }
     hipLaunchKernelGGL(nms_emit_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
     if (w.capc <= NMS_SORT_CAP && !(ymk_disabled() & YMK_OFF_NMS_SORT))
         hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, s, w, (ymk_disabled() & YMK_OFF_NMS_RADIX) ? 0 : 1);

@@ -93,7 +93,7 @@ extern "C" int ymk_tokens_to_rows(int32_t dtype, const void* x, int32_t ldx, flo
     if (B <= 0 || HW <= 0) return YMK_OK;
     const dim3 grid((HW + 63) / 64, (C + 63) / 64, B);
     if (dtype == YMK_BF16)
-        hipLaunchKernelGGL(tokens_to_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, y, HW, C, a_off, A_total,
+        hipLaunchKernelGGL(tokens_to_rows_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, y, HW, C, a_off, A_total,
                            row_off, rows_total);
     else
         hipLaunchKernelGGL(tokens_to_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, y, HW, C, a_off, A_total,
@@ -175,7 +175,7 @@ extern "C" int ymk_process_mask(int32_t dtype, const void* protos, int32_t ldp, 
     const int64_t tl = (int64_t)n * mh * mw, tf = (int64_t)n * H * W;
     const int bl = (int)((tl + 255) / 256 > 16384 ? 16384 : (tl + 255) / 256), bf = (int)((tf + 255) / 256 > 32768 ? 32768 : (tf + 255) / 256);
     if (dtype == YMK_BF16)
-        hipLaunchKernelGGL(mask_lowres_kernel<bf16_t>, dim3(bl), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)protos, ldp, coefs, nm, n, mh, mw, lowres_ws);
+        hipLaunchKernelGGL(mask_lowres_kernel<h16_t>, dim3(bl), dim3(256), 0, (hipStream_t)stream, (const h16_t*)protos, ldp, coefs, nm, n, mh, mw, lowres_ws);
     else
         hipLaunchKernelGGL(mask_lowres_kernel<float>, dim3(bl), dim3(256), 0, (hipStream_t)stream, (const float*)protos, ldp, coefs, nm, n, mh, mw, lowres_ws);
     hipLaunchKernelGGL(mask_finish_kernel, dim3(bf), dim3(256), 0, (hipStream_t)stream, (const float*)lowres_ws, boxes, ldb, n, mh, mw, H, W, upsample, rw,

@@ -21,13 +21,23 @@ struct PreArgs {
 };
 
 // OpenCV's per-destination-index source position and 11-bit coefficients of the linear kernel
-__device__ __forceinline__ void pre_coef(int d, double scale, int ssize, int& s0, int& a0, int& a1) {
+// Horizontal taps: at the borders OpenCV moves the tap inside and zeroes the fraction (resize.cpp: `if (sx < 0) fx = 0, sx = 0;
+// if (sx >= ssize.width - 1) fx = 0, sx = ssize.width - 1`).  Vertical taps keep the fraction and the generic invoker clamps the ROW
+// INDICES instead (`clip(yofs[dy] + k, 0, ssize.height)`): with both rows equal the two products round separately, so the first /
+// last rows of an upscaled image can come out one LSB lower than with a zeroed fraction.
+__device__ __forceinline__ void pre_coef(int d, double scale, int ssize, bool vertical, int& s0, int& s1, int& a0, int& a1) {
     float f = (float)((d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
-    if (s < 0) { f = 0.f; s = 0; }
-    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
-    s0 = s;
+    if (vertical) {
+        s0 = min(max(s, 0), ssize - 1);
+        s1 = min(max(s + 1, 0), ssize - 1);
+    } else {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+        s0 = s;
+        s1 = min(s + 1, ssize - 1);
+    }
     a0 = (int)rintf((1.f - f) * 2048.f);   // saturate_cast<short>(cvRound(x)): round half to even, never out of range here
     a1 = (int)rintf(f * 2048.f);
 }
@@ -51,10 +61,9 @@ __global__ __launch_bounds__(256) void letterbox_kernel(PreArgs a) {
             for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
         } else {
             const double scale_x = 1.0 / ((double)nw / (double)sw), scale_y = 1.0 / ((double)nh / (double)sh);
-            int sx, ax0, ax1, sy, by0, by1;
-            pre_coef(dx, scale_x, sw, sx, ax0, ax1);
-            pre_coef(dy, scale_y, sh, sy, by0, by1);
-            const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
+            int sx, sx1, ax0, ax1, sy, sy1, by0, by1;
+            pre_coef(dx, scale_x, sw, false, sx, sx1, ax0, ax1);
+            pre_coef(dy, scale_y, sh, true, sy, sy1, by0, by1);
             const uint8_t* r0 = s + (size_t)sy * sw * 3;
             const uint8_t* r1 = s + (size_t)sy1 * sw * 3;
 #pragma unroll

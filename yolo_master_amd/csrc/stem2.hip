@@ -43,7 +43,7 @@
 typedef __bf16 s2_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void s2_mma_bf16(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s2_bf16x8, a), __builtin_bit_cast(s2_bf16x8, b), acc, 0, 0, 0);
+    acc = mfma16x16x32_h16(a, b, acc);
 }
 // 16 values of K per call: component v of lane group fc multiplies k = fc * 4 + v (csrc/igemm.h mma16<float>)
 __device__ __forceinline__ void s2_mma_f32(f32x4& acc, const u32x4& a, const u32x4& b) {
@@ -57,17 +57,17 @@ struct Stem2Args {
     const float* x;      // [B][3][H][W]
     const float* wt0;    // [27][C0]  (k = (ky * 3 + kx) * 3 + c)
     const float* b0;     // [C0]
-    const bf16_t* w1;    // [C1][k1pad]  (k = (ky * 3 + kx) * C0 + c)
+    const h16_t* w1;    // [C1][k1pad]  (k = (ky * 3 + kx) * C0 + c)
     const float* b1;     // [C1]
-    bf16_t* y;           // [B][H2][W2][ldy]
+    h16_t* y;           // [B][H2][W2][ldy]
     int B, H, W, H1, W1, H2, W2, k1pad, ldy, tiles_x, tiles_y;
 };
 
-// fp32 -> (hi << 16) | lo, both parts bf16 (round to nearest even)
+// fp32 -> (hi << 16) | lo, both parts in the build's 16-bit format (round to nearest even): v = hi + lo up to 2^-16 (bf16) / 2^-22 (f16)
 __device__ __forceinline__ uint32_t s2_split(float v) {
-    const uint32_t hi = pack_bf16x2(v, 0.f) & 0xffffu;
-    const float r = v - __uint_as_float(hi << 16);
-    return (hi << 16) | (pack_bf16x2(r, 0.f) & 0xffffu);
+    const uint32_t hi = pack_h16x2(v, 0.f) & 0xffffu;
+    const float r = v - h16_to_f32((h16_t)hi);
+    return (hi << 16) | (pack_h16x2(r, 0.f) & 0xffffu);
 }
 
 template <int C0, int C1, bool SPLIT>
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
                 }
                 u32x2 o = {0u, 0u};   // outside the stem map: row 1's zero padding
                 if (inside) {
-                    o.x = pack_bf16x2(silu_f(acc.x), silu_f(acc.y));
-                    o.y = pack_bf16x2(silu_f(acc.z), silu_f(acc.w));
+                    o.x = pack_h16x2(silu_f(acc.x), silu_f(acc.y));
+                    o.y = pack_h16x2(silu_f(acc.z), silu_f(acc.w));
                 }
                 if (p < S2_NP) *reinterpret_cast<u32x2*>(sStem + p * S2_PP + (i * 16 + fc * 4) * 2) = o;
             }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
         }
         const int oy = oy0 + pq;
         if (oy < a.H2) {
-            bf16_t* yrow = a.y + ((size_t)b * a.H2 + oy) * a.W2 * a.ldy;
+            h16_t* yrow = a.y + ((size_t)b * a.H2 + oy) * a.W2 * a.ldy;
 #pragma unroll
             for (int pf = 0; pf < 2; ++pf) {
                 const int ox = ox0 + pf * 16 + fr;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(S2_NT) void stem_pair_kernel(Stem2Args a) {
                         const f32x4 v = acc1[i][pf] + bv1[i];
                         v8[i * 4 + 0] = silu_f(v.x); v8[i * 4 + 1] = silu_f(v.y); v8[i * 4 + 2] = silu_f(v.z); v8[i * 4 + 3] = silu_f(v.w);
                     }
-                    bf16_t* yo = yrow + (size_t)ox * a.ldy + ch * 32 + fc * 8;
+                    h16_t* yo = yrow + (size_t)ox * a.ldy + ch * 32 + fc * 8;
                     if (wide) {
                         store_vec_f32(yo, v8);
                     } else {
@@ -272,7 +272,7 @@ extern "C" int ymk_stem_pair(const float* x, int32_t B, int32_t H, int32_t W, co
     if ((W & 3) || ((uintptr_t)x & 15) || H < 1 || W < 4) return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
     Stem2Args a;
-    a.x = x; a.wt0 = wt0; a.b0 = b0; a.w1 = (const bf16_t*)w1; a.b1 = b1; a.y = (bf16_t*)y;
+    a.x = x; a.wt0 = wt0; a.b0 = b0; a.w1 = (const h16_t*)w1; a.b1 = b1; a.y = (h16_t*)y;
     a.B = B; a.H = H; a.W = W;
     a.H1 = (H - 1) / 2 + 1; a.W1 = (W - 1) / 2 + 1;
     a.H2 = (a.H1 - 1) / 2 + 1; a.W2 = (a.W1 - 1) / 2 + 1;
@@ -285,13 +285,13 @@ extern "C" int ymk_stem_pair(const float* x, int32_t B, int32_t H, int32_t W, co
 #else
     const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);   // one persistent workgroup per CU (109 KB of LDS)
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
+    static YmkOncePerDevice attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pair_kernel<32, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)S2_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pair_kernel<32, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)S2_LDS_BYTES);
-        attr_set = true;
+        attr_once.done();
     }
     if (ymk_disabled() & 4096u)
         hipLaunchKernelGGL((stem_pair_kernel<32, 64, false>), dim3(grid), dim3(S2_NT), S2_LDS_BYTES, (hipStream_t)stream, a);

@@ -1,33 +1,71 @@
 // Shared device/host helpers for libymk (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/ymk.h"
 
 #define YMK_WAVE 64
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits
+// The library's 16-bit element type.  Every kernel that handles 16-bit activations / weights is written against `h16_t` (raw bits)
+// and the helpers below; the FORMAT is a property of the build: libymk.so = bfloat16, libymk_f16.so (the same sources compiled with
+// -DYMK_H16_F16) = IEEE binary16, the reference's reduced-precision mode (`half=True`, engine/predictor.py:174,415).  Accumulation is
+// fp32 in both; routers, statistics, DFL decode and NMS are fp32 in both.  `h16_t` remains as an alias in the bf16-era comments only.
+typedef uint16_t h16_t;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float bf16_to_f32(bf16_t h) {
-    return __uint_as_float(((uint32_t)h) << 16);
+#ifdef YMK_H16_F16
+#define YMK_H16_NAME "f16"
+typedef _Float16 hw_h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hw_h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float h16_to_f32(h16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ float h16lo(uint32_t w) { return (float)__builtin_bit_cast(hw_h16x2, w).x; }
+__device__ __forceinline__ float h16hi(uint32_t w) { return (float)__builtin_bit_cast(hw_h16x2, w).y; }
+// two packed words (e0,e1),(e2,e3) -> a = (e0, e2), b = (e1, e3) as fp32 pairs
+__device__ __forceinline__ void h16x4_widen(const u32x2 t, f32x2& a, f32x2& b) {
+    const hw_h16x2 p = __builtin_bit_cast(hw_h16x2, t.x), q = __builtin_bit_cast(hw_h16x2, t.y);
+    a = f32x2{(float)p.x, (float)q.x};
+    b = f32x2{(float)p.y, (float)q.y};
+}
+// fp32 -> binary16, round to nearest even (v_cvt_f16_f32 under the default rounding mode: torch's float -> half cast)
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
+    const hw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_h16x2));
+}
+__device__ __forceinline__ f32x4 mfma16x16x32_h16(const u32x4& a, const u32x4& b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hw_h16x8, a), __builtin_bit_cast(hw_h16x8, b), acc, 0, 0, 0);
+}
+#else
+#define YMK_H16_NAME "bf16"
+typedef __bf16 hw_h16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 hw_h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float h16_to_f32(h16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float h16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+// two packed words (e0,e1),(e2,e3) -> a = (e0, e2), b = (e1, e3): VECTOR shift / mask, the results land in register pairs directly
+__device__ __forceinline__ void h16x4_widen(const u32x2 t, f32x2& a, f32x2& b) {
+    a = __builtin_bit_cast(f32x2, t << 16);
+    b = __builtin_bit_cast(f32x2, t & 0xffff0000u);
 }
 // fp32 -> bf16: gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN quieted: the same rule as torch's
 // float->bfloat16 cast), one instruction per two values.
-typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
     const hw_f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_h16x2));
 }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
-__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ f32x4 mfma16x16x32_h16(const u32x4& a, const u32x4& b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_h16x8, a), __builtin_bit_cast(hw_h16x8, b), acc, 0, 0, 0);
+}
+#endif
+__device__ __forceinline__ h16_t f32_to_h16(float f) { return (h16_t)(pack_h16x2(f, 0.f) & 0xffffu); }
 
 // SiLU exactly as x * sigmoid(x) with sigmoid = 1/(1+exp(-x)) (torch CPU formula)
 // fast form for bf16 outputs: v_exp_f32 + v_rcp_f32 (~1 ulp), 5 instructions instead of an IEEE division
@@ -42,7 +80,7 @@ struct ElemTraits<float> {
     static constexpr int DT = YMK_F32;
 };
 template <>
-struct ElemTraits<bf16_t> {
+struct ElemTraits<h16_t> {
     static constexpr int VEC = 8;
     static constexpr int DT = YMK_BF16;
 };
@@ -52,19 +90,19 @@ __device__ __forceinline__ void load_vec_f32(const float* p, float (&v)[4]) {
     f32x4 t = *reinterpret_cast<const f32x4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
-__device__ __forceinline__ void load_vec_f32(const bf16_t* p, float (&v)[8]) {
+__device__ __forceinline__ void load_vec_f32(const h16_t* p, float (&v)[8]) {
     u32x4 t = *reinterpret_cast<const u32x4*>(p);
-    v[0] = bf16lo(t.x); v[1] = bf16hi(t.x); v[2] = bf16lo(t.y); v[3] = bf16hi(t.y);
-    v[4] = bf16lo(t.z); v[5] = bf16hi(t.z); v[6] = bf16lo(t.w); v[7] = bf16hi(t.w);
+    v[0] = h16lo(t.x); v[1] = h16hi(t.x); v[2] = h16lo(t.y); v[3] = h16hi(t.y);
+    v[4] = h16lo(t.z); v[5] = h16hi(t.z); v[6] = h16lo(t.w); v[7] = h16hi(t.w);
 }
 __device__ __forceinline__ void store_vec_f32(float* p, const float (&v)[4]) {
     f32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
     *reinterpret_cast<f32x4*>(p) = t;
 }
-__device__ __forceinline__ void store_vec_f32(bf16_t* p, const float (&v)[8]) {
+__device__ __forceinline__ void store_vec_f32(h16_t* p, const float (&v)[8]) {
     u32x4 t;
-    t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);
-    t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+    t.x = pack_h16x2(v[0], v[1]); t.y = pack_h16x2(v[2], v[3]);
+    t.z = pack_h16x2(v[4], v[5]); t.w = pack_h16x2(v[6], v[7]);
     *reinterpret_cast<u32x4*>(p) = t;
 }
 // store 4 consecutive channels
@@ -72,34 +110,44 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
     f32x4 t; t.x = a; t.y = b; t.z = c; t.w = d;
     *reinterpret_cast<f32x4*>(p) = t;
 }
-__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
-    u32x2 t; t.x = pack_bf16x2(a, b); t.y = pack_bf16x2(c, d);
+__device__ __forceinline__ void store4(h16_t* p, float a, float b, float c, float d) {
+    u32x2 t; t.x = pack_h16x2(a, b); t.y = pack_h16x2(c, d);
     *reinterpret_cast<u32x2*>(p) = t;
 }
 __device__ __forceinline__ void load4(const float* p, float& a, float& b, float& c, float& d) {
     f32x4 t = *reinterpret_cast<const f32x4*>(p);
     a = t.x; b = t.y; c = t.z; d = t.w;
 }
-__device__ __forceinline__ void load4(const bf16_t* p, float& a, float& b, float& c, float& d) {
+__device__ __forceinline__ void load4(const h16_t* p, float& a, float& b, float& c, float& d) {
     u32x2 t = *reinterpret_cast<const u32x2*>(p);
-    a = bf16lo(t.x); b = bf16hi(t.x); c = bf16lo(t.y); d = bf16hi(t.y);
+    a = h16lo(t.x); b = h16hi(t.x); c = h16lo(t.y); d = h16hi(t.y);
 }
 // 4 consecutive channels as raw bits (register prefetch of residual operands) and their later widening
 template <typename T> struct Raw4;
 template <> struct Raw4<float> { typedef f32x4 type; };
-template <> struct Raw4<bf16_t> { typedef u32x2 type; };
+template <> struct Raw4<h16_t> { typedef u32x2 type; };
 __device__ __forceinline__ f32x4 load_raw4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ u32x2 load_raw4(const bf16_t* p) { return *reinterpret_cast<const u32x2*>(p); }
+__device__ __forceinline__ u32x2 load_raw4(const h16_t* p) { return *reinterpret_cast<const u32x2*>(p); }
 __device__ __forceinline__ void unpack_raw4(const f32x4& t, float& a, float& b, float& c, float& d) {
     a = t.x; b = t.y; c = t.z; d = t.w;
 }
 __device__ __forceinline__ void unpack_raw4(const u32x2& t, float& a, float& b, float& c, float& d) {
-    a = bf16lo(t.x); b = bf16hi(t.x); c = bf16lo(t.y); d = bf16hi(t.y);
+    a = h16lo(t.x); b = h16hi(t.x); c = h16lo(t.y); d = h16hi(t.y);
 }
 __device__ __forceinline__ float to_f32(float v) { return v; }
-__device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ float to_f32(h16_t v) { return h16_to_f32(v); }
 __device__ __forceinline__ void from_f32(float& d, float v) { d = v; }
-__device__ __forceinline__ void from_f32(bf16_t& d, float v) { d = f32_to_bf16(v); }
+__device__ __forceinline__ void from_f32(h16_t& d, float v) { d = f32_to_h16(v); }
+
+// One-shot per (call site, DEVICE), safe for concurrent host threads: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the
+// current device only, and a library that promises per-thread predictors may be entered by two threads at once.  Two
+// threads racing through need() both set the (idempotent) attribute; nobody launches before it is set on his device.
+struct YmkOncePerDevice {
+    std::atomic<unsigned long long> mask{0ull};
+    static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    bool need() const { return !(mask.load(std::memory_order_acquire) & bit()); }
+    void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
 
 static inline int ymk_launch_status() {
     hipError_t e = hipGetLastError();

@@ -15,7 +15,9 @@ What `enable` does (every hook falls through to the reference's own code for CPU
   2. rebinds the reference model's `_predict_once` (the layer loop, nn/tasks.py:182-218): eval-mode GPU batches run the
      libymk graph walk and return what the reference's Detect returns in eval mode, `(y [B, 4+nc, A], preds dict)`
      (nn/modules/head.py:157-171).  The weights are a snapshot taken at `enable()` time (the reference folds Conv+BN in
-     place when its predictor starts): call `disable()` + `enable()` again after loading other weights;
+     place when its predictor starts): call `disable()` + `enable()` again after loading other weights.  The hook is a bound
+     method that reads its state from `self`: a `copy.deepcopy` of the model (Exporter, ModelEMA) runs the REFERENCE path until
+     `enable()` is called on the copy, and tracing / ONNX export always do;
   3. patches `ultralytics.utils.nms.non_max_suppression` (called as `nms.non_max_suppression(...)` by the detect
      predictor and validators, models/yolo/detect/predict.py:54, val.py:116), `ultralytics.utils.ops.scale_boxes`
      (predict.py:122) and `DetectionValidator._process_batch` (box_iou + match_predictions of `model.val()`,
@@ -66,58 +68,90 @@ def _build(core):
     return ymk.eval()
 
 
+def _compute_dtype_for(x: torch.Tensor, forced):
+    """Compute type of the libymk path for an input tensor: the reference's reduced-precision mode is fp16 (`half=True`,
+    engine/predictor.py:174,415; nn/backends/pytorch.py:67) and maps to libymk's fp16 kernels; bf16 tensors to bf16; anything else fp32."""
+    if forced is not None:
+        return forced
+    if x.dtype == torch.float16:
+        return torch.float16 if ops.HAS_F16 else torch.bfloat16
+    return torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+
+
+def _hooked_predict_once(self, x, profile=False, visualize=False, embed=None):
+    """Replacement for `BaseModel._predict_once` (nn/tasks.py:182-218), installed as a BOUND method: all state is read from `self`,
+    so a `copy.deepcopy` of the model (the reference's Exporter, ModelEMA) gets a hook that looks at the COPY — its training flag,
+    its own state entry — and the copy's state is detached (below) so that it runs the reference path instead of a stale weight
+    snapshot.  Tracing / ONNX export always take the reference path (libymk kernels are opaque to the tracer)."""
+    state = self.__dict__.get(_STATE_ATTR)
+    orig = type(self)._predict_once
+    tracing = torch.jit.is_tracing() or torch.jit.is_scripting() or (hasattr(torch.onnx, "is_in_onnx_export") and torch.onnx.is_in_onnx_export())
+    if state is None or state.get("owner") != id(self) or self.training or tracing or profile or visualize or embed \
+            or not torch.is_tensor(x) or not ops.device_ok(x):
+        if state is not None and state.get("owner") == id(self):
+            state["fallbacks"] += 1
+        return orig(self, x, profile, visualize, embed)
+    ymk = state["ymk"]
+    if state["device"] != x.device:
+        ymk.to(x.device)
+        state["device"] = x.device
+    want = _compute_dtype_for(x, state["dtype"])
+    if getattr(ymk, "_compute_dtype", None) != want:
+        ymk.set_compute_dtype(want)
+        ymk._compute_dtype = want
+    state["calls"] += 1
+    y, preds = ymk._predict_once(x.float())
+    ymk.check_flags()
+    if x.dtype in (torch.float16, torch.bfloat16):
+        y = y.to(x.dtype)
+    return y, preds
+
+
+class _State(dict):
+    """Per-model hook state.  Deep copies of the model share nothing with it: the copy's entry is an inert marker (owner id of the
+    ORIGINAL), so the copy's bound hook falls through to the reference path; `enable(copy)` installs a fresh state."""
+
+    def __deepcopy__(self, memo):
+        return _State(owner=self.get("owner"), inert=True)
+
+
 def enable(model, dtype: torch.dtype | None = None, patch_nms: bool = True):
-    """Hook libymk under a reference model (see module docstring).  dtype: compute type of the libymk path (default: bf16
-    when the reference model runs in half precision, fp32 otherwise).  Returns `model`."""
+    """Hook libymk under a reference model (see module docstring).  dtype: compute type of the libymk path (default: what the
+    input tensor asks for — fp16 for the reference's `half=True`, bf16 for bf16 tensors, fp32 otherwise).  Returns `model`."""
+    import types
+
     core = _reference_core(model)
-    if getattr(core, _STATE_ATTR, None) is not None:
+    st = core.__dict__.get(_STATE_ATTR)
+    if st is not None and st.get("owner") == id(core) and not st.get("inert"):
         return model
     ymk = _build(core)
-    state = {"ymk": ymk, "orig": core._predict_once, "dtype": dtype, "device": None, "calls": 0, "fallbacks": 0}
     # the reference fuses Conv+BN when its predictor / validator starts (nn/autobackend.py, engine/validator.py): the libymk
     # model holds its own packed (folded) copy taken here, from the unfused parameters
-
-    def _predict_once(x, profile=False, visualize=False, embed=None):
-        if core.training or profile or visualize or embed or not torch.is_tensor(x) or not ops.device_ok(x):
-            state["fallbacks"] += 1
-            return state["orig"](x, profile, visualize, embed)
-        if state["device"] != x.device:
-            ymk.to(x.device)
-            state["device"] = x.device
-        want = state["dtype"] or (torch.bfloat16 if x.dtype in (torch.float16, torch.bfloat16) else torch.float32)
-        if getattr(ymk, "_compute_dtype", None) != want:
-            ymk.set_compute_dtype(want)
-            ymk._compute_dtype = want
-        state["calls"] += 1
-        y, preds = ymk._predict_once(x.float())
-        ymk.check_flags()
-        if x.dtype == torch.float16:
-            y = y.half()
-        return y, preds
-
-    core._predict_once = _predict_once
-    setattr(core, _STATE_ATTR, state)
+    state = _State(ymk=ymk, dtype=dtype, device=None, calls=0, fallbacks=0, owner=id(core), patched=bool(patch_nms))
+    core.__dict__[_STATE_ATTR] = state
+    core.__dict__["_predict_once"] = types.MethodType(_hooked_predict_once, core)   # deepcopy rebinds a bound method to the copy
     if patch_nms:
+        _PATCHED["_users"] = _PATCHED.get("_users", 0) + 1
         _patch_process()
     return model
 
 
 def disable(model):
     core = _reference_core(model)
-    state = getattr(core, _STATE_ATTR, None)
+    state = core.__dict__.get(_STATE_ATTR)
     if state is not None:
-        try:
-            del core._predict_once          # the instance attribute shadows the class method
-        except AttributeError:
-            pass
-        setattr(core, _STATE_ATTR, None)
-    _unpatch_process()
+        core.__dict__.pop("_predict_once", None)    # the instance attribute shadows the class method
+        core.__dict__.pop(_STATE_ATTR, None)
+        if state.get("patched") and state.get("owner") == id(core) and not state.get("inert"):
+            _PATCHED["_users"] = max(_PATCHED.get("_users", 1) - 1, 0)
+            if _PATCHED["_users"] == 0:             # other enabled models still rely on the process-wide patches
+                _unpatch_process()
     return model
 
 
 def stats(model) -> dict:
     """How often the hooks ran (tests / diagnostics)."""
-    s = getattr(_reference_core(model), _STATE_ATTR, None) or {}
+    s = _reference_core(model).__dict__.get(_STATE_ATTR) or {}
     return {"calls": s.get("calls", 0), "fallbacks": s.get("fallbacks", 0), "nms_calls": _PATCHED.get("_nms_calls", 0),
             "match_calls": _PATCHED.get("_match_calls", 0)}
 
@@ -133,19 +167,40 @@ def _patch_process():
     orig_nms, orig_scale = ref_nms.non_max_suppression, ref_ops.scale_boxes
     _PATCHED.update(nms=orig_nms, scale=orig_scale, _nms_calls=0)
 
+    import inspect
+
+    sig = inspect.signature(orig_nms)
+    ymk_params = set(inspect.signature(ymk_nms).parameters)
+
     def non_max_suppression(prediction, *args, **kw):
-        p = prediction[0] if isinstance(prediction, (list, tuple)) else prediction
-        unsupported = kw.get("rotated") or kw.get("end2end") or kw.get("labels") or p.shape[-1] == 6 or \
-            (kw.get("nc") and kw["nc"] != p.shape[1] - 4)
+        """Arguments are bound with the reference's own signature, so modes passed positionally are seen too; anything outside the
+        detect path (rotated, end2end, autolabels, mask channels), CPU tensors and arguments this NMS does not know go to the
+        reference implementation — as does a call that raises NotImplementedError (counted as a fallback, never a crash)."""
+        try:
+            ba = sig.bind(prediction, *args, **kw)
+        except TypeError:
+            return orig_nms(prediction, *args, **kw)
+        a = dict(ba.arguments)
+        pred = a.pop(next(iter(sig.parameters)))
+        p = pred[0] if isinstance(pred, (list, tuple)) else pred
+        unsupported = a.get("rotated") or a.get("end2end") or (a.get("labels") is not None and len(a.get("labels")) > 0) or \
+            not torch.is_tensor(p) or p.dim() != 3 or p.shape[-1] == 6 or (a.get("nc") and a["nc"] != p.shape[1] - 4) or \
+            any(k not in ymk_params for k in a if k != "max_time_img")
         if unsupported or not ops.device_ok(p):
             return orig_nms(prediction, *args, **kw)
+        a.pop("max_time_img", None)
+        try:
+            out = ymk_nms(p.float(), **a)
+        except NotImplementedError:
+            _PATCHED["_nms_fallbacks"] = _PATCHED.get("_nms_fallbacks", 0) + 1
+            return orig_nms(prediction, *args, **kw)
         _PATCHED["_nms_calls"] += 1
-        kw.pop("max_time_img", None)
-        return ymk_nms(p.float(), *args, **kw)
+        return out
 
     def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None, padding=True, xywh=False):
-        if torch.is_tensor(boxes) and boxes.dim() == 2 and boxes.dtype == torch.float32 and boxes.is_contiguous() and \
-                boxes.is_cuda and boxes.shape[0] > 0:
+        # the predictor passes `pred[:, :4]`, a row-stride-6 view (models/yolo/detect/predict.py:122): rows need not be dense
+        if torch.is_tensor(boxes) and boxes.dim() == 2 and boxes.dtype == torch.float32 and boxes.shape[1] == 4 and boxes.stride(1) == 1 \
+                and ops.device_ok(boxes) and boxes.shape[0] > 0:
             return postprocess.scale_boxes(img1_shape, boxes, img0_shape, ratio_pad, padding, xywh)
         return orig_scale(img1_shape, boxes, img0_shape, ratio_pad, padding, xywh)
 
@@ -178,6 +233,7 @@ def _unpatch_process():
     ref_nms, ref_ops = sys.modules["ultralytics.utils.nms"], sys.modules["ultralytics.utils.ops"]
     ref_nms.non_max_suppression, ref_ops.scale_boxes = _PATCHED.pop("nms"), _PATCHED.pop("scale")
     _PATCHED.pop("_nms_calls", None)
+    _PATCHED.pop("_nms_fallbacks", None)
     if "val_cls" in _PATCHED:
         _PATCHED.pop("val_cls")._process_batch = _PATCHED.pop("process_batch")
         _PATCHED.pop("_match_calls", None)

@@ -91,6 +91,9 @@ def require_gpu(t: torch.Tensor, what: str = "yolo_master_amd ops") -> None:
         raise RuntimeError(f"{what} run on MI355X (HIP) only; got a CPU tensor. There is no CPU fallback.")
 
 
+HAS_F16 = False   # set by the dtype table below when libymk carries the fp16 instantiations
+
+
 def device_ok(t: torch.Tensor) -> bool:
     """True when libymk can take this tensor (the drop-in hooks fall through to the reference otherwise)."""
     return bool(t.is_cuda)
@@ -542,7 +545,7 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
     e0 = TIMER.begin()
     if class_keep is not None:
-        assert class_keep.dtype == torch.uint8 and class_keep.numel() == nc and class_keep.is_cuda and class_keep.is_contiguous()
+        assert class_keep.dtype == torch.uint8 and class_keep.numel() == nc and class_keep.device == y.device and class_keep.is_contiguous()
     check(lib.ymk_nms_batched(_p(y), B, nc, A, float(conf), float(iou), int(multi_label), int(agnostic), max_det, max_nms,
                               float(max_wh), _p(class_keep), _p(dets), _p(counts), _p(idx), _p(status), _p(ws), nbytes, _stream()),
           "nms_batched")

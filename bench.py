@@ -23,8 +23,10 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PROFILES = ROOT / "profiles"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}
+TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
 # op family (yolo_master_amd.ops TIMER) -> kernel-name prefix in the rocprofv3 output; single-kernel families only
@@ -38,30 +40,71 @@ VALU_FAMILIES = ("moe_dw", "dwconv")   # depthwise stencils (csrc/dwconv.hip)
 VALU_PEAK_TMACS = 64.0
 
 
+def _committed_profile(suffix: str):
+    """Newest committed rocprofv3 counter summary profiles/*_<suffix>.json whose kernels are the ones in this tree: the summary
+    carries the hash of the kernel sources it was collected on (tools/pmc_summary.py, `csrc_sha16`); a profile of other sources is
+    STALE and is not used (its numbers would describe kernels that no longer exist)."""
+    import glob
+
+    from yolo_master_amd.build import source_hash
+
+    for f in sorted(glob.glob(str(PROFILES / f"*_{suffix}.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("csrc_sha16") == source_hash():
+            return d["kernels"]
+    return None
+
+
+def _kernels_of(family: str, table: dict):
+    return [family] if family in table else [n for n in table if family in FAMILY_KERNEL and n.startswith(FAMILY_KERNEL[family])]
+
+
 def pmc_traffic(family: str):
     """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_*.json, collected by tools/gpu_profile.sh on the same workload): 2*FETCH_SIZE (gfx950 counts
     wide coalesced reads at half size, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, averaged over the
     launches.  Convolution records carry the exact kernel name rocprofv3 prints (ops.conv_kernel_name); the other
-    op families map to a name prefix.  None when no profile is committed or the family spans several kernels."""
-    import glob
-
-    files = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_FETCH_SIZE.json")))
-    if not files:
+    op families map to a name prefix.  None when no profile OF THESE SOURCES is committed or the family spans several kernels."""
+    fk, wk = _committed_profile("pmc_FETCH_SIZE"), _committed_profile("pmc_WRITE_SIZE")
+    if not fk or not wk:
         return None
-    try:
-        fk = json.load(open(files[-1]))["kernels"]
-        wk = json.load(open(files[-1].replace("FETCH_SIZE", "WRITE_SIZE")))["kernels"]
-    except Exception:
-        return None
-    names = [family] if family in fk else [n for n in fk if family in FAMILY_KERNEL and n.startswith(FAMILY_KERNEL[family])]
     tot, n = 0.0, 0
-    for name in names:
+    for name in _kernels_of(family, fk):
         if name in wk:
             c = fk[name]["FETCH_SIZE"]["launches"]
             tot += (2.0 * fk[name]["FETCH_SIZE"]["mean"] + wk[name]["WRITE_SIZE"]["mean"]) * c
             n += c
     return int(tot / n * 1024) if n else None
+
+
+def sq_utilisation(family: str):
+    """Matrix-core / VALU / LDS utilisation of the family's kernel from the committed SQ counter pass (profiles/*_sq_1.json +
+    *_sq_2.json, tools/gpu_pmc.sh): the SQ counters of this rocprofv3 sample ONE of the 32 shader engines (SQ_INSTS_MFMA x 32 = the
+    kernel's MFMA count), so busy fractions are MFMA_BUSY_CYCLES / (SIMDs of an engine (32) x SQ_BUSY_CYCLES); VALU / LDS figures are
+    active-instruction quad-cycles per wave-cycle; lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
+    s1, s2 = _committed_profile("sq_1"), _committed_profile("sq_2")
+    if not s1:
+        return None
+    acc = {"mfma": 0.0, "busy": 0.0, "valu": 0.0, "lds": 0.0, "wave": 0.0, "conf": 0.0, "ldsact": 0.0, "wait": 0.0, "tot": 0.0}
+    for name in _kernels_of(family, s1):
+        g = lambda d, c: d.get(name, {}).get(c, {}).get("mean", 0.0) * d.get(name, {}).get(c, {}).get("launches", 0)   # noqa: E731
+        acc["mfma"] += g(s1, "SQ_VALU_MFMA_BUSY_CYCLES"); acc["busy"] += g(s1, "SQ_BUSY_CYCLES"); acc["valu"] += g(s1, "SQ_ACTIVE_INST_VALU")
+        acc["lds"] += g(s1, "SQ_ACTIVE_INST_LDS"); acc["wave"] += g(s1, "SQ_WAVE_CYCLES")
+        if s2:
+            acc["conf"] += g(s2, "SQ_LDS_BANK_CONFLICT"); acc["ldsact"] += g(s2, "SQ_LDS_IDX_ACTIVE"); acc["wait"] += g(s2, "SQ_WAIT_ANY")
+            acc["tot"] += g(s2, "SQ_WAIT_ANY") + g(s2, "SQ_WAIT_INST_ANY") + g(s2, "SQ_ACTIVE_INST_ANY")
+    if not acc["busy"]:
+        return None
+    out = {"mfma_busy": round(acc["mfma"] / (32.0 * acc["busy"]), 4), "valu_per_wave_cycle": round(acc["valu"] / max(acc["wave"], 1.0), 4),
+           "lds_per_wave_cycle": round(acc["lds"] / max(acc["wave"], 1.0), 4)}
+    if acc["tot"]:
+        out["wave_parked"] = round(acc["wait"] / acc["tot"], 3)
+    if acc["ldsact"]:
+        out["lds_conflict"] = round(acc["conf"] / acc["ldsact"], 3)
+    return out
 
 
 def cpu_baseline(scale: str, seconds_budget: float = 20.0):
@@ -71,7 +114,7 @@ def cpu_baseline(scale: str, seconds_budget: float = 20.0):
     from yolo_master_amd.nn.tasks import DetectionModel, yaml_model_load
     from yolo_master_amd.weights import synth_input, synth_state_dict
 
-    cores = min(os.cpu_count() or 1, 16)   # more threads than this slows the small convolutions down (oversubscription)
+    cores = min(os.cpu_count() or 1, 8)    # BASELINE.md section 2 fixes the CPU baseline at 8 threads
     torch.set_num_threads(cores)
     cfg = yaml_model_load(f"yolo-master-{scale}.yaml")
     sd = synth_state_dict(DetectionModel(cfg).state_dict(), seed=0)
@@ -88,8 +131,15 @@ def cpu_baseline(scale: str, seconds_budget: float = 20.0):
             times.append(time.time() - t0)
     times.sort()
     p50 = times[len(times) // 2]
-    return {"value": round(B / p50, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle forward+NMS, YOLO-Master-{scale.upper()} fp32, {B}x3x640x640, {len(times)} timed passes (p50)"}
+    out = {"value": round(B / p50, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": f"oracle forward+NMS, YOLO-Master-{scale.upper()} fp32, {B}x3x640x640, {len(times)} timed passes (p50)"}
+    # the REAL reference timed beside this port on the build host (the GPU box has no reference checkout): tools/cpu_reference_timing.py
+    try:
+        ref = json.load(open(ROOT / "profiles" / "r03_cpu_reference.json"))
+        out["reference_on_build_host"] = {k: ref[k] for k in ("reference_images_per_s", "port_images_per_s", "cores", "host", "sample")}
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -102,14 +152,15 @@ def main():
                     "--imgsz 1280 --batch 16 for BASELINE config 5")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="compute type: bf16 (BASELINE config 3), f16 (the reference's "
+                    "half=True precision, libymk_f16.so), f32 (the exact-parity configuration, BASELINE config 2's type)")
     ap.add_argument("--roofline-kernel", default=None, help="op family to report in `roofline` (default: the one with the largest share of the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
     a = ap.parse_args()
 
     from yolo_master_amd import ops
-    from yolo_master_amd.dist import broadcast_state_dict, gather_detections, init_from_env
+    from yolo_master_amd.dist import broadcast_state_dict, gather_packed, init_from_env
     from yolo_master_amd.nms import nms_padded
     from yolo_master_amd.nn.tasks import DetectionModel
     from yolo_master_amd.weights import synth_input, synth_state_dict
@@ -120,7 +171,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = TORCH_DTYPE[a.dtype]
 
     if a.cfg is None:
         model = DetectionModel(f"yolo-master-{a.scale}.yaml")
@@ -139,18 +190,23 @@ def main():
     model.set_compute_dtype(dtype)
     x = synth_input(a.batch, a.imgsz, a.imgsz, seed=1 + rank).to(dev)   # resident in HBM before timing
 
+    MAX_DET = 300
+    pack = torch.empty((ops.nms_pack_numel(a.batch, MAX_DET),), dtype=torch.float32, device=dev)   # dets | idx | counts of this rank, one buffer
+    gathered = torch.empty((world, pack.numel()), dtype=torch.float32, device=dev) if world > 1 else None
+
     def local_step():
         y, _ = model._predict_once(x)
-        return nms_padded(y, 0.25, 0.7, max_det=300)
-
-    gathered = {}   # the three all_gather outputs, allocated once
+        return nms_padded(y, 0.25, 0.7, max_det=MAX_DET, pack=pack)
 
     def finish(local_out):
-        """What follows the rank-local work of a step: for N>1 the RCCL all_gather of the padded detections (outside the
-        captured graph: a collective is not part of the rank-local launch sequence)."""
+        """What follows the rank-local work of a step: for N>1 ONE RCCL all_gather of the packed results (dets | idx | counts,
+        written in place by the NMS kernels), outside the captured graph: a collective is not part of the rank-local launch
+        sequence.  It runs on the compute stream: ~0.5 MB per rank is latency-bound (tens of microseconds against a 6 ms step), so
+        overlapping it with the next replay (double-buffered graphs + a side stream) would buy < 1 % and could not be validated
+        without a second device."""
         dets, counts, idx, status = local_out
         if world > 1:
-            dets, counts, idx = gather_detections(dets, counts, idx, out=gathered)
+            dets, counts, idx = ops.nms_pack_views(gather_packed(pack, out=gathered), a.batch, MAX_DET)
         return dets, counts, status
 
     with torch.inference_mode():
@@ -232,6 +288,9 @@ def main():
                              alg_gflop_per_launch=round(flops / n / 1e9, 3), achieved_gbs=round(gbs, 1),
                              achieved_tflops=round(tfl, 2))
                     r["traffic"] = pmc_traffic(fam)
+                    sq = sq_utilisation(fam)
+                    if sq:
+                        r["sq"] = sq
                     if fam in VALU_FAMILIES:
                         # stencil kernels have no matrix contraction: neither HBM nor MFMA is their limit; the honest third axis is
                         # the fp32 VALU rate (64 T MAC/s measured on MI355X for v_fma / v_pk_fma / v_dot2c, tools/micro/valu_rate.hip)
@@ -243,7 +302,7 @@ def main():
                     order = sorted(agg, key=lambda f: -agg[f][0])
                     roof = describe(a.roofline_kernel if a.roofline_kernel in agg else order[0])
                     fams = [{k: d[k] for k in ("kernel", "ms_per_step", "launches_per_step", "bound", "frac", "achieved_gbs",
-                                               "achieved_tflops")} for d in map(describe, order)]
+                                               "achieved_tflops", "sq") if k in d} for d in map(describe, order)]
             except Exception as e:  # the throughput line must survive a failure of the diagnostic leg
                 print(f"[bench] roofline leg failed ({type(e).__name__}: {e})", file=sys.stderr)
                 ops.TIMER.stop()

@@ -130,14 +130,14 @@ def pytest_runtest_logreport(report):
 
 
 def pytest_runtest_protocol(item, nextitem):
-    """CPU-side tests get ONE retry (rendezvous ports, process spawning and compiler invocations can fail
-    transiently on a busy host); a test has to fail twice to be reported as failed, and every retry is printed.
-    GPU parity tests are never retried.  Disable with YMK_NO_RERUN=1."""
+    """ONLY the multi-process rendezvous tests (tests/test_dist_gloo.py: spawned gloo workers on an OS-picked port) get one retry,
+    and every retry is printed; no parity, oracle, host-logic or emulator test is ever retried — a failure there is a failure
+    (round-2 review: a blanket retry masked flakes on the suite that stands in for hardware).  Disable with YMK_NO_RERUN=1."""
     import os
 
     from _pytest.runner import runtestprotocol
 
-    if "gpu" in item.keywords or os.environ.get("YMK_NO_RERUN"):
+    if "gpu" in item.keywords or os.environ.get("YMK_NO_RERUN") or item.module.__name__.rsplit(".", 1)[-1] != "test_dist_gloo":
         return None
     item.ihook.pytest_runtest_logstart(nodeid=item.nodeid, location=item.location)
     reports = runtestprotocol(item, nextitem=nextitem, log=False)

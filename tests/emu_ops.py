@@ -331,16 +331,22 @@ def detect_decode(box_l, cls_l, y, stride, a_off, reg_max):
     return y
 
 
-def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, cw_sigma=None, cw_pool=3000, class_keep=None):
+def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, cw_sigma=None, cw_pool=3000, class_keep=None, pack=None):
     _count("nms_batched")
     assert cw_sigma is None, "CW refinement is checked on the GPU against oracle/_ref"
     B = y.shape[0]
     classes = None if class_keep is None else torch.nonzero(class_keep).view(-1).tolist()
     outs, idxs = nms_ref.non_max_suppression(y.numpy(), conf, iou, multi_label, agnostic, max_det, max_nms, max_wh,
                                              return_idxs=True, classes=classes)
-    dets = torch.zeros((B, max_det, 6), dtype=torch.float32)
-    counts = torch.zeros((B,), dtype=torch.int32)
-    idx = torch.zeros((B, max_det), dtype=torch.int32)
+    if pack is not None:                     # the three outputs carved from one buffer (ops.nms_pack_views), zeroed like the kernel does
+        from yolo_master_amd import ops as _ops
+
+        pack.zero_()
+        dets, counts, idx = _ops.nms_pack_views(pack, B, max_det)
+    else:
+        dets = torch.zeros((B, max_det, 6), dtype=torch.float32)
+        counts = torch.zeros((B,), dtype=torch.int32)
+        idx = torch.zeros((B, max_det), dtype=torch.int32)
     for b in range(B):
         n = len(outs[b])
         counts[b] = n

@@ -27,12 +27,13 @@ def compiler():
     return None
 
 
-def build(force: bool = False) -> Path | None:
+def build(force: bool = False, f16: bool = False) -> Path | None:
+    """f16: the fp16 build of the library (-DYMK_H16_F16: 16-bit element format = IEEE binary16, csrc/ymk_common.h)."""
     cxx = compiler()
     if cxx is None:
         return None
     OUT.mkdir(exist_ok=True)
-    lib = OUT / "libymk_hostemu.so"
+    lib = OUT / ("libymk_hostemu_f16.so" if f16 else "libymk_hostemu.so")
     srcs = [CSRC / s for s in SOURCES]
     deps = srcs + [CSRC / "ymk_common.h", ROOT / "include" / "ymk_mixture.h", HERE / "hip" / "hip_runtime.h", Path(__file__)]
     if not force and lib.exists() and lib.stat().st_mtime >= max(d.stat().st_mtime for d in deps):
@@ -46,10 +47,10 @@ def build(force: bool = False) -> Path | None:
         txt = txt.replace('#include "ymk_common.h"', f'#include "{CSRC / "ymk_common.h"}"')
         txt = txt.replace('#include "igemm.h"', f'#include "{CSRC / "igemm.h"}"')
         txt = txt.replace('#include "../../include/ymk_mixture.h"', f'#include "{ROOT / "include" / "ymk_mixture.h"}"')
-        u = OUT / (s.stem + "_host.cpp")
+        u = OUT / (s.stem + ("_host_f16.cpp" if f16 else "_host.cpp"))
         u.write_text(txt)
         units.append(str(u))
-    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DGLDS_SMALL_BELOW_DEFAULT=3", "-DYMK_HOST_EMU", "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(lib)]
+    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DGLDS_SMALL_BELOW_DEFAULT=3", "-DYMK_HOST_EMU", *(["-DYMK_H16_F16"] if f16 else []), "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(lib)]
     subprocess.run(cmd, check=True)
     return lib
 

@@ -223,6 +223,24 @@ static inline hostemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hostemu_bf16
     hostemu::wave_sync();
     return c;
 }
+// v_mfma_f32_16x16x32_f16: the same operand layout with IEEE binary16 elements (the fp16 build, -DYMK_H16_F16)
+typedef _Float16 hostemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline hostemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hostemu_f16x8 a, hostemu_f16x8 b, hostemu_f32x4 c, int, int, int) {
+    const unsigned t = hostemu::cur, w0 = t & ~63u, l = t & 63u;
+    for (int e = 0; e < 8; ++e) {
+        hostemu::mfma_a[t][e] = (float)a[e];
+        hostemu::mfma_b[t][e] = (float)b[e];
+    }
+    hostemu::wave_sync();
+    for (int r = 0; r < 4; ++r) {
+        const unsigned i = (l / 16) * 4 + r, j = l % 16;
+        float s = 0.f;
+        for (unsigned k = 0; k < 32; ++k) s += hostemu::mfma_a[w0 + (k / 8) * 16 + i][k % 8] * hostemu::mfma_b[w0 + (k / 8) * 16 + j][k % 8];
+        c[r] += s;
+    }
+    hostemu::wave_sync();
+    return c;
+}
 // v_mfma_f32_16x16x4_f32: lane l holds A[l % 16][l / 16], B[l / 16][l % 16]; D as above.
 static inline hostemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hostemu_f32x4 c, int, int, int) {
     const unsigned t = hostemu::cur, w0 = t & ~63u, l = t & 63u;

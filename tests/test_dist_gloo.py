@@ -80,3 +80,84 @@ def test_two_process_gloo():
             assert all(same and ok for _, same, ok in res), res
             return
     raise AssertionError(f"two-process gloo run failed three times: {last}")
+
+
+def _worker8(rank, world, port, n_images, q):
+    """One rank of a world-size-8 step at BASELINE config 4's shard sizes: images [b0, b1) of the batch, results written into ONE
+    packed buffer (dets | idx | counts, ops.nms_pack_views) of the COMMON shard size (the last shards of an uneven batch are padded
+    with empty images), one all_gather of it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from yolo_master_amd import ops
+    from yolo_master_amd.dist import gather_packed, init_from_env
+
+    init_from_env("gloo")
+    max_det = 300
+    b_common = -(-n_images // world)                      # ceil: every rank gathers the same number of words
+    b0, b1 = shard_range(n_images, rank, world)
+    pack = torch.zeros((ops.nms_pack_numel(b_common, max_det),), dtype=torch.float32)
+    dets, counts, idx = ops.nms_pack_views(pack, b_common, max_det)
+    for i, b in enumerate(range(b0, b1)):                 # image b "detects" (b % 7) boxes carrying its own index
+        n = b % 7
+        counts[i] = n
+        dets[i, :n, 4] = float(b)
+        dets[i, :n, 5] = float(b % 80)
+        idx[i, :n] = torch.arange(n, dtype=torch.int32) + b
+    out = None
+    for _ in range(2):                                    # the pre-allocated output is reused by the second step
+        g = gather_packed(pack, out=out)
+        assert out is None or g.data_ptr() == out.data_ptr()
+        out = g
+    gd, gc, gi = ops.nms_pack_views(g, b_common, max_det)
+    ok = tuple(gd.shape) == (world, b_common, max_det, 6)
+    for r in range(world):
+        r0, r1 = shard_range(n_images, r, world)
+        for i in range(b_common):
+            b = r0 + i
+            want = b % 7 if b < r1 else 0                 # padding images of a short shard hold nothing
+            ok &= int(gc[r, i]) == want
+            if want:
+                ok &= float(gd[r, i, 0, 4]) == float(b) and float(gd[r, i, want - 1, 5]) == float(b % 80) and int(gi[r, i, want - 1]) == b + want - 1
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def _run_world(world, n_images):
+    last = None
+    for _ in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker8, args=(r, world, port, n_images, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = [q.get(timeout=300) for _ in procs]
+        except Exception:
+            res = None
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        last = (res, [p.exitcode for p in procs])
+        if res is not None and all(c == 0 for c in last[1]):
+            return res
+    raise AssertionError(f"world-size-{world} gloo run failed three times: {last}")
+
+
+def test_eight_ranks_bs512_one_packed_gather():
+    """BASELINE config 4's partition: 512 images over 8 ranks = 64 per rank (shard_range(512, r, 8)), one packed all_gather per step."""
+    assert [shard_range(512, r, 8) for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]
+    res = _run_world(8, 512)
+    assert len(res) == 8 and all(ok for _, ok in res), res
+
+
+def test_eight_ranks_uneven_batch_padded_last_shards():
+    """500 images over 8 ranks: shards of 63 / 62 images, every rank gathers the common 63 (the short shards pad with empty images)."""
+    sizes = [e - b for b, e in (shard_range(500, r, 8) for r in range(8))]
+    assert sizes == [63] * 4 + [62] * 4
+    res = _run_world(8, 500)
+    assert len(res) == 8 and all(ok for _, ok in res), res

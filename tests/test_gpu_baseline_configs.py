@@ -3,8 +3,9 @@
 * config 2 — YOLO-Master-N, 32 x 3 x 640 x 640, fp32: routing decisions, NMS kept anchor indices and classes bit-exact;
   scores within 1e-4; boxes within 1e-4 in the unit the network regresses (DFL bins = pixels / anchor stride);
   every layer's activations within 1e-4.  No noise-relative escape, no overlap-ratio fallback.
-* config 3 — YOLO-Master-S, 64 x 3 x 640 x 640, bf16 (the benchmarked configuration) against the reference's fp32
-  result: routing agreement, score / box error percentiles, kept-set overlap.
+* config 3 — YOLO-Master-S, 64 x 3 x 640 x 640, bf16 (the benchmarked configuration) and fp16 (the reference's half=True
+  precision) against the reference's fp32 result, with the REFERENCE'S OWN 16-bit evaluation as the bar
+  (tests/golden/make_golden_ref16.py): routing agreement, score / box error percentiles, kept-set overlap.
 
 Both use the well-conditioned synthetic weights of tools/make_conditioned.py (cfg/cond_<scale>.npz): with them the
 reference's own fp32 result is 6e-4 px / 2.4e-6 from the exact (fp64) one at 640 x 640, and its discrete decisions
@@ -94,16 +95,24 @@ def test_config2_n_b32_640_fp32_vs_reference(golden_dir):
     print(f"config 2: {nk} kept detections over {B} images identical to the reference (indices, classes)")
 
 
-def test_config3_s_b64_640_bf16_vs_reference_fp32(golden_dir):
-    """The benchmarked configuration.  bf16 storage (8 mantissa bits) through 26 layers cannot meet an fp32 bar; what is
-    asserted is how far the bf16 result sits from the REFERENCE's fp32 one, image by image (bounds = 2x measured on MI355X)."""
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+def test_config3_s_b64_640_16bit_vs_reference(fmt, golden_dir):
+    """The benchmarked configuration, in both 16-bit formats (bf16 = the bench line; f16 = the reference's own `half=True`
+    precision on libymk_f16.so).  A 16-bit evaluation cannot meet an fp32 bar through 26 layers; the bar that CAN be stated is the
+    reference's own: tests/golden/make_golden_ref16.py ran the REAL reference model in fp16 and in bf16 on the same weights and
+    images and recorded how far each sits from the reference's fp32 result (routing agreement, score / box error percentiles on
+    same-routing images, NMS kept-set Jaccard, and the fp32 router margins of every flipped decision).  libymk's 16-bit result must
+    be AT LEAST AS CLOSE to the reference's fp32 result as the reference's own evaluation in that format is (x 1.25 for the
+    percentile estimates: the two evaluations round at different points of the graph)."""
     from yolo_master_amd.nms import non_max_suppression
     from yolo_master_amd.weights import synth_input
 
+    dtype = torch.bfloat16 if fmt == "bf16" else torch.float16
     z = load_npz(golden_dir / "fwd_s640_b64.npz")
+    r16 = load_npz(golden_dir / "ref16_s640_b64.npz")
     B, H, W = int(z["B"]), int(z["H"]), int(z["W"])
-    assert (B, H, W, chr(int(z["scale"]))) == (64, 640, 640, "s")
-    m = _model("s", torch.bfloat16, str(z["calib"]))
+    assert (B, H, W, chr(int(z["scale"]))) == (64, 640, 640, "s") and int(r16["B"]) == B
+    m = _model("s", dtype, str(z["calib"]))
     x = synth_input(B, H, W, seed=int(z["seed"]))
     with torch.inference_mode():
         y, _ = m._predict_once(x.to(DEV))
@@ -111,12 +120,14 @@ def test_config3_s_b64_640_bf16_vs_reference_fp32(golden_dir):
     assert torch.isfinite(y).all()
     same_img = np.ones(B, bool)
     agree, total, rw_err = 0, 0, 0.0
+    flipped = []
     for i in MOE:
         r = m.model[i].last_route
         same = ((r["gate_w"] > 0).cpu().numpy() == z[f"route{i}_retained"]).all(1)
         same_img &= same
         agree, total = agree + int(same.sum()), total + B
         rw_err = max(rw_err, float(np.abs(r["route_w"].cpu().numpy() - z[f"route{i}_route_w"]).max()))
+        flipped += [(int(b), i, float(r16[f"margin::gap{i}"][b]), float(r16[f"margin::thr{i}"][b])) for b in np.nonzero(~same)[0]]
     yc = y.cpu()
     A = yc.shape[2]
     idx = z["y_idx"].astype(np.int64)
@@ -126,22 +137,33 @@ def test_config3_s_b64_640_bf16_vs_reference_fp32(golden_dir):
     sel = same_img[img]                       # samples that lie in images whose four routed expert sets equal the reference's
     ps = np.percentile(err[(ch >= 4) & sel], [50, 99, 100])
     pb = np.percentile(err[(ch < 4) & sel], [50, 99, 100])
-    ps_all = np.percentile(err[ch >= 4], [50, 99, 100])
-    pb_all = np.percentile(err[ch < 4], [50, 99, 100])
     dets, kept = non_max_suppression(y, float(z["conf"]), float(z["iou"]), return_idxs=True)
     jac = []
     for b in range(B):
         a_, b_ = set(kept[b].cpu().numpy().tolist()), set(z[f"nms{b}_idx"].tolist())
         jac.append(len(a_ & b_) / max(len(a_ | b_), 1) if (a_ or b_) else 1.0)
     jac = np.array(jac)
-    print(f"config 3 (bf16 vs reference fp32): routing identical on {agree}/{total} (image, layer) pairs = {int(same_img.sum())}/{B} images, "
-          f"route_w max err {rw_err:.2e}; same-routing images: scores |d| p50 {ps[0]:.2e} p99 {ps[1]:.2e} max {ps[2]:.2e}, boxes px p50 "
-          f"{pb[0]:.2e} p99 {pb[1]:.2e} max {pb[2]:.2e}, kept-set Jaccard median {np.median(jac[same_img]):.3f} min {jac[same_img].min():.3f}; "
-          f"all images: scores p50 {ps_all[0]:.2e} p99 {ps_all[1]:.2e}, boxes p50 {pb_all[0]:.2e} p99 {pb_all[1]:.2e}, Jaccard median "
-          f"{np.median(jac):.3f} min {jac.min():.3f}")
-    assert agree >= 0.8 * total, f"bf16 changed the routed expert set on {total - agree} of {total} (image, layer) pairs"
-    # measured on MI355X (round 2): 225/256 pairs = 49/64 images; same-routing images: scores p50 7.5e-5 p99 3.8e-3, boxes p50 0.14 px
-    # p99 1.3 px, Jaccard median 0.865 (min 0.78); bounds = 2x those
-    assert ps[0] <= 1.5e-4 and ps[1] <= 8e-3, f"scores {ps}"
-    assert pb[0] <= 0.3 and pb[1] <= 2.7, f"boxes {pb}"
-    assert np.median(jac[same_img]) >= 0.75 and jac[same_img].min() >= 0.5, f"kept-set Jaccard {np.median(jac[same_img])} min {jac[same_img].min()}"
+    ref_agree, ref_ps, ref_pb, ref_jac = int(r16[f"{fmt}::agree_pairs"]), r16[f"{fmt}::score_pct"], r16[f"{fmt}::box_pct"], r16[f"{fmt}::jaccard"]
+    ref_same = r16[f"{fmt}::same_img"]
+    print(f"config 3 ({fmt} vs reference fp32) libymk | the reference's own {fmt}: routing identical on {agree} | {ref_agree} of {total} (image, layer) pairs "
+          f"= {int(same_img.sum())} | {int(ref_same.sum())} of {B} images (route_w max err {rw_err:.2e}); same-routing images: scores p50 {ps[0]:.2e} | "
+          f"{ref_ps[0]:.2e}, p99 {ps[1]:.2e} | {ref_ps[1]:.2e}; boxes px p50 {pb[0]:.2e} | {ref_pb[0]:.2e}, p99 {pb[1]:.2e} | {ref_pb[1]:.2e}; kept-set "
+          f"Jaccard median {np.median(jac[same_img]):.3f} | {np.median(ref_jac[ref_same]):.3f}, min {jac[same_img].min():.3f} | {ref_jac[ref_same].min():.3f}")
+    for b, i, gap, thr in flipped:
+        print(f"   flipped: image {b} layer {i}: fp32 router margins: logit gap 2nd-3rd {gap:.2e}, |w2 - 0.4| {thr:.2e}")
+    # Every image's FIRST flipped layer (later ones see a different input) is a near call of the fp32 router itself: its margin is
+    # inside the range in which the reference's own evaluation in this format flips (first-flip margins there: fp16 <= 0.022, bf16 <= 0.051)
+    first = {}
+    for b, i, gap, thr in flipped:
+        if b not in first or i < first[b][0]:
+            first[b] = (i, min(gap, thr))
+    ref_first = {}
+    for b, i, gap, thr in r16[f"{fmt}::flips"]:
+        if b not in ref_first or i < ref_first[b][0]:
+            ref_first[b] = (i, min(gap, thr))
+    lim = 1.5 * max(v[1] for v in ref_first.values())
+    assert all(v[1] <= lim for v in first.values()), f"a routing decision flipped far from the fp32 router's thresholds: {first} (limit {lim:.3f})"
+    assert agree >= ref_agree - 4, f"{fmt}: routing agrees on {agree} pairs; the reference's own {fmt} run on {ref_agree}"
+    assert ps[0] <= 1.25 * ref_ps[0] and ps[1] <= 1.25 * ref_ps[1], f"scores {ps} vs the reference's own {ref_ps}"
+    assert pb[0] <= 1.25 * ref_pb[0] and pb[1] <= 1.25 * ref_pb[1], f"boxes {pb} vs the reference's own {ref_pb}"
+    assert np.median(jac[same_img]) >= np.median(ref_jac[ref_same]) - 0.02 and jac[same_img].min() >= ref_jac[ref_same].min() - 0.1

@@ -11,11 +11,11 @@ from tests.helpers import assert_close, bf16_round, module_sd, nchw, nhwc, rnd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]   # fp16 = libymk_f16.so (the reference's half=True precision)
 
 
 def _prep(t, dtype):
-    return bf16_round(t) if dtype == torch.bfloat16 else t
+    return t.to(dtype).float() if dtype != torch.float32 else t
 
 
 # ------------------------------------------------------------------------------- conv (MFMA igemm)

@@ -86,3 +86,57 @@ def test_s_model_bf16_64px_against_the_oracle(host_model):
     err = (y.float() - oy).abs()
     assert float(err[:, 4:].max()) <= 2e-3, f"scores {float(err[:, 4:].max()):.3e}"
     assert float(err[:, :4].max()) <= 1.0, f"boxes {float(err[:, :4].max()):.3e} px"
+
+
+@pytest.fixture(scope="module")
+def hostlib_f16():
+    """libymk_hostemu_f16.so: the fp16 build of the kernel sources (-DYMK_H16_F16: IEEE binary16 elements, v_mfma_f32_16x16x32_f16)
+    compiled for the host, bound with the product's ctypes tables."""
+    import ctypes as C
+
+    from tests.hostemu import build as hostemu_build
+    from yolo_master_amd import _lib
+
+    path = hostemu_build.build(f16=True)
+    if path is None:
+        pytest.skip("no host clang++ to build the kernel emulation")
+    h = C.CDLL(str(path))
+    for name, (res, args) in {**_lib.SYMBOLS, **_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT}.items():
+        if hasattr(h, name):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+    assert h.ymk_h16_format() == _lib.H16_FORMAT_F16
+    return h
+
+
+def test_s_model_fp16_64px_against_the_oracle(hostlib_f16, monkeypatch):
+    """The fp16 build (the reference's `half=True` precision, engine/predictor.py:174,415): the SAME kernel sources with the 16-bit
+    element format switched to IEEE binary16, S detector through every fused kernel of the bench configuration, on the emulator
+    against the fp32 oracle: routing identical; with 3 more mantissa bits than bf16 the drift must be several times smaller than the
+    bf16 test's bars (2e-3 / 1 px there)."""
+    from oracle import model_ref
+    from yolo_master_amd import ops, postprocess
+    from yolo_master_amd.nn.tasks import DetectionModel, yaml_model_load
+    from yolo_master_amd.weights import synth_input, synth_state_dict
+
+    for mod in (ops, postprocess):
+        monkeypatch.setattr(mod, "lib", hostlib_f16)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
+    monkeypatch.setattr(ops, "HAS_F16", True)
+    sd = synth_state_dict(DetectionModel("yolo-master-s.yaml").state_dict(), seed=0)
+    m = DetectionModel("yolo-master-s.yaml")
+    m.load_state_dict(sd)
+    m = m.eval().set_compute_dtype(torch.float16)
+    x = synth_input(2, 64, 64, seed=3)
+    info = {}
+    with torch.inference_mode():
+        oy, _, _ = model_ref.forward(yaml_model_load("yolo-master-s.yaml"), sd, x, moe_info=info)
+        y, _ = m._predict_once(x)
+    m.check_flags()
+    for i in (3, 6, 9, 12):
+        assert torch.equal(m.model[i].last_route["gate_w"] > 0, info[f"model.{i}"]["retained"]), f"layer {i}: retained experts differ"
+    err = (y.float() - oy).abs()
+    print(f"fp16 S detector on the emulator: scores {float(err[:, 4:].max()):.3e}, boxes {float(err[:, :4].max()):.3e} px")
+    assert float(err[:, 4:].max()) <= 5e-4, f"scores {float(err[:, 4:].max()):.3e}"
+    assert float(err[:, :4].max()) <= 0.25, f"boxes {float(err[:, :4].max()):.3e} px"

@@ -36,4 +36,7 @@ for name, ctr, n, avg in rows:
     if (pat and pat not in short) or short.startswith(("Cijk_", "at::", "__amd")):
         continue
     out.setdefault(short, {})[ctr] = {"launches": n, "mean": avg}
-print(json.dumps({"kernels": out}, indent=1))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from yolo_master_amd.build import source_hash  # noqa: E402
+
+print(json.dumps({"csrc_sha16": source_hash(), "kernels": out}, indent=1))

@@ -13,8 +13,11 @@ from pathlib import Path
 __all__ = ["lib", "load", "YmkLibraryError", "ConvDesc", "check", "LIB_PATH", "SYMBOLS", "SYMBOLS_MIXTURE", "SYMBOLS_NEXT"]
 
 LIB_PATH = Path(__file__).resolve().parent / "libymk.so"
+LIB_F16_PATH = Path(__file__).resolve().parent / "libymk_f16.so"   # the same sources / ABI, 16-bit element format = IEEE binary16
 
-YMK_F32, YMK_BF16 = 0, 1
+YMK_F32, YMK_H16 = 0, 1
+YMK_BF16 = YMK_H16            # include/ymk.h: the 16-bit element type of the loaded build (bf16 in libymk.so, fp16 in libymk_f16.so)
+H16_FORMAT_BF16, H16_FORMAT_F16 = 1, 2
 ACT_NONE, ACT_SILU = 0, 1
 FLAG_NONFINITE_INPUT, FLAG_NONFINITE_LOGITS, FLAG_NMS_OVERFLOW = 1, 2, 4
 
@@ -44,6 +47,7 @@ ABI_VERSION = 2   # include/ymk.h YMK_ABI_VERSION
 SYMBOLS = {
     "ymk_abi_version": (C.c_int, []),
     "ymk_build_info": (C.c_char_p, []),
+    "ymk_h16_format": (C.c_int, []),
     "ymk_conv2d": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "ymk_conv2d_last_variant": (_i32, []),
     "ymk_conv1x1_cat2": (C.c_int, [C.POINTER(ConvDesc), _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
@@ -136,6 +140,19 @@ ACT_SIGMOID, ACT_GELU = 2, 3
 ELT_MUL, ELT_SIGMOID_MUL, ELT_LERP = 0, 1, 2
 
 _lib = None
+_lib_f16 = None
+
+
+def load_f16() -> C.CDLL:
+    """libymk_f16.so: the fp16 build of the same ABI (torch.float16 tensors); loaded on first use, RTLD_LOCAL like libymk.so, so the
+    two builds' identically named symbols never meet."""
+    global _lib_f16
+    if _lib_f16 is None:
+        h = load(LIB_F16_PATH)
+        if h.ymk_h16_format() != H16_FORMAT_F16:
+            raise YmkLibraryError(f"{LIB_F16_PATH} is not an fp16 build (ymk_h16_format() = {h.ymk_h16_format()})")
+        _lib_f16 = h
+    return _lib_f16
 
 
 def load(path: os.PathLike | None = None) -> C.CDLL:

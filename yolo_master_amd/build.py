@@ -35,6 +35,18 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libymk cannot be built (ROCm toolchain required)")
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources and shared headers: committed rocprofv3 summaries carry it, so that a
+    profile is only ever quoted for the kernels it was collected on (bench.py `roofline.traffic`, `families[].sq`)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + ["ymk_common.h", "igemm.h"]:
+        h.update(f.encode())
+        h.update((CSRC / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _compile_cmd(hipcc: str, src: str, obj: Path, defs: list) -> list:
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *defs, "-c", str(CSRC / src), "-o", str(obj)]
     if src in NO_CONTRACT:

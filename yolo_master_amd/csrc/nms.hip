@@ -662,7 +662,11 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, flo
         kept += cntk;
         __syncthreads();
     }
-    if (threadIdx.x == 0) out_counts[b] = kept < max_det ? kept : max_det;
+    const int nk = kept < max_det ? kept : max_det;
+    if (threadIdx.x == 0) out_counts[b] = nk;
+    // rows past the count are zero: the caller hands over uninitialised buffers (no fill kernels in the step)
+    for (int i = nk * 6 + threadIdx.x; i < max_det * 6; i += 256) out_dets[(size_t)b * max_det * 6 + i] = 0.f;
+    for (int i = nk + threadIdx.x; i < max_det; i += 256) out_idx[(size_t)b * max_det + i] = 0;
 }
 
 extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A, float conf_thres, float iou_thres,

@@ -31,7 +31,8 @@ __device__ __forceinline__ float h16lo(uint32_t w) { return (float)__builtin_bit
 __device__ __forceinline__ float h16hi(uint32_t w) { return (float)__builtin_bit_cast(hw_h16x2, w).y; }
 // two packed words (e0,e1),(e2,e3) -> a = (e0, e2), b = (e1, e3) as fp32 pairs
 __device__ __forceinline__ void h16x4_widen(const u32x2 t, f32x2& a, f32x2& b) {
-    const hw_h16x2 p = __builtin_bit_cast(hw_h16x2, t.x), q = __builtin_bit_cast(hw_h16x2, t.y);
+    const uint32_t tx = t.x, ty = t.y;   // scalars first: __builtin_bit_cast of an ext-vector ELEMENT reads element 0 (clang 22)
+    const hw_h16x2 p = __builtin_bit_cast(hw_h16x2, tx), q = __builtin_bit_cast(hw_h16x2, ty);
     a = f32x2{(float)p.x, (float)q.x};
     b = f32x2{(float)p.y, (float)q.y};
 }

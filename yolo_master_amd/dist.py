@@ -64,6 +64,27 @@ def broadcast_state_dict(module: torch.nn.Module, src: int = 0) -> None:
         module.repack()
 
 
+def gather_packed(pack: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """ONE collective per step: all_gather of every rank's packed NMS result (ops.nms_pack_numel words: dets | idx | counts, written
+    in place by the NMS kernels — nothing is copied to form it).  pack: float32 [n] with the same n on every rank (pad the last shard
+    of an uneven batch to the common B_local).  Returns float32 [world, n] in rank order = the original image order for contiguous
+    shards (ops.nms_pack_views(result, B_local, max_det) gives dets [world, B_local, max_det, 6], counts, idx).
+    out: the caller's pre-allocated [world, n] buffer (a serving loop reuses it every batch)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return pack.unsqueeze(0)
+    world = dist.get_world_size()
+    if out is None or tuple(out.shape) != (world, pack.numel()) or out.dtype != pack.dtype or out.device != pack.device:
+        out = torch.empty((world, pack.numel()), dtype=pack.dtype, device=pack.device)
+    if dist.get_backend() == "nccl":      # RCCL over xGMI: 0.54 MB per rank at 64 images x 300 detections — latency-bound
+        dist.all_gather_into_tensor(out, pack)
+        return out
+    src = pack.cpu()                      # gloo (CPU tests / single-GPU functional runs)
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src)
+    out.copy_(torch.stack(parts, 0))
+    return out
+
+
 def gather_detections(dets: torch.Tensor, counts: torch.Tensor, idx: torch.Tensor | None = None, out: dict | None = None):
     """all_gather of per-rank padded detections.  dets [B_local, max_det, 6], counts [B_local].
     Every rank must hold the same B_local (pad the last shard).  Returns tensors with leading dim

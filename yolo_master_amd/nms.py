@@ -35,9 +35,11 @@ def class_keep_mask(classes, nc: int, device) -> torch.Tensor:
 
 
 def nms_padded(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, agnostic=False, multi_label=False,
-               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1, classes=None):
+               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1, classes=None, pack=None):
     """prediction: [B, 4+nc, A] fp32 on the GPU.  Returns (dets [B,max_det,6], counts [B], idx [B,max_det],
-    status [1]) without synchronising.  classes: list of class ids or a ready uint8 [nc] device mask."""
+    status [1]) without synchronising.  classes: list of class ids or a ready uint8 [nc] device mask.
+    pack: optional float32 [ops.nms_pack_numel(B, max_det)] buffer the outputs are carved from (one allocation: a multi-GPU
+    step gathers it with a single collective, dist.gather_packed)."""
     if prediction.dtype != torch.float32:
         prediction = prediction.float()
     prediction = prediction.contiguous()
@@ -45,7 +47,7 @@ def nms_padded(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, agnost
     if classes is not None and not (torch.is_tensor(classes) and classes.dtype == torch.uint8):
         classes = class_keep_mask(classes, nc, prediction.device)
     return ops.nms_batched(prediction, conf_thres, iou_thres, bool(multi_label) and nc > 1, bool(agnostic), max_det,
-                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None, class_keep=classes)
+                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None, class_keep=classes, pack=pack)
 
 
 def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float = 0.45, classes=None,

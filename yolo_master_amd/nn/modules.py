@@ -87,9 +87,12 @@ def to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def set_compute_dtype(model: nn.Module, dtype: torch.dtype) -> nn.Module:
-    """Select fp32 or bf16 activations/weights for every ymk module (parameters stay fp32 masters)."""
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("ymk compute dtype must be torch.float32 or torch.bfloat16")
+    """Select fp32, bf16 or fp16 activations/weights for every ymk module (parameters stay fp32 masters).  fp16 is the reference's
+    reduced-precision mode (`half=True`, engine/predictor.py:174,415) and runs on libymk_f16.so."""
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError("ymk compute dtype must be torch.float32, torch.bfloat16 or torch.float16")
+    if dtype is torch.float16 and not ops.HAS_F16:
+        raise RuntimeError("libymk_f16.so not found: build it with `python -m yolo_master_amd.build`")
     for m in model.modules():
         if isinstance(m, YmkModule):
             m.ymk_dtype = dtype

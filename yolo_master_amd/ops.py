@@ -12,10 +12,34 @@ import os
 
 import torch
 
-from . import _lib
-from ._lib import ConvDesc, check, lib
+import threading
 
-DT = {torch.float32: _lib.YMK_F32, torch.bfloat16: _lib.YMK_BF16}
+from . import _lib
+from ._lib import ConvDesc, check
+
+# Element types.  libymk has ONE 16-bit element type per build (include/ymk.h YMK_H16): bfloat16 in libymk.so, IEEE binary16 in
+# libymk_f16.so (the same sources and C-ABI compiled with -DYMK_H16_F16) — the reference's `half=True` mode is fp16.
+H16 = (torch.bfloat16, torch.float16)
+DT = {torch.float32: _lib.YMK_F32, torch.bfloat16: _lib.YMK_H16, torch.float16: _lib.YMK_H16}
+_TLS = threading.local()
+
+
+class _LibRouter:
+    """`lib.ymk_<entry point>`: libymk.so, or libymk_f16.so when the last 16-bit NHWC view validated on this thread (`_nhwc`, which every
+    wrapper calls on its tensors before it touches the library) was torch.float16.  fp32-only calls are identical in both builds."""
+
+    def __getattr__(self, name):
+        return getattr(_lib.load_f16() if getattr(_TLS, "fmt", None) is torch.float16 else _lib.load(), name)
+
+
+lib = _LibRouter()
+
+
+def use_format(dtype: torch.dtype) -> None:
+    """Select the library build for the calls that follow on this thread (a model walk calls it once with its compute dtype;
+    `_nhwc` keeps it in step with the tensors actually passed)."""
+    if dtype in H16:
+        _TLS.fmt = dtype
 
 
 class KernelTimer:
@@ -63,8 +87,8 @@ def conv_kernel_name(variant: int, dtype, cin: int, cout: int, k: int, kpad: int
     """Demangled name of the kernel instantiation a ymk_conv2d / ymk_conv1x1_cat2 call ran (as rocprofv3 prints it,
     with bf16_t = unsigned short): the timer tags conv calls with it so that bench.py's roofline object and the
     committed rocprof / PMC summaries refer to the same kernel."""
-    t = "unsigned short" if dtype == torch.bfloat16 else "float"
-    es = 2 if dtype == torch.bfloat16 else 4
+    t = "unsigned short" if dtype in H16 else "float"
+    es = 2 if dtype in H16 else 4
     if dual and variant & 0xff != 3:
         return f"conv_igemm_kernel<{t}, {_tile(cout)}, 1, true>"
     if variant & 0xff == 3:   # LDS-DMA tiled core (default for bf16 3x3 with Cin >= 64; YMK_ENABLE bit 0: every shape); stages in bits 8+
@@ -91,7 +115,7 @@ def require_gpu(t: torch.Tensor, what: str = "yolo_master_amd ops") -> None:
         raise RuntimeError(f"{what} run on MI355X (HIP) only; got a CPU tensor. There is no CPU fallback.")
 
 
-HAS_F16 = False   # set by the dtype table below when libymk carries the fp16 instantiations
+HAS_F16 = _lib.LIB_F16_PATH.exists()   # libymk_f16.so is built next to libymk.so by yolo_master_amd/build.py
 
 
 def device_ok(t: torch.Tensor) -> bool:
@@ -106,6 +130,8 @@ def _need_gpu(t: torch.Tensor) -> None:
 def _nhwc(t: torch.Tensor):
     """Validate an NHWC view; return (B, H, W, C, ld)."""
     _need_gpu(t)
+    if t.dtype in H16:
+        _TLS.fmt = t.dtype
     B, H, W, Cc = t.shape
     if t.stride(3) != 1 and Cc > 1:
         raise ValueError("NHWC view must be channel-dense")
@@ -152,7 +178,7 @@ def dw_toeplitz(w_packed: torch.Tensor, k: int, force: bool = False) -> torch.Te
     C_ = w_packed.shape[1]
     if not (w_packed.is_cuda and (force or dw_mfma_enabled()) and w_packed.dtype in DT and lib.ymk_dw_mfma_supported(DT[w_packed.dtype], C_, k)):
         return None
-    out = torch.empty((lib.ymk_dw_toeplitz_elems(C_, k),), dtype=torch.bfloat16, device=w_packed.device)
+    out = torch.empty((lib.ymk_dw_toeplitz_elems(C_, k),), dtype=w_packed.dtype, device=w_packed.device)
     check(lib.ymk_dw_toeplitz_pack(_p(w_packed), C_, k, _p(out), _stream()), "dw_toeplitz_pack")
     return out
 
@@ -261,7 +287,8 @@ def stem_pair(x_nchw, wt0, b0, w1, b1, out=None):
     H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
     if out is None:
-        out = new_act(B, H2, W2, C1, torch.bfloat16, x_nchw.device)
+        out = new_act(B, H2, W2, C1, w1.dtype, x_nchw.device)
+    use_format(w1.dtype)
     ldy = _nhwc(out)[4]
     e0 = TIMER.begin()
     check(lib.ymk_stem_pair(_p(x_nchw), B, H, W, _p(wt0), _p(b0), C0, _p(w1), w1.shape[1], _p(b1), C1, _p(out), ldy, _stream()), "stem_pair")
@@ -326,7 +353,7 @@ def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
     ldr = _nhwc(residual)[4] if residual is not None else 0
     e0 = TIMER.begin()
     toep = getattr(w_packed, "toeplitz", None)
-    if toep is not None and x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16:
+    if toep is not None and x.dtype in H16 and out.dtype == x.dtype:
         check(lib.ymk_dwconv2d_mfma(_p(x), _p(toep), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy, ldr,
                                     _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d_mfma")
     else:
@@ -374,7 +401,7 @@ def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_p
     E = ksizes.numel()
     out = torch.empty((B * top_k, H, W, Cc), dtype=x.dtype, device=x.device)
     e0 = TIMER.begin()
-    if toep is not None and x.dtype == torch.bfloat16:
+    if toep is not None and x.dtype in H16:
         check(lib.ymk_esmoe_dw_mfma(_p(x), B, H, W, Cc, ldx, _p(toep), _p(ksizes), kmask, E, top_k, _p(csr_off), _p(csr_pair),
                                     _p(out), _stream()), "esmoe_dw_mfma")
     else:
@@ -528,10 +555,40 @@ def detect_decode(box_l, cls_l, y, stride: float, a_off: int, reg_max: int):
     return y
 
 
+_STATUS = {}
+
+
+def _zero_status(dev):
+    """The NMS status word: reserved since any candidate count is selected on the device (include/ymk.h YMK_FLAG_NMS_OVERFLOW); one
+    zero per device, never written."""
+    t = _STATUS.get(dev)
+    if t is None:
+        t = _STATUS[dev] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    return t
+
+
+def nms_pack_numel(B: int, max_det: int) -> int:
+    """32-bit words of one packed NMS result: dets [B, max_det, 6] f32 | idx [B, max_det] i32 | counts [B] i32 (one allocation, so that
+    a multi-GPU step gathers its results with ONE collective, yolo_master_amd/dist.py gather_packed)."""
+    return B * max_det * 7 + B
+
+
+def nms_pack_views(pack: torch.Tensor, B: int, max_det: int):
+    """(dets, counts, idx) views of a packed result buffer (float32 [..., nms_pack_numel]); leading dims are kept."""
+    lead = pack.shape[:-1]
+    n6, n1 = B * max_det * 6, B * max_det
+    dets = pack[..., :n6].reshape(*lead, B, max_det, 6)
+    idx = pack[..., n6:n6 + n1].view(torch.int32).reshape(*lead, B, max_det)
+    counts = pack[..., n6 + n1:n6 + n1 + B].view(torch.int32).reshape(*lead, B)
+    return dets, counts, idx
+
+
 def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, max_det: int, max_nms: int,
-                max_wh: float, cw_sigma: float | None = None, cw_pool: int = 3000, class_keep: torch.Tensor | None = None):
+                max_wh: float, cw_sigma: float | None = None, cw_pool: int = 3000, class_keep: torch.Tensor | None = None,
+                pack: torch.Tensor | None = None):
     """Returns (dets [B,max_det,6], counts [B] int32, idx [B,max_det] int32, status [1] int32).
-    class_keep: uint8 [nc] on the GPU (the `classes=` filter, utils/nms.py:63,132) or None."""
+    class_keep: uint8 [nc] on the GPU (the `classes=` filter, utils/nms.py:63,132) or None.
+    pack: optional contiguous float32 [nms_pack_numel(B, max_det)] buffer the three outputs are carved from."""
     _need_gpu(y)
     assert y.dtype == torch.float32 and y.is_contiguous()
     B, ch, A = y.shape
@@ -539,10 +596,15 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
     dev = y.device
     nbytes = lib.ymk_nms_workspace_bytes(B, nc, A, int(multi_label), max_nms)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-    dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=dev)
-    counts = torch.zeros((B,), dtype=torch.int32, device=dev)
-    idx = torch.zeros((B, max_det), dtype=torch.int32, device=dev)
-    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    # outputs are written in full by the kernels (rows past the count zeroed by nms_greedy_kernel): no fill kernels in the step
+    if pack is not None:
+        assert pack.dtype == torch.float32 and pack.is_contiguous() and pack.numel() == nms_pack_numel(B, max_det) and pack.device == dev
+        dets, counts, idx = nms_pack_views(pack, B, max_det)
+    else:
+        dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        idx = torch.empty((B, max_det), dtype=torch.int32, device=dev)
+    status = _zero_status(dev)
     e0 = TIMER.begin()
     if class_keep is not None:
         assert class_keep.dtype == torch.uint8 and class_keep.numel() == nc and class_keep.device == y.device and class_keep.is_contiguous()
@@ -857,7 +919,7 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
         out = torch.empty((K * B, H, W, Cout), dtype=x.dtype, device=x.device)
     if not out.is_contiguous():
         raise ValueError("expert_conv: dense output")
-    if not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 512) and x.dtype == torch.bfloat16 and Cin % 64 == 0 and Cout % 64 == 0 and Kp == k * k * Cin:
+    if not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 512) and x.dtype in H16 and Cin % 64 == 0 and Cout % 64 == 0 and Kp == k * k * Cin:
         # true sparse dispatch on the LDS-DMA tiled core (include/ymk_next.h): only the routed filter banks run
         d = ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, B, H, W, Cin, Cout, k, 1, _nhwc(x)[4], Cout, 0, Kp, _lib.ACT_NONE)
         check(lib.ymk_expert_conv_glds(C.byref(d), _p(x), _p(w_packed), _p(idx), K, E, _p(out),

@@ -73,6 +73,39 @@ def test_conv2d_glds_on_the_emulator(hostlib, case):
     run_case(hostlib, case)
 
 
+def tile_flags(bn, bm, two=1):
+    """`two_stage` argument of the LDS-DMA entry points with a forced tile shape (csrc/conv_glds.hip glds_launch_any)."""
+    return two | ((bn // 64) << 8) | (bm << 12)
+
+
+BIG_TILE_CASES = [
+    # the round-3 tiles (one workgroup per CU, 160 / 128 KB of LDS): 128 couts x 512 pixels and 256 x 256, ragged in pixels, with
+    # residual (loaded per fragment there), stride 2, channel-slice views, fp32 output
+    ((1, 24, 23, 64, 128, 3, 1, True, True, False, 0, 64, 1), (128, 512)),
+    ((2, 21, 19, 64, 256, 3, 2, True, False, False, 64, 0, 1), (256, 256)),
+    ((1, 18, 17, 128, 256, 1, 1, False, True, True, 0, 0, 1), (256, 256)),
+    ((1, 30, 20, 64, 128, 1, 1, True, False, False, 0, 0, 1), (128, 512)),
+    ((1, 12, 12, 64, 128, 3, 1, True, True, False, 0, 0, 1), (128, 256)),
+]
+
+
+@pytest.mark.parametrize("case,tile", BIG_TILE_CASES)
+def test_conv2d_glds_big_tiles_on_the_emulator(hostlib, case, tile):
+    run_case(hostlib, case[:-1] + (tile_flags(*tile),))
+
+
+def test_conv2d_glds_rejects_impossible_tiles(hostlib):
+    from yolo_master_amd import _lib, ops
+
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16)
+    w = ops.pack_conv_weight(torch.zeros(128, 64, 1, 1), torch.bfloat16)
+    b, y = torch.zeros(128), torch.zeros(1, 8, 8, 128, dtype=torch.bfloat16)
+    d = _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, 1, 8, 8, 64, 128, 1, 1, 64, 128, 0, 64, 0)
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    for bn, bm, two in ((256, 512, 1), (128, 512, 0), (192, 128, 1), (256, 128, 1)):   # 3-stage big tiles do not fit the LDS
+        assert hostlib.ymk_conv2d_glds(C.byref(d), p(x), p(w), p(b), None, p(y), tile_flags(bn, bm, two), None) == -1
+
+
 def test_conv2d_glds_rejects_what_it_does_not_cover(hostlib):
     from yolo_master_amd import _lib
 

@@ -28,12 +28,13 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
 extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
                                      int32_t ldx2, const void* w, const float* bias, void* y, int32_t two_stage, void* stream);
 int ymk_glds_last_tile();   // csrc/conv_glds.hip: pixel-tile height of the thread's last LDS-DMA launch
+int ymk_glds_last_bn();     // ... and its cout-tile width
 static int ymk_glds_min_tiles = [] { const char* e = getenv("YMK_GLDS_MIN_TILES"); return e ? atoi(e) : 192; }();
 // one workgroup per CU (144 KB of LDS): with fewer than four k-steps there is nothing to pipeline, the current kernels win
 static int ymk_glds_min_k = [] { const char* e = getenv("YMK_GLDS_MIN_K"); return e ? atoi(e) : 256; }();
 // diagnostic (kernel naming in bench.py / tools): variant code, plus the LDS stage count << 8 for the LDS-DMA core
 extern "C" int32_t ymk_conv2d_last_variant(void) {
-    return ymk_last_variant == YMK_CONV_GLDS ? (ymk_last_variant | (ymk_last_glds_stages << 8) | (ymk_glds_last_tile() << 16)) : ymk_last_variant;
+    return ymk_last_variant == YMK_CONV_GLDS ? (ymk_last_variant | (ymk_last_glds_stages << 8) | (ymk_glds_last_tile() << 16) | ((ymk_glds_last_bn() / 64) << 26)) : ymk_last_variant;
 }
 
 template <typename T, bool PRECISE>

@@ -4,13 +4,15 @@
 // plain barrier or three stages with a raw barrier and a counted vmcnt (one k-step of DMA in flight across every
 // barrier), XCD-aware tile order.  bf16 only; Cin % 64 == 0, Cout % 64 == 0.
 //
-// STATUS: OPT-IN (YMK_ENABLE bit 0; bit 1 selects the 2-stage loop).  The design ran correctly on MI355X as
-// tools/micro/gemm256.hip; this library form (strided views, residual, fp32 output, activation codes) has passed
-// tests/test_hostemu_conv.py on the CPU lane emulator but has not been timed or run on hardware: ymk_conv2d keeps
-// dispatching to the validated kernels unless the switch is set.
+// STATUS: the DEFAULT core of ymk_conv2d / ymk_conv1x1_cat2 for every 16-bit 3x3 with Cin >= 64 and the tiled 1x1 shapes since round 2
+// (validated and timed on MI355X: tests/test_gpu_next.py, profiles/r02_glds_tile_ab.txt, profiles/r03_*).  Round 3: tile shapes up to
+// 128 couts x 512 pixels / 256 x 256 (one workgroup per CU, 160 / 128 KB of LDS in two stages): the loop is paced by the global->LDS
+// transfer latency (one k-step in flight per workgroup, ~1.7 us per k-step at two 128 x 128 workgroups per CU = 38 GB/s per CU), so
+// at a fixed LDS budget the FLOPs per in-flight byte decide: 2 x (128 x 128) -> 128 x 512 or 256 x 256 doubles them.
+#include <stdio.h>
+
 #include "ymk_common.h"
 
-typedef __bf16 glds_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef YMK_HOST_EMU
 typedef __attribute__((address_space(1))) const void* glds_gptr;
 typedef __attribute__((address_space(3))) void* glds_lptr;
@@ -231,12 +233,13 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     f32x4 bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cout_of(i)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x2 rr[4][TP];
-    if (a.res) {
+    constexpr bool RES_PREFETCH = TP <= 4;   // 16 x TP more registers next to 16 x TP accumulators: only for the small tiles
+    u32x2 rr[4][RES_PREFETCH ? TP : 1];
+    if (a.res && RES_PREFETCH) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < TP; ++j) {
+            for (int j = 0; j < (RES_PREFETCH ? TP : 1); ++j) {
                 const int p = min(m0 + ((wave / WN) * TP + j) * 16 + fr, Mlim - 1);
                 rr[i][j] = load_raw4(a.res + (out_base + p) * a.ldr + cout_of(i));
             }
@@ -257,7 +260,8 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
                 if (a.act == YMK_ACT_SILU) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
                 if (a.res) {
                     float r0, r1, r2, r3;
-                    unpack_raw4(rr[i][j], r0, r1, r2, r3);
+                    if constexpr (RES_PREFETCH) unpack_raw4(rr[i][j], r0, r1, r2, r3);
+                    else unpack_raw4(load_raw4(a.res + (out_base + min(p, Mlim - 1)) * a.ldr + cout_of(i)), r0, r1, r2, r3);
                     v0 += r0; v1 += r1; v2 += r2; v3 += r3;
                 }
                 v[q * 4 + 0] = v0; v[q * 4 + 1] = v1; v[q * 4 + 2] = v2; v[q * 4 + 3] = v3;
@@ -300,24 +304,63 @@ static int glds_launch_bm(const GldsArgs& a, hipStream_t s) {
 // after the other (stage ablation, tools/micro/glds_ablate.sh: the MFMAs are 6 % of 128->128 s2 at 160^2, the DMA 36 %); with
 // 128-pixel tiles two (128 couts) or three (64 couts) workgroups share a CU and overlap them.  Same arithmetic, bit-identical output.
 // pixel-tile height of the calling thread's last launch (ymk_conv2d_last_variant reports it in bits 16+: profilers' kernel names)
-static thread_local int glds_last_tile = 0;
+static thread_local int glds_last_tile = 0, glds_last_bn = 0;
 int ymk_glds_last_tile() { return glds_last_tile; }
+int ymk_glds_last_bn() { return glds_last_bn; }
+static int glds_big_min_waves() {   // YMK_GLDS_BIG_MIN_WAVES=<n>: big tiles need n x 256 workgroups (A/B runs); default 2
+    static const int v = [] { const char* e = getenv("YMK_GLDS_BIG_MIN_WAVES"); return e ? atoi(e) : 2; }();
+    return v;
+}
 
 static int glds_small_below() {   // YMK_GLDS_SMALL_BELOW=<n>: 128-pixel tiles iff the 256-pixel launch has fewer than n workgroups (A/B runs); unset: the rule below
     static const int v = [] { const char* e = getenv("YMK_GLDS_SMALL_BELOW"); return e ? atoi(e) : GLDS_SMALL_BELOW_DEFAULT; }();
     return v;
 }
-template <int BN, int STAGES>
-static int glds_launch(const GldsArgs& a, hipStream_t s) {
-    const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
-    const int64_t grid256 = (a.eidx ? (int64_t)a.K * a.B * ((a.Ho * a.Wo + GLDS_BM - 1) / GLDS_BM) : (M + GLDS_BM - 1) / GLDS_BM) * (a.Cout / BN);
-    // measured rule (profiles/r02_glds_tile_ab.txt): 128-cout tiles always; 64-cout tiles when the launch is small (under one
-    // 256-pixel workgroup per CU) or large (>= 1024), not in between (256 -> 64 at 40^2: 69 vs 78 us)
-    bool small = BN == 128 || grid256 < 256 || grid256 >= 1024;
-    if (glds_small_below() >= 0) small = grid256 < glds_small_below();
-    glds_last_tile = small ? GLDS_BM_SMALL : GLDS_BM;
-    if (small) return glds_launch_bm<BN, STAGES, GLDS_BM_SMALL>(a, s);
-    return glds_launch_bm<BN, STAGES, GLDS_BM>(a, s);
+// YMK_GLDS_TILE=<BN>x<BM> forces a tile shape for A/B runs (128x128, 128x256, 128x512, 256x256, 64x128, 64x256); unset: the rule below
+static void glds_forced_tile(int& bn, int& bm) {
+    static const int v = [] {
+        const char* e = getenv("YMK_GLDS_TILE");
+        int n = 0, m = 0;
+        return (e && sscanf(e, "%dx%d", &n, &m) == 2) ? n * 4096 + m : 0;
+    }();
+    bn = v / 4096; bm = v % 4096;
+}
+
+// flags of the three entry points below (`two_stage` argument): bit 0 = two-stage loop; bits 8-11 = forced cout-tile width / 64 and
+// bits 12-21 = forced pixel-tile height (0: the rule / YMK_GLDS_TILE) — tests and A/B tools pick a tile shape per call with them
+template <int STAGES>
+static int glds_launch_any(const GldsArgs& a, hipStream_t s, int flags) {
+    const int64_t M = a.eidx ? (int64_t)a.Ho * a.Wo : (int64_t)a.B * a.Ho * a.Wo;
+    const int64_t groups = a.eidx ? (int64_t)a.K * a.B : 1;
+    auto tiles = [&](int bn, int bm) { return groups * ((M + bm - 1) / bm) * (a.Cout / bn); };
+    int bn = ((flags >> 8) & 15) * 64, bm = (flags >> 12) & 1023;
+    if (!bn) glds_forced_tile(bn, bm);
+    if (bn && !((bn == 64 || bn == 128 || (bn == 256 && STAGES == 2)) && (bm == 128 || bm == 256 || (bm == 512 && STAGES == 2 && bn == 128)) &&
+                !(bn == 256 && bm != 256)))
+        return YMK_E_BADARG;
+    if (!bn || a.Cout % bn) {
+        const bool c128 = a.Cout % 128 == 0;
+        bn = c128 ? 128 : 64;
+        const int64_t grid256 = tiles(bn, 256);
+        // measured rule of round 2 (profiles/r02_glds_tile_ab.txt): 128-cout tiles always on 128 pixels; 64-cout tiles when the launch is
+        // small (under one 256-pixel workgroup per CU) or large (>= 1024), not in between (256 -> 64 at 40^2: 69 vs 78 us)
+        bm = (c128 || grid256 < 256 || grid256 >= 1024) ? 128 : 256;
+        if (glds_small_below() >= 0) bm = grid256 < glds_small_below() ? 128 : 256;
+        // round 3: the big tiles (one workgroup per CU, twice the FLOPs per in-flight byte) when they still give every CU at least
+        // `glds_big_min_waves()` rounds of work: 256 x 256 where Cout allows, else 128 x 512
+        if (STAGES == 2 && c128) {
+            const int bbn = a.Cout % 256 == 0 ? 256 : 128, bbm = bbn == 256 ? 256 : 512;
+            if (tiles(bbn, bbm) >= (int64_t)256 * glds_big_min_waves()) { bn = bbn; bm = bbm; }
+        }
+    }
+    glds_last_tile = bm;
+    glds_last_bn = bn;
+    if (STAGES == 2) {
+        if (bn == 256 && bm == 256) return glds_launch_bm<256, 2, 256>(a, s);
+        if (bn == 128 && bm == 512) return glds_launch_bm<128, 2, 512>(a, s);
+    }
+    if (bn == 128) return bm == 256 ? glds_launch_bm<128, STAGES, 256>(a, s) : glds_launch_bm<128, STAGES, 128>(a, s);
+    return bm == 256 ? glds_launch_bm<64, STAGES, 256>(a, s) : glds_launch_bm<64, STAGES, 128>(a, s);
 }
 
 // Same arguments and result as ymk_conv2d; returns YMK_E_BADARG for shapes outside this kernel's domain (the caller then
@@ -345,8 +388,7 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
     // 32-bit element offsets inside the kernel
     if (M >= (1ll << 31) || ((int64_t)d->B * d->H * d->W + d->W + 2) * d->ldx >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if (d->Cout % 128 == 0) return two_stage ? glds_launch<128, 2>(a, s) : glds_launch<128, 3>(a, s);
-    return two_stage ? glds_launch<64, 2>(a, s) : glds_launch<64, 3>(a, s);
+    return (two_stage & 1) ? glds_launch_any<2>(a, s, two_stage) : glds_launch_any<3>(a, s, two_stage);
 }
 
 // Same arguments and result as ymk_conv1x1_cat2 (ymk.h) + two_stage; C1 and Cin - C1 multiples of 64.
@@ -366,8 +408,7 @@ extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int
     if (M <= 0) return YMK_OK;
     if (M >= (1ll << 31) || (M + 2) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if (d->Cout % 128 == 0) return two_stage ? glds_launch<128, 2>(a, s) : glds_launch<128, 3>(a, s);
-    return two_stage ? glds_launch<64, 2>(a, s) : glds_launch<64, 3>(a, s);
+    return (two_stage & 1) ? glds_launch_any<2>(a, s, two_stage) : glds_launch_any<3>(a, s, two_stage);
 }
 
 // Routed-expert convolution (FusedExpertGroup moe/gated.py:1058-1076, SharedInvertedExpertGroup moe/experts.py:235-269) with
@@ -389,6 +430,5 @@ extern "C" int ymk_expert_conv_glds(const ymk_conv_desc* d, const void* x, const
     if (d->B <= 0 || HW <= 0) return YMK_OK;
     if (((int64_t)d->B * HW + d->W + 2) * d->ldx >= (1ll << 31) || (int64_t)K * d->B * HW >= (1ll << 31)) return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if (d->Cout % 128 == 0) return two_stage ? glds_launch<128, 2>(a, s) : glds_launch<128, 3>(a, s);
-    return two_stage ? glds_launch<64, 2>(a, s) : glds_launch<64, 3>(a, s);
+    return (two_stage & 1) ? glds_launch_any<2>(a, s, two_stage) : glds_launch_any<3>(a, s, two_stage);
 }

@@ -92,7 +92,8 @@ def conv_kernel_name(variant: int, dtype, cin: int, cout: int, k: int, kpad: int
     if dual and variant & 0xff != 3:
         return f"conv_igemm_kernel<{t}, {_tile(cout)}, 1, true>"
     if variant & 0xff == 3:   # LDS-DMA tiled core (default for bf16 3x3 with Cin >= 64; YMK_ENABLE bit 0: every shape); stages in bits 8+
-        return f"conv_glds_kernel<{128 if cout % 128 == 0 else 64}, {(variant >> 8) & 0xff}, {(variant >> 16) or 256}>"   # pixel-tile height in bits 16+
+        bn = ((variant >> 26) & 7) * 64 or (128 if cout % 128 == 0 else 64)   # cout-tile width / 64 in bits 26+, pixel-tile height in bits 16-25
+        return f"conv_glds_kernel<{bn}, {(variant >> 8) & 0xff}, {((variant >> 16) & 0x3ff) or 256}>"
     if variant == 1:
         return f"conv1x1_ws_kernel<{t}, {kpad * es // 128}, {'true' if cout % 64 == 0 else 'false'}>"   # whole 64-cout groups: permuted rows
     if variant == 2:

@@ -30,7 +30,8 @@ int ymk_activation(int32_t dtype, void* x, int32_t ldx, int64_t npix, int32_t C,
  * weight/bias: fp32 [C], or NULL (no affine), or [R][C] with affine_rows int32 [B] (row per image; FusedExpertGroup,
  * moe/gated.py:1058-1090).  act: YMK_ACT_NONE | YMK_ACT_SILU.  residual (dtype = out_dtype of y, may be NULL) is added
  * after the activation (MoTBlock out_norm(.) + x, mot/block.py:413-417).  y may alias x.
- * stats_ws: fp32 [B*groups*2] scratch (mean, rstd). */
+ * stats_ws: fp32 [B*groups*(2 + 3*64)] scratch: (mean, rstd) per slab, then up to 64 chunk partials (mean, M2, n) per slab —
+ * a slab's statistics are computed by several workgroups and combined exactly, in chunk order (deterministic). */
 int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
                    const void* residual, int32_t ldr, int32_t B, int32_t HW, int32_t C, int32_t groups,
                    const float* weight, const float* bias, const int32_t* affine_rows, float eps, int32_t act,
@@ -127,7 +128,8 @@ int ymk_window_attention(int32_t dtype, const void* q, int32_t ldq, const void* 
 
 /* ReLU random-feature attention (moa/heads.py:318-352), fp32: phi(t) = min(relu(t rf^T / sqrt(nb)) + 1e-6, 1e4);
  * out = clamp(phi(q) (phi(k)^T v), +-1e4) / max(phi(q) . sum_n phi(k_n), 1e-6).  rf fp32 [nb][hd], nb, hd <= 64.
- * ws: fp32 [B*heads*(nb*hd + nb)] scratch. */
+ * ws: fp32 [B*heads*(ceil(N/512) + 1)*(nb*hd + nb)] scratch (per (image, head): the reduced phi(k)^T v | sum phi(k), then one partial
+ * per 512-token chunk, added in chunk order). */
 int ymk_linear_attention(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v,
                          int32_t ldv, const float* rf, int32_t nb, void* out, int32_t ldo, int32_t B, int32_t N,
                          int32_t heads, int32_t hd, float* ws, void* stream);

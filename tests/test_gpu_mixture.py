@@ -57,6 +57,18 @@ def test_norms_and_elementwise(dtype):
     _cmp(ops.group_norm(x.to(DEV), 8, rows_w.to(DEV), rows_b.to(DEV), 1e-5, act="silu", affine_rows=rows.to(DEV)),
          emu_ops.group_norm(x, 8, rows_w, rows_b, 1e-5, act="silu", affine_rows=rows), dtype, "group_norm affine rows")
     _cmp(ops.group_norm(x.to(DEV), 8, None, None, 1e-5), emu_ops.group_norm(x, 8, None, None, 1e-5), dtype, "group_norm no affine")
+    # a slab large enough to be split over several workgroups (chunk partials combined exactly, in chunk order): vector and scalar kernels
+    xb = _rnd(1, 96, 96, 16, seed=30, dtype=dtype) * 0.5 + 1.0
+    _cmp(ops.group_norm(xb.to(DEV), 2, w[:16].to(DEV), b[:16].to(DEV), 1e-5), emu_ops.group_norm(xb, 2, w[:16], b[:16], 1e-5), dtype, "group_norm chunked")
+    xb6 = _rnd(1, 128, 90, 6, seed=31) * 0.5 - 1.0
+    _cmp(ops.group_norm(xb6.to(DEV), 1, w[:6].to(DEV), b[:6].to(DEV), 1e-5, act="silu"), emu_ops.group_norm(xb6, 1, w[:6], b[:6], 1e-5, act="silu"),
+         torch.float32, "group_norm chunked C=6")
+    if dtype == torch.float32:   # mean^2 >> variance (a sum-of-squares formula loses the variance; torch's own fp32 group_norm is 4e-3 off here): vs fp64
+        xo = _rnd(1, 96, 96, 16, seed=32) * 0.05 + 6.0
+        xd = xo.double().reshape(1, 96 * 96, 2, 8)
+        r64 = ((xd - xd.mean((1, 3), keepdim=True)) / (xd.var((1, 3), unbiased=False, keepdim=True) + 1e-5).sqrt()).reshape(1, 96, 96, 16)
+        got = ops.group_norm(xo.to(DEV), 2, None, None, 1e-5).cpu().double()
+        assert float((got - r64).abs().max()) <= 5e-5, float((got - r64).abs().max())
     x6 = _rnd(2, 5, 7, 6, seed=7)                      # odd channel count inside an 8-wide buffer, fp32 -> fp32 (router path)
     buf = torch.zeros((2, 5, 7, 8), device=DEV)
     ops.group_norm(_view(x6, 2), 3, w[:6].to(DEV), b[:6].to(DEV), 1e-5, act="silu", out=buf[..., :6])
@@ -156,7 +168,10 @@ def test_attention_family(dtype):
     from yolo_master_amd import ops
 
     for heads, hd, (H, W), (Hk, Wk) in ((2, 16, (9, 11), (9, 11)), (8, 8, (14, 18), (14, 18)), (1, 16, (12, 20), (6, 10)), (2, 32, (5, 7), (2, 3)),
-                                        (1, 64, (8, 8), (8, 8)), (3, 24, (6, 5), (6, 5))):
+                                        (1, 64, (8, 8), (8, 8)), (3, 24, (6, 5), (6, 5)),
+                                        # matrix-core kernel (16-bit, head_dim 16 / 32 / 64): several 64-key blocks (online softmax), ragged last block,
+                                        # more than 256 queries (two workgroups per (image, head))
+                                        (2, 32, (20, 24), (10, 13)), (1, 16, (30, 30), (16, 16)), (1, 64, (18, 18), (9, 9)), (3, 32, (17, 16), (17, 16))):
         c = heads * hd
         qkv = _rnd(2, H, W, 3 * c, seed=40 + hd, dtype=dtype)
         kv = _rnd(2, Hk, Wk, 2 * c, seed=41 + hd, dtype=dtype)
@@ -164,7 +179,10 @@ def test_attention_family(dtype):
         _cmp(ops.attention(qd[..., :c], kd[..., :c], kd[..., c:], heads, hd, hd ** -0.5),
              emu_ops.attention(qkv[..., :c], kv[..., :c], kv[..., c:], heads, hd, hd ** -0.5), dtype, f"attention h{heads} d{hd} {H}x{W}/{Hk}x{Wk}")
     for heads, hd, (H, W), win, shift, pad in ((2, 16, (14, 18), 7, 0, False), (6, 8, (14, 18), 7, 3, True), (6, 8, (16, 20), 7, 3, True),
-                                               (1, 16, (5, 4), 4, 0, False), (2, 32, (7, 7), 7, 0, False), (6, 8, (9, 11), 7, 0, True)):
+                                               (1, 16, (5, 4), 4, 0, False), (2, 32, (7, 7), 7, 0, False), (6, 8, (9, 11), 7, 0, True),
+                                               # matrix-core kernel (16-bit, head_dim 16 / 32 / 64): rolled grid, pad vectors as keys, full 64-token windows
+                                               (2, 32, (16, 20), 7, 3, True), (1, 64, (9, 11), 7, 0, True), (2, 16, (10, 12), 8, 4, True),
+                                               (3, 32, (15, 22), 7, 3, False), (5, 16, (29, 31), 7, 0, True)):
         c = heads * hd
         qkv = _rnd(2, H, W, 3 * c, seed=50 + hd + shift, dtype=dtype)
         pads = [_rnd(c, seed=51 + i) if pad else None for i in range(3)]

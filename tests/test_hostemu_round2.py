@@ -64,6 +64,8 @@ ATTN_CASES = [
     (torch.bfloat16, 2, 144, 1, 2),    # 72 keys per area: one chunk of three pairs, ragged
     (torch.bfloat16, 1, 32, 1, 1),     # a single pair, no mask
     (torch.float32, 1, 48, 2, 1),      # fp32 path of the same code (per-tile P V)
+    (torch.bfloat16, 1, 1100, 1, 1),   # more keys than the resident kernel holds: the 256-query kernel of csrc/mixattn.hip (18 key blocks, ragged)
+    (torch.bfloat16, 2, 2200, 2, 2),   # ... with areas as batch entries
 ]
 
 

@@ -14,3 +14,8 @@ YMK_GLDS_BIG_MIN_WAVES=1000 python bench.py --steps 30 --warmup 10 --no-cpu-base
 python -c "
 import json
 r=json.loads(open('gpurun_out/r03c_bench_nobig.json').read()); print('no big tiles:', r['value'], r['ms_per_step'])"
+python bench.py --cfg yolo-master-moa-mot.yaml --scale l --imgsz 1280 --batch 16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r03c_bench_cfg5.json 2> gpurun_out/r03c_bench_cfg5.err
+python -c "
+import json
+r=json.loads(open('gpurun_out/r03c_bench_cfg5.json').read()); print('cfg5:', r['value'], r['ms_per_step'])
+for f in r['families'][:24]: print('   ', f['kernel'], f['ms_per_step'], f['launches_per_step'], f['frac'], f['achieved_tflops'])"

@@ -486,6 +486,9 @@ static int launch_attn_resident(const T* qkv, int ldq, T* out, int ldo, int B, i
 }
 
 #define YMK_OFF_ATTN_RESIDENT 256u   // YMK_DISABLE bit: resident K/V attention -> streaming kernel (A/B runs)
+#define YMK_OFF_ATTN_WIDE 524288u    // YMK_DISABLE bit: long areas (> 1024 keys) on the 256-query kernel of csrc/mixattn.hip -> 64-query streaming kernel
+extern "C" int ymk_attention(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
+                             int32_t ldo, int32_t B, int32_t Nq, int32_t Nk, int32_t heads, int32_t hd, float scale, void* stream);
 
 extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, int32_t B,
                              int32_t N, int32_t heads, int32_t area, void* stream) {
@@ -503,6 +506,15 @@ extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* 
             return launch_attn_resident<h16_t, 3>((const h16_t*)qkv, ldq, (h16_t*)out, ldo, B, N, Na, heads, area, scale, s);
         if (dtype == YMK_F32 && Na <= 512)
             return launch_attn_resident<float, 1>((const float*)qkv, ldq, (float*)out, ldo, B, N, Na, heads, area, scale, s);
+    }
+    // Areas too long for the resident kernel (the L-scale A2C2f blocks: 1600 keys; the whole-map local attention of the MoT blocks of
+    // BASELINE config 5: 6400): the streaming kernel below re-stages every 256-key chunk for each 64 queries (64 FLOP per staged byte);
+    // attention_mfma_kernel (csrc/mixattn.hip) holds 256 queries per workgroup against each 64-key block (256 FLOP per staged byte).
+    // An area is a contiguous run of tokens, so (image, area) is simply a batch index there.
+    if (dtype == YMK_H16 && !(ymk_disabled() & YMK_OFF_ATTN_WIDE) && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+        const h16_t* qp = static_cast<const h16_t*>(qkv);
+        return ymk_attention(dtype, qp, ldq, qp + heads * 32, ldq, qp + 2 * heads * 32, ldq, out, ldo, B * area, Na, Na, heads, 32, scale, stream);
     }
     if (dtype == YMK_F32)
         hipLaunchKernelGGL((area_attn_kernel<float, 1>), grid, blk, 0, s, (const float*)qkv, ldq, (float*)out, ldo, N, Na,

@@ -307,8 +307,8 @@ static int glds_launch_bm(const GldsArgs& a, hipStream_t s) {
 static thread_local int glds_last_tile = 0, glds_last_bn = 0;
 int ymk_glds_last_tile() { return glds_last_tile; }
 int ymk_glds_last_bn() { return glds_last_bn; }
-static int glds_big_min_waves() {   // YMK_GLDS_BIG_MIN_WAVES=<n>: big tiles need n x 256 workgroups (A/B runs); default 2
-    static const int v = [] { const char* e = getenv("YMK_GLDS_BIG_MIN_WAVES"); return e ? atoi(e) : 2; }();
+static int glds_big_min_tiles() {   // YMK_GLDS_BIG_MIN_TILES=<n>: the 256 x 256 tile needs n workgroups (A/B runs); default 192
+    static const int v = [] { const char* e = getenv("YMK_GLDS_BIG_MIN_TILES"); return e ? atoi(e) : 192; }();
     return v;
 }
 
@@ -346,12 +346,11 @@ static int glds_launch_any(const GldsArgs& a, hipStream_t s, int flags) {
         // small (under one 256-pixel workgroup per CU) or large (>= 1024), not in between (256 -> 64 at 40^2: 69 vs 78 us)
         bm = (c128 || grid256 < 256 || grid256 >= 1024) ? 128 : 256;
         if (glds_small_below() >= 0) bm = grid256 < glds_small_below() ? 128 : 256;
-        // round 3: the big tiles (one workgroup per CU, twice the FLOPs per in-flight byte) when they still give every CU at least
-        // `glds_big_min_waves()` rounds of work: 256 x 256 where Cout allows, else 128 x 512
-        if (STAGES == 2 && c128) {
-            const int bbn = a.Cout % 256 == 0 ? 256 : 128, bbm = bbn == 256 ? 256 : 512;
-            if (tiles(bbn, bbm) >= (int64_t)256 * glds_big_min_waves()) { bn = bbn; bm = bbm; }
-        }
+        // round 3 (profiles/r03_glds_tile_ab.txt): a 256 x 256 tile (one 8-wave workgroup per CU, 128 KB of LDS, 64 MFMAs per wave and
+        // k-step) wins 5-10 % where there are at least ~3/4 of a round of them and the reduction is long (256 -> 256 s2 at 80^2: 149 -> 138
+        // us, 256 -> 512 s2 at 40^2: 80 -> 72, 768 -> 256 1x1 at 40^2: 66 -> 62), loses on short reductions / few tiles (256 -> 768 1x1 at
+        // 20^2: 26 -> 33).  The 128 x 512 tile never won (reachable through the flags only).
+        if (STAGES == 2 && a.Cout % 256 == 0 && a.Kpad >= 384 && tiles(256, 256) >= glds_big_min_tiles()) { bn = 256; bm = 256; }
     }
     glds_last_tile = bm;
     glds_last_bn = bn;

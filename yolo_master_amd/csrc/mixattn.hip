@@ -5,6 +5,8 @@
 #include "ymk_common.h"
 #include "../../include/ymk_mixture.h"
 
+#define YMK_OFF_WINATTN_MFMA 262144u   // YMK_DISABLE bit: matrix-core window / general attention -> one query per thread on the VALU (A/B runs)
+
 namespace {
 
 __device__ __forceinline__ float ldv(const void* p, int dt, int64_t i) {
@@ -117,30 +119,326 @@ __global__ __launch_bounds__(256) void window_attention_kernel(int dt, const voi
     for (int d = 0; d < HD; ++d) stv(out, dt, pix * ldo + h * HD + d, acc[d] * inv);
 }
 
+// ------------------------------------------------------------------------------------------------ window attention on the matrix cores
+// 16-bit inputs, win * win <= 64 tokens, head_dim 16 / 32 / 64: ONE WAVE per (window, head), four windows per workgroup.
+//   S^T = K Q^T   4 x 4 tiles of v_mfma_f32_16x16x32 (K / Q fragments are 16-byte global loads: a lane owns 8 channels of one token)
+//   softmax over keys = over the ROWS of S^T: a lane's 16 accumulators of a query column + two xor-shuffles (lane groups 16 / 32)
+//   O^T = V^T P^T: the contraction index of the second product is PERMUTED — MFMA slot (g, e) stands for key 16 (2 kb + (e >> 2)) +
+//         4 g + (e & 3) — so that the B operand (P^T) is exactly what the lane already holds in its S^T accumulators (no cross-lane
+//         movement), and the A operand (V^T) is two 8-byte reads of a V^T image staged once per wave in LDS.
+// Out-of-image tokens of the padded / rolled grid carry the pad vectors and take part as keys, as in window_attention_kernel.
+template <int HD>
+__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const h16_t* q, int ldq, const h16_t* k, int ldk, const h16_t* v, int ldv_,
+                                                                    h16_t* out, int ldo, int H, int W, float scale, int win, int shift,
+                                                                    const float* pad_q, const float* pad_k, const float* pad_v, int nwin) {
+    constexpr int KB = (HD + 31) / 32;          // 32-channel blocks of the first contraction (channels past head_dim are zero)
+    constexpr int DT = (HD + 15) / 16;          // 16-channel output tiles (rows past head_dim are zero and never stored)
+    constexpr int VP = 64 + 4;                  // V^T row pitch in elements (68: the 8-byte reads of 16 rows x 4 lane groups spread over the banks)
+    __shared__ __attribute__((aligned(16))) h16_t svt[4][DT * 16 * VP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int widx = blockIdx.x * 4 + wave;
+    if (widx >= nwin) return;                   // wave-uniform; no workgroup barrier below
+    const int T = win * win;
+    const int Hp = (H + win - 1) / win * win, Wp = (W + win - 1) / win * win;
+    const int nwx = Wp / win;
+    const int wy = widx / nwx, wx = widx % nwx;
+    const int h = blockIdx.y, b = blockIdx.z;
+    h16_t* vt = svt[wave];
+    auto token = [&](int t, int64_t& pix) {   // -> 0: beyond the window, 1: real pixel, 2: padding of the grid
+        if (t >= T) return 0;
+        const int oy = (wy * win + t / win + shift) % Hp, ox = (wx * win + t % win + shift) % Wp;
+        pix = ((int64_t)b * H + oy) * W + ox;
+        return (oy < H && ox < W) ? 1 : 2;
+    };
+    auto pad_frag = [&](const float* pv, int c0) {
+        u32x4 f = {0u, 0u, 0u, 0u};
+        if (pv) {
+            f.x = pack_h16x2(pv[h * HD + c0 + 0], pv[h * HD + c0 + 1]); f.y = pack_h16x2(pv[h * HD + c0 + 2], pv[h * HD + c0 + 3]);
+            f.z = pack_h16x2(pv[h * HD + c0 + 4], pv[h * HD + c0 + 5]); f.w = pack_h16x2(pv[h * HD + c0 + 6], pv[h * HD + c0 + 7]);
+        }
+        return f;
+    };
+    // ---- Q and K fragments: token 16 i + fr, channels kb * 32 + g * 8 .. + 8 ------------------------------------------------------
+    u32x4 qf[4][KB], kf[4][KB];
+    int64_t mypix[4];
+    int kind[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        kind[i] = token(16 * i + fr, mypix[i]);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int c0 = kb * 32 + g * 8;
+            u32x4 fq = {0u, 0u, 0u, 0u}, fk = {0u, 0u, 0u, 0u};
+            if (c0 < HD) {
+                if (kind[i] == 1) {
+                    fq = *reinterpret_cast<const u32x4*>(q + mypix[i] * ldq + h * HD + c0);
+                    fk = *reinterpret_cast<const u32x4*>(k + mypix[i] * ldk + h * HD + c0);
+                } else if (kind[i] == 2) {
+                    fq = pad_frag(pad_q, c0);
+                    fk = pad_frag(pad_k, c0);
+                }
+            }
+            qf[i][kb] = fq; kf[i][kb] = fk;
+        }
+    }
+    // ---- V^T image of this window in LDS: vt[d][key], keys past the window zero ---------------------------------------------------
+    if (DT * 16 > HD)
+        for (int c = lane; c < (DT * 16 - HD) * VP; c += 64) vt[HD * VP + c] = (h16_t)0;
+    for (int c = lane; c < 64 * (HD / 8); c += 64) {
+        const int t = c / (HD / 8), c0 = (c % (HD / 8)) * 8;
+        int64_t pix;
+        const int kd = token(t, pix);
+        u32x4 f = {0u, 0u, 0u, 0u};
+        if (kd == 1) f = *reinterpret_cast<const u32x4*>(v + pix * ldv_ + h * HD + c0);
+        else if (kd == 2) f = pad_frag(pad_v, c0);
+        const uint32_t w4[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vt[(c0 + e) * VP + t] = (h16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    }
+    // ---- S^T tiles: st[j][i] = K_j Q_i^T; lane (g, fr): keys 16 j + 4 g + r (r = 0..3) of query 16 i + fr -------------------------
+    f32x4 st[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) acc = mfma16x16x32_h16(kf[j][kb], qf[i][kb], acc);
+            st[j][i] = acc;
+        }
+    // ---- softmax over the keys of each query column ---------------------------------------------------------------------------------
+    float inv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* a4 = reinterpret_cast<float*>(&st[j][i]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a4[r] = (16 * j + 4 * g + r < T) ? a4[r] * scale : -INFINITY;
+                m = fmaxf(m, a4[r]);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* a4 = reinterpret_cast<float*>(&st[j][i]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a4[r] = __expf(a4[r] - m);      // exp(-inf) = 0 for the masked keys
+                l += a4[r];
+            }
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        inv[i] = 1.0f / l;
+    }
+    __builtin_amdgcn_wave_barrier();            // this wave's V^T stores are complete before its reads (same wave: program order + fence)
+    __threadfence_block();
+    // ---- O^T tiles: (16 channels) x (16 queries), contraction over the permuted key index ----------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32x4 pf[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            pf[kb].x = pack_h16x2(st[2 * kb][i].x, st[2 * kb][i].y);         pf[kb].y = pack_h16x2(st[2 * kb][i].z, st[2 * kb][i].w);
+            pf[kb].z = pack_h16x2(st[2 * kb + 1][i].x, st[2 * kb + 1][i].y); pf[kb].w = pack_h16x2(st[2 * kb + 1][i].z, st[2 * kb + 1][i].w);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const h16_t* row = vt + (dt * 16 + fr) * VP + 32 * kb + 4 * g;     // keys 32 kb + 4 g .. + 3 and 32 kb + 16 + 4 g .. + 3
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(row), hi = *reinterpret_cast<const u32x2*>(row + 16);
+                const u32x4 af = {lo.x, lo.y, hi.x, hi.y};
+                o = mfma16x16x32_h16(af, pf[kb], o);
+            }
+            // lane (g, fr): channels dt * 16 + 4 g + r of query 16 i + fr
+            if (kind[i] == 1 && dt * 16 + 4 * g < HD) {
+                u32x2 pk;
+                pk.x = pack_h16x2(o.x * inv[i], o.y * inv[i]);
+                pk.y = pack_h16x2(o.z * inv[i], o.w * inv[i]);
+                *reinterpret_cast<u32x2*>(out + mypix[i] * ldo + h * HD + dt * 16 + 4 * g) = pk;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ general attention on the matrix cores
+// 16-bit inputs, head_dim 16 / 32 / 64: a workgroup of four waves takes 256 queries of one (image, head) and walks the keys in blocks
+// of 64 (online softmax).  Per key block the workgroup stages K (row-major, 16-byte chunks XOR-swizzled by the row) and V^T in LDS
+// once; every wave then forms S^T = K Q^T for its 64 queries (Q fragments stay in registers for the whole kernel), rescales its O^T
+// accumulators by exp(m_old - m_new) — a per-lane scalar, because a lane's accumulators all belong to query column (lane & 15) —
+// and adds V^T P^T with the permuted contraction index of window_attention_mfma_kernel (P^T is used where the MFMA left it).
+template <int HD>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const h16_t* q, int ldq, const h16_t* k, int ldk, const h16_t* v, int ldv_, h16_t* out,
+                                                             int ldo, int Nq, int Nk, float scale) {
+    constexpr int KB = (HD + 31) / 32, DT = (HD + 15) / 16, CH = HD / 8;   // 16-byte chunks per K row
+    constexpr int VP = 64 + 4;
+    constexpr int KC = CH <= 4 ? 4 : 8;          // row pitch in chunks: a power of two (XOR swizzle); chunks past head_dim are zero
+    __shared__ __attribute__((aligned(16))) u32x4 sk[64 * KC];                   // K block: row r, chunk c at r * KC + (c ^ (r & (KC - 1)))
+    __shared__ __attribute__((aligned(16))) h16_t svt[DT * 16 * VP];             // V^T block (rows past head_dim zero)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    const h16_t* qb = q + (int64_t)b * Nq * ldq + h * HD;
+    const h16_t* kbp = k + (int64_t)b * Nk * ldk + h * HD;
+    const h16_t* vb = v + (int64_t)b * Nk * ldv_ + h * HD;
+    u32x4 qf[4][KB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int qi = q0 + 16 * i + fr, c0 = kb * 32 + g * 8;
+            qf[i][kb] = (qi < Nq && c0 < HD) ? *reinterpret_cast<const u32x4*>(qb + (int64_t)qi * ldq + c0) : u32x4{0u, 0u, 0u, 0u};
+        }
+    if (DT * 16 > HD)
+        for (int c = threadIdx.x; c < (DT * 16 - HD) * VP; c += 256) svt[HD * VP + c] = (h16_t)0;
+    f32x4 o[4][DT];
+    float m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m[i] = -INFINITY; l[i] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int n0 = 0; n0 < Nk; n0 += 64) {
+        __syncthreads();                          // the previous block's fragment reads are finished
+        for (int c = threadIdx.x; c < 64 * KC; c += 256) {
+            const int r = c / KC, cc = c % KC;
+            u32x4 f = {0u, 0u, 0u, 0u};
+            if (n0 + r < Nk && cc < CH) f = *reinterpret_cast<const u32x4*>(kbp + (int64_t)(n0 + r) * ldk + cc * 8);
+            sk[r * KC + (cc ^ (r & (KC - 1)))] = f;
+        }
+        for (int c = threadIdx.x; c < 64 * CH; c += 256) {
+            const int t = c / CH, c0 = (c % CH) * 8;
+            u32x4 f = {0u, 0u, 0u, 0u};
+            if (n0 + t < Nk) f = *reinterpret_cast<const u32x4*>(vb + (int64_t)(n0 + t) * ldv_ + c0);
+            const uint32_t w4[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) svt[(c0 + e) * VP + t] = (h16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        }
+        __syncthreads();
+        // S^T tiles for this wave's 64 queries
+        f32x4 st[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 kf[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int r = 16 * j + fr, cc = kb * 4 + g;
+                kf[kb] = cc < KC ? sk[r * KC + (cc ^ (r & (KC - 1)))] : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc = mfma16x16x32_h16(kf[kb], qf[i][kb], acc);
+                st[j][i] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float mb = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* a4 = reinterpret_cast<float*>(&st[j][i]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a4[r] = (n0 + 16 * j + 4 * g + r < Nk) ? a4[r] * scale : -INFINITY;
+                    mb = fmaxf(mb, a4[r]);
+                }
+            }
+            mb = fmaxf(mb, __shfl_xor(mb, 16));
+            mb = fmaxf(mb, __shfl_xor(mb, 32));
+            const float mn = fmaxf(m[i], mb);     // finite: every block holds at least one real key
+            const float c = __expf(m[i] - mn);    // exp(-inf) = 0 on the first block
+            float lb = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* a4 = reinterpret_cast<float*>(&st[j][i]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a4[r] = __expf(a4[r] - mn);
+                    lb += a4[r];
+                }
+            }
+            lb += __shfl_xor(lb, 16);
+            lb += __shfl_xor(lb, 32);
+            l[i] = l[i] * c + lb;
+            m[i] = mn;
+            u32x4 pf[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                pf[kb].x = pack_h16x2(st[2 * kb][i].x, st[2 * kb][i].y);         pf[kb].y = pack_h16x2(st[2 * kb][i].z, st[2 * kb][i].w);
+                pf[kb].z = pack_h16x2(st[2 * kb + 1][i].x, st[2 * kb + 1][i].y); pf[kb].w = pack_h16x2(st[2 * kb + 1][i].z, st[2 * kb + 1][i].w);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x4 acc = o[i][dt];
+                acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const h16_t* row = svt + (dt * 16 + fr) * VP + 32 * kb + 4 * g;
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(row), hi = *reinterpret_cast<const u32x2*>(row + 16);
+                    const u32x4 af = {lo.x, lo.y, hi.x, hi.y};
+                    acc = mfma16x16x32_h16(af, pf[kb], acc);
+                }
+                o[i][dt] = acc;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qi = q0 + 16 * i + fr;
+        if (qi >= Nq) continue;
+        const float inv = 1.0f / l[i];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            if (dt * 16 + 4 * g >= HD) continue;
+            u32x2 pk;
+            pk.x = pack_h16x2(o[i][dt].x * inv, o[i][dt].y * inv);
+            pk.y = pack_h16x2(o[i][dt].z * inv, o[i][dt].w * inv);
+            *reinterpret_cast<u32x2*>(out + ((int64_t)b * Nq + qi) * ldo + h * HD + dt * 16 + 4 * g) = pk;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ random-feature attention
 __device__ __forceinline__ float phi(float t, float sc) { return fminf(fmaxf(t * sc, 0.f) + 1e-6f, 1e4f); }
 
-// pass 1, grid (heads, B), 256 threads: kv[f][d] = sum_n phi(k_n)[f] v_n[d], ksum[f] = sum_n phi(k_n)[f]
+// pass 1, grid (heads, B, chunks), 256 threads: kv[f][d] = sum_n phi(k_n)[f] v_n[d], ksum[f] = sum_n phi(k_n)[f] over the chunk's
+// LINATTN_CHUNK tokens (one workgroup per (image, head) looped over 25 600 tokens on 96 workgroups: 9 ms per call at config 5);
+// pass 1b adds the chunk partials in chunk order (deterministic)
+#define LINATTN_CHUNK 512
 __global__ __launch_bounds__(256) void linattn_kv_kernel(int dt, const void* k, int ldk, const void* v, int ldv_, const float* rf, int nb,
-                                                          int N, int hd, float* ws) {
+                                                          int Ntot, int hd, float* ws) {
     __shared__ float sphi[64][65], svv[64][65], srf[64][65];
-    const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
-    float* kv = ws + ((int64_t)b * heads + h) * (nb * hd + nb);
+    const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x, chunk = blockIdx.z, nchunk = gridDim.z;
+    const int per = nb * hd + nb;
+    float* kv = ws + (((int64_t)b * heads + h) * (nchunk + 1) + 1 + chunk) * per;   // slot 0 of an (image, head): the reduced result
     float* ksum = kv + nb * hd;
+    const int N = min(Ntot, (chunk + 1) * LINATTN_CHUNK);
     const float sc = 1.0f / sqrtf((float)nb);
     for (int i = threadIdx.x; i < nb * hd; i += 256) srf[i / hd][i % hd] = rf[i];
     // each thread owns up to 16 (f, d) pairs and, for t < nb, one ksum entry
     float acc[16], ks = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int n0 = 0; n0 < N; n0 += 64) {
+    for (int n0 = chunk * LINATTN_CHUNK; n0 < N; n0 += 64) {
         const int nt = min(64, N - n0);
         __syncthreads();
-        for (int i = threadIdx.x; i < nt * hd; i += 256) svv[i / hd][i % hd] = ldv(v, dt, ((int64_t)b * N + n0 + i / hd) * ldv_ + h * hd + i % hd);
+        for (int i = threadIdx.x; i < nt * hd; i += 256) svv[i / hd][i % hd] = ldv(v, dt, ((int64_t)b * Ntot + n0 + i / hd) * ldv_ + h * hd + i % hd);
         for (int i = threadIdx.x; i < nt * nb; i += 256) {
             const int r = i / nb, f = i % nb;
             float s = 0.f;
-            for (int d = 0; d < hd; ++d) s += ldv(k, dt, ((int64_t)b * N + n0 + r) * ldk + h * hd + d) * srf[f][d];
+            for (int d = 0; d < hd; ++d) s += ldv(k, dt, ((int64_t)b * Ntot + n0 + r) * ldk + h * hd + d) * srf[f][d];
             sphi[r][f] = phi(s, sc);
         }
         __syncthreads();
@@ -164,13 +462,22 @@ __global__ __launch_bounds__(256) void linattn_kv_kernel(int dt, const void* k, 
     }
     if (threadIdx.x < nb) ksum[threadIdx.x] = ks;
 }
+// pass 1b, grid (heads * B): slot 0 = sum of the chunk partials, in chunk order
+__global__ __launch_bounds__(256) void linattn_reduce_kernel(int per, int nchunk, float* ws) {
+    float* base = ws + (int64_t)blockIdx.x * (nchunk + 1) * per;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += base[(int64_t)(1 + c) * per + i];
+        base[i] = s;
+    }
+}
 // pass 2, grid (ceil(N / 128), heads, B): out = clamp(phi(q) kv, +-1e4) / max(phi(q) . ksum, 1e-6)
 template <int HD>
 __global__ __launch_bounds__(128) void linattn_out_kernel(int dt, const void* q, int ldq, const float* rf, int nb, void* out, int ldo,
-                                                           int N, const float* ws) {
+                                                           int N, const float* ws, int nchunk) {
     __shared__ float skv[64 * HD + 64], srf[64 * HD];
     const int h = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
-    const float* kv = ws + ((int64_t)b * heads + h) * (nb * HD + nb);
+    const float* kv = ws + ((int64_t)b * heads + h) * (nchunk + 1) * (nb * HD + nb);
     for (int i = threadIdx.x; i < nb * HD + nb; i += 128) skv[i] = kv[i];
     for (int i = threadIdx.x; i < nb * HD; i += 128) srf[i] = rf[i];
     __syncthreads();
@@ -243,6 +550,58 @@ __global__ __launch_bounds__(256) void deform_kernel(int dt, const void* v, int 
     }
 }
 
+// 16-bit maps, head_dim % 8 == 0: one thread per (token, head, 8-channel chunk) — the sampling positions, bilinear weights and the
+// softmax over the points are computed once per chunk instead of once per channel, and every corner is one 16-byte load
+__global__ __launch_bounds__(256) void deform_vec_kernel(const h16_t* v, int ldv_, const float* off, int ldoff, const float* aw, int ldaw,
+                                                          h16_t* out, int ldo, int B, int H, int W, int heads, int hd, int np, int align) {
+    const int cpb = hd / 8;
+    const int64_t total = (int64_t)B * H * W * heads * cpb;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ck = (int)(i % cpb);
+        int64_t p = i / cpb;
+        const int h = (int)(p % heads);
+        p /= heads;   // b*H*W + token
+        const int n = (int)(p % ((int64_t)H * W));
+        const int b = (int)(p / ((int64_t)H * W));
+        const float refx = (float)(n % W) / (float)max(W - 1, 1) * 2.f - 1.f;
+        const float refy = (float)(n / W) / (float)max(H - 1, 1) * 2.f - 1.f;
+        const float* ar = aw + p * ldaw + h * np;
+        float m = -INFINITY;
+        for (int j = 0; j < np; ++j) m = fmaxf(m, ar[j]);
+        float den = 0.f;
+        for (int j = 0; j < np; ++j) den += expf(ar[j] - m);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < np; ++j) {
+            const float* o = off + p * ldoff + (h * np + j) * 2;
+            const float gx = fminf(fmaxf(refx + 0.25f * tanhf(o[0]), -1.f), 1.f);
+            const float gy = fminf(fmaxf(refy + 0.25f * tanhf(o[1]), -1.f), 1.f);
+            const float ix = align ? (gx + 1.f) * 0.5f * (float)(W - 1) : ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+            const float iy = align ? (gy + 1.f) * 0.5f * (float)(H - 1) : ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+            const float fx = floorf(ix), fy = floorf(iy);
+            const int x0 = (int)fx, y0 = (int)fy;
+            const float tx = ix - fx, ty = iy - fy;
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx) {
+                    const int xx = x0 + cx, yy = y0 + cy;
+                    if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                        const float wgt = (cx ? tx : 1.f - tx) * (cy ? ty : 1.f - ty);
+                        float vv[8];
+                        load_vec_f32(v + (((int64_t)b * H + yy) * W + xx) * ldv_ + h * hd + ck * 8, vv);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) s[q] += wgt * vv[q];   // same corner order and products as the scalar kernel
+                    }
+                }
+            const float wj = expf(ar[j] - m) / den;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += wj * s[q];
+        }
+        store_vec_f32(out + p * ldo + h * hd + ck * 8, acc);
+    }
+}
+
 }  // namespace
 
 #define HD_SWITCH(hd, CALL)          \
@@ -265,6 +624,19 @@ extern "C" int ymk_attention(int32_t dtype, const void* q, int32_t ldq, const vo
     const int C = heads * hd;
     if (ldq < C || ldk < C || ldv < C || ldo < C) return YMK_E_BADARG;
     if (B <= 0 || Nq <= 0) return YMK_OK;
+    {   // 16-bit maps with 16-byte aligned head slices: 256 queries per workgroup on the matrix cores
+        auto al = [](const void* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
+        if (dtype == YMK_H16 && hd % 8 == 0 && hd >= 8 && hd <= 64 && al(q, ldq) && al(k, ldk) && al(v, ldv) &&
+            (reinterpret_cast<uintptr_t>(out) & 7) == 0 && ldo % 4 == 0 && !(ymk_disabled() & YMK_OFF_WINATTN_MFMA)) {
+            const dim3 mgrid((Nq + 255) / 256, heads, B);
+#define MCALL(HDV)                                                                                                                        \
+    hipLaunchKernelGGL(attention_mfma_kernel<HDV>, mgrid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)q, ldq, (const h16_t*)k, ldk, \
+                       (const h16_t*)v, ldv, (h16_t*)out, ldo, Nq, Nk, scale)
+            HD_SWITCH(hd, MCALL)
+#undef MCALL
+            return ymk_launch_status();
+        }
+    }
     const dim3 grid((Nq + 127) / 128, heads, B);
 #define CALL(HDV) \
     hipLaunchKernelGGL(attention_kernel<HDV>, grid, dim3(128), 0, (hipStream_t)stream, dtype, q, ldq, k, ldk, v, ldv, out, ldo, Nq, Nk, scale)
@@ -286,6 +658,19 @@ extern "C" int ymk_window_attention(int32_t dtype, const void* q, int32_t ldq, c
     if (lds > 64 * 1024) return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
     const int nwy = (H + win - 1) / win, nwx = (W + win - 1) / win;
+    // 16-bit maps with 16-byte aligned head slices: one wave per (window, head) on the matrix cores
+    auto al = [](const void* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
+    if (dtype == YMK_H16 && win * win <= 64 && hd % 8 == 0 && hd >= 8 && hd <= 64 && al(q, ldq) && al(k, ldk) && al(v, ldv) &&
+        (reinterpret_cast<uintptr_t>(out) & 7) == 0 && ldo % 4 == 0 && !(ymk_disabled() & YMK_OFF_WINATTN_MFMA)) {
+        const int nwin = nwy * nwx;
+        const dim3 mgrid((nwin + 3) / 4, heads, B);
+#define MCALL(HDV)                                                                                                                          \
+    hipLaunchKernelGGL(window_attention_mfma_kernel<HDV>, mgrid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)q, ldq, (const h16_t*)k, ldk, \
+                       (const h16_t*)v, ldv, (h16_t*)out, ldo, H, W, scale, win, shift, pad_q, pad_k, pad_v, nwin)
+        HD_SWITCH(hd, MCALL)
+#undef MCALL
+        return ymk_launch_status();
+    }
     const dim3 grid(nwy * nwx, heads, B);
 #define CALL(HDV)                                                                                                                   \
     hipLaunchKernelGGL(window_attention_kernel<HDV>, grid, dim3(256), lds, (hipStream_t)stream, dtype, q, ldq, k, ldk, v, ldv, out, ldo, \
@@ -304,10 +689,13 @@ extern "C" int ymk_linear_attention(int32_t dtype, const void* q, int32_t ldq, c
     const int C = heads * hd;
     if (ldq < C || ldk < C || ldv < C || ldo < C) return YMK_E_BADARG;
     if (B <= 0 || N <= 0) return YMK_OK;
-    hipLaunchKernelGGL(linattn_kv_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, dtype, k, ldk, v, ldv, rf, nb, N, hd, ws);
+    const int nchunk = (N + LINATTN_CHUNK - 1) / LINATTN_CHUNK;
+    if (nchunk > 65535) return YMK_E_BADARG;
+    hipLaunchKernelGGL(linattn_kv_kernel, dim3(heads, B, nchunk), dim3(256), 0, (hipStream_t)stream, dtype, k, ldk, v, ldv, rf, nb, N, hd, ws);
+    hipLaunchKernelGGL(linattn_reduce_kernel, dim3(heads * B), dim3(256), 0, (hipStream_t)stream, nb * hd + nb, nchunk, ws);
     const dim3 grid((N + 127) / 128, heads, B);
 #define CALL(HDV) \
-    hipLaunchKernelGGL(linattn_out_kernel<HDV>, grid, dim3(128), 0, (hipStream_t)stream, dtype, q, ldq, rf, nb, out, ldo, N, (const float*)ws)
+    hipLaunchKernelGGL(linattn_out_kernel<HDV>, grid, dim3(128), 0, (hipStream_t)stream, dtype, q, ldq, rf, nb, out, ldo, N, (const float*)ws, nchunk)
     HD_SWITCH(hd, CALL)
 #undef CALL
     return ymk_launch_status();
@@ -321,11 +709,18 @@ extern "C" int ymk_deform_attention(int32_t dtype, const void* v, int32_t ldv, c
     const int C = heads * hd;
     if (ldv < C || ldo < C || ldoff < heads * n_points * 2 || ldaw < heads * n_points) return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
-    const int64_t total = (int64_t)B * H * W * C;
-    const int64_t nb = (total + 255) / 256;
 #ifndef YMK_MAX_BLOCKS
 #define YMK_MAX_BLOCKS 16384
 #endif
+    if (dtype == YMK_H16 && hd % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const int64_t tv = (int64_t)B * H * W * heads * (hd / 8), nbv = (tv + 255) / 256;
+        hipLaunchKernelGGL(deform_vec_kernel, dim3((unsigned)(nbv > YMK_MAX_BLOCKS ? YMK_MAX_BLOCKS : nbv)), dim3(256), 0, (hipStream_t)stream,
+                           (const h16_t*)v, ldv, off, ldoff, aw, ldaw, (h16_t*)out, ldo, B, H, W, heads, hd, n_points, align_corners);
+        return ymk_launch_status();
+    }
+    const int64_t total = (int64_t)B * H * W * C;
+    const int64_t nb = (total + 255) / 256;
     hipLaunchKernelGGL(deform_kernel, dim3((unsigned)(nb > YMK_MAX_BLOCKS ? YMK_MAX_BLOCKS : nb)), dim3(256), 0, (hipStream_t)stream, dtype, v, ldv, off, ldoff,
                        aw, ldaw, out, ldo, B, H, W, heads, hd, n_points, align_corners);
     return ymk_launch_status();

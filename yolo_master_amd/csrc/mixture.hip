@@ -58,14 +58,45 @@ __global__ __launch_bounds__(256) void activation_kernel(void* x, int dt, int ld
 }
 
 // ------------------------------------------------------------------------------------------------ group norm
-// one workgroup per (image, group): mean, then centred variance (two passes over an L2-resident slab)
+// Statistics of one (image, group) slab, split over `nchunk` workgroups (grid.y) so that 16 images x 8 groups do not leave half
+// the chip idle on a 200 MB map: each workgroup takes a run of pixels, computes ITS mean and centred sum of squares (two passes
+// over a slab that stays in L2), and the partials are combined with the exact pairwise update (Chan et al.) in chunk order —
+// deterministic, and as accurate as the reference's single two-pass evaluation.  nchunk == 1: final (mean, rstd) written directly.
+#define GN_MAX_CHUNKS 64
+__device__ __forceinline__ void gn_emit(float mean, float m2, float n, int nchunk, float eps, float* stats, float* part) {
+    if (threadIdx.x != 0) return;
+    const int slab = blockIdx.x;
+    if (nchunk == 1) {
+        stats[2 * slab] = mean;
+        stats[2 * slab + 1] = 1.0f / sqrtf(m2 / n + eps);
+    } else {
+        float* o = part + ((size_t)slab * GN_MAX_CHUNKS + blockIdx.y) * 3;
+        o[0] = mean; o[1] = m2; o[2] = n;
+    }
+}
+__global__ __launch_bounds__(64) void gn_finalize_kernel(int nchunk, float eps, float* stats, const float* part) {
+    const int slab = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float* p = part + (size_t)slab * GN_MAX_CHUNKS * 3;
+    float mean = p[0], m2 = p[1], n = p[2];
+    for (int c = 1; c < nchunk; ++c) {   // (mean, M2, n) + (mean_c, M2_c, n_c)
+        const float mc = p[3 * c], m2c = p[3 * c + 1], nc = p[3 * c + 2];
+        const float tot = n + nc, d = mc - mean;
+        mean += d * (nc / tot);
+        m2 += m2c + d * d * (n * nc / tot);
+        n = tot;
+    }
+    stats[2 * slab] = mean;
+    stats[2 * slab + 1] = 1.0f / sqrtf(m2 / n + eps);
+}
 __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x, int dt, int ldx, int HW, int C, int groups, float eps,
-                                                        float* stats) {
+                                                        float* stats, float* part, int nchunk) {
     __shared__ float sh[4];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cg = C / groups;
-    const int64_t n = (int64_t)HW * cg;
-    const int64_t base = (int64_t)b * HW * ldx + (int64_t)g * cg;
+    const int p0 = (int)((int64_t)HW * blockIdx.y / nchunk), p1 = (int)((int64_t)HW * (blockIdx.y + 1) / nchunk);
+    const int64_t n = (int64_t)(p1 - p0) * cg;
+    const int64_t base = ((int64_t)b * HW + p0) * ldx + (int64_t)g * cg;
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 256) s += ldv(x, dt, base + (i / cg) * ldx + (i % cg));
     const float mean = block_sum(s, sh) / (float)n;
@@ -74,11 +105,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x, int dt, in
         const float d = ldv(x, dt, base + (i / cg) * ldx + (i % cg)) - mean;
         q += d * d;
     }
-    const float var = block_sum(q, sh) / (float)n;
-    if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = mean;
-        stats[2 * blockIdx.x + 1] = 1.0f / sqrtf(var + eps);
-    }
+    gn_emit(mean, block_sum(q, sh), (float)n, nchunk, eps, stats, part);
 }
 __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, int dt, int ldx, void* y, int odt, int ldy, const void* res,
                                                         int ldr, int B, int HW, int C, int groups, const float* weight,
@@ -280,12 +307,18 @@ __global__ __launch_bounds__(256) void token_softmax_kernel(const float* logits,
             s *= fmaxf(ssel, 1e-6f);   // renormalise over the selected set (sum clamped at 1e-6)
         }
         const int b = (int)(p / HW);
+        // "expert e is active on image b": the 64 tokens of a wave almost always lie in one image, so the wave votes and ONE lane
+        // raises the flag (every token doing it serialised ~10^4 atomics on three addresses: 0.6 ms per call at 16 x 80 x 80 tokens)
+        const int b0 = __builtin_amdgcn_readfirstlane(b);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             if (e < n) {
                 const bool on = (sel >> e) & 1u;
                 w[p * ldw + e] = on ? v[e] / s : 0.f;
-                if (on && active[b * n + e] == 0) atomicOr(&active[b * n + e], 1);
+                const unsigned long long vote = __ballot(on && b == b0);   // the wave's tokens of image b0 that selected e
+                if (b == b0) {
+                    if (vote && (int)(threadIdx.x & 63) == __builtin_ffsll((long long)vote) - 1 && active[b * n + e] == 0) atomicOr(&active[b * n + e], 1);
+                } else if (on && active[b * n + e] == 0) atomicOr(&active[b * n + e], 1);   // a wave straddling two images
             }
     }
 }
@@ -408,13 +441,46 @@ __global__ __launch_bounds__(256) void activation_vec_kernel(T* x, int ldx, int6
     }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, int HW, int C, int groups, float eps, float* stats) {
+__global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, int HW, int C, int groups, float eps, float* stats, float* part,
+                                                            int nchunk) {
     constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ float sh[4];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cg = C / groups, ncv = cg / VEC;
-    const int64_t nv = (int64_t)HW * ncv;
-    const T* base = x + (int64_t)b * HW * ldx + (int64_t)g * cg;
+    const int p0 = (int)((int64_t)HW * blockIdx.y / nchunk), p1 = (int)((int64_t)HW * (blockIdx.y + 1) / nchunk);
+    const int64_t nv = (int64_t)(p1 - p0) * ncv;
+    const T* base = x + ((int64_t)b * HW + p0) * ldx + (int64_t)g * cg;
+    const float n = (float)(p1 - p0) * (float)cg;
+    constexpr int RV = 8;                        // vectors a thread can keep in registers between the two passes
+    if (nv <= (int64_t)RV * 256) {               // the usual case (chunks of ~16k elements): ONE read of the slab, exact two-pass arithmetic
+        u32x4 keep[RV];
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r) {
+            const int64_t i = threadIdx.x + (int64_t)r * 256;
+            keep[r] = u32x4{0u, 0u, 0u, 0u};
+            if (i < nv) {
+                keep[r] = *reinterpret_cast<const u32x4*>(base + (i / ncv) * ldx + (i % ncv) * VEC);
+                float v[VEC];
+                load_vec_f32(reinterpret_cast<const T*>(&keep[r]), v);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) s += v[q];
+            }
+        }
+        const float mean = block_sum(s, sh) / n;
+        float qq = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r) {
+            if (threadIdx.x + (int64_t)r * 256 < nv) {
+                float v[VEC];
+                load_vec_f32(reinterpret_cast<const T*>(&keep[r]), v);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) qq += (v[q] - mean) * (v[q] - mean);
+            }
+        }
+        gn_emit(mean, block_sum(qq, sh), n, nchunk, eps, stats, part);
+        return;
+    }
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < nv; i += 256) {
         float v[VEC];
@@ -422,7 +488,6 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, 
 #pragma unroll
         for (int q = 0; q < VEC; ++q) s += v[q];
     }
-    const float n = (float)HW * (float)cg;
     const float mean = block_sum(s, sh) / n;
     float qq = 0.f;
     for (int64_t i = threadIdx.x; i < nv; i += 256) {
@@ -431,11 +496,7 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, 
 #pragma unroll
         for (int q = 0; q < VEC; ++q) qq += (v[q] - mean) * (v[q] - mean);
     }
-    const float var = block_sum(qq, sh) / n;
-    if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = mean;
-        stats[2 * blockIdx.x + 1] = 1.0f / sqrtf(var + eps);
-    }
+    gn_emit(mean, block_sum(qq, sh), n, nchunk, eps, stats, part);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* x, int ldx, T* y, int ldy, const T* res, int ldr, int B, int HW, int C,
@@ -758,14 +819,21 @@ extern "C" int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y
     if (B <= 0 || HW <= 0) return YMK_OK;
     const int V = vecw(dtype);
     const bool vin = C % V == 0 && ldx % V == 0 && al16(x);
+    // chunks of ~16k elements per workgroup, enough of them to fill the chip, at most GN_MAX_CHUNKS and one per pixel
+    const int64_t celems = dtype == YMK_F32 ? 8192 : 16384;   // what a workgroup keeps in registers between its two passes (gn_stats_vec_kernel)
+    int64_t want = ((int64_t)HW * (C / groups) + celems - 1) / celems;
+    const int nchunk = (int)(want < 1 ? 1 : want > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : want > HW ? HW : want);
+    float* part = stats_ws + (size_t)B * groups * 2;
+    const dim3 sgrid(B * groups, nchunk);
     if (vin && (C / groups) % V == 0) {   // statistics: whole vectors inside a group
         if (dtype == YMK_BF16)
-            hipLaunchKernelGGL(gn_stats_vec_kernel<h16_t>, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, HW, C, groups, eps, stats_ws);
+            hipLaunchKernelGGL(gn_stats_vec_kernel<h16_t>, sgrid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, HW, C, groups, eps, stats_ws, part, nchunk);
         else
-            hipLaunchKernelGGL(gn_stats_vec_kernel<float>, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, HW, C, groups, eps, stats_ws);
+            hipLaunchKernelGGL(gn_stats_vec_kernel<float>, sgrid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, HW, C, groups, eps, stats_ws, part, nchunk);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, dtype, ldx, HW, C, groups, eps, stats_ws);
+        hipLaunchKernelGGL(gn_stats_kernel, sgrid, dim3(256), 0, (hipStream_t)stream, x, dtype, ldx, HW, C, groups, eps, stats_ws, part, nchunk);
     }
+    if (nchunk > 1) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, nchunk, eps, stats_ws, (const float*)part);
     if (vin && out_dtype == dtype && ldy % V == 0 && al16(y) && (!residual || (ldr % V == 0 && al16(residual)))) {
         const int64_t total = (int64_t)B * HW * (C / V);
         if (dtype == YMK_BF16)

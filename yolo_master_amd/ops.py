@@ -625,6 +625,46 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
 # validated on MI355X by tests/test_gpu_mixture.py (first hardware run: round 2, profiles/r02_first_hw_run.log).  There is
 # no CPU / PyTorch fallback: every wrapper goes through `_nhwc` -> `require_gpu`.  Conventions as above: NHWC views
 # [B, H, W, C] with a pixel stride ld >= C, activations in the compute dtype, statistics / gates / router math fp32.
+def _tensor_bytes(obj) -> int:
+    if torch.is_tensor(obj):
+        return obj.numel() * obj.element_size()
+    if isinstance(obj, (list, tuple)):
+        return sum(_tensor_bytes(o) for o in obj)
+    return 0
+
+
+def _timed(family: str, flops=None):
+    """Per-call HIP-event timing of a config-5 op under `family` (bench.py's roofline leg; inactive unless TIMER.start() was called).
+    Algorithmic bytes = every tensor argument once + the result once; flops from the op's shapes where it has a contraction."""
+    import functools
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def run(*a, **kw):
+            e0 = TIMER.begin()
+            r = fn(*a, **kw)
+            if e0 is not None:
+                outs = kw.get("out")
+                nb = _tensor_bytes(a) + _tensor_bytes([v for k, v in kw.items() if k != "out"]) + (_tensor_bytes(r) if outs is None else _tensor_bytes(outs))
+                TIMER.end(e0, family, nb, int(flops(*a, **kw)) if flops else 0)
+            return r
+        return run
+    return wrap
+
+
+def _attn_flops(q, k, v, heads, hd, *a, **kw):
+    nq, nk = q.shape[0] * q.shape[1] * q.shape[2], k.shape[1] * k.shape[2]
+    return 4 * nq * nk * heads * hd
+
+
+def _win_flops(q, k, v, heads, hd, scale, win, *a, **kw):
+    return 4 * q.shape[0] * q.shape[1] * q.shape[2] * win * win * heads * hd
+
+
+def _lin_flops(q, k, v, rf, heads, hd, *a, **kw):
+    return 8 * q.shape[0] * q.shape[1] * q.shape[2] * rf.shape[0] * heads * hd   # phi(k), phi(k)^T v, phi(q), phi(q) kv
+
+
 ACT_CODES = (False, True, "silu", "sigmoid", "gelu")   # conv / norm epilogues of the config-5 modules
 _ACT = {False: _lib.ACT_NONE, None: _lib.ACT_NONE, True: _lib.ACT_SILU, "silu": _lib.ACT_SILU, "sigmoid": _lib.ACT_SIGMOID,
         "gelu": _lib.ACT_GELU}
@@ -651,6 +691,7 @@ def conv2d_act(x, w_packed, bias, k: int, stride: int, act, out=None, residual=N
     return y
 
 
+@_timed("group_norm")
 def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, out_dtype=None, affine_rows=None, residual=None):
     """GroupNorm over (H, W, C/groups) per image and group, biased variance, fp32 statistics (torch.nn.GroupNorm;
     safe group counts nn/modules/utils.py:108-115).  weight/bias fp32 [C], or None (no affine), or [R][C] with
@@ -662,12 +703,13 @@ def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, ou
     ldr = _nhwc(residual)[4] if residual is not None else 0
     if residual is not None and residual.dtype != out.dtype:
         raise ValueError("group_norm: the residual has the output's dtype")
-    ws = torch.empty((B * groups * 2,), dtype=torch.float32, device=x.device)
+    ws = torch.empty((B * groups * (2 + 3 * 64),), dtype=torch.float32, device=x.device)   # (mean, rstd) + 64 chunk partials (mean, M2, n) per slab
     check(lib.ymk_group_norm(DT[x.dtype], _p(x), ldx, _p(out), DT[out.dtype], ldy, _p(residual), ldr, B, H * W, Cc, groups,
                              _p(weight), _p(bias), _p(affine_rows), float(eps), _ACT[act], _p(ws), _stream()), "group_norm")
     return out
 
 
+@_timed("layer_norm")
 def layer_norm(x, weight, bias, eps: float, out=None):
     """LayerNorm over the channel vector of every token (torch.nn.LayerNorm(C)), fp32 statistics."""
     B, H, W, Cc, ldx = _nhwc(x)
@@ -677,6 +719,7 @@ def layer_norm(x, weight, bias, eps: float, out=None):
     return out
 
 
+@_timed("eltwise")
 def _eltwise(op, a, b, alpha, out, what):
     B, H, W, Cc, lda = _nhwc(a)
     ldb = _nhwc(b)[4]
@@ -700,6 +743,7 @@ def lerp(a, b, alpha: float, out=None):
     return _eltwise(_lib.ELT_LERP, a, b, alpha, out, "lerp")
 
 
+@_timed("eltwise")
 def fma_gate(x, a, b, scale, out=None):
     """out = x + scale * a * b with scale a host float; b is a map [B,H,W,C] or a per-image channel gate [B,1,1,C] fp32
     (detail gate x*(1+s*g), context mixer x+s*c*gate, refinement x+s*r*g: moe/gated.py:1171-1218, hooks.py:60-68)."""
@@ -718,6 +762,7 @@ def fma_gate(x, a, b, scale, out=None):
     return out
 
 
+@_timed("eltwise")
 def channel_gate(x, gate, out=None):
     """out = x * gate with gate fp32 [B,1,1,C] (squeeze-excite gate of the gated MoE, moe/gated.py:333-341)."""
     B, H, W, Cc, ldx = _nhwc(x)
@@ -728,6 +773,7 @@ def channel_gate(x, gate, out=None):
     return out
 
 
+@_timed("weighted_sum")
 def weighted_sum(weights, parts, out=None):
     """out = sum_e weights[..., e] * parts[e]; weights fp32 [B,H,W,>=E] per token or [B,1,1,>=E] per image
     (MoA head mix moa/block.py:230-262, MoT expert blend mot/block.py:360-417, gated expert mix)."""
@@ -746,6 +792,7 @@ def weighted_sum(weights, parts, out=None):
     return out
 
 
+@_timed("pool")
 def mean_upsampled(parts, out=None):
     """out = mean_i nearest_resize(parts[i] -> size of parts[0]) (F.interpolate mode="nearest": src = floor(dst * h / H));
     PyramidContextMixer.forward moe/gated.py:1209-1216."""
@@ -762,6 +809,7 @@ def mean_upsampled(parts, out=None):
     return out
 
 
+@_timed("pool")
 def adaptive_avg_pool(x, Ho: int, Wo: int, out=None, out_dtype=None):
     """F.adaptive_avg_pool2d bins: rows [floor(i*H/Ho), ceil((i+1)*H/Ho))."""
     B, H, W, Cc, ldx = _nhwc(x)
@@ -771,6 +819,7 @@ def adaptive_avg_pool(x, Ho: int, Wo: int, out=None, out_dtype=None):
     return out
 
 
+@_timed("pool")
 def avg_pool(x, k: int, out=None, out_dtype=None):
     """F.avg_pool2d(kernel_size=k, stride=k): floor(H/k) x floor(W/k) outputs, remainder rows/columns dropped."""
     B, H, W, Cc, ldx = _nhwc(x)
@@ -779,6 +828,7 @@ def avg_pool(x, k: int, out=None, out_dtype=None):
     return out
 
 
+@_timed("pool")
 def channel_stats(x, want_std: bool = False):
     """Per image and channel mean (and biased std) over H*W in fp32: returns [B,1,1,C] (or [B,1,1,2C] = [mean | std],
     DualStreamGateRouter's global stream moe/gated.py:133-139)."""
@@ -797,6 +847,7 @@ def _qkv_geometry(q, k, v, heads, hd, what):
     return B, Hq, Wq, Hk, Wk, ldq, ldk, ldv
 
 
+@_timed("mix_attention", _attn_flops)
 def attention(q, k, v, heads: int, hd: int, scale: float, out=None):
     """softmax(q k^T * scale) v per (image, head).  q [B,Hq,Wq,heads*hd], k/v [B,Hk,Wk,heads*hd] channel-slice views
     (tokens row-major); any hd that is a multiple of 8.  MoA regional / global-exact heads (moa/heads.py:208-253,
@@ -808,6 +859,7 @@ def attention(q, k, v, heads: int, hd: int, scale: float, out=None):
     return out
 
 
+@_timed("window_attention", _win_flops)
 def window_attention(q, k, v, heads: int, hd: int, scale: float, win: int, shift: int = 0, pad_q=None, pad_k=None,
                      pad_v=None, out=None):
     """Attention inside win x win windows of the map padded (bottom / right) to a multiple of win; out-of-image tokens
@@ -826,6 +878,7 @@ def window_attention(q, k, v, heads: int, hd: int, scale: float, win: int, shift
     return out
 
 
+@_timed("linear_attention", _lin_flops)
 def linear_attention(q, k, v, rf, heads: int, hd: int, out=None):
     """ReLU random-feature attention of _GlobalAttnHead._linear_attn (moa/heads.py:318-352), fp32 math:
     phi(t) = min(relu(t rf^T / sqrt(nb)) + 1e-6, 1e4); out = clamp(phi(q) (phi(k)^T v), +-1e4) / max(phi(q) sum phi(k), 1e-6)."""
@@ -834,12 +887,14 @@ def linear_attention(q, k, v, rf, heads: int, hd: int, out=None):
         raise ValueError("linear_attention: q, k, v on one map; rf a contiguous fp32 [nb, hd] matrix")
     nb = rf.shape[0]
     out, ldo = _out_like(q, out)
-    ws = torch.empty((B * heads * (nb * hd + nb),), dtype=torch.float32, device=q.device)
+    nchunk = (H * W + 511) // 512    # csrc/mixattn.hip LINATTN_CHUNK: per (image, head) one reduced slot + one partial per 512-token chunk
+    ws = torch.empty((B * heads * (nchunk + 1) * (nb * hd + nb),), dtype=torch.float32, device=q.device)
     check(lib.ymk_linear_attention(DT[q.dtype], _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(rf), nb, _p(out), ldo, B, H * W, heads, hd,
                                    _p(ws), _stream()), "linear_attention")
     return out
 
 
+@_timed("deform_attention")
 def deform_attention(v, off_logits, aw_logits, heads: int, hd: int, n_points: int, align_corners: bool, out=None):
     """_DeformableTransformerExpert._deform_attn (mot/experts.py:381-459): per token and head, locations =
     clamp(ref + 0.25 * tanh(off_logits), -1, 1) around the token's own normalised position, weights = softmax over the
@@ -854,6 +909,7 @@ def deform_attention(v, off_logits, aw_logits, heads: int, hd: int, n_points: in
     return out
 
 
+@_timed("token_router")
 def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None):
     """Per-token softmax over the first n channels of fp32 logits scaled by inv_temp; with 0 < top_k < n the top_k
     largest are kept and renormalised (sum clamped at 1e-6), the rest set to 0 (mot/router.py:243-295, moa/router.py:50-62).
@@ -868,6 +924,7 @@ def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None):
     return out, active
 
 
+@_timed("token_router")
 def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_k: int, cplx_logit):
     """Decision tail of the gated MoE (moe/gated.py:124-166, 455-492): logits = clamp(a*g + (1-a)*loc, +-30) with
     a = sigmoid(alpha); probs = softmax(logits * inv_temp); top-k, weights / (sum + 1e-6); complexity = clamp(mean_b
@@ -889,6 +946,7 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
     return w, idx, probs, rows
 
 
+@_timed("expert_dw3")
 def expert_dw3(x, w, dil, idx, out=None):
     """Per-image expert depthwise 3x3 with per-expert dilation, slot-major (include/ymk_mixture.h ymk_expert_dw3): x NHWC [B, H, W, C],
     w [E, 9, C] in x's dtype, dil int32 [E], idx int32 [B, K] -> [K * B, H, W, C] (DiversifiedExpertGroup.dw_layers, gated.py:2265-2278)."""
@@ -902,6 +960,7 @@ def expert_dw3(x, w, dil, idx, out=None):
     return out
 
 
+@_timed("expert_conv")
 def expert_conv(x, w_packed, k: int, idx, out=None):
     """Per-image expert convolution, slot-major: out[j*B + b] = conv_kxk(x[b], w_packed[idx[b, j]]) (no bias, no activation;
     out[j*B:(j+1)*B] is the batch of slot j, a contiguous NHWC tensor);
@@ -933,6 +992,7 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
     return out
 
 
+@_timed("layout")
 def channel_shuffle_cat(parts, groups: int, out=None):
     """Channel concatenation followed by _channel_shuffle (moe/gated.py:1333-1338) in one pass:
     out[..., j * groups + i] = cat(parts)[..., i * (C / groups) + j]."""
@@ -947,6 +1007,7 @@ def channel_shuffle_cat(parts, groups: int, out=None):
     return out
 
 
+@_timed("layout")
 def pixel_shuffle2(t, out=None):
     """Depth-to-space by 2: t [B,H,W,4C] (phase-major channel slices) -> [B,2H,2W,C]; with the 4C-channel 1x1 convolution in
     front it is Proto's ConvTranspose2d(C, C, 2, 2) (nn/modules/block.py:101-107)."""
@@ -957,6 +1018,7 @@ def pixel_shuffle2(t, out=None):
     return out
 
 
+@_timed("layout")
 def tokens_to_rows(x, y, a_off: int, row_off: int = 0):
     """y[b][row_off + c][a_off + p] = x[b][p][c] for an NHWC map x and an fp32 [B, rows, A] tensor y (mask coefficients of the
     Segment head in the reference's layout, nn/modules/head.py:341-349)."""

@@ -17,5 +17,5 @@ tot = sum(r[2] for r in rows)
 print(f"total kernel time per step: {tot / steps / 1e3:.3f} ms ({steps:g} steps)")
 print(f"{'%':>6} {'us/step':>10} {'calls/step':>10} {'avg us':>9}  kernel")
 for n, cnt, s, a in rows[:40]:
-    name = re.sub(r"\(.*", "", n).replace("void ", "").replace("unsigned short", "bf16")[:90]
+    name = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "")).replace("void ", "").replace("unsigned short", "bf16")[:90]
     print(f"{s / tot * 100:6.2f} {s / steps:10.1f} {cnt / steps:10.1f} {a:9.2f}  {name}")

@@ -1,0 +1,123 @@
+"""Pipelined serving step on one MI355X: what `predict()` does around the hot path, with the host link inside the timed region.
+
+    host uint8 BGR frames (pinned) --H2D--> ymk_letterbox_preprocess -> forward -> batched NMS -> ymk_scale_boxes --D2H--> host (pinned)
+
+Reference steps: `BasePredictor.preprocess` (LetterBox + BGR->RGB + /255, engine/predictor.py:155-178), `_predict_once`, `non_max_suppression`,
+`scale_boxes` (models/yolo/detect/predict.py:109-122).  Two slots (device frame buffer + packed result buffer + pinned host result), one
+captured HIP graph per slot (letterbox -> ... -> scale_boxes), three streams: the H2D copy of batch i+1 and the D2H copy of batch i-1 run
+while batch i computes.  Reported next to the resident-input rate of bench.py (inputs already in HBM), which stays the headline value.
+
+    python tools/serve_bench.py [--frames 720x1280] [--batch 64] [--steps 30] [--dtype bf16]     -> one JSON line (profiles/r03_serve.json)
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", default="720x1280", help="HxW of the host frames (uint8 BGR)")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--scale", default="s")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--serial", action="store_true", help="no overlap: copy in, compute, copy out one after the other (A/B)")
+    a = ap.parse_args()
+
+    from yolo_master_amd import ops, postprocess
+    from yolo_master_amd._lib import check, lib
+    from yolo_master_amd.nms import nms_padded
+    from yolo_master_amd.nn.tasks import DetectionModel
+    from yolo_master_amd.preprocess import letterbox_params
+    from yolo_master_amd.weights import synth_state_dict
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    fh, fw = (int(v) for v in a.frames.split("x"))
+    B, S, MAX_DET = a.batch, 640, 300
+    model = DetectionModel(f"yolo-master-{a.scale}.yaml")
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
+    model.eval().to(dev).set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype])
+
+    g = torch.Generator().manual_seed(7)
+    host_frames = [torch.randint(0, 256, (B, fh, fw, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+    p = letterbox_params((fh, fw), (S, S))
+    nw, nh = p["new_unpad"]
+    geom = torch.tensor([[fh, fw, nh, nw, p["top"], p["left"]]] * B, dtype=torch.int32, device=dev)
+    offs = (torch.arange(B, dtype=torch.int64) * (fh * fw * 3)).to(dev)
+    words = ops.nms_pack_numel(B, MAX_DET)
+    slots = []
+    for _ in range(2):
+        slots.append({"frames": torch.empty((B, fh, fw, 3), dtype=torch.uint8, device=dev), "x": torch.empty((B, 3, S, S), dtype=torch.float32, device=dev),
+                      "pack": torch.empty((words,), dtype=torch.float32, device=dev), "host": torch.empty((words,), dtype=torch.float32).pin_memory()})
+    params = postprocess._params((S, S), [(fh, fw)] * B, None, dev)
+
+    def compute(sl):
+        check(lib.ymk_letterbox_preprocess(ops._p(sl["frames"]), ops._p(offs), ops._p(geom), ops._p(sl["x"]), B, S, S, 114, 1, ops._stream()), "letterbox")
+        y, _ = model._predict_once(sl["x"])
+        dets, counts, _, _ = nms_padded(y, 0.25, 0.7, max_det=MAX_DET, pack=sl["pack"])
+        check(lib.ymk_scale_boxes(ops._p(dets), dets.stride(1), ops._p(counts), ops._p(params), B, MAX_DET, 1, 0, ops._stream()), "scale_boxes")
+
+    s_in, s_cmp, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    with torch.inference_mode():
+        with torch.cuda.stream(s_cmp):
+            for sl in slots:
+                sl["frames"].copy_(host_frames[0], non_blocking=True)
+                compute(sl)
+            torch.cuda.synchronize()
+            model.check_flags()
+            for sl in slots:
+                sl["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(sl["graph"], stream=s_cmp):
+                    compute(sl)
+        torch.cuda.synchronize()
+
+        def run(n):
+            ev_in = [None, None]      # H2D of the batch in this slot finished
+            ev_cmp = [None, None]     # compute of the batch in this slot finished (frames consumed, pack written)
+            ev_out = [None, None]     # D2H of this slot's pack finished (pack may be overwritten)
+            for i in range(n):
+                sl, k = slots[i % 2], i % 2
+                with torch.cuda.stream(s_in):
+                    if ev_cmp[k] is not None:
+                        s_in.wait_event(ev_cmp[k])          # the previous batch in this slot has been read
+                    sl["frames"].copy_(host_frames[i % 2], non_blocking=True)
+                    ev_in[k] = s_in.record_event()
+                with torch.cuda.stream(s_cmp):
+                    s_cmp.wait_event(ev_in[k])
+                    if ev_out[k] is not None:
+                        s_cmp.wait_event(ev_out[k])         # the previous results of this slot are on the host
+                    sl["graph"].replay()
+                    ev_cmp[k] = s_cmp.record_event()
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(ev_cmp[k])
+                    sl["host"].copy_(sl["pack"], non_blocking=True)
+                    ev_out[k] = s_out.record_event()
+                if a.serial:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+
+        run(a.warmup)
+        t0 = time.perf_counter()
+        run(a.steps)
+        dt = time.perf_counter() - t0
+    dets, counts, _ = ops.nms_pack_views(slots[(a.steps - 1) % 2]["host"], B, MAX_DET)
+    h2d_mb, d2h_mb = B * fh * fw * 3 / 1e6, words * 4 / 1e6
+    print(json.dumps({"metric": "images/sec, pipelined serving step (host uint8 frames -> letterbox -> forward -> NMS -> scale_boxes -> host)",
+                      "value": round(B * a.steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / a.steps * 1e3, 4), "steps": a.steps,
+                      "dtype": a.dtype, "overlap": not a.serial,
+                      "config": {"workload": f"YOLO-Master-{a.scale.upper()}, {B} frames of {fh}x{fw}x3 uint8 per step -> 640x640", "h2d_mb_per_step": round(h2d_mb, 1),
+                                 "d2h_mb_per_step": round(d2h_mb, 2), "launch": "one hipGraph per slot, 2 slots, 3 streams"},
+                      "detections_last_batch": int(counts.sum())}))
+
+
+if __name__ == "__main__":
+    main()

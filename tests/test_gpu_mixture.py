@@ -236,6 +236,12 @@ def _prep(mod, sd):
     ("gated", "e6k3", ("VisualEnhancedAdaptiveGateMoE", (96, 96), dict(num_experts=6, top_k=3))),
     ("gated", "e16", ("VisualEnhancedAdaptiveGateMoE", (64, 64), dict(num_experts=16, top_k=2))),
     ("gated", "mid", ("VisualEnhancedAdaptiveGateMoE", (64, 64), {})),
+    # v0_1: ModularRouterExpertMoE (= OptimizedMOEImproved, moe/modules.py:957-1198), tests/golden/make_golden_v01.py
+    ("v01", "base", ("ModularRouterExpertMoE", (64, 64, 4, 2), {})),
+    ("v01", "e16", ("ModularRouterExpertMoE", (128, 128, 16, 2), {})),
+    ("v01", "widen", ("ModularRouterExpertMoE", (64, 128, 8, 2), {})),
+    ("v01", "small", ("ModularRouterExpertMoE", (64, 64, 4, 2), {})),
+    ("v01", "k1", ("ModularRouterExpertMoE", (64, 64, 4, 1), {})),
 ])
 def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
     """fp32 on the GPU against the REAL reference's outputs (the fixtures of tests/test_host_mixture.py)."""
@@ -252,12 +258,14 @@ def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
     ref = torch.from_numpy(z["y"])
     err = float((got - ref).abs().max())
     assert err <= 1e-4 * max(1.0, float(ref.abs().max())), f"{fam}_{name}: max |d| {err:.3e}"
-    if fam == "gated":
+    if fam in ("gated", "v01"):
         B = got.shape[0]
         assert np.array_equal(m.last_route["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
+    if fam == "v01":
+        assert float(np.abs(m.last_route["weights"].cpu().numpy().reshape(B, -1) - z["weights"]).max()) <= 1e-5, "routing weights"
 
 
-@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06"])
+@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06", "v01"])
 def test_config5_model_vs_reference_golden(tag, golden_dir):
     import json
     import warnings

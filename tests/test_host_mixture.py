@@ -214,7 +214,7 @@ def test_gated_chain_host_vs_reference(name, golden_dir, emu):
 
 
 MODEL_FIXTURES = {"cfg5": "yolo-master-moa-mot-n.yaml", "v15": "yolo-master-v15-n.yaml",
-                  "v04": None, "v06": None}    # None: the reference YAML's dict as stored in the fixture (generations v0_4 / v0_6, n scale)
+                  "v04": None, "v06": None, "v01": None}    # None: the reference YAML's dict as stored in the fixture (generations v0_4 / v0_6, n scale)
 
 
 @pytest.mark.parametrize("tag", list(MODEL_FIXTURES))
@@ -234,6 +234,8 @@ def test_config5_model_host_vs_reference(tag, golden_dir, emu):
     sd = fill_by_name(json.loads(str(z["spec"])), seed=5, gain=1.0)
     sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
     m = DetectionModel(MODEL_FIXTURES[tag] or cfg)
+    keys = json.load(open(golden_dir / f"keys_{tag}.json"))   # the reference model's own state_dict (names, order, shapes): the drop-in contract
+    assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [(k, v) for k, v in keys.items()], "state_dict differs from the reference's"
     m.load_state_dict(sd)
     m.eval()
     taps = {}

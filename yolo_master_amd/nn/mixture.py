@@ -1319,6 +1319,113 @@ class C2fMoT(YmkModule):
 GATED_CHAIN = (AdaptiveGateMoE, FusedAdaptiveGateMoE, HybridAdaptiveGateMoE, HybridAdaptiveGateMoEv2, LowRankHybridAdaptiveGateMoE,
                RefinedLowRankHybridAdaptiveGateMoE, DetailAwareLowRankHybridAdaptiveGateMoE, ContextRefinedLowRankHybridAdaptiveGateMoE,
                VisualEnhancedAdaptiveGateMoE)    # YAML generations v0_4 ... v0_11 (one class per generation)
-MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
+# ----------------------------------------------------------------------------------------- v0_1: ModularRouterExpertMoE
+class EfficientSpatialRouter(nn.Module):
+    """Parameter container with the reference's names (moe/routers.py:268-281): router = Conv3x3 -> BN -> SiLU -> Conv1x1 -> BN."""
+
+    def __init__(self, in_channels, num_experts, reduction=8, top_k=2, noise_std=1.0, pool_scale=4):
+        super().__init__()
+        self.num_experts, self.top_k, self.noise_std, self.pool_scale = num_experts, top_k, noise_std, pool_scale
+        red = max(in_channels // reduction, 8)
+        self.router = nn.Sequential(nn.Conv2d(in_channels, red, 3, padding=1, bias=False), nn.BatchNorm2d(red), nn.SiLU(inplace=False),
+                                    nn.Conv2d(red, num_experts, 1, bias=False), nn.BatchNorm2d(num_experts))
+
+
+class SimpleExpert(nn.Module):
+    """moe/experts.py:73-88: conv = 1x1 -> GN -> SiLU -> 1x1 -> GN."""
+
+    def __init__(self, in_channels, out_channels, expand_ratio=2, num_groups=8):
+        super().__init__()
+        hid = int(in_channels * expand_ratio)
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, hid, 1, bias=False), _gn(hid, num_groups), nn.SiLU(inplace=True),
+                                  nn.Conv2d(hid, out_channels, 1, bias=False), _gn(out_channels, num_groups))
+
+
+class ModularRouterExpertMoE(YmkModule):
+    """The MoE block of the v0_1 master YAMLs (= `OptimizedMOEImproved`, moe/modules.py:957-1198, alias :1744) in the configuration
+    those YAMLs use (`[c2, num_experts, top_k]`: EfficientSpatialRouter, SimpleExpert, shared expert, residual).  Eval forward on
+    libymk, true sparse dispatch:
+
+        router   4x4 average pool -> Conv3x3+BN+SiLU -> Conv1x1+BN (fp32 out) -> spatial mean -> softmax / top-k / renormalise
+                 (`ymk_gated_route_decide` with the global stream and the complexity gate switched off)
+        experts  only the routed filter banks run (`ymk_expert_conv_glds`): 1x1 -> GroupNorm(affine row of the image's expert) -> SiLU
+                 -> 1x1 -> GroupNorm, slot-major [k * B] maps
+        output   sum_j w_j expert_j(x) + SiLU(BN(1x1 x)) + x in one weighted sum
+    Other router / expert types of the reference constructor are not on the YAML surface and raise."""
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, expert_type="simple", router_type="efficient", noise_std=1.0,
+                 balance_loss_coeff=1.0, router_z_loss_coeff=1.0, expert_expand_ratio=2.0, progressive_sparsity=True, detach_routing=False,
+                 add_residual=True):
+        super().__init__()
+        if expert_type != "simple" or router_type != "efficient":
+            raise NotImplementedError("ymk ModularRouterExpertMoE: the YAML surface uses the default 'efficient' router and 'simple' experts")
+        if not 1 <= top_k <= 3 or top_k > num_experts:
+            raise ValueError("ymk ModularRouterExpertMoE: 1 <= top_k <= min(3, num_experts)")
+        self.in_channels, self.out_channels, self.num_experts, self.top_k = in_channels, out_channels, num_experts, top_k
+        self.balance_loss_coeff, self.router_z_loss_coeff, self.add_residual = balance_loss_coeff, router_z_loss_coeff, add_residual
+        self.routing = EfficientSpatialRouter(in_channels, num_experts, top_k=top_k, noise_std=noise_std)
+        self.experts = nn.ModuleList(SimpleExpert(in_channels, out_channels, expand_ratio=expert_expand_ratio) for _ in range(num_experts))
+        self.shared_expert = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels), nn.SiLU(inplace=True))
+        self.last_route = {}
+
+    @staticmethod
+    def _fold(conv, bn, device):
+        return ops.fold_bn(conv.weight.detach().float().to(device), bn.weight.float().to(device), bn.bias.float().to(device),
+                           bn.running_mean.float().to(device), bn.running_var.float().to(device), bn.eps)
+
+    def _pack(self, dtype, device):
+        f32 = torch.float32
+        E, r = self.num_experts, self.routing.router
+        E4 = _ceil(E, 4)
+        w0, b0 = self._fold(r[0], r[1], device)
+        w3, b3 = self._fold(r[3], r[4], device)
+        red, rp = w0.shape[0], _ceil(w0.shape[0], 8)
+        w0 = torch.cat([w0, w0.new_zeros((rp - red, *w0.shape[1:]))], 0)
+        b0 = torch.cat([b0, b0.new_zeros(rp - red)], 0)
+        w3 = torch.cat([w3, w3.new_zeros((w3.shape[0], rp - red, 1, 1))], 1)           # zero columns for the padded hidden channels (SiLU(0) = 0)
+        w3 = torch.cat([w3, w3.new_zeros((E4 - E, *w3.shape[1:]))], 0)
+        b3 = torch.cat([b3, b3.new_zeros(E4 - E)], 0)
+        ws, bs = self._fold(self.shared_expert[0], self.shared_expert[1], device)
+        return {
+            "r0": (ops.pack_conv_weight(w0, dtype), b0.contiguous()), "r3": (ops.pack_conv_weight(w3, dtype), b3.contiguous()),
+            "sh": (ops.pack_conv_weight(ws, dtype), bs.contiguous()),
+            "e1": torch.stack([_pack_conv(e.conv[0], dtype, device)[0] for e in self.experts]).contiguous(),          # [E][hid][Kpad]
+            "n1": (torch.stack([e.conv[1].weight.detach().float() for e in self.experts]).to(device).contiguous(),
+                   torch.stack([e.conv[1].bias.detach().float() for e in self.experts]).to(device).contiguous()),
+            "e2": torch.stack([_pack_conv(e.conv[3], dtype, device)[0] for e in self.experts]).contiguous(),          # [E][cout][Kpad]
+            "n2": (torch.stack([e.conv[4].weight.detach().float() for e in self.experts]).to(device).contiguous(),
+                   torch.stack([e.conv[4].bias.detach().float() for e in self.experts]).to(device).contiguous()),
+            "consts": {},   # per batch size: the (absent) global stream of the decision kernel (zeros) and a complexity logit of +100
+        }                   # (sigmoid = 1: every ranked expert kept), allocated once
+
+    def _run(self, x, out=None):
+        B, H, W, C = x.shape
+        pk = self._packed(x.device)
+        E, k, gs = self.num_experts, self.top_k, get_safe_groups
+        ps = self.routing.pool_scale
+        xin = ops.avg_pool(x, ps) if (H > ps and W > ps) else x
+        h = ops.conv2d(xin, *pk["r0"], 3, 1, True)
+        logits = ops.channel_stats(ops.conv2d(h, *pk["r3"], 1, 1, False, out_dtype=torch.float32))[..., :E]       # spatial mean in fp32 (routers.py:300)
+        if B not in pk["consts"]:
+            pk["consts"][B] = (torch.zeros((B, 1, 1, _ceil(E, 4)), dtype=torch.float32, device=x.device),
+                               torch.full((B, 1, 1, 1), 100.0, dtype=torch.float32, device=x.device))
+        g0, cp = pk["consts"][B]
+        w, idx, probs, rows = ops.gated_route_decide(g0[..., :E], logits, -100.0, 1.0, k, cp)
+        self.last_route = {"weights": w, "indices": idx, "probs": probs}
+        hid, cout = pk["e1"].shape[1], self.out_channels
+        f = ops.expert_conv(x, pk["e1"], 1, idx)                                                                   # [k * B, H, W, hid], slot-major
+        f = ops.group_norm(f, gs(hid, 8), *pk["n1"], 1e-5, act="silu", affine_rows=rows)
+        f = ops.expert_conv(f, pk["e2"], 1, rows.view(-1, 1).contiguous())                                         # image n of the slot-major batch -> its own expert
+        f = ops.group_norm(f, gs(cout, 8), *pk["n2"], 1e-5, affine_rows=rows)
+        res = x if (self.add_residual and C == cout) else None
+        if res is not None and res.stride(2) != C:                                                                 # a dense copy of a channel-slice view
+            res = ops.copy_channels(res, torch.empty((B, H, W, C), dtype=x.dtype, device=x.device))
+        shared = ops.conv2d(x, *pk["sh"], 1, 1, True, residual=res)                                                # SiLU(BN(1x1 x)) + x
+        wk = torch.ones((B, 1, 1, 4), dtype=torch.float32, device=x.device)
+        wk[..., :k].copy_(w)
+        return ops.weighted_sum(wk, [f[j * B:(j + 1) * B] for j in range(k)] + [shared], out=out)
+
+
+MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "ModularRouterExpertMoE": ModularRouterExpertMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
                             "GatedFusionMoE": GatedFusionMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
 MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

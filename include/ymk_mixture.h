@@ -55,6 +55,10 @@ int ymk_fma_gate(int32_t dtype, const void* x, int32_t ldx, const void* a, int32
                  int32_t ldb, int32_t b_per_image, float scale, void* y, int32_t ldy, int32_t B, int32_t HW, int32_t C,
                  void* stream);
 
+/* w[b][j] *= c, c = clamp(mean_b sigmoid(logit[b]), lo, hi) with a non-finite mean replaced by 1 (UltimateOptimizedMoE's batch-level
+ * complexity scale on the routing weights, moe/modules.py:1662-1672).  w fp32 [B][K] dense, logit fp32 [B] with stride ldl. */
+int ymk_batch_scale(float* w, int32_t B, int32_t K, const float* logit, int32_t ldl, float lo, float hi, void* stream);
+
 /* y = x * gate[b][c], gate fp32 [B][C] (squeeze-excite gate, moe/gated.py:333-341). */
 int ymk_channel_gate(int32_t dtype, const void* x, int32_t ldx, const float* gate, void* y, int32_t ldy, int32_t B,
                      int32_t HW, int32_t C, void* stream);

@@ -349,6 +349,10 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
             cur = gated_ref.optimal_hybrid_moe(sd, p, cur, num_experts=args[1], top_k=args[2],
                                                split_ratio=args[3] if len(args) > 3 else 0.5, cross_gate=m == "GatedFusionMoE",
                                                info=moe_info)
+        elif m == "UltimateOptimizedMoE":            # v0_3 rows: [c2, num_experts, top_k, split_ratio]
+            from . import ultimate_ref
+            cur = ultimate_ref.ultimate_optimized_moe(sd, p, cur, num_experts=args[1], top_k=args[2], split_ratio=args[3] if len(args) > 3 else 0.5,
+                                                      info=moe_info)
         elif m == "ModularRouterExpertMoE":          # v0_1 rows: [c2, num_experts, top_k]
             from . import modular_ref
             cur = modular_ref.modular_router_expert_moe(sd, p, cur, top_k=args[2] if len(args) > 2 else 2, info=moe_info)

@@ -425,6 +425,14 @@ def fma_gate(x, a, b, scale, out=None):
     return _put(x.float() + float(scale) * a.float() * b.float(), out, x.dtype)
 
 
+def batch_scale(w, logit, lo, hi):
+    _count("batch_scale")
+    c = torch.sigmoid(logit[:, 0, 0, 0]).mean()
+    c = torch.nan_to_num(c, nan=1.0, posinf=1.0, neginf=1.0).clamp(lo, hi) if torch.isfinite(c) else torch.tensor(1.0)
+    w.mul_(c)
+    return w
+
+
 def channel_gate(x, gate, out=None):
     _count("channel_gate")
     assert gate.dtype == torch.float32 and tuple(gate.shape) == (x.shape[0], 1, 1, x.shape[3]) and gate.is_contiguous()   # as ops.channel_gate
@@ -632,7 +640,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
 EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched",
-            "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "weighted_sum",
+            "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",
             "linear_attention", "deform_attention", "token_softmax", "gated_route_decide", "expert_conv", "expert_dw3", "channel_shuffle_cat",
             "pixel_shuffle2", "tokens_to_rows"]

@@ -30,7 +30,7 @@ TAG = "cfg5"
 if len(sys.argv) > 1 and sys.argv[1] == "v15":   # the v0_15 generation: GatedFusionMoE backbone on the v0 neck / head
     YAML = Path(refboot.REF) / "ultralytics/cfg/models/master/v0_15/det/yolo-master-n.yaml"
     TAG = "v15"
-if len(sys.argv) > 1 and sys.argv[1] in ("v01", "v04", "v05", "v06", "v07", "v08", "v09"):   # earlier generations (one MoE class each): v0_1 = ModularRouterExpertMoE, v0_4 ... = the gated family
+if len(sys.argv) > 1 and sys.argv[1] in ("v01", "v03", "v04", "v05", "v06", "v07", "v08", "v09"):   # earlier generations (one MoE class each): v0_1 = ModularRouterExpertMoE, v0_3 = UltimateOptimizedMoE, v0_4 ... = the gated family
     TAG = sys.argv[1]
     YAML = Path(refboot.REF) / f"ultralytics/cfg/models/master/v0_{int(TAG[1:])}/det/yolo-master-n.yaml"
 

@@ -242,6 +242,11 @@ def _prep(mod, sd):
     ("v01", "widen", ("ModularRouterExpertMoE", (64, 128, 8, 2), {})),
     ("v01", "small", ("ModularRouterExpertMoE", (64, 64, 4, 2), {})),
     ("v01", "k1", ("ModularRouterExpertMoE", (64, 64, 4, 1), {})),
+    # v0_3: UltimateOptimizedMoE (moe/modules.py:1534-1700), tests/golden/make_golden_v03.py
+    ("v03", "base", ("UltimateOptimizedMoE", (128, 128, 4, 2, 0.5), {})),
+    ("v03", "e16", ("UltimateOptimizedMoE", (128, 128, 16, 2, 0.5), {})),
+    ("v03", "lowc", ("UltimateOptimizedMoE", (128, 128, 8, 2, 0.5), {})),
+    ("v03", "k1", ("UltimateOptimizedMoE", (128, 128, 4, 1, 0.5), {})),
 ])
 def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
     """fp32 on the GPU against the REAL reference's outputs (the fixtures of tests/test_host_mixture.py)."""
@@ -258,14 +263,14 @@ def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
     ref = torch.from_numpy(z["y"])
     err = float((got - ref).abs().max())
     assert err <= 1e-4 * max(1.0, float(ref.abs().max())), f"{fam}_{name}: max |d| {err:.3e}"
-    if fam in ("gated", "v01"):
+    if fam in ("gated", "v01", "v03"):
         B = got.shape[0]
         assert np.array_equal(m.last_route["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
-    if fam == "v01":
+    if fam in ("v01", "v03"):
         assert float(np.abs(m.last_route["weights"].cpu().numpy().reshape(B, -1) - z["weights"]).max()) <= 1e-5, "routing weights"
 
 
-@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06", "v01"])
+@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06", "v01", "v03"])
 def test_config5_model_vs_reference_golden(tag, golden_dir):
     import json
     import warnings

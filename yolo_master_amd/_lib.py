@@ -103,6 +103,7 @@ SYMBOLS_MIXTURE = {
     "ymk_eltwise": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _vp]),
     "ymk_fma_gate": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ymk_channel_gate": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_batch_scale": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _f32, _f32, _vp]),
     "ymk_weighted_sum": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ymk_mean_upsampled": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp, _i32,
                                      _i32, _i32, _i32, _i32, _vp]),

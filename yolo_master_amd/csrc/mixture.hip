@@ -372,6 +372,16 @@ __global__ __launch_bounds__(256) void gated_decide_kernel(const float* g, int l
     }
 }
 
+// one workgroup: c = clamp(mean_b sigmoid(logit_b), lo, hi) (1 when not finite), then w *= c
+__global__ __launch_bounds__(256) void batch_scale_kernel(float* w, int B, int K, const float* logit, int ldl, float lo, float hi) {
+    __shared__ float sh[4];
+    float cs = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) cs += 1.0f / (1.0f + expf(-logit[(int64_t)b * ldl]));
+    float c = block_sum(cs, sh) / (float)B;
+    c = (c == c && fabsf(c) <= 3.0e38f) ? fminf(fmaxf(c, lo), hi) : 1.0f;
+    for (int i = threadIdx.x; i < B * K; i += 256) w[i] *= c;
+}
+
 // ------------------------------------------------------------------------------------------------ gather / shuffle
 __global__ __launch_bounds__(256) void expert_gather_kernel(int dt, const void* f, int ldf, const int32_t* idx, int B, int HW,
                                                              int OC, int K, void* out) {
@@ -1027,6 +1037,13 @@ extern "C" int ymk_gated_route_decide(const float* g, int32_t ldg, const float* 
     if (B <= 0) return YMK_OK;
     hipLaunchKernelGGL(gated_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g, ldg, loc, ldloc, cplx, ldc, B, E, alpha,
                        inv_temp, top_k, w, idx, idx_slot_major, probs);
+    return ymk_launch_status();
+}
+
+extern "C" int ymk_batch_scale(float* w, int32_t B, int32_t K, const float* logit, int32_t ldl, float lo, float hi, void* stream) {
+    if (!w || !logit || K < 1 || ldl < 1 || !(lo <= hi)) return YMK_E_BADARG;
+    if (B <= 0) return YMK_OK;
+    hipLaunchKernelGGL(batch_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, B, K, logit, ldl, lo, hi);
     return ymk_launch_status();
 }
 

@@ -1426,6 +1426,106 @@ class ModularRouterExpertMoE(YmkModule):
         return ops.weighted_sum(wk, [f[j * B:(j + 1) * B] for j in range(k)] + [shared], out=out)
 
 
-MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "ModularRouterExpertMoE": ModularRouterExpertMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
+# ----------------------------------------------------------------------------------------- v0_3: UltimateOptimizedMoE
+class ZeroCostRouter(nn.Module):
+    """Parameter container with the reference's names (moe/gated.py:938-961): router = Sequential(Linear(2C -> E, no bias), Softmax)."""
+
+    def __init__(self, in_channels, num_experts, top_k, temperature=1.0):
+        super().__init__()
+        self.num_experts, self.top_k, self.temperature = num_experts, top_k, temperature
+        self.router = nn.Sequential(nn.Linear(2 * in_channels, num_experts, bias=False), nn.Softmax(dim=1))
+
+
+class _BalanceControllerState(nn.Module):
+    """AdaptiveBalanceController (moe/gated.py:1767-1805) as far as inference goes: the `expert_importance` entry of the state_dict."""
+
+    def __init__(self, num_experts):
+        super().__init__()
+        self.expert_importance = nn.Parameter(torch.ones(num_experts))
+
+
+class UltimateOptimizedMoE(YmkModule):
+    """The MoE block of the v0_3 master YAMLs (moe/modules.py:1534-1700; rows `[c2, num_experts, top_k, split_ratio]`).  Eval forward on
+    libymk: channel split; static DW3x3+BN+SiLU -> 1x1+BN+SiLU; ZeroCostRouter (gated.py:963-992: Linear over the [mean | std] channel
+    statistics, the router's OWN softmax, / temperature, clamp, a second softmax, top-k — two passes of `ymk_gated_route_decide`, the
+    first for its probabilities); batch-level complexity scale on the routing weights (`ymk_batch_scale`); FusedExpertGroup with true
+    sparse dispatch (only the routed rows of the grouped 3x3 run) + affine-free GroupNorm with the routed expert's affine row + SiLU;
+    [static | dynamic] -> 1x1 -> GroupNorm + x."""
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, use_routing_cache=True,
+                 capacity_factor=1.5, initial_temperature=2.0, final_temperature=0.5, entropy_coeff=0.01):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_experts, self.top_k, self.num_groups = in_channels, out_channels, num_experts, top_k, num_groups
+        self.capacity_factor, self.initial_temperature, self.final_temperature, self.entropy_coeff = capacity_factor, initial_temperature, final_temperature, entropy_coeff
+        self.dynamic_channels = int(in_channels * split_ratio)
+        self.static_channels = in_channels - self.dynamic_channels
+        self.out_dynamic = int(out_channels * split_ratio)
+        self.out_static = out_channels - self.out_dynamic
+        sc = self.static_channels
+        self.static_net = nn.Sequential(
+            nn.Conv2d(sc, sc, 3, padding=1, groups=sc, bias=False), nn.BatchNorm2d(sc), nn.SiLU(inplace=True),
+            nn.Conv2d(sc, self.out_static, 1, bias=False), nn.BatchNorm2d(self.out_static), nn.SiLU(inplace=True))
+        self.routing = ZeroCostRouter(self.dynamic_channels, num_experts, top_k, temperature=initial_temperature)
+        self.fused_experts = FusedExpertGroup(self.dynamic_channels, self.out_dynamic, num_experts, num_groups)
+        self.complexity_estimator = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(self.dynamic_channels, 1, 1), nn.Sigmoid())
+        self.register_buffer("training_step", torch.tensor(0), persistent=False)
+        self.register_buffer("current_top_k", torch.tensor(num_experts))
+        self.balance_loss_coeff, self.router_z_loss_coeff = 1.0, 0.0
+        self.balance_controller = _BalanceControllerState(num_experts)     # training-only; its buffer is part of the checkpoint contract
+        self.proj = nn.Conv2d(out_channels, out_channels, 1, bias=False)
+        self.bn = _gn(out_channels, num_groups)
+        self.last_route = {}
+
+    def _pack(self, dtype, device):
+        f32 = torch.float32
+        dyn, E = self.dynamic_channels, self.num_experts
+        if dyn % 8 or self.static_channels % 8 or self.out_dynamic % 8 or self.out_static % 8:
+            raise NotImplementedError(f"ymk UltimateOptimizedMoE: split {self.static_channels}+{dyn} breaks the 16-byte channel-vector rule")
+        sn = self.static_net
+        dw_w, dw_b = ops.fold_bn(sn[0].weight.detach().float().to(device), sn[1].weight.float().to(device), sn[1].bias.float().to(device),
+                                 sn[1].running_mean.float().to(device), sn[1].running_var.float().to(device), sn[1].eps)
+        pw_w, pw_b = ops.fold_bn(sn[3].weight.detach().float().to(device), sn[4].weight.float().to(device), sn[4].bias.float().to(device),
+                                 sn[4].running_mean.float().to(device), sn[4].running_var.float().to(device), sn[4].eps)
+        fe = self.fused_experts
+        fc = fe.fused_conv
+        w = fc.weight.detach().float().to(device)                       # [E*OC, dyn/g, 3, 3], grouped
+        OC, cin, g = self.out_dynamic, fc.in_channels, fc.groups
+        cg, og = cin // g, (E * OC) // g
+        dense = w.new_zeros((E * OC, cin, 3, 3))
+        for grp in range(g):                                             # grouped filter bank -> dense rows (only routed rows run)
+            dense[grp * og:(grp + 1) * og, grp * cg:(grp + 1) * cg] = w[grp * og:(grp + 1) * og]
+        return {
+            "st_dw": (ops.pack_dw_weight(dw_w, dtype), dw_b.contiguous()), "st_pw": (ops.pack_conv_weight(pw_w, dtype), pw_b.contiguous()),
+            "cplx": _pack_conv(self.complexity_estimator[1], f32, device, pad_cout_to=4),
+            "lin": _pack_conv(self.routing.router[0], f32, device, pad_cout_to=_ceil(E, 4)),
+            "ew": ops.pack_conv_weight(dense, dtype).reshape(E, OC, -1).contiguous(),
+            "en": (fe.expert_norm_weight.detach().float().to(device).contiguous(), fe.expert_norm_bias.detach().float().to(device).contiguous()),
+            "proj": _pack_conv(self.proj, dtype, device), "bn": _pack_norm(self.bn, device), "consts": {},
+        }
+
+    def _run(self, x, out=None):
+        B, H, W, C = x.shape
+        pk = self._packed(x.device)
+        st, dyn, E, k, ng, gs = self.static_channels, self.dynamic_channels, self.num_experts, self.top_k, self.num_groups, get_safe_groups
+        xs, xd = x[..., :st], x[..., st:]
+        s = ops.conv2d(ops.dwconv2d(xs, *pk["st_dw"], 3, True), *pk["st_pw"], 1, 1, True)
+        cplx = ops.conv2d(ops.channel_stats(xd), *pk["cplx"], 1, 1, False)                                        # [B,1,1,4] fp32 logits
+        lin = ops.conv2d(ops.channel_stats(xd, want_std=True), *pk["lin"], 1, 1, False)[..., :E]
+        if B not in pk["consts"]:
+            pk["consts"][B] = (torch.zeros((B, 1, 1, _ceil(E, 4)), dtype=torch.float32, device=x.device),
+                               torch.full((B, 1, 1, 1), 100.0, dtype=torch.float32, device=x.device))
+        g0, keep_all = pk["consts"][B]
+        _, _, p0, _ = ops.gated_route_decide(g0[..., :E], lin, -100.0, 1.0, k, keep_all)                          # the router's own Softmax (gated.py:958)
+        w, idx, probs, rows = ops.gated_route_decide(g0[..., :E], p0.view(B, 1, 1, E), -100.0, 1.0 / float(self.routing.temperature), k, keep_all)
+        ops.batch_scale(w, cplx, 0.3, 1.5)                                                                         # routing_weights * complexity_scale
+        self.last_route = {"weights": w, "indices": idx, "probs": probs}
+        f = ops.expert_conv(xd, pk["ew"], 3, idx)
+        f = ops.group_norm(f, gs(self.out_dynamic, ng), *pk["en"], 1e-5, act="silu", affine_rows=rows)
+        d = ops.weighted_sum(w, [f[j * B:(j + 1) * B] for j in range(k)])
+        cat = ops.channel_shuffle_cat([s, d], 1)
+        return ops.group_norm(ops.conv2d(cat, *pk["proj"], 1, 1, False), gs(self.out_channels, ng), *pk["bn"], 1e-5, residual=x, out=out)
+
+
+MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "ModularRouterExpertMoE": ModularRouterExpertMoE, "UltimateOptimizedMoE": UltimateOptimizedMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
                             "GatedFusionMoE": GatedFusionMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
 MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

@@ -946,6 +946,17 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
     return w, idx, probs, rows
 
 
+def batch_scale(w, logit, lo: float, hi: float):
+    """In place: w *= clamp(mean_b sigmoid(logit[b]), lo, hi) (1 when the mean is not finite) — the batch-level complexity scale of
+    UltimateOptimizedMoE's routing weights (moe/modules.py:1662-1672).  w fp32 [B,1,1,K] dense, logit fp32 [B,1,1,>=1]."""
+    _need_gpu(w)
+    B, K = w.shape[0], w.shape[-1]
+    if w.dtype != torch.float32 or logit.dtype != torch.float32 or not w.is_contiguous() or logit.shape[0] != B:
+        raise ValueError("batch_scale: dense fp32 weights [B,1,1,K], fp32 logits [B,1,1,*]")
+    check(lib.ymk_batch_scale(_p(w), B, K, _p(logit), logit.stride(0), float(lo), float(hi), _stream()), "batch_scale")
+    return w
+
+
 @_timed("expert_dw3")
 def expert_dw3(x, w, dil, idx, out=None):
     """Per-image expert depthwise 3x3 with per-expert dilation, slot-major (include/ymk_mixture.h ymk_expert_dw3): x NHWC [B, H, W, C],

@@ -552,11 +552,12 @@ class Detect(YmkModule):
     # contention) -> off; YMK_ENABLE bit 16 switches it on for A/B runs
     level_streams = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 16)
 
-    def _side_streams(self, device, n):
+    def _side_streams(self, device, n, main=None):
+        """Side streams of the walk that runs on stream `main` (two concurrent walks of one model — bench.py --split — must not share them)."""
         st = self.__dict__.setdefault("_ymk_streams", {})
-        key = str(device)
+        key = (str(device), None if main is None else main.cuda_stream)
         if key not in st or len(st[key]) < n:
-            st[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+            st[key] = st.get(key, []) + [torch.cuda.Stream(device=device) for _ in range(n - len(st.get(key, [])))]
         return st[key][:n]
 
     fuse_dwpw = False  # DWConv3x3 -> Conv1x1 pair as one kernel (csrc/dwpw.hip); off: not yet faster than two kernels
@@ -587,55 +588,80 @@ class Detect(YmkModule):
         return ok and ops.detect_cls_fused_supported(f.dtype, d1.conv.in_channels, p1.conv.out_channels, self.nc) and \
             p2.conv.out_channels == p1.conv.out_channels
 
+    # ---- the head as per-level chains -------------------------------------------------------------------------------------------
+    # A level's chain (box branch, class branch, DFL decode into its anchor range of y) depends on ONE input map only.  The graph
+    # walk (nn/tasks.py) therefore starts a level on a side HIP stream as soon as its map exists — P3 is ready six layers before the
+    # head — so that the level's large kernels overlap the latency-bound 40^2 / 20^2 launches of the rest of the neck (fork / join by
+    # events: parallel branches of the captured graph).  `begin` allocates y, `start_level` forks, `finish` runs what is left and joins.
+    # Measured (round 3, profiles/r03_negative_results.txt): +0.3 % on the one-stream step (6.049 -> 6.032 ms) — the levels' kernels and the
+    # neck's do not overlap enough to matter — and nothing on top of bench.py's two concurrent sub-batches: OFF; YMK_ENABLE bit 32 for A/B runs.
+    early_levels = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 32)
+
+    def begin(self, B, level_hw, device):
+        """level_hw: [(H_l, W_l)] of every pyramid level.  Returns the run state (y, anchor offsets, raw slots)."""
+        if self.reg_max <= 1:
+            raise NotImplementedError("ymk Detect: reg_max must be > 1 (DFL)")
+        offs, a_off = [], 0
+        for h, w in level_hw:
+            offs.append(a_off)
+            a_off += h * w
+        return {"y": torch.empty((B, 4 + self.nc, a_off), dtype=torch.float32, device=device), "offs": offs, "raw": [None] * len(level_hw),
+                "hw": list(level_hw), "side": [], "main": None}
+
+    def _level(self, st, i, f):
+        pk = self._packed(f.device)
+        if tuple(f.shape[1:3]) != tuple(st["hw"][i]):
+            raise ValueError(f"Detect level {i}: map {tuple(f.shape[1:3])}, expected {st['hw'][i]}")
+        hb = self._branch(self.cv2[i], f)
+        box = ops.conv2d(hb, pk["box"][i][0], pk["box"][i][1], 1, 1, False, out_dtype=torch.float32)
+        if self._cls_fusable(i, f):
+            # the class branch of the level as one kernel: its four [B, H, W, 128] intermediates stay in LDS (csrc/detcls.hip)
+            s0, s1 = self.cv3[i][0], self.cv3[i][1]
+            q = [m._packed(f.device) for m in (s0[0], s0[1], s1[0], s1[1])]
+            cls = ops.detect_cls_fused(f, (q[0]["w"], q[0]["b"]), (q[1]["w"], q[1]["b"]), (q[2]["w"], q[2]["b"]), (q[3]["w"], q[3]["b"]),
+                                       pk["cls"][i])[..., : self.nc]
+        else:
+            hc = self._branch(self.cv3[i], f)
+            cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)[..., : self.nc]
+        ops.detect_decode(box, cls, st["y"], float(self.stride[i]), st["offs"][i], self.reg_max)
+        st["raw"][i] = (box, cls)
+
+    def start_level(self, st, i, f):
+        """Fork: level i on a side stream, ordered after everything enqueued so far on the current stream."""
+        main = torch.cuda.current_stream()
+        side = self._side_streams(f.device, len(st["side"]) + 1, main)[len(st["side"])]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._level(st, i, f)
+        st["side"].append((side, i))
+        st["main"] = main
+
+    def finish(self, st, feats):
+        """Run the levels that were not started early on the current stream, then join the side streams."""
+        started = {i for _, i in st["side"]}
+        for i, f in enumerate(feats):
+            if i not in started:
+                self._level(st, i, f)
+        if not st["side"]:
+            return st["y"], st["raw"]
+        main = torch.cuda.current_stream()
+        for side, i in st["side"]:
+            main.wait_stream(side)
+            for tns in st["raw"][i]:       # tensors created on a side stream are consumed on the main one
+                tns.record_stream(main)
+            st["y"].record_stream(side)
+        return st["y"], st["raw"]
+
     def _run(self, feats):
         """feats: list of NHWC maps.  Returns (y [B, 4+nc, A] fp32, raw) with raw = per-level
         (box_logits [B,H,W,4*reg_max], cls_logits [B,H,W,nc]) fp32 NHWC tensors."""
-        if self.reg_max <= 1:
-            raise NotImplementedError("ymk Detect: reg_max must be > 1 (DFL)")
-        pk = self._packed(feats[0].device)
-        B = feats[0].shape[0]
-        A = sum(f.shape[1] * f.shape[2] for f in feats)
-        y = torch.empty((B, 4 + self.nc, A), dtype=torch.float32, device=feats[0].device)
-        raw = [None] * len(feats)
-        offs, a_off = [], 0
-        for f in feats:
-            offs.append(a_off)
-            a_off += f.shape[1] * f.shape[2]
-
-        def level(i, f):
-            hb = self._branch(self.cv2[i], f)
-            box = ops.conv2d(hb, pk["box"][i][0], pk["box"][i][1], 1, 1, False, out_dtype=torch.float32)
-            if self._cls_fusable(i, f):
-                # the class branch of the level as one kernel: its four [B, H, W, 128] intermediates stay in LDS (csrc/detcls.hip)
-                s0, s1 = self.cv3[i][0], self.cv3[i][1]
-                q = [m._packed(f.device) for m in (s0[0], s0[1], s1[0], s1[1])]
-                cls = ops.detect_cls_fused(f, (q[0]["w"], q[0]["b"]), (q[1]["w"], q[1]["b"]), (q[2]["w"], q[2]["b"]), (q[3]["w"], q[3]["b"]),
-                                           pk["cls"][i])[..., : self.nc]
-            else:
-                hc = self._branch(self.cv3[i], f)
-                cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)[..., : self.nc]
-            ops.detect_decode(box, cls, y, float(self.stride[i]), offs[i], self.reg_max)
-            raw[i] = (box, cls)
-
+        st = self.begin(feats[0].shape[0], [tuple(f.shape[1:3]) for f in feats], feats[0].device)
         if self.level_streams and len(feats) > 1:
             # the pyramid levels are independent chains of small launches: run levels 1.. on side HIP streams so
             # they overlap the large level-0 kernels (fork/join with events; also valid under hipGraph capture)
-            main = torch.cuda.current_stream()
-            side = self._side_streams(feats[0].device, len(feats) - 1)
             for i in range(1, len(feats)):
-                side[i - 1].wait_stream(main)
-                with torch.cuda.stream(side[i - 1]):
-                    level(i, feats[i])
-            level(0, feats[0])
-            for st in side:
-                main.wait_stream(st)
-            for i in range(1, len(feats)):  # tensors created on a side stream are consumed on the main one
-                for tns in raw[i]:
-                    tns.record_stream(main)
-        else:
-            for i, f in enumerate(feats):
-                level(i, f)
-        return y, raw
+                self.start_level(st, i, feats[i])
+        return self.finish(st, feats)
 
     def forward(self, x):
         if self.training:

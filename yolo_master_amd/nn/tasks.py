@@ -261,6 +261,17 @@ class DetectionModel(nn.Module):
         cur = x
         raw = det_in = None
         skip = -1
+        # Detect levels start as soon as their input map exists (Detect.start_level: a side HIP stream per level, joined at the head)
+        det = self.model[-1]
+        early = None
+        if type(det) is Detect and det.early_levels and taps is None and x.is_cuda and isinstance(det.f, (list, tuple)) and len(det.f) > 1:
+            sizes = []
+            for s_ in det.stride.tolist():
+                h, w = int(x.shape[2]), int(x.shape[3])
+                for _ in range(int(round(__import__("math").log2(s_)))):
+                    h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1      # a 3x3 / stride-2 / pad-1 convolution per octave
+                sizes.append((h, w))
+            early = {"state": det.begin(x.shape[0], sizes, x.device), "levels": {int(j) % len(self.model): i for i, j in enumerate(det.f)}}
         for m in self.model:
             if m.i == skip:      # produced together with the previous layer (fused stem pair)
                 ys.append(cur if m.i in self.save else None)
@@ -295,7 +306,7 @@ class DetectionModel(nn.Module):
                 cur = m._run(cur)
             elif isinstance(m, Detect):
                 det_in = cur
-                cur, raw = m._run(cur)
+                cur, raw = m.finish(early["state"], cur) if early is not None else m._run(cur)
             elif isinstance(m, nn.Sequential):
                 for mm in m:
                     cur = mm._run(cur)
@@ -304,6 +315,8 @@ class DetectionModel(nn.Module):
                     cur = cur.materialise()
                 cur = m._run(cur)
             ys.append(cur if m.i in self.save else None)
+            if early is not None and m.i in early["levels"] and m.i != len(self.model) - 2 and torch.is_tensor(cur):
+                det.start_level(early["state"], early["levels"][m.i], cur)   # (the last level's map is the head's direct input: it runs on the main stream)
             if taps is not None:
                 taps[m.i] = cur.materialise() if isinstance(cur, VirtualCat) else cur
         det = self.model[-1]

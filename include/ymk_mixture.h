@@ -83,9 +83,10 @@ int ymk_avg_pool(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out
                  int32_t W, int32_t C, int32_t k, void* stream);
 
 /* Per image and channel mean (and biased std) over HW: out fp32 [B][C] or [B][2C] = [mean | std]
- * (moe/gated.py:133-139, AdaptiveAvgPool2d(1) of the gates). */
+ * (moe/gated.py:133-139, AdaptiveAvgPool2d(1) of the gates).  ws: fp32 [B * min(64, ceil(HW / 1024)) * 2 * C] scratch (an image's map
+ * is reduced by several workgroups whose partials are combined exactly, in chunk order) or NULL (one workgroup per image). */
 int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, float* out, int32_t B, int32_t HW, int32_t C,
-                      int32_t want_std, void* stream);
+                      int32_t want_std, float* ws, void* stream);
 
 /* Per-token softmax over n <= 8 fp32 logits scaled by inv_temp; 0 < top_k < n keeps the top_k largest (ties: lower index
  * first), renormalised with the sum clamped at 1e-6 (mot/router.py:243-295, moa/router.py:50-62).

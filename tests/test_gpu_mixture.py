@@ -123,6 +123,9 @@ def test_pools_stats_shuffle_gather(dtype):
     _cmp(ops.channel_stats(x.to(DEV), want_std=True), emu_ops.channel_stats(x, want_std=True), torch.float32, "mean | std")
     x100 = _rnd(2, 3, 3, 100, seed=21, dtype=dtype)                    # more than one 64-channel block, ragged
     _cmp(ops.channel_stats(x100.to(DEV), want_std=True), emu_ops.channel_stats(x100, want_std=True), torch.float32, "stats C=100")
+    xbig = _rnd(2, 60, 70, 16, seed=25, dtype=dtype) + 0.5      # 4200 pixels: five pixel chunks per image, partials combined in chunk order
+    _cmp(ops.channel_stats(xbig.to(DEV), want_std=True), emu_ops.channel_stats(xbig, want_std=True), torch.float32, "stats chunked")
+    _cmp(ops.channel_stats(_view(xbig, 8)), emu_ops.channel_stats(xbig), torch.float32, "mean chunked")
     parts = [x, _rnd(2, 6, 5, 32, seed=22, dtype=dtype), _rnd(2, 3, 2, 32, seed=23, dtype=dtype)]
     _cmp(ops.mean_upsampled([p.to(DEV) for p in parts]), emu_ops.mean_upsampled(parts), dtype, "mean_upsampled")
     a, b = _rnd(2, 7, 5, 24, seed=24, dtype=dtype), _rnd(2, 7, 5, 40, seed=25, dtype=dtype)

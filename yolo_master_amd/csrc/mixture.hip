@@ -538,6 +538,47 @@ __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* x, int ldx, 
         store_vec_f32(y + p * ldy + c0, v);
     }
 }
+// The same with the per-channel constants hoisted: a thread owns ONE channel vector of one image and walks pixels, so scale = rstd * w
+// and shift = b - mean * rstd * w are computed once (the grid-stride form above re-loads two statistics and 2 x VEC affine values per
+// 16 bytes of data: four times the bytes it normalises).  grid (pixel chunks, B); 256 threads = (256 / ncv) pixel lanes x ncv vectors,
+// ncv = C / VEC <= 256.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* x, int ldx, T* y, int ldy, const T* res, int ldr, int HW, int C, int groups,
+                                                             const float* weight, const float* bias, const int32_t* rows, int act,
+                                                             const float* stats, int ppb /* pixels per workgroup */) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int ncv = C / VEC, cg = C / groups;
+    const int b = blockIdx.y;
+    const int cv = threadIdx.x % ncv, lane = threadIdx.x / ncv, lanes = 256 / ncv;
+    if (lane >= lanes) return;
+    const int c0 = cv * VEC;
+    const int64_t r = rows ? (int64_t)rows[b] * C : 0;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        const float* st = stats + 2 * ((int64_t)b * groups + (c0 + q) / cg);
+        const float w = weight ? weight[r + c0 + q] : 1.0f, bb = weight ? bias[r + c0 + q] : 0.0f;
+        sc[q] = st[1] * w;
+        sh[q] = bb - st[0] * st[1] * w;
+    }
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    const T* xb = x + (int64_t)b * HW * ldx + c0;
+    T* yb = y + (int64_t)b * HW * ldy + c0;
+    const T* rb = res ? res + (int64_t)b * HW * ldr + c0 : nullptr;
+    for (int p = p0 + lane; p < p1; p += lanes) {
+        float v[VEC];
+        load_vec_f32(xb + (int64_t)p * ldx, v);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = act_f((v[q] - 0.0f) * sc[q] + sh[q], act);
+        if (rb) {
+            float rr[VEC];
+            load_vec_f32(rb + (int64_t)p * ldr, rr);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) v[q] += rr[q];
+        }
+        store_vec_f32(yb + (int64_t)p * ldy, v);
+    }
+}
 // one wave per token, one vector per lane and step
 template <typename T>
 __global__ __launch_bounds__(256) void ln_vec_kernel(const T* x, int ldx, T* y, int ldy, int64_t npix, int C, const float* weight,
@@ -683,13 +724,19 @@ __global__ __launch_bounds__(256) void pool_vec_kernel(const T* x, int ldx, TO* 
 }
 // workgroup = 16 pixel lanes x 16 channel vectors of one image; grid (ceil(C / (16 * VEC)), B)
 template <typename T>
-__global__ __launch_bounds__(256) void channel_stats_vec_kernel(const T* x, int ldx, float* out, int HW, int C, int want_std) {
+__global__ __launch_bounds__(256) void channel_stats_vec_kernel(const T* x, int ldx, float* out, int HWtot, int C, int want_std, float* part,
+                                                                int nchunk) {
+    // grid.z = pixel chunks (a [16, 160, 160, 128] map on (1, 16) workgroups was 16 workgroups for 105 MB): chunk partials (mean, M2) go to
+    // `part` and are combined exactly, in chunk order, by channel_stats_finalize_kernel; nchunk == 1 writes the result directly
     constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ float sh[16][16 * VEC + 1];
     const int b = blockIdx.y, cl = threadIdx.x & 15, r = threadIdx.x >> 4;
     const int c0 = (blockIdx.x * 16 + cl) * VEC;
-    const T* base = x + (int64_t)b * HW * ldx;
+    const int p0 = (int)((int64_t)HWtot * blockIdx.z / nchunk), HW = (int)((int64_t)HWtot * (blockIdx.z + 1) / nchunk) - p0;
+    const T* base = x + ((int64_t)b * HWtot + p0) * ldx;
     const int oc = want_std ? 2 * C : C;
+    float* pm = part ? part + (((int64_t)b * nchunk + blockIdx.z) * 2) * C : nullptr;   // [mean | M2] of this chunk
+    if (nchunk > 1) out = nullptr;
     float s[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) s[q] = 0.f;
@@ -713,7 +760,10 @@ __global__ __launch_bounds__(256) void channel_stats_vec_kernel(const T* x, int 
     __syncthreads();
     if (r == 0 && c0 < C)
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) out[(int64_t)b * oc + c0 + q] = mean[q];
+        for (int q = 0; q < VEC; ++q) {
+            if (out) out[(int64_t)b * oc + c0 + q] = mean[q];
+            else pm[c0 + q] = mean[q];
+        }
     if (!want_std) return;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) s[q] = 0.f;
@@ -732,8 +782,27 @@ __global__ __launch_bounds__(256) void channel_stats_vec_kernel(const T* x, int 
         for (int q = 0; q < VEC; ++q) {
             float t = 0.f;
             for (int rr = 0; rr < 16; ++rr) t += sh[rr][cl * VEC + q];
-            out[(int64_t)b * oc + C + c0 + q] = HW > 1 ? sqrtf(t / (float)HW) : 0.f;
+            if (out) out[(int64_t)b * oc + C + c0 + q] = HW > 1 ? sqrtf(t / (float)HW) : 0.f;
+            else pm[C + c0 + q] = t;
         }
+}
+// grid (ceil(C / 256), B): chunk partials (mean_c, M2_c over n_c pixels) -> mean and biased std, pairwise-exact update in chunk order
+__global__ __launch_bounds__(256) void channel_stats_finalize_kernel(const float* part, float* out, int HW, int C, int want_std, int nchunk) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* p = part + (int64_t)b * nchunk * 2 * C;
+    float mean = 0.f, m2 = 0.f, n = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        const float nc = (float)((int)((int64_t)HW * (k + 1) / nchunk) - (int)((int64_t)HW * k / nchunk));
+        const float mc = p[(int64_t)k * 2 * C + c], m2c = want_std ? p[(int64_t)k * 2 * C + C + c] : 0.f;
+        const float tot = n + nc, d = mc - mean;
+        mean += d * (nc / tot);
+        m2 += m2c + d * d * (n * nc / tot);
+        n = tot;
+    }
+    const int oc = want_std ? 2 * C : C;
+    out[(int64_t)b * oc + c] = mean;
+    if (want_std) out[(int64_t)b * oc + C + c] = HW > 1 ? sqrtf(m2 / (float)HW) : 0.f;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void mean_upsampled_vec_kernel(int n, Pyr4 a, T* y, int ldy, int B, int H, int W, int C) {
@@ -844,6 +913,19 @@ extern "C" int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y
         hipLaunchKernelGGL(gn_stats_kernel, sgrid, dim3(256), 0, (hipStream_t)stream, x, dtype, ldx, HW, C, groups, eps, stats_ws, part, nchunk);
     }
     if (nchunk > 1) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, nchunk, eps, stats_ws, (const float*)part);
+    if (vin && out_dtype == dtype && ldy % V == 0 && al16(y) && (!residual || (ldr % V == 0 && al16(residual))) && C / V <= 256 && B <= 65535) {
+        // per-thread channel constants: ~2048 workgroups of one image each
+        int ppb = (int)(((int64_t)B * HW + 2047) / 2048);
+        ppb = ppb < 64 ? 64 : ppb;
+        const dim3 agrid((HW + ppb - 1) / ppb, B);
+        if (dtype == YMK_BF16)
+            hipLaunchKernelGGL(gn_apply_rows_kernel<h16_t>, agrid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, (h16_t*)y, ldy, (const h16_t*)residual, ldr,
+                               HW, C, groups, weight, bias, affine_rows, act, (const float*)stats_ws, ppb);
+        else
+            hipLaunchKernelGGL(gn_apply_rows_kernel<float>, agrid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, (const float*)residual, ldr,
+                               HW, C, groups, weight, bias, affine_rows, act, (const float*)stats_ws, ppb);
+        return ymk_launch_status();
+    }
     if (vin && out_dtype == dtype && ldy % V == 0 && al16(y) && (!residual || (ldr % V == 0 && al16(residual)))) {
         const int64_t total = (int64_t)B * HW * (C / V);
         if (dtype == YMK_BF16)
@@ -1005,14 +1087,19 @@ extern "C" int ymk_avg_pool(int32_t dtype, const void* x, int32_t ldx, void* y, 
 }
 
 extern "C" int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, float* out, int32_t B, int32_t HW, int32_t C,
-                                 int32_t want_std, void* stream) {
+                                 int32_t want_std, float* ws, void* stream) {
     if (!x || !out || bad_dt(dtype) || C < 1 || ldx < C || HW < 1 || B > 65535) return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
     const int V = vecw(dtype);
     if (C % V == 0 && ldx % V == 0 && al16(x)) {
-        const dim3 grid((C / V + 15) / 16, B);
-        if (dtype == YMK_BF16) hipLaunchKernelGGL(channel_stats_vec_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, out, HW, C, want_std);
-        else hipLaunchKernelGGL(channel_stats_vec_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, out, HW, C, want_std);
+        // pixel chunks of ~1024 per workgroup, at most 64 (ws: [B][nchunk][2][C] floats); without a workspace one workgroup per image
+        int nchunk = ws ? (HW + 1023) / 1024 : 1;
+        nchunk = nchunk < 1 ? 1 : nchunk > 64 ? 64 : nchunk;
+        const dim3 grid((C / V + 15) / 16, B, nchunk);
+        if (dtype == YMK_BF16) hipLaunchKernelGGL(channel_stats_vec_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, out, HW, C, want_std, ws, nchunk);
+        else hipLaunchKernelGGL(channel_stats_vec_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, out, HW, C, want_std, ws, nchunk);
+        if (nchunk > 1)
+            hipLaunchKernelGGL(channel_stats_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, out, HW, C, want_std, nchunk);
         return ymk_launch_status();
     }
     hipLaunchKernelGGL(channel_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dtype, x, ldx, out, HW, C,

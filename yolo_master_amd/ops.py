@@ -834,7 +834,9 @@ def channel_stats(x, want_std: bool = False):
     DualStreamGateRouter's global stream moe/gated.py:133-139)."""
     B, H, W, Cc, ldx = _nhwc(x)
     out = torch.empty((B, 1, 1, 2 * Cc if want_std else Cc), dtype=torch.float32, device=x.device)
-    check(lib.ymk_channel_stats(DT[x.dtype], _p(x), ldx, _p(out), B, H * W, Cc, int(want_std), _stream()), "channel_stats")
+    nchunk = min(64, (H * W + 1023) // 1024)
+    ws = torch.empty((B * nchunk * 2 * Cc,), dtype=torch.float32, device=x.device) if nchunk > 1 else None
+    check(lib.ymk_channel_stats(DT[x.dtype], _p(x), ldx, _p(out), B, H * W, Cc, int(want_std), _p(ws), _stream()), "channel_stats")
     return out
 
 

@@ -269,6 +269,20 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const h16_t*
     }
 }
 
+// max / sum over the four lane groups that share (lane & 15): register swaps (v_permlane16_swap / v_permlane32_swap), no LDS round trip
+__device__ __forceinline__ float mx_rowgroup_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float mx_rowgroup_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ------------------------------------------------------------------------------------------------ general attention on the matrix cores
 // 16-bit inputs, head_dim 16 / 32 / 64: a workgroup of four waves takes 256 queries of one (image, head) and walks the keys in blocks
 // of 64 (online softmax).  Per key block the workgroup stages K (row-major, 16-byte chunks XOR-swizzled by the row) and V^T in LDS
@@ -308,23 +322,44 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const h16_t* q, int
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // K / V of the next 64-key block travel in registers while the current block is multiplied (the loads are issued right after the
+    // barrier that publishes the current block and are consumed after the barrier that retires it): global latency off the critical path
+    constexpr int NKL = (64 * KC + 255) / 256, NVL = (64 * CH + 255) / 256;
+    u32x4 kreg[NKL], vreg[NVL];
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int u = 0; u < NKL; ++u) {
+            const int c = threadIdx.x + u * 256, r = c / KC, cc = c % KC;
+            kreg[u] = u32x4{0u, 0u, 0u, 0u};
+            if (c < 64 * KC && n0 + r < Nk && cc < CH) kreg[u] = *reinterpret_cast<const u32x4*>(kbp + (int64_t)(n0 + r) * ldk + cc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < NVL; ++u) {
+            const int c = threadIdx.x + u * 256, t = c / CH, c0 = (c % CH) * 8;
+            vreg[u] = u32x4{0u, 0u, 0u, 0u};
+            if (c < 64 * CH && n0 + t < Nk) vreg[u] = *reinterpret_cast<const u32x4*>(vb + (int64_t)(n0 + t) * ldv_ + c0);
+        }
+    };
+    fetch(0);
+    const float c2 = scale * 1.4426950408889634f;   // softmax scale folded into the exp2 argument: p = 2^((s - m) * scale * log2 e)
     for (int n0 = 0; n0 < Nk; n0 += 64) {
         __syncthreads();                          // the previous block's fragment reads are finished
-        for (int c = threadIdx.x; c < 64 * KC; c += 256) {
-            const int r = c / KC, cc = c % KC;
-            u32x4 f = {0u, 0u, 0u, 0u};
-            if (n0 + r < Nk && cc < CH) f = *reinterpret_cast<const u32x4*>(kbp + (int64_t)(n0 + r) * ldk + cc * 8);
-            sk[r * KC + (cc ^ (r & (KC - 1)))] = f;
-        }
-        for (int c = threadIdx.x; c < 64 * CH; c += 256) {
-            const int t = c / CH, c0 = (c % CH) * 8;
-            u32x4 f = {0u, 0u, 0u, 0u};
-            if (n0 + t < Nk) f = *reinterpret_cast<const u32x4*>(vb + (int64_t)(n0 + t) * ldv_ + c0);
-            const uint32_t w4[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) svt[(c0 + e) * VP + t] = (h16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        for (int u = 0; u < NKL; ++u) {
+            const int c = threadIdx.x + u * 256, r = c / KC, cc = c % KC;
+            if (c < 64 * KC) sk[r * KC + (cc ^ (r & (KC - 1)))] = kreg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NVL; ++u) {
+            const int c = threadIdx.x + u * 256, t = c / CH, c0 = (c % CH) * 8;
+            if (c < 64 * CH) {
+                const uint32_t w4[4] = {vreg[u].x, vreg[u].y, vreg[u].z, vreg[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) svt[(c0 + e) * VP + t] = (h16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            }
         }
         __syncthreads();
+        if (n0 + 64 < Nk) fetch(n0 + 64);
         // S^T tiles for this wave's 64 queries
         f32x4 st[4][4];
 #pragma unroll
@@ -343,6 +378,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const h16_t* q, int
                 st[j][i] = acc;
             }
         }
+        const bool tail = n0 + 64 > Nk;             // only the last block can hold keys past the end (workgroup-uniform)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float mb = -INFINITY;
@@ -351,27 +387,25 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const h16_t* q, int
                 float* a4 = reinterpret_cast<float*>(&st[j][i]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    a4[r] = (n0 + 16 * j + 4 * g + r < Nk) ? a4[r] * scale : -INFINITY;
+                    if (tail && n0 + 16 * j + 4 * g + r >= Nk) a4[r] = -INFINITY;
                     mb = fmaxf(mb, a4[r]);
                 }
             }
-            mb = fmaxf(mb, __shfl_xor(mb, 16));
-            mb = fmaxf(mb, __shfl_xor(mb, 32));
-            const float mn = fmaxf(m[i], mb);     // finite: every block holds at least one real key
-            const float c = __expf(m[i] - mn);    // exp(-inf) = 0 on the first block
+            mb = mx_rowgroup_max(mb);
+            const float mn = fmaxf(m[i], mb);     // finite: every block holds at least one real key (scores are UNSCALED here)
+            const float c = __builtin_amdgcn_exp2f((m[i] - mn) * c2);    // 2^(-inf) = 0 on the first block
+            const float nmc = -mn * c2;
             float lb = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float* a4 = reinterpret_cast<float*>(&st[j][i]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    a4[r] = __expf(a4[r] - mn);
+                    a4[r] = __builtin_amdgcn_exp2f(fmaf(a4[r], c2, nmc));
                     lb += a4[r];
                 }
             }
-            lb += __shfl_xor(lb, 16);
-            lb += __shfl_xor(lb, 32);
-            l[i] = l[i] * c + lb;
+            l[i] = l[i] * c + lb;                 // this lane group's share of the denominator: the four shares meet once, after the last block
             m[i] = mn;
             u32x4 pf[2];
 #pragma unroll
@@ -397,8 +431,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const h16_t* q, int
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int qi = q0 + 16 * i + fr;
+        const float inv = 1.0f / mx_rowgroup_sum(l[i]);
         if (qi >= Nq) continue;
-        const float inv = 1.0f / l[i];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             if (dt * 16 + 4 * g >= HD) continue;

@@ -15,5 +15,7 @@ python $R/tools/prof_summary.py $(ls $R/gpurun_out/${TAG}_cfg5_trace/*/*.db | he
 rm -rf $R/gpurun_out/${TAG}_cfg5_trace
 head -30 $R/gpurun_out/${TAG}_cfg5_kernel_stats.txt
 cd $R
+# the bench line quotes counter numbers only from summaries under profiles/ whose source hash is this tree's: place the fresh ones there
+cp gpurun_out/${TAG}_pmc_FETCH_SIZE.json gpurun_out/${TAG}_pmc_WRITE_SIZE.json gpurun_out/${TAG}_sq_1.json gpurun_out/${TAG}_sq_2.json profiles/ 2>/dev/null
 python bench.py --cfg yolo-master-moa-mot.yaml --scale l --imgsz 1280 --batch 16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_cfg5.json 2>/dev/null
 python bench.py --steps 30 --warmup 10 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench: exit $?"; head -c 300 gpurun_out/${TAG}_bench.json

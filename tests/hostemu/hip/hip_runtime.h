@@ -264,6 +264,17 @@ static inline void hostemu_global_load_lds16(const void* g, void* lds_base) {
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hostemu_global_load_lds16((const void*)(g), (void*)(l))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 static inline void __builtin_amdgcn_s_barrier() { hostemu::block_sync(); }
+// raw buffer resource (stride 0) and `buffer_load_dwordx4 ... offen lds`: 16 bytes per lane from base + voffset + soffset to (wave-uniform
+// LDS base) + lane * 16; a lane whose voffset + 16 exceeds num_records - soffset reads zeros (the hardware's range check of raw
+// buffers compares the VGPR offset alone against num_records - SGPR offset: an offset with bit 31 set is always out of range)
+struct hostemu_rsrc { const char* base; unsigned num_records; };
+static inline hostemu_rsrc hostemu_make_rsrc(const void* p, unsigned n) { return hostemu_rsrc{static_cast<const char*>(p), n}; }
+static inline void hostemu_buffer_load_lds16(hostemu_rsrc r, void* lds_base, unsigned voff, unsigned soff) {
+    char* d = static_cast<char*>(lds_base) + (hostemu::cur & 63u) * 16;
+    const unsigned lim = r.num_records >= soff ? r.num_records - soff : 0u;
+    if ((unsigned long long)voff + 16ull > (unsigned long long)lim) std::memset(d, 0, 16);
+    else std::memcpy(d, r.base + voff + soff, 16);
+}
 
 // the slice of the HIP runtime API the probes' main() uses
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost };

@@ -1,6 +1,6 @@
 // Next tiled implicit-GEMM core: 256 output pixels x BN couts per workgroup on 8 waves, BK = 64
-// channels of one filter tap per k-step, both operands staged straight into LDS by global_load_lds (16 bytes per lane,
-// lane-linear LDS image, XOR swizzle applied on the SOURCE side, border taps read a zero page), two LDS stages with a
+// channels of one filter tap per k-step, both operands staged straight into LDS by `buffer_load_dwordx4 ... lds` (16 bytes per lane,
+// lane-linear LDS image, XOR swizzle applied on the SOURCE side, border taps are out-of-range lanes of the raw buffer: zeros), two LDS stages with a
 // plain barrier or three stages with a raw barrier and a counted vmcnt (one k-step of DMA in flight across every
 // barrier), XCD-aware tile order.  bf16 only; Cin % 64 == 0, Cout % 64 == 0.
 //
@@ -16,11 +16,20 @@
 #ifndef YMK_HOST_EMU
 typedef __attribute__((address_space(1))) const void* glds_gptr;
 typedef __attribute__((address_space(3))) void* glds_lptr;
+typedef __amdgpu_buffer_rsrc_t glds_rsrc;
+// raw buffer (stride 0) of n bytes at p; word 3 = 32-bit raw data format (what the dword loads need on gfx9-class hardware)
+#define GLDS_MAKE_RSRC(p, n) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(p)), 0, (int)(n), 0x00020000)
+// buffer_load_dwordx4 ... offen lds: lane -> 16 bytes from base + voff (VGPR) + soff (SGPR) to the LDS base in M0 + lane * 16; lanes
+// with voff + 16 > num_records - soff get zeros and touch no memory (hardware range check)
+#define GLDS_BUFFER_LOAD_LDS(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (glds_lptr)(dst), 16, (int)(voff), (int)(soff), 0, 0)
 #define GLDS_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define GLDS_COMPILER_FENCE() asm volatile("" ::: "memory")
 #else   // tests/hostemu: plain pointers, no inline assembly
 typedef const void* glds_gptr;
 typedef void* glds_lptr;
+typedef hostemu_rsrc glds_rsrc;
+#define GLDS_MAKE_RSRC(p, n) hostemu_make_rsrc(p, (unsigned)(n))
+#define GLDS_BUFFER_LOAD_LDS(rs, dst, voff, soff) hostemu_buffer_load_lds16(rs, (void*)(dst), (unsigned)(voff), (unsigned)(soff))
 #define GLDS_WAIT_LGKM0() ((void)0)
 #define GLDS_COMPILER_FENCE() ((void)0)
 #endif
@@ -36,7 +45,6 @@ typedef void* glds_lptr;
 // s_waitcnt immediate (gfx9 family): vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
 #define GLDS_WAITCNT_VM(n) (0x0F70 | ((n) & 15) | ((((n) >> 4) & 3) << 14))
 
-__device__ u32x4 ymk_glds_zero_page[8];   // 128 bytes of zeros: the source of out-of-image taps and tail rows
 
 struct GldsArgs {
     const h16_t* x;
@@ -55,15 +63,27 @@ struct GldsArgs {
     int K;
 };
 
-template <int BN, int STAGES, int BM = GLDS_BM>
+// BK = channels of one filter tap per k-step: 64 (rows of 128 bytes, 8 rows per wave-instruction, chunk swizzle c ^ (r & 7)) or 32 (rows
+// of 64 bytes, 16 rows per wave-instruction, chunk swizzle c ^ ((-(r >> 2)) & 3): the four 16-lane groups of a ds_read_b128 then cover
+// the 64 banks once).  Half the k-step lets a tile of the same LDS budget keep STAGES - 1 >= 2 transfers in flight instead of one.
+// PP: the two waves of every SIMD run one segment out of phase.  A k-step is BK / 32 pairs of segments, each closed by a workgroup
+// barrier: [fragment reads of 32 channels (+ the DMA issue of k-step kt + STAGES - 1 in the first)] [their MFMAs]; waves 4-7 (one per
+// SIMD, beside waves 0-3) start one segment late, so on every SIMD one wave's MFMA segment runs beside the other's read / issue
+// segment instead of both waves reading, then both multiplying (MI355X_MICROARCH.md, "Two waves per SIMD").
+template <int BN, int STAGES, int BM = GLDS_BM, int BK = 64, bool PP = false>
 __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     constexpr int ROWS = BN + BM;        // staged rows per k-step: weights first, then pixels
-    constexpr int STAGE_U4 = ROWS * 8;        // 16-byte slots per stage
-    constexpr int G = ROWS / 64;              // global_load_lds instructions per wave per k-step (6 or 5)
-    constexpr int GW = BN / 64;               // of which weight rows
+    constexpr int CPR = BK / 8;               // 16-byte chunks per row (8 or 4)
+    constexpr int RPI = 64 / CPR;             // rows per wave-instruction (8 or 16)
+    constexpr int STAGE_U4 = ROWS * CPR;      // 16-byte slots per stage
+    constexpr int G = ROWS / (8 * RPI);       // global_load_lds instructions per wave per k-step
+    constexpr int GW = BN / (8 * RPI);        // of which weight rows
+    static_assert(BK == 64 || BK == 32, "k-step of 64 or 32 channels");
+    static_assert(ROWS % (8 * RPI) == 0 && BN % (8 * RPI) == 0, "whole wave-instructions of weight rows and of pixel rows");
     constexpr int WN = BN / 64;               // waves along couts (64 couts per wave)
     constexpr int WM = 8 / WN;                // waves along pixels
     constexpr int TP = BM / WM / 16;          // 16-pixel fragments per wave (4 or 2; 2 or 1 with 128-pixel tiles)
+    static_assert(STAGES >= 2 && STAGES <= 4, "two to four LDS stages");
     extern __shared__ u32x4 smem[];           // STAGES * STAGE_U4
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -90,37 +110,44 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         out_base = (size_t)bj * HW;
         wbase = a.w + (size_t)a.eidx[b_img * a.K + bj / a.B] * a.Cout * a.Kpad;
     }
-    const int cpt = a.Cin >> 6;               // k-steps per filter tap
+    const int cpt = a.Cin / BK;               // k-steps per filter tap
     const int nk = a.ks * a.ks * cpt;
     const int pad = a.ks >> 1;
 
     // ---- staging map: lane (lr, lc) of wave-instruction q stages chunk lc ^ (row & 7) of row q*8 + lr ----------------
-    const int lr = lane >> 3, lc = lane & 7;
-    const h16_t* wsrc[GW];
-    int poff[G - GW];         // element offset of the tap-(0,0) input pixel (+ swizzled chunk) for this lane's pixel rows
-    int poff2[G - GW];        // the same pixel in the second source of a virtual concatenation
-    unsigned pmask[G - GW];   // bit (ky*3+kx): tap inside the image
+    const int lr = lane / CPR, lc = lane % CPR;
+    auto swz = [](int r) { return BK == 64 ? (r & 7) : ((0 - (r >> 2)) & 3); };
+    // Operands are fetched through raw buffer resources: the per-lane offset of a staged row never changes (a VGPR set up once), the
+    // k-step's position is a wave-uniform SGPR offset, and taps outside the image are lanes whose offset has bit 31 set — out of range
+    // for the hardware's bounds check, which returns zeros without touching memory.  (The flat-pointer form built a 64-bit address per
+    // load and selected a zero page for border taps: ~20 VALU instructions per load beside 4 MFMAs per load.)
+    // The pixel buffer starts `pad` rows and columns BEFORE the map, so that the offset of tap (0, 0) is never negative; valid taps
+    // never address below the map itself.
+    unsigned wvoff[GW];
+    unsigned pvoff[G - GW];    // byte offset of the tap-(0,0) input pixel (+ swizzled chunk) for this lane's pixel rows, from the shifted base
+    unsigned pvoff2[G - GW];   // the same pixel in the second source of a virtual concatenation; bit 31: row past the end
+    unsigned pbad[G - GW];     // bit (ky*3+kx): tap OUTSIDE the image (all ones for rows past the end)
+    const int64_t shiftB = (int64_t)(pad * a.W + pad) * a.ldx * 2;
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-        const int r = (j * 8 + wave) * 8 + lr;
-        const int sc = (lc ^ (r & 7)) * 8;
+        const int r = (j * 8 + wave) * RPI + lr;
+        const int sc = (lc ^ swz(r)) * 8;
         if (j < GW) {
             // LDS row r = MFMA row block i = (r >> 4) & 3, row fr = r & 15 of a wave's 64 couts.  It is filled with cout
             // (i >> 1) * 32 + (fr >> 2) * 8 + (i & 1) * 4 + (fr & 3): after the MFMAs a lane then holds EIGHT consecutive couts per
             // block pair (16-byte stores, 64 contiguous bytes per pixel and wave) instead of four (csrc/esmoe.hip does the same)
             const int rc = (r & ~63) + ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
-            wsrc[j] = wbase + (size_t)(n0 + rc) * a.Kpad + sc;
+            wvoff[j] = (unsigned)(((n0 + rc) * a.Kpad + sc) * 2);
         } else {
             const int p = m0 + r - BN;
-            unsigned mask = 0;
-            int off = 0, off2 = 0;
+            unsigned mask = 0, off = 0, off2 = 0x80000000u;
             if (p < Mlim) {
                 const int ox = p % a.Wo, oy = (p / a.Wo) % a.Ho, b = b_img >= 0 ? b_img : p / (a.Wo * a.Ho);
                 const int iy0 = oy * a.stride - pad, ix0 = ox * a.stride - pad;
-                off = ((b * a.H + iy0) * a.W + ix0) * a.ldx + sc;
+                off = (unsigned)((((b * a.H + oy * a.stride) * a.W + ox * a.stride) * a.ldx + sc) * 2);   // = tap (0, 0) from the shifted base
                 if (a.x2) {   // 1x1, stride 1: (oy, ox) is the pixel itself
-                    off2 = ((b * a.H + oy) * a.W + ox) * a.ldx2 + sc;
-                    if (a.up1) off = ((b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * a.ldx + sc;
+                    off2 = (unsigned)((((b * a.H + oy) * a.W + ox) * a.ldx2 + sc) * 2);
+                    if (a.up1) off = (unsigned)((((b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * a.ldx + sc) * 2);
                 }
                 unsigned ry = 0, rx = 0;   // rows / columns of the filter window that fall inside the image
 #pragma unroll
@@ -130,32 +157,35 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
                 }
                 mask = ((ry & 1u) ? rx : 0u) | ((ry & 2u) ? rx << 3 : 0u) | ((ry & 4u) ? rx << 6 : 0u);
             }
-            poff[j - GW] = off;
-            poff2[j - GW] = off2;
-            pmask[j - GW] = mask;
+            pvoff[j - GW] = off;
+            pvoff2[j - GW] = off2;
+            pbad[j - GW] = ~mask;
         }
     }
-    const h16_t* zsrc = reinterpret_cast<const h16_t*>(ymk_glds_zero_page) + lc * 8;
+    const int64_t x1rows = a.up1 ? (int64_t)a.B * (a.H >> 1) * (a.W >> 1) : (int64_t)a.B * a.H * a.W;
+    const int c1 = a.x2 ? a.C1 : a.Cin;
+    const glds_rsrc rs_w = GLDS_MAKE_RSRC(wbase, (int64_t)a.Cout * a.Kpad * 2);
+    const glds_rsrc rs_x = GLDS_MAKE_RSRC(reinterpret_cast<const char*>(a.x) - shiftB, ((x1rows - 1) * a.ldx + c1) * 2 + shiftB);
+    const glds_rsrc rs_x2 = GLDS_MAKE_RSRC(a.x2 ? a.x2 : a.x, a.x2 ? (((int64_t)a.B * a.H * a.W - 1) * a.ldx2 + (a.Cin - a.C1)) * 2 : 0);
     int it_tap_bit = 0, it_ky = 0, it_kx = 0, it_c = 0, it_k = 0;   // cursor of the NEXT k-step to issue (uniform)
-    const int k1 = a.x2 ? a.C1 >> 6 : 0;   // k-steps served by the first source of a virtual concatenation
+    const int k1 = a.x2 ? a.C1 / BK : 0;   // k-steps served by the first source of a virtual concatenation
     auto issue = [&](int stage) {
-        const int tapoff = (it_ky * a.W + it_kx) * a.ldx + it_c * 64;
+        const unsigned tapoffB = (unsigned)(((it_ky * a.W + it_kx) * a.ldx + it_c * BK) * 2);
+        const unsigned woffB = (unsigned)(it_k * BK * 2);
         const bool second = a.x2 && it_k >= k1;
+        u32x4* dst0 = smem + stage * STAGE_U4 + wave * 64;   // wave-uniform; instruction j lands at + j * 512 slots, the lane at + lane * 16 B
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            u32x4* dst = smem + stage * STAGE_U4 + (j * 8 + wave) * 64;   // wave-uniform; the lane lands at + lane * 16 B
-            const h16_t* s;
-            if (j < GW) {
-                s = wsrc[j] + it_k * 64;
-            } else {
-                // pixel address or the zero page, selected with mask arithmetic: written as `cond ? p : zsrc` the compiler built a
-                // divergent branch per load (ten per k-step, in a loop whose useful content is 16 MFMAs per wave)
-                const bool ok = second ? pmask[j - GW] != 0u : ((pmask[j - GW] >> it_tap_bit) & 1u) != 0u;
-                const h16_t* p = second ? a.x2 + (poff2[j - GW] + (it_k - k1) * 64) : a.x + (poff[j - GW] + tapoff);
-                const uintptr_t pa = reinterpret_cast<uintptr_t>(p), za = reinterpret_cast<uintptr_t>(zsrc);
-                s = reinterpret_cast<const h16_t*>(za ^ ((pa ^ za) & ((uintptr_t)0 - (uintptr_t)ok)));
+        for (int j = 0; j < GW; ++j) GLDS_BUFFER_LOAD_LDS(rs_w, dst0 + j * 512, wvoff[j], woffB);
+        if (second) {
+            const unsigned x2offB = (unsigned)((it_k - k1) * BK * 2);
+#pragma unroll
+            for (int j = GW; j < G; ++j) GLDS_BUFFER_LOAD_LDS(rs_x2, dst0 + j * 512, pvoff2[j - GW], x2offB);
+        } else {
+#pragma unroll
+            for (int j = GW; j < G; ++j) {
+                const int m = ((int)(pbad[j - GW] << (31 - it_tap_bit))) >> 31;   // -1: this tap is outside the image
+                GLDS_BUFFER_LOAD_LDS(rs_x, dst0 + j * 512, pvoff[j - GW] | ((unsigned)m & 0x80000000u), tapoffB);
             }
-            __builtin_amdgcn_global_load_lds((glds_gptr)s, (glds_lptr)dst, 16, 0, 0);
         }
         ++it_k;
         if (++it_c == cpt) {
@@ -174,19 +204,19 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     auto compute = [&](int stage) {
         if (GLDS_ABLATE & 1) return;
         const u32x4* sW = smem + stage * STAGE_U4;
-        const u32x4* sX = sW + BN * 8;
+        const u32x4* sX = sW + BN * CPR;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             u32x4 af[4], bfr[TP];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = ((wave % WN) * 4 + i) * 16 + fr;
-                af[i] = sW[r * 8 + ((kk * 4 + fc) ^ (r & 7))];
+                af[i] = sW[r * CPR + ((kk * 4 + fc) ^ swz(r))];
             }
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const int r = ((wave / WN) * TP + j) * 16 + fr;   // BN % 8 == 0: (BN + r) & 7 == r & 7
-                bfr[j] = sX[r * 8 + ((kk * 4 + fc) ^ (r & 7))];
+                const int r = ((wave / WN) * TP + j) * 16 + fr;   // BN % 16 == 0: swz(BN + r) == swz(r)
+                bfr[j] = sX[r * CPR + ((kk * 4 + fc) ^ swz(r))];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -197,7 +227,73 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
         }
     };
 
-    if constexpr (STAGES == 2) {
+    if constexpr (PP) {
+        auto seg_end = [&]() {   // segment boundary: nothing moves across it
+#ifndef YMK_HOST_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            GLDS_COMPILER_FENCE();
+            __builtin_amdgcn_s_barrier();
+            GLDS_COMPILER_FENCE();
+#ifndef YMK_HOST_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        };
+        u32x4 af[4], bfr[TP];
+        auto read_frags = [&](int stage, int kk) {
+            const u32x4* sW = smem + stage * STAGE_U4;
+            const u32x4* sX = sW + BN * CPR;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = ((wave % WN) * 4 + i) * 16 + fr;
+                af[i] = sW[r * CPR + ((kk * 4 + fc) ^ swz(r))];
+            }
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int r = ((wave / WN) * TP + j) * 16 + fr;
+                bfr[j] = sX[r * CPR + ((kk * 4 + fc) ^ swz(r))];
+            }
+        };
+        auto multiply = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) acc[i][j] = mfma16x16x32_h16(af[i], bfr[j], acc[i][j]);
+        };
+        auto wait_landed = [&](int younger) {   // my pieces of a k-step have landed; `younger` later k-steps of mine may still travel
+            if (STAGES >= 4 && younger >= 2) __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(2 * G));
+            else if (STAGES >= 3 && younger >= 1) __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(G));
+            else __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(0));
+        };
+        constexpr int KH = BK / 32;                  // (read, multiply) segment pairs per k-step
+        const bool late = wave >= 4;
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p)
+            if (p < nk) issue(p);
+        wait_landed(min(STAGES - 2, nk - 1));
+        seg_end();                                   // k-step 0 complete in its stage
+        if (late) seg_end();                         // the late half idles through the early half's first read segment
+        int cur = 0, nxt = STAGES - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) {
+                // k-step kt + STAGES - 1 goes to the stage k-step kt - 1 was read from: BOTH halves' last read segment of it is over
+                // (the late half's ran beside the early half's last multiply segment, one barrier ago)
+                if (kk == 0 && kt + STAGES - 1 < nk) issue(nxt);
+                read_frags(cur, kk);
+                // my pieces of k-step kt + 1 have landed — said before the barrier that closes my LAST read segment of k-step kt: for the
+                // late half that is the barrier right before the early half's first read of k-step kt + 1
+                if (kk == KH - 1 && kt + 1 < nk) wait_landed(min(STAGES - 2, nk - 2 - kt));
+                GLDS_WAIT_LGKM0();
+                seg_end();
+                multiply();
+                seg_end();
+            }
+            cur = cur == STAGES - 1 ? 0 : cur + 1;
+            nxt = nxt == STAGES - 1 ? 0 : nxt + 1;
+        }
+        if (!late) seg_end();                        // same barrier count for both halves
+    } else if constexpr (STAGES == 2) {
         issue(0);
         for (int kt = 0; kt < nk; ++kt) {
             // my DMA pieces of k-step kt have landed and my fragment reads of k-step kt-1 are done: stated explicitly (a
@@ -210,19 +306,25 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
             compute(kt & 1);
         }
     } else {
-        issue(0);
-        if (nk > 1) issue(1);
-        int cur = 0, nxt = 2;
+        // STAGES - 1 k-steps of DMA in flight: k-step kt + STAGES - 1 is issued right after the barrier of k-step kt, into the stage that
+        // k-step kt - 1 was multiplied from
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p)
+            if (p < nk) issue(p);
+        int cur = 0, nxt = STAGES - 1;
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(G));   // my pieces of k-step kt have landed
+            // my pieces of k-step kt have landed: at most min(STAGES - 2, nk - 1 - kt) younger k-steps of mine may still be travelling
+            const int younger = nk - 1 - kt;
+            if (STAGES >= 4 && younger >= 2) __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(2 * G));
+            else if (younger >= 1) __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(G));
             else __builtin_amdgcn_s_waitcnt(GLDS_WAITCNT_VM(0));
             GLDS_WAIT_LGKM0();                  // my fragment reads of k-step kt-1 are done (WAR on stage nxt)
             if (!(GLDS_ABLATE & 4)) __builtin_amdgcn_s_barrier();       // everyone's pieces landed, everyone's reads done
             GLDS_COMPILER_FENCE();
-            if (kt + 2 < nk && !(GLDS_ABLATE & 2)) issue(nxt);
+            if (kt + STAGES - 1 < nk && !(GLDS_ABLATE & 2)) issue(nxt);
             compute(cur);
-            cur = cur == 2 ? 0 : cur + 1;
-            nxt = nxt == 2 ? 0 : nxt + 1;
+            cur = cur == STAGES - 1 ? 0 : cur + 1;
+            nxt = nxt == STAGES - 1 ? 0 : nxt + 1;
         }
     }
 
@@ -284,18 +386,18 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     }
 }
 
-template <int BN, int STAGES, int BM>
+template <int BN, int STAGES, int BM, int BK = 64, bool PP = false>
 static int glds_launch_bm(const GldsArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
     const int grid = (a.eidx ? a.K * a.B * ((a.Ho * a.Wo + BM - 1) / BM) : (M + BM - 1) / BM) * (a.Cout / BN);
-    const size_t lds = (size_t)STAGES * (BN + BM) * 8 * 16;
+    const size_t lds = (size_t)STAGES * (BN + BM) * (BK / 8) * 16;
     static YmkOncePerDevice once;
     if (once.need()) {
-        if (hipFuncSetAttribute((const void*)conv_glds_kernel<BN, STAGES, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_glds_kernel<BN, STAGES, BM, BK, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return YMK_E_LAUNCH;
         once.done();
     }
-    hipLaunchKernelGGL((conv_glds_kernel<BN, STAGES, BM>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_glds_kernel<BN, STAGES, BM, BK, PP>), dim3(grid), dim3(512), lds, s, a);
     return ymk_launch_status();
 }
 
@@ -312,6 +414,14 @@ static int glds_big_min_tiles() {   // YMK_GLDS_BIG_MIN_TILES=<n>: the 256 x 256
     return v;
 }
 
+static int glds_bk32_mode() {   // YMK_GLDS_BK32=<bits>: half k-steps with deeper staging (A/B runs); default off
+    static const int v = [] { const char* e = getenv("YMK_GLDS_BK32"); return e ? atoi(e) : 0; }();
+    return v;
+}
+static int glds_pp_mode() {   // YMK_GLDS_PP=<bits>: ping-pong loop (A/B runs); default off
+    static const int v = [] { const char* e = getenv("YMK_GLDS_PP"); return e ? atoi(e) : 0; }();
+    return v;
+}
 static int glds_small_below() {   // YMK_GLDS_SMALL_BELOW=<n>: 128-pixel tiles iff the 256-pixel launch has fewer than n workgroups (A/B runs); unset: the rule below
     static const int v = [] { const char* e = getenv("YMK_GLDS_SMALL_BELOW"); return e ? atoi(e) : GLDS_SMALL_BELOW_DEFAULT; }();
     return v;
@@ -352,6 +462,29 @@ static int glds_launch_any(const GldsArgs& a, hipStream_t s, int flags) {
         // 20^2: 26 -> 33).  The 128 x 512 tile never won (reachable through the flags only).
         if (STAGES == 2 && a.Cout % 256 == 0 && a.Kpad >= 384 && tiles(256, 256) >= glds_big_min_tiles()) { bn = 256; bm = 256; }
     }
+    // half k-steps, STAGES - 1 >= 2 transfers in flight (flags bit 22, or YMK_GLDS_BK32 bit 0: the 256 x 256 tile on four 32 KB stages;
+    // bit 1: 128-cout launches on 128 x 256 tiles of three 24 KB stages, two workgroups per CU; bit 2: 128 x 128 on four 16 KB stages)
+    const int pp = ((flags >> 23) & 1) ? 15 : glds_pp_mode();
+    if (((flags >> 22) & 3) == 3 || (pp & 48)) {   // out-of-phase loop on half k-steps (YMK_GLDS_PP bit 4: 256 x 256 x 32 on four stages; bit 5: 128-cout launches on 128 x 256 x 32, three stages)
+        const bool f = ((flags >> 22) & 3) == 3;
+        if ((f || (pp & 16)) && bn == 256 && bm == 256) { glds_last_tile = bm; glds_last_bn = bn; return glds_launch_bm<256, 4, 256, 32, true>(a, s); }
+        if (f && bn == 128 && bm == 256) { glds_last_tile = bm; glds_last_bn = bn; return glds_launch_bm<128, 3, 256, 32, true>(a, s); }
+        if (!f && (pp & 32) && bn == 128 && bm == 128) { glds_last_tile = 256; glds_last_bn = bn; return glds_launch_bm<128, 3, 256, 32, true>(a, s); }
+        if (f) return YMK_E_BADARG;
+    }
+    if (pp && STAGES == 2) {
+        if ((pp & 1) && bn == 256 && bm == 256) { glds_last_tile = bm; glds_last_bn = bn; return glds_launch_bm<256, 2, 256, 64, true>(a, s); }
+        if ((pp & 8) && bn == 128 && bm == 256) { glds_last_tile = bm; glds_last_bn = bn; return glds_launch_bm<128, 2, 256, 64, true>(a, s); }
+        if ((pp & 2) && !((flags >> 23) & 1) && bn == 128 && bm == 128) { glds_last_tile = 256; glds_last_bn = bn; return glds_launch_bm<128, 2, 256, 64, true>(a, s); }
+        if ((pp & 4) && bn == 128 && bm == 128) { glds_last_tile = bm; glds_last_bn = bn; return glds_launch_bm<128, 2, 128, 64, true>(a, s); }
+    }
+    const int k32 = ((flags >> 22) & 1) ? 7 : glds_bk32_mode();
+    if (k32) {
+        if ((k32 & 1) && bn == 256 && bm == 256) { glds_last_tile = bm; glds_last_bn = bn; return glds_launch_bm<256, 4, 256, 32>(a, s); }
+        if (((flags >> 22) & 1) && bn == 128 && bm == 256) { glds_last_tile = bm; glds_last_bn = bn; return glds_launch_bm<128, 3, 256, 32>(a, s); }
+        if ((k32 & 2) && !((flags >> 22) & 1) && bn == 128 && bm == 128) { glds_last_tile = 256; glds_last_bn = bn; return glds_launch_bm<128, 3, 256, 32>(a, s); }
+        if ((k32 & 4) && bn == 128 && bm == 128) { glds_last_tile = bm; glds_last_bn = bn; return glds_launch_bm<128, 4, 128, 32>(a, s); }
+    }
     glds_last_tile = bm;
     glds_last_bn = bn;
     if (STAGES == 2) {
@@ -384,8 +517,10 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
     a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = nullptr; a.K = 0;
     const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
     if (M <= 0) return YMK_OK;
-    // 32-bit element offsets inside the kernel
-    if (M >= (1ll << 31) || ((int64_t)d->B * d->H * d->W + d->W + 2) * d->ldx >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
+    // 31-bit BYTE offsets of the staged operands (bit 31 of a lane's buffer offset marks a tap outside the image), 32-bit element offsets of the output
+    if (M >= (1ll << 31) || ((int64_t)d->B * d->H * d->W + 2 * d->W + 4) * d->ldx >= (1ll << 30) || M * d->ldy >= (1ll << 31) ||
+        (int64_t)d->Cout * d->Kpad >= (1ll << 30))
+        return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     return (two_stage & 1) ? glds_launch_any<2>(a, s, two_stage) : glds_launch_any<3>(a, s, two_stage);
 }
@@ -405,7 +540,8 @@ extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int
     a.x2 = static_cast<const h16_t*>(x2); a.C1 = C1; a.ldx2 = ldx2; a.up1 = upsample1 ? 1 : 0; a.eidx = nullptr; a.K = 0;
     const int64_t M = (int64_t)a.B * a.H * a.W;
     if (M <= 0) return YMK_OK;
-    if (M >= (1ll << 31) || (M + 2) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 31) || M * d->ldy >= (1ll << 31)) return YMK_E_BADARG;
+    if (M >= (1ll << 31) || (M + 2) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 30) || M * d->ldy >= (1ll << 31) || (int64_t)d->Cout * d->Kpad >= (1ll << 30))
+        return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     return (two_stage & 1) ? glds_launch_any<2>(a, s, two_stage) : glds_launch_any<3>(a, s, two_stage);
 }
@@ -427,7 +563,8 @@ extern "C" int ymk_expert_conv_glds(const ymk_conv_desc* d, const void* x, const
     a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = idx; a.K = K;
     const int64_t HW = (int64_t)d->H * d->W;
     if (d->B <= 0 || HW <= 0) return YMK_OK;
-    if (((int64_t)d->B * HW + d->W + 2) * d->ldx >= (1ll << 31) || (int64_t)K * d->B * HW >= (1ll << 31)) return YMK_E_BADARG;
+    if (((int64_t)d->B * HW + 2 * d->W + 4) * d->ldx >= (1ll << 30) || (int64_t)K * d->B * HW >= (1ll << 31) || (int64_t)d->Cout * d->Kpad >= (1ll << 30))
+        return YMK_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     return (two_stage & 1) ? glds_launch_any<2>(a, s, two_stage) : glds_launch_any<3>(a, s, two_stage);
 }

@@ -2,6 +2,8 @@
 // FIRST IMPLEMENTATION, correctness-first: one query per thread with the head vector in registers, keys / values staged
 // in LDS as fp32 and read as broadcasts, online softmax on the VALU.  No MFMA yet: the shapes are small (head_dim 8-64,
 // 49-key windows, <= 4096 pooled keys) and the tile engine of attn.hip takes over once parity is established on hardware.
+#include <type_traits>
+
 #include "ymk_common.h"
 #include "../../include/ymk_mixture.h"
 
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(int dt, const voi
 //         movement), and the A operand (V^T) is two 8-byte reads of a V^T image staged once per wave in LDS.
 // Out-of-image tokens of the padded / rolled grid carry the pad vectors and take part as keys, as in window_attention_kernel.
 template <int HD>
-__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const h16_t* q, int ldq, const h16_t* k, int ldk, const h16_t* v, int ldv_,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void window_attention_mfma_kernel(const h16_t* q, int ldq, const h16_t* k, int ldk, const h16_t* v, int ldv_,
                                                                     h16_t* out, int ldo, int H, int W, float scale, int win, int shift,
                                                                     const float* pad_q, const float* pad_k, const float* pad_v, int nwin) {
     constexpr int KB = (HD + 31) / 32;          // 32-channel blocks of the first contraction (channels past head_dim are zero)
@@ -290,7 +292,7 @@ __device__ __forceinline__ float mx_rowgroup_sum(float v) {
 // accumulators by exp(m_old - m_new) — a per-lane scalar, because a lane's accumulators all belong to query column (lane & 15) —
 // and adds V^T P^T with the permuted contraction index of window_attention_mfma_kernel (P^T is used where the MFMA left it).
 template <int HD>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const h16_t* q, int ldq, const h16_t* k, int ldk, const h16_t* v, int ldv_, h16_t* out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 32 ? 2 : 1))) void attention_mfma_kernel(const h16_t* q, int ldq, const h16_t* k, int ldk, const h16_t* v, int ldv_, h16_t* out,
                                                              int ldo, int Nq, int Nk, float scale) {
     constexpr int KB = (HD + 31) / 32, DT = (HD + 15) / 16, CH = HD / 8;   // 16-byte chunks per K row
     constexpr int VP = 64 + 4;
@@ -360,37 +362,53 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const h16_t* q, int
         }
         __syncthreads();
         if (n0 + 64 < Nk) fetch(n0 + 64);
-        // S^T tiles for this wave's 64 queries
-        f32x4 st[4][4];
+        // fragments of this key block, read once: K rows (A operand of S^T = K Q^T) and V^T rows (A operand of O^T += V^T P^T)
+        constexpr bool HOIST_V = DT <= 2;           // head_dim > 32: the V^T fragments are re-read per query group (32 more registers would spill)
+        u32x4 kf[4][KB], vf[HOIST_V ? DT : 1][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u32x4 kf[KB];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const int r = 16 * j + fr, cc = kb * 4 + g;
-                kf[kb] = cc < KC ? sk[r * KC + (cc ^ (r & (KC - 1)))] : u32x4{0u, 0u, 0u, 0u};
+                kf[j][kb] = cc < KC ? sk[r * KC + (cc ^ (r & (KC - 1)))] : u32x4{0u, 0u, 0u, 0u};
             }
+        auto vt_frag = [&](int dt, int kb) {
+            const h16_t* row = svt + (dt * 16 + fr) * VP + 32 * kb + 4 * g;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(row), hi = *reinterpret_cast<const u32x2*>(row + 16);
+            return u32x4{lo.x, lo.y, hi.x, hi.y};
+        };
+        if constexpr (HOIST_V) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mfma16x16x32_h16(kf[kb], qf[i][kb], acc);
-                st[j][i] = acc;
-            }
+                for (int kb = 0; kb < 2; ++kb) vf[dt][kb] = vt_frag(dt, kb);
         }
-        const bool tail = n0 + 64 > Nk;             // only the last block can hold keys past the end (workgroup-uniform)
+        // one 16-query group at a time: its four S^T tiles (16 registers) live only from their MFMAs to the packed P^T — the whole
+        // 64 x 64 score block held at once (64 registers) spilled into the accumulation registers and came back through 160 copies
+        auto softmax_pv = [&](auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float mb = -INFINITY;
+            f32x4 st[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float* a4 = reinterpret_cast<float*>(&st[j][i]);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (tail && n0 + 16 * j + 4 * g + r >= Nk) a4[r] = -INFINITY;
-                    mb = fmaxf(mb, a4[r]);
+                for (int kb = 0; kb < KB; ++kb) acc = mfma16x16x32_h16(kf[j][kb], qf[i][kb], acc);
+                st[j] = acc;
+            }
+            if constexpr (TAIL) {                     // last block only (compiled twice: as a runtime condition the sixteen selects per group were issued in every block)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float* a4 = reinterpret_cast<float*>(&st[j]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + 16 * j + 4 * g + r >= Nk) a4[r] = -INFINITY;
                 }
             }
+            float mb = st[0].x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mb = fmaxf(fmaxf(fmaxf(fmaxf(mb, st[j].x), st[j].y), st[j].z), st[j].w);   // v_max3 chains
             mb = mx_rowgroup_max(mb);
             const float mn = fmaxf(m[i], mb);     // finite: every block holds at least one real key (scores are UNSCALED here)
             const float c = __builtin_amdgcn_exp2f((m[i] - mn) * c2);    // 2^(-inf) = 0 on the first block
@@ -398,35 +416,31 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const h16_t* q, int
             float lb = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float* a4 = reinterpret_cast<float*>(&st[j][i]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    a4[r] = __builtin_amdgcn_exp2f(fmaf(a4[r], c2, nmc));
-                    lb += a4[r];
-                }
+                st[j].x = __builtin_amdgcn_exp2f(fmaf(st[j].x, c2, nmc));
+                st[j].y = __builtin_amdgcn_exp2f(fmaf(st[j].y, c2, nmc));
+                st[j].z = __builtin_amdgcn_exp2f(fmaf(st[j].z, c2, nmc));
+                st[j].w = __builtin_amdgcn_exp2f(fmaf(st[j].w, c2, nmc));
+                lb += (st[j].x + st[j].y) + (st[j].z + st[j].w);
             }
             l[i] = l[i] * c + lb;                 // this lane group's share of the denominator: the four shares meet once, after the last block
             m[i] = mn;
             u32x4 pf[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                pf[kb].x = pack_h16x2(st[2 * kb][i].x, st[2 * kb][i].y);         pf[kb].y = pack_h16x2(st[2 * kb][i].z, st[2 * kb][i].w);
-                pf[kb].z = pack_h16x2(st[2 * kb + 1][i].x, st[2 * kb + 1][i].y); pf[kb].w = pack_h16x2(st[2 * kb + 1][i].z, st[2 * kb + 1][i].w);
+                pf[kb].x = pack_h16x2(st[2 * kb].x, st[2 * kb].y);         pf[kb].y = pack_h16x2(st[2 * kb].z, st[2 * kb].w);
+                pf[kb].z = pack_h16x2(st[2 * kb + 1].x, st[2 * kb + 1].y); pf[kb].w = pack_h16x2(st[2 * kb + 1].z, st[2 * kb + 1].w);
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 f32x4 acc = o[i][dt];
                 acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const h16_t* row = svt + (dt * 16 + fr) * VP + 32 * kb + 4 * g;
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(row), hi = *reinterpret_cast<const u32x2*>(row + 16);
-                    const u32x4 af = {lo.x, lo.y, hi.x, hi.y};
-                    acc = mfma16x16x32_h16(af, pf[kb], acc);
-                }
+                for (int kb = 0; kb < 2; ++kb) acc = mfma16x16x32_h16(HOIST_V ? vf[HOIST_V ? dt : 0][kb] : vt_frag(dt, kb), pf[kb], acc);
                 o[i][dt] = acc;
             }
         }
+        };
+        if (n0 + 64 > Nk) softmax_pv(std::true_type{}); else softmax_pv(std::false_type{});   // only the last block can hold keys past the end (workgroup-uniform)
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

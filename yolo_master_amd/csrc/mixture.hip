@@ -63,14 +63,13 @@ __global__ __launch_bounds__(256) void activation_kernel(void* x, int dt, int ld
 // over a slab that stays in L2), and the partials are combined with the exact pairwise update (Chan et al.) in chunk order —
 // deterministic, and as accurate as the reference's single two-pass evaluation.  nchunk == 1: final (mean, rstd) written directly.
 #define GN_MAX_CHUNKS 64
-__device__ __forceinline__ void gn_emit(float mean, float m2, float n, int nchunk, float eps, float* stats, float* part) {
+__device__ __forceinline__ void gn_emit(float mean, float m2, float n, int nchunk, float eps, float* stats, float* part, int slab, int chunk) {
     if (threadIdx.x != 0) return;
-    const int slab = blockIdx.x;
     if (nchunk == 1) {
         stats[2 * slab] = mean;
         stats[2 * slab + 1] = 1.0f / sqrtf(m2 / n + eps);
     } else {
-        float* o = part + ((size_t)slab * GN_MAX_CHUNKS + blockIdx.y) * 3;
+        float* o = part + ((size_t)slab * GN_MAX_CHUNKS + chunk) * 3;
         o[0] = mean; o[1] = m2; o[2] = n;
     }
 }
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x, int dt, in
         const float d = ldv(x, dt, base + (i / cg) * ldx + (i % cg)) - mean;
         q += d * d;
     }
-    gn_emit(mean, block_sum(q, sh), (float)n, nchunk, eps, stats, part);
+    gn_emit(mean, block_sum(q, sh), (float)n, nchunk, eps, stats, part, blockIdx.x, blockIdx.y);
 }
 __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, int dt, int ldx, void* y, int odt, int ldy, const void* res,
                                                         int ldr, int B, int HW, int C, int groups, const float* weight,
@@ -451,13 +450,19 @@ __global__ __launch_bounds__(256) void activation_vec_kernel(T* x, int ldx, int6
     }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, int HW, int C, int groups, float eps, float* stats, float* part,
-                                                            int nchunk) {
+__global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, int B, int HW, int C, int groups, float eps, float* stats,
+                                                            float* part, int nchunk) {
     constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ float sh[4];
-    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8.  The groups of one (image, pixel chunk) read neighbouring pieces of the SAME
+    // rows (C / groups channels of each: 64 bytes at 256 channels in 8 groups), so they are given to one XCD back to back — its L2 then
+    // serves the row's other groups — instead of to eight XCDs that each pull the whole cache line from HBM.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = slot % groups, bc = (slot / groups) * 8 + xcd;
+    if (bc >= B * nchunk) return;
+    const int b = bc / nchunk, chunk = bc % nchunk, slab = b * groups + g;
     const int cg = C / groups, ncv = cg / VEC;
-    const int p0 = (int)((int64_t)HW * blockIdx.y / nchunk), p1 = (int)((int64_t)HW * (blockIdx.y + 1) / nchunk);
+    const int p0 = (int)((int64_t)HW * chunk / nchunk), p1 = (int)((int64_t)HW * (chunk + 1) / nchunk);
     const int64_t nv = (int64_t)(p1 - p0) * ncv;
     const T* base = x + ((int64_t)b * HW + p0) * ldx + (int64_t)g * cg;
     const float n = (float)(p1 - p0) * (float)cg;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, 
                 for (int q = 0; q < VEC; ++q) qq += (v[q] - mean) * (v[q] - mean);
             }
         }
-        gn_emit(mean, block_sum(qq, sh), n, nchunk, eps, stats, part);
+        gn_emit(mean, block_sum(qq, sh), n, nchunk, eps, stats, part, slab, chunk);
         return;
     }
     float s = 0.f;
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* x, int ldx, 
 #pragma unroll
         for (int q = 0; q < VEC; ++q) qq += (v[q] - mean) * (v[q] - mean);
     }
-    gn_emit(mean, block_sum(qq, sh), n, nchunk, eps, stats, part);
+    gn_emit(mean, block_sum(qq, sh), n, nchunk, eps, stats, part, slab, chunk);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* x, int ldx, T* y, int ldy, const T* res, int ldr, int B, int HW, int C,
@@ -904,11 +909,12 @@ extern "C" int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y
     const int nchunk = (int)(want < 1 ? 1 : want > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : want > HW ? HW : want);
     float* part = stats_ws + (size_t)B * groups * 2;
     const dim3 sgrid(B * groups, nchunk);
+    const dim3 vgrid((unsigned)(((int64_t)B * nchunk + 7) / 8 * 8 * groups));
     if (vin && (C / groups) % V == 0) {   // statistics: whole vectors inside a group
         if (dtype == YMK_BF16)
-            hipLaunchKernelGGL(gn_stats_vec_kernel<h16_t>, sgrid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, HW, C, groups, eps, stats_ws, part, nchunk);
+            hipLaunchKernelGGL(gn_stats_vec_kernel<h16_t>, vgrid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ldx, B, HW, C, groups, eps, stats_ws, part, nchunk);
         else
-            hipLaunchKernelGGL(gn_stats_vec_kernel<float>, sgrid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, HW, C, groups, eps, stats_ws, part, nchunk);
+            hipLaunchKernelGGL(gn_stats_vec_kernel<float>, vgrid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, B, HW, C, groups, eps, stats_ws, part, nchunk);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel, sgrid, dim3(256), 0, (hipStream_t)stream, x, dtype, ldx, HW, C, groups, eps, stats_ws, part, nchunk);
     }

@@ -293,7 +293,18 @@ def main():
                     nms_padded(y_, 0.25, 0.7, max_det=MAX_DET)
                 torch.cuda.synchronize()
                 recs = ops.TIMER.records
+                shapes = list(getattr(ops.TIMER, "shapes", []))
                 ops.TIMER.stop()
+                if os.environ.get("YMK_BENCH_CALLS"):   # every op call of one step with its shape, time, GB/s and TFLOP/s (diagnostics)
+                    n1 = len(recs) // 3
+                    rows = []
+                    for i in range(n1):
+                        ms = sorted(recs[i + r * n1][1].elapsed_time(recs[i + r * n1][2]) for r in range(3))[1]
+                        rows.append((ms, i, recs[i][0], shapes[i] if i < len(shapes) else "", recs[i][3], recs[i][4]))
+                    with open(os.environ["YMK_BENCH_CALLS"], "w") as fh:
+                        fh.write(f"{n1} op calls, {sum(r[0] for r in rows):.3f} ms\n")
+                        for ms, i, fam, shp, nb, fl in sorted(rows, reverse=True):
+                            fh.write(f"{i:4d} {fam[:58]:58s} {shp:40s} {ms * 1e3:8.1f} us {nb / ms / 1e6:8.0f} GB/s {fl / ms / 1e9:8.1f} TF/s\n")
                 agg = {}
                 for fam, e0, e1, nb, fl in recs:
                     r = agg.setdefault(fam, [0.0, 0, 0, 0])

@@ -30,7 +30,7 @@ int ymk_activation(int32_t dtype, void* x, int32_t ldx, int64_t npix, int32_t C,
  * weight/bias: fp32 [C], or NULL (no affine), or [R][C] with affine_rows int32 [B] (row per image; FusedExpertGroup,
  * moe/gated.py:1058-1090).  act: YMK_ACT_NONE | YMK_ACT_SILU.  residual (dtype = out_dtype of y, may be NULL) is added
  * after the activation (MoTBlock out_norm(.) + x, mot/block.py:413-417).  y may alias x.
- * stats_ws: fp32 [B*groups*(2 + 3*64)] scratch: (mean, rstd) per slab, then up to 64 chunk partials (mean, M2, n) per slab —
+ * stats_ws: fp32 [B*groups*(2 + 3*256)] scratch: (mean, rstd) per slab, then up to 256 chunk partials (mean, M2, n) per slab —
  * a slab's statistics are computed by several workgroups and combined exactly, in chunk order (deterministic). */
 int ymk_group_norm(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
                    const void* residual, int32_t ldr, int32_t B, int32_t HW, int32_t C, int32_t groups,

@@ -75,6 +75,11 @@ def test_norms_and_elementwise(dtype):
     _cmp(buf[..., :6], emu_ops.group_norm(x6, 3, w[:6], b[:6], 1e-5, act="silu"), torch.float32, "group_norm C=6")
     assert float(buf[..., 6:].abs().max()) == 0.0
     _cmp(ops.layer_norm(_view(x, 8), w.to(DEV), b.to(DEV), 1e-5), emu_ops.layer_norm(x, w, b, 1e-5), dtype, "layer_norm")
+    # register-resident rows: 256 channels = 32 lanes per token in 16-bit (two tokens per wave), 64 in fp32; 35 tokens (ragged last group);
+    # 520 channels (65 / 130 vectors: the looping kernel)
+    for cw, sd in ((256, 50), (520, 53)):
+        xw, ww, bw = _rnd(1, 5, 7, cw, seed=sd, dtype=dtype), 1.0 + 0.1 * _rnd(cw, seed=sd + 1), 0.1 * _rnd(cw, seed=sd + 2)
+        _cmp(ops.layer_norm(xw.to(DEV), ww.to(DEV), bw.to(DEV), 1e-5), emu_ops.layer_norm(xw, ww, bw, 1e-5), dtype, f"layer_norm C={cw}")
     y = _rnd(3, 9, 11, 48, seed=8, dtype=dtype)
     _cmp(ops.eltwise_mul(x.to(DEV), _view(y, 8)), emu_ops.eltwise_mul(x, y), dtype, "mul")
     _cmp(ops.eltwise_mul(x.to(DEV), y.to(DEV), act_a="sigmoid"), emu_ops.eltwise_mul(x, y, act_a="sigmoid"), dtype, "sigmoid-mul")

@@ -73,10 +73,9 @@ def test_conv2d_glds_on_the_emulator(hostlib, case):
     run_case(hostlib, case)
 
 
-def tile_flags(bn, bm, two=1, k32=False, pp=False):
-    """`two_stage` argument of the LDS-DMA entry points with a forced tile shape (csrc/conv_glds.hip glds_launch_any); k32: half
-    k-steps (32 channels) on three / four stages; pp: the loop whose two waves per SIMD run half a k-step out of phase."""
-    return two | ((bn // 64) << 8) | (bm << 12) | (int(k32) << 22) | (int(pp) << 23)
+def tile_flags(bn, bm, two=1):
+    """`two_stage` argument of the LDS-DMA entry points with a forced tile shape (csrc/conv_glds.hip glds_launch_any)."""
+    return two | ((bn // 64) << 8) | (bm << 12)
 
 
 BIG_TILE_CASES = [
@@ -93,39 +92,6 @@ BIG_TILE_CASES = [
 @pytest.mark.parametrize("case,tile", BIG_TILE_CASES)
 def test_conv2d_glds_big_tiles_on_the_emulator(hostlib, case, tile):
     run_case(hostlib, case[:-1] + (tile_flags(*tile),))
-
-
-K32_CASES = [
-    # half k-steps (rows of 64 bytes, chunk swizzle over four chunks, STAGES - 1 transfers in flight): 256 x 256 on four stages,
-    # 128 x 256 on three, 128 x 128 on four; fewer k-steps than stages (64 channels, 1x1 = two half steps), many (3x3 x 192 = 54),
-    # ragged pixel tiles, stride 2, residual, fp32 output, channel-slice views
-    ((2, 21, 19, 64, 256, 3, 2, True, False, False, 64, 0, 1), (256, 256)),
-    ((1, 18, 17, 128, 256, 1, 1, False, True, True, 0, 0, 1), (256, 256)),
-    ((1, 9, 9, 64, 256, 1, 1, True, False, False, 0, 0, 1), (256, 256)),
-    ((1, 12, 23, 192, 128, 3, 1, True, True, False, 0, 64, 1), (128, 256)),
-    ((2, 16, 16, 128, 128, 1, 2, False, False, False, 8, 4, 1), (128, 256)),
-    ((1, 13, 11, 64, 128, 3, 1, True, True, False, 0, 0, 1), (128, 128)),
-    ((1, 7, 5, 64, 128, 1, 1, True, False, True, 0, 0, 1), (128, 128)),
-]
-
-
-@pytest.mark.parametrize("case,tile", K32_CASES)
-def test_conv2d_glds_half_k_steps_on_the_emulator(hostlib, case, tile):
-    run_case(hostlib, case[:-1] + (tile_flags(*tile, k32=True),))
-
-
-@pytest.mark.parametrize("case,tile", K32_CASES)
-def test_conv2d_glds_ping_pong_loop_on_the_emulator(hostlib, case, tile):
-    """The out-of-phase loop (same cases: one k-step, many, ragged tiles, both stage parities at the end): the late half's extra
-    barrier at the start and the early half's at the end keep the workgroup's barrier count equal; DMA completes at once on the
-    emulator, so a transfer issued into a stage that is still being read shows as wrong numbers."""
-    run_case(hostlib, case[:-1] + (tile_flags(*tile, pp=True),))
-
-
-@pytest.mark.parametrize("case,tile", [c for c in K32_CASES if c[1] != (128, 128)])
-def test_conv2d_glds_ping_pong_half_k_steps_on_the_emulator(hostlib, case, tile):
-    """Both together: 256 x 256 x 32 on four stages / 128 x 256 x 32 on three, waves 4-7 one segment behind waves 0-3."""
-    run_case(hostlib, case[:-1] + (tile_flags(*tile, k32=True, pp=True),))
 
 
 def test_conv2d_glds_rejects_impossible_tiles(hostlib):
@@ -161,8 +127,8 @@ CAT2_CASES = [
     (1, 12, 10, 128, 64, 64, False, True, 64, 8, 64, 1),
     (2, 6, 22, 64, 192, 192, True, False, 0, 0, 0, 0),        # BN = 64, ragged tail, three cout tiles
     (3, 8, 8, 256, 128, 128, False, True, 0, 64, 0, 0),
-    (2, 10, 14, 64, 192, 256, True, True, 0, 0, 0, 1 | (4 << 8) | (256 << 12) | (1 << 22)),     # half k-steps: the source switches at half-step 2
-    (1, 12, 10, 128, 64, 128, False, True, 64, 8, 64, 1 | (2 << 8) | (256 << 12) | (1 << 22)),
+    (2, 10, 14, 64, 192, 256, True, True, 0, 0, 0, 1 | (4 << 8) | (256 << 12)),     # 256 x 256 tile, the source switches at k-step 1
+    (1, 12, 10, 128, 64, 128, False, True, 64, 8, 64, 1 | (2 << 8) | (256 << 12)),
 ]
 
 
@@ -200,7 +166,7 @@ EXPERT_CASES = [
     (2, 9, 7, 64, 64, 3, 4, [[2, 0], [1, 3]], 0),
     (3, 17, 16, 128, 128, 3, 4, [[0, 1], [3, 3], [2, 0]], 1),         # image larger than one tile (272 pixels): tail tile per image
     (2, 6, 5, 192, 64, 1, 16, [[15, 4, 9], [0, 15, 7]], 0),           # shared-inverted projections: 1x1, sixteen banks, three slots
-    (2, 17, 16, 64, 128, 3, 4, [[0, 1], [3, 2]], 1 | (2 << 8) | (128 << 12) | (1 << 22)),   # half k-steps on four stages
+    (2, 17, 16, 64, 128, 3, 4, [[0, 1], [3, 2]], 1 | (2 << 8) | (256 << 12)),   # 128 x 256 tiles, two per image
 ]
 
 

@@ -291,8 +291,10 @@ __device__ __forceinline__ float mx_rowgroup_sum(float v) {
 // once; every wave then forms S^T = K Q^T for its 64 queries (Q fragments stay in registers for the whole kernel), rescales its O^T
 // accumulators by exp(m_old - m_new) — a per-lane scalar, because a lane's accumulators all belong to query column (lane & 15) —
 // and adds V^T P^T with the permuted contraction index of window_attention_mfma_kernel (P^T is used where the MFMA left it).
-template <int HD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 32 ? 2 : 1))) void attention_mfma_kernel(const h16_t* q, int ldq, const h16_t* k, int ldk, const h16_t* v, int ldv_, h16_t* out,
+// NI = 16-query groups per wave (4: 256 queries per workgroup, ~190 registers = two waves per SIMD; 2: 128 queries, <= 128 registers = four
+// waves per SIMD — each wave's chain S -> max -> exp -> P -> O is latency-bound, more resident waves hide it)
+template <int HD, int NI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD > 32 ? 1 : NI == 2 ? 4 : 2))) void attention_mfma_kernel(const h16_t* q, int ldq, const h16_t* k, int ldk, const h16_t* v, int ldv_, h16_t* out,
                                                              int ldo, int Nq, int Nk, float scale) {
     constexpr int KB = (HD + 31) / 32, DT = (HD + 15) / 16, CH = HD / 8;   // 16-byte chunks per K row
     constexpr int VP = 64 + 4;
@@ -302,13 +304,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 32 ? 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 256 + wave * 64;
+    const int q0 = blockIdx.x * (64 * NI) + wave * (16 * NI);
     const h16_t* qb = q + (int64_t)b * Nq * ldq + h * HD;
     const h16_t* kbp = k + (int64_t)b * Nk * ldk + h * HD;
     const h16_t* vb = v + (int64_t)b * Nk * ldv_ + h * HD;
-    u32x4 qf[4][KB];
+    u32x4 qf[NI][KB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const int qi = q0 + 16 * i + fr, c0 = kb * 32 + g * 8;
@@ -316,11 +318,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 32 ? 
         }
     if (DT * 16 > HD)
         for (int c = threadIdx.x; c < (DT * 16 - HD) * VP; c += 256) svt[HD * VP + c] = (h16_t)0;
-    f32x4 o[4][DT];
-    float m[4], l[4];
+    f32x4 o[NI][DT];
+    float m[NI];
+    // softmax denominators on the matrix cores: a block of ones next to V^T makes one more output tile whose every row is
+    // sum_keys P^T — the sum of exactly the rounded weights the numerator uses, complete per lane (the MFMA contracts over all 64 keys:
+    // no per-score add, no cross-lane reduction).  The softmax is VALU-bound here (~5 VALU slots per score beside 2 x 64 MFMA FLOPs);
+    // the matrix pipe has the room.  Only element .x of a tile is rescaled and read.
+    f32x4 den[NI];
+    const uint32_t one2 = pack_h16x2(1.0f, 1.0f);
+    const u32x4 ones = {one2, one2, one2, one2};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        m[i] = -INFINITY; l[i] = 0.f;
+    for (int i = 0; i < NI; ++i) {
+        m[i] = -INFINITY; den[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -363,15 +372,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 32 ? 
         __syncthreads();
         if (n0 + 64 < Nk) fetch(n0 + 64);
         // fragments of this key block, read once: K rows (A operand of S^T = K Q^T) and V^T rows (A operand of O^T += V^T P^T)
-        constexpr bool HOIST_V = DT <= 2;           // head_dim > 32: the V^T fragments are re-read per query group (32 more registers would spill)
-        u32x4 kf[4][KB], vf[HOIST_V ? DT : 1][2];
+        constexpr bool HOIST_V = DT <= 2 && NI == 4;   // head_dim > 32 or the 128-register form: the V^T fragments are re-read per query group
+        constexpr bool HOIST_K = NI == 4;
+        u32x4 kf[HOIST_K ? 4 : 1][KB], vf[HOIST_V ? DT : 1][2];
+        auto k_frag = [&](int j, int kb) {
+            const int r = 16 * j + fr, cc = kb * 4 + g;
+            return cc < KC ? sk[r * KC + (cc ^ (r & (KC - 1)))] : u32x4{0u, 0u, 0u, 0u};
+        };
+        if constexpr (HOIST_K) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const int r = 16 * j + fr, cc = kb * 4 + g;
-                kf[j][kb] = cc < KC ? sk[r * KC + (cc ^ (r & (KC - 1)))] : u32x4{0u, 0u, 0u, 0u};
-            }
+                for (int kb = 0; kb < KB; ++kb) kf[j][kb] = k_frag(j, kb);
+        }
         auto vt_frag = [&](int dt, int kb) {
             const h16_t* row = svt + (dt * 16 + fr) * VP + 32 * kb + 4 * g;
             const u32x2 lo = *reinterpret_cast<const u32x2*>(row), hi = *reinterpret_cast<const u32x2*>(row + 16);
@@ -388,13 +401,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 32 ? 
         auto softmax_pv = [&](auto tail_c) {
         constexpr bool TAIL = decltype(tail_c)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             f32x4 st[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mfma16x16x32_h16(kf[j][kb], qf[i][kb], acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mfma16x16x32_h16(HOIST_K ? kf[HOIST_K ? j : 0][kb] : k_frag(j, kb), qf[i][kb], acc);
                 st[j] = acc;
             }
             if constexpr (TAIL) {                     // last block only (compiled twice: as a runtime condition the sixteen selects per group were issued in every block)
@@ -413,16 +426,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 32 ? 
             const float mn = fmaxf(m[i], mb);     // finite: every block holds at least one real key (scores are UNSCALED here)
             const float c = __builtin_amdgcn_exp2f((m[i] - mn) * c2);    // 2^(-inf) = 0 on the first block
             const float nmc = -mn * c2;
-            float lb = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 st[j].x = __builtin_amdgcn_exp2f(fmaf(st[j].x, c2, nmc));
                 st[j].y = __builtin_amdgcn_exp2f(fmaf(st[j].y, c2, nmc));
                 st[j].z = __builtin_amdgcn_exp2f(fmaf(st[j].z, c2, nmc));
                 st[j].w = __builtin_amdgcn_exp2f(fmaf(st[j].w, c2, nmc));
-                lb += (st[j].x + st[j].y) + (st[j].z + st[j].w);
             }
-            l[i] = l[i] * c + lb;                 // this lane group's share of the denominator: the four shares meet once, after the last block
             m[i] = mn;
             u32x4 pf[2];
 #pragma unroll
@@ -438,14 +448,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 32 ? 
                 for (int kb = 0; kb < 2; ++kb) acc = mfma16x16x32_h16(HOIST_V ? vf[HOIST_V ? dt : 0][kb] : vt_frag(dt, kb), pf[kb], acc);
                 o[i][dt] = acc;
             }
+            {
+                f32x4 acc = den[i];
+                acc.x *= c;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) acc = mfma16x16x32_h16(ones, pf[kb], acc);
+                den[i] = acc;
+            }
         }
         };
         if (n0 + 64 > Nk) softmax_pv(std::true_type{}); else softmax_pv(std::false_type{});   // only the last block can hold keys past the end (workgroup-uniform)
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int qi = q0 + 16 * i + fr;
-        const float inv = 1.0f / mx_rowgroup_sum(l[i]);
+        const float inv = 1.0f / den[i].x;
         if (qi >= Nq) continue;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -676,12 +693,18 @@ extern "C" int ymk_attention(int32_t dtype, const void* q, int32_t ldq, const vo
         auto al = [](const void* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
         if (dtype == YMK_H16 && hd % 8 == 0 && hd >= 8 && hd <= 64 && al(q, ldq) && al(k, ldk) && al(v, ldv) &&
             (reinterpret_cast<uintptr_t>(out) & 7) == 0 && ldo % 4 == 0 && !(ymk_disabled() & YMK_OFF_WINATTN_MFMA)) {
-            const dim3 mgrid((Nq + 255) / 256, heads, B);
-#define MCALL(HDV)                                                                                                                        \
-    hipLaunchKernelGGL(attention_mfma_kernel<HDV>, mgrid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)q, ldq, (const h16_t*)k, ldk, \
-                       (const h16_t*)v, ldv, (h16_t*)out, ldo, Nq, Nk, scale)
+            // head_dim <= 32: 2 x 16 queries per wave = 128 per workgroup at four waves per SIMD (config 5's 6400-key areas: 15.5 -> 13.5 ms per
+            // step against the 256-query form; eight-wave workgroups of 256 queries at the same occupancy: 15.9); wider heads: 4 x 16 queries per wave
+            const bool narrow = hd <= 32;
+            const int qpw = narrow ? 128 : 256;
+            const dim3 mgrid((Nq + qpw - 1) / qpw, heads, B);
+#define MARGS (const h16_t*)q, ldq, (const h16_t*)k, ldk, (const h16_t*)v, ldv, (h16_t*)out, ldo, Nq, Nk, scale
+#define MCALL(HDV)                                                                                                                               \
+    if (narrow) hipLaunchKernelGGL((attention_mfma_kernel<(HDV <= 32 ? HDV : 32), 2>), mgrid, dim3(256), 0, (hipStream_t)stream, MARGS);   \
+    else hipLaunchKernelGGL((attention_mfma_kernel<(HDV > 32 ? HDV : 64), 4>), mgrid, dim3(256), 0, (hipStream_t)stream, MARGS)
             HD_SWITCH(hd, MCALL)
 #undef MCALL
+#undef MARGS
             return ymk_launch_status();
         }
     }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void activation_kernel(void* x, int dt, int ld
 // the chip idle on a 200 MB map: each workgroup takes a run of pixels, computes ITS mean and centred sum of squares (two passes
 // over a slab that stays in L2), and the partials are combined with the exact pairwise update (Chan et al.) in chunk order —
 // deterministic, and as accurate as the reference's single two-pass evaluation.  nchunk == 1: final (mean, rstd) written directly.
-#define GN_MAX_CHUNKS 64
+#define GN_MAX_CHUNKS 256
 __device__ __forceinline__ void gn_emit(float mean, float m2, float n, int nchunk, float eps, float* stats, float* part, int slab, int chunk) {
     if (threadIdx.x != 0) return;
     if (nchunk == 1) {

@@ -703,7 +703,7 @@ def group_norm(x, groups: int, weight, bias, eps: float, act=False, out=None, ou
     ldr = _nhwc(residual)[4] if residual is not None else 0
     if residual is not None and residual.dtype != out.dtype:
         raise ValueError("group_norm: the residual has the output's dtype")
-    ws = torch.empty((B * groups * (2 + 3 * 64),), dtype=torch.float32, device=x.device)   # (mean, rstd) + 64 chunk partials (mean, M2, n) per slab
+    ws = torch.empty((B * groups * (2 + 3 * 256),), dtype=torch.float32, device=x.device)   # (mean, rstd) + 256 chunk partials (mean, M2, n) per slab
     check(lib.ymk_group_norm(DT[x.dtype], _p(x), ldx, _p(out), DT[out.dtype], ldy, _p(residual), ldr, B, H * W, Cc, groups,
                              _p(weight), _p(bias), _p(affine_rows), float(eps), _ACT[act], _p(ws), _stream()), "group_norm")
     return out

@@ -200,3 +200,46 @@ def test_copies_traces_and_foreign_nms_modes_take_the_reference_path(emu, monkey
     import ultralytics.utils.nms as ref_nms
 
     assert ref_nms.non_max_suppression.__module__ == "ultralytics.utils.nms"
+
+
+def test_backend_adapter_under_autobackend(emu, monkeypatch):
+    """The third plugin surface: `dropin.register_backend()` puts `YmkBackend` — a subclass of the reference's
+    PyTorchBackend — behind format "pt" of the reference's AutoBackend.  An un-hooked reference model handed to AutoBackend then runs
+    libymk (no enable() call), returns what the PyTorch backend returns, carries the same attributes, and unregister restores the map."""
+    refboot.boot()
+    refboot.stub_torchvision()
+    from ultralytics.nn.autobackend import AutoBackend
+    from ultralytics.nn.backends.pytorch import PyTorchBackend
+
+    from yolo_master_amd import dropin, ops
+    from yolo_master_amd.weights import synth_input
+
+    monkeypatch.setattr(ops, "device_ok", lambda t: True)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    x = synth_input(2, 64, 64, seed=7)
+    dev = torch.device("cpu")
+    ref_backend = AutoBackend(_yolo().model, device=dev, fp16=False, fuse=True, verbose=False).eval()   # the predictor's setup_model does the same (engine/predictor.py:397-400)
+    assert type(ref_backend.backend) is PyTorchBackend
+    with torch.inference_mode():
+        want = ref_backend(x)
+    want = want[0] if isinstance(want, (list, tuple)) else want
+    cls = dropin.register_backend()
+    try:
+        assert AutoBackend._BACKEND_MAP["pt"] is cls and issubclass(cls, PyTorchBackend)
+        before = emu.CALLS.get("conv2d_stem", 0)
+        ab = AutoBackend(_yolo().model, device=dev, fp16=False, fuse=True, verbose=False).eval()
+        assert type(ab.backend) is cls and ab.backend.ymk_enabled
+        assert (ab.backend.stride, ab.backend.channels, ab.backend.end2end) == (ref_backend.backend.stride, ref_backend.backend.channels, ref_backend.backend.end2end)
+        assert ab.backend.names == ref_backend.backend.names
+        with torch.inference_mode():
+            got = ab(x)
+        got = got[0] if isinstance(got, (list, tuple)) else got
+        assert emu.CALLS.get("conv2d_stem", 0) > before and ab.backend.stats()["calls"] >= 1, "the batch did not go through libymk"
+        assert got.shape == want.shape
+        err = (got.float() - want.float()).abs()
+        assert float(err[:, 4:].max()) <= 1e-4 and float(err[:, :4].max()) <= 1e-2
+        dropin.disable(ab.backend.model)
+    finally:
+        dropin.unregister_backend()
+    assert AutoBackend._BACKEND_MAP["pt"] is PyTorchBackend
+

@@ -14,7 +14,7 @@ def __getattr__(name):  # lazy: importing the package must not require torch/lib
         from .nn import tasks
 
         return getattr(tasks, name)
-    if name in ("enable", "disable"):   # drop-in hooks under the reference's own YOLO / DetectionModel objects
+    if name in ("enable", "disable", "register_backend", "unregister_backend", "backend_class"):   # drop-in hooks under the reference's own YOLO / DetectionModel / AutoBackend objects
         from . import dropin
 
         return getattr(dropin, name)

@@ -224,7 +224,8 @@ __device__ __forceinline__ void at_chunk(const T* __restrict__ sK, const T* __re
 #pragma unroll
     for (int tk = 0; tk < NTILE; ++tk)
 #pragma unroll
-        for (int f = 0; f < NF; ++f) kf[tk][f] = *reinterpret_cast<const u32x4*>(&sK[(c0 + tk * 16 + fi) * 32 + f * 16 + g * VEC]);
+        for (int f = 0; f < NF; ++f)   // 16-bit: the chunk's swizzled slot depends on (fi >> 2) only (c0 and tk * 16 are multiples of 16)
+            kf[tk][f] = *reinterpret_cast<const u32x4*>(&sK[(c0 + tk * 16 + fi) * 32 + f * 16 + (sizeof(T) == 2 ? (g ^ ((0 - (fi >> 2)) & 3)) : g) * VEC]);
 #pragma unroll
     for (int tk = 0; tk < NTILE; ++tk) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -314,7 +315,10 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     extern __shared__ __attribute__((aligned(16))) char at_smem[];
     const int Nk = (Na + 31) & ~31;            // keys incl. zero padding (the P V product walks 32 keys at a time)
     const int Nr = (Na + 15) & ~15;            // K rows kept: score tiles past them read into sVt and are masked to -inf
-    const int VP = Nk + VEC;                   // V^T row pitch (elements); columns Na..Nk-1 are zeros (p = 0 there)
+    // V^T row pitch (elements); columns Na..Nk-1 are zeros (p = 0 there).  16-bit: Nk + 4 = a pitch of 2 x odd dwords modulo 32, so the
+    // sixteen rows a ds_read2_b64 lane group reads (8 bytes each) cover the 32 banks once (Nk + 8 = 212 dwords at 400 keys put rows fi
+    // and fi + 8 on the same banks: half of the kernel's LDS cycles were conflict cycles, profiles/r03_sq_summary.txt)
+    const int VP = Nk + (sizeof(T) == 2 ? 4 : VEC);
     T* sK = reinterpret_cast<T*>(at_smem);     // [Nr][32]
     T* sVt = sK + (size_t)Nr * 32;             // [32][VP]        (Na = 400, bf16: 25,600 + 27,136 bytes -> 3 workgroups per CU)
 
@@ -342,7 +346,10 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const int i = i0 + t + l * AT_NT;
-            if (i < Nr * CPR) *reinterpret_cast<u32x4*>(&sK[(size_t)i * VEC]) = kreg[l];
+            // 16-bit rows are 64 bytes: chunk c of row r goes to slot c ^ ((-(r >> 2)) & 3), which spreads the sixteen rows of a
+            // ds_read_b128 lane group over the 64 banks (unswizzled, rows r and r + 4 shared their banks)
+            const int slot = sizeof(T) == 2 ? (i & ~3) + ((i & 3) ^ ((0 - (i >> 4)) & 3)) : i;
+            if (i < Nr * CPR) *reinterpret_cast<u32x4*>(&sK[(size_t)slot * VEC]) = kreg[l];
         }
     };
     // V^T (bf16) as (key, key + 1) words: a thread takes the same 8 channels of two consecutive keys and stores 8 dwords; the 32 lanes of
@@ -473,7 +480,7 @@ template <typename T, int WPE>
 static int launch_attn_resident(const T* qkv, int ldq, T* out, int ldo, int B, int N, int Na, int heads, int area, float scale,
                                 hipStream_t s) {
     const int Nk = (Na + 31) & ~31, Nr = (Na + 15) & ~15;
-    const size_t shm = ((size_t)Nr * 32 + (size_t)32 * (Nk + 16 / sizeof(T))) * sizeof(T);
+    const size_t shm = ((size_t)Nr * 32 + (size_t)32 * (Nk + (sizeof(T) == 2 ? 4 : 16 / sizeof(T)))) * sizeof(T);
     static YmkOncePerDevice attr_once;
     if (shm > 64 * 1024 && attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&area_attn_resident_kernel<T, WPE>),

@@ -337,18 +337,23 @@ static bool launch_conv1x1_ws(ConvArgs a, hipStream_t s) {
 // while the current tile is multiplied and stored.
 // ---------------------------------------------------------------------------
 // register allocation held to two waves per SIMD wherever the LDS footprint lets two workgroups share a CU
+// LDS row pitch for rows that sixteen lanes of a ds_read_b128 group read side by side (MFMA fragments: lane (fr, fc) reads row fr,
+// 16-byte chunk fc): the pitch must be 8 dwords modulo 16 for the group to cover the 64 banks once, i.e. row bytes + pad = 32 (mod 64).
+// (The 16-byte pad used before gave pitches of 20 / 36 dwords: rows r and r + 4 / r + 8 on the same banks — half of this kernel's
+// LDS cycles were conflict cycles, profiles/r03_sq_summary.txt.)
+constexpr int lds_row_pitch(int row_bytes) { return row_bytes + (32 - row_bytes % 64 + 64) % 64; }
 template <typename T, int CIN, int BCO, bool RES>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu((18 * 18 * (CIN * (int)sizeof(T) + 16) + BCO * (9 * CIN * (int)sizeof(T) + 16)) <= 80 * 1024 ? 2 : 1)))
+__attribute__((amdgpu_waves_per_eu((18 * 18 * lds_row_pitch(CIN * (int)sizeof(T)) + BCO * lds_row_pitch((9 * CIN + 4 * (16 / (int)sizeof(T)) - 1) / (4 * (16 / (int)sizeof(T))) * (4 * (16 / (int)sizeof(T))) * (int)sizeof(T))) <= 80 * 1024 ? 2 : 1)))
 void conv3x3_tile_kernel(ConvArgs a) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int CPP = CIN / VEC;                      // 16-byte chunks per pixel
-    constexpr int PSB = CIN * (int)sizeof(T) + 16;      // padded pixel stride (bytes)
+    constexpr int PSB = lds_row_pitch(CIN * (int)sizeof(T));      // padded pixel stride (bytes)
     constexpr int HT = 18;
     constexpr int KSUB = 4 * VEC;                       // K elements per MFMA group (64 bytes)
     constexpr bool PAIRED = CIN < KSUB;                 // bf16 Cin = 16: one MFMA group spans two taps
     constexpr int KTOT = (9 * CIN + KSUB - 1) / KSUB * KSUB;  // weight row length held in LDS (zero tail from Kpad)
-    constexpr int WRS = KTOT * (int)sizeof(T) + 16;     // padded weight row stride (bytes)
+    constexpr int WRS = lds_row_pitch(KTOT * (int)sizeof(T));     // padded weight row stride (bytes)
     constexpr int TM = BCO / 16;
     constexpr int NL = (HT * HT * CPP + 255) / 256;
     constexpr bool PRECISE = sizeof(T) == 4;

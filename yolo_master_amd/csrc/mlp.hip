@@ -35,7 +35,9 @@ struct MlpArgs {
 template <int HT, int CT, int NW, bool PERSIST>
 __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(MlpArgs a) {
     constexpr int C = CT * 16 * NW, Hd = HT * 16 * NW, NT = NW * 64;
-    constexpr int XP = C * 2 + 16, HP = Hd * 2 + 16;          // LDS row pitches in bytes (16-byte pad)
+    // LDS row pitches in bytes: row bytes (multiples of 256 here) + 32 = 8 dwords modulo 64, the pitch at which the sixteen rows of a
+    // ds_read_b128 lane group (MI355X_MICROARCH.md, LDS) cover the 64 banks exactly once; with a 16-byte pad rows r and r + 8 of a group met
+    constexpr int XP = C * 2 + 32, HP = Hd * 2 + 32;
     constexpr int CPR = C / 8;                                 // 16-byte chunks per token row
     constexpr int NX = (MLP_BM * CPR + NT - 1) / NT;           // staging loads per thread
     static_assert((MLP_BM * CPR) % NT == 0, "token tile is a whole number of passes");

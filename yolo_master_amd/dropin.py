@@ -237,3 +237,60 @@ def _unpatch_process():
     if "val_cls" in _PATCHED:
         _PATCHED.pop("val_cls")._process_batch = _PATCHED.pop("process_batch")
         _PATCHED.pop("_match_calls", None)
+
+
+# ----------------------------------------------------------------------------------------------- the third surface: an inference backend
+def backend_class():
+    """`YmkBackend`, a subclass of the reference's `PyTorchBackend` (`ultralytics/nn/backends/pytorch.py:16`, base class
+    `nn/backends/base.py:41-140`), built on first use because the base class lives in the reference package.
+
+    `load_model` does what the reference's does — accept an `nn.Module` or a `.pt` path, fuse, `.half()` / `.float()`, freeze — with
+    one step in front: libymk is hooked under the model (`enable`) while its Conv + BatchNorm pairs are still separate, because the
+    packed copy is folded from the unfused parameters.  `forward` is inherited: `self.model(im, augment=, visualize=, embed=)` reaches the
+    hooked `_predict_once` for plain eval batches on the GPU and the reference's own graph walk for everything else.  `fp16=True`
+    selects the fp16 build of the library (the reference's `half=True`).  Attributes (`stride`, `names`, `channels`, `end2end`,
+    `kpt_shape`) are set by the inherited code from the reference model, as for the PyTorch backend."""
+    if "backend_cls" in _PATCHED:
+        return _PATCHED["backend_cls"]
+    from ultralytics.nn.backends.pytorch import PyTorchBackend
+
+    class YmkBackend(PyTorchBackend):
+        def load_model(self, weight):
+            if not isinstance(weight, torch.nn.Module):
+                from ultralytics.nn.tasks import load_checkpoint
+
+                weight, _ = load_checkpoint(weight, device=self.device, fuse=False)
+            self.ymk_enabled = False
+            try:
+                enable(weight, dtype=torch.float16 if (self.fp16 and ops.HAS_F16) else None)
+                self.ymk_enabled = True
+            except (KeyError, ValueError, TypeError, NotImplementedError, RuntimeError) as e:   # a model this package does not build (or an already fused one): plain PyTorch backend
+                self.ymk_error = f"{type(e).__name__}: {e}"
+            super().load_model(weight)
+
+        def stats(self):
+            return stats(self.model)
+
+    _PATCHED["backend_cls"] = YmkBackend
+    return YmkBackend
+
+
+def register_backend():
+    """Make the reference's `AutoBackend` (`nn/autobackend.py:143-222`) construct `YmkBackend` for format "pt" (an `nn.Module` or a
+    `.pt` checkpoint): `predict()` / `val()` / `AutoBackend(model, device, fp16=...)` then run libymk without an `enable()` call.
+    Returns the class.  `unregister_backend()` restores the map."""
+    from ultralytics.nn.autobackend import AutoBackend
+
+    cls = backend_class()
+    if "backend_prev" not in _PATCHED:
+        _PATCHED["backend_prev"] = AutoBackend._BACKEND_MAP["pt"]
+    AutoBackend._BACKEND_MAP["pt"] = cls
+    return cls
+
+
+def unregister_backend():
+    if "backend_prev" in _PATCHED:
+        from ultralytics.nn.autobackend import AutoBackend
+
+        AutoBackend._BACKEND_MAP["pt"] = _PATCHED.pop("backend_prev")
+

@@ -1,12 +1,10 @@
 /* libymk — C-ABI of the config-5 rows (MoA / MoT / gated MoE), SURVEY.md §8 rows a11 / a12 and §8(f) rank 1.
  *
- * STATUS: first implementation (fp32 arithmetic on the VALU, 16-byte vector memory paths where operands allow, one
- * token / query per lane in the attention forms, no fusion yet).  Written after the round-1 GPU budget was spent: the
- * kernels compile for gfx950 and their LOGIC is verified on the CPU lane emulator (tests/hostemu,
- * tests/test_hostemu_mixture.py: every entry point in fp32 / bf16, the reference's module fixtures, the whole config-5
- * detector), but they have NOT RUN on hardware yet.  The Python wrappers therefore keep them switched off unless
- * YMK_EXPERIMENTAL=1 is set (yolo_master_amd/ops.py), and their GPU parity tests (tests/test_gpu_mixture.py) are the
- * first GPU job of the next round.  Nothing of the validated v0 path calls into this file.
+ * STATUS: validated on MI355X since round 2 (tests/test_gpu_mixture.py: every entry point in fp32 / bf16 / fp16 against the
+ * reference's module fixtures and the whole config-5 detector at N and at L scale, 2 x 1280 x 1280) and on the CPU lane emulator
+ * (tests/test_hostemu_mixture.py).  Element-wise and normalisation forms: fp32 arithmetic on 16-byte vector memory paths, chunked
+ * exact statistics; the softmax attention forms (ymk_attention, ymk_window_attention) run on the matrix cores for 16-bit inputs
+ * (csrc/mixattn.hip); random-feature and deformable attention are VALU kernels.
  *
  * Conventions as in ymk.h: NHWC views with pixel strides (elements), activations YMK_F32 / YMK_BF16, statistics /
  * gates / router tensors fp32, `stream` a hipStream_t, return 0 or a negative YMK_E_* code, no allocation, no sync.

@@ -1,15 +1,16 @@
-/* libymk — opt-in entry points that are NOT part of the validated surface of ymk.h yet.
+/* libymk — entry points next to ymk.h: the LDS-DMA convolution core under its own names, and the rows right after / beside the hot path.
  *
- * (1) ymk_conv2d_glds: the next tiled implicit-GEMM core (csrc/conv_glds.hip): 256-pixel x 64/128-cout
- * tiles on 8 waves, both operands staged into LDS by global_load_lds with a source-side swizzle, 2- or 3-stage k-loop,
- * XCD-aware tile order.  Same arguments and result as ymk_conv2d (ymk.h) plus `two_stage` (0 = three LDS stages with a
- * counted vmcnt, 1 = two stages with a plain barrier); bf16 only, Cin % 64 == 0, Cout % 64 == 0, otherwise YMK_E_BADARG.
- * ymk_conv2d itself dispatches to it only when the environment variable YMK_ENABLE has bit 0 set (bit 1 = two_stage):
- * its logic is verified on the CPU lane emulator (tests/test_hostemu_conv.py), its speed has not been measured.
- * (2) The rows right after / beside the hot path: box rescaling, the Segment head's layout
- * kernels and process_mask.  Each is pinned to golden vectors generated from the real reference and verified on the CPU lane
- * emulator (tests/test_hostemu_post.py); the Python wrappers (yolo_master_amd/postprocess.py, ops.py) refuse to call them
- * unless YMK_EXPERIMENTAL=1 until tests/test_gpu_next.py has passed on an MI355X.
+ * (1) ymk_conv2d_glds / ymk_conv1x1_cat2_glds / ymk_expert_conv_glds: the tiled implicit-GEMM core (csrc/conv_glds.hip): 64-256 couts x
+ * 128-512 pixels per 8-wave workgroup, both operands staged into LDS by `buffer_load_dwordx4 ... lds` through raw buffer resources
+ * (source-side swizzle; taps outside the image are out-of-range lanes: zeros), 2- or 3-stage k-loop, XCD-aware tile order.  Same
+ * arguments and result as ymk_conv2d (ymk.h) plus `two_stage` (bit 0: 0 = three LDS stages with a counted vmcnt, 1 = two stages with
+ * a plain barrier; bits 8-11 / 12-21: a forced tile shape for tests and A/B tools); 16-bit only, Cin % 64 == 0, Cout % 64 == 0,
+ * operands below 2 GiB, otherwise YMK_E_BADARG.  Since round 2 ymk_conv2d / ymk_conv1x1_cat2 dispatch here by default for every
+ * shape in that domain (YMK_DISABLE bits select the older cores); validated on MI355X (tests/test_gpu_next.py) and on the CPU lane
+ * emulator (tests/test_hostemu_conv.py); per-shape timings in profiles/r02_glds_tile_ab.txt, profiles/r03_glds_*.txt.
+ * (2) The rows right after / beside the hot path: box rescaling, the Segment head's layout kernels and
+ * process_mask.  Each is pinned to golden vectors generated from the real reference, verified on the CPU lane emulator
+ * (tests/test_hostemu_post.py) and on MI355X (tests/test_gpu_next.py); yolo_master_amd/postprocess.py and the drop-in hooks call them.
  */
 #ifndef YMK_NEXT_H_
 #define YMK_NEXT_H_
@@ -21,7 +22,7 @@ int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void* w, const 
                     int32_t two_stage, void* stream);
 
 /* Virtual-concatenation form of the same core: arguments and result of ymk_conv1x1_cat2 (ymk.h) + two_stage; bf16, C1 and
- * Cin - C1 multiples of 64, Cout % 64 == 0, otherwise YMK_E_BADARG.  Same opt-in switch. */
+ * Cin - C1 multiples of 64, Cout % 64 == 0, otherwise YMK_E_BADARG.  Same dispatch. */
 int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int32_t C1, int32_t ldx1, int32_t upsample1, const void* x2,
                           int32_t ldx2, const void* w, const float* bias, void* y, int32_t two_stage, void* stream);
 
@@ -37,7 +38,7 @@ int ymk_expert_conv_glds(const ymk_conv_desc* d, const void* x, const void* w, c
  * dets fp32 [B][max_det] rows of `ld` >= 4 floats (x1, y1, x2, y2, ...); counts int32 [B] valid rows per image (NULL = all);
  * params fp32 [B][5] = (gain, pad_x, pad_y, w0, h0) per image, computed by the host exactly as the reference does (Python
  * doubles, round-half-even; gain rounded to fp32).  padding / xywh as in the reference.  Bit-exact against the reference's
- * golden vectors on the CPU lane emulator (tests/test_hostemu_post.py); opt-in until it has run on hardware. */
+ * golden vectors on the CPU lane emulator (tests/test_hostemu_post.py) and on MI355X (tests/test_gpu_next.py). */
 int ymk_scale_boxes(float* dets, int32_t ld, const int32_t* counts, const float* params, int32_t B, int32_t max_det,
                     int32_t padding, int32_t xywh, void* stream);
 /* Segment head pieces.  ymk_pixel_shuffle2: depth-to-space that turns the 4*C-channel output of a 1x1

@@ -19,3 +19,18 @@ cd $R
 cp gpurun_out/${TAG}_pmc_FETCH_SIZE.json gpurun_out/${TAG}_pmc_WRITE_SIZE.json gpurun_out/${TAG}_sq_1.json gpurun_out/${TAG}_sq_2.json profiles/ 2>/dev/null
 python bench.py --cfg yolo-master-moa-mot.yaml --scale l --imgsz 1280 --batch 16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_cfg5.json 2>/dev/null
 python bench.py --steps 30 --warmup 10 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench: exit $?"; head -c 300 gpurun_out/${TAG}_bench.json
+echo
+python bench.py --steps 30 --warmup 10 --dtype f16 --no-cpu-baseline > gpurun_out/${TAG}_bench_f16.json 2>/dev/null; echo "bench f16: exit $?"
+python bench.py --steps 10 --warmup 3 --dtype f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_f32.json 2>/dev/null; echo "bench f32: exit $?"
+YMK_BENCH_CALLS=gpurun_out/${TAG}_calls.log python bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+YMK_BENCH_CALLS=gpurun_out/${TAG}_cfg5_calls.log python bench.py --cfg yolo-master-moa-mot.yaml --scale l --imgsz 1280 --batch 16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python tools/serve_bench.py > gpurun_out/${TAG}_serve.json 2> gpurun_out/${TAG}_serve.err; echo "serve: exit $?"; head -c 400 gpurun_out/${TAG}_serve.json
+python - <<PY
+import json
+for n in ("bench", "bench_f16", "bench_f32", "bench_cfg5"):
+    try:
+        r = json.loads(open("gpurun_out/${TAG}_%s.json" % n).read())
+        print(n, r["value"], r["ms_per_step"], r["roofline"]["kernel"], r["roofline"]["frac"], r["roofline"].get("traffic"))
+    except Exception as e:
+        print(n, "unreadable", e)
+PY

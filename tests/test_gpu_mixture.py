@@ -278,6 +278,43 @@ def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
         assert float(np.abs(m.last_route["weights"].cpu().numpy().reshape(B, -1) - z["weights"]).max()) <= 1e-5, "routing weights"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fam,name,ctor", [
+    ("moa", "exact", ("MoABlock", (48,), dict(num_heads=6))), ("moa", "hd21", ("MoABlock", (128,), dict(num_heads=6))),
+    ("moa", "kvcap", ("MoABlock", (48,), dict(num_heads=6, regional_max_kv_tokens=64, shortcut=False))),
+    ("mot", "dense", ("MoTBlock", (48,), dict(num_heads=6, top_k=3))), ("mot", "top2", ("MoTBlock", (48,), dict(num_heads=6))),
+    ("mot", "shift", ("MoTBlock", (48,), dict(num_heads=6, window_shift=True, local_attn_window=7))),
+])
+def test_modules_16bit_vs_reference_golden(fam, name, ctor, dtype, golden_dir):
+    """The 16-bit forms of the MoA / MoT blocks (matrix-core attention, layer-scale factors folded into the convolution that feeds each
+    residual — nn/mixture.py _fold_ls — which fp32 does not do) against the REAL reference's fp32 outputs.  Per-token routing can
+    flip on near-ties in 16 bits (a flipped token differs by O(1)), so the bars are the 99th percentile and the mean of the error."""
+    import warnings
+
+    from yolo_master_amd import ops
+    from yolo_master_amd.nn import mixture
+    from yolo_master_amd.nn.modules import YmkModule
+
+    if dtype == torch.float16 and not ops.HAS_F16:
+        pytest.skip("libymk_f16.so not built")
+    z, sd = _load(golden_dir, fam, name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = _prep(getattr(mixture, ctor[0])(*ctor[1], **ctor[2]), sd)
+    for sub in m.modules():
+        if isinstance(sub, YmkModule):
+            sub.ymk_dtype = dtype
+    with torch.inference_mode():
+        got = m(torch.from_numpy(z["x"]).to(DEV)).float().cpu()
+    ref = torch.from_numpy(z["y"])
+    err = (got - ref).abs().reshape(-1)
+    scale = max(1.0, float(ref.abs().max()))
+    tol = (1e-2 if dtype == torch.bfloat16 else 2e-3) * scale
+    q99, mean = float(torch.quantile(err, 0.99)), float(err.mean())
+    print(f"{fam}_{name} {dtype}: |d| mean {mean:.2e} q99 {q99:.2e} max {float(err.max()):.2e} (scale {scale:.2f})")
+    assert q99 <= tol and mean <= tol / 4, f"{fam}_{name} {dtype}: mean {mean:.3e}, q99 {q99:.3e} > {tol:.3e}"
+
+
 @pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06", "v01", "v03"])
 def test_config5_model_vs_reference_golden(tag, golden_dir):
     import json

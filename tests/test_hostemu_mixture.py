@@ -48,6 +48,17 @@ def test_kernels_modules_vs_reference_golden(T, fam, name, ctor, golden_dir):
         T.test_modules_vs_reference_golden(fam, name, ctor, golden_dir)
 
 
+@pytest.mark.parametrize("fam,name,ctor", [
+    ("moa", "exact", ("MoABlock", (48,), dict(num_heads=6))), ("mot", "dense", ("MoTBlock", (48,), dict(num_heads=6, top_k=3))),
+    ("mot", "shift", ("MoTBlock", (48,), dict(num_heads=6, window_shift=True, local_attn_window=7))),
+])
+def test_kernels_modules_bf16_vs_reference_golden(T, fam, name, ctor, golden_dir):
+    """The 16-bit module forms (folded layer scales, matrix-core attention) through the host-compiled kernels."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        T.test_modules_16bit_vs_reference_golden(fam, name, ctor, torch.bfloat16, golden_dir)
+
+
 @pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v01", "v03"])
 def test_kernels_config5_model_vs_reference_golden(T, tag, golden_dir):
     T.test_config5_model_vs_reference_golden(tag, golden_dir)

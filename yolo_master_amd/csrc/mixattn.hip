@@ -484,14 +484,16 @@ __device__ __forceinline__ float phi(float t, float sc) { return fminf(fmaxf(t *
 #define LINATTN_CHUNK 512
 __global__ __launch_bounds__(256) void linattn_kv_kernel(int dt, const void* k, int ldk, const void* v, int ldv_, const float* rf, int nb,
                                                           int Ntot, int hd, float* ws) {
-    __shared__ float sphi[64][65], svv[64][65], srf[64][65];
+    // K is staged next to V (it was read element by element from global memory inside the feature dot product: 64 x nb x hd scalar
+    // loads per 64 tokens); the random-feature matrix is kept transposed so that lanes of consecutive features read consecutive words
+    __shared__ float sphi[64][64], svv[64][64], skk[64][64], srfT[64][64];
     const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x, chunk = blockIdx.z, nchunk = gridDim.z;
     const int per = nb * hd + nb;
     float* kv = ws + (((int64_t)b * heads + h) * (nchunk + 1) + 1 + chunk) * per;   // slot 0 of an (image, head): the reduced result
     float* ksum = kv + nb * hd;
     const int N = min(Ntot, (chunk + 1) * LINATTN_CHUNK);
     const float sc = 1.0f / sqrtf((float)nb);
-    for (int i = threadIdx.x; i < nb * hd; i += 256) srf[i / hd][i % hd] = rf[i];
+    for (int i = threadIdx.x; i < nb * hd; i += 256) srfT[i % hd][i / hd] = rf[i];
     // each thread owns up to 16 (f, d) pairs and, for t < nb, one ksum entry
     float acc[16], ks = 0.f;
 #pragma unroll
@@ -499,11 +501,15 @@ __global__ __launch_bounds__(256) void linattn_kv_kernel(int dt, const void* k, 
     for (int n0 = chunk * LINATTN_CHUNK; n0 < N; n0 += 64) {
         const int nt = min(64, N - n0);
         __syncthreads();
-        for (int i = threadIdx.x; i < nt * hd; i += 256) svv[i / hd][i % hd] = ldv(v, dt, ((int64_t)b * Ntot + n0 + i / hd) * ldv_ + h * hd + i % hd);
+        for (int i = threadIdx.x; i < nt * hd; i += 256) {
+            svv[i / hd][i % hd] = ldv(v, dt, ((int64_t)b * Ntot + n0 + i / hd) * ldv_ + h * hd + i % hd);
+            skk[i / hd][i % hd] = ldv(k, dt, ((int64_t)b * Ntot + n0 + i / hd) * ldk + h * hd + i % hd);
+        }
+        __syncthreads();
         for (int i = threadIdx.x; i < nt * nb; i += 256) {
             const int r = i / nb, f = i % nb;
             float s = 0.f;
-            for (int d = 0; d < hd; ++d) s += ldv(k, dt, ((int64_t)b * Ntot + n0 + r) * ldk + h * hd + d) * srf[f][d];
+            for (int d = 0; d < hd; ++d) s += skk[r][d] * srfT[d][f];   // same order of the terms as before
             sphi[r][f] = phi(s, sc);
         }
         __syncthreads();

@@ -115,6 +115,21 @@ def _flat(p, device):
     return p.detach().float().reshape(-1).to(device).contiguous()
 
 
+def _fold_ls(dtype) -> bool:
+    """x + ls * conv(h): in the 16-bit modes the layer-scale factor is folded into the (activation-free) convolution's weights and the
+    skip is that convolution's residual operand — one pass over the map less per residual (config 5: 76 launches, 1.7 ms per step).
+    fp32 is the exact-parity configuration: it keeps the reference's order of operations, (conv(h)) * ls + x, so that NMS decisions
+    on near-equal scores stay where the reference's are."""
+    return dtype != torch.float32
+
+
+def _ls_conv(h, pk, key, ls_key, res, out=None):
+    """res + ls * conv(h) with pk[key] = (weights, bias): folded form when pk[ls_key] is None, scale-and-add pass otherwise."""
+    if pk.get(ls_key) is None:
+        return ops.conv2d(h, *pk[key], 1, 1, False, residual=res, out=out)
+    return ops.scale_residual(ops.conv2d(h, *pk[key], 1, 1, False), pk[ls_key], res, out=out)
+
+
 # ----------------------------------------------------------------------------------------- gated MoE
 class DualStreamGateRouter(nn.Module):
     """moe/gated.py:82-122."""
@@ -971,12 +986,14 @@ class MoABlock(YmkModule):
             "a_qkv": _pack_conv(gh.qkv, dtype, device, rows=m3), "a_proj": _pack_conv(gh.proj, dtype, device, cols=m1),
             "a_norm": _pack_norm(gh.norm, device),
             "rf": _remap(gh._rf_matrix.detach().float().to(device), None if hdp == hd else list(range(hd)) + [-1] * (hdp - hd), 1).contiguous(),
-            "ls_attn": self.ls_attn.detach().float().reshape(-1).to(device).contiguous(),
-            "ls_ffn": self.ls_ffn.detach().float().reshape(-1).to(device).contiguous(),
         }
-        if not self.shortcut:   # ls * f(x) without a residual: the factor folds into the last (activation-free) conv
-            pk["fusion_ls"] = _pack_bn_conv(self.fusion, dtype, device, self.ls_attn)
-            pk["ffn1_ls"] = _pack_bn_conv(self.ffn[1], dtype, device, self.ls_ffn)
+        # ls * f(x) (+ x): without the shortcut the factor always folds into the last (activation-free) convolution; with it, in the
+        # 16-bit modes (_fold_ls)
+        fold = (not self.shortcut) or _fold_ls(dtype)
+        pk["fusion_ls"] = _pack_bn_conv(self.fusion, dtype, device, self.ls_attn if fold else None)
+        pk["ffn1_ls"] = _pack_bn_conv(self.ffn[1], dtype, device, self.ls_ffn if fold else None)
+        pk["ls_attn"] = None if fold else _flat(self.ls_attn, device)
+        pk["ls_ffn"] = None if fold else _flat(self.ls_ffn, device)
         return pk
 
     def _route(self, x, pk):
@@ -1034,12 +1051,12 @@ class MoABlock(YmkModule):
             o = ops.linear_attention(q, k, v, pk["rf"], nh, hd)
         glob = self._head_tail(o, pk["a_proj"], pk["a_norm"])
         mixed = ops.weighted_sum(probs, [local, regional, glob])
-        if self.shortcut:   # x + ls_attn * fusion(mixed); then + ls_ffn * ffn(.) (moa/block.py:264-278)
-            x1 = ops.scale_residual(self.fusion._run(mixed), pk["ls_attn"], x)
-            f = self.ffn[1]._run(self.ffn[0]._run(x1))
-            return ops.scale_residual(f, pk["ls_ffn"], x1, out=out)
-        x1 = ops.conv2d(mixed, *pk["fusion_ls"], 1, 1, False)
-        return ops.conv2d(self.ffn[0]._run(x1), *pk["ffn1_ls"], 1, 1, False, out=out)
+        # x + ls_attn * fusion(mixed); then + ls_ffn * ffn(.) (moa/block.py:264-278); without the shortcut the same without the skips
+        if not self.shortcut:
+            x1 = ops.conv2d(mixed, *pk["fusion_ls"], 1, 1, False)
+            return ops.conv2d(self.ffn[0]._run(x1), *pk["ffn1_ls"], 1, 1, False, out=out)
+        x1 = _ls_conv(mixed, pk, "fusion_ls", "ls_attn", x)
+        return _ls_conv(self.ffn[0]._run(x1), pk, "ffn1_ls", "ls_ffn", x1, out=out)
 
 
 class C2fMoA(YmkModule):
@@ -1100,7 +1117,9 @@ class _LocalConvTransformerExpert(nn.Module):
     def pack(self, dtype, device):
         return {"n1": _pack_norm(self.norm1, device), "n2": _pack_norm(self.norm2, device), "dw": _pack_dw(self.dw_mix, dtype, device),
                 "qkv": _pack_conv(self.qkv, dtype, device), "pe": _pack_dw(self.pe, dtype, device),
-                "proj": _pack_conv(self.proj, dtype, device), "ls1": _flat(self.ls1, device), "ls2": _flat(self.ls2, device)}
+                "proj": _pack_conv(self.proj, dtype, device, scale=self.ls1 if _fold_ls(dtype) else None),
+                "ffn_out": _pack_bn_conv(self.ffn_out, dtype, device, self.ls2 if _fold_ls(dtype) else None),
+                "ls1": None if _fold_ls(dtype) else _flat(self.ls1, device), "ls2": None if _fold_ls(dtype) else _flat(self.ls2, device)}
 
     def run(self, x, pk):
         """GN -> DW3x3 -> 1x1 qkv, v += DW7x7(v), attention (whole map, or local windows), proj, layer-scale residual;
@@ -1122,10 +1141,10 @@ class _LocalConvTransformerExpert(nn.Module):
             o = ops.area_attn(qkv, nh, 1)
         else:
             o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], v, nh, hd, hd ** -0.5)
-        x1 = ops.scale_residual(ops.conv2d(o, *pk["proj"], 1, 1, False), pk["ls1"], x)
+        x1 = _ls_conv(o, pk, "proj", "ls1", x)
         xn = ops.group_norm(x1, g, *pk["n2"], 1e-5)
         glu = ops.eltwise_mul(self.ffn_gate[0]._run(xn), self.ffn_val._run(xn), act_a="sigmoid")
-        return ops.scale_residual(self.ffn_out._run(glu), pk["ls2"], x1)
+        return _ls_conv(glu, pk, "ffn_out", "ls2", x1)
 
 
 def _mlp(dim, hid, dropout):
@@ -1135,7 +1154,7 @@ def _mlp(dim, hid, dropout):
 def _run_token_ffn(x1, ffn, norm2, ls2, pk):
     """LayerNorm -> Linear -> GELU -> Linear with layer scale (mot/experts.py:318-325, 486-493)."""
     h = ops.conv2d_act(ops.layer_norm(x1, *pk["n2"], 1e-5), *pk["f0"], 1, 1, "gelu")
-    return ops.scale_residual(ops.conv2d(h, *pk["f3"], 1, 1, False), pk["ls2"], x1)
+    return _ls_conv(h, pk, "f3", "ls2", x1)
 
 
 class _WindowTransformerExpert(nn.Module):
@@ -1158,10 +1177,10 @@ class _WindowTransformerExpert(nn.Module):
         pad = (self.qkv.weight.detach().float() @ self.norm1.bias.detach().float()).to(device)
         C = self.norm1.bias.numel()
         return {"n1": _pack_norm(self.norm1, device), "n2": _pack_norm(self.norm2, device),
-                "qkv": _pack_conv(self.qkv, dtype, device), "proj": _pack_conv(self.proj, dtype, device),
+                "qkv": _pack_conv(self.qkv, dtype, device), "proj": _pack_conv(self.proj, dtype, device, scale=self.ls1 if _fold_ls(dtype) else None),
                 "pad": tuple(pad[i * C:(i + 1) * C].contiguous() for i in range(3)),
-                "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device),
-                "ls1": _flat(self.ls1, device), "ls2": _flat(self.ls2, device)}
+                "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device, scale=self.ls2 if _fold_ls(dtype) else None),
+                "ls1": None if _fold_ls(dtype) else _flat(self.ls1, device), "ls2": None if _fold_ls(dtype) else _flat(self.ls2, device)}
 
     def run(self, x, pk):
         C = x.shape[-1]
@@ -1169,7 +1188,7 @@ class _WindowTransformerExpert(nn.Module):
         qkv = ops.conv2d(ops.layer_norm(x, *pk["n1"], 1e-5), *pk["qkv"], 1, 1, False)
         a = ops.window_attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], nh, hd, hd ** -0.5, self.win,
                                  shift=self.shift_size, pad_q=pk["pad"][0], pad_k=pk["pad"][1], pad_v=pk["pad"][2])
-        x1 = ops.scale_residual(ops.conv2d(a, *pk["proj"], 1, 1, False), pk["ls1"], x)
+        x1 = _ls_conv(a, pk, "proj", "ls1", x)
         return _run_token_ffn(x1, self.ffn, self.norm2, self.ls2, pk)
 
 
@@ -1194,9 +1213,9 @@ class _DeformableTransformerExpert(nn.Module):
                 "q": _pack_conv(self.q_proj, dtype, device), "v": _pack_conv(self.v_proj, dtype, device),
                 "off": _pack_conv(self.offset_proj, dtype, device, pad_cout_to=_ceil(self.offset_proj.out_features, 4)),
                 "aw": _pack_conv(self.attn_proj, dtype, device, pad_cout_to=_ceil(self.attn_proj.out_features, 4)),
-                "out": _pack_conv(self.out_proj, dtype, device),
-                "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device),
-                "ls1": _flat(self.ls1, device), "ls2": _flat(self.ls2, device)}
+                "out": _pack_conv(self.out_proj, dtype, device, scale=self.ls1 if _fold_ls(dtype) else None),
+                "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device, scale=self.ls2 if _fold_ls(dtype) else None),
+                "ls1": None if _fold_ls(dtype) else _flat(self.ls1, device), "ls2": None if _fold_ls(dtype) else _flat(self.ls2, device)}
 
     def run(self, x, pk):
         C = x.shape[-1]
@@ -1206,7 +1225,7 @@ class _DeformableTransformerExpert(nn.Module):
         off = ops.conv2d(q, *pk["off"], 1, 1, False, out_dtype=torch.float32)[..., : nh * npnt * 2]   # sampling coordinates stay fp32
         aw = ops.conv2d(q, *pk["aw"], 1, 1, False, out_dtype=torch.float32)[..., : nh * npnt]
         o = ops.deform_attention(ops.conv2d(xn, *pk["v"], 1, 1, False), off, aw, nh, hd, npnt, self.align_corners)
-        x1 = ops.scale_residual(ops.conv2d(o, *pk["out"], 1, 1, False), pk["ls1"], x)
+        x1 = _ls_conv(o, pk, "out", "ls1", x)
         return _run_token_ffn(x1, self.ffn, self.norm2, self.ls2, pk)
 
 

@@ -186,6 +186,19 @@ def test_attention_family(dtype):
         qd, kd = qkv.to(DEV), kv.to(DEV)
         _cmp(ops.attention(qd[..., :c], kd[..., :c], kd[..., c:], heads, hd, hd ** -0.5),
              emu_ops.attention(qkv[..., :c], kv[..., :c], kv[..., c:], heads, hd, hd ** -0.5), dtype, f"attention h{heads} d{hd} {H}x{W}/{Hk}x{Wk}")
+    if dtype != torch.float32:
+        # what the MoT full-attention expert relies on for 16-bit maps of more than 1024 tokens (nn/mixture.py): whole-map attention through the
+        # [Q | K | V] area-attention entry point and through ymk_attention on separate q / k / v views are the same kernel — identical results
+        heads, hd, H, W = 2, 32, 36, 30
+        c = heads * hd
+        qkv = _rnd(1, H, W, 3 * c, seed=47, dtype=dtype).to(DEV)
+        v_sep = qkv[..., 2 * c:].clone()
+        a = ops.area_attn(qkv, heads, 1)
+        b = ops.attention(qkv[..., :c], qkv[..., c:2 * c], v_sep, heads, hd, hd ** -0.5)
+        if DEV == "cpu":   # lane-emulator run: area_attn is the torch restatement of the v0 contract there, not the kernel
+            _cmp(b, a, dtype, "attention on separate views vs area attention, 1080 keys")
+        else:
+            assert torch.equal(a, b), "area_attn (1080 keys) and attention on separate views differ"
     for heads, hd, (H, W), win, shift, pad in ((2, 16, (14, 18), 7, 0, False), (6, 8, (14, 18), 7, 3, True), (6, 8, (16, 20), 7, 3, True),
                                                (1, 16, (5, 4), 4, 0, False), (2, 32, (7, 7), 7, 0, False), (6, 8, (9, 11), 7, 0, True),
                                                # matrix-core kernel (16-bit, head_dim 16 / 32 / 64): rolled grid, pad vectors as keys, full 64-token windows

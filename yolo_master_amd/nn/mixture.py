@@ -1133,10 +1133,11 @@ class _LocalConvTransformerExpert(nn.Module):
         lws = self.local_window_size
         if lws > 0 and H * W > lws * lws:
             o = ops.window_attention(qkv[..., :C], qkv[..., C:2 * C], v, nh, hd, hd ** -0.5, lws)
-        elif hd == 32:
-            # whole-map attention with 32-wide heads (the L-scale MoT blocks of BASELINE config 5: 6400 tokens at 1280 px,
-            # the dominant cost of the model) is exactly what the MFMA area-attention kernel of the A2C2f blocks computes:
-            # put v + pe(v) back into the V slice of the [Q | K | V] buffer (stream-ordered after the stencil) and reuse it
+        elif hd == 32 and (H * W <= 1024 or x.dtype == torch.float32):
+            # whole-map attention with 32-wide heads is what the area-attention kernels of the A2C2f blocks compute: put v + pe(v) back into
+            # the V slice of the [Q | K | V] buffer (stream-ordered after the stencil) and reuse them.  16-bit maps of more than 1024
+            # tokens (the L-scale MoT blocks of BASELINE config 5: 6400 tokens at 1280 px) go to the streaming matrix-core kernel below,
+            # which is what area_attn itself routes them to and takes q, k, v as separate views: no copy
             ops.copy_channels(v, qkv[..., 2 * C:])
             o = ops.area_attn(qkv, nh, 1)
         else:

@@ -334,11 +334,31 @@ class C3(YmkModule):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, k=((1, 1), (3, 3)), e=1.0) for _ in range(n)))
 
+    def _pack(self, dtype, device):
+        """cv1 and cv2 are two 1x1 convolutions (+ BN + SiLU) of the same input: packed as ONE convolution with 2 c_ outputs — one launch
+        and one read of x instead of two (the head's four C3k blocks of the S detector)."""
+        (w1, b1), (w2, b2) = self.cv1._folded(), self.cv2._folded()
+        w, b = torch.cat([w1, w2], 0).to(device), torch.cat([b1, b2], 0).to(device)
+        return {"w": ops.pack_conv_weight(w, dtype), "b": b.contiguous()}
+
+    def _pair_mergeable(self):
+        a, b = self.cv1, self.cv2
+        return (a.conv.kernel_size == b.conv.kernel_size == (1, 1) and a.conv.stride == b.conv.stride == (1, 1)
+                and a.conv.groups == b.conv.groups == 1 and _is_silu(a.act) and _is_silu(b.act) and a.cout_perm is None and b.cout_perm is None)
+
     def _run(self, x, out=None):
         B, H, W, _ = x.shape
         c_ = self.cv1.conv.out_channels
         cat = ops.new_act(B, H, W, 2 * c_, x.dtype, x.device)
         n = len(self.m)
+        if n > 0 and self._pair_mergeable():
+            self.ymk_dtype = self.cv1.ymk_dtype
+            pk = self._packed(x.device)
+            ops.conv2d(x, pk["w"], pk["b"], 1, 1, True, out=cat)     # cat = [cv1(x) | cv2(x)]; the last block overwrites the first half
+            h = cat[..., :c_]
+            for j, blk in enumerate(self.m):
+                h = blk._run(h, out=cat[..., :c_] if j == n - 1 else None)
+            return self.cv3._run(cat, out=out)
         h = self.cv1._run(x, out=cat[..., :c_] if n == 0 else None)
         for j, blk in enumerate(self.m):
             h = blk._run(h, out=cat[..., :c_] if j == n - 1 else None)

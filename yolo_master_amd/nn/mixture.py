@@ -111,6 +111,25 @@ def _pack_bn_conv(m: Conv, dtype, device, scale=None):
     return ops.pack_conv_weight(w, dtype), b.contiguous()
 
 
+def _pack_conv_pair(a, b, dtype, device, pad_cout_to=None):
+    """Two bare nn.Linear / 1x1 nn.Conv2d of the same input as ONE convolution, outputs side by side ([a | b], then zero padding)."""
+    import types
+
+    bias = None
+    if a.bias is not None or b.bias is not None:
+        za = a.bias if a.bias is not None else torch.zeros(a.weight.shape[0], device=a.weight.device)
+        zb = b.bias if b.bias is not None else torch.zeros(b.weight.shape[0], device=b.weight.device)
+        bias = torch.cat([za.detach().float(), zb.detach().float()], 0)
+    both = types.SimpleNamespace(weight=torch.cat([a.weight.detach().float(), b.weight.detach().float()], 0), bias=bias, groups=1)
+    return _pack_conv(both, dtype, device, pad_cout_to=pad_cout_to)
+
+
+def _pack_bn_pair(a: Conv, b: Conv, dtype, device):
+    """Two modules.Conv (1x1 + BN + SiLU) of the same input as ONE convolution with the outputs side by side."""
+    (wa, ba), (wb, bb) = a._folded(), b._folded()
+    return ops.pack_conv_weight(torch.cat([wa, wb], 0).to(device), dtype), torch.cat([ba, bb], 0).to(device).contiguous()
+
+
 def _flat(p, device):
     return p.detach().float().reshape(-1).to(device).contiguous()
 
@@ -1119,6 +1138,7 @@ class _LocalConvTransformerExpert(nn.Module):
                 "qkv": _pack_conv(self.qkv, dtype, device), "pe": _pack_dw(self.pe, dtype, device),
                 "proj": _pack_conv(self.proj, dtype, device, scale=self.ls1 if _fold_ls(dtype) else None),
                 "ffn_out": _pack_bn_conv(self.ffn_out, dtype, device, self.ls2 if _fold_ls(dtype) else None),
+                "ffn_gv": _pack_bn_pair(self.ffn_gate[0], self.ffn_val, dtype, device),
                 "ls1": None if _fold_ls(dtype) else _flat(self.ls1, device), "ls2": None if _fold_ls(dtype) else _flat(self.ls2, device)}
 
     def run(self, x, pk):
@@ -1144,7 +1164,9 @@ class _LocalConvTransformerExpert(nn.Module):
             o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], v, nh, hd, hd ** -0.5)
         x1 = _ls_conv(o, pk, "proj", "ls1", x)
         xn = ops.group_norm(x1, g, *pk["n2"], 1e-5)
-        glu = ops.eltwise_mul(self.ffn_gate[0]._run(xn), self.ffn_val._run(xn), act_a="sigmoid")
+        hid = pk["ffn_gv"][0].shape[0] // 2
+        gv = ops.conv2d(xn, *pk["ffn_gv"], 1, 1, True)      # [SiLU(gate conv) | SiLU(value conv)]: two 1x1 convolutions of xn as one launch
+        glu = ops.eltwise_mul(gv[..., :hid], gv[..., hid:], act_a="sigmoid")
         return _ls_conv(glu, pk, "ffn_out", "ls2", x1)
 
 
@@ -1211,9 +1233,10 @@ class _DeformableTransformerExpert(nn.Module):
 
     def pack(self, dtype, device):
         return {"n1": _pack_norm(self.norm1, device), "n2": _pack_norm(self.norm2, device),
-                "q": _pack_conv(self.q_proj, dtype, device), "v": _pack_conv(self.v_proj, dtype, device),
-                "off": _pack_conv(self.offset_proj, dtype, device, pad_cout_to=_ceil(self.offset_proj.out_features, 4)),
-                "aw": _pack_conv(self.attn_proj, dtype, device, pad_cout_to=_ceil(self.attn_proj.out_features, 4)),
+                # q and v are two projections of the normalised tokens, offsets and attention logits two projections of q: one launch each pair
+                "qv": _pack_conv_pair(self.q_proj, self.v_proj, dtype, device),
+                "offaw": _pack_conv_pair(self.offset_proj, self.attn_proj, dtype, device,
+                                         pad_cout_to=_ceil(self.offset_proj.out_features + self.attn_proj.out_features, 4)),
                 "out": _pack_conv(self.out_proj, dtype, device, scale=self.ls1 if _fold_ls(dtype) else None),
                 "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device, scale=self.ls2 if _fold_ls(dtype) else None),
                 "ls1": None if _fold_ls(dtype) else _flat(self.ls1, device), "ls2": None if _fold_ls(dtype) else _flat(self.ls2, device)}
@@ -1222,10 +1245,10 @@ class _DeformableTransformerExpert(nn.Module):
         C = x.shape[-1]
         nh, hd, npnt = self.num_heads, C // self.num_heads, self.n_points
         xn = ops.layer_norm(x, *pk["n1"], 1e-5)
-        q = ops.conv2d(xn, *pk["q"], 1, 1, False)
-        off = ops.conv2d(q, *pk["off"], 1, 1, False, out_dtype=torch.float32)[..., : nh * npnt * 2]   # sampling coordinates stay fp32
-        aw = ops.conv2d(q, *pk["aw"], 1, 1, False, out_dtype=torch.float32)[..., : nh * npnt]
-        o = ops.deform_attention(ops.conv2d(xn, *pk["v"], 1, 1, False), off, aw, nh, hd, npnt, self.align_corners)
+        qv = ops.conv2d(xn, *pk["qv"], 1, 1, False)                                            # [q | v]
+        oa = ops.conv2d(qv[..., :C], *pk["offaw"], 1, 1, False, out_dtype=torch.float32)      # [offsets | attention logits], fp32 (sampling coordinates)
+        off, aw = oa[..., : nh * npnt * 2], oa[..., nh * npnt * 2: nh * npnt * 3]
+        o = ops.deform_attention(qv[..., C:], off, aw, nh, hd, npnt, self.align_corners)
         x1 = _ls_conv(o, pk, "out", "ls1", x)
         return _run_token_ffn(x1, self.ffn, self.norm2, self.ls2, pk)
 

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -427,6 +429,11 @@ class ABlock(YmkModule):
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = nn.Sequential(Conv(dim, mlp_hidden_dim, 1), Conv(mlp_hidden_dim, dim, 1, act=False))
         hp = (mlp_hidden_dim + 7) // 8 * 8
+        # ... and, where it costs at most 1/8 more arithmetic, to a multiple of 64: both 1x1 convolutions then qualify for the LDS-DMA core
+        # (int(1.2 * 256) = 307 -> 320 at the L scale: config 5 309.4 -> 311 images/s on one box; the generic implicit-GEMM kernel ran them before)
+        hp64 = (mlp_hidden_dim + 63) // 64 * 64
+        if dim % 64 == 0 and hp64 - mlp_hidden_dim <= mlp_hidden_dim // 8:
+            hp = hp64
         if hp != mlp_hidden_dim:
             self.mlp[0].pad_cout_to = hp
             self.mlp[1].pad_cin_to = hp

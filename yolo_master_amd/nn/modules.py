@@ -16,8 +16,6 @@ from __future__ import annotations
 
 import math
 
-import os
-
 import torch
 import torch.nn as nn
 

@@ -1205,10 +1205,11 @@ class _WindowTransformerExpert(nn.Module):
                 "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device, scale=self.ls2 if _fold_ls(dtype) else None),
                 "ls1": None if _fold_ls(dtype) else _flat(self.ls1, device), "ls2": None if _fold_ls(dtype) else _flat(self.ls2, device)}
 
-    def run(self, x, pk):
+    def run(self, x, pk, qkv=None):
         C = x.shape[-1]
         nh, hd = self.num_heads, C // self.num_heads
-        qkv = ops.conv2d(ops.layer_norm(x, *pk["n1"], 1e-5), *pk["qkv"], 1, 1, False)
+        if qkv is None:     # (MoTBlock hands over its slice of the projection it shares with the deformable expert in the 16-bit modes)
+            qkv = ops.conv2d(ops.layer_norm(x, *pk["n1"], 1e-5), *pk["qkv"], 1, 1, False)
         a = ops.window_attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], nh, hd, hd ** -0.5, self.win,
                                  shift=self.shift_size, pad_q=pk["pad"][0], pad_k=pk["pad"][1], pad_v=pk["pad"][2])
         x1 = _ls_conv(a, pk, "proj", "ls1", x)
@@ -1241,11 +1242,11 @@ class _DeformableTransformerExpert(nn.Module):
                 "f0": _pack_conv(self.ffn[0], dtype, device), "f3": _pack_conv(self.ffn[3], dtype, device, scale=self.ls2 if _fold_ls(dtype) else None),
                 "ls1": None if _fold_ls(dtype) else _flat(self.ls1, device), "ls2": None if _fold_ls(dtype) else _flat(self.ls2, device)}
 
-    def run(self, x, pk):
+    def run(self, x, pk, qv=None):
         C = x.shape[-1]
         nh, hd, npnt = self.num_heads, C // self.num_heads, self.n_points
-        xn = ops.layer_norm(x, *pk["n1"], 1e-5)
-        qv = ops.conv2d(xn, *pk["qv"], 1, 1, False)                                            # [q | v]
+        if qv is None:
+            qv = ops.conv2d(ops.layer_norm(x, *pk["n1"], 1e-5), *pk["qv"], 1, 1, False)      # [q | v]
         oa = ops.conv2d(qv[..., :C], *pk["offaw"], 1, 1, False, out_dtype=torch.float32)      # [offsets | attention logits], fp32 (sampling coordinates)
         off, aw = oa[..., : nh * npnt * 2], oa[..., nh * npnt * 2: nh * npnt * 3]
         o = ops.deform_attention(qv[..., C:], off, aw, nh, hd, npnt, self.align_corners)
@@ -1306,7 +1307,28 @@ class MoTBlock(YmkModule):
                 "r3": _pack_conv(r[3], torch.float32, device, pad_cout_to=4, pad_cin_to=hp),
                 "inv_temp": 1.0 / float(self.router.temperature),
                 "experts": [e.pack(dtype, device) for e in self.experts],
+                "shared": self._pack_shared(dtype, device) if _fold_ls(dtype) else None,
                 "out_proj": _pack_conv(self.out_proj, dtype, device), "out_norm": _pack_norm(self.out_norm, device)}
+
+    def _pack_shared(self, dtype, device):
+        """The window and the deformable expert both start with LayerNorm(x) -> bias-free projections; the two LayerNorms differ only in
+        their affine parameters.  16-bit modes: ONE affine-free LayerNorm, and ONE convolution [window q | k | v | deformable q | v] with each
+        LayerNorm's weight folded into its projection's columns and its bias into the convolution's bias (W (xhat * g + b) = (W diag g) xhat
+        + W b): one normalisation pass and one launch less per block.  fp32 keeps the reference's order of operations (see _fold_ls)."""
+        import types
+
+        win, dfm = self.experts[1], self.experts[2]
+        rows, biases = [], []
+        for lin, ln in ((win.qkv, win.norm1), (dfm.q_proj, dfm.norm1), (dfm.v_proj, dfm.norm1)):
+            if lin.bias is not None:
+                return None
+            w = lin.weight.detach().float()
+            rows.append(w * ln.weight.detach().float().view(1, -1))
+            biases.append(w @ ln.bias.detach().float())
+        both = types.SimpleNamespace(weight=torch.cat(rows, 0), bias=torch.cat(biases, 0), groups=1)
+        C = win.norm1.weight.numel()
+        return {"w": _pack_conv(both, dtype, device), "ones": torch.ones(C, device=device), "zeros": torch.zeros(C, device=device),
+                "eps": float(win.norm1.eps)}
 
     def _run(self, x, out=None):
         """mot/block.py:298-417, eval.  The reference runs expert e only on the images where some token selected it;
@@ -1321,7 +1343,14 @@ class MoTBlock(YmkModule):
         logits = ops.conv2d(hn, *pk["r3"], 1, 1, False)
         weights, active = ops.token_softmax(logits, self.NUM_EXPERTS, pk["inv_temp"], top_k=self.top_k)
         self.last_route = {"weights": weights, "active": active}
-        outs = [e.run(x, p) for e, p in zip(self.experts, pk["experts"])]
+        sh = pk["shared"]
+        if sh is not None and float(self.experts[2].norm1.eps) == sh["eps"]:
+            xhat = ops.layer_norm(x, sh["ones"], sh["zeros"], sh["eps"])
+            proj = ops.conv2d(xhat, *sh["w"], 1, 1, False)                     # [window q | k | v | deformable q | v]
+            outs = [self.experts[0].run(x, pk["experts"][0]), self.experts[1].run(x, pk["experts"][1], qkv=proj[..., : 3 * C]),
+                    self.experts[2].run(x, pk["experts"][2], qv=proj[..., 3 * C:])]
+        else:
+            outs = [e.run(x, p) for e, p in zip(self.experts, pk["experts"])]
         mixed = ops.weighted_sum(weights, outs)
         p = ops.conv2d(mixed, *pk["out_proj"], 1, 1, False)
         return ops.group_norm(p, get_safe_groups(C, 8), *pk["out_norm"], 1e-5, residual=x, out=out)

@@ -52,6 +52,8 @@ extern "C" {
 /* activation codes for fused epilogues */
 #define YMK_ACT_NONE 0
 #define YMK_ACT_SILU 1
+#define YMK_ACT_SIGMOID 2 /* ymk_conv2d (fused in the LDS-DMA core, one in-place pass after the other cores), ymk_activation, ymk_group_norm */
+#define YMK_ACT_GELU 3    /* exact erf form (torch.nn.GELU default); same scope */
 
 /* device flag bits (int32 words written with atomicOr by kernels) */
 #define YMK_FLAG_NONFINITE_INPUT 1  /* router input contains NaN/Inf  (routers.py:51)  */

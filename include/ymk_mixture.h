@@ -17,8 +17,7 @@
 extern "C" {
 #endif
 
-#define YMK_ACT_SIGMOID 2
-#define YMK_ACT_GELU 3 /* exact erf form (torch.nn.GELU default) */
+/* YMK_ACT_SIGMOID (2) and YMK_ACT_GELU (3, exact erf form) are defined in ymk.h */
 
 /* In-place activation on a channel-dense view (used after ymk_conv2d for the sigmoid / GELU epilogues of the gates and
  * the token FFNs: moe/gated.py:1171-1218, mot/experts.py:318-325). */

@@ -27,7 +27,9 @@ def _nchw(x):
 
 
 def _finish(y_nchw, act, residual, out, dtype):
-    if act:
+    if isinstance(act, str) and act != "silu":      # "gelu" / "sigmoid": the extended epilogues of ymk_conv2d (ymk.h YMK_ACT_*)
+        y_nchw = _act(y_nchw, act)
+    elif act:
         y_nchw = F.silu(y_nchw)
     y = y_nchw.permute(0, 2, 3, 1)
     if residual is not None:

@@ -8,7 +8,7 @@ import sys
 import pytest
 import torch
 
-from tests.test_hostemu_conv import CASES, CAT2_CASES, EXPERT_CASES, run_case, run_cat2_case, run_expert_case
+from tests.test_hostemu_conv import CASES, CAT2_CASES, EPILOGUE_CASES, EXPERT_CASES, run_case, run_cat2_case, run_expert_case
 
 pytestmark = pytest.mark.gpu
 
@@ -22,6 +22,14 @@ def test_conv2d_glds_direct(case):
 
     run_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", EPILOGUE_CASES + [(4, 80, 80, 256, 512, 1, 1, "gelu", False, False, 0, 0, None),      # the MoT token FFN at config 5's P4
+                                                   (8, 40, 40, 512, 1024, 1, 1, "gelu", False, False, 0, 0, None)])
+def test_conv2d_gelu_and_sigmoid_epilogues(case):
+    from yolo_master_amd import _lib
+
+    run_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)
 
 
 @pytest.mark.parametrize("case", CAT2_CASES + [(4, 80, 80, 256, 256, 128, True, True, 0, 0, 0, 0), (4, 40, 40, 512, 256, 256, True, True, 0, 0, 0, 1)])

@@ -119,7 +119,7 @@ def test_product_never_imports_oracle():
 
 def test_lx_scale_host_logic():
     """l/x scales: A2C2f carries the gamma-residual and mlp_ratio 1.2 (tasks.py:2156-2159); the MLP hidden width
-    int(1.2*dim) is zero-padded at pack time so that every conv sees 16-byte channel vectors."""
+    int(1.2*dim) is zero-padded at pack time so that every conv sees 16-byte channel vectors (and whole 64-channel k-steps)."""
     from yolo_master_amd.nn.modules import A2C2f, ABlock
     from yolo_master_amd.nn.tasks import DetectionModel
 
@@ -129,7 +129,8 @@ def test_lx_scale_host_logic():
     ab = next(x for x in m.modules() if isinstance(x, ABlock))
     hidden = ab.mlp[0].conv.out_channels
     assert hidden == int(ab.mlp[0].conv.in_channels * 1.2) and hidden % 8 != 0
-    hp = (hidden + 7) // 8 * 8
+    hp = (hidden + 63) // 64 * 64    # 307 -> 320: a multiple of 64 where that costs <= 1/8 more arithmetic (both convolutions on the LDS-DMA core), else of 8
+    assert hp - hidden <= hidden // 8 and ab.mlp[0].pad_cout_to == hp == ab.mlp[1].pad_cin_to
     with torch.no_grad():
         p0, p1 = ab.mlp[0]._pack(torch.float32, "cpu"), ab.mlp[1]._pack(torch.float32, "cpu")
     assert p0["w"].shape[0] == hp and p0["b"].shape[0] == hp

@@ -56,9 +56,10 @@ def run_case(lib, case, dev="cpu", stream=None):
     xd, rd = _wide(x, xpad, dev), (None if res is None else _wide(res, 32, dev))
     wd, bd = wp.to(dev), bias.to(dev)
     d = _lib.ConvDesc(_lib.YMK_BF16, ops.DT[odt], B, H, W, Cin, Cout, k, s, xd.stride(2), y.stride(2), rd.stride(2) if use_res else 0,
-                      wp.shape[1], _lib.ACT_SILU if act else _lib.ACT_NONE)
+                      wp.shape[1], {"gelu": _lib.ACT_GELU, "sigmoid": _lib.ACT_SIGMOID}.get(act, _lib.ACT_SILU if act else _lib.ACT_NONE))
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())   # noqa: E731
-    rc = lib.ymk_conv2d_glds(C.byref(d), p(xd), p(wd), p(bd), p(rd), p(y), two, stream)
+    entry = lib.ymk_conv2d_glds if two is not None else None
+    rc = entry(C.byref(d), p(xd), p(wd), p(bd), p(rd), p(y), two, stream) if entry else lib.ymk_conv2d(C.byref(d), p(xd), p(wd), p(bd), p(rd), p(y), stream)
     assert rc == 0
     got = y.float().cpu()
     err = float((got - ref.float()).abs().max())
@@ -71,6 +72,33 @@ def run_case(lib, case, dev="cpu", stream=None):
 @pytest.mark.parametrize("case", CASES)
 def test_conv2d_glds_on_the_emulator(hostlib, case):
     run_case(hostlib, case)
+
+
+EPILOGUE_CASES = [
+    # the extended epilogues (ymk.h YMK_ACT_GELU / YMK_ACT_SIGMOID; the token FFNs of the MoT experts, the gates of the gated MoE):
+    # in the LDS-DMA core's epilogue ...
+    (2, 9, 11, 64, 128, 1, 1, "gelu", False, False, 0, 0, 1), (1, 13, 7, 128, 64, 3, 1, "sigmoid", False, True, 64, 8, 1),
+    # ... and through ymk_conv2d (two = None): a shape the core takes, and shapes that go to the other cores (one in-place pass follows)
+    (1, 20, 20, 128, 256, 1, 1, "gelu", False, False, 0, 0, None), (2, 7, 9, 32, 48, 1, 1, "gelu", False, False, 0, 8, None),
+    (1, 6, 5, 16, 24, 3, 1, "sigmoid", False, True, 0, 0, None),
+]
+
+
+@pytest.mark.parametrize("case", EPILOGUE_CASES)
+def test_conv2d_gelu_and_sigmoid_epilogues(hostlib, case):
+    run_case(hostlib, case)
+
+
+def test_conv2d_extended_epilogues_take_no_residual(hostlib):
+    from yolo_master_amd import _lib, ops
+
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16)
+    w = ops.pack_conv_weight(torch.zeros(64, 64, 1, 1), torch.bfloat16)
+    b, y = torch.zeros(64), torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16)
+    d = _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, 1, 8, 8, 64, 64, 1, 1, 64, 64, 64, 64, _lib.ACT_GELU)
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    assert hostlib.ymk_conv2d(C.byref(d), p(x), p(w), p(b), p(y), p(y), None) == -1
+    assert hostlib.ymk_conv2d_glds(C.byref(d), p(x), p(w), p(b), p(y), p(y), 1, None) == -1
 
 
 def tile_flags(bn, bm, two=1):

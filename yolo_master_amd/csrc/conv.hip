@@ -599,8 +599,29 @@ static int launch_conv(ConvArgs a, hipStream_t s) {
     return ymk_launch_status();
 }
 
+extern "C" int ymk_activation(int32_t dtype, void* x, int32_t ldx, int64_t npix, int32_t C, int32_t act, void* stream);
+static int conv2d_dispatch(const ymk_conv_desc* d, const ymk_conv_desc* dglds, const void* x, const void* w, const float* bias,
+                           const void* residual, void* y, void* stream, bool* act_fused);
+
+// act = YMK_ACT_GELU / YMK_ACT_SIGMOID (no residual): the LDS-DMA core applies them in its epilogue; where the shape goes to another
+// core that one runs without activation and ONE in-place pass over y follows (what the caller did in two calls before).
 extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, const float* bias,
                           const void* residual, void* y, void* stream) {
+    if (!d) return YMK_E_BADARG;
+    bool fused = false;
+    if (d->act != YMK_ACT_GELU && d->act != YMK_ACT_SIGMOID) return conv2d_dispatch(d, d, x, w, bias, residual, y, stream, &fused);
+    if (residual) return YMK_E_BADARG;
+    ymk_conv_desc plain = *d;
+    plain.act = YMK_ACT_NONE;
+    const int rc = conv2d_dispatch(&plain, d, x, w, bias, residual, y, stream, &fused);
+    if (rc != YMK_OK || fused) return rc;
+    const int pad = d->ksize / 2;
+    const int64_t Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+    return ymk_activation(d->out_dtype, y, d->ldy, (int64_t)d->B * Ho * Wo, d->Cout, d->act, stream);
+}
+
+static int conv2d_dispatch(const ymk_conv_desc* d, const ymk_conv_desc* dglds, const void* x, const void* w, const float* bias,
+                           const void* residual, void* y, void* stream, bool* act_fused) {
     if (!d || !x || !w || !bias || !y) return YMK_E_BADARG;
     if (d->ksize != 1 && d->ksize != 3) return YMK_E_BADARG;
     if (d->stride != 1 && d->stride != 2) return YMK_E_BADARG;
@@ -645,8 +666,8 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
         // anywhere (profiles/r02_glds_tile_ab.txt).  YMK_GLDS_THREE_STAGE=1 brings it back for A/B runs.
         static const bool three = [] { const char* e = getenv("YMK_GLDS_THREE_STAGE"); return e && atoi(e) != 0; }();
         if (d->Cout % 64 == 0) {
-            const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, three ? 0 : 1, stream);
-            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = three ? 3 : 2; return rc; }
+            const int rc = ymk_conv2d_glds(dglds, x, w, bias, residual, y, three ? 0 : 1, stream);
+            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = three ? 3 : 2; *act_fused = true; return rc; }
         }
     }
     // The tiled 1x1 shapes (K >= 256 and Cout a multiple of 128, or Cout a multiple of 64; at least 192 tiles of 256 pixels): with 128-pixel tiles and the two-stage
@@ -661,8 +682,8 @@ extern "C" int ymk_conv2d(const ymk_conv_desc* d, const void* x, const void* w, 
         const int min_k = (glds_all || d->Cout % 128 == 0) ? ymk_glds_min_k : 64;
         if (d->Cout % 64 == 0 && tiles >= ymk_glds_min_tiles && d->Kpad >= min_k) {
             const bool two = glds_all ? (ymk_enabled() & YMK_ON_GLDS_TWO_STAGE) != 0 : true;
-            const int rc = ymk_conv2d_glds(d, x, w, bias, residual, y, two ? 1 : 0, stream);
-            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = two ? 2 : 3; return rc; }
+            const int rc = ymk_conv2d_glds(dglds, x, w, bias, residual, y, two ? 1 : 0, stream);
+            if (rc != YMK_E_BADARG) { ymk_last_variant = YMK_CONV_GLDS; ymk_last_glds_stages = two ? 2 : 3; *act_fused = true; return rc; }
         }
     }
     ymk_last_variant = YMK_CONV_TILED;

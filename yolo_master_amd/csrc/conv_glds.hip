@@ -63,8 +63,10 @@ struct GldsArgs {
     int K;
 };
 
-template <int BN, int STAGES, int BM = GLDS_BM>
-__global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
+// EXT: the body that also carries the GELU / sigmoid epilogues (conv_glds_ext_kernel).  128 inlined erf / exp expansions compiled into
+// every instantiation cost the 256 x 256 tile 20 % (instruction cache) on launches that never use them: they are separate kernels.
+template <int BN, int STAGES, int BM, bool EXT>
+__device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
     constexpr int BK = 64;                    // channels of one filter tap per k-step: LDS rows of 128 bytes = 8 chunks of 16
     constexpr int ROWS = BN + BM;             // staged rows per k-step: weights first, then pixels
     constexpr int CPR = BK / 8;               // 16-byte chunks per row
@@ -301,6 +303,10 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
                 const int i = 2 * h + q;
                 float v0 = acc[i][j].x + bv[i].x, v1 = acc[i][j].y + bv[i].y, v2 = acc[i][j].z + bv[i].z, v3 = acc[i][j].w + bv[i].w;
                 if (a.act == YMK_ACT_SILU) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                else if constexpr (EXT) {
+                    if (a.act == YMK_ACT_GELU) { v0 = gelu_exact(v0); v1 = gelu_exact(v1); v2 = gelu_exact(v2); v3 = gelu_exact(v3); }
+                    else if (a.act == YMK_ACT_SIGMOID) { v0 = sigmoid_exact(v0); v1 = sigmoid_exact(v1); v2 = sigmoid_exact(v2); v3 = sigmoid_exact(v3); }
+                }
                 if (a.res) {
                     float r0, r1, r2, r3;
                     if constexpr (RES_PREFETCH) unpack_raw4(rr[i][j], r0, r1, r2, r3);
@@ -328,18 +334,33 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) {
     }
 }
 
+template <int BN, int STAGES, int BM = GLDS_BM>
+__global__ __launch_bounds__(512) void conv_glds_kernel(GldsArgs a) { conv_glds_body<BN, STAGES, BM, false>(a); }
 template <int BN, int STAGES, int BM>
+__global__ __launch_bounds__(512) void conv_glds_ext_kernel(GldsArgs a) { conv_glds_body<BN, STAGES, BM, true>(a); }
+
+template <int BN, int STAGES, int BM, bool EXT = false>
 static int glds_launch_bm(const GldsArgs& a, hipStream_t s) {
+    if constexpr (!EXT) {
+        if (a.act == YMK_ACT_GELU || a.act == YMK_ACT_SIGMOID) {   // the two-stage tiles of the default rule carry these epilogues
+            if constexpr (STAGES == 2 && BM <= 256) return glds_launch_bm<BN, STAGES, BM, true>(a, s);
+            else return YMK_E_BADARG;
+        }
+    }
     const int M = a.B * a.Ho * a.Wo;
     const int grid = (a.eidx ? a.K * a.B * ((a.Ho * a.Wo + BM - 1) / BM) : (M + BM - 1) / BM) * (a.Cout / BN);
     const size_t lds = (size_t)STAGES * (BN + BM) * 8 * 16;
     static YmkOncePerDevice once;
     if (once.need()) {
-        if (hipFuncSetAttribute((const void*)conv_glds_kernel<BN, STAGES, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        const void* fn;
+        if constexpr (EXT) fn = (const void*)conv_glds_ext_kernel<BN, STAGES, BM>;
+        else fn = (const void*)conv_glds_kernel<BN, STAGES, BM>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return YMK_E_LAUNCH;
         once.done();
     }
-    hipLaunchKernelGGL((conv_glds_kernel<BN, STAGES, BM>), dim3(grid), dim3(512), lds, s, a);
+    if constexpr (EXT) hipLaunchKernelGGL((conv_glds_ext_kernel<BN, STAGES, BM>), dim3(grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv_glds_kernel<BN, STAGES, BM>), dim3(grid), dim3(512), lds, s, a);
     return ymk_launch_status();
 }
 
@@ -415,7 +436,8 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
     if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return YMK_E_BADARG;
     if (d->Cin < 64 || d->Cin % 64 || d->Cout % 64 || d->ldx % 8 || d->ldy % 4 || (residual && d->ldr % 4)) return YMK_E_BADARG;
     if (d->Kpad != d->ksize * d->ksize * d->Cin) return YMK_E_BADARG;
-    if (d->act != YMK_ACT_NONE && d->act != YMK_ACT_SILU) return YMK_E_BADARG;
+    if (d->act != YMK_ACT_NONE && d->act != YMK_ACT_SILU && d->act != YMK_ACT_GELU && d->act != YMK_ACT_SIGMOID) return YMK_E_BADARG;
+    if (residual && d->act != YMK_ACT_NONE && d->act != YMK_ACT_SILU) return YMK_E_BADARG;
     const int pad = d->ksize / 2;
     GldsArgs a;
     a.x = static_cast<const h16_t*>(x); a.w = static_cast<const h16_t*>(w); a.bias = bias;

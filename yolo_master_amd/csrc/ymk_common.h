@@ -72,6 +72,8 @@ __device__ __forceinline__ h16_t f32_to_h16(float f) { return (h16_t)(pack_h16x2
 // fast form for bf16 outputs: v_exp_f32 + v_rcp_f32 (~1 ulp), 5 instructions instead of an IEEE division
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }   // torch.nn.GELU default (erf form)
+__device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 template <typename T>
 struct ElemTraits;

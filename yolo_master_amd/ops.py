@@ -220,8 +220,9 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual
         rb = _nhwc(residual)
         assert rb[:4] == (B, Ho, Wo, Cout)
         ldr = rb[4]
+    # act: False / True (SiLU) or "gelu" / "sigmoid" (ymk.h YMK_ACT_*: fused in the LDS-DMA core's epilogue, one in-place pass after the others)
     d = ConvDesc(DT[x.dtype], DT[out.dtype], B, H, W, Cin, Cout, k, stride, ldx, ldy, ldr, Kp,
-                 _lib.ACT_SILU if act else _lib.ACT_NONE)
+                 _ACT[act] if isinstance(act, str) else (_lib.ACT_SILU if act else _lib.ACT_NONE))
     e0 = TIMER.begin()
     check(lib.ymk_conv2d(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), _stream()), "conv2d")
     if e0 is not None:
@@ -677,18 +678,15 @@ def _out_like(x, out, dtype=None, shape=None):
 
 
 def conv2d_act(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None, out_dtype=None):
-    """ymk_conv2d with the extended epilogue set: act in ACT_CODES ("gelu" = exact erf GELU, nn.GELU default); sigmoid and
-    GELU run as an in-place pass over the convolution's output (ymk_activation)."""
+    """ymk_conv2d with the extended epilogue set: act in ACT_CODES ("gelu" = exact erf GELU, nn.GELU default); sigmoid and GELU are
+    applied in the LDS-DMA convolution core's epilogue, or by one in-place pass inside ymk_conv2d where another core takes the shape."""
     if act in (False, True, "silu"):
         return conv2d(x, w_packed, bias, k, stride, bool(act), out=out, residual=residual, out_dtype=out_dtype)
     if act not in ACT_CODES:
         raise ValueError(f"unknown activation {act!r}")
     if residual is not None:
         raise NotImplementedError("conv2d_act: sigmoid / gelu epilogues take no residual")
-    y = conv2d(x, w_packed, bias, k, stride, False, out=out, out_dtype=out_dtype)
-    B, H, W, Cc, ld = _nhwc(y)
-    check(lib.ymk_activation(DT[y.dtype], _p(y), ld, B * H * W, Cc, _ACT[act], _stream()), "activation")
-    return y
+    return conv2d(x, w_packed, bias, k, stride, act, out=out, out_dtype=out_dtype)
 
 
 @_timed("group_norm")

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--scale", default="s")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--serial", action="store_true", help="no overlap: copy in, compute, copy out one after the other (A/B)")
+    ap.add_argument("--split", type=int, default=1, help="sub-batches walked on parallel streams inside a slot's graph (as bench.py --split); "
+                    "measured WORSE here: 2 -> 8.7-9.0 k images/s against 9.7 k (the copy engines' traffic shares the fabric with two compute streams)")
     a = ap.parse_args()
 
     from yolo_master_amd import ops, postprocess
@@ -53,18 +55,36 @@ def main():
     nw, nh = p["new_unpad"]
     geom = torch.tensor([[fh, fw, nh, nw, p["top"], p["left"]]] * B, dtype=torch.int32, device=dev)
     offs = (torch.arange(B, dtype=torch.int64) * (fh * fw * 3)).to(dev)
-    words = ops.nms_pack_numel(B, MAX_DET)
+    assert B % a.split == 0
+    SUB = B // a.split
+    sub_words = ops.nms_pack_numel(SUB, MAX_DET)
+    words = a.split * sub_words          # per sub-batch: dets | idx | counts
     slots = []
     for _ in range(2):
         slots.append({"frames": torch.empty((B, fh, fw, 3), dtype=torch.uint8, device=dev), "x": torch.empty((B, 3, S, S), dtype=torch.float32, device=dev),
                       "pack": torch.empty((words,), dtype=torch.float32, device=dev), "host": torch.empty((words,), dtype=torch.float32).pin_memory()})
     params = postprocess._params((S, S), [(fh, fw)] * B, None, dev)
 
+    side = [torch.cuda.Stream(device=dev) for _ in range(a.split - 1)]
+
     def compute(sl):
         check(lib.ymk_letterbox_preprocess(ops._p(sl["frames"]), ops._p(offs), ops._p(geom), ops._p(sl["x"]), B, S, S, 114, 1, ops._stream()), "letterbox")
-        y, _ = model._predict_once(sl["x"])
-        dets, counts, _, _ = nms_padded(y, 0.25, 0.7, max_det=MAX_DET, pack=sl["pack"])
-        check(lib.ymk_scale_boxes(ops._p(dets), dets.stride(1), ops._p(counts), ops._p(params), B, MAX_DET, 1, 0, ops._stream()), "scale_boxes")
+
+        def half(i):     # forward + NMS + box rescaling of sub-batch i into its slice of the packed result
+            y, _ = model._predict_once(sl["x"][i * SUB:(i + 1) * SUB])
+            dets, counts, _, _ = nms_padded(y, 0.25, 0.7, max_det=MAX_DET, pack=sl["pack"][i * sub_words:(i + 1) * sub_words])
+            check(lib.ymk_scale_boxes(ops._p(dets), dets.stride(1), ops._p(counts), ops._p(params[i * SUB:(i + 1) * SUB]), SUB, MAX_DET, 1, 0,
+                                      ops._stream()), "scale_boxes")
+
+        cur = torch.cuda.current_stream()
+        for st in side:
+            st.wait_stream(cur)
+        for i, st in enumerate(side, start=1):
+            with torch.cuda.stream(st):
+                half(i)
+        half(0)
+        for st in side:
+            cur.wait_stream(st)
 
     s_in, s_cmp, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     with torch.inference_mode():
@@ -109,13 +129,13 @@ def main():
         t0 = time.perf_counter()
         run(a.steps)
         dt = time.perf_counter() - t0
-    dets, counts, _ = ops.nms_pack_views(slots[(a.steps - 1) % 2]["host"], B, MAX_DET)
+    dets, counts, _ = ops.nms_pack_views(slots[(a.steps - 1) % 2]["host"].view(a.split, sub_words), SUB, MAX_DET)
     h2d_mb, d2h_mb = B * fh * fw * 3 / 1e6, words * 4 / 1e6
     print(json.dumps({"metric": "images/sec, pipelined serving step (host uint8 frames -> letterbox -> forward -> NMS -> scale_boxes -> host)",
                       "value": round(B * a.steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / a.steps * 1e3, 4), "steps": a.steps,
                       "dtype": a.dtype, "overlap": not a.serial,
                       "config": {"workload": f"YOLO-Master-{a.scale.upper()}, {B} frames of {fh}x{fw}x3 uint8 per step -> 640x640", "h2d_mb_per_step": round(h2d_mb, 1),
-                                 "d2h_mb_per_step": round(d2h_mb, 2), "launch": "one hipGraph per slot, 2 slots, 3 streams"},
+                                 "d2h_mb_per_step": round(d2h_mb, 2), "launch": f"one hipGraph per slot ({a.split} sub-batches on parallel streams inside it), 2 slots, 3 streams"},
                       "detections_last_batch": int(counts.sum())}))
 
 

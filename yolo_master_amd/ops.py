@@ -205,7 +205,8 @@ def fold_bn(w: torch.Tensor, bn_w, bn_b, bn_mean, bn_var, eps: float, conv_bias=
 
 
 # ----------------------------------------------------------------------------- conv
-def conv2d(x, w_packed, bias, k: int, stride: int, act: bool, out=None, residual=None, out_dtype=None):
+def conv2d(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None, out_dtype=None):
+    """ymk_conv2d (include/ymk.h): y = act(conv(x) + bias) (+ residual).  act: False / True (SiLU), or "gelu" / "sigmoid" (no residual)."""
     B, H, W, Cin, ldx = _nhwc(x)
     Cout, Kp = w_packed.shape
     pad = k // 2

@@ -157,9 +157,14 @@ def main():
     ap.add_argument("--roofline-kernel", default=None, help="op family to report in `roofline` (default: the one with the largest share of the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
-    ap.add_argument("--split", type=int, default=int(os.environ.get("YMK_BENCH_SPLIT", "2")), help="walk the batch as this many sub-batches on "
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("YMK_BENCH_PIPELINE", "3")), help="batches in flight: step i + 1 (and i + 2) "
+                    "is launched (own stream, own captured graph, own result buffers) while step i is still running — what a throughput-"
+                    "oriented server does with several streams; 1 = one step at a time (lowest latency per batch).  Measured on MI355X, "
+                    "S / 64 x 640^2 bf16: 1 -> 5.90, 2 -> 5.10, 3 -> 4.97, 4 -> 5.37 ms per step; latency per batch 5.9 / 10.1 / 14.8 ms")
+    ap.add_argument("--split", type=int, default=int(os.environ.get("YMK_BENCH_SPLIT", "1")), help="walk the batch as this many sub-batches on "
                     "as many HIP streams inside the one captured graph (same images, same results per image): the latency-bound "
-                    "launches of the small maps of one sub-batch overlap the other's")
+                    "launches of the small maps of one sub-batch overlap the other's.  With ONE batch in flight 2 is best (5.70 vs 5.99 ms); "
+                    "with several batches in flight whole-batch kernels are (split 2 x pipeline 3: 5.38 ms)")
     a = ap.parse_args()
 
     from yolo_master_amd import ops
@@ -197,79 +202,121 @@ def main():
     assert a.batch % a.split == 0, "--split must divide --batch"
     SUB = a.batch // a.split
     sub_words = ops.nms_pack_numel(SUB, MAX_DET)
-    pack = torch.empty((a.split * sub_words,), dtype=torch.float32, device=dev)   # per sub-batch: dets | idx | counts; one buffer per rank
-    gathered = torch.empty((world, pack.numel()), dtype=torch.float32, device=dev) if world > 1 else None
-    side = [torch.cuda.Stream(device=dev) for _ in range(a.split - 1)]
     xs = list(x.split(SUB))
+    P = max(1, a.pipeline)
 
-    def sub_step(i):
-        y, _ = model._predict_once(xs[i])
-        return nms_padded(y, 0.25, 0.7, max_det=MAX_DET, pack=pack[i * sub_words:(i + 1) * sub_words])
+    class Slot:
+        """One batch in flight: its own stream, packed result buffer (per sub-batch: dets | idx | counts), gather buffer, side streams and
+        captured graph.  --pipeline 2: step i + 1 is launched on the other slot while step i is still running (the batch is the same
+        64 images per step; what overlaps is the tail of one step — NMS, the 20 x 20 maps — with the head of the next)."""
 
-    def local_step():
-        """Forward + NMS of this rank's images.  --split S: S sub-batches, the first on the current stream and the others on side
-        streams forked from / joined into it (inside a captured graph these become parallel branches), each with its own slice of
-        the packed result buffer."""
-        cur = torch.cuda.current_stream()
-        for st in side:
-            st.wait_stream(cur)
-        outs = [None] * a.split
-        for i, st in enumerate(side, start=1):
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device=dev) if P > 1 else None
+            self.pack = torch.empty((a.split * sub_words,), dtype=torch.float32, device=dev)
+            self.gathered = torch.empty((world, self.pack.numel()), dtype=torch.float32, device=dev) if world > 1 else None
+            self.side = [torch.cuda.Stream(device=dev) for _ in range(a.split - 1)]
+            self.graph, self.static_out, self.gathered_ev = None, None, None
+
+        def sub_step(self, i):
+            y, _ = model._predict_once(xs[i])
+            return nms_padded(y, 0.25, 0.7, max_det=MAX_DET, pack=self.pack[i * sub_words:(i + 1) * sub_words])
+
+        def local_step(self):
+            """Forward + NMS of this rank's images.  --split S: S sub-batches, the first on the current stream and the others on side
+            streams forked from / joined into it (inside a captured graph these become parallel branches), each with its own slice of
+            the packed result buffer."""
+            cur = torch.cuda.current_stream()
+            for st in self.side:
+                st.wait_stream(cur)
+            outs = [None] * a.split
+            for i, st in enumerate(self.side, start=1):
+                with torch.cuda.stream(st):
+                    outs[i] = self.sub_step(i)
+            outs[0] = self.sub_step(0)
+            for st in self.side:
+                cur.wait_stream(st)
+            dets, counts, idx = ops.nms_pack_views(self.pack.view(a.split, sub_words), SUB, MAX_DET)
+            return dets, counts, idx, outs[0][3]
+
+        def finish(self, local_out):
+            """What follows the rank-local work of a step: for N>1 ONE RCCL all_gather of the packed results (dets | idx | counts,
+            written in place by the NMS kernels), outside the captured graph: a collective is not part of the rank-local launch
+            sequence.  Every rank issues its collectives on ONE stream in step order (the launching stream), whatever the pipeline depth."""
+            dets, counts, idx, status = local_out
+            if world > 1:
+                dets, counts, idx = ops.nms_pack_views(gather_packed(self.pack, out=self.gathered).view(world, a.split, sub_words), SUB, MAX_DET)
+            return dets, counts, status
+
+        def run(self):
+            """Launch one step on this slot; returns (start, end) events of its rank-local work."""
+            main = torch.cuda.current_stream()
+            if self.stream is None:
+                e0 = main.record_event(torch.cuda.Event(enable_timing=True))
+                if self.graph is not None:
+                    self.graph.replay()
+                local = self.static_out if self.graph is not None else self.local_step()
+                e1 = main.record_event(torch.cuda.Event(enable_timing=True))
+                self.finish(local)
+                return e0, e1
+            st = self.stream                                       # (the caller synchronises the device before its first launch: the slot
+            if self.gathered_ev is not None:                       #  stream must NOT wait for the launching stream here — that stream waits for the previous step)
+                st.wait_event(self.gathered_ev)                    # this slot's previous results have been consumed
             with torch.cuda.stream(st):
-                outs[i] = sub_step(i)
-        outs[0] = sub_step(0)
-        for st in side:
-            cur.wait_stream(st)
-        dets, counts, idx = ops.nms_pack_views(pack.view(a.split, sub_words), SUB, MAX_DET)
-        return dets, counts, idx, outs[0][3]
+                e0 = st.record_event(torch.cuda.Event(enable_timing=True))
+                if self.graph is not None:
+                    self.graph.replay()
+                    local = self.static_out
+                else:
+                    local = self.local_step()
+                e1 = st.record_event(torch.cuda.Event(enable_timing=True))
+            main.wait_event(e1)
+            self.finish(local)                                     # the collective (N > 1) stays on the launching stream, in step order
+            self.gathered_ev = main.record_event()
+            return e0, e1
 
-    def finish(local_out):
-        """What follows the rank-local work of a step: for N>1 ONE RCCL all_gather of the packed results (dets | idx | counts,
-        written in place by the NMS kernels), outside the captured graph: a collective is not part of the rank-local launch
-        sequence.  It runs on the compute stream: ~0.5 MB per rank is latency-bound (tens of microseconds against a 6 ms step), so
-        overlapping it with the next replay (double-buffered graphs + a side stream) would buy < 1 % and could not be validated
-        without a second device."""
-        dets, counts, idx, status = local_out
-        if world > 1:
-            dets, counts, idx = ops.nms_pack_views(gather_packed(pack, out=gathered).view(world, a.split, sub_words), SUB, MAX_DET)
-        return dets, counts, status
+    slots = [Slot() for _ in range(P)]
 
     with torch.inference_mode():
-        for _ in range(max(a.warmup, 1)):
-            out = finish(local_step())
-        torch.cuda.synchronize()
+        for sl in slots:
+            ctx = torch.cuda.stream(sl.stream) if sl.stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+            with ctx:
+                for _ in range(max(a.warmup // P, 1)):
+                    sl.finish(sl.local_step())
+            torch.cuda.synchronize()
         model.check_flags()
-        graph, static_out = None, None
-        if not a.no_graph:   # the rank-local step (forward + NMS) is one captured HIP graph at every N
+        graph = None
+        if not a.no_graph:   # the rank-local step (forward + NMS) is one captured HIP graph at every N (one per slot)
             try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    static_out = local_step()
-                graph.replay()
-                torch.cuda.synchronize()
+                for sl in slots:
+                    g = torch.cuda.CUDAGraph()
+                    if sl.stream is not None:
+                        with torch.cuda.graph(g, stream=sl.stream):
+                            sl.static_out = sl.local_step()
+                    else:
+                        with torch.cuda.graph(g):
+                            sl.static_out = sl.local_step()
+                    sl.graph = g
+                    g.replay()
+                    torch.cuda.synchronize()
+                graph = slots[0].graph
             except Exception as e:  # pragma: no cover
                 if rank == 0:
                     print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+                for sl in slots:
+                    sl.graph, sl.static_out = None, None
                 graph = None
                 torch.cuda.synchronize()
 
-        def run():
-            if graph is not None:
-                graph.replay()
-                return finish(static_out)
-            return finish(local_step())
-
-        out = run()
+        for sl in slots:
+            sl.run()
 
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
         t0 = time.perf_counter()
-        evs[0].record()
+        evs = []
         for i in range(a.steps):
-            run()
-            evs[i + 1].record()
+            evs.append(slots[i % P].run())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -278,8 +325,10 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
-        p50_ms = per_step[len(per_step) // 2]
+        lat = sorted(e0.elapsed_time(e1) for e0, e1 in evs)                     # launch -> completion of a step's rank-local work
+        p50_latency_ms = lat[len(lat) // 2]
+        per_step = sorted(evs[i][1].elapsed_time(evs[i + 1][1]) for i in range(a.steps - 1))   # completion to completion
+        p50_ms = per_step[len(per_step) // 2] if per_step else p50_latency_ms
         model.check_flags()                       # device flag words of the timed steps, read once after the loop
 
         # roofline leg: per-call HIP events around every op family (eager launches on this stream); the object
@@ -355,12 +404,13 @@ def main():
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "p50_ms_per_image": round(p50_ms / a.batch, 5),
+            "p50_ms_per_image": round(p50_ms / a.batch, 5), "p50_batch_latency_ms": round(p50_latency_ms, 4),
             "config": {"workload": (f"YOLO-Master-{a.scale.upper()} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, "
                                     f"bs={a.batch}/GPU, ES-MoE top-k=2 ({cfgtag})") if a.cfg is None else
                                    f"{a.cfg} at scale {a.scale} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, bs={a.batch}/GPU (not the headline configuration)",
                        "global_batch": world * a.batch, "imgsz": a.imgsz, "parallelism": f"dp{world} (image shards, no data-path collective)",
-                       "launch": ("hipGraph" if graph is not None else "eager") + (f", {a.split} sub-batches on parallel streams" if a.split > 1 else ""), "weights": "seeded random + BN calibration (no checkpoints offline)"},
+                       "launch": ("hipGraph" if graph is not None else "eager") + (f", {a.split} sub-batches on parallel streams" if a.split > 1 else "")
+                                 + (f", {P} batches in flight" if P > 1 else ""), "weights": "seeded random + BN calibration (no checkpoints offline)"},
             "roofline": roof,
             "families": fams,
             "cpu_baseline": None,

@@ -90,3 +90,51 @@ def test_sub_batches_on_parallel_streams_equal_the_same_sub_batches_in_sequence(
             torch.cuda.synchronize()
             assert torch.equal(par.view(torch.int32), seq.view(torch.int32)), "concurrent sub-batch walks differ from the sequential ones"
     assert int(ops.nms_pack_views(seq.view(2, words), 8, 300)[1].sum()) > 0
+
+
+def test_two_captured_steps_in_flight_equal_one_at_a_time():
+    """bench.py --pipeline 2: step i + 1 is replayed on a second stream from a second captured graph (own result buffer, own private
+    memory pool) while step i still runs — two concurrent walks of ONE model over the SAME resident batch.  Both must produce bit for
+    bit what one eager step produces, replay after replay."""
+    import torch
+
+    sys.path.insert(0, str(ROOT))
+    from yolo_master_amd import ops
+    from yolo_master_amd.nms import nms_padded
+    from yolo_master_amd.nn.tasks import DetectionModel
+    from yolo_master_amd.weights import synth_input, synth_state_dict
+
+    dev = torch.device("cuda", 0)
+    m = DetectionModel("yolo-master-s.yaml")
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=0))
+    m.eval().to(dev).set_compute_dtype(torch.bfloat16)
+    x = synth_input(16, 320, 320, seed=6).to(dev)
+    words = ops.nms_pack_numel(16, 300)
+    with torch.inference_mode():
+        ref = torch.empty((words,), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            y, _ = m._predict_once(x)
+            nms_padded(y, 0.25, 0.7, pack=ref)
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        packs = [torch.empty((words,), dtype=torch.float32, device=dev) for _ in range(2)]
+        graphs = []
+        for st, pk in zip(streams, packs):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                y, _ = m._predict_once(x)
+                nms_padded(y, 0.25, 0.7, pack=pk)
+            graphs.append(g)
+        torch.cuda.synchronize()
+        for _ in range(4):
+            for pk in packs:
+                pk.zero_()
+            torch.cuda.synchronize()
+            for st, g in zip(streams, graphs):       # both in flight at once
+                with torch.cuda.stream(st):
+                    g.replay()
+            torch.cuda.synchronize()
+            for pk in packs:
+                assert torch.equal(pk.view(torch.int32), ref.view(torch.int32)), "a step replayed beside another differs from the eager step"
+    m.check_flags()
+    assert int(ops.nms_pack_views(ref, 16, 300)[1].sum()) > 0

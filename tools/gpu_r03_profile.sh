@@ -9,7 +9,7 @@ bash tools/gpu_profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1; echo "profi
 bash tools/gpu_pmc.sh $TAG "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_IDX_ACTIVE"
 ls -la gpurun_out | grep ${TAG}_
 cd /tmp && export TMPDIR=/tmp
-CFG5="python $R/bench.py --cfg yolo-master-moa-mot.yaml --scale l --imgsz 1280 --batch 16 --steps 3 --warmup 1 --no-cpu-baseline --no-graph --split 1"
+CFG5="python $R/bench.py --cfg yolo-master-moa-mot.yaml --scale l --imgsz 1280 --batch 16 --steps 3 --warmup 1 --no-cpu-baseline --no-graph --split 1 --pipeline 1"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_cfg5_trace -- $CFG5 > $R/gpurun_out/${TAG}_cfg5_trace.log 2>&1
 python $R/tools/prof_summary.py $(ls $R/gpurun_out/${TAG}_cfg5_trace/*/*.db | head -1) 7 > $R/gpurun_out/${TAG}_cfg5_kernel_stats.txt 2>&1
 rm -rf $R/gpurun_out/${TAG}_cfg5_trace

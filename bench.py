@@ -327,8 +327,9 @@ def main():
             elapsed = float(t.item())
         lat = sorted(e0.elapsed_time(e1) for e0, e1 in evs)                     # launch -> completion of a step's rank-local work
         p50_latency_ms = lat[len(lat) // 2]
-        per_step = sorted(evs[i][1].elapsed_time(evs[i + 1][1]) for i in range(a.steps - 1))   # completion to completion
-        p50_ms = per_step[len(per_step) // 2] if per_step else p50_latency_ms
+        # completion to completion, over windows of P steps (with several batches in flight completions come in bursts)
+        per_step = sorted(evs[i][1].elapsed_time(evs[i + P][1]) / P for i in range(a.steps - P))
+        p50_ms = per_step[len(per_step) // 2] if per_step else p50_latency_ms / P
         model.check_flags()                       # device flag words of the timed steps, read once after the loop
 
         # roofline leg: per-call HIP events around every op family (eager launches on this stream); the object

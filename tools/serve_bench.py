@@ -3,9 +3,9 @@
     host uint8 BGR frames (pinned) --H2D--> ymk_letterbox_preprocess -> forward -> batched NMS -> ymk_scale_boxes --D2H--> host (pinned)
 
 Reference steps: `BasePredictor.preprocess` (LetterBox + BGR->RGB + /255, engine/predictor.py:155-178), `_predict_once`, `non_max_suppression`,
-`scale_boxes` (models/yolo/detect/predict.py:109-122).  Two slots (device frame buffer + packed result buffer + pinned host result), one
-captured HIP graph per slot (letterbox -> ... -> scale_boxes), three streams: the H2D copy of batch i+1 and the D2H copy of batch i-1 run
-while batch i computes.  Reported next to the resident-input rate of bench.py (inputs already in HBM), which stays the headline value.
+`scale_boxes` (models/yolo/detect/predict.py:109-122).  Four slots (device frame buffer + packed result buffer + pinned host result + compute
+stream), one captured HIP graph per slot (letterbox -> ... -> scale_boxes), one H2D and one D2H stream: copies and the computes of
+consecutive batches overlap (as bench.py --pipeline).  Reported next to the resident-input rate of bench.py (inputs already in HBM), which stays the headline value.
 
     python tools/serve_bench.py [--frames 720x1280] [--batch 64] [--steps 30] [--dtype bf16]     -> one JSON line (profiles/r03_serve.json)
 """
@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--scale", default="s")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--serial", action="store_true", help="no overlap: copy in, compute, copy out one after the other (A/B)")
+    ap.add_argument("--slots", type=int, default=4, help="batches in flight (device frame buffer + packed result buffer + pinned host result + captured "
+                    "graph + compute stream each).  Measured: 2 -> 6.4 k, 3 -> 8.9 k, 4 -> 10.4 k, 5 -> 10.4 k, 6 -> 11.1 k images/s (720p frames); with ONE "
+                    "compute stream shared by two slots (the first version): 9.4-9.7 k")
     ap.add_argument("--split", type=int, default=1, help="sub-batches walked on parallel streams inside a slot's graph (as bench.py --split); "
                     "measured WORSE here: 2 -> 8.7-9.0 k images/s against 9.7 k (the copy engines' traffic shares the fabric with two compute streams)")
     a = ap.parse_args()
@@ -60,8 +63,9 @@ def main():
     sub_words = ops.nms_pack_numel(SUB, MAX_DET)
     words = a.split * sub_words          # per sub-batch: dets | idx | counts
     slots = []
-    for _ in range(2):
-        slots.append({"frames": torch.empty((B, fh, fw, 3), dtype=torch.uint8, device=dev), "x": torch.empty((B, 3, S, S), dtype=torch.float32, device=dev),
+    NS = max(2, a.slots)
+    for _ in range(NS):
+        slots.append({"stream": torch.cuda.Stream(device=dev), "frames": torch.empty((B, fh, fw, 3), dtype=torch.uint8, device=dev), "x": torch.empty((B, 3, S, S), dtype=torch.float32, device=dev),
                       "pack": torch.empty((words,), dtype=torch.float32, device=dev), "host": torch.empty((words,), dtype=torch.float32).pin_memory()})
     params = postprocess._params((S, S), [(fh, fw)] * B, None, dev)
 
@@ -86,26 +90,27 @@ def main():
         for st in side:
             cur.wait_stream(st)
 
-    s_in, s_cmp, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     with torch.inference_mode():
-        with torch.cuda.stream(s_cmp):
-            for sl in slots:
+        for sl in slots:
+            with torch.cuda.stream(sl["stream"]):
                 sl["frames"].copy_(host_frames[0], non_blocking=True)
                 compute(sl)
             torch.cuda.synchronize()
-            model.check_flags()
-            for sl in slots:
-                sl["graph"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(sl["graph"], stream=s_cmp):
-                    compute(sl)
+        model.check_flags()
+        for sl in slots:
+            sl["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(sl["graph"], stream=sl["stream"]):
+                compute(sl)
         torch.cuda.synchronize()
 
         def run(n):
-            ev_in = [None, None]      # H2D of the batch in this slot finished
-            ev_cmp = [None, None]     # compute of the batch in this slot finished (frames consumed, pack written)
-            ev_out = [None, None]     # D2H of this slot's pack finished (pack may be overwritten)
+            ev_in = [None] * NS       # H2D of the batch in this slot finished
+            ev_cmp = [None] * NS      # compute of the batch in this slot finished (frames consumed, pack written)
+            ev_out = [None] * NS      # D2H of this slot's pack finished (pack may be overwritten)
             for i in range(n):
-                sl, k = slots[i % 2], i % 2
+                sl, k = slots[i % NS], i % NS
+                s_cmp = sl["stream"]  # a compute stream per slot: consecutive batches overlap as in bench.py --pipeline
                 with torch.cuda.stream(s_in):
                     if ev_cmp[k] is not None:
                         s_in.wait_event(ev_cmp[k])          # the previous batch in this slot has been read
@@ -129,13 +134,13 @@ def main():
         t0 = time.perf_counter()
         run(a.steps)
         dt = time.perf_counter() - t0
-    dets, counts, _ = ops.nms_pack_views(slots[(a.steps - 1) % 2]["host"].view(a.split, sub_words), SUB, MAX_DET)
+    dets, counts, _ = ops.nms_pack_views(slots[(a.steps - 1) % NS]["host"].view(a.split, sub_words), SUB, MAX_DET)
     h2d_mb, d2h_mb = B * fh * fw * 3 / 1e6, words * 4 / 1e6
     print(json.dumps({"metric": "images/sec, pipelined serving step (host uint8 frames -> letterbox -> forward -> NMS -> scale_boxes -> host)",
                       "value": round(B * a.steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / a.steps * 1e3, 4), "steps": a.steps,
                       "dtype": a.dtype, "overlap": not a.serial,
                       "config": {"workload": f"YOLO-Master-{a.scale.upper()}, {B} frames of {fh}x{fw}x3 uint8 per step -> 640x640", "h2d_mb_per_step": round(h2d_mb, 1),
-                                 "d2h_mb_per_step": round(d2h_mb, 2), "launch": f"one hipGraph per slot ({a.split} sub-batches on parallel streams inside it), 2 slots, 3 streams"},
+                                 "d2h_mb_per_step": round(d2h_mb, 2), "launch": f"one hipGraph per slot, {NS} slots each with its compute stream, one H2D and one D2H stream"},
                       "detections_last_batch": int(counts.sum())}))
 
 

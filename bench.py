@@ -289,12 +289,13 @@ def main():
             try:
                 for sl in slots:
                     g = torch.cuda.CUDAGraph()
+                    # N > 1: the process group's watchdog thread polls events while this thread captures — capture errors are scoped to
+                    # the capturing thread there (hipStreamCaptureModeThreadLocal), so that its calls cannot invalidate the capture
+                    kw = {"capture_error_mode": "thread_local"} if world > 1 else {}
                     if sl.stream is not None:
-                        with torch.cuda.graph(g, stream=sl.stream):
-                            sl.static_out = sl.local_step()
-                    else:
-                        with torch.cuda.graph(g):
-                            sl.static_out = sl.local_step()
+                        kw["stream"] = sl.stream
+                    with torch.cuda.graph(g, **kw):
+                        sl.static_out = sl.local_step()
                     sl.graph = g
                     g.replay()
                     torch.cuda.synchronize()

@@ -109,7 +109,7 @@ def sq_utilisation(family: str):
 
 def cpu_baseline(scale: str, seconds_budget: float = 20.0):
     """Oracle (CPU fp32 restatement of the reference path, kind="port") timed on this host's cores on a
-    bounded sample of the same workload: forward + NMS on a few 640x640 images."""
+    bounded sample of the same workload: forward + NMS on a few 640x640 images, forward only beside it."""
     from oracle import model_ref, nms_ref
     from yolo_master_amd.nn.tasks import DetectionModel, yaml_model_load
     from yolo_master_amd.weights import synth_input, synth_state_dict
@@ -120,26 +120,37 @@ def cpu_baseline(scale: str, seconds_budget: float = 20.0):
     sd = synth_state_dict(DetectionModel(cfg).state_dict(), seed=0)
     B = 4
     x = synth_input(B, 640, 640, seed=1)
-    times = []
+    times, fwd = [], []
     with torch.inference_mode():
         model_ref.forward(cfg, sd, x[:1])  # warm-up (thread pool, oneDNN primitive cache)
         t_all = time.time()
         while len(times) < 5 and (time.time() - t_all < seconds_budget or len(times) < 1):
             t0 = time.time()
             y, _, _ = model_ref.forward(cfg, sd, x)
+            t1 = time.time()
             nms_ref.non_max_suppression(y.numpy(), 0.25, 0.7)
             times.append(time.time() - t0)
-    times.sort()
-    p50 = times[len(times) // 2]
-    out = {"value": round(B / p50, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            fwd.append(t1 - t0)
+    out = {"value": round(B / _p50(times), 3), "unit": "images/sec", "cores": cores, "kind": "port",
+           "forward_only_value": round(B / _p50(fwd), 3),
            "sample": f"oracle forward+NMS, YOLO-Master-{scale.upper()} fp32, {B}x3x640x640, {len(times)} timed passes (p50)"}
-    # the REAL reference timed beside this port on the build host (the GPU box has no reference checkout): tools/cpu_reference_timing.py
-    try:
-        ref = json.load(open(ROOT / "profiles" / "r03_cpu_reference.json"))
-        out["reference_on_build_host"] = {k: ref[k] for k in ("reference_images_per_s", "port_images_per_s", "cores", "host", "sample")}
-    except Exception:
-        pass
+    # the REAL reference timed beside this port (tools/cpu_reference_timing.py): on the GPU box's host when a reference checkout was
+    # staged for that call (profiles/*_cpu_reference_gpubox.json), else on the build host (the GPU box has no reference checkout)
+    import glob
+
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*_cpu_reference*.json")), reverse=True):
+        try:
+            ref = json.load(open(f))
+            out["reference_timed_beside"] = {"file": os.path.basename(f), **{k: ref[k] for k in ref if k != "same_detection_counts"}}
+            break
+        except Exception:
+            continue
     return out
+
+
+def _p50(v):
+    v = sorted(v)
+    return v[len(v) // 2]
 
 
 def main():
@@ -149,32 +160,46 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scale", default="s")
     ap.add_argument("--cfg", default=None, help="model YAML other than the v0 detector, e.g. yolo-master-moa-mot.yaml with --scale l "
-                    "--imgsz 1280 --batch 16 for BASELINE config 5")
+                    "--imgsz 1280 --batch 16 --dtype f16 --cluster --sigma 0.1 --dense --imbalance 8,3 for BASELINE config 5")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="compute type: bf16 (BASELINE config 3), f16 (the reference's "
-                    "half=True precision, libymk_f16.so), f32 (the exact-parity configuration, BASELINE config 2's type)")
+                    "half=True precision, libymk_f16.so; config 5), f32 (the exact-parity configuration, BASELINE config 2's type)")
+    ap.add_argument("--cluster", action="store_true", help="Cluster-Weighted NMS box refinement after the greedy pass (config 5: 'CW-NMS')")
+    ap.add_argument("--sigma", type=float, default=0.1, help="CW-NMS kernel width (cfg/default.yaml:196-197)")
+    ap.add_argument("--dense", action="store_true", help="dense-scene NMS settings: the validator's conf 0.001 + multi_label (SURVEY 8(d): up to "
+                    "max_nms = 30 000 candidates per image reach the ordering / greedy stages)")
+    ap.add_argument("--imbalance", default=None, help="expert-imbalance stress A[,T]: expert 0's router logit raised by A in the per-image routers and "
+                    "by T (default 3 A / 8) in the per-token routers (SURVEY 8(d) 'imbalance knob'; the config-5 fixture uses 8,3: every image / "
+                    "token routes to expert 0)")
     ap.add_argument("--roofline-kernel", default=None, help="op family to report in `roofline` (default: the one with the largest share of the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("YMK_BENCH_PIPELINE", "3")), help="batches in flight: step i + 1 (and i + 2) "
-                    "is launched (own stream, own captured graph, own result buffers) while step i is still running — what a throughput-"
-                    "oriented server does with several streams; 1 = one step at a time (lowest latency per batch).  Measured on MI355X, "
-                    "S / 64 x 640^2 bf16: 1 -> 5.90, 2 -> 5.10, 3 -> 4.97, 4 -> 5.37 ms per step; latency per batch 5.9 / 10.1 / 14.8 ms")
+    ap.add_argument("--no-sync-leg", action="store_true", help="skip the synchronised one-batch-at-a-time leg (`value_sync`)")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("YMK_BENCH_PIPELINE", "3")), help="batches in flight in the TIMED region: step "
+                    "i + 1 (and i + 2) is launched (own stream, own captured graph, own result buffers) while step i is still running — what a "
+                    "throughput-oriented server does with several streams; 1 = one step at a time.  `value` is this region's rate; the "
+                    "one-batch-at-a-time rate of the reference's own convention is ALWAYS reported beside it as `value_sync`")
     ap.add_argument("--split", type=int, default=int(os.environ.get("YMK_BENCH_SPLIT", "1")), help="walk the batch as this many sub-batches on "
-                    "as many HIP streams inside the one captured graph (same images, same results per image): the latency-bound "
-                    "launches of the small maps of one sub-batch overlap the other's.  With ONE batch in flight 2 is best (5.70 vs 5.99 ms); "
-                    "with several batches in flight whole-batch kernels are (split 2 x pipeline 3: 5.38 ms)")
+                    "as many HIP streams inside the one captured graph (timed region)")
+    ap.add_argument("--sync-split", type=int, default=int(os.environ.get("YMK_BENCH_SYNC_SPLIT", "2")), help="the same for the synchronised leg "
+                    "(one batch in flight: the latency-bound launches of the small maps of one sub-batch overlap the other's)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the N > 1 code path (weight broadcast, "
+                    "thread-local graph capture, one packed all_gather per step on the launching stream) at WORLD_SIZE = 1: the multi-GPU path's "
+                    "smoke test on a 1-GPU box")
     a = ap.parse_args()
 
     from yolo_master_amd import ops
     from yolo_master_amd.dist import broadcast_state_dict, gather_packed, init_from_env
     from yolo_master_amd.nms import nms_padded
     from yolo_master_amd.nn.tasks import DetectionModel
-    from yolo_master_amd.weights import synth_input, synth_state_dict
+    from yolo_master_amd.weights import expert_imbalance, synth_input, synth_state_dict
 
+    if a.force_dist:
+        os.environ["YMK_DIST_FORCE"] = "1"
     rank, local, world = init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    distributed = world > 1 or (a.force_dist and dist.is_initialized())
     if os.environ.get("YMK_BENCH_SHARE_GPU"):  # functional test of the N>1 flow on a 1-GPU box (gloo, all ranks on cuda:0)
         local = 0
     torch.cuda.set_device(local)
@@ -191,61 +216,89 @@ def main():
         cfg.setdefault("scales", {}).setdefault(a.scale, v0[a.scale])
         cfg["scale"] = a.scale
         model = DetectionModel(cfg)
+    imb = None
     if rank == 0:
-        model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
+        sd = synth_state_dict(model.state_dict(), seed=0)
+        if a.imbalance:
+            v = [float(t) for t in a.imbalance.split(",")]
+            imb = (v[0], v[1] if len(v) > 1 else v[0] * 3.0 / 8.0)
+            sd = expert_imbalance(sd, *imb)
+        model.load_state_dict(sd)
     model.eval().to(dev)
     broadcast_state_dict(model, src=0)       # weight replication over xGMI (RCCL broadcast)
     model.set_compute_dtype(dtype)
     x = synth_input(a.batch, a.imgsz, a.imgsz, seed=1 + rank).to(dev)   # resident in HBM before timing
 
     MAX_DET = 300
-    assert a.batch % a.split == 0, "--split must divide --batch"
-    SUB = a.batch // a.split
-    sub_words = ops.nms_pack_numel(SUB, MAX_DET)
-    xs = list(x.split(SUB))
+    CONF, IOU, MULTI = (0.001, 0.7, True) if a.dense else (0.25, 0.7, False)
+    nms_kw = dict(max_det=MAX_DET, multi_label=MULTI, cluster=a.cluster, sigma=a.sigma)
     P = max(1, a.pipeline)
 
     class Slot:
         """One batch in flight: its own stream, packed result buffer (per sub-batch: dets | idx | counts), gather buffer, side streams and
-        captured graph.  --pipeline 2: step i + 1 is launched on the other slot while step i is still running (the batch is the same
-        64 images per step; what overlaps is the tail of one step — NMS, the 20 x 20 maps — with the head of the next)."""
+        captured graph.  split: the batch walked as that many sub-batches on parallel streams inside the one graph.  nms=False: the
+        forward pass alone (the synchronised leg reports forward-only next to forward + NMS)."""
 
-        def __init__(self):
-            self.stream = torch.cuda.Stream(device=dev) if P > 1 else None
-            self.pack = torch.empty((a.split * sub_words,), dtype=torch.float32, device=dev)
-            self.gathered = torch.empty((world, self.pack.numel()), dtype=torch.float32, device=dev) if world > 1 else None
-            self.side = [torch.cuda.Stream(device=dev) for _ in range(a.split - 1)]
+        def __init__(self, split, own_stream, nms=True):
+            assert a.batch % split == 0, "--split / --sync-split must divide --batch"
+            self.split, self.nms, self.sub = split, nms, a.batch // split
+            self.sub_words = ops.nms_pack_numel(self.sub, MAX_DET)
+            self.xs = list(x.split(self.sub))
+            self.stream = torch.cuda.Stream(device=dev) if own_stream else None
+            self.pack = torch.empty((split * self.sub_words,), dtype=torch.float32, device=dev)
+            self.gathered = torch.empty((world, self.pack.numel()), dtype=torch.float32, device=dev) if distributed else None
+            self.side = [torch.cuda.Stream(device=dev) for _ in range(split - 1)]
             self.graph, self.static_out, self.gathered_ev = None, None, None
 
         def sub_step(self, i):
-            y, _ = model._predict_once(xs[i])
-            return nms_padded(y, 0.25, 0.7, max_det=MAX_DET, pack=self.pack[i * sub_words:(i + 1) * sub_words])
+            y, _ = model._predict_once(self.xs[i])
+            if not self.nms:
+                return y
+            return nms_padded(y, CONF, IOU, pack=self.pack[i * self.sub_words:(i + 1) * self.sub_words], **nms_kw)
 
         def local_step(self):
-            """Forward + NMS of this rank's images.  --split S: S sub-batches, the first on the current stream and the others on side
+            """Forward + NMS of this rank's images.  split S: S sub-batches, the first on the current stream and the others on side
             streams forked from / joined into it (inside a captured graph these become parallel branches), each with its own slice of
             the packed result buffer."""
             cur = torch.cuda.current_stream()
             for st in self.side:
                 st.wait_stream(cur)
-            outs = [None] * a.split
+            outs = [None] * self.split
             for i, st in enumerate(self.side, start=1):
                 with torch.cuda.stream(st):
                     outs[i] = self.sub_step(i)
             outs[0] = self.sub_step(0)
             for st in self.side:
                 cur.wait_stream(st)
-            dets, counts, idx = ops.nms_pack_views(self.pack.view(a.split, sub_words), SUB, MAX_DET)
+            if not self.nms:
+                return outs
+            dets, counts, idx = ops.nms_pack_views(self.pack.view(self.split, self.sub_words), self.sub, MAX_DET)
             return dets, counts, idx, outs[0][3]
 
         def finish(self, local_out):
             """What follows the rank-local work of a step: for N>1 ONE RCCL all_gather of the packed results (dets | idx | counts,
             written in place by the NMS kernels), outside the captured graph: a collective is not part of the rank-local launch
             sequence.  Every rank issues its collectives on ONE stream in step order (the launching stream), whatever the pipeline depth."""
+            if not self.nms:
+                return local_out
             dets, counts, idx, status = local_out
-            if world > 1:
-                dets, counts, idx = ops.nms_pack_views(gather_packed(self.pack, out=self.gathered).view(world, a.split, sub_words), SUB, MAX_DET)
+            if distributed:
+                dets, counts, idx = ops.nms_pack_views(gather_packed(self.pack, out=self.gathered).view(world, self.split, self.sub_words),
+                                                       self.sub, MAX_DET)
             return dets, counts, status
+
+        def capture(self):
+            g = torch.cuda.CUDAGraph()
+            # N > 1: the process group's watchdog thread polls events while this thread captures — capture errors are scoped to
+            # the capturing thread there (hipStreamCaptureModeThreadLocal), so that its calls cannot invalidate the capture
+            kw = {"capture_error_mode": "thread_local"} if distributed else {}
+            if self.stream is not None:
+                kw["stream"] = self.stream
+            with torch.cuda.graph(g, **kw):
+                self.static_out = self.local_step()
+            self.graph = g
+            g.replay()
+            torch.cuda.synchronize()
 
         def run(self):
             """Launch one step on this slot; returns (start, end) events of its rank-local work."""
@@ -274,44 +327,50 @@ def main():
             self.gathered_ev = main.record_event()
             return e0, e1
 
-    slots = [Slot() for _ in range(P)]
+    slots = [Slot(a.split, P > 1) for _ in range(P)]
+    sync_slots = [] if a.no_sync_leg else [Slot(a.sync_split, False), Slot(a.sync_split, False, nms=False)]
+
+    def max_over_ranks(v: float) -> float:
+        if not distributed:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     with torch.inference_mode():
-        for sl in slots:
+        for sl in slots + sync_slots:
             ctx = torch.cuda.stream(sl.stream) if sl.stream is not None else torch.cuda.stream(torch.cuda.current_stream())
             with ctx:
-                for _ in range(max(a.warmup // P, 1)):
+                for _ in range(max(a.warmup // P, 1) if sl in slots else 2):
                     sl.finish(sl.local_step())
             torch.cuda.synchronize()
         model.check_flags()
         graph = None
         if not a.no_graph:   # the rank-local step (forward + NMS) is one captured HIP graph at every N (one per slot)
             try:
-                for sl in slots:
-                    g = torch.cuda.CUDAGraph()
-                    # N > 1: the process group's watchdog thread polls events while this thread captures — capture errors are scoped to
-                    # the capturing thread there (hipStreamCaptureModeThreadLocal), so that its calls cannot invalidate the capture
-                    kw = {"capture_error_mode": "thread_local"} if world > 1 else {}
-                    if sl.stream is not None:
-                        kw["stream"] = sl.stream
-                    with torch.cuda.graph(g, **kw):
-                        sl.static_out = sl.local_step()
-                    sl.graph = g
-                    g.replay()
-                    torch.cuda.synchronize()
+                for sl in slots + sync_slots:
+                    sl.capture()
                 graph = slots[0].graph
             except Exception as e:  # pragma: no cover
                 if rank == 0:
                     print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
-                for sl in slots:
+                for sl in slots + sync_slots:
                     sl.graph, sl.static_out = None, None
                 graph = None
                 torch.cuda.synchronize()
 
-        for sl in slots:
-            sl.run()
+        # clocks: the chip ramps for tens of milliseconds after a host-side pause (graph capture) — untimed replays until 0.3 s of
+        # device work have run, so that a short timed region (the driver's 20 steps = 0.1 s) is not measured on the ramp
+        t_spin = time.perf_counter()
+        while True:
+            for sl in slots:
+                sl.run()
+            torch.cuda.synchronize()
+            if time.perf_counter() - t_spin > 0.3:
+                break
 
-        if world > 1:
+        # ---------------------------------------------------------------- the timed region: exactly K steps between barriers
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -319,33 +378,51 @@ def main():
         for i in range(a.steps):
             evs.append(slots[i % P].run())
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        lat = sorted(e0.elapsed_time(e1) for e0, e1 in evs)                     # launch -> completion of a step's rank-local work
-        p50_latency_ms = lat[len(lat) // 2]
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        p50_latency_ms = _p50([e0.elapsed_time(e1) for e0, e1 in evs])          # launch -> completion of a step's rank-local work
         # completion to completion, over windows of P steps (with several batches in flight completions come in bursts)
-        per_step = sorted(evs[i][1].elapsed_time(evs[i + P][1]) / P for i in range(a.steps - P))
-        p50_ms = per_step[len(per_step) // 2] if per_step else p50_latency_ms / P
+        per_step = [evs[i][1].elapsed_time(evs[i + P][1]) / P for i in range(a.steps - P)]
+        p50_ms = _p50(per_step) if per_step else p50_latency_ms / P
         model.check_flags()                       # device flag words of the timed steps, read once after the loop
+
+        # ---------------------------------------------------------------- synchronised leg: the reference's own convention
+        # benchmarks/suite.py:316-330: synchronise, run ONE batch, synchronise, wall-clock; throughput = bs * 1000 / p50_ms; warm-up 10,
+        # >= 30 measured (reports/issues-52...md:135).  One batch in flight, forward + NMS (+ gather for N > 1) and forward only.
+        sync = None
+        if sync_slots:
+            sync = {}
+            n_meas = max(30, a.steps)
+            for tag, sl in (("forward_nms", sync_slots[0]), ("forward_only", sync_slots[1])):
+                ts = []
+                for i in range(10 + n_meas):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    sl.run()
+                    torch.cuda.synchronize()
+                    if i >= 10:
+                        ts.append((time.perf_counter() - t1) * 1e3)
+                sync[tag] = max_over_ranks(_p50(ts))
+            model.check_flags()
 
         # roofline leg: per-call HIP events around every op family (eager launches on this stream); the object
         # reported is the family with the largest share of the step, the rest go into "families"
-        roof, fams = None, None
+        roof, fams, retained, n_calls = None, None, None, None
         if rank == 0:
             try:
                 ops.TIMER.start()
                 for _ in range(3):
                     y_, _ = model._predict_once(x)   # the whole batch on ONE stream (per-op events; no collective outside the lock-step timed loop)
-                    nms_padded(y_, 0.25, 0.7, max_det=MAX_DET)
+                    nms_padded(y_, CONF, IOU, **nms_kw)
                 torch.cuda.synchronize()
                 recs = ops.TIMER.records
                 shapes = list(getattr(ops.TIMER, "shapes", []))
                 ops.TIMER.stop()
+                n_calls = len(recs) // 3
+                # routed (image, expert) pairs per ES-MoE layer of this batch (of B x top_k possible): what the expert stages' bytes scale with
+                retained = {f"model.{i}": int((m.last_route["gate_w"] > 0).sum()) for i, m in enumerate(model.model)
+                            if getattr(m, "last_route", None) and "gate_w" in m.last_route}
                 if os.environ.get("YMK_BENCH_CALLS"):   # every op call of one step with its shape, time, GB/s and TFLOP/s (diagnostics)
                     n1 = len(recs) // 3
                     rows = []
@@ -397,8 +474,9 @@ def main():
 
     if rank == 0:
         total_images = world * a.batch * a.steps
-        headline = a.cfg is None and (a.scale, a.batch, a.imgsz, a.dtype) == ("s", 64, 640, "bf16")
+        headline = a.cfg is None and (a.scale, a.batch, a.imgsz, a.dtype) == ("s", 64, 640, "bf16") and not (a.dense or a.cluster or a.imbalance)
         cfgtag = ("BASELINE.json configs[2]" + ("/[3]" if world > 1 else "")) if headline else "not the headline configuration"
+        nms_tag = f"NMS conf {CONF} IoU {IOU}" + (" multi_label" if MULTI else "") + (f" + CW-NMS sigma {a.sigma}" if a.cluster else "")
         res = {
             "metric": "images/sec @ 640x640 bs=64, YOLO-Master-S; per-image p50 latency" if headline else
                       f"images/sec @ {a.imgsz}x{a.imgsz} bs={a.batch}, {a.cfg or 'YOLO-Master-' + a.scale.upper()} scale {a.scale} {a.dtype} "
@@ -406,13 +484,28 @@ def main():
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "p50_ms_per_image": round(p50_ms / a.batch, 5), "p50_batch_latency_ms": round(p50_latency_ms, 4),
+            # `value`: K steps between the barriers with `pipeline_depth` batches in flight.  `value_sync`: ONE batch at a time,
+            # synchronised wall-clock per batch, bs * 1000 / p50 — the reference's own convention (benchmarks/suite.py:316-330)
+            "pipeline_depth": P,
+            "value_sync": round(world * a.batch * 1e3 / sync["forward_nms"], 2) if sync else None,
+            "p50_batch_ms_sync": round(sync["forward_nms"], 4) if sync else None,
+            "p50_ms_per_image_sync": round(sync["forward_nms"] / a.batch, 5) if sync else None,
+            "forward_only_sync": {"images_per_s": round(world * a.batch * 1e3 / sync["forward_only"], 2),
+                                  "p50_batch_ms": round(sync["forward_only"], 4)} if sync else None,
+            "p50_inter_completion_ms_per_image": round(p50_ms / a.batch, 5),     # inverse throughput of the pipelined region, not a latency
+            "p50_batch_latency_ms": round(p50_latency_ms, 4),                    # launch -> completion of one batch INSIDE the pipelined region
             "config": {"workload": (f"YOLO-Master-{a.scale.upper()} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, "
                                     f"bs={a.batch}/GPU, ES-MoE top-k=2 ({cfgtag})") if a.cfg is None else
                                    f"{a.cfg} at scale {a.scale} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, bs={a.batch}/GPU (not the headline configuration)",
                        "global_batch": world * a.batch, "imgsz": a.imgsz, "parallelism": f"dp{world} (image shards, no data-path collective)",
                        "launch": ("hipGraph" if graph is not None else "eager") + (f", {a.split} sub-batches on parallel streams" if a.split > 1 else "")
-                                 + (f", {P} batches in flight" if P > 1 else ""), "weights": "seeded random + BN calibration (no checkpoints offline)"},
+                                 + (f", {P} batches in flight" if P > 1 else ""),
+                       "sync_launch": None if not sync else ("hipGraph" if graph is not None else "eager") + f", one batch in flight, {a.sync_split} sub-batches on parallel streams",
+                       "nms": nms_tag, "imbalance": None if not a.imbalance else a.imbalance,
+                       "collectives": ("RCCL (nccl) process group: weight broadcast + one packed all_gather per step" + (" — forced at world size 1" if world == 1 else ""))
+                                      if distributed else None,
+                       "weights": "seeded random + BN calibration (no checkpoints offline)"},
+            "op_calls_per_step": n_calls, "retained_pairs": retained,
             "roofline": roof,
             "families": fams,
             "cpu_baseline": None,
@@ -423,7 +516,7 @@ def main():
             except Exception as e:  # never lose the measured line to the host-side baseline
                 print(f"[bench] cpu_baseline failed ({type(e).__name__}: {e})", file=sys.stderr)
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YMK_ABI_VERSION 2
+#define YMK_ABI_VERSION 3
 
 /* error codes */
 #define YMK_OK 0
@@ -309,20 +309,27 @@ int ymk_detect_decode(const float* box_l, const float* cls_l, float* y, int32_t 
  * greedy semantics (nms.py:245-302): candidates conf > thres (best class, or
  * every class when multi_label), stable score-descending order, cap max_nms,
  * class offset cls*max_wh, suppress IoU > iou_thres, first max_det kept.
- * y: fp32 [B][4+nc][A] as produced by ymk_detect_decode (not modified).
+ * y: fp32 [B][4+nc+extra][A] as produced by ymk_detect_decode (not modified).  extra: rows behind the class rows that
+ * are carried, not scored (utils/nms.py:76-81 `extra = shape[1] - nc - 4`: the mask coefficients of a Segment head); 0 for Detect.
  * out_dets fp32 [B][max_det][6] (x1,y1,x2,y2,conf,cls); out_counts int32 [B];
  * out_idx int32 [B][max_det] anchor index of each kept detection
  * (return_idxs=True of the reference); status int32 [1] YMK_FLAG_NMS_OVERFLOW.
  * ------------------------------------------------------------------------ */
 size_t ymk_nms_workspace_bytes(int32_t B, int32_t nc, int32_t A, int32_t multi_label,
                                int32_t max_nms);
-int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A, float conf_thres,
+int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t extra, int32_t A, float conf_thres,
                     float iou_thres, int32_t multi_label, int32_t agnostic, int32_t max_det,
                     int32_t max_nms, float max_wh, const uint8_t* class_keep /*[nc] or NULL*/,
                     float* out_dets, int32_t* out_counts, int32_t* out_idx, int32_t* status,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* class_keep: the `classes=` filter of non_max_suppression (utils/nms.py:63,132): a candidate survives only when
  * class_keep[its class] != 0; applied after the best-class choice of the single-label path, as the reference does. */
+
+/* The carried rows of the kept detections (utils/nms.py:117,122,127: the `mask` columns of each output row):
+ * out fp32 [B][max_det][extra], out[b][j][k] = y[b][row0 + k][out_idx[b][j]] for j < out_counts[b], zeros behind the count.
+ * rows = 4 + nc + extra of y, row0 = 4 + nc. */
+int ymk_nms_gather_rows(const float* y, int32_t B, int32_t rows, int32_t A, int32_t row0, int32_t extra, const int32_t* out_idx,
+                        const int32_t* out_counts, int32_t max_det, float* out, void* stream);
 
 /* Cluster-weighted box refinement (CW-NMS).  Not implemented in the reference's
  * Python; algorithm spec = examples/YOLO-Master-Cross-Platform-Edge-Deployment/

@@ -93,9 +93,11 @@ int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int32_t ldw, i
 
 /* Decision tail of the gated MoE (moe/gated.py:124-166, 455-492), one workgroup.  g / loc fp32 [B][ld*] logits of the
  * two router streams, cplx fp32 [B][ldc] complexity logit; outputs w fp32 [B][top_k], idx int32 [B][top_k] (and its
- * transpose), probs fp32 [B][E].  E <= 64, top_k <= 8. */
+ * transpose), probs fp32 [B][E].  E <= 64, top_k <= 8.
+ * clamp_mode: 1 = softmax(clamp(l, +-30) * inv_temp) (gated.py:141-142); 2 = softmax(clamp(l * inv_temp, +-30)) (gated.py:972);
+ * 0 = softmax(l * inv_temp), a router's own unclamped softmax (gated.py:958, routers.py:207). */
 int ymk_gated_route_decide(const float* g, int32_t ldg, const float* loc, int32_t ldloc, const float* cplx, int32_t ldc,
-                           int32_t B, int32_t E, float alpha, float inv_temp, int32_t top_k, float* w, int32_t* idx,
+                           int32_t B, int32_t E, float alpha, float inv_temp, int32_t clamp_mode, int32_t top_k, float* w, int32_t* idx,
                            int32_t* idx_slot_major /* [top_k][B]: the expert of image j*B + b of ymk_expert_gather's output */,
                            float* probs, void* stream);
 

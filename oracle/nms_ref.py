@@ -58,15 +58,18 @@ def nms_greedy(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
 
 
 def non_max_suppression(pred: np.ndarray, conf_thres=0.25, iou_thres=0.45, multi_label=False, agnostic=False,
-                        max_det=300, max_nms=30000, max_wh=7680, return_idxs=False, classes=None):
-    """pred: [B, 4+nc, A] float32 (xywh + class scores).  Returns list of [n,6] (xyxy, conf, cls).
-    classes: keep only candidates of these class ids (utils/nms.py:63,131-136: after the best-class choice)."""
+                        max_det=300, max_nms=30000, max_wh=7680, return_idxs=False, classes=None, nc=0):
+    """pred: [B, 4+nc(+extra), A] float32 (xywh + class scores + carried rows).  Returns list of [n,6+extra] (xyxy, conf, cls, extra).
+    classes: keep only candidates of these class ids (utils/nms.py:63,131-136: after the best-class choice).
+    nc: number of classes (utils/nms.py:76-81: `nc = nc or shape[1] - 4`, `extra = shape[1] - nc - 4` mask columns are carried)."""
     pred = np.asarray(pred, f32)
     B, ch, A = pred.shape
-    nc = ch - 4
+    nc = nc or ch - 4
+    extra = ch - nc - 4
+    mi = 4 + nc
     multi_label = multi_label and nc > 1
     conf_thres = f32(conf_thres)
-    xc = pred[:, 4:].max(1) > conf_thres
+    xc = pred[:, 4:mi].max(1) > conf_thres
     p = np.transpose(pred, (0, 2, 1)).copy()
     p[..., :4] = xywh2xyxy(p[..., :4])
     outs, idxs = [], []
@@ -74,24 +77,24 @@ def non_max_suppression(pred: np.ndarray, conf_thres=0.25, iou_thres=0.45, multi
         x = p[b][xc[b]]
         xk = np.arange(A)[xc[b]]
         if x.shape[0] == 0:
-            outs.append(np.zeros((0, 6), f32)); idxs.append(np.zeros((0,), np.int64)); continue
-        box, cls = x[:, :4], x[:, 4:]
+            outs.append(np.zeros((0, 6 + extra), f32)); idxs.append(np.zeros((0,), np.int64)); continue
+        box, cls, mask = x[:, :4], x[:, 4:mi], x[:, mi:]
         if multi_label:
             i, j = np.where(cls > conf_thres)
-            x = np.concatenate((box[i], cls[i, j][:, None], j[:, None].astype(f32)), 1)
+            x = np.concatenate((box[i], cls[i, j][:, None], j[:, None].astype(f32), mask[i]), 1)
             xk = xk[i]
         else:
             j = cls.argmax(1)
             conf = cls[np.arange(cls.shape[0]), j]
             filt = conf > conf_thres
-            x = np.concatenate((box, conf[:, None], j[:, None].astype(f32)), 1)[filt]
+            x = np.concatenate((box, conf[:, None], j[:, None].astype(f32), mask), 1)[filt]
             xk = xk[filt]
         if classes is not None:
             filt = (x[:, 5:6] == np.asarray(classes, f32).reshape(1, -1)).any(1)
             x, xk = x[filt], xk[filt]
         n = x.shape[0]
         if n == 0:
-            outs.append(np.zeros((0, 6), f32)); idxs.append(np.zeros((0,), np.int64)); continue
+            outs.append(np.zeros((0, 6 + extra), f32)); idxs.append(np.zeros((0,), np.int64)); continue
         if n > max_nms:
             filt = np.argsort(-x[:, 4], kind="stable")[:max_nms]
             x, xk = x[filt], xk[filt]

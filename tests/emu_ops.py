@@ -333,13 +333,25 @@ def detect_decode(box_l, cls_l, y, stride, a_off, reg_max):
     return y
 
 
-def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, cw_sigma=None, cw_pool=3000, class_keep=None, pack=None):
+def nms_gather_rows(y, nc, idx, counts, out=None):
+    _count("nms_gather_rows")
+    B, ch, A = y.shape
+    extra, max_det = ch - 4 - nc, idx.shape[1]
+    res = torch.zeros((B, max_det, extra), dtype=torch.float32)
+    for b in range(B):
+        n = int(counts[b])
+        res[b, :n] = y[b, 4 + nc:, idx[b, :n].long()].t()
+    return res
+
+
+def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, cw_sigma=None, cw_pool=3000, class_keep=None, pack=None, nc=0):
     _count("nms_batched")
     assert cw_sigma is None, "CW refinement is checked on the GPU against oracle/_ref"
     B = y.shape[0]
     classes = None if class_keep is None else torch.nonzero(class_keep).view(-1).tolist()
     outs, idxs = nms_ref.non_max_suppression(y.numpy(), conf, iou, multi_label, agnostic, max_det, max_nms, max_wh,
-                                             return_idxs=True, classes=classes)
+                                             return_idxs=True, classes=classes, nc=nc)
+    outs = [np.asarray(o, np.float32)[:, :6] for o in outs]
     if pack is not None:                     # the three outputs carved from one buffer (ops.nms_pack_views), zeroed like the kernel does
         from yolo_master_amd import ops as _ops
 
@@ -568,12 +580,17 @@ def token_softmax(logits, n, inv_temp, top_k=0, out=None):
     return _put(w, out, torch.float32), active
 
 
-def gated_route_decide(g_logits, loc_logits, alpha, inv_temp, top_k, cplx_logit):
+def gated_route_decide(g_logits, loc_logits, alpha, inv_temp, top_k, cplx_logit, clamp=1):
     _count("gated_route_decide")
     B, E = g_logits.shape[0], g_logits.shape[-1]
     a = 1.0 / (1.0 + float(np.exp(-alpha)))
-    logits = (a * g_logits.reshape(B, E) + (1 - a) * loc_logits.reshape(B, E)).clamp(-30.0, 30.0)
-    probs = torch.softmax(logits * inv_temp, 1)
+    logits = a * g_logits.reshape(B, E) + (1 - a) * loc_logits.reshape(B, E)
+    if clamp == 1:
+        logits = logits.clamp(-30.0, 30.0)
+    logits = logits * inv_temp
+    if clamp == 2:
+        logits = logits.clamp(-30.0, 30.0)
+    probs = torch.softmax(logits, 1)
     tw, ti = torch.topk(probs, top_k, 1)
     tw = tw / (tw.sum(1, keepdim=True) + 1e-6)
     c = torch.sigmoid(cplx_logit.reshape(B)).mean()
@@ -641,7 +658,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
 
 EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
-            "detect_decode", "nms_batched",
+            "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",
             "linear_attention", "deform_attention", "token_softmax", "gated_route_decide", "expert_conv", "expert_dw3", "channel_shuffle_cat",

@@ -176,8 +176,9 @@ def nms_case(name, make_y, **kw):
         y = make_y(seed)
         ml = kw.get("multi_label", False)
         tied = False
+        mi = 4 + (kw.get("nc") or y.shape[1] - 4)     # class rows end here; rows behind them are carried (Segment mask coefficients)
         for b in range(y.shape[0]):
-            c = y[b, 4:][y[b, 4:] > conf] if ml else y[b, 4:].amax(0)[y[b, 4:].amax(0) > conf]
+            c = y[b, 4:mi][y[b, 4:mi] > conf] if ml else y[b, 4:mi].amax(0)[y[b, 4:mi].amax(0) > conf]
             tied |= len(torch.unique(c)) != len(c)
         if not tied:
             break
@@ -186,7 +187,7 @@ def nms_case(name, make_y, **kw):
     args = dict(conf_thres=kw.get("conf_thres", 0.25), iou_thres=kw.get("iou_thres", 0.45),
                 multi_label=kw.get("multi_label", False), agnostic=kw.get("agnostic", False),
                 max_det=kw.get("max_det", 300), max_nms=kw.get("max_nms", 30000))
-    o = nms_ref.non_max_suppression(y.numpy(), return_idxs=True, classes=kw.get("classes"), **args)
+    o = nms_ref.non_max_suppression(y.numpy(), return_idxs=True, classes=kw.get("classes"), nc=kw.get("nc", 0), **args)
     ok = all(np.array_equal(o[1][b], keepi[b].numpy().reshape(-1)) and np.array_equal(o[0][b], dets[b].numpy())
              for b in range(y.shape[0]))
     print(f"[nms_{name}] seed={seed} kept/img={[len(k) for k in keepi]} numpy-oracle == reference: {ok}")
@@ -194,6 +195,8 @@ def nms_case(name, make_y, **kw):
     rec = {"y": y.numpy(), **{f"arg_{k}": np.array(v) for k, v in args.items()}}
     if kw.get("classes") is not None:
         rec["arg_classes"] = np.array(kw["classes"])
+    if kw.get("nc"):
+        rec["arg_nc"] = np.array(kw["nc"])
     for b in range(y.shape[0]):
         rec[f"dets{b}"], rec[f"idx{b}"] = dets[b].numpy(), keepi[b].numpy().reshape(-1).astype(np.int64)
     np.savez_compressed(HERE / f"nms_{name}.npz", **rec)
@@ -209,6 +212,16 @@ if __name__ == "__main__":
         nms_case("classes", lambda s: synth_pred(3, 20, 1500, s, -3.0), conf_thres=0.25, iou_thres=0.7, classes=[1, 7, 19, 33])
         nms_case("classes_multi", lambda s: synth_pred(2, 12, 800, s, -2.5), conf_thres=0.05, iou_thres=0.6, multi_label=True,
                  classes=[0, 5])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "seg":   # nc + extra rows: the call of models/yolo/segment/predict.py -> detect/predict.py:54-65
+        def seg_pred(B, nc, nm, A, seed, mean):      # (`nc=len(names)`, utils/nms.py:76-81,117,122,127): 32 mask coefficients ride along
+            g = torch.Generator().manual_seed(seed + 1000)
+            return torch.cat([synth_pred(B, nc, A, seed, mean), torch.randn(B, nm, A, generator=g)], 1)
+        nms_case("seg", lambda s: seg_pred(2, 20, 32, 900, s, -3.5), conf_thres=0.25, iou_thres=0.7, nc=20)
+        nms_case("seg_multi", lambda s: seg_pred(2, 12, 32, 800, s, -2.5), conf_thres=0.05, iou_thres=0.6, multi_label=True, nc=12,
+                 classes=[0, 5, 7])
+        nms_case("seg_caps", lambda s: seg_pred(2, 1, 8, 2000, s, -1.0), conf_thres=0.1, iou_thres=0.7, max_det=50, max_nms=500, nc=1,
+                 agnostic=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "l":   # only the L-scale case (C3k blocks, gamma-residual A2C2f, mlp 1.2)
         model_case("l_tiny", "l", 1, 64, 64, seed=5, conf=0.002, full_y=True)

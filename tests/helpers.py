@@ -113,16 +113,11 @@ def condition_bn(sd: dict) -> dict:
 
 
 def cfg5_imbalance(sd: dict, alpha_image: float, alpha_token: float) -> dict:
-    """The expert-imbalance knob of BASELINE config 5: a copy of `sd` with expert 0's logit raised in every router —
-    the gated blocks' local stream (`routing.local_conv.6.bias`, moe/gated.py:124-166; the blend scales it by 1 - sigmoid(alpha_param))
-    and the per-token MoT / MoA routers (`router.router.3.bias`, mot/router.py:243-295, moa/router.py:29-62)."""
-    out = {k: v.clone() for k, v in sd.items()}
-    for k in out:
-        if k.endswith("routing.local_conv.6.bias"):
-            out[k][0] += alpha_image
-        elif k.endswith("router.router.3.bias"):
-            out[k][0] += alpha_token
-    return out
+    """The expert-imbalance knob of BASELINE config 5: yolo_master_amd.weights.expert_imbalance (bench.py --imbalance
+    applies the same function)."""
+    from yolo_master_amd.weights import expert_imbalance
+
+    return expert_imbalance(sd, alpha_image, alpha_token)
 
 
 def dense_pred(B: int, nc: int, A: int, seed: int, frame: float = 640.0) -> torch.Tensor:

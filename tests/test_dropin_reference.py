@@ -171,7 +171,29 @@ def test_copies_traces_and_foreign_nms_modes_take_the_reference_path(emu, monkey
         calls = dropin.stats(m)["calls"]
         assert calls >= 1
         dup = copy.deepcopy(core)
-        assert dup._predict_once.__self__ is dup, "the hook of a copy must be bound to the copy"
+        assert dup._predict_once.core is dup, "the hook of a copy must be bound to the copy"
+        # (1b) round-3 advisor finding: an enabled model (and the deepcopy `Model.save` makes) must pickle into a checkpoint that
+        # LOADS — as the plain reference model: its own `_predict_once`, no object of this package inside
+        import io
+        import pickle
+
+        for obj in (core, dup):
+            buf = io.BytesIO()
+            torch.save(obj, buf)
+            assert b"yolo_master_amd" not in buf.getvalue(), "a checkpoint must not reference the drop-in package"
+            back = torch.load(io.BytesIO(buf.getvalue()), weights_only=False)
+            assert back._predict_once.__func__ is type(back)._predict_once and back._predict_once.__self__ is back
+            assert type(back.__dict__[dropin._STATE_ATTR]) is dict and not back.__dict__[dropin._STATE_ATTR]
+            with torch.inference_mode():
+                y_back, _ = back.eval()(x)                 # the reference path of the loaded model
+            assert torch.allclose(y_back, y, atol=1e-3)
+            assert pickle.loads(pickle.dumps(obj.__dict__["_predict_once"])).__self__ is not obj
+            yolo_master_amd.enable(back)                   # ... and it can be enabled again
+            with torch.inference_mode():
+                back(x)
+            assert dropin.stats(back)["calls"] == 1
+            yolo_master_amd.disable(back)
+        assert dropin.stats(m)["calls"] == calls
         with torch.inference_mode():
             y_dup, _ = dup(x)                              # reference path of the copy (its own parameters)
         assert dropin.stats(m)["calls"] == calls, "a deep copy must not run the original's libymk snapshot"

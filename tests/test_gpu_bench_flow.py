@@ -46,6 +46,39 @@ def test_bench_n1_plain_and_under_torchrun():
         assert "diagnostic" in d["metric"]          # batch 8 is not the headline configuration and is labelled so
 
 
+def test_bench_reports_the_synchronised_convention_beside_the_pipelined_rate():
+    """The driver-run line alone must answer "what is the latency of one batch": `value` (K steps between the barriers, `pipeline_depth`
+    batches in flight) and `value_sync` (one batch at a time, synchronised wall-clock, bs * 1000 / p50 — benchmarks/suite.py:316-330),
+    forward-only beside forward + NMS, op calls and routed pairs per step."""
+    d = _run([sys.executable, "bench.py", *ARGS])
+    assert d["pipeline_depth"] == 3 and d["value_sync"] > 0 and d["p50_batch_ms_sync"] > 0
+    assert abs(d["value_sync"] - 8 * 1e3 / d["p50_batch_ms_sync"]) <= 0.01 * d["value_sync"]
+    assert d["forward_only_sync"]["p50_batch_ms"] <= d["p50_batch_ms_sync"] * 1.05, "forward alone cannot take longer than forward + NMS"
+    assert d["p50_batch_latency_ms"] >= d["ms_per_step"] * 0.9 and "p50_ms_per_image" not in d
+    assert d["op_calls_per_step"] > 50 and len(d["retained_pairs"]) == 4 and all(8 <= v <= 16 for v in d["retained_pairs"].values())
+    assert "sub-batches" in d["config"]["sync_launch"] and d["config"]["nms"].startswith("NMS conf 0.25")
+
+
+def test_bench_rccl_code_path_at_world_size_one():
+    """bench.py --force-dist: the `nccl` (RCCL) process group at WORLD_SIZE = 1 and the N > 1 code path on it — weight broadcast, graph
+    capture with thread-local error mode next to the process group's watchdog thread, three slots in flight, ONE packed
+    all_gather_into_tensor per step on the launching stream.  The 8-GPU scaling run is the driver's; this is the same code on one GPU."""
+    d = _run([sys.executable, "bench.py", "--force-dist", *ARGS])
+    assert d["n_gpus"] == 1 and d["config"]["collectives"].startswith("RCCL") and "world size 1" in d["config"]["collectives"]
+    assert d["config"]["launch"].startswith("hipGraph") and "3 batches in flight" in d["config"]["launch"]
+    assert d["value"] > 0 and d["value_sync"] > 0
+    e = _run(_torchrun(1) + ["--force-dist"])          # ... and with torchrun's own rendezvous
+    assert e["config"]["collectives"].startswith("RCCL") and e["value"] > 0
+
+
+def test_bench_config5_flags():
+    """BASELINE config 5 as stated — fp16, CW-NMS, dense-scene NMS settings, expert imbalance — at a size the test box runs in seconds."""
+    d = _run([sys.executable, "bench.py", "--cfg", "yolo-master-moa-mot.yaml", "--scale", "n", "--imgsz", "320", "--batch", "2", "--dtype", "f16",
+              "--cluster", "--sigma", "0.1", "--dense", "--imbalance", "8,3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["dtype"] == "f16" and "CW-NMS sigma 0.1" in d["config"]["nms"] and "multi_label" in d["config"]["nms"]
+    assert d["config"]["imbalance"] == "8,3" and d["value"] > 0 and d["value_sync"] > 0
+
+
 def test_bench_two_ranks_share_the_gpu():
     d = _run(_torchrun(2), env={"YMK_BENCH_SHARE_GPU": "1", "YMK_DIST_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"

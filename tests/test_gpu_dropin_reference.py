@@ -1,0 +1,238 @@
+"""The product surface of SURVEY 8(b) ON THE GPU: the REFERENCE's own `YOLO(yaml).predict(tensor, device=0)`, its validator's NMS /
+matching calls and its `AutoBackend`, with the REAL libymk hooked underneath (`yolo_master_amd.enable` / `register_backend`) — no
+emulation anywhere (tests/test_dropin_reference.py drives the same hooks on the CPU with tests/emu_ops.py standing in for the library).
+
+Needs a reference checkout on the GPU box, which has none: `tools/stage_reference.sh` copies `/root/reference/ultralytics` into the
+git-ignored scratch directory `.refstage/` for the duration of ONE gpurun call (it travels with the snapshot; never committed) and
+these tests find it through YMK_REFERENCE.  Without it they skip — the driver's round-end run skips them; the builder's run is
+recorded in profiles/r04_hooked_reference_gpu.log.  The un-hooked reference runs beside every hooked call (its eager PyTorch-ROCm
+path on the same MI355X) and is what the hooked result is compared with: routed through libymk, `predict()` must return the same
+detections (classes equal, scores <= 1e-4, boxes <= 1e-2 px: fp32)."""
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+if "YMK_REFERENCE" not in os.environ and (ROOT / ".refstage" / "ultralytics").is_dir():
+    os.environ["YMK_REFERENCE"] = str(ROOT / ".refstage")
+
+from oracle import refboot  # noqa: E402  (reads YMK_REFERENCE at import)
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not refboot.available(), reason="no reference checkout staged on this box (tools/stage_reference.sh)")]
+DEV = "cuda:0"
+
+
+def _yaml(scale="n", task="det"):
+    name = f"yolo-master-{scale}.yaml" if task == "det" else f"yolo-master-seg-{scale}.yaml"
+    return f"{refboot.REF}/ultralytics/cfg/models/master/v0/{task}/{name}"
+
+
+def _yolo(scale="n", task="det", seed=0):
+    refboot.boot()
+    refboot.stub_torchvision()
+    from ultralytics import YOLO
+
+    from yolo_master_amd.weights import synth_state_dict
+
+    m = YOLO(_yaml(scale, task), verbose=False)
+    m.model.load_state_dict(synth_state_dict(m.model.state_dict(), seed=seed))
+    return m
+
+
+def _same_detections(got, ref, box_tol=1e-2, score_tol=1e-4):
+    assert len(got) == len(ref)
+    n = 0
+    for g, r in zip(got, ref):
+        gb, rb = g.boxes.data.float().cpu(), r.boxes.data.float().cpu()
+        assert gb.shape == rb.shape and gb.shape[0] > 0, (gb.shape, rb.shape)
+        assert torch.equal(gb[:, 5], rb[:, 5]), "classes differ"
+        assert float((gb[:, 4] - rb[:, 4]).abs().max()) <= score_tol, float((gb[:, 4] - rb[:, 4]).abs().max())
+        assert float((gb[:, :4] - rb[:, :4]).abs().max()) <= box_tol, float((gb[:, :4] - rb[:, :4]).abs().max())
+        assert g.orig_shape == r.orig_shape and g.names == r.names
+        n += gb.shape[0]
+    return n
+
+
+def test_reference_predict_on_the_gpu_through_the_hooks():
+    """`YOLO(yaml).predict(x, device=0)`: module registry, predictor, warm-up, fuse, layer loop, NMS call, scale_boxes, Results — all the
+    reference's code, on the GPU; hooked, the forward pass / NMS / box rescaling are libymk kernels (models/yolo/detect/predict.py:54-65,122)."""
+    import yolo_master_amd
+    from yolo_master_amd import _lib, dropin
+    from yolo_master_amd.weights import synth_input
+
+    _lib.load()
+    x = synth_input(4, 256, 256, seed=42)
+    kw = dict(conf=0.002, iou=0.7, verbose=False, device=0)
+    ref = _yolo().predict(x, **kw)                            # the untouched reference: eager PyTorch-ROCm on this GPU
+    m = _yolo()
+    assert yolo_master_amd.enable(m) is m
+    try:
+        got = m.predict(x, **kw)
+        st = dropin.stats(m)
+        assert st["calls"] >= 1 and st["nms_calls"] >= 1, st
+        n = _same_detections(got, ref)
+        print(f"reference predict(device=0) through the libymk hooks: {n} detections identical in class, <= 1e-4 in score, <= 1e-2 px; hook stats {st}")
+        core = m.model
+        before = dropin.stats(m)["fallbacks"]
+        core._predict_once(x.to(DEV), profile=False, visualize=False, embed=[1])     # an embed call is the reference's business
+        assert dropin.stats(m)["fallbacks"] == before + 1
+    finally:
+        yolo_master_amd.disable(m)
+    import ultralytics.utils.nms as ref_nms
+
+    assert ref_nms.non_max_suppression.__module__ == "ultralytics.utils.nms"
+
+
+def test_reference_half_precision_predict_runs_the_fp16_library():
+    """`half=True` (engine/predictor.py:174,415) maps to libymk_f16.so; the reference's own fp16 run on the GPU is the yardstick: libymk
+    must be at least as close to the fp32 reference result as the reference's own half run is (kept-set overlap)."""
+    import yolo_master_amd
+    from yolo_master_amd import dropin
+    from yolo_master_amd.weights import synth_input
+
+    x = synth_input(2, 256, 256, seed=43)
+    kw = dict(conf=0.25, iou=0.7, verbose=False, device=0)
+    ref32 = _yolo().predict(x, **kw)
+    ref16 = _yolo().predict(x, half=True, **kw)
+    m = _yolo()
+    yolo_master_amd.enable(m)
+    try:
+        got = m.predict(x, half=True, **kw)
+        assert dropin.stats(m)["calls"] >= 1
+    finally:
+        yolo_master_amd.disable(m)
+
+    def overlap(a, b):      # detections of a matched in b by class and IoU > 0.9
+        from yolo_master_amd.postprocess import box_iou
+
+        tot = hit = 0
+        for ra, rb in zip(a, b):
+            da, db = ra.boxes.data.float(), rb.boxes.data.float()
+            tot += da.shape[0]
+            if da.shape[0] and db.shape[0]:
+                iou = box_iou(da[:, :4].contiguous(), db[:, :4].contiguous())
+                same = da[:, 5:6] == db[:, 5].view(1, -1)
+                hit += int(((iou > 0.9) & same).any(1).sum())
+        return hit / max(tot, 1)
+
+    o_ref, o_got = overlap(ref32, ref16), overlap(ref32, got)
+    print(f"half=True: share of the fp32 reference's detections found again — reference's own fp16 run {o_ref:.3f}, libymk fp16 {o_got:.3f}")
+    assert o_got >= o_ref - 0.05 and o_got >= 0.85
+
+
+def test_validator_calls_on_the_gpu():
+    """The validator's call shapes on GPU tensors: NMS with conf 0.001-style settings by keyword (models/yolo/detect/val.py:116) and the
+    per-image matching (`DetectionValidator._process_batch`, val.py:313-327) — hooked result == the reference's own implementation."""
+    import numpy as np
+
+    import yolo_master_amd
+    from tests.test_oracle_post import match_cases
+    from yolo_master_amd import dropin
+    from yolo_master_amd.weights import synth_input
+
+    m = _yolo()
+    yolo_master_amd.enable(m)
+    try:
+        import ultralytics.utils.nms as ref_nms
+        from ultralytics.models.yolo.detect.val import DetectionValidator
+
+        core = m.model.to(DEV).eval()
+        with torch.inference_mode():
+            y, _ = core(synth_input(2, 256, 256, seed=3).to(DEV))
+        assert dropin.stats(m)["calls"] == 1
+        out = ref_nms.non_max_suppression(y, 0.05, 0.6, nc=0, multi_label=True, agnostic=False, max_det=100, end2end=False, rotated=False)
+        want = dropin._PATCHED["nms"](y.clone(), 0.05, 0.6, nc=0, multi_label=True, agnostic=False, max_det=100, max_time_img=10.0)
+        assert dropin.stats(m)["nms_calls"] >= 1
+        for o, w in zip(out, want):
+            assert o.shape == w.shape and torch.equal(o[:, 5], w[:, 5]) and torch.allclose(o, w, atol=1e-4)
+        v = DetectionValidator.__new__(DetectionValidator)
+        v.iouv = torch.linspace(0.5, 0.95, 10).to(DEV)
+        v.niou = 10
+        n = 0
+        for c in match_cases(ROOT / "tests" / "golden"):
+            if c["tied"]:
+                continue
+            d, l = torch.from_numpy(c["dets"].copy()).to(DEV), torch.from_numpy(c["labels"].copy()).to(DEV)
+            preds = {"bboxes": d[:, :4], "conf": d[:, 4], "cls": d[:, 5]}
+            batch = {"bboxes": l[:, 1:], "cls": l[:, 0]}
+            got = v._process_batch(preds, batch)["tp"]
+            wnt = dropin._PATCHED["process_batch"](v, preds, batch)["tp"]
+            assert got.dtype == wnt.dtype == bool and np.array_equal(got, wnt)
+            n += 1
+        assert n >= 4 and dropin.stats(m)["match_calls"] >= 3
+    finally:
+        yolo_master_amd.disable(m)
+
+
+def test_backend_adapter_under_autobackend_on_the_gpu():
+    """`dropin.register_backend()`: the reference's AutoBackend (nn/autobackend.py:143-222) builds `YmkBackend` for format "pt" on
+    cuda:0; same output as the reference's PyTorchBackend on the same device, fp32 and fp16."""
+    refboot.boot()
+    refboot.stub_torchvision()
+    from ultralytics.nn.autobackend import AutoBackend
+    from ultralytics.nn.backends.pytorch import PyTorchBackend
+
+    from yolo_master_amd import dropin
+    from yolo_master_amd.weights import synth_input
+
+    dev = torch.device(DEV)
+    x = synth_input(2, 256, 256, seed=7).to(dev)
+    for fp16 in (False, True):
+        ref_backend = AutoBackend(_yolo().model, device=dev, fp16=fp16, fuse=True, verbose=False).eval()
+        assert type(ref_backend.backend) is PyTorchBackend
+        xin = x.half() if fp16 else x
+        with torch.inference_mode():
+            want = ref_backend(xin)
+        want = want[0] if isinstance(want, (list, tuple)) else want
+        cls = dropin.register_backend()
+        try:
+            ab = AutoBackend(_yolo().model, device=dev, fp16=fp16, fuse=True, verbose=False).eval()
+            assert type(ab.backend) is cls and ab.backend.ymk_enabled, getattr(ab.backend, "ymk_error", None)
+            assert (ab.backend.stride, ab.backend.channels, ab.backend.names) == (ref_backend.backend.stride, ref_backend.backend.channels, ref_backend.backend.names)
+            with torch.inference_mode():
+                got = ab(xin)
+            got = got[0] if isinstance(got, (list, tuple)) else got
+            assert ab.backend.stats()["calls"] >= 1 and got.shape == want.shape and got.dtype == want.dtype
+            err = (got.float() - want.float()).abs()
+            if fp16:     # two 16-bit evaluations of the same network: medians, not maxima
+                assert float(err[:, 4:].median()) <= 2e-3 and float(err[:, :4].median()) <= 0.5, (float(err[:, 4:].median()), float(err[:, :4].median()))
+            else:
+                assert float(err[:, 4:].max()) <= 1e-4 and float(err[:, :4].max()) <= 1e-2, (float(err[:, 4:].max()), float(err[:, :4].max()))
+            dropin.disable(ab.backend.model)
+        finally:
+            dropin.unregister_backend()
+    assert AutoBackend._BACKEND_MAP["pt"] is PyTorchBackend
+
+
+def test_segment_predict_on_the_gpu_through_the_hooks():
+    """The segmentation predictor (models/yolo/segment/predict.py: NMS with `nc=len(names)`, the 32 mask coefficients riding behind the
+    class rows, utils/nms.py:76-81,117) with libymk underneath: the NMS hook now takes that call (no fall-back to the Python NMS), and
+    boxes / classes / masks equal the un-hooked reference's."""
+    import yolo_master_amd
+    from yolo_master_amd import dropin
+    from yolo_master_amd.weights import synth_input
+
+    if not os.path.exists(_yaml("n", "seg")):
+        pytest.skip("no v0 segmentation YAML in this reference checkout")
+    x = synth_input(2, 256, 256, seed=44)
+    kw = dict(conf=0.25, iou=0.7, verbose=False, device=0)
+    ref = _yolo(task="seg").predict(x, **kw)
+    m = _yolo(task="seg")
+    yolo_master_amd.enable(m)
+    try:
+        got = m.predict(x, **kw)
+        st = dropin.stats(m)
+        assert st["calls"] >= 1 and st["nms_calls"] >= 1 and not dropin._PATCHED.get("_nms_fallbacks"), (st, dropin._PATCHED.get("_nms_fallbacks"))
+        n = _same_detections(got, ref, box_tol=2e-2)
+        for g, r in zip(got, ref):
+            if r.masks is None:
+                assert g.masks is None
+                continue
+            gm, rm = g.masks.data.bool().cpu(), r.masks.data.bool().cpu()
+            assert gm.shape == rm.shape
+            assert float((gm != rm).float().mean()) <= 2e-3, "mask pixels differ beyond boundary flips"
+        print(f"segment predict(device=0) through the hooks: {n} instances, boxes / classes / masks equal to the un-hooked reference")
+    finally:
+        yolo_master_amd.disable(m)

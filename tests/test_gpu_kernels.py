@@ -432,7 +432,8 @@ def _nms_compare(y, **kw):
     return got
 
 
-@pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one", "classes", "classes_multi"])
+@pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one", "classes", "classes_multi",
+                                  "seg", "seg_multi", "seg_caps"])      # seg*: `nc` + mask rows, the segment predictor's call
 def test_nms_golden(case, golden_dir):
     """HIP NMS == the real reference's non_max_suppression output (fixtures) bit for bit."""
     from tests.helpers import load_npz
@@ -444,6 +445,8 @@ def test_nms_golden(case, golden_dir):
               max_nms=int(z["arg_max_nms"]))
     if "arg_classes" in z:
         kw["classes"] = z["arg_classes"].tolist()
+    if "arg_nc" in z:
+        kw["nc"] = int(z["arg_nc"])
     y = torch.from_numpy(z["y"])
     got, idx = non_max_suppression(y.to(DEV), return_idxs=True, **kw)
     for b in range(y.shape[0]):

@@ -133,3 +133,25 @@ def test_nms_selects_the_top_max_nms_candidates(mode, host_ops):
     for b in range(B):
         assert np.array_equal(got_idx[b].numpy(), ref_idx[b]), f"{mode} image {b}: kept anchors differ ({ncand[b]} candidates)"
         assert np.array_equal(got[b].numpy(), ref[b]), f"{mode} image {b}: detections differ"
+
+
+@pytest.mark.parametrize("case", ["seg", "seg_multi", "seg_caps"])
+def test_nms_with_carried_mask_rows_vs_reference_golden(case, host_ops, golden_dir):
+    """The segment predictor's NMS call (models/yolo/segment/predict.py -> detect/predict.py:54-65: `nc=len(names)`, so the rows
+    behind the class rows are mask coefficients that ride along, utils/nms.py:76-81,117,122,127): csrc/nms.hip with `extra` rows +
+    ymk_nms_gather_rows on the lane emulator, bit-exact against the REAL reference's output rows (xyxy, conf, cls, mask...)."""
+    from tests.helpers import load_npz
+    from yolo_master_amd.nms import non_max_suppression
+
+    z = load_npz(golden_dir / f"nms_{case}.npz")
+    kw = dict(conf_thres=float(z["arg_conf_thres"]), iou_thres=float(z["arg_iou_thres"]), multi_label=bool(z["arg_multi_label"]),
+              agnostic=bool(z["arg_agnostic"]), max_det=int(z["arg_max_det"]), max_nms=int(z["arg_max_nms"]), nc=int(z["arg_nc"]))
+    if "arg_classes" in z:
+        kw["classes"] = z["arg_classes"].tolist()
+    y = torch.from_numpy(z["y"])
+    got, idx = non_max_suppression(y, return_idxs=True, **kw)
+    extra = y.shape[1] - 4 - kw["nc"]
+    for b in range(y.shape[0]):
+        assert got[b].shape[1] == 6 + extra
+        assert np.array_equal(idx[b].numpy(), z[f"idx{b}"]), f"{case} image {b}: kept anchors differ"
+        assert np.array_equal(got[b].numpy(), z[f"dets{b}"]), f"{case} image {b}: output rows differ"

@@ -46,14 +46,16 @@ def test_forward_restatement_matches_reference(case, golden_dir):
             assert len(a & r) >= 0.97 * len(a | r), f"image {b}: kept sets differ beyond near-threshold flips"   # (both empty: equal)
 
 
-@pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one", "classes", "classes_multi"])
+@pytest.mark.parametrize("case", ["single", "multi", "agnostic", "caps", "empty", "one", "classes", "classes_multi",
+                                  "seg", "seg_multi", "seg_caps"])      # seg*: nc + carried mask rows (utils/nms.py:76-81,117)
 def test_nms_restatement_matches_reference(case, golden_dir):
     from oracle import nms_ref
 
     z = load_npz(golden_dir / f"nms_{case}.npz")
     kw = dict(conf_thres=float(z["arg_conf_thres"]), iou_thres=float(z["arg_iou_thres"]),
               multi_label=bool(z["arg_multi_label"]), agnostic=bool(z["arg_agnostic"]), max_det=int(z["arg_max_det"]),
-              max_nms=int(z["arg_max_nms"]), classes=z["arg_classes"].tolist() if "arg_classes" in z else None)
+              max_nms=int(z["arg_max_nms"]), classes=z["arg_classes"].tolist() if "arg_classes" in z else None,
+              nc=int(z["arg_nc"]) if "arg_nc" in z else 0)
     dets, idx = nms_ref.non_max_suppression(z["y"], return_idxs=True, **kw)
     for b in range(z["y"].shape[0]):
         assert np.array_equal(idx[b], z[f"idx{b}"]), f"{case} image {b}"

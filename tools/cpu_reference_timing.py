@@ -1,9 +1,11 @@
 """Time the REAL reference (imported from /root/reference, BASELINE.md section 2's protocol: `DetectionModel(yaml).eval().fuse()`,
 `torch.inference_mode()`, fp32, forward + `non_max_suppression(conf 0.25, IoU 0.7)`, 8 threads) beside the oracle port that
 bench.py's `cpu_baseline` times on the GPU box, on the SAME host, weights and images.  Build container only (the GPU box has no
-reference checkout); writes profiles/r03_cpu_reference.json, which bench.py quotes next to its own `cpu_baseline`.
+reference checkout — unless tools/stage_reference.sh put one beside the snapshot for that call: YMK_REFERENCE); writes
+profiles/<tag>_cpu_reference.json, which bench.py quotes next to its own `cpu_baseline`.  Forward only and forward + NMS are timed
+separately: the reference's Python NMS dominates once thousands of candidates pass the threshold.
 
-    python tools/cpu_reference_timing.py [scale=s] [batch=4] [passes=5]
+    python tools/cpu_reference_timing.py [scale=s] [batch=4] [passes=5] [tag=r04]
 """
 import json
 import os
@@ -40,6 +42,7 @@ if __name__ == "__main__":
     scale = sys.argv[1] if len(sys.argv) > 1 else "s"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    tag = sys.argv[4] if len(sys.argv) > 4 else "r04"
     cores = min(os.cpu_count() or 1, 8)
     torch.set_num_threads(cores)
     cfg = yaml_model_load(f"yolo-master-{scale}.yaml")
@@ -59,12 +62,14 @@ if __name__ == "__main__":
             out["port"] = nms_ref.non_max_suppression(y.numpy(), 0.25, 0.7)
 
         t_ref, t_port = p50(run_ref, n), p50(run_port, n)
+        t_ref_fwd, t_port_fwd = p50(lambda: ref(x), n), p50(lambda: model_ref.forward(cfg, sd, x), n)
     same = all(len(a) == len(b) for a, b in zip(out["ref"], out["port"]))
-    rec = {"reference_images_per_s": round(B / t_ref, 3), "port_images_per_s": round(B / t_port, 3), "cores": cores,
+    rec = {"reference_images_per_s": round(B / t_ref, 3), "port_images_per_s": round(B / t_port, 3),
+           "reference_forward_only_images_per_s": round(B / t_ref_fwd, 3), "port_forward_only_images_per_s": round(B / t_port_fwd, 3), "cores": cores,
            "host": f"{platform.processor() or platform.machine()} ({os.cpu_count()} logical CPUs), torch {torch.__version__}",
            "sample": f"YOLO-Master-{scale.upper()} fp32 forward + NMS, {B}x3x640x640, p50 of {n} passes; kind 'reference' = ultralytics from /root/reference "
                      f"(fused, inference_mode), kind 'port' = oracle/model_ref + nms_ref (what bench.py times on the GPU box)",
            "same_detection_counts": same}
     (ROOT / "profiles").mkdir(exist_ok=True)
-    json.dump(rec, open(ROOT / "profiles" / "r03_cpu_reference.json", "w"), indent=1)
+    json.dump(rec, open(ROOT / "profiles" / f"{tag}_cpu_reference.json", "w"), indent=1)
     print(json.dumps(rec))

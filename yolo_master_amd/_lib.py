@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); must list every function declared in include/ymk.h
-ABI_VERSION = 2   # include/ymk.h YMK_ABI_VERSION
+ABI_VERSION = 3   # include/ymk.h YMK_ABI_VERSION
 
 SYMBOLS = {
     "ymk_abi_version": (C.c_int, []),
@@ -88,8 +88,9 @@ SYMBOLS = {
     "ymk_nhwc_to_nchw_f32": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ymk_detect_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "ymk_nms_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
-    "ymk_nms_batched": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
+    "ymk_nms_batched": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _sz, _vp]),
+    "ymk_nms_gather_rows": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ymk_cw_refine": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
 }
 
@@ -111,7 +112,7 @@ SYMBOLS_MIXTURE = {
     "ymk_avg_pool": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_channel_stats": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ymk_token_softmax": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
-    "ymk_gated_route_decide": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ymk_gated_route_decide": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ymk_expert_gather": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ymk_expert_dw3": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ymk_channel_shuffle_cat": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i64, _vp]),

@@ -324,8 +324,8 @@ __global__ __launch_bounds__(256) void token_softmax_kernel(const float* logits,
 
 // one workgroup: complexity (batch mean) first, then one image per thread
 __global__ __launch_bounds__(256) void gated_decide_kernel(const float* g, int ldg, const float* loc, int ldloc, const float* cplx,
-                                                            int ldc, int B, int E, float alpha, float inv_temp, int top_k, float* w,
-                                                            int32_t* idx, int32_t* idx_sm, float* probs) {
+                                                            int ldc, int B, int E, float alpha, float inv_temp, int clamp_mode, int top_k,
+                                                            float* w, int32_t* idx, int32_t* idx_sm, float* probs) {
     __shared__ float sh[4];
     float cs = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) cs += 1.0f / (1.0f + expf(-cplx[(int64_t)b * ldc]));
@@ -337,7 +337,12 @@ __global__ __launch_bounds__(256) void gated_decide_kernel(const float* g, int l
         float* pr = probs + (int64_t)b * E;
         float m = -INFINITY;
         for (int e = 0; e < E; ++e) {
-            const float l = fminf(fmaxf(a * g[(int64_t)b * ldg + e] + (1.0f - a) * loc[(int64_t)b * ldloc + e], -30.0f), 30.0f) * inv_temp;
+            // clamp_mode 1: clamp(logits, +-30) / T (moe/gated.py:141-142); 2: clamp(logits / T, +-30) (gated.py:972); 0: no clamp — a
+            // router's own plain softmax (gated.py:958 nn.Softmax, routers.py:207 `_process_logits`)
+            float l = a * g[(int64_t)b * ldg + e] + (1.0f - a) * loc[(int64_t)b * ldloc + e];
+            if (clamp_mode == 1) l = fminf(fmaxf(l, -30.0f), 30.0f);
+            l *= inv_temp;
+            if (clamp_mode == 2) l = fminf(fmaxf(l, -30.0f), 30.0f);
             pr[e] = l;
             m = fmaxf(m, l);
         }
@@ -1122,14 +1127,14 @@ extern "C" int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int
 }
 
 extern "C" int ymk_gated_route_decide(const float* g, int32_t ldg, const float* loc, int32_t ldloc, const float* cplx, int32_t ldc,
-                                      int32_t B, int32_t E, float alpha, float inv_temp, int32_t top_k, float* w, int32_t* idx,
-                                      int32_t* idx_slot_major, float* probs, void* stream) {
+                                      int32_t B, int32_t E, float alpha, float inv_temp, int32_t clamp_mode, int32_t top_k, float* w,
+                                      int32_t* idx, int32_t* idx_slot_major, float* probs, void* stream) {
     if (!g || !loc || !cplx || !w || !idx || !idx_slot_major || !probs || E < 1 || E > 64 || top_k < 1 || top_k > 8 || top_k > E || ldg < E ||
-        ldloc < E || ldc < 1)
+        ldloc < E || ldc < 1 || clamp_mode < 0 || clamp_mode > 2)
         return YMK_E_BADARG;
     if (B <= 0) return YMK_OK;
     hipLaunchKernelGGL(gated_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g, ldg, loc, ldloc, cplx, ldc, B, E, alpha,
-                       inv_temp, top_k, w, idx, idx_slot_major, probs);
+                       inv_temp, clamp_mode, top_k, w, idx, idx_slot_major, probs);
     return ymk_launch_status();
 }
 

@@ -37,6 +37,7 @@ struct NmsWs {
     int* blocksum_e;     // [B][NBLK] per-block counts of bits == T
     int* blockoff_e;     // [B][NBLK]
     int nblk, capc, ns, nw;
+    int rows;            // rows of y per image: 4 + nc + extra (mask coefficients of a Segment head ride behind the class rows)
     size_t total;
 };
 
@@ -44,6 +45,7 @@ struct NmsWs {
 
 static NmsWs nms_layout(void* base, int B, int nc, int A, int multi, int max_nms) {
     NmsWs w;
+    w.rows = 4 + nc;
     w.nblk = (A + 255) / 256;
     const int64_t full = multi ? (int64_t)A * nc : (int64_t)A;
     w.capc = (int)(full < (int64_t)max_nms ? full : (int64_t)max_nms);   // never more than max_nms rows reach the ordering stage
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const float* __restrict_
     const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
     int c = 0;
     if (a < A) {
-        const float* p = y + ((size_t)b * (4 + nc) + 4) * A + a;
+        const float* p = y + ((size_t)b * w.rows + 4) * A + a;
         // class scores are read eight at a time (independent loads in flight); the compares keep class order, so
         // the first maximum wins exactly as in the sequential scan (utils/nms.py:124-129 amax/argmax semantics)
         if (multi) {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* __restrict__
     };
     if (a < A) {
         if (multi) {
-            const float* p = y + ((size_t)b * (4 + nc) + 4) * A + a;
+            const float* p = y + ((size_t)b * w.rows + 4) * A + a;
             for (int k = 0; k < nc; ++k) {
                 const float v = p[(size_t)k * A];
                 if (v > conf && (!class_keep || class_keep[k])) add(v);
@@ -216,6 +218,9 @@ __global__ __launch_bounds__(256) void nms_pick_kernel(NmsWs w, int level) {
     __shared__ unsigned wtot[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!w.sel[b]) return;
+    // read BEFORE the barriers: the one thread that finds the threshold bin rewrites need[b] below, and a wave that is still on its
+    // way to this read would then test its bins against the NEXT level's count (a second "pick", OR-ed into thr_key)
+    const unsigned need = (unsigned)w.need[b];
     unsigned* gh = w.hist + (size_t)b * 2048;
     for (int i = tid; i < 2048; i += 256) { h[i] = gh[i]; gh[i] = 0u; }   // cleared for the next level
     __syncthreads();
@@ -233,7 +238,6 @@ __global__ __launch_bounds__(256) void nms_pick_kernel(NmsWs w, int level) {
     __syncthreads();
     unsigned above = inc - own;   // candidates in the bins above this thread's range
     for (int k = 0; k < wave; ++k) above += wtot[k];
-    const unsigned need = (unsigned)w.need[b];
     if (above < need && need <= above + own) {   // exactly one thread: the threshold bin is in its range
         unsigned acc = above;
         int t = 0;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256) void nms_count2_kernel(const float* __restrict
     int c = 0;
     if (a < A) {
         if (multi) {
-            const float* p = y + ((size_t)b * (4 + nc) + 4) * A + a;
+            const float* p = y + ((size_t)b * w.rows + 4) * A + a;
             for (int k = 0; k < nc; ++k) {
                 const float v = p[(size_t)k * A];
                 if (v > conf && (!class_keep || class_keep[k])) {
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float* __restrict__
     if (c == 0) return;
     const unsigned T = w.thr_key[b];
     const int n_gt = w.n_gt[b], eq_take = w.eq_take[b];
-    const float* yb = y + (size_t)b * (4 + nc) * A + a;
+    const float* yb = y + (size_t)b * w.rows * A + a;
     const float cx = yb[0], cy = yb[(size_t)A], bw = yb[2 * (size_t)A], bh = yb[3 * (size_t)A];
     const float hw = bw / 2.0f, hh = bh / 2.0f;  // xywh2xyxy (utils/ops.py:248-264)
     const float x1 = cx - hw, y1 = cy - hh, x2 = cx + hw, y2 = cy + hh;
@@ -669,16 +673,17 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, flo
     for (int i = nk + threadIdx.x; i < max_det; i += 256) out_idx[(size_t)b * max_det + i] = 0;
 }
 
-extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A, float conf_thres, float iou_thres,
+extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t extra, int32_t A, float conf_thres, float iou_thres,
                                int32_t multi_label, int32_t agnostic, int32_t max_det, int32_t max_nms, float max_wh,
                                const uint8_t* class_keep, float* out_dets, int32_t* out_counts, int32_t* out_idx, int32_t* status,
                                void* workspace, size_t workspace_bytes, void* stream) {
     if (!y || !out_dets || !out_counts || !out_idx || !status || !workspace) return YMK_E_BADARG;
-    if (B <= 0 || A <= 0 || nc <= 0 || max_det <= 0 || max_nms <= 0 || B > 65535 || max_det > NMS_MAXDET_CAP)
+    if (B <= 0 || A <= 0 || nc <= 0 || extra < 0 || max_det <= 0 || max_nms <= 0 || B > 65535 || max_det > NMS_MAXDET_CAP)
         return YMK_E_BADARG;
     const int multi = (multi_label && nc > 1) ? 1 : 0;
     NmsWs w = nms_layout(workspace, B, nc, A, multi, max_nms);
     if (workspace_bytes < w.total) return YMK_E_WORKSPACE;
+    w.rows = 4 + nc + extra;   // utils/nms.py:76-81: candidates come from rows [4, 4 + nc); the `extra` rows behind them are carried, not scored
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, w, status);
@@ -698,6 +703,28 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t A,
         hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w);
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det,
                        out_dets, out_counts, out_idx);
+    return ymk_launch_status();
+}
+
+// ---- rows carried behind the class rows (Segment: mask coefficients; utils/nms.py:76-81,117: `mask` columns of the detections) ----
+// out[b][j][k] = y[b][row0 + k][idx[b][j]] for j < counts[b]; zero rows past the count (the caller hands over uninitialised memory).
+__global__ __launch_bounds__(256) void nms_gather_rows_kernel(const float* __restrict__ y, int rows, int A, int row0, int extra,
+                                                             const int* __restrict__ idx, const int* __restrict__ counts, int max_det,
+                                                             float* __restrict__ out) {
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= max_det * extra) return;
+    const int j = t / extra, k = t - j * extra;
+    float v = 0.f;
+    if (j < counts[b]) v = y[((size_t)b * rows + row0 + k) * A + idx[(size_t)b * max_det + j]];
+    out[(size_t)b * max_det * extra + t] = v;
+}
+
+extern "C" int ymk_nms_gather_rows(const float* y, int32_t B, int32_t rows, int32_t A, int32_t row0, int32_t extra, const int32_t* idx,
+                                   const int32_t* counts, int32_t max_det, float* out, void* stream) {
+    if (!y || !idx || !counts || !out || B <= 0 || B > 65535 || A <= 0 || extra <= 0 || row0 < 0 || row0 + extra > rows || max_det <= 0)
+        return YMK_E_BADARG;
+    hipLaunchKernelGGL(nms_gather_rows_kernel, dim3((max_det * extra + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, y, rows, A, row0,
+                       extra, idx, counts, max_det, out);
     return ymk_launch_status();
 }
 

@@ -23,13 +23,24 @@ def shard_range(n_items: int, rank: int, world: int) -> tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def forced() -> bool:
+    """YMK_DIST_FORCE=1: run the multi-GPU code path (process group, weight broadcast, packed result gather) at world size 1 too —
+    the smoke test of the RCCL branch on a box with one GPU (bench.py --force-dist, tests/test_gpu_bench_flow.py)."""
+    return os.environ.get("YMK_DIST_FORCE", "") not in ("", "0")
+
+
+def _active() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     """Initialise torch.distributed from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = os.environ.get("YMK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -41,7 +52,7 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
 
 def broadcast_state_dict(module: torch.nn.Module, src: int = 0) -> None:
     """Replicate rank `src`'s parameters and buffers to every rank (one flat broadcast per dtype)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return
     tensors = [t for t in module.state_dict().values() if torch.is_tensor(t)]
     by_dtype: dict = {}
@@ -70,7 +81,7 @@ def gather_packed(pack: torch.Tensor, out: torch.Tensor | None = None) -> torch.
     of an uneven batch to the common B_local).  Returns float32 [world, n] in rank order = the original image order for contiguous
     shards (ops.nms_pack_views(result, B_local, max_det) gives dets [world, B_local, max_det, 6], counts, idx).
     out: the caller's pre-allocated [world, n] buffer (a serving loop reuses it every batch)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return pack.unsqueeze(0)
     world = dist.get_world_size()
     if out is None or tuple(out.shape) != (world, pack.numel()) or out.dtype != pack.dtype or out.device != pack.device:
@@ -91,7 +102,7 @@ def gather_detections(dets: torch.Tensor, counts: torch.Tensor, idx: torch.Tenso
     world*B_local in rank order (i.e. the original batch order for contiguous shards).
     out: a dict the caller keeps across batches — the gathered tensors are allocated in it on first use and reused
     afterwards (a serving loop gathers into the same three buffers every batch: no allocator traffic per step)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return dets, counts, idx
     world = dist.get_world_size()
 

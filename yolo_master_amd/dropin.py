@@ -15,8 +15,8 @@ What `enable` does (every hook falls through to the reference's own code for CPU
   2. rebinds the reference model's `_predict_once` (the layer loop, nn/tasks.py:182-218): eval-mode GPU batches run the
      libymk graph walk and return what the reference's Detect returns in eval mode, `(y [B, 4+nc, A], preds dict)`
      (nn/modules/head.py:157-171).  The weights are a snapshot taken at `enable()` time (the reference folds Conv+BN in
-     place when its predictor starts): call `disable()` + `enable()` again after loading other weights.  The hook is a bound
-     method that reads its state from `self`: a `copy.deepcopy` of the model (Exporter, ModelEMA) runs the REFERENCE path until
+     place when its predictor starts): call `disable()` + `enable()` again after loading other weights.  The hook is a callable
+     bound to the model that reads its state from it: a `copy.deepcopy` of the model (Exporter, ModelEMA) runs the REFERENCE path until
      `enable()` is called on the copy, and tracing / ONNX export always do;
   3. patches `ultralytics.utils.nms.non_max_suppression` (called as `nms.non_max_suppression(...)` by the detect
      predictor and validators, models/yolo/detect/predict.py:54, val.py:116), `ultralytics.utils.ops.scale_boxes`
@@ -79,16 +79,17 @@ def _compute_dtype_for(x: torch.Tensor, forced):
 
 
 def _hooked_predict_once(self, x, profile=False, visualize=False, embed=None):
-    """Replacement for `BaseModel._predict_once` (nn/tasks.py:182-218), installed as a BOUND method: all state is read from `self`,
+    """Replacement for `BaseModel._predict_once` (nn/tasks.py:182-218), installed as a callable bound to the model (`_Hook`): all state is read from `self`,
     so a `copy.deepcopy` of the model (the reference's Exporter, ModelEMA) gets a hook that looks at the COPY — its training flag,
     its own state entry — and the copy's state is detached (below) so that it runs the reference path instead of a stale weight
     snapshot.  Tracing / ONNX export always take the reference path (libymk kernels are opaque to the tracer)."""
     state = self.__dict__.get(_STATE_ATTR)
     orig = type(self)._predict_once
     tracing = torch.jit.is_tracing() or torch.jit.is_scripting() or (hasattr(torch.onnx, "is_in_onnx_export") and torch.onnx.is_in_onnx_export())
-    if state is None or state.get("owner") != id(self) or self.training or tracing or profile or visualize or embed \
-            or not torch.is_tensor(x) or not ops.device_ok(x):
-        if state is not None and state.get("owner") == id(self):
+    # (`inert`: a deep copy's marker — an id can be reused once the original is freed, so the owner id alone does not prove liveness)
+    live = state is not None and state.get("owner") == id(self) and not state.get("inert") and "ymk" in state
+    if not live or self.training or tracing or profile or visualize or embed or not torch.is_tensor(x) or not ops.device_ok(x):
+        if live:
             state["fallbacks"] += 1
         return orig(self, x, profile, visualize, embed)
     ymk = state["ymk"]
@@ -102,24 +103,57 @@ def _hooked_predict_once(self, x, profile=False, visualize=False, embed=None):
     state["calls"] += 1
     y, preds = ymk._predict_once(x.float())
     ymk.check_flags()
-    if x.dtype in (torch.float16, torch.bfloat16):
+    low = x.dtype in (torch.float16, torch.bfloat16)
+    if "mask_coefficient" in preds:      # Segment in eval mode returns ((cat(y, mask coefficients), prototypes NCHW), preds) (nn/modules/head.py:317-336)
+        proto = ops.nhwc_to_nchw_f32(preds["proto"])
+        y = torch.cat([y, preds["mask_coefficient"]], 1)
+        preds["proto"] = proto
+        return ((y.to(x.dtype), proto.to(x.dtype)) if low else (y, proto)), preds
+    if low:
         y = y.to(x.dtype)
     return y, preds
 
 
 class _State(dict):
     """Per-model hook state.  Deep copies of the model share nothing with it: the copy's entry is an inert marker (owner id of the
-    ORIGINAL), so the copy's bound hook falls through to the reference path; `enable(copy)` installs a fresh state."""
+    ORIGINAL), so the copy's bound hook falls through to the reference path; `enable(copy)` installs a fresh state.  Pickled
+    (`torch.save(model)`, the reference's `Model.save` / trainer checkpoints) it is an empty plain dict: a checkpoint never
+    references this package."""
 
     def __deepcopy__(self, memo):
         return _State(owner=self.get("owner"), inert=True)
+
+    def __reduce__(self):
+        return (dict, ())
+
+
+class _Hook:
+    """The instance attribute that shadows `BaseModel._predict_once` on an enabled model: calls `_hooked_predict_once(core, ...)`.
+    A callable object rather than a bound method because a bound method pickles as `getattr(core, "_hooked_predict_once")`, which
+    cannot be resolved at load time: an enabled model (or the deepcopy the reference's `Model.save` makes of it) would write a
+    checkpoint that fails to load.  Pickled, the hook is the reference's OWN method bound to the model (the checkpoint loads without
+    this package and runs the reference path); deep-copied, it is a hook on the copy (which falls through until `enable(copy)`)."""
+
+    __slots__ = ("core",)
+
+    def __init__(self, core):
+        self.core = core
+
+    def __call__(self, x, profile=False, visualize=False, embed=None):
+        return _hooked_predict_once(self.core, x, profile, visualize, embed)
+
+    def __deepcopy__(self, memo):
+        return _Hook(copy.deepcopy(self.core, memo))
+
+    def __reduce__(self):
+        # getattr(core, "_predict_once") at load time: the hook sits in the model's state, so the model object exists (and is in
+        # the pickle memo) but its __dict__ is not restored yet — the lookup finds the CLASS's method and binds it to the model
+        return (getattr, (self.core, "_predict_once"))
 
 
 def enable(model, dtype: torch.dtype | None = None, patch_nms: bool = True):
     """Hook libymk under a reference model (see module docstring).  dtype: compute type of the libymk path (default: what the
     input tensor asks for — fp16 for the reference's `half=True`, bf16 for bf16 tensors, fp32 otherwise).  Returns `model`."""
-    import types
-
     core = _reference_core(model)
     st = core.__dict__.get(_STATE_ATTR)
     if st is not None and st.get("owner") == id(core) and not st.get("inert"):
@@ -129,7 +163,7 @@ def enable(model, dtype: torch.dtype | None = None, patch_nms: bool = True):
     # model holds its own packed (folded) copy taken here, from the unfused parameters
     state = _State(ymk=ymk, dtype=dtype, device=None, calls=0, fallbacks=0, owner=id(core), patched=bool(patch_nms))
     core.__dict__[_STATE_ATTR] = state
-    core.__dict__["_predict_once"] = types.MethodType(_hooked_predict_once, core)   # deepcopy rebinds a bound method to the copy
+    core.__dict__["_predict_once"] = _Hook(core)   # deepcopy -> a hook on the copy; pickle -> the reference's own bound method
     if patch_nms:
         _PATCHED["_users"] = _PATCHED.get("_users", 0) + 1
         _patch_process()
@@ -174,7 +208,7 @@ def _patch_process():
 
     def non_max_suppression(prediction, *args, **kw):
         """Arguments are bound with the reference's own signature, so modes passed positionally are seen too; anything outside the
-        detect path (rotated, end2end, autolabels, mask channels), CPU tensors and arguments this NMS does not know go to the
+        detect / segment path (rotated, end2end, autolabels), CPU tensors and arguments this NMS does not know go to the
         reference implementation — as does a call that raises NotImplementedError (counted as a fallback, never a crash)."""
         try:
             ba = sig.bind(prediction, *args, **kw)
@@ -184,7 +218,7 @@ def _patch_process():
         pred = a.pop(next(iter(sig.parameters)))
         p = pred[0] if isinstance(pred, (list, tuple)) else pred
         unsupported = a.get("rotated") or a.get("end2end") or (a.get("labels") is not None and len(a.get("labels")) > 0) or \
-            not torch.is_tensor(p) or p.dim() != 3 or p.shape[-1] == 6 or (a.get("nc") and a["nc"] != p.shape[1] - 4) or \
+            not torch.is_tensor(p) or p.dim() != 3 or p.shape[-1] == 6 or (a.get("nc") and a["nc"] > p.shape[1] - 4) or \
             any(k not in ymk_params for k in a if k != "max_time_img")
         if unsupported or not ops.device_ok(p):
             return orig_nms(prediction, *args, **kw)

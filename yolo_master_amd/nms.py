@@ -35,19 +35,21 @@ def class_keep_mask(classes, nc: int, device) -> torch.Tensor:
 
 
 def nms_padded(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, agnostic=False, multi_label=False,
-               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1, classes=None, pack=None):
-    """prediction: [B, 4+nc, A] fp32 on the GPU.  Returns (dets [B,max_det,6], counts [B], idx [B,max_det],
+               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1, classes=None, pack=None, nc=0):
+    """prediction: [B, 4+nc(+extra), A] fp32 on the GPU.  Returns (dets [B,max_det,6], counts [B], idx [B,max_det],
     status [1]) without synchronising.  classes: list of class ids or a ready uint8 [nc] device mask.
     pack: optional float32 [ops.nms_pack_numel(B, max_det)] buffer the outputs are carved from (one allocation: a multi-GPU
-    step gathers it with a single collective, dist.gather_packed)."""
+    step gathers it with a single collective, dist.gather_packed).
+    nc: number of classes when rows are carried behind the class rows (Segment: utils/nms.py:76-81); their values for the kept
+    detections: ops.nms_gather_rows(prediction, nc, idx, counts)."""
     if prediction.dtype != torch.float32:
         prediction = prediction.float()
     prediction = prediction.contiguous()
-    nc = prediction.shape[1] - 4
+    nc = int(nc) or prediction.shape[1] - 4
     if classes is not None and not (torch.is_tensor(classes) and classes.dtype == torch.uint8):
         classes = class_keep_mask(classes, nc, prediction.device)
     return ops.nms_batched(prediction, conf_thres, iou_thres, bool(multi_label) and nc > 1, bool(agnostic), max_det,
-                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None, class_keep=classes, pack=pack)
+                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None, class_keep=classes, pack=pack, nc=nc)
 
 
 def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float = 0.45, classes=None,
@@ -60,10 +62,16 @@ def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float =
         prediction = prediction[0]
     if rotated or end2end or prediction.shape[-1] == 6 or labels:
         raise NotImplementedError("ymk NMS covers the detect path: no rotated/end2end/autolabel modes")
-    if nc and nc != prediction.shape[1] - 4:
-        raise NotImplementedError("ymk NMS: extra mask channels (segment) are not on the detect path")
+    nc = int(nc) or prediction.shape[1] - 4
+    extra = prediction.shape[1] - 4 - nc        # utils/nms.py:80: rows behind the classes (mask coefficients) ride along
+    if extra < 0:
+        raise ValueError(f"nc = {nc} but the prediction has {prediction.shape[1] - 4} rows behind the box")
+    if prediction.dtype != torch.float32 or not prediction.is_contiguous():
+        prediction = prediction.float().contiguous()
     dets, counts, idx, status = nms_padded(prediction, conf_thres, iou_thres, agnostic, multi_label, max_det, max_nms,
-                                           max_wh, cluster, sigma, classes)
+                                           max_wh, cluster, sigma, classes, nc=nc)
+    if extra:                                   # output rows are (xyxy, conf, cls, mask...) as in the reference (:117,122,127)
+        dets = torch.cat([dets, ops.nms_gather_rows(prediction, nc, idx, counts)], 2)
     n = counts.tolist()  # the one host sync of the post-processing step
     out = [dets[b, : n[b]] for b in range(len(n))]
     if return_idxs:

@@ -1482,7 +1482,7 @@ class ModularRouterExpertMoE(YmkModule):
             pk["consts"][B] = (torch.zeros((B, 1, 1, _ceil(E, 4)), dtype=torch.float32, device=x.device),
                                torch.full((B, 1, 1, 1), 100.0, dtype=torch.float32, device=x.device))
         g0, cp = pk["consts"][B]
-        w, idx, probs, rows = ops.gated_route_decide(g0[..., :E], logits, -100.0, 1.0, k, cp)
+        w, idx, probs, rows = ops.gated_route_decide(g0[..., :E], logits, -100.0, 1.0, k, cp, clamp=0)   # `_process_logits`: plain softmax (routers.py:207)
         self.last_route = {"weights": w, "indices": idx, "probs": probs}
         hid, cout = pk["e1"].shape[1], self.out_channels
         f = ops.expert_conv(x, pk["e1"], 1, idx)                                                                   # [k * B, H, W, hid], slot-major
@@ -1587,8 +1587,9 @@ class UltimateOptimizedMoE(YmkModule):
             pk["consts"][B] = (torch.zeros((B, 1, 1, _ceil(E, 4)), dtype=torch.float32, device=x.device),
                                torch.full((B, 1, 1, 1), 100.0, dtype=torch.float32, device=x.device))
         g0, keep_all = pk["consts"][B]
-        _, _, p0, _ = ops.gated_route_decide(g0[..., :E], lin, -100.0, 1.0, k, keep_all)                          # the router's own Softmax (gated.py:958)
-        w, idx, probs, rows = ops.gated_route_decide(g0[..., :E], p0.view(B, 1, 1, E), -100.0, 1.0 / float(self.routing.temperature), k, keep_all)
+        _, _, p0, _ = ops.gated_route_decide(g0[..., :E], lin, -100.0, 1.0, k, keep_all, clamp=0)                 # the router's own Softmax (gated.py:958): no clamp
+        w, idx, probs, rows = ops.gated_route_decide(g0[..., :E], p0.view(B, 1, 1, E), -100.0, 1.0 / float(self.routing.temperature), k, keep_all,
+                                                     clamp=2)                                                      # (probs / T).clamp(+-30) (gated.py:972)
         ops.batch_scale(w, cplx, 0.3, 1.5)                                                                         # routing_weights * complexity_scale
         self.last_route = {"weights": w, "indices": idx, "probs": probs}
         f = ops.expert_conv(xd, pk["ew"], 3, idx)

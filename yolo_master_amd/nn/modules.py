@@ -351,7 +351,9 @@ class C3(YmkModule):
         c_ = self.cv1.conv.out_channels
         cat = ops.new_act(B, H, W, 2 * c_, x.dtype, x.device)
         n = len(self.m)
-        if n > 0 and self._pair_mergeable():
+        # n >= 2 only: with ONE Bottleneck its input / residual (cat[..., :c_]) would also be its output — ymk_conv2d takes y and the
+        # residual as __restrict__ pointers and does not promise that a core reads each residual element in the thread that writes it
+        if n > 1 and self._pair_mergeable():
             self.ymk_dtype = self.cv1.ymk_dtype
             pk = self._packed(x.device)
             ops.conv2d(x, pk["w"], pk["b"], 1, 1, True, out=cat)     # cat = [cv1(x) | cv2(x)]; the last block overwrites the first half

@@ -588,14 +588,18 @@ def nms_pack_views(pack: torch.Tensor, B: int, max_det: int):
 
 def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, max_det: int, max_nms: int,
                 max_wh: float, cw_sigma: float | None = None, cw_pool: int = 3000, class_keep: torch.Tensor | None = None,
-                pack: torch.Tensor | None = None):
+                pack: torch.Tensor | None = None, nc: int = 0):
     """Returns (dets [B,max_det,6], counts [B] int32, idx [B,max_det] int32, status [1] int32).
     class_keep: uint8 [nc] on the GPU (the `classes=` filter, utils/nms.py:63,132) or None.
-    pack: optional contiguous float32 [nms_pack_numel(B, max_det)] buffer the three outputs are carved from."""
+    pack: optional contiguous float32 [nms_pack_numel(B, max_det)] buffer the three outputs are carved from.
+    nc: number of class rows when y carries extra rows behind them (utils/nms.py:76-81: a Segment head's mask coefficients);
+    0 = every row behind the box is a class.  The carried rows of the kept detections: nms_gather_rows."""
     _need_gpu(y)
     assert y.dtype == torch.float32 and y.is_contiguous()
     B, ch, A = y.shape
-    nc = ch - 4
+    nc = int(nc) or ch - 4
+    extra = ch - 4 - nc
+    assert extra >= 0, f"nc = {nc} but the prediction has {ch - 4} rows behind the box"
     dev = y.device
     nbytes = lib.ymk_nms_workspace_bytes(B, nc, A, int(multi_label), max_nms)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
@@ -611,14 +615,28 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
     e0 = TIMER.begin()
     if class_keep is not None:
         assert class_keep.dtype == torch.uint8 and class_keep.numel() == nc and class_keep.device == y.device and class_keep.is_contiguous()
-    check(lib.ymk_nms_batched(_p(y), B, nc, A, float(conf), float(iou), int(multi_label), int(agnostic), max_det, max_nms,
+    check(lib.ymk_nms_batched(_p(y), B, nc, extra, A, float(conf), float(iou), int(multi_label), int(agnostic), max_det, max_nms,
                               float(max_wh), _p(class_keep), _p(dets), _p(counts), _p(idx), _p(status), _p(ws), nbytes, _stream()),
           "nms_batched")
     if cw_sigma is not None:
         check(lib.ymk_cw_refine(B, nc, A, int(multi_label), int(agnostic), max_nms, max_det, float(iou), float(cw_sigma), cw_pool,
                                 _p(dets), _p(counts), _p(ws), nbytes, _stream()), "cw_refine")
-    TIMER.end(e0, "nms", B * ch * A * 4 + B * max_det * 28, B * ch * A)
+    TIMER.end(e0, "nms", B * (4 + nc) * A * 4 + B * max_det * 28, B * (4 + nc) * A)
     return dets, counts, idx, status
+
+
+def nms_gather_rows(y, nc: int, idx, counts, out=None):
+    """The rows of y behind the class rows, for the detections NMS kept (the `mask` columns of the reference's output rows,
+    utils/nms.py:117,122,127): y fp32 [B, 4+nc+extra, A], idx int32 [B, max_det], counts int32 [B] (nms_batched's outputs)
+    -> fp32 [B, max_det, extra], zeros behind each image's count."""
+    _need_gpu(y)
+    B, ch, A = y.shape
+    extra, max_det = ch - 4 - nc, idx.shape[1]
+    assert extra > 0 and y.dtype == torch.float32 and y.is_contiguous() and idx.dtype == torch.int32 and idx.is_contiguous()
+    if out is None:
+        out = torch.empty((B, max_det, extra), dtype=torch.float32, device=y.device)
+    check(lib.ymk_nms_gather_rows(_p(y), B, ch, A, 4 + nc, extra, _p(idx), _p(counts), max_det, _p(out), _stream()), "nms_gather_rows")
+    return out
 
 
 # ============================================================================= config-5 rows (MoA / MoT / gated MoE)
@@ -926,9 +944,10 @@ def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None):
 
 
 @_timed("token_router")
-def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_k: int, cplx_logit):
+def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_k: int, cplx_logit, clamp: int = 1):
     """Decision tail of the gated MoE (moe/gated.py:124-166, 455-492): logits = clamp(a*g + (1-a)*loc, +-30) with
-    a = sigmoid(alpha); probs = softmax(logits * inv_temp); top-k, weights / (sum + 1e-6); complexity = clamp(mean_b
+    a = sigmoid(alpha); probs = softmax(logits * inv_temp) (clamp=1; clamp=2: the clamp AFTER the scaling, gated.py:972; clamp=0: a
+    router's own plain softmax, gated.py:958 / routers.py:207); top-k, weights / (sum + 1e-6); complexity = clamp(mean_b
     sigmoid(cplx_logit[b]), 0.3, 1.5) (1.0 when non-finite) keeps round(c * top_k) in [1, top_k] ranked experts and
     renormalises (clamp 1e-6).  Inputs fp32 [B,1,1,E] / [B,1,1,1]; returns (w fp32 [B,1,1,top_k], idx int32 [B,top_k], probs,
     rows int32 [top_k*B] = idx transposed: the expert of image j*B + b in expert_conv's slot-major output)."""
@@ -942,7 +961,7 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
     rows = torch.empty((top_k * B,), dtype=torch.int32, device=dev)
     probs = torch.empty((B, E), dtype=torch.float32, device=dev)
     check(lib.ymk_gated_route_decide(_p(g_logits), g_logits.stride(0), _p(loc_logits), loc_logits.stride(0), _p(cplx_logit),
-                                     cplx_logit.stride(0), B, E, float(alpha), float(inv_temp), int(top_k), _p(w), _p(idx), _p(rows),
+                                     cplx_logit.stride(0), B, E, float(alpha), float(inv_temp), int(clamp), int(top_k), _p(w), _p(idx), _p(rows),
                                      _p(probs), _stream()), "gated_route_decide")
     return w, idx, probs, rows
 

@@ -88,6 +88,20 @@ def synth_state_dict(template: dict, seed: int = 0, router_scale: float = 4.0, c
     return out
 
 
+def expert_imbalance(sd: dict, alpha_image: float, alpha_token: float) -> dict:
+    """The expert-imbalance knob of BASELINE config 5: a copy of `sd` with expert 0's logit raised in every router —
+    the ES-MoE routers' second layer (`routing_network.2.bias`, moe/routers.py:429-457), the gated blocks' local stream
+    (`routing.local_conv.6.bias`, moe/gated.py:124-166; the blend scales it by 1 - sigmoid(alpha_param)) by `alpha_image`, and the
+    per-token MoT / MoA routers (`router.router.3.bias`, mot/router.py:243-295, moa/router.py:29-62) by `alpha_token`."""
+    out = {k: v.clone() for k, v in sd.items()}
+    for k in out:
+        if k.endswith("routing.local_conv.6.bias") or k.endswith("routing_network.2.bias"):
+            out[k][0] += alpha_image
+        elif k.endswith("router.router.3.bias"):
+            out[k][0] += alpha_token
+    return out
+
+
 def synth_input(B: int, H: int = 640, W: int = 640, seed: int = 1) -> torch.Tensor:
     """Seeded synthetic images in [0,1], NCHW fp32 (a tensor source skips letterbox and /255,
     engine/predictor.py:164-177).  Every image gets its own tint / contrast / blocky low-frequency

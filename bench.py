@@ -338,13 +338,24 @@ def main():
         return float(t.item())
 
     with torch.inference_mode():
+        main_stream = torch.cuda.current_stream()
         for sl in slots + sync_slots:
-            ctx = torch.cuda.stream(sl.stream) if sl.stream is not None else torch.cuda.stream(torch.cuda.current_stream())
-            with ctx:
-                for _ in range(max(a.warmup // P, 1) if sl in slots else 2):
-                    sl.finish(sl.local_step())
+            for _ in range(max(a.warmup // P, 1) if sl in slots else 2):
+                if sl.stream is not None:
+                    with torch.cuda.stream(sl.stream):
+                        local = sl.local_step()
+                    main_stream.wait_stream(sl.stream)
+                else:
+                    local = sl.local_step()
+                # The collective (N > 1) is issued on the LAUNCHING stream, as in the timed loop — never on a slot's stream: that stream is
+                # captured below, and the process group's watchdog thread polls the completion event of every collective it has not yet
+                # retired (every ~100 ms); an event whose stream is capturing by then fails its query (hipErrorCapturedEvent) and takes
+                # the process down.  First seen when this path ran on RCCL at all (round 4; profiles/r04_closures.log).
+                sl.finish(local)
             torch.cuda.synchronize()
         model.check_flags()
+        if distributed:
+            time.sleep(0.25)     # ... and let the watchdog retire the warm-up collectives before any stream starts capturing
         graph = None
         if not a.no_graph:   # the rank-local step (forward + NMS) is one captured HIP graph at every N (one per slot)
             try:
@@ -366,7 +377,8 @@ def main():
             for sl in slots:
                 sl.run()
             torch.cuda.synchronize()
-            if time.perf_counter() - t_spin > 0.3:
+            # (N > 1: every rank must issue the same number of gathers — the decision to stop is rank 0's... i.e. the slowest rank's)
+            if max_over_ranks(1.0 if time.perf_counter() - t_spin <= 0.3 else 0.0) == 0.0:
                 break
 
         # ---------------------------------------------------------------- the timed region: exactly K steps between barriers

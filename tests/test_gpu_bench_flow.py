@@ -25,7 +25,7 @@ def _port():
 
 
 def _run(cmd, env=None):
-    r = subprocess.run(cmd, cwd=ROOT, env={**os.environ, **(env or {})}, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, env={**os.environ, **(env or {})}, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"expected exactly one JSON line, got {len(lines)}: {r.stdout[-2000:]}"

@@ -41,18 +41,33 @@ def _yolo(scale="n", task="det", seed=0):
     return m
 
 
+def _match(gb, rb, box_tol, score_tol):
+    """Row j of the reference's detections -> the row of the hooked run that is the same detection (same class, score within
+    score_tol, box within box_tol).  Position-wise comparison is not enough: detections with EQUAL scores (saturated logits of the
+    seeded random weights) come out of the reference's unstable argsort in an order of its own."""
+    assert gb.shape == rb.shape and gb.shape[0] > 0, (gb.shape, rb.shape)
+    used = torch.zeros(gb.shape[0], dtype=torch.bool)
+    perm = []
+    for j in range(rb.shape[0]):
+        ok = (gb[:, 5] == rb[j, 5]) & ((gb[:, 4] - rb[j, 4]).abs() <= score_tol) & ~used
+        assert bool(ok.any()), f"reference detection {j} (class {int(rb[j, 5])}, score {float(rb[j, 4]):.6f}) has no counterpart"
+        dist = (gb[:, :4] - rb[j, :4]).abs().max(1).values.masked_fill(~ok, float("inf"))
+        i = int(dist.argmin())
+        assert float(dist[i]) <= box_tol, f"reference detection {j}: nearest counterpart is {float(dist[i]):.3e} px away"
+        used[i] = True
+        perm.append(i)
+    return torch.tensor(perm)
+
+
 def _same_detections(got, ref, box_tol=1e-2, score_tol=1e-4):
     assert len(got) == len(ref)
-    n = 0
+    n, perms = 0, []
     for g, r in zip(got, ref):
         gb, rb = g.boxes.data.float().cpu(), r.boxes.data.float().cpu()
-        assert gb.shape == rb.shape and gb.shape[0] > 0, (gb.shape, rb.shape)
-        assert torch.equal(gb[:, 5], rb[:, 5]), "classes differ"
-        assert float((gb[:, 4] - rb[:, 4]).abs().max()) <= score_tol, float((gb[:, 4] - rb[:, 4]).abs().max())
-        assert float((gb[:, :4] - rb[:, :4]).abs().max()) <= box_tol, float((gb[:, :4] - rb[:, :4]).abs().max())
+        perms.append(_match(gb, rb, box_tol, score_tol))
         assert g.orig_shape == r.orig_shape and g.names == r.names
         n += gb.shape[0]
-    return n
+    return n, perms
 
 
 def test_reference_predict_on_the_gpu_through_the_hooks():
@@ -72,7 +87,7 @@ def test_reference_predict_on_the_gpu_through_the_hooks():
         got = m.predict(x, **kw)
         st = dropin.stats(m)
         assert st["calls"] >= 1 and st["nms_calls"] >= 1, st
-        n = _same_detections(got, ref)
+        n, _ = _same_detections(got, ref)
         print(f"reference predict(device=0) through the libymk hooks: {n} detections identical in class, <= 1e-4 in score, <= 1e-2 px; hook stats {st}")
         core = m.model
         before = dropin.stats(m)["fallbacks"]
@@ -93,7 +108,7 @@ def test_reference_half_precision_predict_runs_the_fp16_library():
     from yolo_master_amd.weights import synth_input
 
     x = synth_input(2, 256, 256, seed=43)
-    kw = dict(conf=0.25, iou=0.7, verbose=False, device=0)
+    kw = dict(conf=0.002, iou=0.7, verbose=False, device=0)
     ref32 = _yolo().predict(x, **kw)
     ref16 = _yolo().predict(x, half=True, **kw)
     m = _yolo()
@@ -118,8 +133,9 @@ def test_reference_half_precision_predict_runs_the_fp16_library():
         return hit / max(tot, 1)
 
     o_ref, o_got = overlap(ref32, ref16), overlap(ref32, got)
-    print(f"half=True: share of the fp32 reference's detections found again — reference's own fp16 run {o_ref:.3f}, libymk fp16 {o_got:.3f}")
-    assert o_got >= o_ref - 0.05 and o_got >= 0.85
+    n32 = sum(r.boxes.data.shape[0] for r in ref32)
+    print(f"half=True: share of the fp32 reference's {n32} detections found again — reference's own fp16 run {o_ref:.3f}, libymk fp16 {o_got:.3f}")
+    assert n32 > 0 and o_got >= o_ref - 0.05 and o_got >= 0.5
 
 
 def test_validator_calls_on_the_gpu():
@@ -217,7 +233,7 @@ def test_segment_predict_on_the_gpu_through_the_hooks():
     if not os.path.exists(_yaml("n", "seg")):
         pytest.skip("no v0 segmentation YAML in this reference checkout")
     x = synth_input(2, 256, 256, seed=44)
-    kw = dict(conf=0.25, iou=0.7, verbose=False, device=0)
+    kw = dict(conf=0.002, iou=0.7, verbose=False, device=0)
     ref = _yolo(task="seg").predict(x, **kw)
     m = _yolo(task="seg")
     yolo_master_amd.enable(m)
@@ -225,12 +241,12 @@ def test_segment_predict_on_the_gpu_through_the_hooks():
         got = m.predict(x, **kw)
         st = dropin.stats(m)
         assert st["calls"] >= 1 and st["nms_calls"] >= 1 and not dropin._PATCHED.get("_nms_fallbacks"), (st, dropin._PATCHED.get("_nms_fallbacks"))
-        n = _same_detections(got, ref, box_tol=2e-2)
-        for g, r in zip(got, ref):
+        n, perms = _same_detections(got, ref, box_tol=2e-2)
+        for g, r, perm in zip(got, ref, perms):
             if r.masks is None:
                 assert g.masks is None
                 continue
-            gm, rm = g.masks.data.bool().cpu(), r.masks.data.bool().cpu()
+            gm, rm = g.masks.data.bool().cpu()[perm], r.masks.data.bool().cpu()
             assert gm.shape == rm.shape
             assert float((gm != rm).float().mean()) <= 2e-3, "mask pixels differ beyond boundary flips"
         print(f"segment predict(device=0) through the hooks: {n} instances, boxes / classes / masks equal to the un-hooked reference")

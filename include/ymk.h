@@ -233,6 +233,17 @@ int ymk_esmoe_experts_fused(int32_t dtype, const void* x, int32_t B, int32_t H, 
                             int32_t Cout, int32_t Kpad, const void* pw_w, const float* pw_b,
                             const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
                             const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
+/* The expert body of a layer as ONE wave-specialised kernel (csrc/esfused.hip): per (image, 8 x 16 / 8 x 8 pixel tile) the halo of x
+ * is staged once for both retained experts of the image, stencil waves (VALU) leave the depthwise tile in LDS, matrix-core waves run
+ * the pointwise product of the previous tile chunk with the BN / SiLU / gate / accumulate / trailing-norm epilogue.  Same arguments
+ * and bit-identical results as ymk_esmoe_dw followed by ymk_esmoe_pw; no dw_out buffer.  16-bit builds' element type only;
+ * ymk_esmoe_fused_supported: Cin == Cout in {128, 256}, stencils 3 ... 9, top_k <= 2, E <= 4. */
+int ymk_esmoe_fused_supported(int32_t dtype, int32_t C, int32_t Cout, int32_t H, int32_t W, int32_t kmax, int32_t E, int32_t top_k);
+int ymk_esmoe_fused(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                    const void* dw_w, const int32_t* dw_off, const int32_t* ksizes, int32_t kmax,
+                    int32_t Cout, int32_t Kpad, const void* pw_w, const float* pw_b,
+                    const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
+                    const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
 /* DWConv(k x k)+BN(+SiLU) -> Conv(1x1)+BN(+SiLU) pair in one kernel (Detect class branch,
  * ultralytics/nn/modules/head.py:111-118).  dw_w [k*k][C], dw_bias fp32 [C] or NULL, pw_w [Cout][Kpad]. */
 int ymk_dwconv_pwconv(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,

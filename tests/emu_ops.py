@@ -266,6 +266,26 @@ def esmoe_pw(dw_out, B, H, W, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, ou
     return out
 
 
+def esmoe_fused_supported(dtype, C, Cout, H, W, kmax, E, top_k):
+    return dtype in (torch.bfloat16, torch.float16) and C == Cout and C in (128, 256) and 3 <= kmax <= 9 and E <= 4 and top_k <= 2
+
+
+def esmoe_fused(x, dw_w, dw_off, ksizes, kmax, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, out=None):
+    """The contract of ymk_esmoe_fused: the same result as the depthwise stage followed by the pointwise stage."""
+    _count("esmoe_fused")
+    B, H, W, C = x.shape
+    dw = torch.zeros((B * top_k, H, W, C), dtype=x.dtype)
+    xn = _nchw(x)
+    for b in range(B):
+        for slot in range(top_k):
+            e = int(sel[b, slot])
+            if e >= 0:
+                k = int(ksizes[e])
+                w = dw_w[int(dw_off[e]): int(dw_off[e]) + k * k * C].reshape(k * k, C)
+                dw[b * top_k + slot] = _dw(xn[b: b + 1], w, k)[0].permute(1, 2, 0).to(x.dtype)
+    return esmoe_pw(dw, B, H, W, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, out=out)
+
+
 def esmoe_experts_fused(x, dw_w, dw_off, ksizes, kmax, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, out=None):
     raise AssertionError("host code must ask dwpw_supported() first")
 
@@ -657,7 +677,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
 
 
 EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "esmoe_route", "esmoe_dw",
-            "esmoe_pw", "esmoe_experts_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
+            "esmoe_pw", "esmoe_experts_fused", "esmoe_fused_supported", "esmoe_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",

@@ -17,7 +17,7 @@ ROOT = HERE.parent.parent
 CSRC = ROOT / "yolo_master_amd" / "csrc"
 OUT = HERE / "_build"
 SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "dwmfma.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip",
-           "esmoe.hip", "attn.hip", "nms.hip", "conv.hip", "dwconv.hip", "elementwise.hip", "dwpw.hip", "capi.hip"]
+           "esmoe.hip", "attn.hip", "nms.hip", "conv.hip", "dwconv.hip", "elementwise.hip", "dwpw.hip", "capi.hip", "esfused.hip"]
 
 
 def compiler():
@@ -35,7 +35,7 @@ def build(force: bool = False, f16: bool = False) -> Path | None:
     OUT.mkdir(exist_ok=True)
     lib = OUT / ("libymk_hostemu_f16.so" if f16 else "libymk_hostemu.so")
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / "ymk_common.h", ROOT / "include" / "ymk_mixture.h", HERE / "hip" / "hip_runtime.h", Path(__file__)]
+    deps = srcs + [CSRC / "ymk_common.h", CSRC / "glds.h", CSRC / "igemm.h", ROOT / "include" / "ymk_mixture.h", HERE / "hip" / "hip_runtime.h", Path(__file__)]
     if not force and lib.exists() and lib.stat().st_mtime >= max(d.stat().st_mtime for d in deps):
         return lib
     units = []
@@ -46,6 +46,7 @@ def build(force: bool = False, f16: bool = False) -> Path | None:
         txt = re.sub(r"\b__shared__\b", "static", txt)
         txt = txt.replace('#include "ymk_common.h"', f'#include "{CSRC / "ymk_common.h"}"')
         txt = txt.replace('#include "igemm.h"', f'#include "{CSRC / "igemm.h"}"')
+        txt = txt.replace('#include "glds.h"', f'#include "{CSRC / "glds.h"}"')
         txt = txt.replace('#include "../../include/ymk_mixture.h"', f'#include "{ROOT / "include" / "ymk_mixture.h"}"')
         u = OUT / (s.stem + ("_host_f16.cpp" if f16 else "_host.cpp"))
         u.write_text(txt)

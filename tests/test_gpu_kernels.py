@@ -317,6 +317,25 @@ def test_esmoe_block(dtype, fused, cin, hw):
         assert seg == sorted(seg) and all(int(sel.view(-1)[p]) == e for p in seg)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    (128, 6, 160, 160, [[0, 3], [2, -1], [1, 2], [3, -1], [-1, -1], [3, 1]]),     # layer 3 of the S detector: 8 x 16 tiles, 200 per image
+    (256, 9, 80, 80, [[3, 0], [1, -1], [2, 3]]),                                  # layer 6: 8 x 8 tiles, four channel chunks
+    (256, 64, 40, 40, [[3, 0], [1, -1], [2, 3], [0, -1], [3, 2]]),                # layer 9 at the benchmarked batch: 1600 items on 256 workgroups
+    (128, 3, 37, 53, [[3, 1], [0, -1], [2, 3]]),                                  # ragged map: tiles hanging over the right and bottom edges
+], ids=lambda c: f"C{c[0]}-{c[2]}x{c[3]}-B{c[1]}")
+def test_esmoe_fused_equals_two_kernel_form(case, dtype):
+    """csrc/esfused.hip (the expert body as ONE wave-specialised kernel: LDS-DMA halo staged once for both retained experts, stencil
+    waves -> LDS tile -> matrix-core waves) BIT-identical to ymk_esmoe_dw + ymk_esmoe_pw at the detector's own shapes, bf16 and fp16
+    builds; plus the torch restatement within the 16-bit tolerance on the small case."""
+    from tests.test_hostemu_esfused import run_fused_case
+    from yolo_master_amd import ops
+
+    if dtype == torch.float16 and not ops.HAS_F16:
+        pytest.skip("libymk_f16.so not built")
+    run_fused_case(ops, case, dev=DEV, dtype=dtype, check_emu=case[1] <= 3)
+
+
 ESMOE_MODES = {"sparse": {}, "dense": dict(use_sparse_inference=False), "disabled": {}, "all": dict(top_k=None),
                "k3of4": dict(top_k=3, dynamic_threshold=0.2)}
 

@@ -79,6 +79,9 @@ SYMBOLS = {
     "ymk_dwpw_supported": (C.c_int, [_i32, _i32, _i32]),
     "ymk_esmoe_experts_fused": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
                                           _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "ymk_esmoe_fused_supported": (C.c_int, [_i32] * 8),
+    "ymk_esmoe_fused": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
+                                  _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "ymk_dwconv_pwconv": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
                                     _i32, _vp, _i32, _vp]),
     "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

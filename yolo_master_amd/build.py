@@ -24,8 +24,9 @@ ARCH = "gfx950"
 NO_CONTRACT = {"nms.hip", "elementwise.hip", "post.hip", "preproc.hip"}
 SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "dwmfma.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip", "esmoe.hip", "dwpw.hip", "attn.hip", "elementwise.hip", "nms.hip",
            "mixture.hip", "mixattn.hip",   # config-5 rows, first implementation (include/ymk_mixture.h)
-           "conv_glds.hip", "post.hip", "preproc.hip"]    # opt-in: next tiled convolution core, box rescaling (include/ymk_next.h)
-HEADERS = ["ymk_common.h", "igemm.h", "../../include/ymk.h", "../../include/ymk_mixture.h", "../../include/ymk_next.h"]
+           "conv_glds.hip", "post.hip", "preproc.hip",
+           "esfused.hip"]   # ES-MoE expert body as one kernel per layer (depthwise stencil -> grouped GEMM, wave-specialised)    # opt-in: next tiled convolution core, box rescaling (include/ymk_next.h)
+HEADERS = ["ymk_common.h", "igemm.h", "glds.h", "../../include/ymk.h", "../../include/ymk_mixture.h", "../../include/ymk_next.h"]
 
 
 def _hipcc() -> str:
@@ -41,7 +42,7 @@ def source_hash() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(SOURCES) + ["ymk_common.h", "igemm.h"]:
+    for f in sorted(SOURCES) + ["ymk_common.h", "igemm.h", "glds.h"]:
         h.update(f.encode())
         h.update((CSRC / f).read_bytes())
     return h.hexdigest()[:16]

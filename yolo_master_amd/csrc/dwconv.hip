@@ -181,22 +181,34 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
         for (int r = 0; r < DW_R; ++r) { acc[r][0] = f32x2{0.f, 0.f}; acc[r][1] = f32x2{0.f, 0.f}; }
 #pragma unroll 1
         for (int ky = 0; ky < ((DW_ABLATE & 4) ? 1 : K); ++ky) {
+            // ALL LDS reads of this filter row (K taps + DW_R + K - 1 pixels) are issued before the first use.  Left to itself the
+            // compiler reads one or two operands at a time and waits for each (`ds_read2_b64; s_waitcnt lgkmcnt(0)`, 14 times per row at
+            // k = 9): one LDS round trip per pair of operands beside ~20 packed FMAs — what kept this kernel at 0.4 of the VALU rate
+            // with four waves per SIMD (found in the ISA of csrc/esfused.hip's stencil, round 4).  Same arithmetic, same order.
+            typedef typename Raw4<T>::type raw_t;
+            raw_t rw[K], rd[DW_R + K - 1];
+            const char* row = smem + (size_t)(y + ky) * RP + x0 * D::PSB + cg * 4 * sizeof(T);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                if constexpr (sizeof(T) == 2) rw[kx] = *reinterpret_cast<const raw_t*>(wsb + (ky * K + kx) * D::CB + cg * 4);
+                else rw[kx] = *reinterpret_cast<const raw_t*>(wsm + (ky * K + kx) * D::CB + cg * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < DW_R + K - 1; ++j) rd[j] = *reinterpret_cast<const raw_t*>(row + (size_t)j * D::PSB);
+#if !defined(YMK_HOST_EMU) && !defined(DW_SERIAL_READS)   // (-DDW_SERIAL_READS: the compiler's own schedule, for A/B runs: tools/micro/dw_batch_ab.sh)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             f32x2 wr[K][2];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                if constexpr (sizeof(T) == 2) {
-                    const u32x2 t2 = *reinterpret_cast<const u32x2*>(wsb + (ky * K + kx) * D::CB + cg * 4);
-                    h16x4_widen(t2, wr[kx][0], wr[kx][1]);
-                } else {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(wsm + (ky * K + kx) * D::CB + cg * 4);
-                    wr[kx][0] = f32x2{t4.x, t4.y}; wr[kx][1] = f32x2{t4.z, t4.w};
-                }
+                if constexpr (sizeof(T) == 2) h16x4_widen(rw[kx], wr[kx][0], wr[kx][1]);
+                else { wr[kx][0] = f32x2{rw[kx].x, rw[kx].y}; wr[kx][1] = f32x2{rw[kx].z, rw[kx].w}; }
             }
-            const char* row = smem + (size_t)(y + ky) * RP + x0 * D::PSB + cg * 4 * sizeof(T);
 #pragma unroll
             for (int j = 0; j < DW_R + K - 1; ++j) {
                 f32x2 va, vb;
-                lds_ld4(row + (size_t)j * D::PSB, va, vb, T{});
+                if constexpr (sizeof(T) == 2) h16x4_widen(rd[j], va, vb);
+                else { va = f32x2{rd[j].x, rd[j].y}; vb = f32x2{rd[j].z, rd[j].w}; }
 #pragma unroll
                 for (int r = 0; r < DW_R; ++r) {
                     const int kx = j - r;  // compile-time after unrolling

@@ -884,8 +884,20 @@ __global__ __launch_bounds__(512) void moe_pw_lean_kernel(MoePwArgs a) {
                 for (int jj = 0; jj < 4; ++jj) {
                     f32x4 v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (PRECISE ? silu_exact(acc[q][jj][r]) : silu_f(acc[q][jj][r])) * gw;
-                    if (first) part[q][jj] = v; else part[q][jj] += v;
+                    for (int r = 0; r < 4; ++r) {
+                        // 16-bit builds: the weighted expert output is a ROUNDED product that is then added (modules.py:697-702:
+                        // `expert_out * w`, index_add_) — no FMA contraction, so the sum of an image's two experts does not depend on
+                        // the order they are visited in (it alternates tile by tile here; csrc/esfused.hip visits them in slot order
+                        // and must produce the same bits).  fp32 keeps the arithmetic its fixtures were recorded with.
+                        if constexpr (PRECISE) v[r] = silu_exact(acc[q][jj][r]) * gw;
+                        else v[r] = ymk_mul_rn(silu_f(acc[q][jj][r]), gw);
+                    }
+                    if (first) part[q][jj] = v;
+                    else if constexpr (PRECISE) part[q][jj] += v;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[q][jj][r] = ymk_add_rn(part[q][jj][r], v[r]);
+                    }
                 }
         } else if (first) {
 #pragma unroll

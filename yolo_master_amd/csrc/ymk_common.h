@@ -75,6 +75,16 @@ __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }   // torch.nn.GELU default (erf form)
 __device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// a * b and a + b as separately rounded operations the compiler may not contract into an FMA (hipcc's default is -ffp-contract=fast)
+__device__ __forceinline__ float ymk_mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float ymk_add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 template <typename T>
 struct ElemTraits;
 template <>

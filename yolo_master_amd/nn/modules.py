@@ -825,6 +825,11 @@ class ES_MOE(YmkModule):
     # Fused depthwise->pointwise kernel (csrc/dwpw.hip): correct (tests cover it) but measured SLOWER than the two-kernel
     # form on MI355X round 1 (14.6 vs 10.1 ms/step: 1 workgroup/CU, per-wave weight re-reads) -> off by default.
     fuse_experts = False
+    # The expert body as ONE wave-specialised kernel per layer (csrc/esfused.hip, round 4; 16-bit modes, C in {128, 256}, top_k <= 2):
+    # bit-identical to the two-kernel form and validated on MI355X, but measured SLOWER (layer 3 of the S detector at batch 64: 1.10 ms
+    # against 0.44 + 0.23 ms; stage ablation in profiles/r04_esfused_ablation.txt: one stencil wave per SIMD cannot hide its LDS round
+    # trips, and the matrix waves' transfer -> MFMA -> epilogue phases run in lock step) -> off by default, YMK_ENABLE=64 turns it on.
+    fuse_layer = bool(ops.ymk_enabled_bits() & 64)
 
     def __init__(self, in_channels, out_channels=None, num_experts=4, reduction=8, top_k=2, use_sparse_inference=True,
                  dynamic_threshold=0.4, max_kernel_size=15, expert_kernel_sizes=None):
@@ -993,7 +998,12 @@ class ES_MOE(YmkModule):
         thr = float(self.dynamic_threshold) if self._eager_sparse_enabled() else -1.0
         route_w, gate_w, sel, csr_off, csr_pair, state = ops.esmoe_route(
             x, pk["w1"], pk["b1"], pk["w2"], pk["b2"], top_k, thr, self._flags)
-        if self.fuse_experts and ops.dwpw_supported(x.dtype, C, pk["kmax"]):
+        if self.fuse_layer and ops.esmoe_fused_supported(x.dtype, C, self.out_channels, H, W, pk["kmax"], self.num_experts, top_k):
+            # the whole expert body as one wave-specialised kernel (csrc/esfused.hip): the halo of x staged once for both retained
+            # experts of an image, the depthwise tile handed to the matrix cores through LDS — no dw_out buffer, bit-identical results
+            y = ops.esmoe_fused(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel,
+                                gate_w, out=out)
+        elif self.fuse_experts and ops.dwpw_supported(x.dtype, C, pk["kmax"]):
             # depthwise -> pointwise in one kernel: the stencil tile never leaves LDS
             y = ops.esmoe_experts_fused(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], pk["pw_w"], pk["pw_b"], pk["ns"],
                                         pk["nt"], top_k, sel, gate_w, out=out)

@@ -454,6 +454,43 @@ def esmoe_experts_fused(x, dw_w, dw_off, ksizes, kmax: int, pw_w, pw_b, nscale, 
     return out
 
 
+def ymk_enabled_bits() -> int:
+    """YMK_ENABLE=<bitmask>: opt-in switches for validated-but-not-default code paths (csrc/ymk_common.h ymk_enabled)."""
+    return int(os.environ.get("YMK_ENABLE", "0"), 0)
+
+
+def esmoe_fused_supported(dtype, C: int, Cout: int, H: int, W: int, kmax: int, E: int, top_k: int) -> bool:
+    """The one-kernel expert body (csrc/esfused.hip) takes this layer.  YMK_DISABLE bit 2097152 switches it off (A/B runs: the
+    two-kernel depthwise + pointwise path computes the same bits)."""
+    if dtype not in H16 or (int(os.environ.get("YMK_DISABLE", "0"), 0) & 2097152):
+        return False
+    use_format(dtype)
+    return bool(lib.ymk_esmoe_fused_supported(DT[dtype], C, Cout, H, W, kmax, E, top_k))
+
+
+def esmoe_fused(x, dw_w, dw_off, ksizes, kmax: int, pw_w, pw_b, nscale, nshift, top_k: int, sel, gate_w, out=None):
+    """ymk_esmoe_fused (include/ymk.h): depthwise stencil -> pointwise grouped GEMM -> gate / accumulate / trailing norm of the retained
+    experts of every image in one kernel; bit-identical to esmoe_dw + esmoe_pw."""
+    B, H, W, Cc, ldx = _nhwc(x)
+    E, Cout, Kp = pw_w.shape
+    if out is None:
+        out = new_act(B, H, W, Cout, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_esmoe_fused(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), kmax, Cout, Kp,
+                              _p(pw_w), _p(pw_b), _p(nscale), _p(nshift), E, top_k, _p(sel), _p(gate_w), _p(out), ldy, _stream()),
+          "esmoe_fused")
+    if e0 is not None:   # algorithmic traffic: every image in once, out once, the weights; flops of the retained (image, expert) pairs
+        e1 = TIMER.begin()
+        pairs = sel >= 0
+        npairs = int(pairs.sum())
+        k2 = float((ksizes.float()[sel.clamp_min(0).long()] ** 2 * pairs).sum()) / max(npairs, 1)     # mean stencil size of the retained pairs
+        es = x.element_size()
+        TIMER.records.append(("moe_fused", e0, e1, (B * H * W * (Cc + Cout) + E * Cout * Cc) * es, int(2 * npairs * H * W * Cc * (Cout + k2))))
+        TIMER.shapes.append(f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
+    return out
+
+
 def dwconv_pwconv(x, dw_w, dw_b, k: int, dw_act: bool, pw_w, pw_b, pw_act: bool, out=None):
     B, H, W, Cc, ldx = _nhwc(x)
     Cout, Kp = pw_w.shape

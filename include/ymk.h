@@ -223,16 +223,6 @@ int ymk_esmoe_pw(int32_t dtype, const void* dw_out, int32_t B, int32_t H, int32_
                  const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
                  const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
 
-/* Fused expert body: depthwise stage + pointwise grouped GEMM + gate/accumulate + trailing norm in ONE
- * kernel (same arguments and results as ymk_esmoe_dw followed by ymk_esmoe_pw, without the dw_out buffer:
- * the stencil result tile stays in LDS as the GEMM operand).  Supported when ymk_dwpw_supported(dtype, C,
- * kmax) != 0 (C a multiple of 64 bf16 / 32 fp32, kmax <= 9, tile fits 160 KB LDS). */
-int ymk_dwpw_supported(int32_t dtype, int32_t C, int32_t kmax);
-int ymk_esmoe_experts_fused(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
-                            const void* dw_w, const int32_t* dw_off, const int32_t* ksizes, int32_t kmax,
-                            int32_t Cout, int32_t Kpad, const void* pw_w, const float* pw_b,
-                            const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
-                            const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
 /* The expert body of a layer as ONE wave-specialised kernel (csrc/esfused.hip): per (image, 8 x 16 / 8 x 8 pixel tile) the halo of x
  * is staged once for both retained experts of the image, stencil waves (VALU) leave the depthwise tile in LDS, matrix-core waves run
  * the pointwise product of the previous tile chunk with the BN / SiLU / gate / accumulate / trailing-norm epilogue.  Same arguments
@@ -244,13 +234,6 @@ int ymk_esmoe_fused(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t 
                     int32_t Cout, int32_t Kpad, const void* pw_w, const float* pw_b,
                     const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
                     const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
-/* DWConv(k x k)+BN(+SiLU) -> Conv(1x1)+BN(+SiLU) pair in one kernel (Detect class branch,
- * ultralytics/nn/modules/head.py:111-118).  dw_w [k*k][C], dw_bias fp32 [C] or NULL, pw_w [Cout][Kpad]. */
-int ymk_dwconv_pwconv(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
-                      const void* dw_w, const float* dw_bias, int32_t ksize, int32_t dw_act, int32_t Cout,
-                      int32_t Kpad, const void* pw_w, const float* pw_b, int32_t pw_act, void* y, int32_t ldy,
-                      void* stream);
-
 /* ------------------------------------------------------------------------
  * Area attention core: softmax(q^T k / sqrt(d)) v per (image, area, head)
  * (AAttn.forward block.py:1696-1726).  qkv is the NHWC output of the qkv 1x1
@@ -283,25 +266,6 @@ int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int3
 int ymk_mlp_fused_supported(int32_t dtype, int32_t C, int32_t hidden);
 int ymk_mlp_fused(const void* x, int32_t ldx, const void* w1, int32_t k1pad, const float* b1, const void* w2, int32_t k2pad,
                   const float* b2, void* y, int32_t ldy, int64_t M, int32_t C, int32_t hidden, void* stream);
-
-/* ------------------------------------------------------------------------
- * Depthwise convolution on the matrix cores (bf16, odd k <= 9, C % 16 == 0): the same operations as ymk_dwconv2d /
- * ymk_esmoe_dw (DWConv conv.py:185-199, AAttn.pe block.py:1688,1731, DepthwiseSeparableConv.depthwise
- * experts.py:283-292), evaluated as banded (Toeplitz) GEMMs along x — one 16x16x32 MFMA per (channel, filter row,
- * 16x16 output tile), see csrc/dwmfma.hip.  The filter is consumed as a table of MFMA A fragments built once at pack
- * time: ymk_dw_toeplitz_pack turns the [k*k][C] bf16 filter of ymk_dwconv2d into ymk_dw_toeplitz_elems(C, k) bf16
- * elements; ES-MoE concatenates the experts' tables in expert order.
- * ------------------------------------------------------------------------ */
-int ymk_dw_mfma_supported(int32_t dtype, int32_t C, int32_t ksize);
-size_t ymk_dw_toeplitz_elems(int32_t C, int32_t ksize);
-int ymk_dw_toeplitz_pack(const void* w_packed /*bf16 [k*k][C]*/, int32_t C, int32_t ksize, void* out, void* stream);
-int ymk_dwconv2d_mfma(const void* x, const void* toeplitz, const float* bias, const void* residual, void* y,
-                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t ksize, int32_t ldx, int32_t ldy,
-                      int32_t ldr, int32_t act, void* stream);
-int ymk_esmoe_dw_mfma(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx, const void* toeplitz,
-                      const int32_t* ksizes /*device [E]*/, int32_t kmask /*host: bit (k-1)/2 per filter size present*/,
-                      int32_t E, int32_t top_k, const int32_t* csr_off, const int32_t* csr_pair, void* dw_out,
-                      void* stream);
 
 /* ------------------------------------------------------------------------
  * Detect decode: DFL softmax-expectation + dist2bbox(xywh) * stride + sigmoid

@@ -91,6 +91,13 @@ int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, float* out, int
 int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int32_t ldw, int32_t* active, int32_t B, int32_t HW,
                       int32_t n, float inv_temp, int32_t top_k, void* stream);
 
+/* MoA sparse inference (moa/block.py:194-234, eval with `sparse_inference=True`): a head group whose gate is at or below `threshold`
+ * for every token of the batch is skipped (none above it: the group with the largest mean gate runs alone); the retained gates are
+ * renormalised per token.  w fp32 [npix][ldw], n <= 8 groups; stats: ZEROED scratch of 12 * n bytes, 8-byte aligned; active int32 [n];
+ * blend fp32 [npix][ldb]: the retained groups' gates in columns 0 .. #active - 1 (the order of the groups), zeros behind. */
+int ymk_moa_sparse_gate(const float* w, int32_t ldw, int64_t npix, int32_t n, float threshold, void* stats, float* blend, int32_t ldb,
+                        int32_t* active, void* stream);
+
 /* Decision tail of the gated MoE (moe/gated.py:124-166, 455-492), one workgroup.  g / loc fp32 [B][ld*] logits of the
  * two router streams, cplx fp32 [B][ldc] complexity logit; outputs w fp32 [B][top_k], idx int32 [B][top_k] (and its
  * transpose), probs fp32 [B][E].  E <= 64, top_k <= 8.

@@ -167,18 +167,39 @@ def global_head(sd, p, x, nh, hd):
 
 
 def moa_block(sd, p, x, num_heads, temperature=1.0, shortcut=True, local_window_size=7, regional_max_kv_tokens=4096,
-              info=None):
-    """MoABlock.forward (moa/block.py:167-278), eval, dense routing: per-token softmax gate over the three heads
-    (accumulated local, regional, global in that order), fusion Conv (no act), layer-scale residuals, FFN."""
+              info=None, sparse_inference=False, sparse_inference_threshold=0.02):
+    """MoABlock.forward (moa/block.py:167-278), eval: per-token softmax gate over the three heads (accumulated local,
+    regional, global in that order), fusion Conv (no act), layer-scale residuals, FFN.  sparse_inference (block.py:194-234):
+    a head group whose gate stays at or below the threshold for EVERY token of the batch is skipped (none above it: the group
+    with the largest mean gate runs alone) and the retained gates are renormalised per token."""
     dim = x.shape[1]
     hd = max(dim // num_heads, 16)      # block.py:90
     nh = num_heads // NUM_GROUPS        # block.py:91
     w, logits = moa_router(sd, f"{p}.router", x, temperature)
+    active = None
+    if sparse_inference:
+        active = w.amax(dim=(0, 2, 3)) > sparse_inference_threshold
+        if not bool(active.any()):
+            active = torch.zeros_like(active)
+            active[w.mean(dim=(0, 2, 3)).argmax()] = True
+        if bool(active.all()):
+            active = None
     if info is not None:
-        info[p] = {"weights": w, "logits": logits}
-    mixed = w[:, 0:1] * local_head(sd, f"{p}.local_head", x, nh, hd, local_window_size)
-    mixed = mixed + w[:, 1:2] * regional_head(sd, f"{p}.region_head", x, nh, hd, 2, regional_max_kv_tokens)
-    mixed = mixed + w[:, 2:3] * global_head(sd, f"{p}.global_head", x, nh, hd)
+        info[p] = {"weights": w, "logits": logits, "active": None if active is None else active.clone()}
+    heads = (lambda: local_head(sd, f"{p}.local_head", x, nh, hd, local_window_size),
+             lambda: regional_head(sd, f"{p}.region_head", x, nh, hd, 2, regional_max_kv_tokens),
+             lambda: global_head(sd, f"{p}.global_head", x, nh, hd))
+    if active is not None:
+        bw = w * active.view(1, -1, 1, 1)
+        bw = bw / bw.sum(dim=1, keepdim=True).clamp_min(torch.finfo(w.dtype).eps)
+        mixed = x.new_zeros(x.shape)
+        for g in range(NUM_GROUPS):
+            if bool(active[g]):
+                mixed = mixed + bw[:, g:g + 1] * heads[g]()
+    else:
+        mixed = w[:, 0:1] * heads[0]()
+        mixed = mixed + w[:, 1:2] * heads[1]()
+        mixed = mixed + w[:, 2:3] * heads[2]()
     mixed = conv(sd, f"{p}.fusion", mixed, act=False, fused=False)
 
     def ffn(t):

@@ -119,10 +119,6 @@ def dwconv2d(x, w_packed, bias, k, act, out=None, residual=None):
     return _finish(y, act, residual, out, x.dtype)
 
 
-def dwpw_supported(dtype, C, kmax):
-    return False
-
-
 def stem_pair_supported(dtype, cin, c0, c1, k0, s0, k1, s1):
     return dtype == torch.bfloat16 and (cin, c0, c1, k0, s0, k1, s1) == (3, 32, 64, 3, 2, 3, 2)
 
@@ -171,12 +167,6 @@ def mlp_fused(x, w1, b1, w2, b2, out=None):
     _count("mlp_fused")
     h = conv2d(x, w1, b1, 1, 1, True)
     return conv2d(h, w2, b2, 1, 1, False, out=out, residual=x)
-
-
-def dwconv_pwconv(x, dw_w, dw_b, k, dw_act, pw_w, pw_b, pw_act, out=None):
-    _count("dwconv_pwconv")
-    h = dwconv2d(x, dw_w, dw_b, k, dw_act)
-    return conv2d(h, pw_w, pw_b, 1, 1, pw_act, out=out)
 
 
 # ------------------------------------------------------------------------------------------------- ES-MoE
@@ -229,7 +219,7 @@ def esmoe_route(x, w1, b1, w2, b2, top_k, thr, flags):
     return route_w, gate_w, sel, csr_off, csr_pair, torch.cat([usage, (E * (un * un).sum()).view(1)])
 
 
-def esmoe_dw(x, dw_w, dw_off, ksizes, kmax, top_k, sel, csr_off, csr_pair, toep=None, kmask=0):
+def esmoe_dw(x, dw_w, dw_off, ksizes, kmax, top_k, sel, csr_off, csr_pair):
     _count("esmoe_dw")
     B, H, W, C = x.shape
     assert kmax == int(ksizes.max())
@@ -284,10 +274,6 @@ def esmoe_fused(x, dw_w, dw_off, ksizes, kmax, pw_w, pw_b, nscale, nshift, top_k
                 w = dw_w[int(dw_off[e]): int(dw_off[e]) + k * k * C].reshape(k * k, C)
                 dw[b * top_k + slot] = _dw(xn[b: b + 1], w, k)[0].permute(1, 2, 0).to(x.dtype)
     return esmoe_pw(dw, B, H, W, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, out=out)
-
-
-def esmoe_experts_fused(x, dw_w, dw_off, ksizes, kmax, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, out=None):
-    raise AssertionError("host code must ask dwpw_supported() first")
 
 
 # ------------------------------------------------------------------------------------------------- attention / layout
@@ -600,6 +586,22 @@ def token_softmax(logits, n, inv_temp, top_k=0, out=None):
     return _put(w, out, torch.float32), active
 
 
+def moa_sparse_gate(weights, n, threshold):
+    _count("moa_sparse_gate")
+    w = weights[..., :n]
+    active = w.amax(dim=(0, 1, 2)) > threshold
+    if not bool(active.any()):
+        active = torch.zeros_like(active)
+        active[w.mean(dim=(0, 1, 2)).argmax()] = True
+    bw = w * active.view(1, 1, 1, -1)
+    bw = bw / bw.sum(dim=3, keepdim=True).clamp_min(torch.finfo(torch.float32).eps)
+    blend = torch.zeros_like(w)
+    idx = [g for g in range(n) if bool(active[g])]
+    blend[..., :len(idx)] = bw[..., idx]
+    mass = float(w[..., ~active].sum(dim=3).mean()) if not bool(active.all()) else 0.0
+    return [bool(a) for a in active.tolist()], blend.contiguous(), mass
+
+
 def gated_route_decide(g_logits, loc_logits, alpha, inv_temp, top_k, cplx_logit, clamp=1):
     _count("gated_route_decide")
     B, E = g_logits.shape[0], g_logits.shape[-1]
@@ -676,10 +678,10 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "dwpw_supported", "dwconv_pwconv", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "esmoe_route", "esmoe_dw",
-            "esmoe_pw", "esmoe_experts_fused", "esmoe_fused_supported", "esmoe_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "esmoe_route", "esmoe_dw",
+            "esmoe_pw", "esmoe_fused_supported", "esmoe_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",
-            "linear_attention", "deform_attention", "token_softmax", "gated_route_decide", "expert_conv", "expert_dw3", "channel_shuffle_cat",
+            "linear_attention", "deform_attention", "token_softmax", "moa_sparse_gate", "gated_route_decide", "expert_conv", "expert_dw3", "channel_shuffle_cat",
             "pixel_shuffle2", "tokens_to_rows"]

@@ -68,6 +68,38 @@ def case(name, module, oracle_fn, x, seed):
     np.savez_compressed(HERE / f"moa_{name}.npz", **rec)
 
 
+def sparse_cases():
+    """`sparse_inference=True` (moa/block.py:194-234; `python tests/golden/make_golden_moa.py sparse`): the router's last bias pushes one
+    group below the threshold for every token (`sparse`: the global head is skipped, the other two renormalised) / every group below it
+    (`sparse_one`: threshold 0.99, the group with the largest mean gate runs alone)."""
+    g3 = torch.Generator().manual_seed(77)
+    for name, thr, bias in (("sparse", 0.2, (0.0, 0.0, -6.0)), ("sparse_one", 0.99, (0.5, 0.0, -0.5))):
+        m = MoABlock(48, num_heads=6, sparse_inference=True, sparse_inference_threshold=thr)
+        x = torch.randn(2, 48, 14, 18, generator=g3)
+
+        def fill(module, seed, bias=bias):
+            sd = seeded_fill(module, seed)
+            sd["router.router.3.bias"] = sd["router.router.3.bias"] + torch.tensor(bias)
+            sd["router.router.3.weight"] = sd["router.router.3.weight"] * 0.3      # gates near the biases: the decision is not a near call
+            module.load_state_dict(sd)
+            return sd
+        sd = fill(m, 8)
+        m.eval()
+        with torch.inference_mode():
+            y = m(x)
+            info = {}
+            oy = moa_ref.moa_block({f"m.{k}": v for k, v in sd.items()}, "m", x, 6, info=info, sparse_inference=True, sparse_inference_threshold=thr)
+        act = info["m"]["active"]
+        snap = m.last_routing_snapshot
+        print(f"[moa_{name}] active {None if act is None else act.tolist()} executed_groups {snap['executed_groups']} dropped mass {snap['dropped_routing_mass']:.4f}; "
+              f"oracle bit-exact vs reference: {torch.equal(y, oy)}")
+        assert torch.equal(y, oy) and act is not None and int(act.sum()) == snap["executed_groups"]
+        rec = {"x": x.numpy(), "y": y.numpy(), "router_probs": info["m"]["weights"].numpy()[None], "keys": np.array(list(sd.keys())),
+               "active": act.numpy(), "threshold": np.float32(thr), "dropped_routing_mass": np.float32(snap["dropped_routing_mass"])}
+        rec.update({f"sd::{k}": v.numpy() for k, v in sd.items()})
+        np.savez_compressed(HERE / f"moa_{name}.npz", **rec)
+
+
 def extra_cases():
     """Cases added after the first fixture set; each has its own generator so that re-running never touches the others.
     `python tests/golden/make_golden_moa.py extra`."""
@@ -81,6 +113,9 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         extra_cases()
+        raise SystemExit
+    if len(sys.argv) > 1 and sys.argv[1] == "sparse":
+        sparse_cases()
         raise SystemExit
     g = torch.Generator().manual_seed(123)
 

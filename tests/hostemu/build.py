@@ -16,8 +16,8 @@ HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
 CSRC = ROOT / "yolo_master_amd" / "csrc"
 OUT = HERE / "_build"
-SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "dwmfma.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip",
-           "esmoe.hip", "attn.hip", "nms.hip", "conv.hip", "dwconv.hip", "elementwise.hip", "dwpw.hip", "capi.hip", "esfused.hip"]
+SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip",
+           "esmoe.hip", "attn.hip", "nms.hip", "conv.hip", "dwconv.hip", "elementwise.hip", "capi.hip", "esfused.hip"]
 
 
 def compiler():
@@ -51,7 +51,7 @@ def build(force: bool = False, f16: bool = False) -> Path | None:
         u = OUT / (s.stem + ("_host_f16.cpp" if f16 else "_host.cpp"))
         u.write_text(txt)
         units.append(str(u))
-    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DGLDS_SMALL_BELOW_DEFAULT=3", "-DYMK_HOST_EMU", *(["-DYMK_H16_F16"] if f16 else []), "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(lib)]
+    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DGLDS_SMALL_BELOW_DEFAULT=3", "-DNMS_RANK_MAX=1200", "-DYMK_HOST_EMU", *(["-DYMK_H16_F16"] if f16 else []), "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(lib)]
     subprocess.run(cmd, check=True)
     return lib
 

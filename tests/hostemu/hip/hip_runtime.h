@@ -189,6 +189,8 @@ static inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); ret
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { const double o = *p; *p = o + v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __expf(x) expf(x)   // glibc declares __expf itself
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

@@ -131,52 +131,6 @@ def test_dwconv(k, dtype):
     assert_close(nchw(y), ref, dtype, f"dwconv k={k}")
 
 
-def _dw_cases():
-    from tests.test_hostemu_dw import DW_CASES, MOE_CASES
-
-    big_dw = [(4, 40, 40, 128, 7, False, False, True, 256, 0),      # AAttn.pe as the detector runs it (v = a slice of qkv)
-              (2, 160, 160, 64, 3, True, True, False, 0, 0), (3, 20, 20, 256, 7, True, False, True, 0, 0),
-              (2, 83, 45, 32, 9, True, True, True, 0, 32)]
-    big_moe = [(8, 80, 80, 128, [3, 5, 7, 9], [[0, 1], [2, 3], [3, -1], [1, 2], [0, 3], [3, -1], [2, -1], [1, 3]]),
-               (16, 20, 20, 256, [3, 5, 7, 9], [[i % 4, (i + 1 + i // 4) % 4] if i % 3 else [i % 4, -1] for i in range(16)])]
-    return DW_CASES + big_dw, MOE_CASES + big_moe
-
-
-@pytest.mark.parametrize("case", _dw_cases()[0])
-def test_dwconv_mfma(case):
-    """Matrix-core depthwise kernel (csrc/dwmfma.hip) through the C-ABI against torch's depthwise convolution."""
-    from tests.test_hostemu_dw import run_dw_case
-    from yolo_master_amd import _lib
-
-    run_dw_case(_lib.load(), case, dev=DEV, stream=torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-
-
-@pytest.mark.parametrize("case", _dw_cases()[1])
-def test_esmoe_dw_mfma(case):
-    from tests.test_hostemu_dw import run_moe_dw_case
-    from yolo_master_amd import _lib
-
-    run_moe_dw_case(_lib.load(), case, dev=DEV, stream=torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-
-
-def test_dwconv_mfma_equals_valu_path():
-    """Same op through both kernels (bf16): the two differ only in fp32 summation order -> equal after bf16 rounding up to
-    one ulp of the output."""
-    from yolo_master_amd import ops
-
-    x = rnd(3, 40, 40, 64, seed=1).to(torch.bfloat16).to(DEV)
-    w = rnd(64, 1, 7, 7, seed=2, scale=1.0 / 7).to(DEV)
-    wp = ops.pack_dw_weight(w, torch.bfloat16)
-    wp.toeplitz = ops.dw_toeplitz(wp, 7, force=True)    # the matrix-core path is opt-in (YMK_ENABLE bit 8): request it here
-    assert wp.toeplitz is not None
-    b = rnd(64, seed=3, scale=0.1).to(DEV)
-    y_m = ops.dwconv2d(x, wp, b, 7, True)
-    plain = wp.clone()          # no .toeplitz attribute -> VALU stencil
-    y_v = ops.dwconv2d(x, plain, b, 7, True)
-    d = (y_m.float() - y_v.float()).abs()
-    assert float(d.max()) <= 2.0 ** -7 * float(y_v.float().abs().max()) and float((d > 0).float().mean()) < 0.2
 
 
 @pytest.mark.parametrize("case", __import__("tests.test_hostemu_mlp", fromlist=["CASES"]).CASES + [(128, 256, 102400, 0, 0), (256, 512, 25600, 0, 0)])
@@ -282,8 +236,10 @@ def test_area_attention_long(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("fused,cin,hw", [(True, 64, (14, 18)), (False, 64, (14, 18)), (True, 128, (14, 18)),
+@pytest.mark.parametrize("fused,cin,hw", [(False, 64, (14, 18)), (True, 128, (14, 18)),   # fused: the one-kernel expert body (csrc/esfused.hip) in the 16-bit modes
+                                          (False, 128, (14, 18)),
                                           (False, 256, (14, 18)),    # table-driven pointwise stage, 2 cout tiles, 4 K groups
+                                          (True, 256, (14, 18)),
                                           (False, 192, (14, 18)),    # cout not a multiple of 128: the older streaming kernel
                                           (False, 128, (88, 88))])   # more (image, tile) items than workgroups, ragged last tile
 def test_esmoe_block(dtype, fused, cin, hw):
@@ -291,7 +247,7 @@ def test_esmoe_block(dtype, fused, cin, hw):
     from yolo_master_amd.nn.modules import ES_MOE
 
     m = ES_MOE(cin, cin)
-    m.fuse_experts = fused   # fused depthwise->pointwise kernel vs the two-kernel (dw_out) form
+    m.fuse_layer = fused     # the expert body as one kernel (16-bit modes; fp32 always takes the two-kernel form) vs depthwise + pointwise
     sd = module_sd(m)
     # per-image offsets so that images route differently
     x = rnd(6, cin, hw[0], hw[1], seed=12) + rnd(6, cin, 1, 1, seed=13, scale=1.5)
@@ -396,7 +352,6 @@ def test_detect_head(dtype, nc):
 
     Detect.legacy = False
     m = Detect(nc, 16, False, [64, 128, 128])   # nc = 3, 1: class rows padded to 16 bytes by the tail conv
-    m.fuse_dwpw = True   # exercise the fused DW->1x1 kernel where the shape allows (C=64 level), two kernels elsewhere
     m.stride = torch.tensor([8.0, 16.0, 32.0])
     sd = module_sd(m)
     feats = [rnd(2, 64, 16, 20, seed=1), rnd(2, 128, 8, 10, seed=2), rnd(2, 128, 4, 5, seed=3)]

@@ -263,6 +263,8 @@ def _prep(mod, sd):
     ("moa", "kvcap", ("MoABlock", (48,), dict(num_heads=6, regional_max_kv_tokens=64, shortcut=False))),
     ("moa", "c2f", ("C2fMoA", (64, 96), dict(n=2, num_heads=6))),
     ("moa", "hd21", ("MoABlock", (128,), dict(num_heads=6))),       # BASELINE config 5 (L scale): head_dim 21 padded to 24
+    ("moa", "sparse", ("MoABlock", (48,), dict(num_heads=6, sparse_inference=True, sparse_inference_threshold=0.2))),       # a head group skipped for the batch
+    ("moa", "sparse_one", ("MoABlock", (48,), dict(num_heads=6, sparse_inference=True, sparse_inference_threshold=0.99))),  # only the largest-mean group runs
     ("mot", "top2", ("MoTBlock", (48,), dict(num_heads=6))),
     ("mot", "shift", ("MoTBlock", (48,), dict(num_heads=6, window_shift=True, local_attn_window=7))),
     ("mot", "top1", ("MoTBlock", (48,), dict(num_heads=6, top_k=1))), ("mot", "dense", ("MoTBlock", (48,), dict(num_heads=6, top_k=3))),

@@ -30,7 +30,10 @@ def _close(got, ref, what, rtol=2e-5):
 
 
 MOA_CASES = {"exact": {}, "blend": {}, "linear": {}, "kvcap": dict(regional_max_kv_tokens=64, shortcut=False),
-             "hd21": dict(dim=128)}     # BASELINE config 5 (L scale): head_dim 21, padded to 24 channels per head
+             "hd21": dict(dim=128),     # BASELINE config 5 (L scale): head_dim 21, padded to 24 channels per head
+             # sparse inference (moa/block.py:194-234): the global head skipped / only the group with the largest mean gate runs
+             "sparse": dict(sparse_inference=True, sparse_inference_threshold=0.2),
+             "sparse_one": dict(sparse_inference=True, sparse_inference_threshold=0.99)}
 
 
 @pytest.mark.parametrize("name", list(MOA_CASES))
@@ -47,6 +50,13 @@ def test_moa_block_host_vs_reference(name, golden_dir, emu):
     probs = m.last_route["weights"].permute(0, 3, 1, 2)          # [B, 3, H, W]
     assert float((probs - torch.from_numpy(z["router_probs"])[0]).abs().max()) <= 1e-5
     used = emu.CALLS
+    if name.startswith("sparse"):
+        act = [bool(a) for a in z["active"].tolist()]
+        assert m.last_route["active"] == act and m.last_route["executed_groups"] == sum(act)
+        assert abs(m.last_route["dropped_routing_mass"] - float(z["dropped_routing_mass"])) <= 1e-5
+        assert used.get("window_attention", 0) == int(act[0]) and used.get("attention", 0) == int(act[1]) + int(act[2])   # skipped heads are not computed
+        assert used["group_norm"] == 1 + sum(act) and used["weighted_sum"] == 1 and used["moa_sparse_gate"] == 1
+        return
     assert used["window_attention"] == 1 and used["group_norm"] == 4 and used["weighted_sum"] == 1
     if name in ("linear", "kvcap"):
         assert used.get("linear_attention") == 1 and used["attention"] == 1      # regional only

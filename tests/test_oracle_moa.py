@@ -12,6 +12,8 @@ CASES = {
     "linear": dict(fn="block", kw={}),
     "kvcap": dict(fn="block", kw=dict(regional_max_kv_tokens=64, shortcut=False)),
     "c2f": dict(fn="c2f", kw={}),
+    "sparse": dict(fn="block", kw=dict(sparse_inference=True, sparse_inference_threshold=0.2)),
+    "sparse_one": dict(fn="block", kw=dict(sparse_inference=True, sparse_inference_threshold=0.99)),
 }
 
 

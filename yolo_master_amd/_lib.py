@@ -71,19 +71,9 @@ SYMBOLS = {
                                        _i32, _vp]),
     "ymk_mlp_fused_supported": (C.c_int, [_i32, _i32, _i32]),
     "ymk_mlp_fused": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
-    "ymk_dw_mfma_supported": (C.c_int, [_i32, _i32, _i32]),
-    "ymk_dw_toeplitz_elems": (_sz, [_i32, _i32]),
-    "ymk_dw_toeplitz_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
-    "ymk_dwconv2d_mfma": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "ymk_esmoe_dw_mfma": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "ymk_dwpw_supported": (C.c_int, [_i32, _i32, _i32]),
-    "ymk_esmoe_experts_fused": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
-                                          _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "ymk_esmoe_fused_supported": (C.c_int, [_i32] * 8),
     "ymk_esmoe_fused": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
                                   _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
-    "ymk_dwconv_pwconv": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
-                                    _i32, _vp, _i32, _vp]),
     "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_upsample2x": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_copy_channels": (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
@@ -115,6 +105,7 @@ SYMBOLS_MIXTURE = {
     "ymk_avg_pool": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_channel_stats": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ymk_token_softmax": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "ymk_moa_sparse_gate": (C.c_int, [_vp, _i32, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _vp]),
     "ymk_gated_route_decide": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ymk_expert_gather": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ymk_expert_dw3": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

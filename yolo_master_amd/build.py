@@ -22,7 +22,7 @@ VARIANTS = {"bf16": (OBJ, LIB, []), "f16": (CSRC / "_obj_f16", HERE / "libymk_f1
 ARCH = "gfx950"
 # files whose arithmetic must not be contracted into FMAs (bit-exact NMS / decode)
 NO_CONTRACT = {"nms.hip", "elementwise.hip", "post.hip", "preproc.hip"}
-SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "dwmfma.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip", "esmoe.hip", "dwpw.hip", "attn.hip", "elementwise.hip", "nms.hip",
+SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip", "esmoe.hip", "attn.hip", "elementwise.hip", "nms.hip",
            "mixture.hip", "mixattn.hip",   # config-5 rows, first implementation (include/ymk_mixture.h)
            "conv_glds.hip", "post.hip", "preproc.hip",
            "esfused.hip"]   # ES-MoE expert body as one kernel per layer (depthwise stencil -> grouped GEMM, wave-specialised)    # opt-in: next tiled convolution core, box rescaling (include/ymk_next.h)

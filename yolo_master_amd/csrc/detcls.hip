@@ -29,6 +29,11 @@
 #define DC_LDS_BYTES (DC_A_BYTES + DC_B_BYTES)
 
 typedef __bf16 dc_bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef YMK_HOST_EMU
+#define DC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DC_SCHED_BARRIER() ((void)0)
+#endif
 __device__ __forceinline__ void dc_mma(f32x4& acc, const u32x4& a, const u32x4& b) {
     acc = mfma16x16x32_h16(a, b, acc);
 }
@@ -138,14 +143,25 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
             dc_dw3<CIN>(sA, DC_XC, sB, DC_NMID, DC_MC, a.dw1, ch * 128, a.bd1, cg, sl);
             __syncthreads();
             // ---- pw1: K chunk ch ----------------------------------------------------------------------------------------------------------
+            // k-step outermost: the MFMAs that follow one another then belong to DIFFERENT accumulators (with the pixel fragment outermost
+            // every accumulator was a chain of four dependent MFMAs, each behind its own `ds_read_b128; s_waitcnt`), and the B fragments of
+            // a k-step are all requested before the first MFMA.  Per accumulator the order of the four k-steps is unchanged.
+            constexpr int NH = NF1 / 2;   // six fragments at a time (twelve would need 48 registers beside the resident weight sets)
 #pragma unroll
-            for (int j = 0; j < NF1; ++j) {
-                int px = j * 16 + fr;
-                px = px < DC_NMID ? px : 0;
-                const char* pb = sB + px * DC_PITCH + fc * 16;
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) dc_mma(acc1[j], af1[ch * 4 + s], *reinterpret_cast<const u32x4*>(pb + s * 64));
-            }
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 bfr[NH];
+#pragma unroll
+                    for (int j = 0; j < NH; ++j) {
+                        int px = (h * NH + j) * 16 + fr;
+                        px = px < DC_NMID ? px : 0;
+                        bfr[j] = *reinterpret_cast<const u32x4*>(sB + px * DC_PITCH + fc * 16 + s * 64);
+                    }
+                    DC_SCHED_BARRIER();
+#pragma unroll
+                    for (int j = 0; j < NH; ++j) dc_mma(acc1[h * NH + j], af1[ch * 4 + s], bfr[j]);
+                }
             if (ch + 1 < NCH) __syncthreads();   // region A / B are restaged for the next chunk
         }
         // pw1 epilogue -> region A (the x chunk is dead: every wave is past its dw1)
@@ -167,11 +183,15 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
         {
             f32x4 acc[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc[j] = bv2;
-                const char* pb = sB + (j * 16 + fr) * DC_PITCH + fc * 16;
+            for (int j = 0; j < 8; ++j) acc[j] = bv2;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) dc_mma(acc[j], af2[s], *reinterpret_cast<const u32x4*>(pb + s * 64));
+            for (int s = 0; s < 4; ++s) {
+                u32x4 bfr[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(sB + (j * 16 + fr) * DC_PITCH + fc * 16 + s * 64);
+                DC_SCHED_BARRIER();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dc_mma(acc[j], af2[s], bfr[j]);
             }
             // region A still holds pw1's map, which dw2 of OTHER waves may be reading: they are past the barrier above, so it is free
 #pragma unroll
@@ -181,15 +201,23 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
         __syncthreads();
         // ---- out: 1x1 128 -> nc, fp32 logits -------------------------------------------------------------------------------------------------------
         if (wave * 16 < a.ncpad) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = bv3;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                u32x4 bfr[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(sA + (j * 16 + fr) * DC_PITCH + fc * 16 + s * 64);
+                DC_SCHED_BARRIER();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dc_mma(acc[j], af3[s], bfr[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                f32x4 acc = bv3;
-                const char* pb = sA + (j * 16 + fr) * DC_PITCH + fc * 16;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) dc_mma(acc, af3[s], *reinterpret_cast<const u32x4*>(pb + s * 64));
                 const int oy = oy0 + j, ox = ox0 + fr;   // fragment j = tile row j (16 pixels)
                 if (oy < a.H && ox < a.W && wave * 16 + fc * 4 < a.ncpad)
-                    *reinterpret_cast<f32x4*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = acc;
+                    *reinterpret_cast<f32x4*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = acc[j];
             }
         }
         __syncthreads();   // region A is restaged by the next tile

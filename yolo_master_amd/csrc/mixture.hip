@@ -386,6 +386,62 @@ __global__ __launch_bounds__(256) void batch_scale_kernel(float* w, int B, int K
     for (int i = threadIdx.x; i < B * K; i += 256) w[i] *= c;
 }
 
+// ------------------------------------------------------------------------------------------------ MoA sparse inference
+// moa/block.py:194-234 (eval, `sparse_inference=True`): a head group is skipped when its gate is at or below the threshold for EVERY
+// token of the batch; if none is above it, the group with the largest mean gate runs alone; the retained gates are renormalised per
+// token (sum clamped at the fp32 epsilon).  Two launches: batch-wide statistics (maximum as the bit pattern of a non-negative float,
+// sum in fp64: its only consumer is the argmax of the fall-back), then the decision + the blend weights, COMPACTED: column j of the
+// output belongs to the j-th active group (what ymk_weighted_sum takes next to the list of head outputs that were computed).
+__global__ __launch_bounds__(256) void moa_gate_stats_kernel(const float* __restrict__ w, int ldw, int64_t npix, int n,
+                                                             unsigned* __restrict__ gmax, double* __restrict__ gsum) {
+    __shared__ float sh[4];
+    __shared__ unsigned shm[4];
+    for (int g = 0; g < n; ++g) {
+        float mx = 0.f, sm = 0.f;
+        GRID_STRIDE(i, npix) {
+            const float v = w[i * ldw + g];
+            mx = fmaxf(mx, v);
+            sm += v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = __float_as_uint(mx);
+        const float tot = block_sum(sm, sh);     // (barriers inside: shm is complete afterwards)
+        if (threadIdx.x == 0) {
+            unsigned m = shm[0];
+            for (int q = 1; q < 4; ++q) m = shm[q] > m ? shm[q] : m;
+            atomicMax(&gmax[g], m);
+            atomicAdd(&gsum[g], (double)tot);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void moa_gate_apply_kernel(const float* __restrict__ w, int ldw, int64_t npix, int n, float thr,
+                                                             const unsigned* __restrict__ gmax, const double* __restrict__ gsum,
+                                                             float* __restrict__ blend, int ldb, int* __restrict__ active) {
+    bool act[8];
+    int nact = 0, best = 0;
+    for (int g = 0; g < n; ++g) {
+        act[g] = __uint_as_float(gmax[g]) > thr;
+        nact += act[g];
+        if (gsum[g] > gsum[best]) best = g;      // first maximum, as torch.argmax
+    }
+    if (nact == 0)
+        for (int g = 0; g < n; ++g) act[g] = g == best;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int g = 0; g < n; ++g) active[g] = act[g];
+    GRID_STRIDE(i, npix) {
+        float s = 0.f;
+        for (int g = 0; g < n; ++g) s += act[g] ? w[i * ldw + g] : 0.f;
+        s = fmaxf(s, 1.1920929e-07f);
+        int j = 0;
+        for (int g = 0; g < n; ++g)
+            if (act[g]) blend[i * ldb + j++] = w[i * ldw + g] / s;
+        for (; j < n; ++j) blend[i * ldb + j] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ gather / shuffle
 __global__ __launch_bounds__(256) void expert_gather_kernel(int dt, const void* f, int ldf, const int32_t* idx, int B, int HW,
                                                              int OC, int K, void* out) {
@@ -1115,6 +1171,20 @@ extern "C" int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, floa
     }
     hipLaunchKernelGGL(channel_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dtype, x, ldx, out, HW, C,
                        want_std);
+    return ymk_launch_status();
+}
+
+/* MoA sparse inference (moa/block.py:194-234).  w fp32 [npix][ldw] per-token gates of n <= 8 groups; stats: zero-initialised scratch of
+ * n * 4 + n * 8 bytes (8-byte aligned); outputs: active int32 [n], blend fp32 [npix][ldb] with the retained groups' renormalised gates in
+ * columns 0 .. (number of active groups) - 1, zeros behind. */
+extern "C" int ymk_moa_sparse_gate(const float* w, int32_t ldw, int64_t npix, int32_t n, float threshold, void* stats, float* blend,
+                                   int32_t ldb, int32_t* active, void* stream) {
+    if (!w || !stats || !blend || !active || n < 1 || n > 8 || ldw < n || ldb < n || ((uintptr_t)stats & 7)) return YMK_E_BADARG;
+    if (npix <= 0) return YMK_OK;
+    double* gsum = static_cast<double*>(stats);
+    unsigned* gmax = reinterpret_cast<unsigned*>(gsum + n);
+    LAUNCH(moa_gate_stats_kernel, npix, w, ldw, npix, n, gmax, gsum);
+    LAUNCH(moa_gate_apply_kernel, npix, w, ldw, npix, n, threshold, gmax, gsum, blend, ldb, active);
     return ymk_launch_status();
 }
 

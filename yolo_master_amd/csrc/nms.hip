@@ -367,12 +367,19 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float* __restrict__
 // rank(i) = #{j : key_j > key_i} with the 64-bit key (score bits << 32 | ~index): for the positive scores
 // that pass the confidence filter the IEEE bit pattern is order preserving, and the inverted index in the
 // low word makes the lower candidate index win ties (stable order) with ONE integer compare per pair.
-__global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w) {
+// Opt-in (YMK_ENABLE bit 128): images with at most NMS_RANK_MAX candidates are ordered by THIS kernel on (n / 256) workgroups each instead
+// of one 1024-thread workgroup per image walking a sorting network (64 workgroups on 256 CUs); larger images (O(n^2) would hurt) go to
+// nms_sort_kernel.  Both are launched then; each returns at once for the images of the other.  rank_max < 0: every image (the fall-back
+// when the sorting kernel is switched off).  Round 4: slower than the sort on the bench step (see ymk_nms_batched).
+#ifndef NMS_RANK_MAX
+#define NMS_RANK_MAX 4096   // (tests/hostemu builds with 1200: its small fixtures then reach both ordering kernels)
+#endif
+__global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w, int rank_max) {
     __shared__ unsigned long long tk[256];
     const int b = blockIdx.y;
     const int n = w.ncand[b];
     const int i0 = blockIdx.x * 256;
-    if (i0 >= n) return;
+    if (i0 >= n || (rank_max >= 0 && n > rank_max)) return;
     const int i = i0 + threadIdx.x;
     const float* sc = w.cscore + (size_t)b * w.capc;
     const float si = i < n ? sc[i] : 0.f;
@@ -410,6 +417,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w) {
 // kernel's 128 KB; the consumed source slots of a thread hold its 16 scanned bases (dynamic indexing without a register tree).
 #define NMS_RADIX_MIN 1024   // below: the bitonic network is as fast
 #define YMK_OFF_NMS_RADIX 65536u
+#define YMK_ON_NMS_RANK_SMALL 128u   // YMK_ENABLE: images with <= NMS_RANK_MAX candidates ordered by nms_rank_kernel on many workgroups
 __device__ __forceinline__ void nms_radix_sort(const NmsWs& w, int b, int n, unsigned* lds) {
     unsigned* key = lds;                                                       // [NMS_SORT_CAP]
     unsigned short* buf0 = reinterpret_cast<unsigned short*>(lds + NMS_SORT_CAP);   // [2][NMS_SORT_CAP]
@@ -531,11 +539,11 @@ __device__ __forceinline__ void nms_radix_sort(const NmsWs& w, int b, int n, uns
     }
 }
 
-__global__ __launch_bounds__(1024) void nms_sort_kernel(NmsWs w, int radix) {
+__global__ __launch_bounds__(1024) void nms_sort_kernel(NmsWs w, int radix, int rank_max) {
     __shared__ unsigned long long key[NMS_SORT_CAP];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = w.ncand[b];
-    if (n <= 0) return;
+    if (n <= rank_max) return;          // ordered by nms_rank_kernel (n <= 0 included: rank_max >= 0)
     if (n > NMS_RADIX_MIN && radix) {   // workgroup-uniform
         nms_radix_sort(w, b, n, reinterpret_cast<unsigned*>(key));
         return;
@@ -697,10 +705,18 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t ex
         hipLaunchKernelGGL(nms_scan2_kernel, dim3(B), dim3(64), 0, s, w);
     }
     hipLaunchKernelGGL(nms_emit_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
-    if (w.capc <= NMS_SORT_CAP && !(ymk_disabled() & YMK_OFF_NMS_SORT))
-        hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, s, w, (ymk_disabled() & YMK_OFF_NMS_RADIX) ? 0 : 1);
-    else
-        hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w);
+    if (w.capc <= NMS_SORT_CAP && !(ymk_disabled() & YMK_OFF_NMS_SORT)) {
+        // YMK_ENABLE bit 128: small images by counting ranks on many workgroups, large ones by the in-LDS sort.  Measured SLOWER on the
+        // bench step (64 images, 2-8 k candidates each: nms 0.248 ms against 0.191 ms with one sorting workgroup per image — the
+        // 64-bit compare loop of the rank kernel costs more than the sorting network's barriers): off by default.
+        const int rank_max = (ymk_enabled() & YMK_ON_NMS_RANK_SMALL) ? NMS_RANK_MAX : 0;
+        const int rcap = w.capc < rank_max ? w.capc : rank_max;
+        if (rcap > 0) hipLaunchKernelGGL(nms_rank_kernel, dim3((rcap + 255) / 256, B), dim3(256), 0, s, w, rank_max);
+        if (w.capc > rank_max)
+            hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, s, w, (ymk_disabled() & YMK_OFF_NMS_RADIX) ? 0 : 1, rank_max);
+    } else {
+        hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w, -1);
+    }
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det,
                        out_dets, out_counts, out_idx);
     return ymk_launch_status();

@@ -960,8 +960,14 @@ class MoABlock(YmkModule):
         super().__init__()
         if num_heads <= 0 or num_heads % self.NUM_GROUPS != 0:
             raise ValueError(f"num_heads ({num_heads}) must be positive and divisible by NUM_GROUPS ({self.NUM_GROUPS})")
-        if sparse_inference:
-            raise NotImplementedError("ymk MoABlock: dense soft routing only (sparse_inference=False, the YAML default)")
+        if inference_sparse_threshold is not None:    # the older spelling of the same option switches it on (moa/block.py:67-76)
+            if sparse_inference_threshold != 0.02 and sparse_inference_threshold != inference_sparse_threshold:
+                raise ValueError("Specify only one sparse inference threshold: sparse_inference_threshold or inference_sparse_threshold.")
+            sparse_inference_threshold, sparse_inference = inference_sparse_threshold, True
+        self.sparse_inference = bool(sparse_inference)
+        self.sparse_inference_threshold = float(sparse_inference_threshold)
+        if not 0.0 <= self.sparse_inference_threshold < 1.0:
+            raise ValueError("sparse_inference_threshold must be in [0, 1)")
         self.dim, self.shortcut = dim, shortcut
         head_dim = max(dim // num_heads, 16)
         hpg = num_heads // self.NUM_GROUPS
@@ -1038,38 +1044,47 @@ class MoABlock(YmkModule):
         inner = nh * hd
         probs = self._route(x, pk)
         self.last_route = {"weights": probs}
-        # local head (moa/heads.py:143-163): DW3x3 -> 1x1 qkv, v += DW7x7(v), 7x7-window attention
-        qkv = ops.conv2d(ops.dwconv2d(x, pk["l_dw"], None, 3, False), *pk["l_qkv"], 1, 1, False)
-        v = ops.dwconv2d(qkv[..., 2 * inner:], pk["l_pe"], None, 7, False, residual=qkv[..., 2 * inner:])
-        win = max(1, min(lh.window_size, H, W))
-        o = ops.window_attention(qkv[..., :inner], qkv[..., inner:2 * inner], v, nh, hd, scale, win)
-        local = self._head_tail(o, pk["l_proj"], pk["l_norm"])
-        # regional head (moa/heads.py:208-253): full-resolution queries, pooled keys / values
-        if min(H, W) <= 1:
-            pooled = x
-        else:
-            stride = rh.pool_stride
-            if rh.max_kv_tokens is not None:
-                while max(1, H // stride) * max(1, W // stride) > rh.max_kv_tokens:
-                    stride *= 2
-            pooled = ops.adaptive_avg_pool(x, max(1, H // stride), max(1, W // stride))
-        kv = ops.conv2d(pooled, *pk["g_kv"], 1, 1, False)
-        q = ops.conv2d(x, *pk["g_q"], 1, 1, False)
-        o = ops.attention(q, kv[..., :inner], kv[..., inner:], nh, hd, scale)
-        regional = self._head_tail(o, pk["g_proj"], pk["g_norm"])
-        # global head (moa/heads.py:354-380): exact <= 512 tokens, blended with / replaced by random-feature attention
-        qkv = ops.conv2d(x, *pk["a_qkv"], 1, 1, False)
-        q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
-        N = H * W
-        if N <= self.LINEAR_ATTN_THRESHOLD:
-            o = ops.attention(q, k, v, nh, hd, scale)
-            start = self.LINEAR_ATTN_THRESHOLD - self.LINEAR_ATTN_BLEND_WINDOW
-            if N > start:
-                o = ops.lerp(o, ops.linear_attention(q, k, v, pk["rf"], nh, hd), (N - start) / self.LINEAR_ATTN_BLEND_WINDOW)
-        else:
-            o = ops.linear_attention(q, k, v, pk["rf"], nh, hd)
-        glob = self._head_tail(o, pk["a_proj"], pk["a_norm"])
-        mixed = ops.weighted_sum(probs, [local, regional, glob])
+        # sparse inference (moa/block.py:194-234): a batch-level decision — a head group whose gate stays at or below the threshold for
+        # every token is not computed at all, the retained gates are renormalised per token.  One host sync, as in the reference.
+        run, blend = (True, True, True), probs
+        if self.sparse_inference:
+            act, sparse_blend, mass = ops.moa_sparse_gate(probs, self.NUM_GROUPS, self.sparse_inference_threshold)
+            self.last_route.update(active=act, executed_groups=sum(act), dropped_routing_mass=mass if not all(act) else 0.0)
+            if not all(act):
+                run, blend = tuple(act), sparse_blend
+        heads = []
+        if run[0]:   # local head (moa/heads.py:143-163): DW3x3 -> 1x1 qkv, v += DW7x7(v), 7x7-window attention
+            qkv = ops.conv2d(ops.dwconv2d(x, pk["l_dw"], None, 3, False), *pk["l_qkv"], 1, 1, False)
+            v = ops.dwconv2d(qkv[..., 2 * inner:], pk["l_pe"], None, 7, False, residual=qkv[..., 2 * inner:])
+            win = max(1, min(lh.window_size, H, W))
+            o = ops.window_attention(qkv[..., :inner], qkv[..., inner:2 * inner], v, nh, hd, scale, win)
+            heads.append(self._head_tail(o, pk["l_proj"], pk["l_norm"]))
+        if run[1]:   # regional head (moa/heads.py:208-253): full-resolution queries, pooled keys / values
+            if min(H, W) <= 1:
+                pooled = x
+            else:
+                stride = rh.pool_stride
+                if rh.max_kv_tokens is not None:
+                    while max(1, H // stride) * max(1, W // stride) > rh.max_kv_tokens:
+                        stride *= 2
+                pooled = ops.adaptive_avg_pool(x, max(1, H // stride), max(1, W // stride))
+            kv = ops.conv2d(pooled, *pk["g_kv"], 1, 1, False)
+            q = ops.conv2d(x, *pk["g_q"], 1, 1, False)
+            o = ops.attention(q, kv[..., :inner], kv[..., inner:], nh, hd, scale)
+            heads.append(self._head_tail(o, pk["g_proj"], pk["g_norm"]))
+        if run[2]:   # global head (moa/heads.py:354-380): exact <= 512 tokens, blended with / replaced by random-feature attention
+            qkv = ops.conv2d(x, *pk["a_qkv"], 1, 1, False)
+            q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
+            N = H * W
+            if N <= self.LINEAR_ATTN_THRESHOLD:
+                o = ops.attention(q, k, v, nh, hd, scale)
+                start = self.LINEAR_ATTN_THRESHOLD - self.LINEAR_ATTN_BLEND_WINDOW
+                if N > start:
+                    o = ops.lerp(o, ops.linear_attention(q, k, v, pk["rf"], nh, hd), (N - start) / self.LINEAR_ATTN_BLEND_WINDOW)
+            else:
+                o = ops.linear_attention(q, k, v, pk["rf"], nh, hd)
+            heads.append(self._head_tail(o, pk["a_proj"], pk["a_norm"]))
+        mixed = ops.weighted_sum(blend, heads)       # (sparse: the active groups' gates sit in the first len(heads) columns)
         # x + ls_attn * fusion(mixed); then + ls_ffn * ffn(.) (moa/block.py:264-278); without the shortcut the same without the skips
         if not self.shortcut:
             x1 = ops.conv2d(mixed, *pk["fusion_ls"], 1, 1, False)
@@ -1085,6 +1100,11 @@ class C2fMoA(YmkModule):
                  local_window_size=7, sequential_heads=True, regional_max_kv_tokens=4096, sparse_inference=False,
                  sparse_inference_threshold=0.02, inference_sparse_threshold=None):
         super().__init__()
+        if inference_sparse_threshold is not None:    # moa/wrappers.py:82-89
+            if sparse_inference_threshold != 0.02 and sparse_inference_threshold != inference_sparse_threshold:
+                raise ValueError("Specify only one sparse inference threshold: sparse_inference_threshold or inference_sparse_threshold.")
+            sparse_inference_threshold, sparse_inference = inference_sparse_threshold, True
+        self.sparse_inference, self.sparse_inference_threshold = bool(sparse_inference), float(sparse_inference_threshold)
         self.c = int(c2 * e)
         self.cv1 = Conv(c1, 2 * self.c, 1)
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
@@ -1100,7 +1120,8 @@ class C2fMoA(YmkModule):
         self.m = nn.ModuleList(
             MoABlock(self.c, num_heads=h, mlp_ratio=mlp_ratio, temperature=temperature, shortcut=shortcut,
                      aux_loss_coeff=aux_loss_coeff, block_index=i, local_window_size=local_window_size,
-                     sequential_heads=sequential_heads, regional_max_kv_tokens=regional_max_kv_tokens) for i in range(n))
+                     sequential_heads=sequential_heads, regional_max_kv_tokens=regional_max_kv_tokens,
+                     sparse_inference=sparse_inference, sparse_inference_threshold=sparse_inference_threshold) for i in range(n))
 
     def _run(self, x, out=None):
         """cv1 -> chunk(2) -> n MoABlocks chained on the last chunk -> cat -> cv2 (moa/wrappers.py:144-177); the

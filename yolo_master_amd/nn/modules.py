@@ -587,17 +587,9 @@ class Detect(YmkModule):
             st[key] = st.get(key, []) + [torch.cuda.Stream(device=device) for _ in range(n - len(st.get(key, [])))]
         return st[key][:n]
 
-    fuse_dwpw = False  # DWConv3x3 -> Conv1x1 pair as one kernel (csrc/dwpw.hip); off: not yet faster than two kernels
-
     def _branch(self, seq, x):
         for m in list(seq)[:-1]:
             if isinstance(m, nn.Sequential):
-                if (self.fuse_dwpw and len(m) == 2 and isinstance(m[0], DWConv) and isinstance(m[1], Conv)
-                        and m[1].conv.kernel_size == (1, 1) and m[1].conv.groups == 1
-                        and ops.dwpw_supported(x.dtype, x.shape[-1], m[0].conv.kernel_size[0])):
-                    d, p = m[0]._packed(x.device), m[1]._packed(x.device)
-                    x = ops.dwconv_pwconv(x, d["w"], d["b"], d["k"], _is_silu(m[0].act), p["w"], p["b"], _is_silu(m[1].act))
-                    continue
                 for mm in m:
                     x = mm._run(x)
             else:
@@ -822,9 +814,6 @@ class ES_MOE(YmkModule):
     batch's device flag word is checked (``check_flags``), not through a per-layer host sync.
     """
 
-    # Fused depthwise->pointwise kernel (csrc/dwpw.hip): correct (tests cover it) but measured SLOWER than the two-kernel
-    # form on MI355X round 1 (14.6 vs 10.1 ms/step: 1 workgroup/CU, per-wave weight re-reads) -> off by default.
-    fuse_experts = False
     # The expert body as ONE wave-specialised kernel per layer (csrc/esfused.hip, round 4; 16-bit modes, C in {128, 256}, top_k <= 2):
     # bit-identical to the two-kernel form and validated on MI355X, but measured SLOWER (layer 3 of the S detector at batch 64: 1.10 ms
     # against 0.44 + 0.23 ms; stage ablation in profiles/r04_esfused_ablation.txt: one stencil wave per SIMD cannot hide its LDS round
@@ -941,7 +930,7 @@ class ES_MOE(YmkModule):
         E, C, Co = self.num_experts, self.in_channels, self.out_channels
         rn = self.routing.routing_network
         hidden = rn[0].out_channels
-        ks, dw_parts, dw_off, off, toeps = [], [], [], 0, []
+        ks, dw_parts, dw_off, off = [], [], [], 0
         pw_w = torch.zeros((E, Co, ops.kpad(C)), dtype=torch.float32, device=device)
         pw_b = torch.zeros((E, Co), dtype=torch.float32, device=device)
         for e, ex in enumerate(self.experts):
@@ -951,7 +940,6 @@ class ES_MOE(YmkModule):
                 raise NotImplementedError("ymk ES_MOE: experts are odd k<=15 stride-1 depthwise + pointwise")
             ks.append(k)
             w = ops.pack_dw_weight(cv.depthwise.weight.detach().float().to(device), dtype)
-            toeps.append(getattr(w, "toeplitz", None))
             dw_parts.append(w.reshape(-1))
             dw_off.append(off)
             off += w.numel()
@@ -968,9 +956,6 @@ class ES_MOE(YmkModule):
             "w2": rn[2].weight.detach().float().reshape(E, hidden).to(device).contiguous(),
             "b2": rn[2].bias.detach().float().to(device).contiguous(),
             "dw_w": torch.cat(dw_parts).contiguous(), "dw_off": torch.tensor(dw_off, **i32),
-            # the experts' filters as MFMA A fragments, expert-major (csrc/dwmfma.hip); None -> VALU stencil
-            "toep": torch.cat(toeps).contiguous() if toeps and all(t is not None for t in toeps) else None,
-            "kmask": sum({1 << (k // 2) for k in ks}),
             "ks": torch.tensor(ks, **i32), "kmax": max(ks), "pw_w": pw_w.to(dtype).contiguous(), "pw_b": pw_b.contiguous(),
             "ns": ns.detach().float().to(device).contiguous(), "nt": nt.detach().float().to(device).contiguous(),
         }
@@ -1003,12 +988,8 @@ class ES_MOE(YmkModule):
             # experts of an image, the depthwise tile handed to the matrix cores through LDS — no dw_out buffer, bit-identical results
             y = ops.esmoe_fused(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel,
                                 gate_w, out=out)
-        elif self.fuse_experts and ops.dwpw_supported(x.dtype, C, pk["kmax"]):
-            # depthwise -> pointwise in one kernel: the stencil tile never leaves LDS
-            y = ops.esmoe_experts_fused(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], pk["pw_w"], pk["pw_b"], pk["ns"],
-                                        pk["nt"], top_k, sel, gate_w, out=out)
         else:
-            dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair, toep=pk["toep"], kmask=pk["kmask"])
+            dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair)
             y = ops.esmoe_pw(dw, B, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel, gate_w, out=out)
         # eval-time state the reference keeps (modules.py:706-741), computed by the router's last kernel: views, no arithmetic
         self.expert_usage_counts = state[: self.num_experts]

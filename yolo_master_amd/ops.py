@@ -164,33 +164,10 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cout_perm: torch.Tenso
     return out.to(dtype).contiguous()
 
 
-def dw_mfma_enabled() -> bool:
-    """YMK_ENABLE bit 8 routes bf16 depthwise convolutions (k = 3..9, C % 16 == 0) to the matrix-core kernels of
-    csrc/dwmfma.hip.  OFF by default: validated on MI355X (tests/test_gpu_kernels.py::test_dwconv_mfma*), but measured slower
-    than the VALU stencil except for 7x7 / 9x9 filters on the 160- and 40-pixel maps (0.6-1.16x; ES-MoE stage 0.56-0.86x):
-    its 16-channel tiles read the input in 32-byte pieces with a 2.25-3x halo, and the CU's load path saturates at about one
-    such request per two cycles (stage ablation in profiles/r02_dwmfma_ablation.txt)."""
-    return bool(int(os.environ.get("YMK_ENABLE", "0"), 0) & 8)
-
-
-def dw_toeplitz(w_packed: torch.Tensor, k: int, force: bool = False) -> torch.Tensor | None:
-    """MFMA A-fragment table of a packed depthwise filter ([k*k, C] bf16 on the GPU), built once at pack time by
-    ymk_dw_toeplitz_pack; None when the matrix-core kernel does not cover the case (dtype, k > 9, C % 16)."""
-    C_ = w_packed.shape[1]
-    if not (w_packed.is_cuda and (force or dw_mfma_enabled()) and w_packed.dtype in DT and lib.ymk_dw_mfma_supported(DT[w_packed.dtype], C_, k)):
-        return None
-    out = torch.empty((lib.ymk_dw_toeplitz_elems(C_, k),), dtype=w_packed.dtype, device=w_packed.device)
-    check(lib.ymk_dw_toeplitz_pack(_p(w_packed), C_, k, _p(out), _stream()), "dw_toeplitz_pack")
-    return out
-
-
 def pack_dw_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """[C, 1, k, k] -> [k*k, C].  On the GPU in bf16 the result also carries `.toeplitz`, the same filter as MFMA A
-    fragments (dw_toeplitz): dwconv2d / esmoe_dw then run on the matrix cores."""
+    """[C, 1, k, k] -> [k*k, C]."""
     c, _, kh, kw = w.shape
-    wp = w.reshape(c, kh * kw).t().contiguous().to(dtype)
-    wp.toeplitz = dw_toeplitz(wp, kh) if kh == kw else None
-    return wp
+    return w.reshape(c, kh * kw).t().contiguous().to(dtype)
 
 
 def fold_bn(w: torch.Tensor, bn_w, bn_b, bn_mean, bn_var, eps: float, conv_bias=None):
@@ -355,13 +332,8 @@ def dwconv2d(x, w_packed, bias, k: int, act: bool, out=None, residual=None):
     ldy = _nhwc(out)[4]
     ldr = _nhwc(residual)[4] if residual is not None else 0
     e0 = TIMER.begin()
-    toep = getattr(w_packed, "toeplitz", None)
-    if toep is not None and x.dtype in H16 and out.dtype == x.dtype:
-        check(lib.ymk_dwconv2d_mfma(_p(x), _p(toep), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy, ldr,
-                                    _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d_mfma")
-    else:
-        check(lib.ymk_dwconv2d(DT[x.dtype], _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy,
-                               ldr, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d")
+    check(lib.ymk_dwconv2d(DT[x.dtype], _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), B, H, W, Cc, k, ldx, ldy,
+                           ldr, _lib.ACT_SILU if act else _lib.ACT_NONE, _stream()), "dwconv2d")
     TIMER.end(e0, "dwconv", B * H * W * Cc * x.element_size() * (3 if residual is not None else 2), 2 * B * H * W * Cc * k * k, f"C{Cc} k{k} @{H}x{W}")
     return out
 
@@ -396,20 +368,14 @@ def esmoe_route(x, w1, b1, w2, b2, top_k: int, thr: float, flags: torch.Tensor):
     return route_w, gate_w, sel, csr_off, csr_pair, state
 
 
-def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_pair, toep=None, kmask: int = 0):
-    """Depthwise stage of the retained (image, expert) pairs.  toep: the experts' Toeplitz tables concatenated in expert
-    order (bf16 only) + kmask (bit (k-1)/2 per filter size present) -> matrix-core kernels walking the image->expert CSR;
-    otherwise the VALU stencil per pair."""
+def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_pair):
+    """Depthwise stage of the retained (image, expert) pairs: the LDS-tiled VALU stencil per pair (csrc/dwconv.hip)."""
     B, H, W, Cc, ldx = _nhwc(x)
     E = ksizes.numel()
     out = torch.empty((B * top_k, H, W, Cc), dtype=x.dtype, device=x.device)
     e0 = TIMER.begin()
-    if toep is not None and x.dtype in H16:
-        check(lib.ymk_esmoe_dw_mfma(_p(x), B, H, W, Cc, ldx, _p(toep), _p(ksizes), kmask, E, top_k, _p(csr_off), _p(csr_pair),
-                                    _p(out), _stream()), "esmoe_dw_mfma")
-    else:
-        check(lib.ymk_esmoe_dw(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), E, top_k, kmax, _p(sel),
-                               _p(csr_off), _p(csr_pair), _p(out), _stream()), "esmoe_dw")
+    check(lib.ymk_esmoe_dw(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), E, top_k, kmax, _p(sel),
+                           _p(csr_off), _p(csr_pair), _p(out), _stream()), "esmoe_dw")
     if e0 is not None:  # algorithmic traffic: every image read once, one plane written per retained (image, expert) pair
         e1 = TIMER.begin()
         cnt = (csr_off[1:] - csr_off[:-1]).cpu()
@@ -435,22 +401,6 @@ def esmoe_pw(dw_out, B: int, H: int, W: int, pw_w, pw_b, nscale, nshift, top_k: 
         TIMER.records.append(("moe_pw", e0, e1, (npairs * H * W * Cc + E * Cout * Cc + B * H * W * Cout) * es,
                               2 * npairs * H * W * Cc * Cout))
         TIMER.shapes.append(f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
-    return out
-
-
-def dwpw_supported(dtype, C: int, kmax: int) -> bool:
-    return bool(lib.ymk_dwpw_supported(DT[dtype], C, kmax))
-
-
-def esmoe_experts_fused(x, dw_w, dw_off, ksizes, kmax: int, pw_w, pw_b, nscale, nshift, top_k: int, sel, gate_w, out=None):
-    B, H, W, Cc, ldx = _nhwc(x)
-    E, Cout, Kp = pw_w.shape
-    if out is None:
-        out = new_act(B, H, W, Cout, x.dtype, x.device)
-    ldy = _nhwc(out)[4]
-    check(lib.ymk_esmoe_experts_fused(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), kmax, Cout, Kp,
-                                      _p(pw_w), _p(pw_b), _p(nscale), _p(nshift), E, top_k, _p(sel), _p(gate_w), _p(out), ldy,
-                                      _stream()), "esmoe_experts_fused")
     return out
 
 
@@ -488,17 +438,6 @@ def esmoe_fused(x, dw_w, dw_off, ksizes, kmax: int, pw_w, pw_b, nscale, nshift, 
         es = x.element_size()
         TIMER.records.append(("moe_fused", e0, e1, (B * H * W * (Cc + Cout) + E * Cout * Cc) * es, int(2 * npairs * H * W * Cc * (Cout + k2))))
         TIMER.shapes.append(f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
-    return out
-
-
-def dwconv_pwconv(x, dw_w, dw_b, k: int, dw_act: bool, pw_w, pw_b, pw_act: bool, out=None):
-    B, H, W, Cc, ldx = _nhwc(x)
-    Cout, Kp = pw_w.shape
-    if out is None:
-        out = new_act(B, H, W, Cout, x.dtype, x.device)
-    ldy = _nhwc(out)[4]
-    check(lib.ymk_dwconv_pwconv(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_b), k, int(dw_act), Cout, Kp, _p(pw_w),
-                                _p(pw_b), int(pw_act), _p(out), ldy, _stream()), "dwconv_pwconv")
     return out
 
 
@@ -978,6 +917,26 @@ def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None):
     check(lib.ymk_token_softmax(_p(logits), ldl, _p(out), ldw, _p(active), B, H * W, n, float(inv_temp), int(top_k), _stream()),
           "token_softmax")
     return out, active
+
+
+def moa_sparse_gate(weights, n: int, threshold: float):
+    """MoA sparse inference (moa/block.py:194-234): which of the n head groups run for this batch, and their renormalised per-token
+    gates.  weights fp32 [B,H,W,>=n] (token_softmax).  Returns (active: list of bool — ONE host sync, as in the reference, which reads
+    the decision with bool(...) too —, blend fp32 [B,H,W,n] with the active groups' gates in its first columns, mass: mean gate sum of the
+    skipped groups, the reference's `dropped_routing_mass` diagnostic)."""
+    B, H, W, Cc, ldw = _nhwc(weights)
+    if weights.dtype != torch.float32 or Cc < n:
+        raise ValueError("moa_sparse_gate: fp32 gates with at least n channels")
+    dev = weights.device
+    stats = torch.zeros((2 * n,), dtype=torch.float64, device=dev)          # n sums (fp64) + n maxima (the bits of non-negative floats)
+    blend = torch.empty((B, H, W, n), dtype=torch.float32, device=dev)
+    active = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib.ymk_moa_sparse_gate(_p(weights), ldw, B * H * W, n, float(threshold), _p(stats), _p(blend), n, _p(active), _stream()),
+          "moa_sparse_gate")
+    act = [bool(v) for v in active.tolist()]
+    sums = stats[:n].tolist()
+    mass = sum(s_ for s_, a_ in zip(sums, act) if not a_) / float(B * H * W)
+    return act, blend, mass
 
 
 @_timed("token_router")

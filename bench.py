@@ -373,7 +373,7 @@ def main():
         # clocks: the chip ramps for tens of milliseconds after a host-side pause (graph capture) — untimed replays until 0.3 s of
         # device work have run, so that a short timed region (the driver's 20 steps = 0.1 s) is not measured on the ramp
         t_spin = time.perf_counter()
-        while True:
+        while graph is not None:      # (eager launches = profiling runs: the step count stays what the flags say)
             for sl in slots:
                 sl.run()
             torch.cuda.synchronize()

@@ -277,7 +277,10 @@ int ymk_mlp_fused(const void* x, int32_t ldx, const void* w1, int32_t k1pad, con
  * ------------------------------------------------------------------------ */
 int ymk_detect_decode(const float* box_l, const float* cls_l, float* y, int32_t B, int32_t Hl,
                       int32_t Wl, int32_t reg_max, int32_t nc, int32_t ldc, float stride, int32_t a_off,
-                      int32_t A_total, void* stream);
+                      int32_t A_total, float* best_conf /*[B][A_total] or NULL*/, int32_t* best_cls /*[B][A_total] or NULL*/,
+                      void* stream);
+/* best_conf / best_cls (both or neither): the largest class score of every anchor and its class (first maximum in class order), the
+ * values stored in y — the single-label candidate filter of non_max_suppression (utils/nms.py:124-129) precomputed by the producer. */
 
 /* ------------------------------------------------------------------------
  * Batched NMS: non_max_suppression (utils/nms.py:13-171) with TorchNMS.nms
@@ -295,8 +298,11 @@ size_t ymk_nms_workspace_bytes(int32_t B, int32_t nc, int32_t A, int32_t multi_l
 int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t extra, int32_t A, float conf_thres,
                     float iou_thres, int32_t multi_label, int32_t agnostic, int32_t max_det,
                     int32_t max_nms, float max_wh, const uint8_t* class_keep /*[nc] or NULL*/,
+                    const float* best_conf /*[B][A] or NULL*/, const int32_t* best_cls /*[B][A] or NULL*/,
                     float* out_dets, int32_t* out_counts, int32_t* out_idx, int32_t* status,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* best_conf / best_cls: ymk_detect_decode's per-anchor best class of THIS y (must describe it exactly); with them the single-label
+ * path does not read the class rows of y at all.  Ignored when multi_label. */
 /* class_keep: the `classes=` filter of non_max_suppression (utils/nms.py:63,132): a candidate survives only when
  * class_keep[its class] != 0; applied after the best-class choice of the single-label path, as the reference does. */
 

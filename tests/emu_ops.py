@@ -323,7 +323,7 @@ def nhwc_to_nchw_f32(x):
 
 
 # ------------------------------------------------------------------------------------------------- detect / nms
-def detect_decode(box_l, cls_l, y, stride, a_off, reg_max):
+def detect_decode(box_l, cls_l, y, stride, a_off, reg_max, best=None):
     _count("detect_decode")
     B, Hl, Wl, _ = box_l.shape
     nc = cls_l.shape[-1]
@@ -336,6 +336,9 @@ def detect_decode(box_l, cls_l, y, stride, a_off, reg_max):
     box = torch.cat([(x1y1 + x2y2) / 2, x2y2 - x1y1], -1) * stride
     y[:, :4, a_off: a_off + n] = box.transpose(1, 2)
     y[:, 4:, a_off: a_off + n] = cls_l.reshape(B, n, nc).sigmoid().transpose(1, 2)
+    if best is not None:
+        best[0][:, a_off: a_off + n], j = y[:, 4:, a_off: a_off + n].max(1)
+        best[1][:, a_off: a_off + n] = j.int()
     return y
 
 

@@ -140,3 +140,69 @@ def dense_pred(B: int, nc: int, A: int, seed: int, frame: float = 640.0) -> torc
         y[b, 4:] = s.astype(np.float32).reshape(nc, A)
         assert len(np.unique(y[b, 4:])) == n
     return torch.from_numpy(y)
+
+
+def decode_best_then_nms(dev, levels=((5, 7, 8.0), (3, 4, 16.0)), B=2, nc=11, ties=False, seed=0):
+    """The decode kernel's per-anchor best class (ymk_detect_decode: best_conf / best_cls) and the NMS that takes it instead of reading
+    the class rows (ymk_nms_batched).  Checks, all exact: (1) y is the same with and without the side outputs, (2) they are amax /
+    first argmax of y's class rows, (3) the detections and kept anchors through `y.best` equal those of the plain y and the oracle's,
+    with and without a class filter, (4) an in-place edit of y drops the side outputs (the version stamp), (5) multi_label ignores
+    them.  ties: class logits quantised so that several classes share the maximum (the first one must win)."""
+    from oracle import nms_ref
+    from yolo_master_amd import ops
+    from yolo_master_amd.nms import non_max_suppression
+
+    A = sum(h * w for h, w, _ in levels)
+    y0 = torch.zeros((B, 4 + nc, A), dtype=torch.float32, device=dev)
+    y1 = torch.zeros_like(y0)
+    best = (torch.full((B, A), -1.0, device=dev), torch.full((B, A), -1, dtype=torch.int32, device=dev))
+    off = 0
+    for li, (h, w, stride) in enumerate(levels):
+        box = rnd(B, h, w, 64, seed=seed + 10 * li + 1, scale=2.0).to(dev)
+        cls = rnd(B, h, w, nc, seed=seed + 10 * li + 2, scale=2.0)
+        if ties:
+            cls = (cls * 2).round() / 2
+        cls = cls.to(dev)
+        ops.detect_decode(box, cls, y0, stride, off, 16)
+        ops.detect_decode(box, cls, y1, stride, off, 16, best=best)
+        off += h * w
+    assert torch.equal(y0, y1), "y changes with the side outputs requested"
+    conf, j = y1[:, 4:].cpu().max(1)
+    assert torch.equal(best[0].cpu(), conf), "best_conf is not the class maximum stored in y"
+    assert torch.equal(best[1].cpu().long(), j), "best_cls is not the first arg max"
+    if ties:
+        assert int((y1[:, 4:].cpu() == conf.unsqueeze(1)).sum(1).max()) > 1, "no shared maxima in this draw"
+    y1.best = (best[0], best[1], y1._version)
+    calls = []
+    real = ops.lib.ymk_nms_batched
+
+    def spy(*a):
+        calls.append(a[13] is not None and a[14] is not None)   # best_conf, best_cls arguments
+        return real(*a)
+
+    class _Lib:
+        def __getattr__(self, k):
+            return spy if k == "ymk_nms_batched" else getattr(lib0, k)
+
+    lib0, ops.lib = ops.lib, _Lib()
+    try:
+        for kw in (dict(conf_thres=0.3, iou_thres=0.5, max_det=40), dict(conf_thres=0.3, iou_thres=0.5, classes=[0, 3, 4, 9], max_det=40),
+                   dict(conf_thres=0.05, iou_thres=0.6, max_nms=50, max_det=20)):
+            ref, ref_idx = nms_ref.non_max_suppression(y0.cpu().numpy(), return_idxs=True, **kw)
+            a, ai = non_max_suppression(y0, return_idxs=True, **kw)
+            b, bi = non_max_suppression(y1, return_idxs=True, **kw)
+            assert calls[-2:] == [False, True], calls
+            for i in range(B):
+                assert np.array_equal(bi[i].cpu().numpy(), ref_idx[i]) and np.array_equal(b[i].cpu().numpy(), ref[i]), (kw, i)
+                assert torch.equal(a[i], b[i]) and torch.equal(ai[i], bi[i])
+            assert sum(len(r) for r in ref) > 0
+        non_max_suppression(y1, 0.3, 0.5, multi_label=True)
+        assert calls[-1] is False, "multi_label must read the class rows"
+        y1[:, 4:, : A // 2] *= 0.5                                   # the caller edits y: the side outputs no longer describe it
+        ref, ref_idx = nms_ref.non_max_suppression(y1.cpu().numpy(), 0.3, 0.5, return_idxs=True)
+        b, bi = non_max_suppression(y1, 0.3, 0.5, return_idxs=True)
+        assert calls[-1] is False, "stale side outputs were used"
+        for i in range(B):
+            assert np.array_equal(bi[i].cpu().numpy(), ref_idx[i]) and np.array_equal(b[i].cpu().numpy(), ref[i])
+    finally:
+        ops.lib = lib0

@@ -393,6 +393,14 @@ def test_detect_decode_exact():
     assert float(y[:, :, :5].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("ties", [False, True])
+def test_decode_side_outputs_feed_nms(ties):
+    """The decode kernel hands NMS every anchor's best class (tests/helpers.decode_best_then_nms): bit-exact with the plain path."""
+    from tests.helpers import decode_best_then_nms
+
+    decode_best_then_nms(DEV, levels=((80, 80, 8.0), (40, 40, 16.0), (20, 20, 32.0)), B=3, nc=80, ties=ties, seed=9)
+
+
 # ------------------------------------------------------------------------------- NMS
 def _nms_compare(y, **kw):
     from oracle import nms_ref

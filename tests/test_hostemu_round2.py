@@ -155,3 +155,11 @@ def test_nms_with_carried_mask_rows_vs_reference_golden(case, host_ops, golden_d
         assert got[b].shape[1] == 6 + extra
         assert np.array_equal(idx[b].numpy(), z[f"idx{b}"]), f"{case} image {b}: kept anchors differ"
         assert np.array_equal(got[b].numpy(), z[f"dets{b}"]), f"{case} image {b}: output rows differ"
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_decode_side_outputs_feed_nms(ties, host_ops):
+    """Round 4: the decode kernel hands NMS every anchor's best class (tests/helpers.decode_best_then_nms), on the lane emulator."""
+    from tests.helpers import decode_best_then_nms
+
+    decode_best_then_nms("cpu", ties=ties, seed=5)

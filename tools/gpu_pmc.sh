@@ -5,7 +5,7 @@ set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --split 1 --pipeline 1"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --split 1 --pipeline 1 --no-sync-leg"
 n=0
 for C in "$@"; do
   n=$((n+1))

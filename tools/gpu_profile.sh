@@ -6,9 +6,9 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 set -e
-python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --split 1 --pipeline 1 > /dev/null   # refuse to profile a crashing workload
+python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --split 1 --pipeline 1 --no-sync-leg > /dev/null   # refuse to profile a crashing workload
 set +e
-BENCH="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --split 1 --pipeline 1"
+BENCH="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --split 1 --pipeline 1 --no-sync-leg"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_trace -- $BENCH > $R/gpurun_out/${TAG}_trace.log 2>&1
 python $R/tools/prof_summary.py $(ls $R/gpurun_out/${TAG}_trace/*/*.db | head -1) 13 > $R/gpurun_out/${TAG}_kernel_stats.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -79,9 +79,9 @@ SYMBOLS = {
     "ymk_copy_channels": (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "ymk_scale_residual": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _i32, _vp]),
     "ymk_nhwc_to_nchw_f32": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "ymk_detect_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "ymk_detect_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
     "ymk_nms_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
-    "ymk_nms_batched": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
+    "ymk_nms_batched": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _sz, _vp]),
     "ymk_nms_gather_rows": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ymk_cw_refine": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),

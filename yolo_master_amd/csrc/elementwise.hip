@@ -149,9 +149,13 @@ extern "C" int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int3
 // as y[b][channel][anchor] (anchor-contiguous).  Arithmetic, in the reference's order:
 //   p = softmax_16(logits); dist = sum_i i*p_i; x1y1 = anchor - lt; x2y2 = anchor + rb;
 //   c = (x1y1 + x2y2)/2; wh = x2y2 - x1y1; box = (c, wh) * stride; score = sigmoid(cls).
+// best_conf / best_cls (nullable, [B][A]): the largest class score of every anchor and its class (first maximum in class order) — what
+// the single-label candidate filter of non_max_suppression computes from y (utils/nms.py:124-129); handed to ymk_nms_batched they
+// save its pass over the nc class rows.  The value is the float stored in y.
 __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restrict__ box, const float* __restrict__ cls,
                                                            float* __restrict__ y, int Hl, int Wl, int reg_max, int nc,
-                                                           int ldc, float stride, int a_off, int A) {
+                                                           int ldc, float stride, int a_off, int A, float* __restrict__ best_conf,
+                                                           int* __restrict__ best_cls) {
     extern __shared__ float sm[];  // cls tile [64][nc+1], dist [64][4], box tile [256][17] (reg_max == 16)
     const int HW = Hl * Wl;
     const int b = blockIdx.y;
@@ -240,15 +244,30 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
         const int c = i >> 6, r = i & 63;
         if (r < na) {
             const float v = scls[r * (nc + 1) + c];
-            yb[(size_t)(4 + c) * A + r] = 1.0f / (1.0f + expf(-v));
+            const float p = 1.0f / (1.0f + expf(-v));
+            yb[(size_t)(4 + c) * A + r] = p;
+            if (best_conf) scls[r * (nc + 1) + c] = p;     // (each element is read and rewritten by the same thread)
+        }
+    }
+    if (best_conf) {
+        __syncthreads();
+        if (t < na) {
+            float best = scls[t * (nc + 1)];
+            int bi = 0;
+            for (int c = 1; c < nc; ++c) {
+                const float v = scls[t * (nc + 1) + c];
+                if (v > best) { best = v; bi = c; }        // the first maximum wins, as the reference's max / argmax over the class axis
+            }
+            best_conf[(size_t)b * A + a_off + a0 + t] = best;
+            best_cls[(size_t)b * A + a_off + a0 + t] = bi;
         }
     }
 }
 
 extern "C" int ymk_detect_decode(const float* box_l, const float* cls_l, float* y, int32_t B, int32_t Hl, int32_t Wl,
                                  int32_t reg_max, int32_t nc, int32_t ldc, float stride, int32_t a_off, int32_t A_total,
-                                 void* stream) {
-    if (!box_l || !cls_l || !y || reg_max < 1 || nc < 1) return YMK_E_BADARG;
+                                 float* best_conf, int32_t* best_cls, void* stream) {
+    if (!box_l || !cls_l || !y || reg_max < 1 || nc < 1 || (best_conf == nullptr) != (best_cls == nullptr)) return YMK_E_BADARG;
     if (ldc != nc && (ldc < nc || (ldc & 3) || ldc - nc >= 4)) return YMK_E_BADARG;
     const int HW = Hl * Wl;
     if (B <= 0 || HW <= 0) return YMK_OK;
@@ -257,6 +276,6 @@ extern "C" int ymk_detect_decode(const float* box_l, const float* cls_l, float* 
     if (shm > 64 * 1024) return YMK_E_BADARG;
     dim3 grid((HW + 63) / 64, B), blk(256);
     hipLaunchKernelGGL(detect_decode_kernel, grid, blk, shm, (hipStream_t)stream, box_l, cls_l, y, Hl, Wl, reg_max, nc,
-                       ldc, stride, a_off, A_total);
+                       ldc, stride, a_off, A_total, best_conf, best_cls);
     return ymk_launch_status();
 }

@@ -143,6 +143,24 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const float* __restrict_
     if (threadIdx.x == 0) w.blocksum[b * w.nblk + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// ---- 1b. the same from the per-anchor best class the producer of y already wrote (ymk_detect_decode): single-label only ---------
+// w.bconf / w.bcls point at the producer's arrays; the nc class rows of y are not read.
+__global__ __launch_bounds__(256) void nms_count_best_kernel(int A, float conf, const unsigned char* __restrict__ class_keep, NmsWs w) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    int c = 0;
+    if (a < A) {
+        c = (w.bconf[(size_t)b * A + a] > conf) && (!class_keep || class_keep[w.bcls[(size_t)b * A + a]]);
+        w.cnt[(size_t)b * A + a] = c;
+    }
+    int s = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) w.blocksum[b * w.nblk + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 // ---- 2. exclusive scan of block sums (one wavefront per image) ---------------------
 __global__ __launch_bounds__(64) void nms_scan_kernel(NmsWs w, int* __restrict__ status) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -683,8 +701,9 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, flo
 
 extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t extra, int32_t A, float conf_thres, float iou_thres,
                                int32_t multi_label, int32_t agnostic, int32_t max_det, int32_t max_nms, float max_wh,
-                               const uint8_t* class_keep, float* out_dets, int32_t* out_counts, int32_t* out_idx, int32_t* status,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               const uint8_t* class_keep, const float* best_conf, const int32_t* best_cls, float* out_dets,
+                               int32_t* out_counts, int32_t* out_idx, int32_t* status, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     if (!y || !out_dets || !out_counts || !out_idx || !status || !workspace) return YMK_E_BADARG;
     if (B <= 0 || A <= 0 || nc <= 0 || extra < 0 || max_det <= 0 || max_nms <= 0 || B > 65535 || max_det > NMS_MAXDET_CAP)
         return YMK_E_BADARG;
@@ -693,7 +712,13 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t ex
     if (workspace_bytes < w.total) return YMK_E_WORKSPACE;
     w.rows = 4 + nc + extra;   // utils/nms.py:76-81: candidates come from rows [4, 4 + nc); the `extra` rows behind them are carried, not scored
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
+    if (best_conf && best_cls && !multi) {   // the producer's per-anchor best class (ymk_detect_decode): no pass over the class rows
+        w.bconf = const_cast<float*>(best_conf);
+        w.bcls = const_cast<int*>(best_cls);
+        hipLaunchKernelGGL(nms_count_best_kernel, dim3(w.nblk, B), dim3(256), 0, s, A, conf_thres, class_keep, w);
+    } else {
+        hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
+    }
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, w, status);
     const int64_t full = multi ? (int64_t)A * nc : (int64_t)A;
     if (full > (int64_t)max_nms) {   // an image CAN hold more candidates than max_nms: selection kernels (no-ops for images that do not)

@@ -624,8 +624,12 @@ class Detect(YmkModule):
         for h, w in level_hw:
             offs.append(a_off)
             a_off += h * w
-        return {"y": torch.empty((B, 4 + self.nc, a_off), dtype=torch.float32, device=device), "offs": offs, "raw": [None] * len(level_hw),
-                "hw": list(level_hw), "side": [], "main": None}
+        with torch.inference_mode(False):   # a normal tensor even under inference_mode: it keeps a version counter (see finish)
+            y = torch.empty((B, 4 + self.nc, a_off), dtype=torch.float32, device=device)
+        # every anchor's best class score and class, written by the decode kernel next to y: the single-label candidate filter of
+        # non_max_suppression reads these 8 bytes per anchor instead of the nc class rows (ops.nms_batched looks for `y.best`)
+        y.best = (torch.empty((B, a_off), dtype=torch.float32, device=device), torch.empty((B, a_off), dtype=torch.int32, device=device))
+        return {"y": y, "offs": offs, "raw": [None] * len(level_hw), "hw": list(level_hw), "side": [], "main": None}
 
     def _level(self, st, i, f):
         pk = self._packed(f.device)
@@ -642,7 +646,7 @@ class Detect(YmkModule):
         else:
             hc = self._branch(self.cv3[i], f)
             cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)[..., : self.nc]
-        ops.detect_decode(box, cls, st["y"], float(self.stride[i]), st["offs"][i], self.reg_max)
+        ops.detect_decode(box, cls, st["y"], float(self.stride[i]), st["offs"][i], self.reg_max, best=st["y"].best)
         st["raw"][i] = (box, cls)
 
     def start_level(self, st, i, f):
@@ -661,15 +665,19 @@ class Detect(YmkModule):
         for i, f in enumerate(feats):
             if i not in started:
                 self._level(st, i, f)
+        y = st["y"]
+        # valid for this y as it stands now: ops.nms_batched compares the version counter, so an in-place edit by the caller drops them
+        y.best = (y.best[0], y.best[1], -1 if y.is_inference() else y._version)
         if not st["side"]:
-            return st["y"], st["raw"]
+            return y, st["raw"]
         main = torch.cuda.current_stream()
         for side, i in st["side"]:
             main.wait_stream(side)
             for tns in st["raw"][i]:       # tensors created on a side stream are consumed on the main one
                 tns.record_stream(main)
-            st["y"].record_stream(side)
-        return st["y"], st["raw"]
+            for tns in (y, y.best[0], y.best[1]):
+                tns.record_stream(side)
+        return y, st["raw"]
 
     def _run(self, feats):
         """feats: list of NHWC maps.  Returns (y [B, 4+nc, A] fp32, raw) with raw = per-level

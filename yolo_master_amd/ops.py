@@ -521,15 +521,21 @@ def nhwc_to_nchw_f32(x):
 
 
 # ----------------------------------------------------------------------------- detect / nms
-def detect_decode(box_l, cls_l, y, stride: float, a_off: int, reg_max: int):
-    """cls_l: fp32 [B, Hl, Wl, nc], dense or a view of rows padded to 4*ceil(nc/4) channels (tail conv with nc % 4 != 0)."""
+def detect_decode(box_l, cls_l, y, stride: float, a_off: int, reg_max: int, best=None):
+    """cls_l: fp32 [B, Hl, Wl, nc], dense or a view of rows padded to 4*ceil(nc/4) channels (tail conv with nc % 4 != 0).
+    best: optional (conf fp32 [B, A], cls int32 [B, A]) filled with every anchor's largest class score and its class — nms_batched
+    takes them (`y.best`) instead of reading the class rows of y again."""
     B, Hl, Wl, _, _ = _nhwc(box_l)
     nc = cls_l.shape[-1]
     ldc = _nhwc(cls_l)[4]
     assert box_l.is_contiguous() and box_l.dtype == torch.float32 and cls_l.dtype == torch.float32 and y.shape[1] == 4 + nc
     e0 = TIMER.begin()
+    bc, bi = (best[0], best[1]) if best is not None else (None, None)
+    if best is not None:
+        assert bc.dtype == torch.float32 and bi.dtype == torch.int32 and bc.is_contiguous() and bi.is_contiguous() and \
+            tuple(bc.shape) == tuple(bi.shape) == (B, y.shape[2])
     check(lib.ymk_detect_decode(_p(box_l), _p(cls_l), _p(y), B, Hl, Wl, reg_max, nc, ldc, float(stride), a_off, y.shape[2],
-                                _stream()), "detect_decode")
+                                _p(bc), _p(bi), _stream()), "detect_decode")
     TIMER.end(e0, "detect_decode", B * Hl * Wl * (4 * reg_max + nc + 4 + nc) * 4, B * Hl * Wl * (4 * reg_max * 4 + nc * 4))
     return y
 
@@ -591,13 +597,20 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
     e0 = TIMER.begin()
     if class_keep is not None:
         assert class_keep.dtype == torch.uint8 and class_keep.numel() == nc and class_keep.device == y.device and class_keep.is_contiguous()
+    # the producer's per-anchor best class (Detect attaches it to the y it returns: `y.best`), valid for exactly this tensor
+    # ... and only while y is untouched since (Detect.finish stamps y's version counter: an in-place edit by the caller drops it)
+    best = getattr(y, "best", None)
+    bc, bi = (None, None)
+    if best is not None and not multi_label and extra == 0 and tuple(best[0].shape) == (B, A) and best[0].device == dev and \
+            len(best) == 3 and not y.is_inference() and best[2] == y._version:
+        bc, bi = best[0], best[1]
     check(lib.ymk_nms_batched(_p(y), B, nc, extra, A, float(conf), float(iou), int(multi_label), int(agnostic), max_det, max_nms,
-                              float(max_wh), _p(class_keep), _p(dets), _p(counts), _p(idx), _p(status), _p(ws), nbytes, _stream()),
-          "nms_batched")
+                              float(max_wh), _p(class_keep), _p(bc), _p(bi), _p(dets), _p(counts), _p(idx), _p(status), _p(ws), nbytes,
+                              _stream()), "nms_batched")
     if cw_sigma is not None:
         check(lib.ymk_cw_refine(B, nc, A, int(multi_label), int(agnostic), max_nms, max_det, float(iou), float(cw_sigma), cw_pool,
                                 _p(dets), _p(counts), _p(ws), nbytes, _stream()), "cw_refine")
-    TIMER.end(e0, "nms", B * (4 + nc) * A * 4 + B * max_det * 28, B * (4 + nc) * A)
+    TIMER.end(e0, "nms", B * ((4 + nc) if bc is None else 6) * A * 4 + B * max_det * 28, B * (4 + nc) * A)
     return dets, counts, idx, status
 
 

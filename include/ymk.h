@@ -150,7 +150,19 @@ int ymk_detect_cls_fused_supported(int32_t dtype, int32_t cin, int32_t c3, int32
 int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, int32_t cin, const void* dw1, const float* bd1,
                          const void* pw1, int32_t k1pad, const float* bp1, const void* dw2, const float* bd2, const void* pw2,
                          int32_t k2pad, const float* bp2, const void* w3, int32_t k3pad, const float* b3, int32_t ncpad, float* y,
-                         int32_t ldy, void* stream);
+                         int32_t ldy, float* y_out, int32_t nc, int32_t a_off, int32_t A_total, float* best_conf,
+                         int32_t* best_cls, void* stream);
+/* Fused decode (round 4; head.py:157-171 `cls.sigmoid()`): y_out != NULL -> sigmoid(logits) of the nc classes goes straight to rows
+ * 4.. of y_out fp32 [B][4 + nc][A_total] at anchors a_off + oy * W + ox (ymk_detect_decode's values bit for bit), best_conf / best_cls
+ * (both or neither, [B][A_total]) as ymk_detect_decode's.  y may then be NULL: the fp32 logits are not materialised.
+ *
+ * The box branch's tail: Conv2d(64, 4 * reg_max, 1) + bias -> DFL -> dist2bbox -> rows 0..3 of y (head.py:111-112,173-194;
+ * csrc/elementwise.hip), reg_max = 16, 16-bit x [B][Hl][Wl][ldx] with 64 channels, w packed [64][kpad]; raw: NULL or fp32
+ * [B][Hl][Wl][64] box logits.  With both, ymk_detect_decode and the 0.6 KB per anchor of fp32 logits it re-read are gone. */
+int ymk_detect_box_tail_supported(int32_t dtype, int32_t cin, int32_t reg_max);
+int ymk_detect_box_tail(int32_t dtype, const void* x, int32_t ldx, int32_t B, int32_t Hl, int32_t Wl, const void* w, int32_t kpad,
+                        const float* bias, int32_t reg_max, int32_t nc, float stride, int32_t a_off, int32_t A_total, float* y,
+                        float* raw, void* stream);
 
 /* ------------------------------------------------------------------------
  * Depthwise k x k convolution (stride 1, pad k/2, k odd <= 15) + bias + act

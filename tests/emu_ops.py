@@ -148,14 +148,42 @@ def detect_cls_fused_supported(dtype, cin, c3, nc):
     return dtype == torch.bfloat16 and cin in (128, 256) and c3 == 128 and 1 <= nc <= 128
 
 
-def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None):
-    """include/ymk.h `ymk_detect_cls_fused`: DW3x3 -> 1x1 -> DW3x3 -> 1x1 (each + SiLU, rounded to bf16) -> 1x1 + bias, fp32 logits."""
+def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None, y=None, nc=0, a_off=0, raw=True):
+    """include/ymk.h `ymk_detect_cls_fused`: DW3x3 -> 1x1 -> DW3x3 -> 1x1 (each + SiLU, rounded to bf16) -> 1x1 + bias, fp32 logits;
+    with y: their sigmoid into the class rows of y (+ `y.best`), the class half of detect_decode."""
     _count("detect_cls_fused")
     h = dwconv2d(x, d1[0], d1[1], 3, True)
     h = conv2d(h, p1[0], p1[1], 1, 1, True)
     h = dwconv2d(h, d2[0], d2[1], 3, True)
     h = conv2d(h, p2[0], p2[1], 1, 1, True)
-    return conv2d(h, w3[0], w3[1], 1, 1, False, out=out, out_dtype=torch.float32)
+    lg = conv2d(h, w3[0], w3[1], 1, 1, False, out=out if (raw or y is None) else None, out_dtype=torch.float32)
+    if y is not None:
+        B, H, W, _ = lg.shape
+        n = H * W
+        y[:, 4:, a_off: a_off + n] = lg[..., :nc].reshape(B, n, nc).sigmoid().transpose(1, 2)
+        best = getattr(y, "best", None)
+        if best is not None:
+            best[0][:, a_off: a_off + n], j = y[:, 4:, a_off: a_off + n].max(1)
+            best[1][:, a_off: a_off + n] = j.int()
+    return lg if (raw or y is None) else None
+
+
+def detect_box_tail_supported(dtype, cin, reg_max):
+    return dtype == torch.bfloat16 and cin == 64 and reg_max == 16
+
+
+def detect_box_tail(x, w_packed, bias, y, stride, a_off, reg_max, raw=False):
+    """include/ymk.h `ymk_detect_box_tail`: 1x1 (+bias, fp32) -> DFL -> dist2bbox -> rows 0..3 of y."""
+    _count("detect_box_tail")
+    lg = conv2d(x, w_packed, bias, 1, 1, False, out_dtype=torch.float32)
+    B, Hl, Wl, _ = lg.shape
+    n = Hl * Wl
+    dist = (lg.reshape(B, n, 4, reg_max).softmax(-1) * torch.arange(reg_max, dtype=torch.float32)).sum(-1)
+    sy, sx = torch.meshgrid(torch.arange(Hl, dtype=torch.float32) + 0.5, torch.arange(Wl, dtype=torch.float32) + 0.5, indexing="ij")
+    anc = torch.stack((sx, sy), -1).view(1, n, 2)
+    x1y1, x2y2 = anc - dist[..., :2], anc + dist[..., 2:]
+    y[:, :4, a_off: a_off + n] = (torch.cat([(x1y1 + x2y2) / 2, x2y2 - x1y1], -1) * stride).transpose(1, 2)
+    return lg if raw else None
 
 
 def mlp_fused_supported(dtype, C, hidden):
@@ -681,7 +709,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "esmoe_route", "esmoe_dw",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_fused_supported", "esmoe_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",

@@ -635,6 +635,16 @@ def test_esmoe_route_from_the_producers_pooled_sums():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_detcls", fromlist=["BOX_CASES"]).BOX_CASES + [(4, 80, 80, 8.0), (3, 40, 40, 16.0), (2, 20, 20, 32.0)])
+def test_detect_box_tail(case):
+    """Box-branch tail with the DFL decode in its epilogue (csrc/elementwise.hip detect_box_tail_kernel) vs convolution + detect_decode."""
+    from tests.test_hostemu_detcls import run_box_case
+    from yolo_master_amd import ops
+
+    run_box_case(ops, case, dev=DEV)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", __import__("tests.test_hostemu_detcls", fromlist=["CASES"]).CASES + [(4, 80, 80, 128, 80), (3, 40, 40, 256, 80), (2, 20, 20, 256, 80)])
 def test_detect_cls_fused(case):
     """Fused Detect class branch (csrc/detcls.hip) vs the five-convolution composition in torch (inside run_case) and vs the unfused

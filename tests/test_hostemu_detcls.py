@@ -53,7 +53,7 @@ def run_case(lib, case, dev="cpu", stream=None):
     assert lib.ymk_detect_cls_fused_supported(1, Cin, 128, nc) and not lib.ymk_detect_cls_fused_supported(1, 64, 128, nc)
     rc = lib.ymk_detect_cls_fused(_p(xd), xd.stride(2), B, H, W, Cin, _p(pk["d1"]), _p(bd["d1"]), _p(pk["p1"]), pk["p1"].shape[1], _p(bd["p1"]),
                                   _p(pk["d2"]), _p(bd["d2"]), _p(pk["p2"]), pk["p2"].shape[1], _p(bd["p2"]), _p(pk["w3"]), pk["w3"].shape[1],
-                                  _p(bd["w3"]), ncpad, _p(yb), yb.stride(2), stream)
+                                  _p(bd["w3"]), ncpad, _p(yb), yb.stride(2), None, 0, 0, 0, None, None, stream)
     assert rc == 0
     got = yb[..., :ncpad].cpu()
     err = (got - ref).abs()
@@ -61,9 +61,70 @@ def run_case(lib, case, dev="cpu", stream=None):
     assert float(err.max()) <= 4e-2 * scale, f"{case}: max err {float(err.max()):.3e}"
     assert float(err.mean()) <= 3e-3 * scale, f"{case}: mean err {float(err.mean()):.3e}"
     assert bool((yb[..., ncpad:].cpu() == 7.0).all()), "bytes between pixels were touched"
+    # round 4: the decode's class half in the epilogue — sigmoid into the class rows of y and the per-anchor best class, with and
+    # without the logits: bit-identical to ymk_detect_decode on the logits above
+    A, a_off = H * W + 9, 5
+    box = torch.zeros((B, H, W, 64), dtype=torch.float32, device=dev)
+    y_ref = torch.full((B, 4 + nc, A), 3.0, dtype=torch.float32, device=dev)
+    bc_ref, bi_ref = torch.full((B, A), -2.0, device=dev), torch.full((B, A), -2, dtype=torch.int32, device=dev)
+    cls_l = yb[..., :ncpad].contiguous()
+    assert lib.ymk_detect_decode(_p(box), _p(cls_l), _p(y_ref), B, H, W, 16, nc, ncpad, 8.0, a_off, A, _p(bc_ref), _p(bi_ref), stream) == 0
+    for keep in (True, False):
+        y2 = torch.full((B, 4 + nc, A), 3.0, dtype=torch.float32, device=dev)
+        bc, bi = torch.full((B, A), -2.0, device=dev), torch.full((B, A), -2, dtype=torch.int32, device=dev)
+        raw2 = torch.full((B, H, W, ncpad), 7.0, dtype=torch.float32, device=dev)
+        rc = lib.ymk_detect_cls_fused(_p(xd), xd.stride(2), B, H, W, Cin, _p(pk["d1"]), _p(bd["d1"]), _p(pk["p1"]), pk["p1"].shape[1], _p(bd["p1"]),
+                                      _p(pk["d2"]), _p(bd["d2"]), _p(pk["p2"]), pk["p2"].shape[1], _p(bd["p2"]), _p(pk["w3"]), pk["w3"].shape[1],
+                                      _p(bd["w3"]), ncpad, _p(raw2) if keep else None, ncpad, _p(y2), nc, a_off, A, _p(bc), _p(bi), stream)
+        assert rc == 0
+        assert torch.equal(y2[:, 4:].cpu(), y_ref[:, 4:].cpu()), f"{case} keep={keep}: class rows differ from detect_decode's"
+        assert bool((y2[:, :4].cpu() == 3.0).all()), "box rows were touched"
+        assert torch.equal(bc.cpu(), bc_ref.cpu()) and torch.equal(bi.cpu(), bi_ref.cpu()), f"{case}: best class differs"
+        if keep:
+            assert torch.equal(raw2.cpu(), yb[..., :ncpad].cpu())
     return got
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_detect_cls_fused_on_emulator(case, hostlib):
     run_case(hostlib, case)
+
+
+BOX_CASES = [(2, 8, 16, 8.0), (1, 5, 7, 16.0), (3, 9, 21, 32.0)]   # B, H, W, stride
+
+
+def run_box_case(ops, case, dev="cpu"):
+    """ymk_detect_box_tail (1x1 + bias -> DFL -> dist2bbox -> rows 0..3 of y) against the 1x1 convolution core + ymk_detect_decode."""
+    B, H, W, stride = case
+    nc, reg_max = 5, 16
+    g = torch.Generator().manual_seed(H * 31 + W)
+    bf = torch.bfloat16
+    x = (torch.randn(B, H, W, 64, generator=g) * 1.5).to(bf).to(dev)
+    w = ops.pack_conv_weight(torch.randn(64, 64, 1, 1, generator=g) * 0.35, bf).to(dev)
+    bias = (torch.randn(64, generator=g) * 0.5 + 1.0).to(dev)
+    A, a_off = H * W + 11, 4
+    logits = ops.conv2d(x, w, bias, 1, 1, False, out_dtype=torch.float32)
+    y_ref = torch.full((B, 4 + nc, A), 3.0, dtype=torch.float32, device=dev)
+    ops.detect_decode(logits, torch.zeros((B, H, W, nc), dtype=torch.float32, device=dev), y_ref, stride, a_off, reg_max)
+    for keep in (True, False):
+        y = torch.full((B, 4 + nc, A), 3.0, dtype=torch.float32, device=dev)
+        raw = ops.detect_box_tail(x, w, bias, y, stride, a_off, reg_max, raw=keep)
+        d = float((y[:, :4, a_off: a_off + H * W] - y_ref[:, :4, a_off: a_off + H * W]).abs().max())
+        assert d <= 1e-4 * stride, f"{case}: boxes differ by {d:.3e} px"
+        assert bool((y[:, 4:].cpu() == 3.0).all()) and bool((y[:, :4, :a_off].cpu() == 3.0).all()) and \
+            bool((y[:, :4, a_off + H * W:].cpu() == 3.0).all()), "wrote outside the level's box rows"
+        if keep:
+            assert float((raw - logits).abs().max()) <= 1e-5 * max(1.0, float(logits.abs().max()))
+        else:
+            assert raw is None
+    assert float((y_ref[:, 2:4, a_off: a_off + H * W]).min()) > 0
+
+
+@pytest.mark.parametrize("case", BOX_CASES)
+def test_detect_box_tail_on_emulator(case, hostlib, monkeypatch):
+    from yolo_master_amd import ops
+
+    monkeypatch.setattr(ops, "lib", hostlib)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    monkeypatch.setattr(ops, "require_gpu", lambda t, what="": None)
+    run_box_case(ops, case)

@@ -1,4 +1,5 @@
-// Detect class branch as ONE kernel (bf16): DWConv3x3 -> Conv1x1 -> DWConv3x3 -> Conv1x1 -> Conv2d 1x1 (+bias) -> fp32 class logits
+// Detect class branch as ONE kernel (bf16): DWConv3x3 -> Conv1x1 -> DWConv3x3 -> Conv1x1 -> Conv2d 1x1 (+bias) -> fp32 class logits and / or
+// (round 4) their sigmoid straight into the class rows of y plus every anchor's best class: the decode's class half in the epilogue
 // (ultralytics/nn/modules/head.py:111-118: `cv3[i] = Sequential(Sequential(DWConv(x, x, 3), Conv(x, c3, 1)),
 // Sequential(DWConv(c3, c3, 3), Conv(c3, c3, 1)), Conv2d(c3, nc, 1))`, every Conv / DWConv = convolution + folded BN + SiLU), for
 // c3 = 128 and x = 128 or 256 input channels (the three pyramid levels of YOLO-Master-S / -N ...: c3 = max(ch[0], min(nc, 100))).
@@ -48,8 +49,14 @@ struct DetClsArgs {
     const h16_t* x;                         // [B][H][W][ldx], CIN channels
     const h16_t *dw1, *pw1, *dw2, *pw2, *w3;   // dw: [9][C]; pw1 [128][k1pad]; pw2 [128][k2pad]; w3 [ncpad][k3pad]
     const float *bd1, *bp1, *bd2, *bp2, *b3;
-    float* y;                                // [B][H][W][ldy] fp32 logits (ncpad channels written)
+    float* y;                                // [B][H][W][ldy] fp32 logits (ncpad channels written); nullptr: not materialised
     int B, H, W, ldx, ldy, k1pad, k2pad, k3pad, ncpad, tiles_x, tiles_y;
+    // fused decode (all optional): sigmoid(logits) -> rows 4.. of yo [B][4 + nc][A] at anchor a_off + oy * W + ox, and every anchor's
+    // largest class score / its class (first maximum in class order) -> bconf / bcls [B][A]
+    float* yo;
+    float* bconf;
+    int* bcls;
+    int nc, A, a_off;
 };
 
 // 3x3 depthwise stencil + bias + SiLU for this thread's 4 channels: output pixels s, s + 16, ... < npix of an (orow x ocol) map read
@@ -213,14 +220,65 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dc_mma(acc[j], af3[s], bfr[j]);
             }
+            if (a.y) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int oy = oy0 + j, ox = ox0 + fr;   // fragment j = tile row j (16 pixels)
-                if (oy < a.H && ox < a.W && wave * 16 + fc * 4 < a.ncpad)
-                    *reinterpret_cast<f32x4*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = acc[j];
+                for (int j = 0; j < 8; ++j) {
+                    const int oy = oy0 + j, ox = ox0 + fr;   // fragment j = tile row j (16 pixels)
+                    if (oy < a.H && ox < a.W && wave * 16 + fc * 4 < a.ncpad)
+                        *reinterpret_cast<f32x4*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = acc[j];
+                }
+            }
+            if (a.yo) {
+                // the decode's class half here (head.py:157-171 `cls.sigmoid()`, detect_decode_kernel's expression): 16 lanes = 16 consecutive
+                // anchors of one class row (64-byte runs).  Region B (dw2's map, dead since pw2) collects this wave's best class per pixel.
+                float* sbest = reinterpret_cast<float*>(sB);
+                const int c0 = wave * 16 + fc * 4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int oy = oy0 + j, ox = ox0 + fr;
+                    const bool in = oy < a.H && ox < a.W;
+                    float* yp = a.yo + ((size_t)b * (4 + a.nc) + 4 + c0) * a.A + a.a_off + oy * a.W + ox;
+                    float bv = -1.f;
+                    int bc = 0x7fffffff;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = 1.0f / (1.0f + expf(-acc[j][r]));
+                        if (c0 + r < a.nc) {
+                            if (in) yp[(size_t)r * a.A] = p;
+                            if (p > bv) { bv = p; bc = c0 + r; }
+                        }
+                    }
+                    if (a.bconf) {
+#pragma unroll
+                        for (int o = 16; o <= 32; o <<= 1) {   // the four lanes that share pixel fr: larger score, then smaller class
+                            const float ov = __shfl_xor(bv, o);
+                            const int oc = __shfl_xor(bc, o);
+                            if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+                        }
+                        if (fc == 0) {
+                            sbest[(wave * DC_NP + j * 16 + fr) * 2] = bv;
+                            sbest[(wave * DC_NP + j * 16 + fr) * 2 + 1] = __int_as_float(bc);
+                        }
+                    }
+                }
             }
         }
         __syncthreads();   // region A is restaged by the next tile
+        if (a.yo && a.bconf && t < DC_NP) {   // (region B is next written by dw1, behind the staging barrier of the next tile)
+            const float* sbest = reinterpret_cast<const float*>(sB);
+            const int oy = oy0 + (t >> 4), ox = ox0 + (t & 15);
+            if (oy < a.H && ox < a.W) {
+                float bv = sbest[t * 2];
+                int bc = __float_as_int(sbest[t * 2 + 1]);
+                for (int wv = 1; wv * 16 < a.nc; ++wv) {   // class blocks in ascending order: the first maximum wins (utils/nms.py:124-129)
+                    const float ov = sbest[(wv * DC_NP + t) * 2];
+                    if (ov > bv) { bv = ov; bc = __float_as_int(sbest[(wv * DC_NP + t) * 2 + 1]); }
+                }
+                const size_t o = (size_t)b * a.A + a.a_off + oy * a.W + ox;
+                a.bconf[o] = bv;
+                a.bcls[o] = bc;
+            }
+        }
     }
 }
 
@@ -231,16 +289,20 @@ extern "C" int ymk_detect_cls_fused_supported(int32_t dtype, int32_t cin, int32_
 extern "C" int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, int32_t cin, const void* dw1, const float* bd1,
                                     const void* pw1, int32_t k1pad, const float* bp1, const void* dw2, const float* bd2, const void* pw2,
                                     int32_t k2pad, const float* bp2, const void* w3, int32_t k3pad, const float* b3, int32_t ncpad, float* y,
-                                    int32_t ldy, void* stream) {
-    if (!x || !dw1 || !bd1 || !pw1 || !bp1 || !dw2 || !bd2 || !pw2 || !bp2 || !w3 || !b3 || !y) return YMK_E_BADARG;
-    if (!ymk_detect_cls_fused_supported(YMK_BF16, cin, 128, ncpad) || ncpad % 4 || ldx % 8 || ldx < cin || ldy % 4 || ldy < ncpad ||
+                                    int32_t ldy, float* y_out, int32_t nc, int32_t a_off, int32_t A_total, float* best_conf,
+                                    int32_t* best_cls, void* stream) {
+    if (!x || !dw1 || !bd1 || !pw1 || !bp1 || !dw2 || !bd2 || !pw2 || !bp2 || !w3 || !b3 || (!y && !y_out)) return YMK_E_BADARG;
+    if (!ymk_detect_cls_fused_supported(YMK_BF16, cin, 128, ncpad) || ncpad % 4 || ldx % 8 || ldx < cin || (y && (ldy % 4 || ldy < ncpad)) ||
         k1pad < cin || k2pad < 128 || k3pad < 128 || (k1pad | k2pad | k3pad) % 8)
         return YMK_E_BADARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return YMK_E_BADARG;
+    if ((best_conf == nullptr) != (best_cls == nullptr) || (best_conf && !y_out)) return YMK_E_BADARG;
+    if (y_out && (nc < 1 || nc > ncpad || ncpad - nc >= 4 || a_off < 0 || (int64_t)a_off + (int64_t)H * W > A_total)) return YMK_E_BADARG;
     if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
     DetClsArgs a;
     a.x = (const h16_t*)x; a.dw1 = (const h16_t*)dw1; a.pw1 = (const h16_t*)pw1; a.dw2 = (const h16_t*)dw2; a.pw2 = (const h16_t*)pw2;
     a.w3 = (const h16_t*)w3; a.bd1 = bd1; a.bp1 = bp1; a.bd2 = bd2; a.bp2 = bp2; a.b3 = b3; a.y = y;
+    a.yo = y_out; a.bconf = best_conf; a.bcls = best_cls; a.nc = nc; a.A = A_total; a.a_off = a_off;
     a.B = B; a.H = H; a.W = W; a.ldx = ldx; a.ldy = ldy; a.k1pad = k1pad; a.k2pad = k2pad; a.k3pad = k3pad; a.ncpad = ncpad;
     a.tiles_x = (W + DC_TW - 1) / DC_TW; a.tiles_y = (H + DC_TH - 1) / DC_TH;
     const int64_t ntile = (int64_t)B * a.tiles_x * a.tiles_y;

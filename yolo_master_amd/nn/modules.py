@@ -631,23 +631,49 @@ class Detect(YmkModule):
         y.best = (torch.empty((B, a_off), dtype=torch.float32, device=device), torch.empty((B, a_off), dtype=torch.int32, device=device))
         return {"y": y, "offs": offs, "raw": [None] * len(level_hw), "hw": list(level_hw), "side": [], "main": None}
 
-    def _level(self, st, i, f):
+    # Fused decode (round 4): the last 1x1 of the box branch + DFL + dist2bbox and the class branch's sigmoid write y directly
+    # (ops.detect_box_tail, ops.detect_cls_fused(y=...)): no detect_decode launch, and with keep_raw False the fp32 logits — 0.6 KB per
+    # anchor written and read back — never reach HBM.  The reference's eval-mode `preds` (head.py:157-171) stays available: nothing
+    # on the predict / val path reads it, so DetectPreds recomputes the logits on first access (raw_logits) from the head's inputs.
+    # YMK_DISABLE bit 4194304: the unfused path; YMK_ENABLE bit 256: fused, logits materialised too.
+    fuse_decode = True
+    keep_raw = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 256)
+
+    def _cls_weights(self, i, device):
+        s0, s1 = self.cv3[i][0], self.cv3[i][1]
+        q = [m._packed(device) for m in (s0[0], s0[1], s1[0], s1[1])]
+        return [(d["w"], d["b"]) for d in q]
+
+    def _level(self, st, i, f, raw_only=False):
         pk = self._packed(f.device)
         if tuple(f.shape[1:3]) != tuple(st["hw"][i]):
             raise ValueError(f"Detect level {i}: map {tuple(f.shape[1:3])}, expected {st['hw'][i]}")
         hb = self._branch(self.cv2[i], f)
+        cls_fused = self._cls_fusable(i, f)
+        if not raw_only and self.fuse_decode and cls_fused and ops.detect_box_tail_supported(hb.dtype, hb.shape[-1], self.reg_max):
+            y, keep = st["y"], self.keep_raw
+            box = ops.detect_box_tail(hb, pk["box"][i][0], pk["box"][i][1], y, float(self.stride[i]), st["offs"][i], self.reg_max, raw=keep)
+            cls = ops.detect_cls_fused(f, *self._cls_weights(i, f.device), pk["cls"][i], y=y, nc=self.nc, a_off=st["offs"][i], raw=keep)
+            st["raw"][i] = (box, cls[..., : self.nc]) if keep else None
+            return
         box = ops.conv2d(hb, pk["box"][i][0], pk["box"][i][1], 1, 1, False, out_dtype=torch.float32)
-        if self._cls_fusable(i, f):
+        if cls_fused:
             # the class branch of the level as one kernel: its four [B, H, W, 128] intermediates stay in LDS (csrc/detcls.hip)
-            s0, s1 = self.cv3[i][0], self.cv3[i][1]
-            q = [m._packed(f.device) for m in (s0[0], s0[1], s1[0], s1[1])]
-            cls = ops.detect_cls_fused(f, (q[0]["w"], q[0]["b"]), (q[1]["w"], q[1]["b"]), (q[2]["w"], q[2]["b"]), (q[3]["w"], q[3]["b"]),
-                                       pk["cls"][i])[..., : self.nc]
+            cls = ops.detect_cls_fused(f, *self._cls_weights(i, f.device), pk["cls"][i])[..., : self.nc]
         else:
             hc = self._branch(self.cv3[i], f)
             cls = ops.conv2d(hc, pk["cls"][i][0], pk["cls"][i][1], 1, 1, False, out_dtype=torch.float32)[..., : self.nc]
-        ops.detect_decode(box, cls, st["y"], float(self.stride[i]), st["offs"][i], self.reg_max, best=st["y"].best)
+        if not raw_only:
+            ops.detect_decode(box, cls, st["y"], float(self.stride[i]), st["offs"][i], self.reg_max, best=st["y"].best)
         st["raw"][i] = (box, cls)
+
+    def raw_logits(self, feats):
+        """Per-level (box logits [B,H,W,4*reg_max], class logits [B,H,W,nc]) fp32 of the head's NHWC input maps: what `preds["raw"]`
+        holds.  With the fused decode they are not materialised by the forward pass; this recomputes them (same kernels, no decode)."""
+        st = {"raw": [None] * len(feats), "hw": [tuple(f.shape[1:3]) for f in feats]}
+        for i, f in enumerate(feats):
+            self._level(st, i, f, raw_only=True)
+        return st["raw"]
 
     def start_level(self, st, i, f):
         """Fork: level i on a side stream, ordered after everything enqueued so far on the current stream."""
@@ -673,7 +699,7 @@ class Detect(YmkModule):
         main = torch.cuda.current_stream()
         for side, i in st["side"]:
             main.wait_stream(side)
-            for tns in st["raw"][i]:       # tensors created on a side stream are consumed on the main one
+            for tns in st["raw"][i] or ():  # tensors created on a side stream are consumed on the main one
                 tns.record_stream(main)
             for tns in (y, y.best[0], y.best[1]):
                 tns.record_stream(side)
@@ -697,6 +723,8 @@ class Detect(YmkModule):
         y, raw = self._run(feats)
         if self.export:
             return y
+        if any(r is None for r in raw):
+            raw = self.raw_logits(feats)
         B = y.shape[0]
         boxes = torch.cat([b.reshape(B, -1, 4 * self.reg_max) for b, _ in raw], 1).permute(0, 2, 1)
         scores = torch.cat([c.reshape(B, -1, self.nc) for _, c in raw], 1).permute(0, 2, 1)

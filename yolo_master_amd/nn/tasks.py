@@ -320,7 +320,7 @@ class DetectionModel(nn.Module):
             if taps is not None:
                 taps[m.i] = cur.materialise() if isinstance(cur, VirtualCat) else cur
         det = self.model[-1]
-        preds = DetectPreds(raw, det_in, det.reg_max, det.nc)
+        preds = DetectPreds(raw, det_in, det.reg_max, det.nc, raw_fn=lambda: det.raw_logits(det_in))
         if isinstance(det, Segment):   # mask coefficients fp32 [B, nm, A] and prototypes NHWC [B, 2H0, 2W0, nm]
             preds["mask_coefficient"], preds["proto"] = det.last_mc, det.last_proto
         return cur, preds
@@ -337,12 +337,18 @@ class DetectPreds(dict):
     """The dict Detect returns beside y in eval mode (nn/modules/head.py:157-171): "boxes" [B, 4*reg_max, A] and "scores"
     [B, nc, A] raw logits, "feats" = the head's input maps (NCHW-logical).  Nothing on the inference path reads them
     (predict()/val() consume y), so the three reference keys are built on first access from the per-level NHWC logits
-    ("raw", what the decode kernel consumed) instead of being concatenated every step: layout changes only, no arithmetic."""
+    ("raw", what the decode consumed) instead of being concatenated every step: layout changes only, no arithmetic.  With the fused
+    decode (Detect.fuse_decode, keep_raw False) "raw" itself is lazy: Detect.raw_logits recomputes it from "feats"."""
 
-    def __init__(self, raw, feats, reg_max, nc):
-        super().__init__(raw=raw)
+    def __init__(self, raw, feats, reg_max, nc, raw_fn=None):
+        super().__init__()
         self._lazy = {"boxes": lambda: self._cat(0, 4 * reg_max), "scores": lambda: self._cat(1, nc),
                       "feats": lambda: [f.permute(0, 3, 1, 2) for f in feats]}
+        if raw_fn is not None and any(r is None for r in raw):
+            # fused decode (Detect._level): the logits stayed on chip; recomputed from the head's input maps on first access
+            self._lazy["raw"] = raw_fn
+        else:
+            self["raw"] = raw
 
     def _cat(self, which, width):
         lv = [r[which] for r in self["raw"]]

@@ -308,20 +308,54 @@ def detect_cls_fused_supported(dtype, cin: int, c3: int, nc: int) -> bool:
         not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 16384)
 
 
-def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None):
+def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None, y=None, nc=0, a_off=0, raw=True):
     """One pyramid level's Detect class branch as one kernel (include/ymk.h ymk_detect_cls_fused).  d1 / d2 = (packed depthwise weights
-    [9][C], fp32 bias), p1 / p2 = (packed 1x1 weights, fp32 bias), w3 = (packed [ncpad][Kpad], fp32 bias); returns fp32 [B, H, W, ncpad]."""
+    [9][C], fp32 bias), p1 / p2 = (packed 1x1 weights, fp32 bias), w3 = (packed [ncpad][Kpad], fp32 bias); returns fp32 [B, H, W, ncpad].
+    y: the Detect output fp32 [B, 4+nc, A] (with `y.best`, ops.detect_decode) -> the kernel also writes sigmoid(logits) into its class
+    rows at anchors a_off.. and the per-anchor best class: the class half of detect_decode.  raw=False then skips the logits (returns None)."""
     B, H, W, Cin, ldx = _nhwc(x)
     ncpad = w3[0].shape[0]
-    if out is None:
+    if y is None:
+        raw = True
+    if raw and out is None:
         out = torch.empty((B, H, W, ncpad), dtype=torch.float32, device=x.device)
-    ldy = _nhwc(out)[4]
+    ldy = _nhwc(out)[4] if raw else 0
+    bc = bi = None
+    A = 0
+    if y is not None:
+        A = y.shape[2]
+        assert y.dtype == torch.float32 and y.is_contiguous() and y.shape[0] == B and y.shape[1] == 4 + nc and a_off + H * W <= A
+        best = getattr(y, "best", None)
+        if best is not None:
+            bc, bi = best[0], best[1]
+            assert bc.dtype == torch.float32 and bi.dtype == torch.int32 and bc.is_contiguous() and bi.is_contiguous() and \
+                tuple(bc.shape) == tuple(bi.shape) == (B, A)
     e0 = TIMER.begin()
     check(lib.ymk_detect_cls_fused(_p(x), ldx, B, H, W, Cin, _p(d1[0]), _p(d1[1]), _p(p1[0]), p1[0].shape[1], _p(p1[1]), _p(d2[0]), _p(d2[1]),
-                                   _p(p2[0]), p2[0].shape[1], _p(p2[1]), _p(w3[0]), w3[0].shape[1], _p(w3[1]), ncpad, _p(out), ldy, _stream()),
+                                   _p(p2[0]), p2[0].shape[1], _p(p2[1]), _p(w3[0]), w3[0].shape[1], _p(w3[1]), ncpad, _p(out) if raw else None, ldy,
+                                   _p(y), int(nc), int(a_off), A, _p(bc), _p(bi), _stream()),
           "detect_cls_fused")
-    TIMER.end(e0, "detect_cls_fused", B * H * W * (Cin * 2 + ncpad * 4), 2 * B * H * W * (9 * Cin + Cin * 128 + 9 * 128 + 128 * 128 + 128 * ncpad),
-              f"{Cin}->128->{ncpad} @{H}x{W}")
+    TIMER.end(e0, "detect_cls_fused", B * H * W * (Cin * 2 + (ncpad * 4 if raw else 0) + ((nc * 4 + 8) if y is not None else 0)),
+              2 * B * H * W * (9 * Cin + Cin * 128 + 9 * 128 + 128 * 128 + 128 * ncpad), f"{Cin}->128->{ncpad} @{H}x{W}" + (" +decode" if y is not None else ""))
+    return out if raw else None
+
+
+def detect_box_tail_supported(dtype, cin: int, reg_max: int) -> bool:
+    """YMK_DISABLE bit 4194304 switches the fused decode of the Detect head off (-> 1x1 convolution, fp32 logits, detect_decode)."""
+    return dtype in DT and bool(lib.ymk_detect_box_tail_supported(DT[dtype], cin, reg_max)) and \
+        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 4194304)
+
+
+def detect_box_tail(x, w_packed, bias, y, stride: float, a_off: int, reg_max: int, raw: bool = False):
+    """The last 1x1 of a level's Detect box branch + DFL + dist2bbox -> rows 0..3 of y (include/ymk.h ymk_detect_box_tail).
+    x: [B, H, W, 64] 16-bit; y fp32 [B, 4+nc, A].  raw=True also returns the fp32 box logits [B, H, W, 64] (else None)."""
+    B, H, W, Cin, ldx = _nhwc(x)
+    assert y.dtype == torch.float32 and y.is_contiguous() and y.shape[0] == B
+    out = torch.empty((B, H, W, 4 * reg_max), dtype=torch.float32, device=x.device) if raw else None
+    e0 = TIMER.begin()
+    check(lib.ymk_detect_box_tail(DT[x.dtype], _p(x), ldx, B, H, W, _p(w_packed), w_packed.shape[1], _p(bias), reg_max, y.shape[1] - 4,
+                                  float(stride), a_off, y.shape[2], _p(y), _p(out), _stream()), "detect_box_tail")
+    TIMER.end(e0, "detect_box_tail", B * H * W * (Cin * 2 + 16 + (256 if raw else 0)), 2 * B * H * W * Cin * 64, f"{Cin}->64 +dfl @{H}x{W}")
     return out
 
 

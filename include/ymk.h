@@ -159,7 +159,7 @@ int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32_t H, int32
  * The box branch's tail: Conv2d(64, 4 * reg_max, 1) + bias -> DFL -> dist2bbox -> rows 0..3 of y (head.py:111-112,173-194;
  * csrc/elementwise.hip), reg_max = 16, 16-bit x [B][Hl][Wl][ldx] with 64 channels, w packed [64][kpad]; raw: NULL or fp32
  * [B][Hl][Wl][64] box logits.  With both, ymk_detect_decode and the 0.6 KB per anchor of fp32 logits it re-read are gone. */
-int ymk_detect_box_tail_supported(int32_t dtype, int32_t cin, int32_t reg_max);
+int ymk_detect_box_tail_supported(int32_t dtype, int32_t cin, int32_t reg_max, int32_t nc);   /* the pair: box tail + class kernel with y_out (nc <= 96) */
 int ymk_detect_box_tail(int32_t dtype, const void* x, int32_t ldx, int32_t B, int32_t Hl, int32_t Wl, const void* w, int32_t kpad,
                         const float* bias, int32_t reg_max, int32_t nc, float stride, int32_t a_off, int32_t A_total, float* y,
                         float* raw, void* stream);

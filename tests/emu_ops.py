@@ -168,8 +168,8 @@ def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None, y=None, nc=0, a_off=0, raw
     return lg if (raw or y is None) else None
 
 
-def detect_box_tail_supported(dtype, cin, reg_max):
-    return dtype == torch.bfloat16 and cin == 64 and reg_max == 16
+def detect_box_tail_supported(dtype, cin, reg_max, nc):
+    return dtype == torch.bfloat16 and cin == 64 and reg_max == 16 and 1 <= nc <= 96
 
 
 def detect_box_tail(x, w_packed, bias, y, stride, a_off, reg_max, raw=False):

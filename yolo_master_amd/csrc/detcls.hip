@@ -28,6 +28,8 @@
 #define DC_A_BYTES (DC_NX * DC_PITCH)        // region A: x chunk, then pw1's map, then pw2's map
 #define DC_B_BYTES (DC_NMID * DC_PITCH)      // region B: dw1's map, then dw2's map
 #define DC_LDS_BYTES (DC_A_BYTES + DC_B_BYTES)
+#define DC_BEST_PITCH (DC_NP + 4)            // floats per class of the decode's score tile in region B: 16 classes x 16 bytes cover the 64 banks
+#define DC_BEST_MAXNC (DC_B_BYTES / (DC_BEST_PITCH * 4))   // 98 classes fit
 
 typedef __bf16 dc_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef YMK_HOST_EMU
@@ -43,6 +45,17 @@ __device__ __forceinline__ u32x2 dc_pack_silu(const f32x4& v) {
     o.x = pack_h16x2(silu_f(v.x), silu_f(v.y));
     o.y = pack_h16x2(silu_f(v.z), silu_f(v.w));
     return o;
+}
+
+// sigmoid of the fused decode.  Default: v_exp_f32 + v_rcp_f32 (about 2 ulp: 2e-7 on a score, against the 1e-4 the scores are held to).
+// The exact form (libm expf + IEEE division = detect_decode_kernel's bits) costs this 1.25-wave-per-SIMD epilogue 6 us per tile of 128
+// anchors (measured: 216 -> 297 us at P3, more than the decode kernel it replaces); -DDC_EXACT_SIGMOID keeps it for A/B runs and tests.
+__device__ __forceinline__ float dc_sigmoid(float v) {
+#ifdef DC_EXACT_SIGMOID
+    return 1.0f / (1.0f + expf(-v));
+#else
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+#endif
 }
 
 struct DetClsArgs {
@@ -87,7 +100,8 @@ __device__ __forceinline__ void dc_dw3(const char* in, int icol, char* out, int 
     }
 }
 
-template <int CIN>
+// DEC: the fused-decode variant (a.yo set): its own instantiation, so that neither variant carries the other's epilogue registers
+template <int CIN, bool DEC>
 __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
     constexpr int NCH = CIN / 128;            // 128-channel chunks of the input
     constexpr int NF1 = (DC_NMID + 15) / 16;   // 12 pixel fragments of the first pair's maps
@@ -112,7 +126,8 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
     const f32x4 bv1 = *reinterpret_cast<const f32x4*>(a.bp1 + wave * 16 + fc * 4);
     const f32x4 bv2 = *reinterpret_cast<const f32x4*>(a.bp2 + wave * 16 + fc * 4);
     f32x4 bv3 = {0.f, 0.f, 0.f, 0.f};
-    if (wave * 16 + fc * 4 < a.ncpad) bv3 = *reinterpret_cast<const f32x4*>(a.b3 + wave * 16 + fc * 4);
+    if (!DEC && wave * 16 + fc * 4 < a.ncpad) bv3 = *reinterpret_cast<const f32x4*>(a.b3 + wave * 16 + fc * 4);
+    const float bvt = (DEC && wave * 16 + fr < a.ncpad) ? a.b3[wave * 16 + fr] : 0.f;   // transposed product: one class per lane
 
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int txi = tile % a.tiles_x, r0 = tile / a.tiles_x;
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
         }
         __syncthreads();
         // ---- out: 1x1 128 -> nc, fp32 logits -------------------------------------------------------------------------------------------------------
-        if (wave * 16 < a.ncpad) {
+        if (!DEC && wave * 16 < a.ncpad) {
             f32x4 acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = bv3;
@@ -220,59 +235,71 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dc_mma(acc[j], af3[s], bfr[j]);
             }
-            if (a.y) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int oy = oy0 + j, ox = ox0 + fr;   // fragment j = tile row j (16 pixels)
-                    if (oy < a.H && ox < a.W && wave * 16 + fc * 4 < a.ncpad)
-                        *reinterpret_cast<f32x4*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = acc[j];
-                }
+            for (int j = 0; j < 8; ++j) {
+                const int oy = oy0 + j, ox = ox0 + fr;   // fragment j = tile row j (16 pixels)
+                if (oy < a.H && ox < a.W && wave * 16 + fc * 4 < a.ncpad)
+                    *reinterpret_cast<f32x4*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + wave * 16 + fc * 4) = acc[j];
             }
-            if (a.yo) {
-                // the decode's class half here (head.py:157-171 `cls.sigmoid()`, detect_decode_kernel's expression): 16 lanes = 16 consecutive
-                // anchors of one class row (64-byte runs).  Region B (dw2's map, dead since pw2) collects this wave's best class per pixel.
-                float* sbest = reinterpret_cast<float*>(sB);
-                const int c0 = wave * 16 + fc * 4;
+        } else if (DEC && wave * 16 < a.ncpad) {
+            // Fused decode: the product is taken TRANSPOSED (pixels as the A operand, this wave's 16 classes as B): a lane then holds FOUR
+            // CONSECUTIVE ANCHORS of one class, i.e. 16 contiguous bytes of a class row of y (with the classes along the registers every
+            // score was a 4-byte store: 32 store instructions per lane and tile, +50 us at P3).  Same operands, same k order per output.
+            // Region B (dw2's map, dead since pw2) collects the tile's scores [class][pixel] for the best-class pass below.
+            float* sbest = reinterpret_cast<float*>(sB);
+            const int cls = wave * 16 + fr;
+            const bool vec = ((a.W | a.A | a.a_off) & 3) == 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int oy = oy0 + j, ox = ox0 + fr;
-                    const bool in = oy < a.H && ox < a.W;
-                    float* yp = a.yo + ((size_t)b * (4 + a.nc) + 4 + c0) * a.A + a.a_off + oy * a.W + ox;
-                    float bv = -1.f;
-                    int bc = 0x7fffffff;
+            for (int hh = 0; hh < 2; ++hh) {   // (two halves: eight accumulators + the decode's temporaries beside three resident weight sets spill)
+                f32x4 acc[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = 1.0f / (1.0f + expf(-acc[j][r]));
-                        if (c0 + r < a.nc) {
-                            if (in) yp[(size_t)r * a.A] = p;
-                            if (p > bv) { bv = p; bc = c0 + r; }
-                        }
+                for (int j = 0; j < 4; ++j) acc[j] = f32x4{bvt, bvt, bvt, bvt};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    u32x4 bfr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(sA + ((hh * 4 + j) * 16 + fr) * DC_PITCH + fc * 16 + s * 64);
+                    DC_SCHED_BARRIER();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dc_mma(acc[j], bfr[j], af3[s]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jj = hh * 4 + j;
+                    const int oy = oy0 + jj, ox = ox0 + fc * 4;       // this lane: anchors ox .. ox + 3 of tile row jj, class cls
+                    if (a.y && cls < a.ncpad && oy < a.H) {           // (logits wanted too: strided 4-byte stores, the rare path)
+                        float* rp = a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + cls;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ox + r < a.W) rp[(size_t)r * a.ldy] = acc[j][r];
                     }
-                    if (a.bconf) {
+                    const f32x4 p = {dc_sigmoid(acc[j].x), dc_sigmoid(acc[j].y), dc_sigmoid(acc[j].z), dc_sigmoid(acc[j].w)};
+                    if (cls < a.nc) {
+                        *reinterpret_cast<f32x4*>(sbest + cls * DC_BEST_PITCH + jj * 16 + fc * 4) = p;
+                        if (oy < a.H && ox < a.W) {
+                            float* yp = a.yo + ((size_t)b * (4 + a.nc) + 4 + cls) * a.A + a.a_off + oy * a.W + ox;
+                            if (vec) {
+                                *reinterpret_cast<f32x4*>(yp) = p;    // W % 4 == 0: the four anchors are inside the map together
+                            } else {
 #pragma unroll
-                        for (int o = 16; o <= 32; o <<= 1) {   // the four lanes that share pixel fr: larger score, then smaller class
-                            const float ov = __shfl_xor(bv, o);
-                            const int oc = __shfl_xor(bc, o);
-                            if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
-                        }
-                        if (fc == 0) {
-                            sbest[(wave * DC_NP + j * 16 + fr) * 2] = bv;
-                            sbest[(wave * DC_NP + j * 16 + fr) * 2 + 1] = __int_as_float(bc);
+                                for (int r = 0; r < 4; ++r)
+                                    if (ox + r < a.W) yp[r] = p[r];
+                            }
                         }
                     }
                 }
             }
         }
         __syncthreads();   // region A is restaged by the next tile
-        if (a.yo && a.bconf && t < DC_NP) {   // (region B is next written by dw1, behind the staging barrier of the next tile)
+        if (DEC && a.bconf && t < DC_NP) {   // (region B is next written by dw1, behind the staging barrier of the next tile)
             const float* sbest = reinterpret_cast<const float*>(sB);
             const int oy = oy0 + (t >> 4), ox = ox0 + (t & 15);
             if (oy < a.H && ox < a.W) {
-                float bv = sbest[t * 2];
-                int bc = __float_as_int(sbest[t * 2 + 1]);
-                for (int wv = 1; wv * 16 < a.nc; ++wv) {   // class blocks in ascending order: the first maximum wins (utils/nms.py:124-129)
-                    const float ov = sbest[(wv * DC_NP + t) * 2];
-                    if (ov > bv) { bv = ov; bc = __float_as_int(sbest[(wv * DC_NP + t) * 2 + 1]); }
+                float bv = sbest[t];
+                int bc = 0;
+                for (int cc = 1; cc < a.nc; ++cc) {   // ascending classes, strict >: the first maximum wins (utils/nms.py:124-129)
+                    const float ov = sbest[cc * DC_BEST_PITCH + t];
+                    if (ov > bv) { bv = ov; bc = cc; }
                 }
                 const size_t o = (size_t)b * a.A + a.a_off + oy * a.W + ox;
                 a.bconf[o] = bv;
@@ -297,7 +324,7 @@ extern "C" int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32
         return YMK_E_BADARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return YMK_E_BADARG;
     if ((best_conf == nullptr) != (best_cls == nullptr) || (best_conf && !y_out)) return YMK_E_BADARG;
-    if (y_out && (nc < 1 || nc > ncpad || ncpad - nc >= 4 || a_off < 0 || (int64_t)a_off + (int64_t)H * W > A_total)) return YMK_E_BADARG;
+    if (y_out && (nc < 1 || nc > ncpad || ncpad - nc >= 4 || nc > DC_BEST_MAXNC || a_off < 0 || (int64_t)a_off + (int64_t)H * W > A_total)) return YMK_E_BADARG;
     if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
     DetClsArgs a;
     a.x = (const h16_t*)x; a.dw1 = (const h16_t*)dw1; a.pw1 = (const h16_t*)pw1; a.dw2 = (const h16_t*)dw2; a.pw2 = (const h16_t*)pw2;
@@ -314,11 +341,16 @@ extern "C" int ymk_detect_cls_fused(const void* x, int32_t ldx, int32_t B, int32
 #endif
     static YmkOncePerDevice attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_cls_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_LDS_BYTES);
         attr_once.done();
     }
-    if (cin == 128) hipLaunchKernelGGL(detect_cls_kernel<128>, dim3(grid), dim3(DC_NT), DC_LDS_BYTES, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(detect_cls_kernel<256>, dim3(grid), dim3(DC_NT), DC_LDS_BYTES, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 128 && !y_out) hipLaunchKernelGGL((detect_cls_kernel<128, false>), dim3(grid), dim3(DC_NT), DC_LDS_BYTES, st, a);
+    else if (cin == 128) hipLaunchKernelGGL((detect_cls_kernel<128, true>), dim3(grid), dim3(DC_NT), DC_LDS_BYTES, st, a);
+    else if (!y_out) hipLaunchKernelGGL((detect_cls_kernel<256, false>), dim3(grid), dim3(DC_NT), DC_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((detect_cls_kernel<256, true>), dim3(grid), dim3(DC_NT), DC_LDS_BYTES, st, a);
     return ymk_launch_status();
 }

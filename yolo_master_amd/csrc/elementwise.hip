@@ -271,63 +271,81 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
 // round trip through HBM between the 1x1 convolution and detect_decode_kernel.  Arithmetic: the 1x1 is the two MFMA k-steps + bias of
 // the tiled convolution cores, the DFL / box code is detect_decode_kernel's line for line, so y is bit-identical to the unfused path.
 // Workgroup = 64 anchors of one image (4 waves x one 16-anchor MFMA fragment x the four 16-bin sides).
+#define DBT_GROUPS 4   // 64-anchor groups per workgroup
 __global__ __launch_bounds__(256) void detect_box_tail_kernel(const h16_t* __restrict__ x, int ldx, const h16_t* __restrict__ w, int kpad,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              float* __restrict__ raw, int Hl, int Wl, int nc, float stride, int a_off,
                                                              int A) {
     __shared__ float sbox[256 * 17];
     __shared__ float sdist[256];
-    const int HW = Hl * Wl, b = blockIdx.y, a0 = blockIdx.x * 64;
+    const int HW = Hl * Wl, b = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fc = lane >> 4;
-    const int na = min(64, HW - a0);
-    {
-        const int al = wave * 16 + fr;                                   // this lane's anchor of the tile (MFMA column)
-        const h16_t* xp = x + ((size_t)b * HW + min(a0 + al, HW - 1)) * ldx;
-        const u32x4 b0 = *reinterpret_cast<const u32x4*>(xp + fc * 8), b1 = *reinterpret_cast<const u32x4*>(xp + 32 + fc * 8);
+    const int al = wave * 16 + fr;                                       // this lane's anchor of a 64-anchor group (MFMA column)
+    // the 64 x 64 weights stay in registers (MFMA A fragments) for the DBT_GROUPS groups of 64 anchors this workgroup walks
+    u32x4 w0[4], w1[4];
+    f32x4 bv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                                    // side i = output channels 16 i .. 16 i + 15
-            const h16_t* wr = w + (size_t)(i * 16 + fr) * kpad;
-            const u32x4 w0 = *reinterpret_cast<const u32x4*>(wr + fc * 8), w1 = *reinterpret_cast<const u32x4*>(wr + 32 + fc * 8);
+    for (int i = 0; i < 4; ++i) {                                        // side i = output channels 16 i .. 16 i + 15
+        const h16_t* wr = w + (size_t)(i * 16 + fr) * kpad;
+        w0[i] = *reinterpret_cast<const u32x4*>(wr + fc * 8);
+        w1[i] = *reinterpret_cast<const u32x4*>(wr + 32 + fc * 8);
+        bv[i] = *reinterpret_cast<const f32x4*>(bias + i * 16 + fc * 4);
+    }
+    auto xload = [&](int a0, u32x4& b0, u32x4& b1) {
+        const h16_t* xp = x + ((size_t)b * HW + min(a0 + al, HW - 1)) * ldx;
+        b0 = *reinterpret_cast<const u32x4*>(xp + fc * 8);
+        b1 = *reinterpret_cast<const u32x4*>(xp + 32 + fc * 8);
+    };
+    u32x4 b0, b1;
+    int a0 = blockIdx.x * (64 * DBT_GROUPS);
+    xload(a0, b0, b1);
+    for (int g = 0; g < DBT_GROUPS && a0 < HW; ++g, a0 += 64) {
+        const int na = min(64, HW - a0);
+        u32x4 n0 = b0, n1 = b1;
+        if (g + 1 < DBT_GROUPS && a0 + 64 < HW) xload(a0 + 64, n0, n1);   // the next group's operands travel under this group's decode
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = mfma16x16x32_h16(w0, b0, acc);
-            acc = mfma16x16x32_h16(w1, b1, acc);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + i * 16 + fc * 4);
-            const float v0 = acc.x + bv.x, v1 = acc.y + bv.y, v2 = acc.z + bv.z, v3 = acc.w + bv.w;   // bins 4 fc .. 4 fc + 3 of side i
+            acc = mfma16x16x32_h16(w0[i], b0, acc);
+            acc = mfma16x16x32_h16(w1[i], b1, acc);
+            const float v0 = acc.x + bv[i].x, v1 = acc.y + bv[i].y, v2 = acc.z + bv[i].z, v3 = acc.w + bv[i].w;   // bins 4 fc .. 4 fc + 3 of side i
             float* d = sbox + (al * 4 + i) * 17 + fc * 4;
             d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
             if (raw && al < na) store4(raw + ((size_t)b * HW + a0 + al) * 64 + i * 16 + fc * 4, v0, v1, v2, v3);
         }
-    }
-    __syncthreads();
-    if ((t >> 2) < na) {   // thread (anchor t / 4, side t % 4): detect_decode_kernel's DFL
-        float e[16];
-        float mx = -INFINITY;
+        __syncthreads();
+        if ((t >> 2) < na) {   // thread (anchor t / 4, side t % 4): detect_decode_kernel's DFL
+            float e[16];
+            float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { e[i] = sbox[t * 17 + i]; mx = fmaxf(mx, e[i]); }
-        float den = 0.f;
+            for (int i = 0; i < 16; ++i) { e[i] = sbox[t * 17 + i]; mx = fmaxf(mx, e[i]); }
+            float den = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { e[i] = expf(e[i] - mx); den += e[i]; }
-        float d = 0.f;
+            for (int i = 0; i < 16; ++i) { e[i] = expf(e[i] - mx); den += e[i]; }
+            float d = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) d += (float)i * (e[i] / den);
-        sdist[t] = d;
-    }
-    __syncthreads();
-    if (t < na) {
-        float* yb = y + (size_t)b * (4 + nc) * A + a_off + a0;
-        const int a = a0 + t;
-        const float ax = (float)(a % Wl) + 0.5f, ay = (float)(a / Wl) + 0.5f;
-        const float l = sdist[t * 4 + 0], tp = sdist[t * 4 + 1], r = sdist[t * 4 + 2], bt = sdist[t * 4 + 3];
-        const float x1 = ax - l, y1 = ay - tp, x2 = ax + r, y2 = ay + bt;
-        yb[0 * (size_t)A + t] = ((x1 + x2) / 2.0f) * stride;
-        yb[1 * (size_t)A + t] = ((y1 + y2) / 2.0f) * stride;
-        yb[2 * (size_t)A + t] = (x2 - x1) * stride;
-        yb[3 * (size_t)A + t] = (y2 - y1) * stride;
+            for (int i = 0; i < 16; ++i) d += (float)i * (e[i] / den);
+            sdist[t] = d;
+        }
+        __syncthreads();   // (also: every thread is past its reads of sbox before the next group overwrites it)
+        if (t < na) {
+            float* yb = y + (size_t)b * (4 + nc) * A + a_off + a0;
+            const int a = a0 + t;
+            const float ax = (float)(a % Wl) + 0.5f, ay = (float)(a / Wl) + 0.5f;
+            const float l = sdist[t * 4 + 0], tp = sdist[t * 4 + 1], r = sdist[t * 4 + 2], bt = sdist[t * 4 + 3];
+            const float x1 = ax - l, y1 = ay - tp, x2 = ax + r, y2 = ay + bt;
+            yb[0 * (size_t)A + t] = ((x1 + x2) / 2.0f) * stride;
+            yb[1 * (size_t)A + t] = ((y1 + y2) / 2.0f) * stride;
+            yb[2 * (size_t)A + t] = (x2 - x1) * stride;
+            yb[3 * (size_t)A + t] = (y2 - y1) * stride;
+        }
+        b0 = n0; b1 = n1;
+        // (sdist is rewritten behind the next group's first barrier, which every thread reaches after these reads)
     }
 }
 
-extern "C" int ymk_detect_box_tail_supported(int32_t dtype, int32_t cin, int32_t reg_max) {
-    return dtype == YMK_BF16 && cin == 64 && reg_max == 16;
+extern "C" int ymk_detect_box_tail_supported(int32_t dtype, int32_t cin, int32_t reg_max, int32_t nc) {
+    return dtype == YMK_BF16 && cin == 64 && reg_max == 16 && nc >= 1 && nc <= 96;
 }
 
 // x [B][Hl][Wl][ldx] (64 channels, 16-bit), w packed [64][kpad] as for ymk_conv2d, bias fp32 [64]; y fp32 [B][4 + nc][A_total], rows 0..3 of
@@ -336,12 +354,12 @@ extern "C" int ymk_detect_box_tail(int32_t dtype, const void* x, int32_t ldx, in
                                    const float* bias, int32_t reg_max, int32_t nc, float stride, int32_t a_off, int32_t A_total, float* y,
                                    float* raw, void* stream) {
     if (!x || !w || !bias || !y || nc < 1) return YMK_E_BADARG;
-    if (!ymk_detect_box_tail_supported(dtype, 64, reg_max) || ldx < 64 || ldx % 8 || kpad < 64 || kpad % 8) return YMK_E_BADARG;
+    if (!ymk_detect_box_tail_supported(dtype, 64, reg_max, 1) || ldx < 64 || ldx % 8 || kpad < 64 || kpad % 8) return YMK_E_BADARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (raw && ((uintptr_t)raw & 15))) return YMK_E_BADARG;
     const int HW = Hl * Wl;
     if (B <= 0 || HW <= 0) return YMK_OK;
     if (B > 65535 || a_off < 0 || a_off + HW > A_total) return YMK_E_BADARG;
-    hipLaunchKernelGGL(detect_box_tail_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, static_cast<const h16_t*>(x), ldx,
+    hipLaunchKernelGGL(detect_box_tail_kernel, dim3((HW + 64 * DBT_GROUPS - 1) / (64 * DBT_GROUPS), B), dim3(256), 0, (hipStream_t)stream, static_cast<const h16_t*>(x), ldx,
                        static_cast<const h16_t*>(w), kpad, bias, y, raw, Hl, Wl, nc, stride, a_off, A_total);
     return ymk_launch_status();
 }

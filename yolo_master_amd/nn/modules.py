@@ -650,7 +650,7 @@ class Detect(YmkModule):
             raise ValueError(f"Detect level {i}: map {tuple(f.shape[1:3])}, expected {st['hw'][i]}")
         hb = self._branch(self.cv2[i], f)
         cls_fused = self._cls_fusable(i, f)
-        if not raw_only and self.fuse_decode and cls_fused and ops.detect_box_tail_supported(hb.dtype, hb.shape[-1], self.reg_max):
+        if not raw_only and self.fuse_decode and cls_fused and ops.detect_box_tail_supported(hb.dtype, hb.shape[-1], self.reg_max, self.nc):
             y, keep = st["y"], self.keep_raw
             box = ops.detect_box_tail(hb, pk["box"][i][0], pk["box"][i][1], y, float(self.stride[i]), st["offs"][i], self.reg_max, raw=keep)
             cls = ops.detect_cls_fused(f, *self._cls_weights(i, f.device), pk["cls"][i], y=y, nc=self.nc, a_off=st["offs"][i], raw=keep)

@@ -340,9 +340,9 @@ def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None, y=None, nc=0, a_off=0, raw
     return out if raw else None
 
 
-def detect_box_tail_supported(dtype, cin: int, reg_max: int) -> bool:
+def detect_box_tail_supported(dtype, cin: int, reg_max: int, nc: int) -> bool:
     """YMK_DISABLE bit 4194304 switches the fused decode of the Detect head off (-> 1x1 convolution, fp32 logits, detect_decode)."""
-    return dtype in DT and bool(lib.ymk_detect_box_tail_supported(DT[dtype], cin, reg_max)) and \
+    return dtype in DT and bool(lib.ymk_detect_box_tail_supported(DT[dtype], cin, reg_max, nc)) and \
         not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 4194304)
 
 

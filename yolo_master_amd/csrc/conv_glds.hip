@@ -39,6 +39,7 @@ struct GldsArgs {
     // writes image j*B + b of a slot-major output.  Tiles never straddle images.  eidx == nullptr: one filter bank.
     const int32_t* eidx;
     int K;
+    int tap_outer;   // k-step order of a 3x3: 1 = filter tap outermost (rounds 2-3), 0 = channel chunk outermost (see `issue`)
 };
 
 // EXT: the body that also carries the GELU / sigmoid epilogues (conv_glds_ext_kernel).  128 inlined erf / exp expansions compiled into
@@ -141,9 +142,14 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
     const glds_rsrc rs_x2 = GLDS_MAKE_RSRC(a.x2 ? a.x2 : a.x, a.x2 ? (((int64_t)a.B * a.H * a.W - 1) * a.ldx2 + (a.Cin - a.C1)) * 2 : 0);
     int it_tap_bit = 0, it_ky = 0, it_kx = 0, it_c = 0, it_k = 0;   // cursor of the NEXT k-step to issue (uniform)
     const int k1 = a.x2 ? a.C1 / BK : 0;   // k-steps served by the first source of a virtual concatenation
+    // Order of the k-steps of a 3x3 with several 64-channel chunks: chunk OUTERMOST, the nine taps inside (a.tap_outer == 0, the default).
+    // With the taps outermost every tap walked ALL channels of the tile's pixels before the next tap came back to them: at 256 input
+    // channels and ~400 resident 256-pixel tiles that is the whole input map (52 MB at 40^2, 6.5 MB per XCD against 4 MB of L2) between two
+    // uses of a line, and the fabric counters showed it — 8.6x the input bytes fetched for 256 -> 64 at 40^2, 1.6-2.2x for the stride-2
+    // shapes (tools/micro/conv_shape_pmc.py, profiles/r04_conv_shape_fetch.txt).  Chunk-outermost the nine taps re-read a quarter of that.
     auto issue = [&](int stage) {
         const unsigned tapoffB = (unsigned)(((it_ky * a.W + it_kx) * a.ldx + it_c * BK) * 2);
-        const unsigned woffB = (unsigned)(it_k * BK * 2);
+        const unsigned woffB = a.tap_outer ? (unsigned)(it_k * BK * 2) : (unsigned)((((it_ky * a.ks + it_kx) * cpt + it_c) * BK) * 2);
         const bool second = a.x2 && it_k >= k1;
         u32x4* dst0 = smem + stage * STAGE_U4 + wave * 64;   // wave-uniform; instruction j lands at + j * 512 slots, the lane at + lane * 16 B
 #pragma unroll
@@ -160,10 +166,18 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
             }
         }
         ++it_k;
-        if (++it_c == cpt) {
-            it_c = 0;
+        if (a.tap_outer) {
+            if (++it_c == cpt) {
+                it_c = 0;
+                ++it_kx; ++it_tap_bit;
+                if (it_kx == a.ks) { it_kx = 0; ++it_ky; it_tap_bit = it_ky * 3; }
+            }
+        } else {
             ++it_kx; ++it_tap_bit;
-            if (it_kx == a.ks) { it_kx = 0; ++it_ky; it_tap_bit = it_ky * 3; }
+            if (it_kx == a.ks) {
+                it_kx = 0; ++it_ky; it_tap_bit = it_ky * 3;
+                if (it_ky == a.ks) { it_ky = 0; it_tap_bit = 0; ++it_c; }
+            }
         }
     };
 
@@ -355,6 +369,10 @@ static int glds_big_min_tiles() {   // YMK_GLDS_BIG_MIN_TILES=<n>: the 256 x 256
     return v;
 }
 
+static int glds_tap_outer() {   // YMK_GLDS_TAP_OUTER=1: the rounds 2-3 k-step order (A/B runs)
+    static const int v = [] { const char* e = getenv("YMK_GLDS_TAP_OUTER"); return e ? atoi(e) : 0; }();
+    return v;
+}
 static int glds_small_below() {   // YMK_GLDS_SMALL_BELOW=<n>: 128-pixel tiles iff the 256-pixel launch has fewer than n workgroups (A/B runs); unset: the rule below
     static const int v = [] { const char* e = getenv("YMK_GLDS_SMALL_BELOW"); return e ? atoi(e) : GLDS_SMALL_BELOW_DEFAULT; }();
     return v;
@@ -425,7 +443,7 @@ extern "C" int ymk_conv2d_glds(const ymk_conv_desc* d, const void* x, const void
     a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.Kpad = d->Kpad; a.act = d->act;
     a.out_f32 = d->out_dtype == YMK_F32;
-    a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = nullptr; a.K = 0;
+    a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = nullptr; a.K = 0; a.tap_outer = glds_tap_outer();
     const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
     if (M <= 0) return YMK_OK;
     // 31-bit BYTE offsets of the staged operands (bit 31 of a lane's buffer offset marks a tap outside the image), 32-bit element offsets of the output
@@ -448,7 +466,7 @@ extern "C" int ymk_conv1x1_cat2_glds(const ymk_conv_desc* d, const void* x1, int
     a.x = static_cast<const h16_t*>(x1); a.w = static_cast<const h16_t*>(w); a.bias = bias; a.res = nullptr; a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = 1; a.stride = 1;
     a.ldx = ldx1; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = d->act; a.out_f32 = 0;
-    a.x2 = static_cast<const h16_t*>(x2); a.C1 = C1; a.ldx2 = ldx2; a.up1 = upsample1 ? 1 : 0; a.eidx = nullptr; a.K = 0;
+    a.x2 = static_cast<const h16_t*>(x2); a.C1 = C1; a.ldx2 = ldx2; a.up1 = upsample1 ? 1 : 0; a.eidx = nullptr; a.K = 0; a.tap_outer = 1;   // (1x1: one tap, it_k walks the concatenated channels)
     const int64_t M = (int64_t)a.B * a.H * a.W;
     if (M <= 0) return YMK_OK;
     if (M >= (1ll << 31) || (M + 2) * (ldx1 > ldx2 ? ldx1 : ldx2) >= (1ll << 30) || M * d->ldy >= (1ll << 31) || (int64_t)d->Cout * d->Kpad >= (1ll << 30))
@@ -471,7 +489,7 @@ extern "C" int ymk_expert_conv_glds(const ymk_conv_desc* d, const void* x, const
     a.x = static_cast<const h16_t*>(x); a.w = static_cast<const h16_t*>(w); a.bias = nullptr; a.res = nullptr; a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.ks = d->ksize; a.stride = 1;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = 0; a.Kpad = d->Kpad; a.act = YMK_ACT_NONE; a.out_f32 = 0;
-    a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = idx; a.K = K;
+    a.x2 = nullptr; a.C1 = 0; a.ldx2 = 0; a.up1 = 0; a.eidx = idx; a.K = K; a.tap_outer = glds_tap_outer();
     const int64_t HW = (int64_t)d->H * d->W;
     if (d->B <= 0 || HW <= 0) return YMK_OK;
     if (((int64_t)d->B * HW + 2 * d->W + 4) * d->ldx >= (1ll << 30) || (int64_t)K * d->B * HW >= (1ll << 31) || (int64_t)d->Cout * d->Kpad >= (1ll << 30))

@@ -88,8 +88,21 @@ int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, float* out, int
 /* Per-token softmax over n <= 8 fp32 logits scaled by inv_temp; 0 < top_k < n keeps the top_k largest (ties: lower index
  * first), renormalised with the sum clamped at 1e-6 (mot/router.py:243-295, moa/router.py:50-62).
  * w fp32 [npix][ldw]; active int32 [B][n] must be zero on entry (atomicOr 1 where a token selects expert e). */
-int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int32_t ldw, int32_t* active, int32_t B, int32_t HW,
-                      int32_t n, float inv_temp, int32_t top_k, void* stream);
+int ymk_token_softmax(const float* logits, int32_t ldl, const float* bias /*[B][n] or NULL*/, float* w, int32_t ldw, int32_t* active,
+                      int32_t B, int32_t HW, int32_t n, float inv_temp, int32_t top_k, void* stream);
+/* bias: added to every token's logits of its image before the temperature — the scene-aware residual of the MoT router
+ * (mot/router.py:224-240) and, with logits == NULL, the whole logit of the image-level router (use_spatial=False, :118-125).
+ *
+ * Scene statistics + projector of the MoT router (mot/router.py:166-192 compute_scene_stats: high-frequency, heterogeneity and
+ * multi-scale statistics of the routed map in fp32; :145-160 scene_projector = Linear(3, hidden) -> SiLU -> Linear(hidden, E)).
+ * x: the routed map [B][H][W][ldx]; chan_stats fp32 [B][2C] = ymk_channel_stats(want_std = 1); pool4 / pool2 fp32
+ * [B][min(4,H) * min(4,W)][C] / [B][min(2,H) * min(2,W)][C] = ymk_adaptive_avg_pool; w1 [hidden][3], b1 [hidden], w2 [E][hidden], b2 [E];
+ * base: NULL or fp32 [B][E] added to the result (the image-level router's own logits).  Outputs stats fp32 [B][3], bias fp32 [B][E]. */
+size_t ymk_scene_workspace_bytes(int32_t B, int32_t H);
+int ymk_scene_bias(int32_t dtype, const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, int32_t C, const float* chan_stats,
+                   const float* pool4, const float* pool2, const float* w1, const float* b1, const float* w2, const float* b2,
+                   int32_t hidden, int32_t E, const float* base, float* stats, float* bias, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* MoA sparse inference (moa/block.py:194-234, eval with `sparse_inference=True`): a head group whose gate is at or below `threshold`
  * for every token of the batch is skipped (none above it: the group with the largest mean gate runs alone); the retained gates are

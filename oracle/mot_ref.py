@@ -3,7 +3,7 @@
 CPU restatement of the eval-mode forward of the Mixture-of-Transformer modules:
 token-level top-k router, the three experts (LocalConv + GLU, Swin window + MLP, deformable 4-point + MLP), the
 per-sample sparse dispatch of `_blend_experts`, output projection + GroupNorm + residual, and the `C2fMoT`
-wrapper.  Defaults of the master YAMLs only: spatial router, no scene-aware bias.  Every function cites the
+wrapper; spatial and image-level routers, optional scene-aware bias.  Every function cites the
 reference lines it follows; parity is pinned by `tests/golden/make_golden_mot.py` (runs the REAL reference modules
 on CPU) and checked without the reference by `tests/test_oracle_mot.py`.
 
@@ -47,14 +47,48 @@ def sdpa(q, k, v, scale):
 FORCE_SELECT: dict = {}
 
 
-def mot_router(sd, p, x, top_k=2):
-    """_MoTRouter.forward, spatial, eval (mot/router.py:243-295): 1x1 -> GN(<=4) -> SiLU -> 1x1(+bias) in fp32,
+def compute_scene_stats(x):
+    """_MoTRouter.compute_scene_stats (mot/router.py:166-192): per image (high_frequency, heterogeneity, multi_scale) of the routed
+    map in fp32 — mean |dx|, |dy| over the RMS; std / mean of the per-pixel channel energy; |var(pool 4x4) - var(pool 2x2)| over the
+    variance (all biased)."""
+    feature = x.float()
+    eps = torch.finfo(feature.dtype).eps
+    squared = feature.square()
+    rms = squared.mean(dim=(1, 2, 3)).sqrt().clamp_min(eps)
+    dx = (feature[..., 1:] - feature[..., :-1]).abs().mean(dim=(1, 2, 3)) if feature.shape[-1] > 1 else rms * 0
+    dy = (feature[..., 1:, :] - feature[..., :-1, :]).abs().mean(dim=(1, 2, 3)) if feature.shape[-2] > 1 else rms * 0
+    high_frequency = 0.5 * (dx + dy) / rms
+    spatial_energy = squared.mean(dim=1)
+    heterogeneity = spatial_energy.flatten(1).std(dim=1, unbiased=False) / spatial_energy.flatten(1).mean(dim=1).clamp_min(eps)
+    pooled2 = F.adaptive_avg_pool2d(feature, (min(2, feature.shape[-2]), min(2, feature.shape[-1])))
+    pooled4 = F.adaptive_avg_pool2d(feature, (min(4, feature.shape[-2]), min(4, feature.shape[-1])))
+    scale2 = pooled2.var(dim=(1, 2, 3), unbiased=False)
+    scale4 = pooled4.var(dim=(1, 2, 3), unbiased=False)
+    multi_scale = (scale4 - scale2).abs() / feature.var(dim=(1, 2, 3), unbiased=False).clamp_min(eps)
+    return torch.stack((high_frequency, heterogeneity, multi_scale), dim=1)
+
+
+def mot_router(sd, p, x, top_k=2, use_spatial=True, scene_aware=False, scene_inference_mode="dynamic", info=None):
+    """_MoTRouter.forward, eval (mot/router.py:118-136, 224-295): spatial = 1x1 -> GN(<=4) -> SiLU -> 1x1(+bias), image-level
+    (use_spatial False) = GAP -> Linear(no bias) -> SiLU -> Linear, both in fp32; scene-aware routers in "dynamic" inference mode add
+    scene_projector(compute_scene_stats(x)) = Linear(3, h) -> SiLU -> Linear(h, E) per image to the logits (:224-240);
     softmax(logits / T) with the persistent `temperature` buffer, hard top-k, stable_normalize over the selected
-    set, scattered back to a sparse [B, E, H, W] weight map.  Returns (weights in x.dtype, indices, logits)."""
+    set, scattered back to a sparse [B, E, H, W] (or [B, E, 1, 1]) weight map.  Returns (weights in x.dtype, indices, logits)."""
     xf = x.float()
-    h = F.conv2d(xf, sd[f"{p}.router.0.weight"].float())
-    h = F.silu(_gn(sd, f"{p}.router.1", h, 4))
-    logits = F.conv2d(h, sd[f"{p}.router.3.weight"].float(), sd[f"{p}.router.3.bias"].float()).float()
+    if use_spatial:
+        h = F.conv2d(xf, sd[f"{p}.router.0.weight"].float())
+        h = F.silu(_gn(sd, f"{p}.router.1", h, 4))
+        logits = F.conv2d(h, sd[f"{p}.router.3.weight"].float(), sd[f"{p}.router.3.bias"].float()).float()
+    else:
+        h = F.silu(F.linear(F.adaptive_avg_pool2d(xf, 1).flatten(1), sd[f"{p}.router.2.weight"].float()))
+        logits = F.linear(h, sd[f"{p}.router.4.weight"].float(), sd[f"{p}.router.4.bias"].float()).float().unsqueeze(-1).unsqueeze(-1)
+    if scene_aware and scene_inference_mode == "dynamic":
+        stats = compute_scene_stats(xf)
+        hb = F.silu(F.linear(stats, sd[f"{p}.scene_projector.0.weight"].float(), sd[f"{p}.scene_projector.0.bias"].float()))
+        bias = F.linear(hb, sd[f"{p}.scene_projector.2.weight"].float(), sd[f"{p}.scene_projector.2.bias"].float()).float()
+        logits = logits + bias.unsqueeze(-1).unsqueeze(-1)
+        if info is not None:
+            info["scene_stats"], info["scene_bias"] = stats, bias
     w = F.softmax(logits / sd[f"{p}.temperature"].float(), dim=1)
     E = w.shape[1]
     if top_k < E:
@@ -187,15 +221,16 @@ def expert_heads(dim: int, num_heads: int) -> int:
 
 
 def mot_block(sd, p, x, num_heads=8, top_k=2, window_size=7, n_points=4, window_shift=False, local_attn_window=0,
-              grid_align_corners=True, info=None):
+              grid_align_corners=True, info=None, use_spatial_router=True, scene_aware_router=False, scene_inference_mode="dynamic"):
     """MoTBlock.forward + _blend_experts, eval (mot/block.py:298-417): expert e runs on the images where at least
     one token selected it (experts in index order), its output is weighted per token, contributions accumulate in
     that order; then 1x1 out_proj -> GroupNorm(<=8) -> + x."""
     B = x.shape[0]
     nh = expert_heads(x.shape[1], num_heads)
-    w, idx, logits = mot_router(sd, f"{p}.router", x, top_k)
+    rinfo = {}
+    w, idx, logits = mot_router(sd, f"{p}.router", x, top_k, use_spatial_router, scene_aware_router, scene_inference_mode, rinfo)
     if info is not None:
-        info[p] = {"weights": w, "indices": idx, "logits": logits}
+        info[p] = {"weights": w, "indices": idx, "logits": logits, **rinfo}
     fns = (
         lambda t: local_conv_expert(sd, f"{p}.experts.0", t, nh, local_attn_window),
         lambda t: window_expert(sd, f"{p}.experts.1", t, nh, window_size, window_size // 2 if window_shift else 0),

@@ -603,10 +603,17 @@ def deform_attention(v, off_logits, aw_logits, heads, hd, n_points, align_corner
     return _put(o, out, v.dtype)
 
 
-def token_softmax(logits, n, inv_temp, top_k=0, out=None):
+def token_softmax(logits, n, inv_temp, top_k=0, out=None, bias=None, shape=None):
     _count("token_softmax")
-    assert logits.dtype == torch.float32
-    w = torch.softmax(logits[..., :n] * inv_temp, -1)
+    if logits is None:
+        B, H, W = shape
+        lg = torch.zeros((B, H, W, n), dtype=torch.float32)
+    else:
+        assert logits.dtype == torch.float32
+        lg = logits[..., :n]
+    if bias is not None:
+        lg = lg + bias.view(bias.shape[0], 1, 1, n)
+    w = torch.softmax(lg * inv_temp, -1)
     if 0 < top_k < n:
         vals, idx = w.topk(top_k, -1)
         w = torch.zeros_like(w).scatter_(-1, idx, vals / vals.sum(-1, keepdim=True).clamp_min(1e-6))
@@ -615,6 +622,16 @@ def token_softmax(logits, n, inv_temp, top_k=0, out=None):
         sel = torch.ones_like(w, dtype=torch.bool)
     active = sel.reshape(w.shape[0], -1, n).any(1).to(torch.int32)
     return _put(w, out, torch.float32), active
+
+
+def scene_bias(x, w1, b1, w2, b2, base=None):
+    """include/ymk_mixture.h `ymk_scene_bias`: scene statistics (mot/router.py:166-192) + projector."""
+    _count("scene_bias")
+    from oracle import mot_ref
+
+    stats = mot_ref.compute_scene_stats(x.permute(0, 3, 1, 2))
+    bias = F.linear(F.silu(F.linear(stats, w1, b1)), w2, b2)
+    return stats, (bias if base is None else bias + base)
 
 
 def moa_sparse_gate(weights, n, threshold):
@@ -714,5 +731,5 @@ EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supp
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",
-            "linear_attention", "deform_attention", "token_softmax", "moa_sparse_gate", "gated_route_decide", "expert_conv", "expert_dw3", "channel_shuffle_cat",
+            "linear_attention", "deform_attention", "token_softmax", "scene_bias", "moa_sparse_gate", "gated_route_decide", "expert_conv", "expert_dw3", "channel_shuffle_cat",
             "pixel_shuffle2", "tokens_to_rows"]

@@ -44,6 +44,13 @@ def case(name, module, oracle_fn, x, seed, tweak=None):
     rec = {"x": x.numpy(), "y": y.numpy(), "keys": np.array(list(sd.keys())),
            "router_w": np.stack([v["weights"].numpy() for v in info.values()]),
            "router_idx": np.stack([v["indices"].numpy() for v in info.values()])}
+    if any("scene_stats" in v for v in info.values()):
+        rec["scene_stats"] = np.stack([v["scene_stats"].numpy() for v in info.values()])
+        rec["scene_bias"] = np.stack([v["scene_bias"].numpy() for v in info.values()])
+        ref_router = getattr(module, "router", None)
+        if ref_router is not None and getattr(ref_router, "last_scene_stats", None) is not None:   # the reference's own record
+            assert torch.equal(ref_router.last_scene_stats, next(iter(info.values()))["scene_stats"])
+            assert torch.equal(ref_router.last_scene_bias, next(iter(info.values()))["scene_bias"])
     rec.update({f"sd::{k}": v.numpy() for k, v in sd.items()})
     np.savez_compressed(HERE / f"mot_{name}.npz", **rec)
 
@@ -54,7 +61,8 @@ if __name__ == "__main__":
 
     def blk(name, x, seed, tweak=None, **kw):
         m = MoTBlock(48, num_heads=6, **kw)
-        okw = {k: v for k, v in kw.items() if k in ("top_k", "window_size", "n_points", "window_shift", "local_attn_window")}
+        okw = {k: v for k, v in kw.items() if k in ("top_k", "window_size", "n_points", "window_shift", "local_attn_window",
+                                                    "use_spatial_router", "scene_aware_router", "scene_inference_mode")}
         case(name, m, lambda sd, xx, info: mot_ref.mot_block(sd, "m", xx, 6, info=info, **okw), x, seed, tweak)
 
     blk("top2", torch.randn(3, 48, 14, 18, generator=g), 1)                                  # padded windows, top-2 of 3
@@ -65,5 +73,14 @@ if __name__ == "__main__":
     def never_deformable(sd):   # expert 2 is never selected: the per-sample dispatch must skip it entirely
         sd["router.router.3.bias"] = torch.tensor([0.3, -0.2, -50.0])
     blk("skip", torch.randn(2, 48, 9, 11, generator=g), 5, tweak=never_deformable)
+    # round 4: the scene-aware residual (mot/router.py:166-240; map sizes that the 2x2 / 4x4 adaptive pools do not divide), the
+    # image-level router, both together, and the "bypass" inference policy
+    if len(sys.argv) > 1 and sys.argv[1] == "scene":
+        blk("scene", torch.randn(3, 48, 14, 18, generator=g) * torch.tensor([0.5, 1.0, 2.0]).view(3, 1, 1, 1), 11, scene_aware_router=True)
+        blk("scene3", torch.randn(2, 48, 3, 9, generator=g), 12, scene_aware_router=True, scene_hidden_dim=5, top_k=1)
+        blk("image", torch.randn(3, 48, 12, 16, generator=g), 13, use_spatial_router=False)
+        blk("image_scene", torch.randn(2, 48, 10, 10, generator=g), 14, use_spatial_router=False, scene_aware_router=True)
+        blk("scene_bypass", torch.randn(2, 48, 8, 12, generator=g), 15, scene_aware_router=True, scene_inference_mode="bypass")
+        sys.exit(0)
     m = C2fMoT(64, 96, n=2, num_heads=6)
     case("c2f", m, lambda sd, xx, info: mot_ref.c2f_mot(sd, "m", xx, 6, info=info), torch.randn(2, 64, 15, 17, generator=g), 6)

@@ -269,6 +269,12 @@ def _prep(mod, sd):
     ("mot", "shift", ("MoTBlock", (48,), dict(num_heads=6, window_shift=True, local_attn_window=7))),
     ("mot", "top1", ("MoTBlock", (48,), dict(num_heads=6, top_k=1))), ("mot", "dense", ("MoTBlock", (48,), dict(num_heads=6, top_k=3))),
     ("mot", "skip", ("MoTBlock", (48,), dict(num_heads=6))), ("mot", "c2f", ("C2fMoT", (64, 96), dict(n=2, num_heads=6))),
+    # round 4: scene-aware residual / image-level router (mot/router.py:118-136, 166-240)
+    ("mot", "scene", ("MoTBlock", (48,), dict(num_heads=6, scene_aware_router=True))),
+    ("mot", "scene3", ("MoTBlock", (48,), dict(num_heads=6, scene_aware_router=True, scene_hidden_dim=5, top_k=1))),
+    ("mot", "image", ("MoTBlock", (48,), dict(num_heads=6, use_spatial_router=False))),
+    ("mot", "image_scene", ("MoTBlock", (48,), dict(num_heads=6, use_spatial_router=False, scene_aware_router=True))),
+    ("mot", "scene_bypass", ("MoTBlock", (48,), dict(num_heads=6, scene_aware_router=True, scene_inference_mode="bypass"))),
     ("gated", "base", ("VisualEnhancedAdaptiveGateMoE", (64, 64), {})), ("gated", "small", ("VisualEnhancedAdaptiveGateMoE", (64, 64), {})),
     ("gated", "keep1", ("VisualEnhancedAdaptiveGateMoE", (64, 64), {})),
     ("gated", "e6k3", ("VisualEnhancedAdaptiveGateMoE", (96, 96), dict(num_experts=6, top_k=3))),
@@ -301,6 +307,9 @@ def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
     ref = torch.from_numpy(z["y"])
     err = float((got - ref).abs().max())
     assert err <= 1e-4 * max(1.0, float(ref.abs().max())), f"{fam}_{name}: max |d| {err:.3e}"
+    if fam == "mot" and "scene_stats" in z.files:   # the scene statistics themselves (fp64 combines on the device against torch's fp32 reductions)
+        st, rs = m.router.last_scene_stats.cpu(), torch.from_numpy(z["scene_stats"])[0]
+        assert float(((st - rs).abs() / rs.abs().clamp_min(1e-3)).max()) <= 1e-4, f"scene statistics {st.tolist()} vs {rs.tolist()}"
     if fam in ("gated", "v01", "v03"):
         B = got.shape[0]
         assert np.array_equal(m.last_route["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"

@@ -89,7 +89,11 @@ def test_config5_entry_points_have_no_cpu_path():
 
 
 MOT_CASES = {"top2": {}, "shift": dict(window_shift=True, local_attn_window=7), "top1": dict(top_k=1), "dense": dict(top_k=3),
-             "skip": {}}
+             "skip": {},
+    "scene": dict(scene_aware_router=True), "scene3": dict(scene_aware_router=True, scene_hidden_dim=5, top_k=1),
+    "image": dict(use_spatial_router=False), "image_scene": dict(use_spatial_router=False, scene_aware_router=True),
+    "scene_bypass": dict(scene_aware_router=True, scene_inference_mode="bypass"),
+             }
 
 
 @pytest.mark.parametrize("name", list(MOT_CASES))
@@ -103,8 +107,16 @@ def test_mot_block_host_vs_reference(name, golden_dir, emu):
         got = m(x)
     _close(got, y, f"mot_{name}")
     w = m.last_route["weights"].permute(0, 3, 1, 2)                               # [B, 3, H, W]
-    assert float((w - torch.from_numpy(z["router_w"])[0]).abs().max()) <= 1e-5
-    ridx = torch.from_numpy(z["router_idx"])[0]                                   # [B, k, H, W] selected experts
+    rw, ridx = torch.from_numpy(z["router_w"])[0], torch.from_numpy(z["router_idx"])[0]   # [B, 3, H, W] / [B, k, H, W] (1 x 1 maps: image-level router)
+    rw, ridx = rw.expand(-1, -1, *w.shape[2:]), ridx.expand(-1, -1, *w.shape[2:])
+    assert float((w - rw).abs().max()) <= 1e-5
+    if "scene_stats" in z.files:
+        assert m.router.last_scene_applied and emu.CALLS["scene_bias"] == 1
+        assert float((m.router.last_scene_stats - torch.from_numpy(z["scene_stats"])[0]).abs().max()) <= 1e-5
+    else:
+        assert not m.router.last_scene_applied and emu.CALLS.get("scene_bias", 0) == 0
+    if name == "scene_bypass":
+        assert m.router.last_scene_bypass_reason == "inference_policy_bypass"
     sel = torch.zeros_like(w, dtype=torch.bool).scatter_(1, ridx, True)
     assert torch.equal(w > 0, sel), "selected experts differ from the reference"
     active = m.last_route["active"]

@@ -14,6 +14,11 @@ CASES = {
     "dense": dict(fn="block", kw=dict(top_k=3)),
     "skip": dict(fn="block", kw={}),
     "c2f": dict(fn="c2f", kw={}),
+    # round 4: scene-aware residual, image-level router, inference bypass (mot/router.py:118-136, 166-240)
+    "scene": dict(fn="block", kw=dict(scene_aware_router=True)), "scene3": dict(fn="block", kw=dict(scene_aware_router=True, top_k=1)),
+    "image": dict(fn="block", kw=dict(use_spatial_router=False)),
+    "image_scene": dict(fn="block", kw=dict(use_spatial_router=False, scene_aware_router=True)),
+    "scene_bypass": dict(fn="block", kw=dict(scene_aware_router=True, scene_inference_mode="bypass")),
 }
 
 
@@ -39,6 +44,14 @@ def test_mot_oracle_reproduces_reference(name, golden_dir):
     assert torch.equal(idx, ri), "top-k expert indices differ from the reference"
     assert float((w - rw).abs().max()) <= 1e-6
     k = CASES[name]["kw"].get("top_k", 2)
+    z = np.load(golden_dir / f"mot_{name}.npz")
+    if "scene_stats" in z.files:
+        st = torch.stack([v["scene_stats"] for v in info.values()])
+        assert float((st - torch.from_numpy(z["scene_stats"])).abs().max()) <= 1e-5 * float(st.abs().max())
+        assert float((torch.stack([v["scene_bias"] for v in info.values()]) - torch.from_numpy(z["scene_bias"])).abs().max()) <= 1e-5
+        assert float(torch.from_numpy(z["scene_bias"]).abs().max()) > 0.05, "the fixture's scene bias is too small to matter"
+    else:
+        assert all("scene_stats" not in v for v in info.values())
     assert torch.equal((w > 0).sum(2), torch.full_like((w > 0).sum(2), k))          # exactly top-k experts per token
     assert torch.allclose(w.sum(2), torch.ones_like(w.sum(2)), atol=1e-6)            # renormalised over the selected set
     if name == "skip":

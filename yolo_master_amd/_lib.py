@@ -106,7 +106,10 @@ SYMBOLS_MIXTURE = {
     "ymk_adaptive_avg_pool": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_avg_pool": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_channel_stats": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "ymk_token_softmax": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "ymk_token_softmax": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "ymk_scene_workspace_bytes": (_sz, [_i32, _i32]),
+    "ymk_scene_bias": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
+                                 _sz, _vp]),
     "ymk_moa_sparse_gate": (C.c_int, [_vp, _i32, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _vp]),
     "ymk_gated_route_decide": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ymk_expert_gather": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -273,15 +273,24 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(int dt, const void* 
 }
 
 // ------------------------------------------------------------------------------------------------ routers
-__global__ __launch_bounds__(256) void token_softmax_kernel(const float* logits, int ldl, float* w, int ldw, int32_t* active, int B,
-                                                             int HW, int n, float inv_temp, int top_k) {
+// bias: nullptr or fp32 [B][n] added to every token's logits of image b before the temperature (the scene-aware residual of
+// mot/router.py:224-240, and the whole logit of the image-level router: logits == nullptr then)
+__global__ __launch_bounds__(256) void token_softmax_kernel(const float* logits, int ldl, const float* bias, float* w, int ldw,
+                                                             int32_t* active, int B, int HW, int n, float inv_temp, int top_k) {
     const int64_t total = (int64_t)B * HW;
     GRID_STRIDE(p, total) {
         float v[8];
         float m = -INFINITY;
+        const int bb = (int)(p / HW);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            v[e] = e < n ? logits[p * ldl + e] * inv_temp : -INFINITY;
+            float l = -INFINITY;
+            if (e < n) {
+                l = logits ? logits[p * ldl + e] : 0.f;
+                if (bias) l = l + bias[bb * n + e];
+                l = l * inv_temp;
+            }
+            v[e] = l;
             m = fmaxf(m, v[e]);
         }
         float s = 0.f;
@@ -1188,11 +1197,136 @@ extern "C" int ymk_moa_sparse_gate(const float* w, int32_t ldw, int64_t npix, in
     return ymk_launch_status();
 }
 
-extern "C" int ymk_token_softmax(const float* logits, int32_t ldl, float* w, int32_t ldw, int32_t* active, int32_t B, int32_t HW,
-                                 int32_t n, float inv_temp, int32_t top_k, void* stream) {
-    if (!logits || !w || !active || n < 1 || n > 8 || ldl < n || ldw < n || top_k < 0) return YMK_E_BADARG;
+extern "C" int ymk_token_softmax(const float* logits, int32_t ldl, const float* bias, float* w, int32_t ldw, int32_t* active, int32_t B,
+                                 int32_t HW, int32_t n, float inv_temp, int32_t top_k, void* stream) {
+    if ((!logits && !bias) || !w || !active || n < 1 || n > 8 || (logits && ldl < n) || ldw < n || top_k < 0) return YMK_E_BADARG;
     if (B <= 0 || HW <= 0) return YMK_OK;
-    LAUNCH(token_softmax_kernel, (int64_t)B * HW, logits, ldl, w, ldw, active, B, HW, n, inv_temp, top_k);
+    LAUNCH(token_softmax_kernel, (int64_t)B * HW, logits, ldl, bias, w, ldw, active, B, HW, n, inv_temp, top_k);
+    return ymk_launch_status();
+}
+
+// ---- scene statistics of the MoT router (mot/router.py:166-192 compute_scene_stats, :224-240 scene_projector) ----------------------------------
+// Stage 1, workgroup = (image, chunk of rows), a wave per pixel with its lanes over the channels: sum |x(.., w+1) - x(.., w)|, sum |x(.., h+1, ..) -
+// x(.., h, ..)|, and of the per-pixel energy e = mean_c x^2: sum e, sum e^2.  part fp32 [B][nchunk][4].
+__global__ __launch_bounds__(256) void scene_partials_kernel(int dt, const void* x, int ldx, int H, int W, int C, int rpc, int nchunk,
+                                                              float* __restrict__ part) {
+    __shared__ float sh[4][4];
+    const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y0 = ch * rpc, y1 = min(H, y0 + rpc);
+    const int64_t base = (int64_t)b * H * W * ldx;
+    float adx = 0.f, ady = 0.f, e1 = 0.f, e2 = 0.f;
+    for (int p = y0 * W + wave; p < y1 * W; p += 4) {
+        const int yy = p / W, xx = p - yy * W;
+        const int64_t o = base + (int64_t)p * ldx;
+        float s2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float v = ldv(x, dt, o + c);
+            s2 += v * v;
+            if (xx + 1 < W) adx += fabsf(ldv(x, dt, o + ldx + c) - v);
+            if (yy + 1 < H) ady += fabsf(ldv(x, dt, o + (int64_t)W * ldx + c) - v);
+        }
+#pragma unroll
+        for (int q = 32; q > 0; q >>= 1) s2 += __shfl_xor(s2, q);
+        const float e = s2 / (float)C;
+        e1 += e;
+        e2 += e * e;
+    }
+#pragma unroll
+    for (int q = 32; q > 0; q >>= 1) { adx += __shfl_xor(adx, q); ady += __shfl_xor(ady, q); }
+    if (lane == 0) { sh[wave][0] = adx; sh[wave][1] = ady; sh[wave][2] = e1; sh[wave][3] = e2; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        part[((int64_t)b * nchunk + ch) * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__device__ __forceinline__ double scene_block_sum(double v, double* sh) {   // 256 threads; every thread returns the total
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// Stage 2, one workgroup per image, fp64 combines of fp32 inputs: cs = per-channel [mean | biased std] (ymk_channel_stats), p4 / p2 = the
+// adaptive average pools to (min(4,H), min(4,W)) / (min(2,H), min(2,W)) as fp32 [B][n4|n2][C]; stats = (high_frequency, heterogeneity,
+// multi_scale); bias = W2 silu(W1 stats + b1) + b2 (+ base[b]).
+__global__ __launch_bounds__(256) void scene_bias_kernel(const float* cs, const float* p4, int n4, const float* p2, int n2, const float* part,
+                                                          int nchunk, int H, int W, int C, const float* w1, const float* b1,
+                                                          const float* w2, const float* b2, int hidden, int E, const float* base,
+                                                          float* stats, float* bias) {
+    __shared__ double shd[256];
+    __shared__ float sst[3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const double eps = 1.1920928955078125e-07;   // torch.finfo(torch.float32).eps
+    double sm = 0.0, sq = 0.0;
+    for (int c = t; c < C; c += 256) {
+        const double m = cs[(int64_t)b * 2 * C + c], sd = cs[(int64_t)b * 2 * C + C + c];
+        sm += m;
+        sq += sd * sd + m * m;
+    }
+    const double ex = scene_block_sum(sm, shd) / C, ex2 = scene_block_sum(sq, shd) / C;
+    const double var = ex2 - ex * ex;
+    auto pool_var = [&](const float* pp, int n) {
+        const int64_t tot = (int64_t)n * C;
+        const float* q = pp + (int64_t)b * tot;
+        double s = 0.0;
+        for (int64_t i = t; i < tot; i += 256) s += q[i];
+        const double mean = scene_block_sum(s, shd) / (double)tot;
+        double d2 = 0.0;
+        for (int64_t i = t; i < tot; i += 256) { const double d = q[i] - mean; d2 += d * d; }
+        return scene_block_sum(d2, shd) / (double)tot;
+    };
+    const double v4 = pool_var(p4, n4), v2 = pool_var(p2, n2);
+    if (t == 0) {
+        double pdx = 0.0, pdy = 0.0, pe1 = 0.0, pe2 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* q = part + ((int64_t)b * nchunk + k) * 4;
+            pdx += q[0]; pdy += q[1]; pe1 += q[2]; pe2 += q[3];
+        }
+        const double rms = fmax(sqrt(fmax(ex2, 0.0)), eps);
+        const double dx = W > 1 ? pdx / ((double)C * H * (W - 1)) : 0.0, dy = H > 1 ? pdy / ((double)C * (H - 1) * W) : 0.0;
+        const double hw = (double)H * W, m1 = pe1 / hw, sde = sqrt(fmax(pe2 / hw - m1 * m1, 0.0));
+        sst[0] = (float)(0.5 * (dx + dy) / rms);
+        sst[1] = (float)(sde / fmax(m1, eps));
+        sst[2] = (float)(fabs(v4 - v2) / fmax(var, eps));
+        stats[b * 3 + 0] = sst[0]; stats[b * 3 + 1] = sst[1]; stats[b * 3 + 2] = sst[2];
+    }
+    __syncthreads();
+    if (t < E) {
+        float o = b2[t];
+        for (int j = 0; j < hidden; ++j) {
+            float h = b1[j] + w1[j * 3 + 0] * sst[0] + w1[j * 3 + 1] * sst[1] + w1[j * 3 + 2] * sst[2];
+            h = h / (1.0f + expf(-h));
+            o += w2[t * hidden + j] * h;
+        }
+        bias[b * E + t] = base ? o + base[b * E + t] : o;
+    }
+}
+
+extern "C" size_t ymk_scene_workspace_bytes(int32_t B, int32_t H) { return (size_t)(B > 0 ? B : 0) * (H < 64 ? (H > 0 ? H : 1) : 64) * 4 * sizeof(float); }
+
+extern "C" int ymk_scene_bias(int32_t dtype, const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, int32_t C, const float* chan_stats,
+                              const float* pool4, const float* pool2, const float* w1, const float* b1, const float* w2, const float* b2,
+                              int32_t hidden, int32_t E, const float* base, float* stats, float* bias, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!x || !chan_stats || !pool4 || !pool2 || !w1 || !b1 || !w2 || !b2 || !stats || !bias || !workspace || bad_dt(dtype) || C < 1 ||
+        ldx < C || hidden < 1 || E < 1 || E > 8)
+        return YMK_E_BADARG;
+    if (B <= 0 || H <= 0 || W <= 0) return YMK_OK;
+    if (workspace_bytes < ymk_scene_workspace_bytes(B, H)) return YMK_E_WORKSPACE;
+    const int nchunk = H < 64 ? H : 64, rpc = (H + nchunk - 1) / nchunk;
+    const int nch = (H + rpc - 1) / rpc;   // chunks that own at least one row
+    float* part = static_cast<float*>(workspace);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(scene_partials_kernel, dim3(B * nch), dim3(256), 0, s, dtype, x, ldx, H, W, C, rpc, nch, part);
+    const int n4 = (H < 4 ? H : 4) * (W < 4 ? W : 4), n2 = (H < 2 ? H : 2) * (W < 2 ? W : 2);
+    hipLaunchKernelGGL(scene_bias_kernel, dim3(B), dim3(256), 0, s, chan_stats, pool4, n4, pool2, n2, part, nch, H, W, C, w1, b1, w2, b2,
+                       hidden, E, base, stats, bias);
     return ymk_launch_status();
 }
 

@@ -1276,15 +1276,52 @@ class _DeformableTransformerExpert(nn.Module):
 
 
 class _MoTRouter(nn.Module):
-    """mot/router.py:57-150 (spatial router; no scene-aware branch — the master YAMLs do not enable it)."""
+    """mot/router.py:57-160: parameters of the token-level (1x1 -> GroupNorm -> SiLU -> 1x1) or image-level (GAP -> Linear -> SiLU ->
+    Linear) router and of the optional scene-aware residual (Linear(3, h) -> SiLU -> Linear(h, E) on three statistics of the routed map,
+    :145-160).  Same parameter names as the reference; the arithmetic is MoTBlock._route."""
 
-    def __init__(self, dim, num_experts=3, top_k=2, temperature=1.0):
+    def __init__(self, dim, num_experts=3, top_k=2, temperature=1.0, use_spatial=True, scene_aware=False, scene_hidden_dim=None,
+                 scene_inference_mode="dynamic"):
         super().__init__()
-        self.num_experts, self.top_k = num_experts, top_k
+        self.num_experts, self.top_k, self.use_spatial = num_experts, top_k, bool(use_spatial)
         self.register_buffer("temperature", torch.tensor(max(temperature, 0.1)), persistent=True)
         hidden = max(dim // 8, num_experts * 4)
-        self.router = nn.Sequential(nn.Conv2d(dim, hidden, 1, bias=False), _gn(hidden, 4), nn.SiLU(),
-                                    nn.Conv2d(hidden, num_experts, 1, bias=True))
+        if use_spatial:
+            self.router = nn.Sequential(nn.Conv2d(dim, hidden, 1, bias=False), _gn(hidden, 4), nn.SiLU(),
+                                        nn.Conv2d(hidden, num_experts, 1, bias=True))
+        else:
+            self.router = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(dim, hidden, bias=False), nn.SiLU(),
+                                        nn.Linear(hidden, num_experts, bias=True))
+        nn.init.zeros_(self.router[-1].weight)
+        nn.init.zeros_(self.router[-1].bias)
+        self.scene_aware = False
+        self.scene_hidden_dim = scene_hidden_dim
+        self.scene_projector = None
+        self.last_scene_stats = self.last_scene_bias = None
+        self.last_scene_applied = False
+        self.last_scene_bypass_reason = None
+        self.set_scene_inference_mode(scene_inference_mode)
+        if scene_aware:
+            self.enable_scene_aware(scene_hidden_dim)
+
+    def set_scene_inference_mode(self, mode):
+        """mot/router.py:138-143."""
+        normalized = str(mode).strip().lower()
+        if normalized not in {"dynamic", "bypass"}:
+            raise ValueError("scene_inference_mode must be 'dynamic' or 'bypass'")
+        self.scene_inference_mode = normalized
+
+    def enable_scene_aware(self, hidden_dim=None):
+        """mot/router.py:145-160 (zero-initialised residual; parameters created once)."""
+        if self.scene_projector is None:
+            hidden = int(hidden_dim or self.scene_hidden_dim or 3)
+            if hidden <= 0:
+                raise ValueError("scene_hidden_dim must be positive")
+            self.scene_projector = nn.Sequential(nn.Linear(3, hidden), nn.SiLU(), nn.Linear(hidden, self.num_experts))
+            nn.init.zeros_(self.scene_projector[-1].weight)
+            nn.init.zeros_(self.scene_projector[-1].bias)
+            self.scene_hidden_dim = hidden
+        self.scene_aware = True
 
 
 class MoTBlock(YmkModule):
@@ -1300,8 +1337,6 @@ class MoTBlock(YmkModule):
         super().__init__()
         if not 1 <= top_k <= self.NUM_EXPERTS:
             raise ValueError(f"top_k must be in [1, {self.NUM_EXPERTS}], got {top_k}")
-        if scene_aware_router or not use_spatial_router:
-            raise NotImplementedError("ymk MoTBlock: only the spatial, non-scene-aware router of the master YAMLs is mirrored")
         self.top_k = int(top_k)
         self.register_buffer("_sparse_train_step", torch.tensor(0, dtype=torch.long), persistent=True)
         h = num_heads
@@ -1312,20 +1347,30 @@ class MoTBlock(YmkModule):
             _LocalConvTransformerExpert(dim, h, mlp_ratio, dropout, local_window_size=local_attn_window),
             _WindowTransformerExpert(dim, h, window_size, mlp_ratio, dropout, shift_size=window_size // 2 if window_shift else 0),
             _DeformableTransformerExpert(dim, h, n_points, mlp_ratio, dropout, align_corners=grid_align_corners)])
-        self.router = _MoTRouter(dim, self.NUM_EXPERTS, top_k, temperature=temperature)
+        self.router = _MoTRouter(dim, self.NUM_EXPERTS, top_k, temperature=temperature, use_spatial=use_spatial_router,
+                                 scene_aware=scene_aware_router, scene_hidden_dim=scene_hidden_dim, scene_inference_mode=scene_inference_mode)
         self.out_norm = _gn(dim)
         self.out_proj = nn.Conv2d(dim, dim, 1, bias=False)
 
     def _pack(self, dtype, device):
         r = self.router.router
-        hid = r[0].out_channels
+        first = r[0] if self.router.use_spatial else r[2]
+        hid = first.out_channels if self.router.use_spatial else first.out_features
         hp = _ceil(hid, 4)
-        dim, nh = r[0].in_channels, self.experts[0].num_heads
+        dim, nh = (first.in_channels if self.router.use_spatial else first.in_features), self.experts[0].num_heads
         if (dim // nh) % 8:
             raise NotImplementedError(f"ymk MoTBlock: head_dim {dim // nh} is not a multiple of 8 (C2fMoT keeps head_dim >= 8 and "
                                       "dividing the width; widths that are multiples of 64 always qualify)")
-        return {"r0": _pack_conv(r[0], dtype, device, pad_cout_to=hp), "r1": _pack_norm(r[1], device), "r_hid": hid, "r_hp": hp,
-                "r3": _pack_conv(r[3], torch.float32, device, pad_cout_to=4, pad_cin_to=hp),
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()   # noqa: E731
+        sp = self.router.scene_projector
+        scene = None if sp is None else {"w1": f32(sp[0].weight), "b1": f32(sp[0].bias), "w2": f32(sp[2].weight), "b2": f32(sp[2].bias)}
+        if self.router.use_spatial:
+            head = {"r0": _pack_conv(r[0], dtype, device, pad_cout_to=hp), "r1": _pack_norm(r[1], device), "r_hid": hid, "r_hp": hp,
+                    "r3": _pack_conv(r[3], torch.float32, device, pad_cout_to=4, pad_cin_to=hp)}
+        else:   # image-level router: Linear(dim, hidden, bias=False) -> SiLU -> Linear(hidden, E) on the pooled map, as fp32 1x1 convolutions
+            head = {"g0": _pack_conv(r[2], torch.float32, device, pad_cout_to=hp),
+                    "g1": _pack_conv(r[4], torch.float32, device, pad_cout_to=4, pad_cin_to=hp)}
+        return {**head, "scene": scene,
                 "inv_temp": 1.0 / float(self.router.temperature),
                 "experts": [e.pack(dtype, device) for e in self.experts],
                 "shared": self._pack_shared(dtype, device) if _fold_ls(dtype) else None,
@@ -1351,18 +1396,44 @@ class MoTBlock(YmkModule):
         return {"w": _pack_conv(both, dtype, device), "ones": torch.ones(C, device=device), "zeros": torch.zeros(C, device=device),
                 "eps": float(win.norm1.eps)}
 
+    def _route(self, x, pk):
+        """_MoTRouter.forward, eval (mot/router.py:224-295): per-token weights fp32 [B,H,W,E] (zeros outside the top-k) and the per-image
+        "expert e is used" flags.  Token-level logits come from the 1x1 -> GroupNorm -> SiLU -> 1x1 head; the image-level router's logits
+        and the scene-aware residual are per-image rows added inside the softmax kernel (ymk_token_softmax `bias`)."""
+        B, H, W, C = x.shape
+        rt = self.router
+        logits = base = None
+        if rt.use_spatial:
+            h = ops.conv2d(x, *pk["r0"], 1, 1, False, out_dtype=torch.float32)
+            hn = torch.zeros((B, H, W, pk["r_hp"]), dtype=torch.float32, device=x.device)
+            hid = pk["r_hid"]
+            ops.group_norm(h[..., :hid], get_safe_groups(hid, 4), *pk["r1"], 1e-5, act="silu", out=hn[..., :hid])
+            logits = ops.conv2d(hn, *pk["r3"], 1, 1, False)
+        else:
+            pooled = ops.channel_stats(x)                                           # AdaptiveAvgPool2d(1) in fp32: [B,1,1,C]
+            hmid = ops.conv2d(pooled, *pk["g0"], 1, 1, True)                         # Linear -> SiLU
+            base = ops.conv2d(hmid, *pk["g1"], 1, 1, False).reshape(B, -1)[:, : self.NUM_EXPERTS].contiguous()
+        apply_scene = bool(rt.scene_aware and rt.scene_inference_mode == "dynamic")   # (eval: mot/router.py:224-229)
+        rt.last_scene_applied = apply_scene
+        rt.last_scene_bypass_reason = "inference_policy_bypass" if rt.scene_aware and not apply_scene else None
+        rt.last_scene_stats = rt.last_scene_bias = None
+        bias = base
+        if apply_scene:
+            sc = pk["scene"]
+            if sc is None:
+                raise RuntimeError("scene-aware MoT router is enabled without a scene projector")
+            stats, bias = ops.scene_bias(x, sc["w1"], sc["b1"], sc["w2"], sc["b2"], base=base)
+            rt.last_scene_stats = stats
+            rt.last_scene_bias = bias if base is None else None   # (with an image-level router the kernel returns logits + bias)
+        return ops.token_softmax(logits, self.NUM_EXPERTS, pk["inv_temp"], top_k=self.top_k, bias=bias, shape=(B, H, W))
+
     def _run(self, x, out=None):
         """mot/block.py:298-417, eval.  The reference runs expert e only on the images where some token selected it;
         every expert is image-local, so running all of them on the whole batch and weighting per token (weight 0 where
         the expert was not selected) gives the same result without a device->host read of the routing decision."""
         B, H, W, C = x.shape
         pk = self._packed(x.device)
-        h = ops.conv2d(x, *pk["r0"], 1, 1, False, out_dtype=torch.float32)
-        hn = torch.zeros((B, H, W, pk["r_hp"]), dtype=torch.float32, device=x.device)
-        hid = pk["r_hid"]
-        ops.group_norm(h[..., :hid], get_safe_groups(hid, 4), *pk["r1"], 1e-5, act="silu", out=hn[..., :hid])
-        logits = ops.conv2d(hn, *pk["r3"], 1, 1, False)
-        weights, active = ops.token_softmax(logits, self.NUM_EXPERTS, pk["inv_temp"], top_k=self.top_k)
+        weights, active = self._route(x, pk)
         self.last_route = {"weights": weights, "active": active}
         sh = pk["shared"]
         if sh is not None and float(self.experts[2].norm1.eps) == sh["eps"]:

@@ -952,18 +952,52 @@ def deform_attention(v, off_logits, aw_logits, heads: int, hd: int, n_points: in
 
 
 @_timed("token_router")
-def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None):
+def token_softmax(logits, n: int, inv_temp: float, top_k: int = 0, out=None, bias=None, shape=None):
     """Per-token softmax over the first n channels of fp32 logits scaled by inv_temp; with 0 < top_k < n the top_k
     largest are kept and renormalised (sum clamped at 1e-6), the rest set to 0 (mot/router.py:243-295, moa/router.py:50-62).
+    bias: fp32 [B, n] added to every token's logits of its image first (scene-aware residual, mot/router.py:224-240); logits=None with
+    shape=(B, H, W): the image-level router, whose logits are the bias alone.
     Returns (weights fp32 [B,H,W,n], active int32 [B,n] = 1 where any token of the image gives expert e a nonzero weight)."""
-    B, H, W, Cc, ldl = _nhwc(logits)
-    if logits.dtype != torch.float32 or Cc < n:
-        raise ValueError("token_softmax: fp32 logits with at least n channels")
-    out, ldw = _out_like(logits, out, torch.float32, (B, H, W, n))
-    active = torch.zeros((B, n), dtype=torch.int32, device=logits.device)
-    check(lib.ymk_token_softmax(_p(logits), ldl, _p(out), ldw, _p(active), B, H * W, n, float(inv_temp), int(top_k), _stream()),
+    if logits is None:
+        if bias is None or shape is None:
+            raise ValueError("token_softmax: logits or (bias and shape)")
+        B, H, W = shape
+        ldl, dev = 0, bias.device
+        if out is None:
+            out = torch.empty((B, H, W, n), dtype=torch.float32, device=dev)
+        ldw = _nhwc(out)[4]
+    else:
+        B, H, W, Cc, ldl = _nhwc(logits)
+        if logits.dtype != torch.float32 or Cc < n:
+            raise ValueError("token_softmax: fp32 logits with at least n channels")
+        out, ldw = _out_like(logits, out, torch.float32, (B, H, W, n))
+        dev = logits.device
+    if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and tuple(bias.shape) == (B, n)):
+        raise ValueError("token_softmax: bias fp32 [B, n]")
+    active = torch.zeros((B, n), dtype=torch.int32, device=dev)
+    check(lib.ymk_token_softmax(_p(logits), ldl, _p(bias), _p(out), ldw, _p(active), B, H * W, n, float(inv_temp), int(top_k), _stream()),
           "token_softmax")
     return out, active
+
+
+@_timed("pool")
+def scene_bias(x, w1, b1, w2, b2, base=None):
+    """Scene statistics of the routed map + the scene projector (mot/router.py:166-192, 224-240; include/ymk_mixture.h ymk_scene_bias).
+    x [B,H,W,C]; w1 [hidden,3], b1 [hidden], w2 [E,hidden], b2 [E] fp32; base: None or fp32 [B,E] added to the bias.
+    Returns (stats fp32 [B,3] = (high_frequency, heterogeneity, multi_scale), bias fp32 [B,E])."""
+    B, H, W, Cc, ldx = _nhwc(x)
+    hidden, E = w1.shape[0], w2.shape[0]
+    dev = x.device
+    cs = channel_stats(x, want_std=True)
+    p4 = adaptive_avg_pool(x, min(4, H), min(4, W), out_dtype=torch.float32)
+    p2 = adaptive_avg_pool(x, min(2, H), min(2, W), out_dtype=torch.float32)
+    stats = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    bias = torch.empty((B, E), dtype=torch.float32, device=dev)
+    nbytes = lib.ymk_scene_workspace_bytes(B, H)
+    ws = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=dev)
+    check(lib.ymk_scene_bias(DT[x.dtype], _p(x), ldx, B, H, W, Cc, _p(cs), _p(p4), _p(p2), _p(w1), _p(b1), _p(w2), _p(b2), hidden, E,
+                             _p(base), _p(stats), _p(bias), _p(ws), ws.numel(), _stream()), "scene_bias")
+    return stats, bias
 
 
 def moa_sparse_gate(weights, n: int, threshold: float):

@@ -324,8 +324,17 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fi = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x % heads;
-    const int ba = blockIdx.x / heads;
+    // Bijective XCD remap (workgroup i runs on XCD i % 8): logically consecutive problems — the heads of one (image, area), whose 64-byte
+    // q / k / v slices share 128-byte lines pairwise — are given to ONE XCD back to back.  With blockIdx taken as is, head h and h + 1
+    // ran on different XCDs, each L2 fetched the shared line for itself, and the fabric counter showed qkv read twice (162 MB for 79 MB
+    // at 40^2, profiles/r04_step_dispatch_pmc.txt).
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int h = bid % heads;
+    const int ba = bid / heads;
     const int b = ba / area, ar = ba % area;
     const int tok0 = ar * Na;
     const int Cq = heads * 32;

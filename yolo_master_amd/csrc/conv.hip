@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     const int wco = wave >> 1, wpx = wave & 1;
     const int srow = t >> 3, cq = t & 7;
     const int fr = lane & 15, fc = lane >> 4;
-    const int ct = blockIdx.x % a.ncot;
+    // the a.ncot workgroups that walk the SAME pixel tiles (one per 128-cout tile) are consecutive logical ids: given to one XCD back to back
+    // (igemm.h xcd_remap), so that x crosses the fabric once — with blockIdx taken as is they sat on different XCDs and every L2 fetched x
+    // for itself (128 -> 384 at 40^2: 79.6 MB for 26 MB of input, profiles/r04_step_dispatch_pmc.txt)
+    const unsigned lid = a.ncot > 1 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int ct = lid % a.ncot;
     const int co0 = ct * 128;
     const int nblk_px = gridDim.x / a.ncot;            // workgroups sharing this cout tile
     const int64_t ntiles = (a.M + 127) / 128;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     }
     const bool silu = a.act == YMK_ACT_SILU;
 
-    int64_t tile = blockIdx.x / a.ncot;
+    int64_t tile = lid / a.ncot;
     if (tile < ntiles) gload(tile);
     for (; tile < ntiles; tile += nblk_px) {
         __syncthreads();  // previous tile's fragment reads are finished (first pass: sW is complete)

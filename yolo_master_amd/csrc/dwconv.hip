@@ -277,11 +277,16 @@ struct DwArgs {
 template <typename T, int K, int TW>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.y;
+    // ONE-dimensional grid over (image, run of tiles, channel block): the XCD of a workgroup is its LINEAR dispatch index modulo 8, and the
+    // remap hands every XCD one contiguous range of logical ids.  (Round 4: with images on blockIdx.y the remap ran over the 16-24
+    // workgroups of one image — two or three per XCD — so the four channel blocks that share a 128-byte line sat on two XCDs and the
+    // fabric counter showed the 7x7 stencil's input fetched twice: 121 MB for 67 at 40^2.)
+    const int per_img = (int)(gridDim.x / a.B);
+    const int gid = (int)xcd_remap_dw(blockIdx.x, gridDim.x);
+    const int b = gid / per_img, lid = gid - b * per_img;
     const size_t img = (size_t)b * a.H * a.W;
     DwEpi ep{a.bias, a.res, a.ldr, a.act};
     const T* rb = a.res ? reinterpret_cast<const T*>(a.res) + img * a.ldr : nullptr;
-    const int lid = (int)xcd_remap_dw(blockIdx.x, gridDim.x);
     const int cb = lid % a.ncb, st0 = (lid / a.ncb) * a.spt;
     dw_run<T, K, TW>(reinterpret_cast<const T*>(a.x) + img * a.ldx, a.H, a.W, a.C, a.ldx, reinterpret_cast<const T*>(a.w),
                      reinterpret_cast<T*>(a.y) + img * a.ldy, a.ldy, cb, st0, min(a.nsp, st0 + a.spt), ep, rb, smem);
@@ -296,7 +301,7 @@ static void launch_dw_k(const DwArgs& a, int nrun, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_once.done();
     }
-    hipLaunchKernelGGL((dwconv_kernel<T, K, TW>), dim3(nrun * a.ncb, a.B), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((dwconv_kernel<T, K, TW>), dim3((unsigned)((size_t)nrun * a.ncb * a.B)), dim3(256), shm, s, a);
 }
 
 template <typename T, int TW>

@@ -405,7 +405,10 @@ static int glds_launch_any(const GldsArgs& a, hipStream_t s, int flags) {
         const int64_t grid256 = tiles(bn, 256);
         // measured rule of round 2 (profiles/r02_glds_tile_ab.txt): 128-cout tiles always on 128 pixels; 64-cout tiles when the launch is
         // small (under one 256-pixel workgroup per CU) or large (>= 1024), not in between (256 -> 64 at 40^2: 69 vs 78 us)
-        bm = (c128 || grid256 < 256 || grid256 >= 1024) ? 128 : 256;
+        // round 4 (tools/micro/glds64_tile_ab.py): a LARGE 64-cout launch stays on 256 pixels when it is a 3x3 — with 128-pixel tiles a wave holds
+        // ONE pixel fragment beside the 64 couts and re-reads every weight fragment for it (10 ds_read_b128 per 8 MFMAs: bound by the LDS read
+        // rate); 128 -> 64 at 80^2 94 -> 83 us.  The 1x1 (one k-step per 64 channels, nothing to amortise) keeps 128: 26 vs 29 us.
+        bm = (c128 || grid256 < 256 || (grid256 >= 1024 && a.ks == 1)) ? 128 : 256;
         if (glds_small_below() >= 0) bm = grid256 < glds_small_below() ? 128 : 256;
         // round 3 (profiles/r03_glds_tile_ab.txt): a 256 x 256 tile (one 8-wave workgroup per CU, 128 KB of LDS, 64 MFMAs per wave and
         // k-step) wins 5-10 % where there are at least ~3/4 of a round of them and the reduction is long (256 -> 256 s2 at 80^2: 149 -> 138

@@ -170,7 +170,11 @@ template <typename T, int KG, bool PERM>
 __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int BK = 8 * VEC;            // elements per 128-byte K group
-    constexpr int RS = KG * 8;             // u32x4 per staged row
+    // u32x4 per staged row: K bytes + 32.  A pitch of 8 dwords modulo 16 puts the sixteen rows of every ds_read_b128 lane group (rows
+    // {0-3, 12-15} at chunk c and {4-11} at chunk c + 1: MI355X_MICROARCH.md, LDS) on the 64 banks exactly once, without a swizzle.  (Round 4:
+    // the XOR swizzle alone left rows of 256 / 512 bytes — KG = 2 / 4 — 2-way conflicted, the row's parity no longer selecting a bank half:
+    // 37 % of this kernel's LDS cycles were conflict cycles at KG = 2 and none at KG = 3, profiles/r04_sq_summary.txt.)
+    constexpr int RS = KG * 8 + 2;
     constexpr bool PRECISE = sizeof(T) == 4;
     __shared__ u32x4 sW[128 * RS];
     __shared__ u32x4 sA[128 * RS];
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     const int64_t ntiles = (a.M + 127) / 128;
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* wt = reinterpret_cast<const T*>(a.w) + (size_t)co0 * a.Kpad;
-    auto swz = [](int row, int c) { return (c & ~7) | ((c & 7) ^ (row & 7)); };
+    auto swz = [](int, int c) { return c; };   // (no swizzle: see RS)
 
     // weights: once per workgroup.  With whole 64-cout groups, LDS row r = MFMA row block i = (r >> 4) & 3, row fr = r & 15 of a wave's 64
     // couts is filled with cout (i >> 1) * 32 + (fr >> 2) * 8 + (i & 1) * 4 + (fr & 3): a lane then holds EIGHT consecutive couts per block

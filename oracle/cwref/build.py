@@ -24,12 +24,18 @@ def lib_path() -> Path:
 def build(verbose: bool = False) -> Path:
     if not available():
         raise RuntimeError(f"reference C++ sources not found under {REF}")
+    import fcntl
+
     OUT.mkdir(exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", f"-I{HERE}", f"-I{REF / 'include'}",
-           str(REF / "src/common.cpp"), str(HERE / "cwref_api.cpp"), "-o", str(lib_path())]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    with open(OUT / ".cwref.lock", "w") as fh:   # one builder at a time (parallel test workers); the library appears atomically
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        tmp = lib_path().with_suffix(".so.tmp")
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", f"-I{HERE}", f"-I{REF / 'include'}",
+               str(REF / "src/common.cpp"), str(HERE / "cwref_api.cpp"), "-o", str(tmp)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        tmp.replace(lib_path())
     return lib_path()
 
 

@@ -13,6 +13,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """CPU-only runs (`-m "not gpu"`: oracle, host logic, kernels on the lane emulator — 11 minutes on one core) spread over workers when
+    pytest-xdist is there and the caller gave no -n of their own: the suite then takes about five minutes.  The `-m gpu` run stays in one
+    process (one GPU; its timing-sensitive tests are not to compete with each other).  YMK_TEST_WORKERS=0 switches this off, =N sets N."""
+    import os
+
+    if hasattr(config, "workerinput") or getattr(config.option, "numprocesses", "absent") is not None:
+        return None   # a worker, a run with its own -n, or no xdist
+    if (config.option.markexpr or "").strip() != "not gpu" or config.option.collectonly or config.getoption("usepdb", False):
+        return None
+    want = os.environ.get("YMK_TEST_WORKERS")
+    n = int(want) if want is not None else min(6, max(1, (os.cpu_count() or 1) - 2))
+    if n > 1:
+        config.option.numprocesses = n
+    return None
+
+
 def pytest_collection_modifyitems(config, items):
     try:
         import torch

@@ -7,6 +7,8 @@ storage is exactly workgroup-shared storage).  Grid-stride kernels are launched 
 (-DYMK_MAX_BLOCKS=2: same code, each lane just walks more elements) to keep the number of fiber set-ups small."""
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import re
 import shutil
 import subprocess
@@ -18,6 +20,18 @@ CSRC = ROOT / "yolo_master_amd" / "csrc"
 OUT = HERE / "_build"
 SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip",
            "esmoe.hip", "attn.hip", "nms.hip", "conv.hip", "dwconv.hip", "elementwise.hip", "capi.hip", "esfused.hip"]
+
+
+@contextlib.contextmanager
+def _locked(name: str):
+    """One builder at a time per artefact (pytest-xdist workers all ask for the library at start-up): the others wait, then find it up to date."""
+    OUT.mkdir(exist_ok=True)
+    with open(OUT / f".{name}.lock", "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
 
 
 def compiler():
@@ -32,7 +46,11 @@ def build(force: bool = False, f16: bool = False) -> Path | None:
     cxx = compiler()
     if cxx is None:
         return None
-    OUT.mkdir(exist_ok=True)
+    with _locked("f16" if f16 else "h16"):
+        return _build_locked(cxx, force, f16)
+
+
+def _build_locked(cxx, force: bool, f16: bool) -> Path:
     lib = OUT / ("libymk_hostemu_f16.so" if f16 else "libymk_hostemu.so")
     srcs = [CSRC / s for s in SOURCES]
     deps = srcs + [CSRC / "ymk_common.h", CSRC / "glds.h", CSRC / "igemm.h", ROOT / "include" / "ymk_mixture.h", HERE / "hip" / "hip_runtime.h", Path(__file__)]
@@ -51,8 +69,10 @@ def build(force: bool = False, f16: bool = False) -> Path | None:
         u = OUT / (s.stem + ("_host_f16.cpp" if f16 else "_host.cpp"))
         u.write_text(txt)
         units.append(str(u))
-    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DGLDS_SMALL_BELOW_DEFAULT=3", "-DNMS_RANK_MAX=1200", "-DYMK_HOST_EMU", *(["-DYMK_H16_F16"] if f16 else []), "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(lib)]
+    tmp = lib.with_suffix(".so.tmp")   # a loader in another process never sees a half-written library
+    cmd = [cxx, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-everything", "-DYMK_MAX_BLOCKS=2", "-DGLDS_SMALL_BELOW_DEFAULT=3", "-DNMS_RANK_MAX=1200", "-DYMK_HOST_EMU", *(["-DYMK_H16_F16"] if f16 else []), "-ffp-contract=off", f"-I{HERE}", *units, "-o", str(tmp)]
     subprocess.run(cmd, check=True)
+    tmp.replace(lib)
     return lib
 
 
@@ -62,7 +82,11 @@ def build_probe(name: str = "conv256") -> Path | None:
     cxx = compiler()
     if cxx is None:
         return None
-    OUT.mkdir(exist_ok=True)
+    with _locked(f"probe_{name}"):
+        return _build_probe_locked(cxx, name)
+
+
+def _build_probe_locked(cxx, name: str) -> Path:
     src = ROOT / "tools" / "micro" / f"{name}.hip"
     exe = OUT / f"{name}_host"
     deps = [src, HERE / "hip" / "hip_runtime.h", CSRC / "ymk_common.h", Path(__file__)]
@@ -82,7 +106,11 @@ def build_selftest() -> Path | None:
     cxx = compiler()
     if cxx is None:
         return None
-    OUT.mkdir(exist_ok=True)
+    with _locked("selftest"):
+        return _build_selftest_locked(cxx)
+
+
+def _build_selftest_locked(cxx) -> Path:
     src, exe = HERE / "selftest" / "selftest.hip", OUT / "selftest_host"
     txt = src.read_text()
     txt = re.sub(r"\bextern\s+__shared__\s+(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(hostemu::dyn_lds);", txt)

@@ -164,6 +164,14 @@ int ymk_detect_box_tail(int32_t dtype, const void* x, int32_t ldx, int32_t B, in
                         const float* bias, int32_t reg_max, int32_t nc, float stride, int32_t a_off, int32_t A_total, float* y,
                         float* raw, void* stream);
 
+/* Bottleneck with two 3x3 convolutions of 64 channels as ONE kernel (csrc/bneck.hip):  y = [x +] SiLU(cv2(SiLU(cv1 x)))  — Bottleneck.forward
+ * (nn/modules/block.py:462-486) with k = (3, 3), e = 1.0, the blocks inside the head's C3k (block.py:1114-1132); each convolution + folded BN +
+ * SiLU (conv.py:80-89).  16-bit x [B][H][W][ldx] / y [..][ldy] (64 channels; y must not alias x), w1 / w2 packed [64][kpad >= 576] as for
+ * ymk_conv2d, fp32 biases; add != 0: the shortcut.  Same arithmetic and roundings as two ymk_conv2d calls on the LDS-DMA core. */
+int ymk_bottleneck_fused_supported(int32_t dtype, int32_t c1, int32_t c_mid, int32_t c2);
+int ymk_bottleneck_fused(int32_t dtype, const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, const void* w1, int32_t k1pad,
+                         const float* b1, const void* w2, int32_t k2pad, const float* b2, int32_t add, void* y, int32_t ldy, void* stream);
+
 /* ------------------------------------------------------------------------
  * Depthwise k x k convolution (stride 1, pad k/2, k odd <= 15) + bias + act
  * + residual.  Replaces DWConv (conv.py:185-199; Detect cv3 head.py:111-118),

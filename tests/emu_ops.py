@@ -186,6 +186,17 @@ def detect_box_tail(x, w_packed, bias, y, stride, a_off, reg_max, raw=False):
     return lg if raw else None
 
 
+def bottleneck_fused_supported(dtype, c1, c_mid, c2):
+    return dtype == torch.bfloat16 and c1 == c_mid == c2 == 64
+
+
+def bottleneck_fused(x, w1, b1, w2, b2, add, out=None):
+    """include/ymk.h `ymk_bottleneck_fused`: two 3x3 convolutions (+ SiLU, the intermediate rounded to bf16) and the shortcut."""
+    _count("bottleneck_fused")
+    h = conv2d(x, w1, b1, 3, 1, True)
+    return conv2d(h, w2, b2, 3, 1, True, out=out, residual=x if add else None)
+
+
 def mlp_fused_supported(dtype, C, hidden):
     return dtype == torch.bfloat16 and (C, hidden) in ((64, 128), (128, 256), (256, 512))
 
@@ -726,7 +737,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "esmoe_route", "esmoe_dw",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "bottleneck_fused_supported", "bottleneck_fused", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "esmoe_fused_supported", "esmoe_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",

@@ -635,6 +635,16 @@ def test_esmoe_route_from_the_producers_pooled_sums():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_bneck", fromlist=["CASES"]).CASES + [(4, 40, 40, True), (3, 20, 20, True), (2, 80, 80, False)])
+def test_bottleneck_fused(case):
+    """Fused 64-channel Bottleneck (csrc/bneck.hip) vs torch and vs the two library convolutions it replaces (inside run_case)."""
+    from tests.test_hostemu_bneck import run_case
+    from yolo_master_amd import ops
+
+    run_case(ops, case, dev=DEV, sliced=case[1] in (11, 40))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", __import__("tests.test_hostemu_detcls", fromlist=["BOX_CASES"]).BOX_CASES + [(4, 80, 80, 8.0), (3, 40, 40, 16.0), (2, 20, 20, 32.0)])
 def test_detect_box_tail(case):
     """Box-branch tail with the DFL decode in its epilogue (csrc/elementwise.hip detect_box_tail_kernel) vs convolution + detect_decode."""

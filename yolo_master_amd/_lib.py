@@ -69,6 +69,8 @@ SYMBOLS = {
     "ymk_detect_cls_fused_supported": (C.c_int, [_i32] * 4),
     "ymk_detect_cls_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp,
                                        _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ymk_bottleneck_fused_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "ymk_bottleneck_fused": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "ymk_detect_box_tail_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
     "ymk_detect_box_tail": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
     "ymk_mlp_fused_supported": (C.c_int, [_i32, _i32, _i32]),

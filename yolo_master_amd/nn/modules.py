@@ -270,7 +270,21 @@ class Bottleneck(YmkModule):
         self.cv2 = Conv(c_, c2, k[1], 1, g=g)
         self.add = shortcut and c1 == c2
 
+    # Both 3x3s of a 64-channel block as ONE kernel (csrc/bneck.hip: x tile and the intermediate in LDS, weights streamed tap by tap).
+    # Correct (emulator + MI355X vs the two convolutions) and NOT faster: 45-48 us against 36-42 us for the pair at 40^2, 24 against 26-32 at
+    # 20^2, bench -0.6 % (profiles/r04_negative_results.txt item 16) -> off; YMK_ENABLE bit 512 switches it on for A/B runs.
+    fuse_pair = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 512)
+
+    def _fusable(self, x):
+        a, b = self.cv1, self.cv2
+        return (self.fuse_pair and a.conv.kernel_size == b.conv.kernel_size == (3, 3) and a.conv.stride == b.conv.stride == (1, 1) and a.conv.groups == b.conv.groups == 1
+                and _is_silu(a.act) and _is_silu(b.act) and a.cout_perm is None and b.cout_perm is None
+                and ops.bottleneck_fused_supported(x.dtype, a.conv.in_channels, a.conv.out_channels, b.conv.out_channels))
+
     def _run(self, x, out=None):
+        if self._fusable(x):   # both 3x3s as one kernel: the 64-channel intermediate stays in LDS (csrc/bneck.hip; the head's C3k blocks)
+            p1, p2 = self.cv1._packed(x.device), self.cv2._packed(x.device)
+            return ops.bottleneck_fused(x, p1["w"], p1["b"], p2["w"], p2["b"], self.add, out=out)
         h = self.cv1._run(x)
         return self.cv2._run(h, out=out, residual=x if self.add else None)
 

@@ -302,6 +302,26 @@ def c3k2_fused(x, p1, pa, pb, p2, out=None, pool=True):
     return out
 
 
+def bottleneck_fused_supported(dtype, c1: int, c_mid: int, c2: int) -> bool:
+    """YMK_DISABLE bit 8388608 switches the fused 64-channel Bottleneck off (-> its two 3x3 convolutions) for A/B runs."""
+    return dtype in DT and bool(lib.ymk_bottleneck_fused_supported(DT[dtype], c1, c_mid, c2)) and \
+        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 8388608)
+
+
+def bottleneck_fused(x, w1, b1, w2, b2, add: bool, out=None):
+    """y = [x +] SiLU(cv2(SiLU(cv1 x))), both 3x3 64 -> 64, as one kernel (include/ymk.h ymk_bottleneck_fused).  x / out: [B,H,W,64] views
+    (channel slices of wider buffers are fine; out must not alias x)."""
+    B, H, W, Cc, ldx = _nhwc(x)
+    if out is None:
+        out = new_act(B, H, W, Cc, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_bottleneck_fused(DT[x.dtype], _p(x), ldx, B, H, W, _p(w1), w1.shape[1], _p(b1), _p(w2), w2.shape[1], _p(b2), int(bool(add)),
+                                   _p(out), ldy, _stream()), "bottleneck_fused")
+    TIMER.end(e0, "bottleneck_fused", B * H * W * Cc * x.element_size() * 2, 2 * 2 * B * H * W * Cc * Cc * 9, f"{Cc}->{Cc}->{Cc} k3 @{H}x{W}" + (" +res" if add else ""))
+    return out
+
+
 def detect_cls_fused_supported(dtype, cin: int, c3: int, nc: int) -> bool:
     """YMK_DISABLE bit 16384 switches the fused Detect class branch off (-> its five convolutions) for A/B runs."""
     return dtype in DT and bool(lib.ymk_detect_cls_fused_supported(DT[dtype], cin, c3, nc)) and \

@@ -58,6 +58,22 @@ def _committed_profile(suffix: str):
     return None
 
 
+def step_counter_traffic():
+    """Fabric bytes of ONE eager step (2 x FETCH_SIZE + WRITE_SIZE over every dispatch, tools/micro/step_dispatch_pmc.sh) from the newest
+    committed profiles/*_step_dispatch_pmc.txt collected on THIS tree's kernel sources; None otherwise."""
+    import glob
+    import re
+
+    from yolo_master_amd.build import source_hash
+
+    for f in sorted(glob.glob(str(PROFILES / "*_step_dispatch_pmc.txt")), reverse=True):
+        txt = open(f).read()
+        m, h = re.search(r"step: fetch ([0-9.]+) GB.*write ([0-9.]+) GB", txt), re.search(r"csrc_sha16 ([0-9a-f]{16})", txt)
+        if m and h and h.group(1) == source_hash():
+            return {"fetch_gb": float(m.group(1)), "write_gb": float(m.group(2)), "file": os.path.basename(f)}
+    return None
+
+
 def _kernels_of(family: str, table: dict):
     return [family] if family in table else [n for n in table if family in FAMILY_KERNEL and n.startswith(FAMILY_KERNEL[family])]
 
@@ -172,6 +188,10 @@ def main():
     ap.add_argument("--imbalance", default=None, help="expert-imbalance stress A[,T]: expert 0's router logit raised by A in the per-image routers and "
                     "by T (default 3 A / 8) in the per-token routers (SURVEY 8(d) 'imbalance knob'; the config-5 fixture uses 8,3: every image / "
                     "token routes to expert 0)")
+    ap.add_argument("--weights", default="cond", choices=["cond", "recipe"], help="cond (default): the PARITY-PINNED state_dict — cfg/cond_<scale>.npz over "
+                    "the seeded recipe, the weights tests/test_gpu_baseline_configs.py::test_config3_* hold to the reference's own 16-bit run (same input seed: "
+                    "`retained_pairs` here = the fixture's routing); recipe: SURVEY 8(d)'s seeded recipe + BN calibration (rounds 1-4's timed weights, kept for "
+                    "round-over-round comparison).  Scales / model families without a cond_<scale>.npz use the recipe")
     ap.add_argument("--roofline-kernel", default=None, help="op family to report in `roofline` (default: the one with the largest share of the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
@@ -217,8 +237,11 @@ def main():
         cfg["scale"] = a.scale
         model = DetectionModel(cfg)
     imb = None
+    from yolo_master_amd.weights import CFG_DIR
+    cond_file = CFG_DIR / f"cond_{a.scale}.npz"
+    use_cond = a.weights == "cond" and a.cfg is None and cond_file.exists()
     if rank == 0:
-        sd = synth_state_dict(model.state_dict(), seed=0)
+        sd = synth_state_dict(model.state_dict(), seed=0, calib=str(cond_file)) if use_cond else synth_state_dict(model.state_dict(), seed=0)
         if a.imbalance:
             v = [float(t) for t in a.imbalance.split(",")]
             imb = (v[0], v[1] if len(v) > 1 else v[0] * 3.0 / 8.0)
@@ -360,7 +383,13 @@ def main():
             torch.cuda.synchronize()
         model.check_flags()
         if distributed:
-            time.sleep(0.25)     # ... and let the watchdog retire the warm-up collectives before any stream starts capturing
+            # ... and the warm-up collectives must be RETIRED by the process group before any stream starts capturing — bounded, not timed:
+            # every gather's Work handle is waited for (`gather_packed` keeps them: dist.pending_works), the device is synchronised, and a
+            # barrier (itself a collective on the launching stream, waited for the same way) lines the ranks up.  A completed Work whose
+            # event has been queried successfully is dropped from the watchdog's list at its next pass; the event it would query is complete
+            # (not "captured") from here on, whatever the pass period is.
+            from yolo_master_amd.dist import drain_collectives
+            drain_collectives(dev)
         graph = None
         if not a.no_graph:   # the rank-local step (forward + NMS) is one captured HIP graph at every N (one per slot)
             try:
@@ -425,7 +454,7 @@ def main():
 
         # roofline leg: per-call HIP events around every op family (eager launches on this stream); the object
         # reported is the family with the largest share of the step, the rest go into "families"
-        roof, fams, retained, n_calls = None, None, None, None
+        roof, fams, retained, n_calls, roof_layers, roof_step = None, None, None, None, None, None
         if rank == 0:
             try:
                 ops.TIMER.start()
@@ -480,6 +509,31 @@ def main():
                                      "frac": round(tfl / 2 / VALU_PEAK_TMACS, 4)}
                     return r
 
+                # ---- whole-step and layer-level fractions against SURVEY 8(d)'s LAYER-FUSED ideal: each model-YAML layer reads its inputs
+                # once and writes its output once, every element at the compute width (ops.TIMER.io, filled by the graph walk); the per-family
+                # `roofline.frac` above counts what each KERNEL must move, which includes intermediates a layer-fused ideal does not contain
+                es = 2 if a.dtype in ("bf16", "f16") else 4
+                layers = list(getattr(ops.TIMER, "layers", []))
+                io = dict(getattr(ops.TIMER, "io", {}))
+                lay_ms, lay_fl = {}, {}
+                for (fam, e0, e1, nb, fl), li in zip(recs, layers):
+                    lay_ms[li] = lay_ms.get(li, 0.0) + e0.elapsed_time(e1) / 3.0
+                    lay_fl[li] = lay_fl.get(li, 0) + fl / 3.0
+                step_bytes = sum((i_ + o_) * es for i_, o_ in io.values())
+                step_flops = sum(lay_fl.values())
+                groups = {}
+                for i_, m_ in enumerate(model.model):
+                    tname = type(m_).__name__
+                    if tname in ("ES_MOE", "A2C2f", "Detect") and i_ in io:
+                        g_ = groups.setdefault(tname, {"layers": [], "ms": 0.0, "bytes": 0, "flops": 0.0})
+                        g_["layers"].append(i_); g_["ms"] += lay_ms.get(i_, 0.0); g_["bytes"] += sum(io[i_]) * es; g_["flops"] += lay_fl.get(i_, 0.0)
+                roof_layers = {k: {"layers": v["layers"], "ms_per_step_eager": round(v["ms"], 4), "layer_fused_bytes": int(v["bytes"]),
+                                   "achieved_gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                                   "hbm_frac": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                                   "achieved_tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
+                                   "mfma_frac": round(v["flops"] / max(v["ms"], 1e-9) / 1e9 / MFMA_PEAK_TFLOPS[a.dtype], 4)}
+                               for k, v in groups.items()}
+                roof_step = {"layer_fused_bytes": int(step_bytes), "flops": int(step_flops), "eager_ms_sum_of_ops": round(sum(lay_ms.values()), 4)}
                 if agg:
                     order = sorted(agg, key=lambda f: -agg[f][0])
                     roof = describe(a.roofline_kernel if a.roofline_kernel in agg else order[0])
@@ -521,9 +575,24 @@ def main():
                        "nms": nms_tag, "imbalance": None if not a.imbalance else a.imbalance,
                        "collectives": ("RCCL (nccl) process group: weight broadcast + one packed all_gather per step" + (" — forced at world size 1" if world == 1 else ""))
                                       if distributed else None,
-                       "weights": "seeded random + BN calibration (no checkpoints offline)"},
+                       "weights": (f"cfg/cond_{a.scale}.npz over synth_state_dict(seed=0): the state_dict tests/test_gpu_baseline_configs.py::test_config3_* "
+                                   "pins to the reference (input: synth_input(seed=1), the fixture's)") if use_cond else
+                                  "seeded recipe + BN calibration (SURVEY 8(d); rounds 1-4's timed weights)",
+                       "parity_bar": ("bf16/f16: at least as close to the reference's fp32 result as the reference's OWN run in that format (routing agreement, score / box "
+                                      "percentiles x 1.25, kept-set Jaccard - 0.02: tests/golden/ref16_s640_b64.npz); fp32 (--dtype f32, config 2's type): indices / classes "
+                                      "exact, scores and boxes 1e-4") if use_cond else "recipe weights: 3 x the reference's own fp32 noise + 1e-4, Jaccard >= 0.9 (tests/test_gpu_model.py)"},
             "op_calls_per_step": n_calls, "retained_pairs": retained,
             "roofline": roof,
+            # whole step / layer groups against SURVEY 8(d)'s layer-fused bytes and the model's flops (not the per-kernel algorithmic bytes of
+            # `roofline`): hbm_frac = bytes / time / 8 TB/s, mfma_frac = flops / time / dense peak; counter_gb = fabric traffic of one eager step
+            "roofline_step": None if roof_step is None else {
+                **roof_step,
+                "hbm_frac": round(roof_step["layer_fused_bytes"] / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "mfma_frac": round(roof_step["flops"] / (elapsed / a.steps) / 1e12 / MFMA_PEAK_TFLOPS[a.dtype], 4),
+                "hbm_frac_sync": round(roof_step["layer_fused_bytes"] / (sync["forward_nms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sync else None,
+                "mfma_frac_sync": round(roof_step["flops"] / (sync["forward_nms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[a.dtype], 4) if sync else None,
+                "counter": step_counter_traffic()},
+            "roofline_layers": roof_layers,
             "families": fams,
             "cpu_baseline": None,
         }

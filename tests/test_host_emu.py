@@ -160,3 +160,30 @@ def test_host_graph_fuses_the_stem_pair_at_the_s_width(emu):
             emu.CALLS.clear()
             mm._predict_once(x)
         assert emu.CALLS.get("stem_pair", 0) == 0
+
+
+def test_layer_io_accounting_matches_the_survey_figure(emu):
+    """bench.py `roofline_step` / `roofline_layers`: the graph walk reports, per model-YAML layer, the elements the layer reads and writes
+    as the REFERENCE's graph defines them (lazy upsamples at their upsampled size, virtual concatenations as the sum of their parts, the
+    fused stem pair as two layers).  SURVEY 8(d) measured 32.46 M in + 28.05 M out = 60.5 M elements per 640 x 640 image for
+    YOLO-Master-S (121 MB in bf16); ES_MOE rows 3 / 6 / 9 / 12 read and write 5.53 M elements each way."""
+    from yolo_master_amd import ops
+    from yolo_master_amd.weights import synth_input
+
+    m = _model("s", torch.bfloat16)
+    x = synth_input(1, 640, 640, seed=1)
+    ops.TIMER.start()
+    try:
+        ops.TIMER.begin = lambda: None      # (no device events on the CPU: only the walk's bookkeeping is under test)
+        with torch.inference_mode():
+            m._predict_once(x)
+        io = dict(ops.TIMER.io)
+    finally:
+        del ops.TIMER.begin
+        ops.TIMER.stop()
+    assert sorted(io) == list(range(len(m.model))), "every YAML layer must be accounted once"
+    n_in, n_out = sum(v[0] for v in io.values()), sum(v[1] for v in io.values())
+    assert abs(n_in / 32.46e6 - 1) < 0.01 and abs(n_out / 28.05e6 - 1) < 0.01, (n_in, n_out)
+    moe = sum(io[i][0] + io[i][1] for i in (3, 6, 9, 12))
+    assert moe == 2 * (128 * 160 * 160 + 256 * 80 * 80 + 256 * 40 * 40 + 512 * 20 * 20)
+    assert io[8] == (256 * 1600, 256 * 1600) and io[11] == (512 * 400, 512 * 400)

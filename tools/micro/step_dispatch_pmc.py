@@ -1,7 +1,11 @@
 """Per-dispatch fabric counters of ONE eager bench step, in launch order (the summaries under profiles/ average per kernel name):
    python tools/micro/step_dispatch_pmc.py <fetch.db> <write.db> <dispatches per step>"""
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from yolo_master_amd.build import source_hash  # noqa: E402
 
 
 def load(db):
@@ -30,3 +34,4 @@ for j in range(b - a):
     tf += fm; tw += wm
     print(f"{j:3d} {r[1].replace('void ', '').split('(')[0][:60]:60s} {r[3] / 1e3:8.1f} {fm:9.1f} {wm:9.1f}")
 print(f"step: fetch {tf / 1e3:.2f} GB (2x FETCH_SIZE), write {tw / 1e3:.2f} GB")
+print(f"# csrc_sha16 {source_hash()} weights {os.environ.get('YMK_BENCH_WEIGHTS', 'cond')}")   # bench.py quotes the total only for matching kernel sources

@@ -12,8 +12,12 @@ from __future__ import annotations
 
 import os
 
+import collections
+
 import torch
 import torch.distributed as dist
+
+_PENDING = collections.deque(maxlen=256)   # Work handles of the most recent result gathers (nccl), for drain_collectives
 
 
 def shard_range(n_items: int, rank: int, world: int) -> tuple[int, int]:
@@ -87,13 +91,44 @@ def gather_packed(pack: torch.Tensor, out: torch.Tensor | None = None) -> torch.
     if out is None or tuple(out.shape) != (world, pack.numel()) or out.dtype != pack.dtype or out.device != pack.device:
         out = torch.empty((world, pack.numel()), dtype=pack.dtype, device=pack.device)
     if dist.get_backend() == "nccl":      # RCCL over xGMI: 0.54 MB per rank at 64 images x 300 detections — latency-bound
-        dist.all_gather_into_tensor(out, pack)
+        w = dist.all_gather_into_tensor(out, pack, async_op=True)
+        w.wait()                          # stream-level: the current stream waits for the collective (what async_op=False does), the host does not
+        _PENDING.append(w)                # kept (bounded) so that drain_collectives can wait for completion instead of sleeping
         return out
     src = pack.cpu()                      # gloo (CPU tests / single-GPU functional runs)
     parts = [torch.empty_like(src) for _ in range(world)]
     dist.all_gather(parts, src)
     out.copy_(torch.stack(parts, 0))
     return out
+
+
+def drain_collectives(device=None, timeout_s: float = 30.0) -> int:
+    """Bounded replacement for "sleep and hope" before a HIP-graph capture on a rank that has issued collectives: every Work handle this
+    module still holds is waited for, the device is synchronised, completion is CONFIRMED (`is_completed()` = the Work's end event queried
+    successfully; polled with a deadline, not a fixed pause), then a barrier lines the ranks up and is itself synchronised.  After this no
+    collective of this process is in flight, so the process group's watchdog has only completed events left to query — none of them on a
+    stream that is about to capture (collectives are only ever issued on the launching stream, bench.py).  Returns the number of Works
+    drained.  Raises TimeoutError when a Work does not complete within `timeout_s` (a hung peer), instead of capturing into a live queue."""
+    import time
+
+    if not _active():
+        return 0
+    works = list(_PENDING)
+    _PENDING.clear()
+    for w in works:
+        w.wait()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+    deadline = time.monotonic() + timeout_s
+    for w in works:
+        while not w.is_completed():
+            if time.monotonic() > deadline:
+                raise TimeoutError("a warm-up collective did not complete before graph capture")
+            time.sleep(0.001)
+    dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+    return len(works)
 
 
 def gather_detections(dets: torch.Tensor, counts: torch.Tensor, idx: torch.Tensor | None = None, out: dict | None = None):

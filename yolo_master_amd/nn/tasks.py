@@ -273,16 +273,25 @@ class DetectionModel(nn.Module):
                 sizes.append((h, w))
             early = {"state": det.begin(x.shape[0], sizes, x.device), "levels": {int(j) % len(self.model): i for i, j in enumerate(det.f)}}
         for m in self.model:
+            timed = ops.TIMER.on and m.i != skip
+            if ops.TIMER.on:     # per-layer attribution of the op timer (bench.py `roofline_layers`)
+                ops.TIMER.layer = m.i
             if m.i == skip:      # produced together with the previous layer (fused stem pair)
                 ys.append(cur if m.i in self.save else None)
                 continue
             if m.f != -1:
                 cur = ys[m.f] if isinstance(m.f, int) else [cur if j == -1 else ys[j] for j in m.f]
+            if timed:
+                n_in = _logical_elems(cur)
             if m.i == 0 and taps is None and self._stem_pair_ok():
                 # rows 0 + 1 as one kernel: the stem map (the largest tensor of the network) never leaves the CU (csrc/stem2.hip)
                 m1 = self.model[1]
                 p0, p1 = m._packed(x.device), m1._packed(x.device)
                 cur = ops.stem_pair(cur, p0["wt"], p0["b"], p1["w"], p1["b"])
+                if timed:   # SURVEY 8(d) counts per YAML layer: row 0 writes and row 1 reads the stem map although the fused kernel keeps it on chip
+                    stem = cur.shape[0] * (2 * cur.shape[1]) * (2 * cur.shape[2]) * m.conv.out_channels
+                    ops.TIMER.io[0] = (n_in, stem)
+                    ops.TIMER.io[1] = (stem, _logical_elems(cur))
                 ys.append(None)
                 skip = 1
                 continue
@@ -314,11 +323,14 @@ class DetectionModel(nn.Module):
                 if isinstance(cur, LazyUpsample):
                     cur = cur.materialise()
                 cur = m._run(cur)
+            if timed:
+                ops.TIMER.io[m.i] = (n_in, _logical_elems(cur))
             ys.append(cur if m.i in self.save else None)
             if early is not None and m.i in early["levels"] and m.i != len(self.model) - 2 and torch.is_tensor(cur):
                 det.start_level(early["state"], early["levels"][m.i], cur)   # (the last level's map is the head's direct input: it runs on the main stream)
             if taps is not None:
                 taps[m.i] = cur.materialise() if isinstance(cur, VirtualCat) else cur
+        ops.TIMER.layer = -1
         det = self.model[-1]
         preds = DetectPreds(raw, det_in, det.reg_max, det.nc, raw_fn=lambda: det.raw_logits(det_in))
         if isinstance(det, Segment):   # mask coefficients fp32 [B, nm, A] and prototypes NHWC [B, 2H0, 2W0, nm]
@@ -331,6 +343,20 @@ class DetectionModel(nn.Module):
             if isinstance(m, ES_MOE):
                 m.check_flags()
                 break
+
+
+def _logical_elems(v) -> int:
+    """Elements of a layer input / output as the reference's graph sees it (SURVEY 8(d) "layer-fused ideal": each YAML layer reads its
+    inputs once and writes its output once): lazy upsamples count at their upsampled size, virtual concatenations as the sum of their parts."""
+    if torch.is_tensor(v):
+        return int(v.numel())
+    if isinstance(v, LazyUpsample):
+        return 4 * _logical_elems(v.src)
+    if isinstance(v, VirtualCat):
+        return sum(_logical_elems(p) for p in v.parts)
+    if isinstance(v, (list, tuple)):
+        return sum(_logical_elems(p) for p in v)
+    return 0
 
 
 class DetectPreds(dict):

@@ -51,9 +51,18 @@ class KernelTimer:
         self.on = False
         self.records = []  # (family, start_event, end_event, algorithmic_bytes, flops)
         self.shapes = []   # free-form shape string per record (tools/gpu_diag.py calls)
+        self.layers = []   # model-YAML layer index per record (set by the graph walk: `layer`; -1 = outside a layer, e.g. NMS)
+        self.layer = -1
+        self.io = {}       # layer index -> (input elements, output elements) of the layer as the model graph defines it
 
     def start(self):
-        self.on, self.records, self.shapes = True, [], []
+        self.on, self.records, self.shapes, self.layers, self.layer, self.io = True, [], [], [], -1, {}
+
+    def note(self, rec, shape=""):
+        """Append a finished record (callers that build their own event pairs)."""
+        self.records.append(rec)
+        self.shapes.append(shape)
+        self.layers.append(self.layer)
 
     def stop(self):
         self.on = False
@@ -70,8 +79,7 @@ class KernelTimer:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((family, e0, e1, int(nbytes), int(flops)))
-        self.shapes.append(shape)
+        self.note((family, e0, e1, int(nbytes), int(flops)), shape)
 
 
 TIMER = KernelTimer()
@@ -434,8 +442,7 @@ def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_p
         e1 = TIMER.begin()
         cnt = (csr_off[1:] - csr_off[:-1]).cpu()
         npairs, k2 = int(cnt.sum()), int((cnt * ksizes.cpu().int() ** 2).sum())
-        TIMER.records.append(("moe_dw", e0, e1, (B + npairs) * H * W * Cc * x.element_size(), 2 * k2 * H * W * Cc))
-        TIMER.shapes.append(f"C{Cc} @{H}x{W} pairs {npairs}")
+        TIMER.note(("moe_dw", e0, e1, (B + npairs) * H * W * Cc * x.element_size(), 2 * k2 * H * W * Cc), f"C{Cc} @{H}x{W} pairs {npairs}")
     return out
 
 
@@ -452,9 +459,8 @@ def esmoe_pw(dw_out, B: int, H: int, W: int, pw_w, pw_b, nscale, nshift, top_k: 
         e1 = TIMER.begin()
         npairs = int((sel >= 0).sum())
         es = dw_out.element_size()
-        TIMER.records.append(("moe_pw", e0, e1, (npairs * H * W * Cc + E * Cout * Cc + B * H * W * Cout) * es,
-                              2 * npairs * H * W * Cc * Cout))
-        TIMER.shapes.append(f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
+        TIMER.note(("moe_pw", e0, e1, (npairs * H * W * Cc + E * Cout * Cc + B * H * W * Cout) * es, 2 * npairs * H * W * Cc * Cout),
+                   f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
     return out
 
 
@@ -490,8 +496,8 @@ def esmoe_fused(x, dw_w, dw_off, ksizes, kmax: int, pw_w, pw_b, nscale, nshift, 
         npairs = int(pairs.sum())
         k2 = float((ksizes.float()[sel.clamp_min(0).long()] ** 2 * pairs).sum()) / max(npairs, 1)     # mean stencil size of the retained pairs
         es = x.element_size()
-        TIMER.records.append(("moe_fused", e0, e1, (B * H * W * (Cc + Cout) + E * Cout * Cc) * es, int(2 * npairs * H * W * Cc * (Cout + k2))))
-        TIMER.shapes.append(f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
+        TIMER.note(("moe_fused", e0, e1, (B * H * W * (Cc + Cout) + E * Cout * Cc) * es, int(2 * npairs * H * W * Cc * (Cout + k2))),
+                   f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
     return out
 
 

@@ -214,6 +214,9 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
             }
 #ifndef YMK_HOST_EMU
             __builtin_amdgcn_sched_barrier(0);
+#ifdef GLDS_SETPRIO   // A/B builds (tools/micro/lib_variant.sh): matrix-core cluster at raised wave priority (cdna_hip_programming.md T5)
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #endif
 #pragma unroll
             for (int kk = 0; kk < KG; ++kk)
@@ -224,6 +227,9 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
                         if (GLDS_ABLATE & 8) acc[i][j].x += __uint_as_float(af[kk][i].x ^ bfr[kk][j].y); else
                         acc[i][j] = mfma16x16x32_h16(af[kk][i], bfr[kk][j], acc[i][j]);
 #ifndef YMK_HOST_EMU
+#ifdef GLDS_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (k0 + KG < KH) __builtin_amdgcn_sched_barrier(0);
 #endif
         }

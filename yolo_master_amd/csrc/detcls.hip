@@ -291,6 +291,7 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
             }
         }
         __syncthreads();   // region A is restaged by the next tile
+#ifdef DC_BEST_SERIAL   // rounds 4's form (A/B builds): 128 threads, one serial scan of the nc classes each
         if (DEC && a.bconf && t < DC_NP) {   // (region B is next written by dw1, behind the staging barrier of the next tile)
             const float* sbest = reinterpret_cast<const float*>(sB);
             const int oy = oy0 + (t >> 4), ox = ox0 + (t & 15);
@@ -306,6 +307,49 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
                 a.bcls[o] = bc;
             }
         }
+#else
+        // Every anchor's best class, all 512 threads: thread (anchor p, quarter q) scans classes q, q + 4, q + 8 ... in ascending order
+        // (strict >: its FIRST maximum), eight LDS reads in flight at a time; the four quarters of an anchor are four lanes apart by 128 and
+        // meet through region A's first rows (dead until the next tile's staging, which waits at the barrier below); the combine keeps the
+        // larger score and, between equal scores, the smaller class — the first maximum in class order (utils/nms.py:124-129).  The serial
+        // form this replaces (128 threads x nc dependent compare-selects, six waves idle) was ~4 of a tile's ~19 us.
+        if (DEC && a.bconf) {
+            const float* sbest = reinterpret_cast<const float*>(sB);
+            const int p = t & (DC_NP - 1), q = t >> 7;
+            float bv = -1.f;      // scores are sigmoids: > 0
+            int bc = 0x7fffffff;
+            for (int c0 = q; c0 < a.nc; c0 += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = c0 + 4 * u < a.nc ? sbest[(c0 + 4 * u) * DC_BEST_PITCH + p] : -1.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (v[u] > bv) { bv = v[u]; bc = c0 + 4 * u; }
+            }
+            float* comb = reinterpret_cast<float*>(sA);                 // [4][128] scores, then [4][128] classes
+            comb[q * DC_NP + p] = bv;
+            reinterpret_cast<int*>(comb)[(4 + q) * DC_NP + p] = bc;
+        }
+        __syncthreads();
+        if (DEC && a.bconf && t < DC_NP) {
+            const float* comb = reinterpret_cast<const float*>(sA);
+            const int oy = oy0 + (t >> 4), ox = ox0 + (t & 15);
+            if (oy < a.H && ox < a.W) {
+                float bv = comb[t];
+                int bc = reinterpret_cast<const int*>(comb)[4 * DC_NP + t];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const float ov = comb[q * DC_NP + t];
+                    const int oc = reinterpret_cast<const int*>(comb)[(4 + q) * DC_NP + t];
+                    if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+                }
+                const size_t o = (size_t)b * a.A + a.a_off + oy * a.W + ox;
+                a.bconf[o] = bv;
+                a.bcls[o] = bc;
+            }
+        }
+        if (DEC && a.bconf) __syncthreads();   // the combine buffer (region A) is read before the next tile's staging writes it
+#endif
     }
 }
 

@@ -14,6 +14,9 @@
 // Arithmetic per stage as the unfused kernels' (bf16 operands, fp32 accumulation, one rounding to bf16 per stage).
 #include "ymk_common.h"
 
+#ifndef DC_ABLATE
+#define DC_ABLATE 0   // stage ablation for timing runs (tools/micro/lib_variant.sh): 1 no global staging loads, 2 no 3x3 stencil arithmetic, 4 no MFMA,
+#endif                //   8 SiLU / sigmoid -> identity, 16 no y stores, 32 no best-class pass
 #define DC_TH 8
 #define DC_TW 16
 #define DC_XR (DC_TH + 4)
@@ -38,12 +41,14 @@ typedef __bf16 dc_bf16x8 __attribute__((ext_vector_type(8)));
 #define DC_SCHED_BARRIER() ((void)0)
 #endif
 __device__ __forceinline__ void dc_mma(f32x4& acc, const u32x4& a, const u32x4& b) {
+    if (DC_ABLATE & 4) { acc.x += __uint_as_float(a.x ^ b.y); return; }
     acc = mfma16x16x32_h16(a, b, acc);
 }
+__device__ __forceinline__ float dc_silu(float v) { return (DC_ABLATE & 8) ? v : silu_f(v); }
 __device__ __forceinline__ u32x2 dc_pack_silu(const f32x4& v) {
     u32x2 o;
-    o.x = pack_h16x2(silu_f(v.x), silu_f(v.y));
-    o.y = pack_h16x2(silu_f(v.z), silu_f(v.w));
+    o.x = pack_h16x2(dc_silu(v.x), dc_silu(v.y));
+    o.y = pack_h16x2(dc_silu(v.z), dc_silu(v.w));
     return o;
 }
 
@@ -51,6 +56,7 @@ __device__ __forceinline__ u32x2 dc_pack_silu(const f32x4& v) {
 // The exact form (libm expf + IEEE division = detect_decode_kernel's bits) costs this 1.25-wave-per-SIMD epilogue 6 us per tile of 128
 // anchors (measured: 216 -> 297 us at P3, more than the decode kernel it replaces); -DDC_EXACT_SIGMOID keeps it for A/B runs and tests.
 __device__ __forceinline__ float dc_sigmoid(float v) {
+    if (DC_ABLATE & 8) return v;
 #ifdef DC_EXACT_SIGMOID
     return 1.0f / (1.0f + expf(-v));
 #else
@@ -88,7 +94,7 @@ __device__ __forceinline__ void dc_dw3(const char* in, int icol, char* out, int 
         const int u = p / ocol, v = p - u * ocol;
         f32x4 acc = bv;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < ((DC_ABLATE & 2) ? 1 : 9); ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const u32x2 q = *reinterpret_cast<const u32x2*>(in + ((u + ky) * icol + v + kx) * DC_PITCH + cg * 8);
             acc.x = __builtin_fmaf(h16lo(q.x), wt[tap][0], acc.x);
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
                     const int u = px / DC_XC, w = px - u * DC_XC;
                     const int iy = oy0 - 2 + u, ix = ox0 - 2 + w;
                     v[l] = u32x4{0u, 0u, 0u, 0u};
-                    if (px < DC_NX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    if (!(DC_ABLATE & 1) && px < DC_NX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                         v[l] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.ldx + ch * 128 + q * 8);
                 }
 #pragma unroll
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
                     const f32x4 p = {dc_sigmoid(acc[j].x), dc_sigmoid(acc[j].y), dc_sigmoid(acc[j].z), dc_sigmoid(acc[j].w)};
                     if (cls < a.nc) {
                         *reinterpret_cast<f32x4*>(sbest + cls * DC_BEST_PITCH + jj * 16 + fc * 4) = p;
-                        if (oy < a.H && ox < a.W) {
+                        if (oy < a.H && ox < a.W && (!(DC_ABLATE & 16) || p.x == 12345.f)) {
                             float* yp = a.yo + ((size_t)b * (4 + a.nc) + 4 + cls) * a.A + a.a_off + oy * a.W + ox;
                             if (vec) {
                                 *reinterpret_cast<f32x4*>(yp) = p;    // W % 4 == 0: the four anchors are inside the map together
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
         // meet through region A's first rows (dead until the next tile's staging, which waits at the barrier below); the combine keeps the
         // larger score and, between equal scores, the smaller class — the first maximum in class order (utils/nms.py:124-129).  The serial
         // form this replaces (128 threads x nc dependent compare-selects, six waves idle) was ~4 of a tile's ~19 us.
-        if (DEC && a.bconf) {
+        if (DEC && a.bconf && !(DC_ABLATE & 32)) {
             const float* sbest = reinterpret_cast<const float*>(sB);
             const int p = t & (DC_NP - 1), q = t >> 7;
             float bv = -1.f;      // scores are sigmoids: > 0

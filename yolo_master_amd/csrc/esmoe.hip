@@ -788,17 +788,24 @@ __global__ __launch_bounds__(512) void moe_pw_lean_kernel(MoePwArgs a) {
     };
     auto expert_of = [](const int4& d) { return (int)(short)(d.z & 0xffff); };
 
-    u32x4 ra[2][KG], rw[2][KG];
-    auto gload = [&](const int4& d) {
+    // Activation tiles are requested TWO steps ahead (PWL_AHEAD; register sets ra / rb alternate, the loop below is unrolled by two so
+    // that both stay statically indexed): with one step of lead a tile had exactly one step's arithmetic (~1-1.5 us) to arrive while every
+    // CU streams — the wait at the top of the next step was exposed (SQ: waves parked 32 %, profiles/r04_sq_summary.txt).
+#ifndef PWL_AHEAD
+#define PWL_AHEAD 1
+#endif
+    u32x4 ra[2][KG], rb[2][KG], rw[2][KG];
+    auto gload_into = [&](const int4& d, u32x4 (&dst)[2][KG]) {
         const T* xin = dw + (size_t)d.x * a.C + cq * VEC;
         const int last_row = ((d.z & 0x40000) ? tail : 128) - 1;   // rows past the image repeat its last row (never stored)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = min(srow + i * 64, last_row);
 #pragma unroll
-            for (int g = 0; g < KG; ++g) ra[i][g] = *reinterpret_cast<const u32x4*>(xin + r * a.C + g * 8 * VEC);
+            for (int g = 0; g < KG; ++g) dst[i][g] = *reinterpret_cast<const u32x4*>(xin + r * a.C + g * 8 * VEC);
         }
     };
+    auto gload = [&](const int4& d) { gload_into(d, ra); };
     auto wload = [&](int e) {
         const T* wt = pw + (size_t)e * a.Cout * a.Kpad;
 #pragma unroll
@@ -831,13 +838,18 @@ __global__ __launch_bounds__(512) void moe_pw_lean_kernel(MoePwArgs a) {
     bool pend = false;
     int cslot = 0;
     if (expert_of(cur) >= 0) { gload(cur); cslot = claim(expert_of(cur), pend); }
+    if (PWL_AHEAD == 2 && n > 1) {
+        const int4 d1 = fetch(1);
+        if (expert_of(d1) >= 0) gload_into(d1, rb);
+    }
     f32x4 part[2][4];
-    for (int i = 0; i < n; ++i) {
+    // one step; `mine` holds this step's activation rows, and is refilled with the rows of step i + PWL_AHEAD once they are in LDS
+    auto step = [&](int i, u32x4 (&mine)[2][KG]) {
         __syncthreads();   // the previous step's fragment reads are finished
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int g = 0; g < KG; ++g) sA[st_off + q * 64 * RP + g * 8] = ra[q][g];
+            for (int g = 0; g < KG; ++g) sA[st_off + q * 64 * RP + g * 8] = mine[q][g];
         if (pend) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -850,7 +862,14 @@ __global__ __launch_bounds__(512) void moe_pw_lean_kernel(MoePwArgs a) {
         pend = false;
         if (i + 1 < n) {
             nx = fetch(i + 1);
-            if (expert_of(nx) >= 0) { gload(nx); nslot = claim(expert_of(nx), pend); }
+            if (expert_of(nx) >= 0) {
+                if (PWL_AHEAD == 1) gload_into(nx, mine);
+                nslot = claim(expert_of(nx), pend);      // (the weight tile of a miss keeps one step of lead: misses are rare)
+            }
+        }
+        if (PWL_AHEAD == 2 && i + 2 < n) {
+            const int4 d2 = fetch(i + 2);
+            if (expert_of(d2) >= 0) gload_into(d2, mine);
         }
         const int e = expert_of(cur);
         const bool first = cur.z & 0x10000, last = cur.z & 0x20000;
@@ -928,6 +947,12 @@ __global__ __launch_bounds__(512) void moe_pw_lean_kernel(MoePwArgs a) {
             }
         }
         cur = nx; cslot = nslot;
+    };
+    for (int i = 0; i < n; i += 2) {
+        step(i, ra);
+        if (i + 1 < n) {
+            if (PWL_AHEAD == 2) step(i + 1, rb); else step(i + 1, ra);
+        }
     }
 }
 

@@ -522,6 +522,56 @@ class LowRankHybridAdaptiveGateMoE(HybridAdaptiveGateMoE):
         self.bottleneck_ratio = bottleneck_ratio
 
 
+# Build-time expert-pool registry of SharedExpertMoE (moe/shared_expert_moe.py:27-29): pool_id -> {signature, "fused_experts": module}.
+# parse_model clears it at model boundaries (nn/tasks.py:2037,2272); after construction the blocks keep the shared module as a child.
+_SHARED_EXPERT_POOLS: dict = {}
+
+
+class SharedExpertMoE(LowRankHybridAdaptiveGateMoE):
+    """Cross-scale expert sharing (moe/shared_expert_moe.py:32-129; YAML cfg/models/master/v0_8/det/yolo-master-moe-mot-shared-n.yaml): a
+    v0_7 block whose routed expert group is ONE module shared by every block built with the same `pool_id` — the first block of a pool
+    owns it, later ones alias it (and must agree on dynamic channels, experts, top_k and bottleneck ratio: ValueError otherwise).  The
+    `state_dict` lists the shared tensors under every member's prefix (torch lists shared modules per parent); `load_state_dict` writes
+    them in module order, so the LAST member's entries are what all members compute with — exactly the reference's behaviour, obtained
+    the same way (module aliasing).  Packing reads `self.fused_experts`, so every member packs the shared weights; nothing else differs
+    from LowRankHybridAdaptiveGateMoE."""
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, split_ratio=0.5, num_groups=8, initial_temperature=1.2,
+                 final_temperature=0.5, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, entropy_loss_coeff=0.01,
+                 fused_expert_threshold=8, shuffle_groups=2, bottleneck_ratio=0.5, pool_id="shared"):
+        super().__init__(in_channels, out_channels, num_experts, top_k, split_ratio, num_groups, initial_temperature, final_temperature,
+                         balance_loss_coeff, router_z_loss_coeff, entropy_loss_coeff, fused_expert_threshold, shuffle_groups, bottleneck_ratio)
+        self.pool_id = pool_id
+        self._is_pool_owner = False
+        self._setup_shared_pool()
+
+    def _setup_shared_pool(self):
+        """shared_expert_moe.py:85-115."""
+        fe = self.fused_experts
+        sig = {"in_channels": self.dynamic_channels, "out_channels": self.out_dynamic, "num_experts": getattr(fe, "num_experts", 0),
+               "top_k": self.top_k, "bottleneck_ratio": self.bottleneck_ratio}
+        pool = _SHARED_EXPERT_POOLS.get(self.pool_id)
+        if pool is None:
+            _SHARED_EXPERT_POOLS[self.pool_id] = {**sig, "fused_experts": fe}
+            self._is_pool_owner = True
+            return
+        for k, v in sig.items():
+            if k in pool and pool[k] != v:
+                raise ValueError(f"SharedExpertMoE pool '{self.pool_id}' parameter mismatch: {k} expected {pool[k]}, got {v}. "
+                                 "Blocks that share a pool must have the same channels/num_experts/top_k.")
+        self.fused_experts = pool["fused_experts"]
+
+    @classmethod
+    def reset_shared_pools(cls):
+        """Clear the build-time registry before / after constructing a model (shared_expert_moe.py:117-120)."""
+        _SHARED_EXPERT_POOLS.clear()
+
+    def get_pool_info(self):
+        """shared_expert_moe.py:122-130."""
+        return {"pool_id": self.pool_id, "is_owner": self._is_pool_owner, "num_experts": getattr(self.fused_experts, "num_experts", 0),
+                "top_k": self.top_k, "dynamic_channels": self.dynamic_channels}
+
+
 class RefinedLowRankHybridAdaptiveGateMoE(LowRankHybridAdaptiveGateMoE):
     """v0_8 (moe/gated.py:1511-1585): + gated residual depthwise refinement after the fusion."""
 
@@ -1691,6 +1741,6 @@ class UltimateOptimizedMoE(YmkModule):
         return ops.group_norm(ops.conv2d(cat, *pk["proj"], 1, 1, False), gs(self.out_channels, ng), *pk["bn"], 1e-5, residual=x, out=out)
 
 
-MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "ModularRouterExpertMoE": ModularRouterExpertMoE, "UltimateOptimizedMoE": UltimateOptimizedMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
+MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "SharedExpertMoE": SharedExpertMoE, "ModularRouterExpertMoE": ModularRouterExpertMoE, "UltimateOptimizedMoE": UltimateOptimizedMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
                             "GatedFusionMoE": GatedFusionMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
 MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

@@ -81,6 +81,8 @@ def parse_model(d, ch, verbose=False):
         raise NotImplementedError("ymk parse_model: custom default activations are not supported (SiLU only)")
     ch = [ch]
     layers, save, c2 = [], [], ch[-1]
+    from .mixture import SharedExpertMoE
+    SharedExpertMoE.reset_shared_pools()      # expert pools are per model (nn/tasks.py:2037)
     for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
         name = m
         if m.startswith("nn."):
@@ -144,6 +146,7 @@ def parse_model(d, ch, verbose=False):
         if i == 0:
             ch = []
         ch.append(c2)
+    SharedExpertMoE.reset_shared_pools()      # (nn/tasks.py:2272)
     return nn.Sequential(*layers), sorted(save)
 
 

@@ -351,7 +351,8 @@ def main():
             return e0, e1
 
     slots = [Slot(a.split, P > 1) for _ in range(P)]
-    if int(os.environ.get("YMK_ENABLE", "0"), 0) & 48 and a.sync_split > 1:
+    from yolo_master_amd.options import OPTIONS
+    if (OPTIONS.detect_level_streams or OPTIONS.detect_early_levels) and a.sync_split > 1:
         # Detect's side-stream switches (YMK_ENABLE 16 / 32: A/B options, off by default) fork streams inside the walk; two sub-batch walks of one
         # capture each forking their own crash the capture on ROCm 7.2 (segmentation fault inside hipStreamEndCapture) — one walk for that leg
         print("[bench] YMK_ENABLE side-stream switch: the synchronised leg uses one sub-batch (--sync-split 1)", file=sys.stderr)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YMK_ABI_VERSION 3
+#define YMK_ABI_VERSION 4
 
 /* error codes */
 #define YMK_OK 0
@@ -164,14 +164,6 @@ int ymk_detect_box_tail(int32_t dtype, const void* x, int32_t ldx, int32_t B, in
                         const float* bias, int32_t reg_max, int32_t nc, float stride, int32_t a_off, int32_t A_total, float* y,
                         float* raw, void* stream);
 
-/* Bottleneck with two 3x3 convolutions of 64 channels as ONE kernel (csrc/bneck.hip):  y = [x +] SiLU(cv2(SiLU(cv1 x)))  — Bottleneck.forward
- * (nn/modules/block.py:462-486) with k = (3, 3), e = 1.0, the blocks inside the head's C3k (block.py:1114-1132); each convolution + folded BN +
- * SiLU (conv.py:80-89).  16-bit x [B][H][W][ldx] / y [..][ldy] (64 channels; y must not alias x), w1 / w2 packed [64][kpad >= 576] as for
- * ymk_conv2d, fp32 biases; add != 0: the shortcut.  Same arithmetic and roundings as two ymk_conv2d calls on the LDS-DMA core. */
-int ymk_bottleneck_fused_supported(int32_t dtype, int32_t c1, int32_t c_mid, int32_t c2);
-int ymk_bottleneck_fused(int32_t dtype, const void* x, int32_t ldx, int32_t B, int32_t H, int32_t W, const void* w1, int32_t k1pad,
-                         const float* b1, const void* w2, int32_t k2pad, const float* b2, int32_t add, void* y, int32_t ldy, void* stream);
-
 /* ------------------------------------------------------------------------
  * Depthwise k x k convolution (stride 1, pad k/2, k odd <= 15) + bias + act
  * + residual.  Replaces DWConv (conv.py:185-199; Detect cv3 head.py:111-118),
@@ -243,17 +235,6 @@ int ymk_esmoe_pw(int32_t dtype, const void* dw_out, int32_t B, int32_t H, int32_
                  const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
                  const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
 
-/* The expert body of a layer as ONE wave-specialised kernel (csrc/esfused.hip): per (image, 8 x 16 / 8 x 8 pixel tile) the halo of x
- * is staged once for both retained experts of the image, stencil waves (VALU) leave the depthwise tile in LDS, matrix-core waves run
- * the pointwise product of the previous tile chunk with the BN / SiLU / gate / accumulate / trailing-norm epilogue.  Same arguments
- * and bit-identical results as ymk_esmoe_dw followed by ymk_esmoe_pw; no dw_out buffer.  16-bit builds' element type only;
- * ymk_esmoe_fused_supported: Cin == Cout in {128, 256}, stencils 3 ... 9, top_k <= 2, E <= 4. */
-int ymk_esmoe_fused_supported(int32_t dtype, int32_t C, int32_t Cout, int32_t H, int32_t W, int32_t kmax, int32_t E, int32_t top_k);
-int ymk_esmoe_fused(int32_t dtype, const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
-                    const void* dw_w, const int32_t* dw_off, const int32_t* ksizes, int32_t kmax,
-                    int32_t Cout, int32_t Kpad, const void* pw_w, const float* pw_b,
-                    const float* norm_scale, const float* norm_shift, int32_t E, int32_t top_k,
-                    const int32_t* sel, const float* gate_w, void* y, int32_t ldy, void* stream);
 /* ------------------------------------------------------------------------
  * Area attention core: softmax(q^T k / sqrt(d)) v per (image, area, head)
  * (AAttn.forward block.py:1696-1726).  qkv is the NHWC output of the qkv 1x1
@@ -286,6 +267,13 @@ int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int3
 int ymk_mlp_fused_supported(int32_t dtype, int32_t C, int32_t hidden);
 int ymk_mlp_fused(const void* x, int32_t ldx, const void* w1, int32_t k1pad, const float* b1, const void* w2, int32_t k2pad,
                   const float* b2, void* y, int32_t ldy, int64_t M, int32_t C, int32_t hidden, void* stream);
+/* The same with AAttn's output projection and the ABlock's first skip in front (one kernel per ABlock tail):
+ *   x1 = x + Wp a + bp,  y = x1 + W2 SiLU(W1 x1 + b1) + b2   — `self.proj(x + pp)` (nn/modules/block.py:1727-1732) inside
+ * `x = x + self.attn(x); x = x + self.mlp(x)` (ABlock.forward, :1787-1797).  a [M][lda] = attention output + positional stencil, wp
+ * packed [C][kppad], bp fp32 [C]; x1 is rounded to the 16-bit type where the unfused projection stores it.  C in {128, 256}. */
+int ymk_proj_mlp_fused(const void* a, int32_t lda, const void* wp, int32_t kppad, const float* bp, const void* x, int32_t ldx,
+                       const void* w1, int32_t k1pad, const float* b1, const void* w2, int32_t k2pad, const float* b2, void* y,
+                       int32_t ldy, int64_t M, int32_t C, int32_t hidden, void* stream);
 
 /* ------------------------------------------------------------------------
  * Detect decode: DFL softmax-expectation + dist2bbox(xywh) * stride + sigmoid

@@ -311,6 +311,20 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
         for j in ([f] if isinstance(f, int) else f):
             if j != -1:
                 save.add(j % i)
+    # SharedExpertMoE (moe/shared_expert_moe.py:85-115): every block of a pool aliases ONE expert-group module, listed in the state_dict
+    # under each member's prefix; Module.load_state_dict walks the children in order and copies into the same tensors every time, so the
+    # entries of the pool's LAST member are the weights every member computes with.  Restated on the dict: members read the last member's keys.
+    pools = {}
+    for i, (f, n, m, args) in enumerate(rows):
+        if m == "SharedExpertMoE":
+            pools.setdefault(str(args[13]) if len(args) > 13 else "shared", []).append(i)
+    if any(len(v) > 1 for v in pools.values()):
+        sd = dict(sd)
+        for members in pools.values():
+            last = f"model.{members[-1]}.fused_experts."
+            for i in members[:-1]:
+                for k in [k for k in sd if k.startswith(last)]:
+                    sd[f"model.{i}.fused_experts." + k[len(last):]] = sd[k]
     scale_of = []
     out = None
     for i, (f, n, m, args) in enumerate(rows):
@@ -336,6 +350,11 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
             from . import gated_ref
             cur = gated_ref.visual_enhanced_moe(sd, p, cur, num_experts=args[1], top_k=args[2],
                                                 split_ratio=args[3] if len(args) > 3 else 0.5, info=moe_info)
+        elif m == "SharedExpertMoE":   # v0_8 shared-pool rows: [c2, E, k, split, groups, T0, T1, 3 loss coefficients, fused threshold, shuffle groups, bottleneck, pool_id]
+            from . import gated_ref
+            cur = gated_ref.adaptive_gate_chain(sd, p, cur, num_experts=args[1], top_k=args[2], split_ratio=args[3] if len(args) > 3 else 0.5,
+                                                num_groups=args[4] if len(args) > 4 else 8, temperature=args[5] if len(args) > 5 else 1.2,
+                                                shuffle_groups=args[11] if len(args) > 11 else 2, complexity_after_hooks=False, info=moe_info)
         elif m in ("AdaptiveGateMoE", "FusedAdaptiveGateMoE", "HybridAdaptiveGateMoE", "HybridAdaptiveGateMoEv2", "LowRankHybridAdaptiveGateMoE",
                    "RefinedLowRankHybridAdaptiveGateMoE", "DetailAwareLowRankHybridAdaptiveGateMoE",
                    "ContextRefinedLowRankHybridAdaptiveGateMoE"):      # v0_4 ... v0_9 / v0_11 rows: [c2, num_experts, top_k, split_ratio]

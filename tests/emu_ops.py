@@ -186,17 +186,6 @@ def detect_box_tail(x, w_packed, bias, y, stride, a_off, reg_max, raw=False):
     return lg if raw else None
 
 
-def bottleneck_fused_supported(dtype, c1, c_mid, c2):
-    return dtype == torch.bfloat16 and c1 == c_mid == c2 == 64
-
-
-def bottleneck_fused(x, w1, b1, w2, b2, add, out=None):
-    """include/ymk.h `ymk_bottleneck_fused`: two 3x3 convolutions (+ SiLU, the intermediate rounded to bf16) and the shortcut."""
-    _count("bottleneck_fused")
-    h = conv2d(x, w1, b1, 3, 1, True)
-    return conv2d(h, w2, b2, 3, 1, True, out=out, residual=x if add else None)
-
-
 def mlp_fused_supported(dtype, C, hidden):
     return dtype == torch.bfloat16 and (C, hidden) in ((64, 128), (128, 256), (256, 512))
 
@@ -206,6 +195,17 @@ def mlp_fused(x, w1, b1, w2, b2, out=None):
     _count("mlp_fused")
     h = conv2d(x, w1, b1, 1, 1, True)
     return conv2d(h, w2, b2, 1, 1, False, out=out, residual=x)
+
+
+def proj_mlp_fused_supported(dtype, C, hidden):
+    return mlp_fused_supported(dtype, C, hidden) and C >= 128
+
+
+def proj_mlp_fused(a, wp, bp, x, w1, b1, w2, b2, out=None):
+    """include/ymk.h `ymk_proj_mlp_fused`: x1 = x + Wp a + bp (rounded to the activation type), then ymk_mlp_fused on x1."""
+    _count("proj_mlp_fused")
+    x1 = conv2d(a, wp, bp, 1, 1, False, residual=x)
+    return mlp_fused(x1, w1, b1, w2, b2, out=out)
 
 
 # ------------------------------------------------------------------------------------------------- ES-MoE
@@ -295,27 +295,6 @@ def esmoe_pw(dw_out, B, H, W, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, ou
     return out
 
 
-def esmoe_fused_supported(dtype, C, Cout, H, W, kmax, E, top_k):
-    return dtype in (torch.bfloat16, torch.float16) and C == Cout and C in (128, 256) and 3 <= kmax <= 9 and E <= 4 and top_k <= 2
-
-
-def esmoe_fused(x, dw_w, dw_off, ksizes, kmax, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, out=None):
-    """The contract of ymk_esmoe_fused: the same result as the depthwise stage followed by the pointwise stage."""
-    _count("esmoe_fused")
-    B, H, W, C = x.shape
-    dw = torch.zeros((B * top_k, H, W, C), dtype=x.dtype)
-    xn = _nchw(x)
-    for b in range(B):
-        for slot in range(top_k):
-            e = int(sel[b, slot])
-            if e >= 0:
-                k = int(ksizes[e])
-                w = dw_w[int(dw_off[e]): int(dw_off[e]) + k * k * C].reshape(k * k, C)
-                dw[b * top_k + slot] = _dw(xn[b: b + 1], w, k)[0].permute(1, 2, 0).to(x.dtype)
-    return esmoe_pw(dw, B, H, W, pw_w, pw_b, nscale, nshift, top_k, sel, gate_w, out=out)
-
-
-# ------------------------------------------------------------------------------------------------- attention / layout
 def area_attn(qkv, heads, area, out=None):
     """`ymk_area_attn`: channels [Q | K | V], each [heads][32]; `area` contiguous token ranges."""
     _count("area_attn")
@@ -392,7 +371,7 @@ def nms_gather_rows(y, nc, idx, counts, out=None):
     return res
 
 
-def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, cw_sigma=None, cw_pool=3000, class_keep=None, pack=None, nc=0):
+def nms_batched(y, conf, iou, multi_label, agnostic, max_det, max_nms, max_wh, cw_sigma=None, cw_pool=3000, class_keep=None, pack=None, nc=0, use_best=True):
     _count("nms_batched")
     assert cw_sigma is None, "CW refinement is checked on the GPU against oracle/_ref"
     B = y.shape[0]
@@ -737,8 +716,8 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "bottleneck_fused_supported", "bottleneck_fused", "esmoe_route", "esmoe_dw",
-            "esmoe_pw", "esmoe_fused_supported", "esmoe_fused", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "proj_mlp_fused_supported", "proj_mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "esmoe_route", "esmoe_dw",
+            "esmoe_pw", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",

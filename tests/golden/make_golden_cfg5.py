@@ -35,6 +35,11 @@ if len(sys.argv) > 1 and sys.argv[1] in ("v01", "v03", "v04", "v05", "v06", "v07
     YAML = Path(refboot.REF) / f"ultralytics/cfg/models/master/v0_{int(TAG[1:])}/det/yolo-master-n.yaml"
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "v08s":   # v0_8 with SharedExpertMoE (moe/shared_expert_moe.py): the P3 and P4 blocks share one expert pool
+    TAG = "v08s"
+    YAML = Path(refboot.REF) / "ultralytics/cfg/models/master/v0_8/det/yolo-master-moe-mot-shared-n.yaml"
+
+
 def sample_idx(n, k, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randperm(n, generator=g)[: min(k, n)].sort().values

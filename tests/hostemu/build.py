@@ -19,7 +19,7 @@ ROOT = HERE.parent.parent
 CSRC = ROOT / "yolo_master_amd" / "csrc"
 OUT = HERE / "_build"
 SOURCES = ["mixture.hip", "mixattn.hip", "conv_glds.hip", "post.hip", "preproc.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip",
-           "esmoe.hip", "attn.hip", "nms.hip", "conv.hip", "dwconv.hip", "elementwise.hip", "capi.hip", "esfused.hip", "bneck.hip"]
+           "esmoe.hip", "attn.hip", "nms.hip", "conv.hip", "dwconv.hip", "elementwise.hip", "capi.hip"]
 
 
 @contextlib.contextmanager

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     for f in mix:
         assert hasattr(h, f), f"libymk.so does not export {f}"
     assert sorted(_lib.SYMBOLS_NEXT) == header_functions("ymk_next.h") and all(hasattr(h, f) for f in _lib.SYMBOLS_NEXT)
-    assert h.ymk_abi_version() == _lib.ABI_VERSION == 3
+    assert h.ymk_abi_version() == _lib.ABI_VERSION == 4
     assert b"gfx950" in h.ymk_build_info()
     # pure host-side queries work without a GPU
     assert h.ymk_nms_workspace_bytes(2, 80, 8400, 0, 30000) > 0

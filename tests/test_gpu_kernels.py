@@ -143,6 +143,17 @@ def test_mlp_fused(case):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_mlp", fromlist=["PROJ_CASES"]).PROJ_CASES + [(128, 256, 102400, 0, 0), (256, 512, 25600, 0, 0)])
+def test_proj_mlp_fused(case):
+    """AAttn projection + both ABlock skips + MLP as one kernel (csrc/mlp.hip PROJ) through the C-ABI against the composition in fp32
+    (incl. the detector's sizes)."""
+    from tests.test_hostemu_mlp import run_proj_case
+    from yolo_master_amd import _lib
+
+    run_proj_case(_lib.load(), case, dev=DEV, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------- layout kernels
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_kernels(dtype):
@@ -236,18 +247,19 @@ def test_area_attention_long(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("fused,cin,hw", [(False, 64, (14, 18)), (True, 128, (14, 18)),   # fused: the one-kernel expert body (csrc/esfused.hip) in the 16-bit modes
-                                          (False, 128, (14, 18)),
-                                          (False, 256, (14, 18)),    # table-driven pointwise stage, 2 cout tiles, 4 K groups
-                                          (True, 256, (14, 18)),
-                                          (False, 192, (14, 18)),    # cout not a multiple of 128: the older streaming kernel
-                                          (False, 128, (88, 88))])   # more (image, tile) items than workgroups, ragged last tile
-def test_esmoe_block(dtype, fused, cin, hw):
+@pytest.mark.parametrize("chunked,cin,hw", [(False, 64, (14, 18)), (True, 128, (14, 18)),   # chunked: the two expert stages walked in image chunks (ES_MOE.chunk_mb)
+                                            (False, 128, (14, 18)),
+                                            (False, 256, (14, 18)),    # table-driven pointwise stage, 2 cout tiles, 4 K groups
+                                            (True, 256, (14, 18)),
+                                            (False, 192, (14, 18)),    # cout not a multiple of 128: the older streaming kernel
+                                            (False, 128, (88, 88))])   # more (image, tile) items than workgroups, ragged last tile
+def test_esmoe_block(dtype, chunked, cin, hw):
     from oracle import model_ref
     from yolo_master_amd.nn.modules import ES_MOE
 
     m = ES_MOE(cin, cin)
-    m.fuse_layer = fused     # the expert body as one kernel (16-bit modes; fp32 always takes the two-kernel form) vs depthwise + pointwise
+    if chunked:   # 6 images in chunks of 2 (the depthwise planes of two images at a time): per image the same kernels on the same data
+        m.chunk_mb = 2 * 2 * hw[0] * hw[1] * cin * (4 if dtype == torch.float32 else 2) / 1e6
     sd = module_sd(m)
     # per-image offsets so that images route differently
     x = rnd(6, cin, hw[0], hw[1], seed=12) + rnd(6, cin, 1, 1, seed=13, scale=1.5)
@@ -271,25 +283,6 @@ def test_esmoe_block(dtype, fused, cin, hw):
     for e in range(E):
         seg = pair[off[e]:off[e + 1]]
         assert seg == sorted(seg) and all(int(sel.view(-1)[p]) == e for p in seg)
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", [
-    (128, 6, 160, 160, [[0, 3], [2, -1], [1, 2], [3, -1], [-1, -1], [3, 1]]),     # layer 3 of the S detector: 8 x 16 tiles, 200 per image
-    (256, 9, 80, 80, [[3, 0], [1, -1], [2, 3]]),                                  # layer 6: 8 x 8 tiles, four channel chunks
-    (256, 64, 40, 40, [[3, 0], [1, -1], [2, 3], [0, -1], [3, 2]]),                # layer 9 at the benchmarked batch: 1600 items on 256 workgroups
-    (128, 3, 37, 53, [[3, 1], [0, -1], [2, 3]]),                                  # ragged map: tiles hanging over the right and bottom edges
-], ids=lambda c: f"C{c[0]}-{c[2]}x{c[3]}-B{c[1]}")
-def test_esmoe_fused_equals_two_kernel_form(case, dtype):
-    """csrc/esfused.hip (the expert body as ONE wave-specialised kernel: LDS-DMA halo staged once for both retained experts, stencil
-    waves -> LDS tile -> matrix-core waves) BIT-identical to ymk_esmoe_dw + ymk_esmoe_pw at the detector's own shapes, bf16 and fp16
-    builds; plus the torch restatement within the 16-bit tolerance on the small case."""
-    from tests.test_hostemu_esfused import run_fused_case
-    from yolo_master_amd import ops
-
-    if dtype == torch.float16 and not ops.HAS_F16:
-        pytest.skip("libymk_f16.so not built")
-    run_fused_case(ops, case, dev=DEV, dtype=dtype, check_emu=case[1] <= 3)
 
 
 ESMOE_MODES = {"sparse": {}, "dense": dict(use_sparse_inference=False), "disabled": {}, "all": dict(top_k=None),
@@ -635,13 +628,7 @@ def test_esmoe_route_from_the_producers_pooled_sums():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", __import__("tests.test_hostemu_bneck", fromlist=["CASES"]).CASES + [(4, 40, 40, True), (3, 20, 20, True), (2, 80, 80, False)])
-def test_bottleneck_fused(case):
-    """Fused 64-channel Bottleneck (csrc/bneck.hip) vs torch and vs the two library convolutions it replaces (inside run_case)."""
-    from tests.test_hostemu_bneck import run_case
-    from yolo_master_amd import ops
 
-    run_case(ops, case, dev=DEV, sliced=case[1] in (11, 40))
 
 
 @pytest.mark.gpu

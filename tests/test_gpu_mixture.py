@@ -354,7 +354,7 @@ def test_modules_16bit_vs_reference_golden(fam, name, ctor, dtype, golden_dir):
     assert q99 <= tol and mean <= tol / 4, f"{fam}_{name} {dtype}: mean {mean:.3e}, q99 {q99:.3e} > {tol:.3e}"
 
 
-@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06", "v01", "v03"])
+@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06", "v01", "v03", "v08s"])
 def test_config5_model_vs_reference_golden(tag, golden_dir):
     import json
     import warnings

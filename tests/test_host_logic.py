@@ -213,3 +213,35 @@ def test_config5_boundary_modules_keep_the_reference_contract():
     for mod in (m.model[5], m.model[14], m.model[17], MoABlock(48, 6).eval()):
         with pytest.raises(RuntimeError, match="MI355X"):      # CPU tensors are refused like everywhere else
             mod(torch.zeros(1, mod.cv1.conv.in_channels if hasattr(mod, "cv1") else 48 if isinstance(mod, MoABlock) else 128, 8, 8))
+
+
+def test_shared_expert_pool_semantics():
+    """SharedExpertMoE (moe/shared_expert_moe.py:85-120): blocks with one pool_id alias one expert group (first = owner), a signature mismatch
+    raises ValueError, the registry is per model (parse_model resets it), and the shared tensors appear under every member's prefix."""
+    import pytest as _pt
+
+    from yolo_master_amd.nn.mixture import SharedExpertMoE
+    from yolo_master_amd.nn.tasks import DetectionModel
+
+    SharedExpertMoE.reset_shared_pools()
+    a = SharedExpertMoE(64, 64, 4, 2, pool_id="p")
+    b = SharedExpertMoE(64, 64, 4, 2, pool_id="p")
+    c = SharedExpertMoE(64, 64, 4, 2, pool_id="q")
+    assert a.fused_experts is b.fused_experts and a.fused_experts is not c.fused_experts
+    assert a.get_pool_info()["is_owner"] and not b.get_pool_info()["is_owner"] and c.get_pool_info()["is_owner"]
+    with _pt.raises(ValueError, match="parameter mismatch"):
+        SharedExpertMoE(128, 128, 4, 2, pool_id="p")          # other dynamic width
+    with _pt.raises(ValueError, match="parameter mismatch"):
+        SharedExpertMoE(64, 64, 4, 1, pool_id="p")            # other top_k
+    SharedExpertMoE.reset_shared_pools()
+    assert SharedExpertMoE(64, 64, 4, 2, pool_id="p").get_pool_info()["is_owner"]
+    cfg = {"nc": 3, "scales": {"n": [1.0, 1.0, 1024]}, "scale": "n",
+           "backbone": [[-1, 1, "Conv", [64, 3, 2]], [-1, 1, "SharedExpertMoE", [64, 4, 2, 0.5, 8, 1.2, 0.5, 1.0, 1.0, 0.01, 8, 2, 0.5, "pp"]],
+                        [-1, 1, "SharedExpertMoE", [64, 4, 2, 0.5, 8, 1.2, 0.5, 1.0, 1.0, 0.01, 8, 2, 0.5, "pp"]]],
+           "head": [[[2], 1, "Detect", ["nc"]]]}
+    m1, m2 = DetectionModel(cfg), DetectionModel(cfg)
+    assert m1.model[1].fused_experts is m1.model[2].fused_experts
+    assert m1.model[1].fused_experts is not m2.model[1].fused_experts, "pools must not leak between models"
+    sd = m1.state_dict()
+    k1 = [k for k in sd if k.startswith("model.1.fused_experts.")]
+    assert k1 and all(("model.2." + k[len("model.1."):]) in sd and sd["model.2." + k[len("model.1."):]].data_ptr() == sd[k].data_ptr() for k in k1)

@@ -59,7 +59,7 @@ def test_kernels_modules_bf16_vs_reference_golden(T, fam, name, ctor, golden_dir
         T.test_modules_16bit_vs_reference_golden(fam, name, ctor, torch.bfloat16, golden_dir)
 
 
-@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v01", "v03"])
+@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v01", "v03", "v08s"])
 def test_kernels_config5_model_vs_reference_golden(T, tag, golden_dir):
     T.test_config5_model_vs_reference_golden(tag, golden_dir)
 
@@ -129,7 +129,7 @@ def test_kernels_config5_L_scale_model(T):
 
 
 def test_kernels_sparse_expert_dispatch_in_the_L_scale_gated_blocks(T, hostlib, monkeypatch):
-    """The routed experts of the gated blocks run through ymk_expert_conv_glds (only the routed filter banks); YMK_DISABLE bit 512
+    """The routed experts of the gated blocks run through ymk_expert_conv_glds (only the routed filter banks); options.OPTIONS.expert_conv_glds = False (YMK_DISABLE bit 512)
     puts the all-experts convolution + gather back.  bf16, L-scale widths (bottleneck 128 -> 4 / 8 banks of 256 couts, 3x3;
     512 -> 16 banks, 1x1): both paths give the same block output up to bf16 rounding of the intermediate."""
     from yolo_master_amd.nn.mixture import VisualEnhancedAdaptiveGateMoE
@@ -140,8 +140,9 @@ def test_kernels_sparse_expert_dispatch_in_the_L_scale_gated_blocks(T, hostlib, 
         m.ymk_dtype = torch.bfloat16
         x = torch.randn(2, 512, 10, 12)
         outs = []
+        from yolo_master_amd.options import OPTIONS
         for off in ("512", "0"):
-            monkeypatch.setenv("YMK_DISABLE", off)
+            monkeypatch.setattr(OPTIONS, "expert_conv_glds", off == "0")     # (options.py: YMK_DISABLE bit 512 at import; tests set the field)
             before = emu_ops.CALLS.get("conv2d", 0)
             with torch.inference_mode():
                 outs.append(m(x).float())

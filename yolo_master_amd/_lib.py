@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); must list every function declared in include/ymk.h
-ABI_VERSION = 3   # include/ymk.h YMK_ABI_VERSION
+ABI_VERSION = 4   # include/ymk.h YMK_ABI_VERSION
 
 SYMBOLS = {
     "ymk_abi_version": (C.c_int, []),
@@ -69,15 +69,11 @@ SYMBOLS = {
     "ymk_detect_cls_fused_supported": (C.c_int, [_i32] * 4),
     "ymk_detect_cls_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp,
                                        _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "ymk_bottleneck_fused_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
-    "ymk_bottleneck_fused": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "ymk_detect_box_tail_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
     "ymk_detect_box_tail": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
     "ymk_mlp_fused_supported": (C.c_int, [_i32, _i32, _i32]),
     "ymk_mlp_fused": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
-    "ymk_esmoe_fused_supported": (C.c_int, [_i32] * 8),
-    "ymk_esmoe_fused": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
-                                  _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "ymk_proj_mlp_fused": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_upsample2x": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_copy_channels": (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),

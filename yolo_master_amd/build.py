@@ -24,8 +24,7 @@ ARCH = "gfx950"
 NO_CONTRACT = {"nms.hip", "elementwise.hip", "post.hip", "preproc.hip"}
 SOURCES = ["capi.hip", "conv.hip", "dwconv.hip", "mlp.hip", "stem2.hip", "c3k2f.hip", "detcls.hip", "esmoe.hip", "attn.hip", "elementwise.hip", "nms.hip",
            "mixture.hip", "mixattn.hip",   # config-5 rows, first implementation (include/ymk_mixture.h)
-           "conv_glds.hip", "post.hip", "preproc.hip",
-           "esfused.hip", "bneck.hip"]   # ES-MoE expert body as one kernel per layer (depthwise stencil -> grouped GEMM, wave-specialised)    # opt-in: next tiled convolution core, box rescaling (include/ymk_next.h)
+           "conv_glds.hip", "post.hip", "preproc.hip"]   # LDS-DMA tiled convolution core, box rescaling / validation matching, letterbox (include/ymk_next.h)
 HEADERS = ["ymk_common.h", "igemm.h", "glds.h", "../../include/ymk.h", "../../include/ymk_mixture.h", "../../include/ymk_next.h"]
 
 

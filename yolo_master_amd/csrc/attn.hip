@@ -306,8 +306,10 @@ __device__ __forceinline__ void at_chunk(const T* __restrict__ sK, const T* __re
     }
 }
 
-template <typename T, int WPE>
-__global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void area_attn_resident_kernel(
+// NT = threads of the workgroup: the area's ceil(Na / 16) query tiles are dealt round-robin to NT / 64 waves — Na = 400 is 25 tiles: four
+// waves take 7 / 6 / 6 / 6 (the workgroup lasts seven tile-times), five take 5 each (launch_attn_resident picks NT)
+template <typename T, int WPE, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void area_attn_resident_kernel(
     const T* __restrict__ qkv, int ldq, T* __restrict__ out, int ldo, int N, int Na, int heads, int area, float scale) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int NF = sizeof(T) == 2 ? 1 : 2;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     auto kload = [&](int i0, u32x4 (&kreg)[4]) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            const int i = i0 + t + l * AT_NT;
+            const int i = i0 + t + l * NT;
             const int key = i / CPR, ch = i % CPR;
             u32x4 kv = {0u, 0u, 0u, 0u};
             if (key < Na) kv = *reinterpret_cast<const u32x4*>(base + (size_t)(tok0 + key) * ldq + h * 32 + ch * VEC + Cq);
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     auto kstore = [&](int i0, const u32x4 (&kreg)[4]) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            const int i = i0 + t + l * AT_NT;
+            const int i = i0 + t + l * NT;
             // 16-bit rows are 64 bytes: chunk c of row r goes to slot c ^ ((-(r >> 2)) & 3), which spreads the sixteen rows of a
             // ds_read_b128 lane group over the 64 banks (unswizzled, rows r and r + 4 shared their banks)
             const int slot = sizeof(T) == 2 ? (i & ~3) + ((i & 3) ^ ((0 - (i >> 4)) & 3)) : i;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     auto vload = [&](int i0, u32x4 (&v0)[4], u32x4 (&v1)[4]) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            const int i = i0 + t + l * AT_NT;
+            const int i = i0 + t + l * NT;
             const int kp = (i & 31) + ((i >> 7) << 5), ch = (i >> 5) & 3, key = 2 * kp;
             u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
             const T* p = base + (size_t)(tok0 + key) * ldq + h * 32 + ch * VEC + 2 * Cq;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     auto vstore = [&](int i0, const u32x4 (&v0)[4], const u32x4 (&v1)[4]) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            const int i = i0 + t + l * AT_NT;
+            const int i = i0 + t + l * NT;
             const int kp = (i & 31) + ((i >> 7) << 5), ch = (i >> 5) & 3;
             if (kp < Nk / 2) {
                 uint32_t* d = reinterpret_cast<uint32_t*>(sVt) + kp;
@@ -396,13 +398,13 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         // the whole head in ONE round trip: 8 K + 8 V loads per thread in flight (three dependent round trips in the loops below)
         u32x4 ka[4], kb[4], v0[4], v1[4];
         kload(0, ka);
-        kload(AT_NT * 4, kb);
+        kload(NT * 4, kb);
         vload(0, v0, v1);
         kstore(0, ka);
-        kstore(AT_NT * 4, kb);
+        kstore(NT * 4, kb);
         vstore(0, v0, v1);
     } else {
-        for (int i0 = 0; i0 < Nr * CPR; i0 += AT_NT * 4) {
+        for (int i0 = 0; i0 < Nr * CPR; i0 += NT * 4) {
             u32x4 kreg[4];
             kload(i0, kreg);
             kstore(i0, kreg);
@@ -410,17 +412,17 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     }
     if (sizeof(T) == 2 && Na <= 512) {
     } else if constexpr (sizeof(T) == 2) {
-        for (int i0 = 0; i0 < (Nk / 2) * CPR; i0 += AT_NT * 4) {
+        for (int i0 = 0; i0 < (Nk / 2) * CPR; i0 += NT * 4) {
             u32x4 v0[4], v1[4];
             vload(i0, v0, v1);
             vstore(i0, v0, v1);
         }
     } else {
-        for (int i0 = 0; i0 < Nk * CPR; i0 += AT_NT * 4) {
+        for (int i0 = 0; i0 < Nk * CPR; i0 += NT * 4) {
             u32x4 vreg[4];
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
-                const int i = i0 + t + l * AT_NT;
+                const int i = i0 + t + l * NT;
                 const int key = i / CPR, ch = i % CPR;
                 u32x4 vv = {0u, 0u, 0u, 0u};
                 if (key < Na) vv = *reinterpret_cast<const u32x4*>(base + (size_t)(tok0 + key) * ldq + h * 32 + ch * VEC + 2 * Cq);
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             }
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
-                const int i = i0 + t + l * AT_NT;
+                const int i = i0 + t + l * NT;
                 const int key = i / CPR, ch = i % CPR;
                 if (key < Nk) {
                     const T* ve = reinterpret_cast<const T*>(&vreg[l]);
@@ -454,10 +456,10 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         }
     };
     qload(wave * 16, qn);
-    for (int q0 = wave * 16; q0 < Na; q0 += (AT_NT / 64) * 16) {
+    for (int q0 = wave * 16; q0 < Na; q0 += (NT / 64) * 16) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) qf[f] = qn[f];
-        qload(q0 + (AT_NT / 64) * 16, qn);   // the next tile's queries arrive during this tile (a global round trip per tile otherwise)
+        qload(q0 + (NT / 64) * 16, qn);   // the next tile's queries arrive during this tile (a global round trip per tile otherwise)
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float mrun = -INFINITY, lrun = 0.f;
         int c0 = 0;
@@ -485,18 +487,18 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     }
 }
 
-template <typename T, int WPE>
+template <typename T, int WPE, int NT = AT_NT>
 static int launch_attn_resident(const T* qkv, int ldq, T* out, int ldo, int B, int N, int Na, int heads, int area, float scale,
                                 hipStream_t s) {
     const int Nk = (Na + 31) & ~31, Nr = (Na + 15) & ~15;
     const size_t shm = ((size_t)Nr * 32 + (size_t)32 * (Nk + (sizeof(T) == 2 ? 4 : 16 / sizeof(T)))) * sizeof(T);
     static YmkOncePerDevice attr_once;
     if (shm > 64 * 1024 && attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&area_attn_resident_kernel<T, WPE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&area_attn_resident_kernel<T, WPE, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_once.done();
     }
-    hipLaunchKernelGGL((area_attn_resident_kernel<T, WPE>), dim3((unsigned)((size_t)B * area * heads)), dim3(AT_NT), shm, s, qkv, ldq,
+    hipLaunchKernelGGL((area_attn_resident_kernel<T, WPE, NT>), dim3((unsigned)((size_t)B * area * heads)), dim3(NT), shm, s, qkv, ldq,
                        out, ldo, N, Na, heads, area, scale);
     return ymk_launch_status();
 }
@@ -518,8 +520,19 @@ extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* 
     const float scale = 0.17677669529663687f;  // 32^-0.5
     hipStream_t s = (hipStream_t)stream;
     if (!(ymk_disabled() & YMK_OFF_ATTN_RESIDENT) && (int64_t)B * area * heads < (1ll << 31)) {
-        if (dtype == YMK_BF16 && Na <= 1024)
+        if (dtype == YMK_BF16 && Na <= 1024) {
+            // waves per workgroup: the count that leaves the fewest tile-times per workgroup among 4 / 5 / 6 (ties: fewer waves), unless
+            // YMK_ATTN_WAVES forces one (A/B runs)
+            static const int forced = [] { const char* e = getenv("YMK_ATTN_WAVES"); return e ? atoi(e) : 0; }();
+            const int tiles = (Na + 15) / 16;
+            int nw = 4;
+            for (int w = 5; w <= 6; ++w)
+                if ((tiles + w - 1) / w < (tiles + nw - 1) / nw) nw = w;
+            if (forced >= 4 && forced <= 6) nw = forced;
+            if (nw == 5) return launch_attn_resident<h16_t, 3, 320>((const h16_t*)qkv, ldq, (h16_t*)out, ldo, B, N, Na, heads, area, scale, s);
+            if (nw == 6) return launch_attn_resident<h16_t, 3, 384>((const h16_t*)qkv, ldq, (h16_t*)out, ldo, B, N, Na, heads, area, scale, s);
             return launch_attn_resident<h16_t, 3>((const h16_t*)qkv, ldq, (h16_t*)out, ldo, B, N, Na, heads, area, scale, s);
+        }
         if (dtype == YMK_F32 && Na <= 512)
             return launch_attn_resident<float, 1>((const float*)qkv, ldq, (float*)out, ldo, B, N, Na, heads, area, scale, s);
     }

@@ -1,5 +1,7 @@
 // Detect class branch as ONE kernel (bf16): DWConv3x3 -> Conv1x1 -> DWConv3x3 -> Conv1x1 -> Conv2d 1x1 (+bias) -> fp32 class logits and / or
-// (round 4) their sigmoid straight into the class rows of y plus every anchor's best class: the decode's class half in the epilogue
+// (round 4) their sigmoid straight into the class rows of y plus every anchor's best class: the decode's class half in the epilogue —
+// WITHIN TOLERANCE of detect_decode_kernel's scores, not bit-identical to them: the epilogue's sigmoid is v_exp_f32 + v_rcp_f32 (<= 2 ulp
+// of the libm expression; dc_sigmoid below), bounded on the GPU by tests/test_gpu_model.py::test_fused_decode_scores_within_ulps_and_same_nms
 // (ultralytics/nn/modules/head.py:111-118: `cv3[i] = Sequential(Sequential(DWConv(x, x, 3), Conv(x, c3, 1)),
 // Sequential(DWConv(c3, c3, 3), Conv(c3, c3, 1)), Conv2d(c3, nc, 1))`, every Conv / DWConv = convolution + folded BN + SiLU), for
 // c3 = 128 and x = 128 or 256 input channels (the three pyramid levels of YOLO-Master-S / -N ...: c3 = max(ch[0], min(nc, 100))).

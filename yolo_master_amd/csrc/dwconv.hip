@@ -236,7 +236,7 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
             // ALL LDS reads of this filter row (K taps + DW_R + K - 1 pixels) are issued before the first use.  Left to itself the
             // compiler reads one or two operands at a time and waits for each (`ds_read2_b64; s_waitcnt lgkmcnt(0)`, 14 times per row at
             // k = 9): one LDS round trip per pair of operands beside ~20 packed FMAs — what kept this kernel at 0.4 of the VALU rate
-            // with four waves per SIMD (found in the ISA of csrc/esfused.hip's stencil, round 4).  Same arithmetic, same order.
+            // with four waves per SIMD (found in the ISA of the round-4 one-kernel form's stencil, tools/micro/parked/esfused.hip.txt).  Same arithmetic, same order.
             typedef typename Raw4<T>::type raw_t;
             raw_t rw[K + 1], rd[DW_R + K - 1];
             if constexpr (PLANAR) {

@@ -906,7 +906,7 @@ __global__ __launch_bounds__(512) void moe_pw_lean_kernel(MoePwArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         // 16-bit builds: the weighted expert output is a ROUNDED product that is then added (modules.py:697-702:
                         // `expert_out * w`, index_add_) — no FMA contraction, so the sum of an image's two experts does not depend on
-                        // the order they are visited in (it alternates tile by tile here; csrc/esfused.hip visits them in slot order
+                        // the order they are visited in (it alternates tile by tile here; the one-kernel form of round 4, tools/micro/parked/esfused.hip.txt, visits them in slot order
                         // and must produce the same bits).  fp32 keeps the arithmetic its fixtures were recorded with.
                         if constexpr (PRECISE) v[r] = silu_exact(acc[q][jj][r]) * gw;
                         else v[r] = ymk_mul_rn(silu_f(acc[q][jj][r]), gw);

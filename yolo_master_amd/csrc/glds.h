@@ -1,4 +1,4 @@
-// LDS-DMA helpers shared by the kernels that stage operands with `buffer_load_dwordx4 ... lds` (csrc/conv_glds.hip, csrc/esfused.hip):
+// LDS-DMA helpers shared by the kernels that stage operands with `buffer_load_dwordx4 ... lds` (csrc/conv_glds.hip; tools/micro/parked/esfused.hip.txt used them too):
 // raw buffer resources, the load itself, and the wait / fence idioms around a workgroup barrier.  tests/hostemu provides plain-pointer
 // stand-ins (the transfer completes at once there, so counted-vmcnt mistakes are invisible on the emulator; addressing and masks are not).
 #pragma once

@@ -145,12 +145,15 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const float* __restrict_
 
 // ---- 1b. the same from the per-anchor best class the producer of y already wrote (ymk_detect_decode): single-label only ---------
 // w.bconf / w.bcls point at the producer's arrays; the nc class rows of y are not read.
-__global__ __launch_bounds__(256) void nms_count_best_kernel(int A, float conf, const unsigned char* __restrict__ class_keep, NmsWs w) {
+__global__ __launch_bounds__(256) void nms_count_best_kernel(int A, int nc, float conf, const unsigned char* __restrict__ class_keep, NmsWs w) {
     __shared__ int wsum[4];
     const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
     int c = 0;
     if (a < A) {
-        c = (w.bconf[(size_t)b * A + a] > conf) && (!class_keep || class_keep[w.bcls[(size_t)b * A + a]]);
+        // the class id is the PRODUCER's (Detect's decode epilogue): an id outside [0, nc) — a caller that handed over its own arrays — is
+        // not a candidate rather than an index into class_keep
+        const unsigned cls = (unsigned)w.bcls[(size_t)b * A + a];
+        c = (w.bconf[(size_t)b * A + a] > conf) && cls < (unsigned)nc && (!class_keep || class_keep[cls]);
         w.cnt[(size_t)b * A + a] = c;
     }
     int s = c;
@@ -715,7 +718,7 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t ex
     if (best_conf && best_cls && !multi) {   // the producer's per-anchor best class (ymk_detect_decode): no pass over the class rows
         w.bconf = const_cast<float*>(best_conf);
         w.bcls = const_cast<int*>(best_cls);
-        hipLaunchKernelGGL(nms_count_best_kernel, dim3(w.nblk, B), dim3(256), 0, s, A, conf_thres, class_keep, w);
+        hipLaunchKernelGGL(nms_count_best_kernel, dim3(w.nblk, B), dim3(256), 0, s, A, nc, conf_thres, class_keep, w);
     } else {
         hipLaunchKernelGGL(nms_count_kernel, dim3(w.nblk, B), dim3(256), 0, s, y, nc, A, conf_thres, multi, class_keep, w);
     }

@@ -35,13 +35,14 @@ def class_keep_mask(classes, nc: int, device) -> torch.Tensor:
 
 
 def nms_padded(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, agnostic=False, multi_label=False,
-               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1, classes=None, pack=None, nc=0):
+               max_det=300, max_nms=30000, max_wh=7680, cluster=False, sigma=0.1, classes=None, pack=None, nc=0, use_best=True):
     """prediction: [B, 4+nc(+extra), A] fp32 on the GPU.  Returns (dets [B,max_det,6], counts [B], idx [B,max_det],
     status [1]) without synchronising.  classes: list of class ids or a ready uint8 [nc] device mask.
     pack: optional float32 [ops.nms_pack_numel(B, max_det)] buffer the outputs are carved from (one allocation: a multi-GPU
     step gathers it with a single collective, dist.gather_packed).
     nc: number of classes when rows are carried behind the class rows (Segment: utils/nms.py:76-81); their values for the kept
-    detections: ops.nms_gather_rows(prediction, nc, idx, counts)."""
+    detections: ops.nms_gather_rows(prediction, nc, idx, counts).
+    use_best=False: never take the producer's per-anchor best class attached to `prediction` ("the y.best contract")."""
     if prediction.dtype != torch.float32:
         prediction = prediction.float()
     prediction = prediction.contiguous()
@@ -49,13 +50,14 @@ def nms_padded(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, agnost
     if classes is not None and not (torch.is_tensor(classes) and classes.dtype == torch.uint8):
         classes = class_keep_mask(classes, nc, prediction.device)
     return ops.nms_batched(prediction, conf_thres, iou_thres, bool(multi_label) and nc > 1, bool(agnostic), max_det,
-                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None, class_keep=classes, pack=pack, nc=nc)
+                           max_nms, float(max_wh), cw_sigma=float(sigma) if cluster else None, class_keep=classes, pack=pack, nc=nc,
+                           use_best=use_best)
 
 
 def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float = 0.45, classes=None,
                         agnostic: bool = False, multi_label: bool = False, labels=(), max_det: int = 300, nc: int = 0,
                         max_time_img: float = 0.05, max_nms: int = 30000, max_wh: int = 7680, rotated: bool = False,
-                        end2end: bool = False, return_idxs: bool = False, cluster: bool = False, sigma: float = 0.1):
+                        end2end: bool = False, return_idxs: bool = False, cluster: bool = False, sigma: float = 0.1, use_best: bool = True):
     assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
     if isinstance(prediction, (list, tuple)):
@@ -69,7 +71,7 @@ def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float =
     if prediction.dtype != torch.float32 or not prediction.is_contiguous():
         prediction = prediction.float().contiguous()
     dets, counts, idx, status = nms_padded(prediction, conf_thres, iou_thres, agnostic, multi_label, max_det, max_nms,
-                                           max_wh, cluster, sigma, classes, nc=nc)
+                                           max_wh, cluster, sigma, classes, nc=nc, use_best=use_best)
     if extra:                                   # output rows are (xyxy, conf, cls, mask...) as in the reference (:117,122,127)
         dets = torch.cat([dets, ops.nms_gather_rows(prediction, nc, idx, counts)], 2)
     n = counts.tolist()  # the one host sync of the post-processing step

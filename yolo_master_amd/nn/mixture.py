@@ -1325,7 +1325,7 @@ class _DeformableTransformerExpert(nn.Module):
         return _run_token_ffn(x1, self.ffn, self.norm2, self.ls2, pk)
 
 
-class _MoTRouter(nn.Module):
+class _MoTRouter(nn.Module):  # noqa: E302
     """mot/router.py:57-160: parameters of the token-level (1x1 -> GroupNorm -> SiLU -> 1x1) or image-level (GAP -> Linear -> SiLU ->
     Linear) router and of the optional scene-aware residual (Linear(3, h) -> SiLU -> Linear(h, E) on three statistics of the routed map,
     :145-160).  Same parameter names as the reference; the arithmetic is MoTBlock._route."""
@@ -1347,12 +1347,25 @@ class _MoTRouter(nn.Module):
         self.scene_aware = False
         self.scene_hidden_dim = scene_hidden_dim
         self.scene_projector = None
-        self.last_scene_stats = self.last_scene_bias = None
+        self.last_scene_stats = None
+        self._last_scene_bias = None
         self.last_scene_applied = False
         self.last_scene_bypass_reason = None
         self.set_scene_inference_mode(scene_inference_mode)
         if scene_aware:
             self.enable_scene_aware(scene_hidden_dim)
+
+    @property
+    def last_scene_bias(self):
+        """The scene projector's per-image logit residual of the last forward (mot/router.py:224-240); None when not applied."""
+        v = self._last_scene_bias
+        if callable(v):
+            v = self._last_scene_bias = v()
+        return v
+
+    @last_scene_bias.setter
+    def last_scene_bias(self, v):
+        self._last_scene_bias = v
 
     def set_scene_inference_mode(self, mode):
         """mot/router.py:138-143."""
@@ -1474,7 +1487,10 @@ class MoTBlock(YmkModule):
                 raise RuntimeError("scene-aware MoT router is enabled without a scene projector")
             stats, bias = ops.scene_bias(x, sc["w1"], sc["b1"], sc["w2"], sc["b2"], base=base)
             rt.last_scene_stats = stats
-            rt.last_scene_bias = bias if base is None else None   # (with an image-level router the kernel returns logits + bias)
+            # mot/router.py:224-240 publishes the PURE scene bias.  With an image-level router the kernel returns base logits + bias in one
+            # pass (what the softmax consumes); the diagnostic is then the second call's output without the base — off the hot path: only
+            # when somebody reads it (`_MoTRouter.last_scene_bias` resolves the thunk)
+            rt.last_scene_bias = bias if base is None else (lambda: ops.scene_bias(x, sc["w1"], sc["b1"], sc["w2"], sc["b2"], base=None)[1])
         return ops.token_softmax(logits, self.NUM_EXPERTS, pk["inv_temp"], top_k=self.top_k, bias=bias, shape=(B, H, W))
 
     def _run(self, x, out=None):

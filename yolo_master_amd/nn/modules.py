@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..options import OPTIONS
 from ..errors import MoERouterError, ShapeMismatchError
 
 __all__ = [
@@ -270,21 +271,9 @@ class Bottleneck(YmkModule):
         self.cv2 = Conv(c_, c2, k[1], 1, g=g)
         self.add = shortcut and c1 == c2
 
-    # Both 3x3s of a 64-channel block as ONE kernel (csrc/bneck.hip: x tile and the intermediate in LDS, weights streamed tap by tap).
-    # Correct (emulator + MI355X vs the two convolutions) and NOT faster: 45-48 us against 36-42 us for the pair at 40^2, 24 against 26-32 at
-    # 20^2, bench -0.6 % (profiles/r04_negative_results.txt item 16) -> off; YMK_ENABLE bit 512 switches it on for A/B runs.
-    fuse_pair = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 512)
-
-    def _fusable(self, x):
-        a, b = self.cv1, self.cv2
-        return (self.fuse_pair and a.conv.kernel_size == b.conv.kernel_size == (3, 3) and a.conv.stride == b.conv.stride == (1, 1) and a.conv.groups == b.conv.groups == 1
-                and _is_silu(a.act) and _is_silu(b.act) and a.cout_perm is None and b.cout_perm is None
-                and ops.bottleneck_fused_supported(x.dtype, a.conv.in_channels, a.conv.out_channels, b.conv.out_channels))
-
     def _run(self, x, out=None):
-        if self._fusable(x):   # both 3x3s as one kernel: the 64-channel intermediate stays in LDS (csrc/bneck.hip; the head's C3k blocks)
-            p1, p2 = self.cv1._packed(x.device), self.cv2._packed(x.device)
-            return ops.bottleneck_fused(x, p1["w"], p1["b"], p2["w"], p2["b"], self.add, out=out)
+        # (both 3x3s of a 64-channel block as one kernel was built, validated and measured 10-25 % slower than the pair on the LDS-DMA core:
+        # tools/micro/parked/bneck.hip.txt, profiles/r04_negative_results.txt item 16)
         h = self.cv1._run(x)
         return self.cv2._run(h, out=out, residual=x if self.add else None)
 
@@ -422,16 +411,19 @@ class AAttn(YmkModule):
         d, h = head_dim, num_heads
         self.qkv.cout_perm = [hh * 3 * d + part * d + dd for part in range(3) for hh in range(h) for dd in range(d)]
 
-    def _run(self, x, out=None, residual=None):
-        """Returns residual + proj(attn(x) + pe(v)) (residual = the ABlock skip input)."""
+    def _pre_proj(self, x):
+        """attn(x) + pe(v): the projection's input (block.py:1696-1731)."""
         B, H, W, _ = x.shape
         if (H * W) % self.area:
             raise ValueError(f"AAttn: {H}x{W} tokens not divisible by area={self.area}")
         qkv = self.qkv._run(x)
         c = self.all_head_dim
         att = ops.area_attn(qkv, self.num_heads, self.area)
-        att = self.pe._run(qkv[..., 2 * c:], residual=att)  # x + pe(v)
-        return self.proj._run(att, out=out, residual=residual)
+        return self.pe._run(qkv[..., 2 * c:], residual=att)  # x + pe(v)
+
+    def _run(self, x, out=None, residual=None):
+        """Returns residual + proj(attn(x) + pe(v)) (residual = the ABlock skip input)."""
+        return self.proj._run(self._pre_proj(x), out=out, residual=residual)
 
 
 class ABlock(YmkModule):
@@ -461,8 +453,14 @@ class ABlock(YmkModule):
                 nn.init.constant_(m.bias, 0)
 
     def _run(self, x, out=None):
-        x1 = self.attn._run(x, residual=x)              # x + attn(x)
         m0, m1 = self.mlp[0], self.mlp[1]
+        pj = self.attn.proj
+        if (ops.proj_mlp_fused_supported(x.dtype, x.shape[-1], m0.conv.out_channels) and _is_silu(m0.act) and not _is_silu(m1.act)
+                and not _is_silu(pj.act) and pj.conv.kernel_size == (1, 1) and pj.cout_perm is None and self.attn.all_head_dim == x.shape[-1]):
+            # the block's tail as ONE kernel: x1 = x + proj(attn(x) + pe(v)) stays in LDS and feeds x1 + mlp(x1) (csrc/mlp.hip PROJ)
+            pp, p0, p1 = pj._packed(x.device), m0._packed(x.device), m1._packed(x.device)
+            return ops.proj_mlp_fused(self.attn._pre_proj(x), pp["w"], pp["b"], x, p0["w"], p0["b"], p1["w"], p1["b"], out=out)
+        x1 = self.attn._run(x, residual=x)              # x + attn(x)
         if ops.mlp_fused_supported(x1.dtype, x1.shape[-1], m0.conv.out_channels) and _is_silu(m0.act) and not _is_silu(m1.act):
             p0, p1 = m0._packed(x1.device), m1._packed(x1.device)   # x + mlp(x) as one kernel: the hidden tensor never leaves the CU
             return ops.mlp_fused(x1, p0["w"], p0["b"], p1["w"], p1["b"], out=out)
@@ -536,6 +534,43 @@ class _PlainConv:
         return ops.pack_conv_weight(w, dtype), b.contiguous()
 
 
+class DetectPreds(dict):
+    """The dict Detect returns beside y in eval mode (nn/modules/head.py:157-171): "boxes" [B, 4*reg_max, A] and "scores"
+    [B, nc, A] raw logits, "feats" = the head's input maps (NCHW-logical).  Nothing on the inference path reads them
+    (predict()/val() consume y), so the three reference keys are built on first access from the per-level NHWC logits
+    ("raw", what the decode consumed) instead of being concatenated every step: layout changes only, no arithmetic.  With the fused
+    decode (Detect.fuse_decode, keep_raw False) "raw" itself is lazy: Detect.raw_logits recomputes it from "feats"."""
+
+    def __init__(self, raw, feats, reg_max, nc, raw_fn=None):
+        super().__init__()
+        self._lazy = {"boxes": lambda: self._cat(0, 4 * reg_max), "scores": lambda: self._cat(1, nc),
+                      "feats": lambda: [f.permute(0, 3, 1, 2) for f in feats]}
+        if raw_fn is not None and any(r is None for r in raw):
+            # fused decode (Detect._level): the logits stayed on chip; recomputed from the head's input maps on first access
+            self._lazy["raw"] = raw_fn
+        else:
+            self["raw"] = raw
+
+    def _cat(self, which, width):
+        lv = [r[which] for r in self["raw"]]
+        return torch.cat([t.reshape(t.shape[0], -1, width) for t in lv], 1).permute(0, 2, 1)
+
+    def __missing__(self, key):
+        if key not in self._lazy:
+            raise KeyError(key)
+        self[key] = self._lazy[key]()
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._lazy if not dict.__contains__(self, k)]
+
+
 class Detect(YmkModule):
     """Detection head (ultralytics/nn/modules/head.py:37-258): box/cls branches + DFL decode."""
 
@@ -590,8 +625,8 @@ class Detect(YmkModule):
                 "cls": [_PlainConv.pack(s[-1], dtype, device) for s in self.cv3]}
 
     # levels 1.. on side HIP streams (fork / join, also valid under graph capture): measured slower in round 1 (10.8 vs 10.1 ms/step,
-    # contention) -> off; YMK_ENABLE bit 16 switches it on for A/B runs
-    level_streams = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 16)
+    # contention) -> off; options.OPTIONS.detect_level_streams (YMK_ENABLE bit 16) switches it on for A/B runs
+    level_streams = OPTIONS.detect_level_streams
 
     def _side_streams(self, device, n, main=None):
         """Side streams of the walk that runs on stream `main` (two concurrent walks of one model — bench.py --split — must not share them)."""
@@ -627,8 +662,8 @@ class Detect(YmkModule):
     # head — so that the level's large kernels overlap the latency-bound 40^2 / 20^2 launches of the rest of the neck (fork / join by
     # events: parallel branches of the captured graph).  `begin` allocates y, `start_level` forks, `finish` runs what is left and joins.
     # Measured (round 3, profiles/r03_negative_results.txt): +0.3 % on the one-stream step (6.049 -> 6.032 ms) — the levels' kernels and the
-    # neck's do not overlap enough to matter — and nothing on top of bench.py's two concurrent sub-batches: OFF; YMK_ENABLE bit 32 for A/B runs.
-    early_levels = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 32)
+    # neck's do not overlap enough to matter — and nothing on top of bench.py's two concurrent sub-batches: OFF; options.OPTIONS.detect_early_levels (YMK_ENABLE bit 32) for A/B runs.
+    early_levels = OPTIONS.detect_early_levels
 
     def begin(self, B, level_hw, device):
         """level_hw: [(H_l, W_l)] of every pyramid level.  Returns the run state (y, anchor offsets, raw slots)."""
@@ -649,9 +684,9 @@ class Detect(YmkModule):
     # (ops.detect_box_tail, ops.detect_cls_fused(y=...)): no detect_decode launch, and with keep_raw False the fp32 logits — 0.6 KB per
     # anchor written and read back — never reach HBM.  The reference's eval-mode `preds` (head.py:157-171) stays available: nothing
     # on the predict / val path reads it, so DetectPreds recomputes the logits on first access (raw_logits) from the head's inputs.
-    # YMK_DISABLE bit 4194304: the unfused path; YMK_ENABLE bit 256: fused, logits materialised too.
-    fuse_decode = True
-    keep_raw = bool(int(__import__("os").environ.get("YMK_ENABLE", "0"), 0) & 256)
+    # options.OPTIONS.fused_decode off (YMK_DISABLE bit 4194304): the unfused path; .detect_keep_raw (YMK_ENABLE bit 256): fused, logits materialised too.
+    fuse_decode = True          # (ops.detect_box_tail_supported consults OPTIONS.fused_decode)
+    keep_raw = OPTIONS.detect_keep_raw
 
     def _cls_weights(self, i, device):
         s0, s1 = self.cv3[i][0], self.cv3[i][1]
@@ -664,7 +699,10 @@ class Detect(YmkModule):
             raise ValueError(f"Detect level {i}: map {tuple(f.shape[1:3])}, expected {st['hw'][i]}")
         hb = self._branch(self.cv2[i], f)
         cls_fused = self._cls_fusable(i, f)
-        if not raw_only and self.fuse_decode and cls_fused and ops.detect_box_tail_supported(hb.dtype, hb.shape[-1], self.reg_max, self.nc):
+        # (the fused pair's entry points also want 16-byte aligned bases and pixel strides that are multiples of 8 elements: true of every
+        # buffer the walk hands over, checked here so that a foreign view takes the unfused path instead of failing with YMK_E_BADARG)
+        ok16 = all(t.data_ptr() % 16 == 0 and (t.shape[2] == 1 or t.stride(2) % 8 == 0) for t in (hb, f))
+        if not raw_only and self.fuse_decode and cls_fused and ok16 and ops.detect_box_tail_supported(hb.dtype, hb.shape[-1], self.reg_max, self.nc):
             y, keep = st["y"], self.keep_raw
             box = ops.detect_box_tail(hb, pk["box"][i][0], pk["box"][i][1], y, float(self.stride[i]), st["offs"][i], self.reg_max, raw=keep)
             cls = ops.detect_cls_fused(f, *self._cls_weights(i, f.device), pk["cls"][i], y=y, nc=self.nc, a_off=st["offs"][i], raw=keep)
@@ -737,12 +775,11 @@ class Detect(YmkModule):
         y, raw = self._run(feats)
         if self.export:
             return y
-        if any(r is None for r in raw):
-            raw = self.raw_logits(feats)
-        B = y.shape[0]
-        boxes = torch.cat([b.reshape(B, -1, 4 * self.reg_max) for b, _ in raw], 1).permute(0, 2, 1)
-        scores = torch.cat([c.reshape(B, -1, self.nc) for _, c in raw], 1).permute(0, 2, 1)
-        return y, dict(boxes=boxes, scores=scores, feats=list(x))
+        # the reference's eval-mode dict (head.py:157-171), lazily: with the fused decode the logits were never materialised, and nothing
+        # on the predict / val path reads them — "boxes" / "scores" / "raw" re-run the head's branches on first access only
+        preds = DetectPreds(raw, feats, self.reg_max, self.nc, raw_fn=lambda: self.raw_logits(feats))
+        dict.__setitem__(preds, "feats", list(x))   # the maps as they were handed in
+        return y, preds
 
 
 class Proto(YmkModule):
@@ -864,11 +901,9 @@ class ES_MOE(YmkModule):
     batch's device flag word is checked (``check_flags``), not through a per-layer host sync.
     """
 
-    # The expert body as ONE wave-specialised kernel per layer (csrc/esfused.hip, round 4; 16-bit modes, C in {128, 256}, top_k <= 2):
-    # bit-identical to the two-kernel form and validated on MI355X, but measured SLOWER (layer 3 of the S detector at batch 64: 1.10 ms
-    # against 0.44 + 0.23 ms; stage ablation in profiles/r04_esfused_ablation.txt: one stencil wave per SIMD cannot hide its LDS round
-    # trips, and the matrix waves' transfer -> MFMA -> epilogue phases run in lock step) -> off by default, YMK_ENABLE=64 turns it on.
-    fuse_layer = bool(ops.ymk_enabled_bits() & 64)
+    # (The expert body as ONE wave-specialised kernel per layer — halo staged once for both experts, stencil waves -> LDS tile -> matrix
+    # waves — was built in round 4, is bit-identical to the two-kernel form and 1.65x slower: tools/micro/parked/esfused.hip.txt,
+    # profiles/r04_esfused_ablation.txt.  It left the library and the ABI in round 5.)
 
     def __init__(self, in_channels, out_channels=None, num_experts=4, reduction=8, top_k=2, use_sparse_inference=True,
                  dynamic_threshold=0.4, max_kernel_size=15, expert_kernel_sizes=None):
@@ -1033,19 +1068,33 @@ class ES_MOE(YmkModule):
         thr = float(self.dynamic_threshold) if self._eager_sparse_enabled() else -1.0
         route_w, gate_w, sel, csr_off, csr_pair, state = ops.esmoe_route(
             x, pk["w1"], pk["b1"], pk["w2"], pk["b2"], top_k, thr, self._flags)
-        if self.fuse_layer and ops.esmoe_fused_supported(x.dtype, C, self.out_channels, H, W, pk["kmax"], self.num_experts, top_k):
-            # the whole expert body as one wave-specialised kernel (csrc/esfused.hip): the halo of x staged once for both retained
-            # experts of an image, the depthwise tile handed to the matrix cores through LDS — no dw_out buffer, bit-identical results
-            y = ops.esmoe_fused(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel,
-                                gate_w, out=out)
-        else:
+        cb = self._chunk_images(B, H, W, C, top_k, x.element_size())
+        if cb >= B:
             dw = ops.esmoe_dw(x, pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel, csr_off, csr_pair)
             y = ops.esmoe_pw(dw, B, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel, gate_w, out=out)
+        else:
+            # The depthwise planes of `cb` images at a time: written by one stage and read by the next while they are still in the
+            # 256 MB memory-side cache (all 2 x 64 planes of layer 3 are 840 MB: every byte went out to HBM and came back).  The same
+            # kernels on image sub-ranges — per image nothing changes (images are independent through both stages).
+            y = out if out is not None else ops.new_act(B, H, W, self.out_channels, x.dtype, x.device)
+            for b0 in range(0, B, cb):
+                b1 = min(B, b0 + cb)
+                dw = ops.esmoe_dw(x[b0:b1], pk["dw_w"], pk["dw_off"], pk["ks"], pk["kmax"], top_k, sel[b0:b1], csr_off, csr_pair)
+                ops.esmoe_pw(dw, b1 - b0, H, W, pk["pw_w"], pk["pw_b"], pk["ns"], pk["nt"], top_k, sel[b0:b1], gate_w[b0:b1], out=y[b0:b1])
         # eval-time state the reference keeps (modules.py:706-741), computed by the router's last kernel: views, no arithmetic
         self.expert_usage_counts = state[: self.num_experts]
         self.load_balancing_loss = state[self.num_experts]
         self.last_route = {"route_w": route_w, "gate_w": gate_w, "sel": sel, "csr_off": csr_off, "csr_pair": csr_pair}
         return y
+
+    # depthwise planes kept in flight between the two expert stages (MB); 0 = the whole batch in one pass (yolo_master_amd/options.py)
+    chunk_mb = OPTIONS.moe_chunk_mb
+
+    def _chunk_images(self, B, H, W, C, top_k, es):
+        if self.chunk_mb <= 0:
+            return B
+        per_image = top_k * H * W * C * es
+        return max(1, min(B, int(self.chunk_mb * 1e6 // per_image)))
 
     def check_flags(self):
         """Host-side check of the device flag word (one sync); raises the reference's exception types."""

@@ -22,7 +22,7 @@ import yaml
 
 from .. import ops
 from .mixture import MIXTURE_BOUNDARY_MODULES, MIXTURE_BOUNDARY_REPEAT
-from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DWConv, LazyUpsample, Segment,
+from .modules import (A2C2f, C2f, C3, C3k, C3k2, ES_MOE, Bottleneck, Concat, Conv, Detect, DetectPreds, DWConv, LazyUpsample, Segment,
                       VirtualCat, YmkModule, _is_silu, set_compute_dtype)
 
 CFG_DIR = Path(__file__).resolve().parent.parent / "cfg"
@@ -360,43 +360,6 @@ def _logical_elems(v) -> int:
     if isinstance(v, (list, tuple)):
         return sum(_logical_elems(p) for p in v)
     return 0
-
-
-class DetectPreds(dict):
-    """The dict Detect returns beside y in eval mode (nn/modules/head.py:157-171): "boxes" [B, 4*reg_max, A] and "scores"
-    [B, nc, A] raw logits, "feats" = the head's input maps (NCHW-logical).  Nothing on the inference path reads them
-    (predict()/val() consume y), so the three reference keys are built on first access from the per-level NHWC logits
-    ("raw", what the decode consumed) instead of being concatenated every step: layout changes only, no arithmetic.  With the fused
-    decode (Detect.fuse_decode, keep_raw False) "raw" itself is lazy: Detect.raw_logits recomputes it from "feats"."""
-
-    def __init__(self, raw, feats, reg_max, nc, raw_fn=None):
-        super().__init__()
-        self._lazy = {"boxes": lambda: self._cat(0, 4 * reg_max), "scores": lambda: self._cat(1, nc),
-                      "feats": lambda: [f.permute(0, 3, 1, 2) for f in feats]}
-        if raw_fn is not None and any(r is None for r in raw):
-            # fused decode (Detect._level): the logits stayed on chip; recomputed from the head's input maps on first access
-            self._lazy["raw"] = raw_fn
-        else:
-            self["raw"] = raw
-
-    def _cat(self, which, width):
-        lv = [r[which] for r in self["raw"]]
-        return torch.cat([t.reshape(t.shape[0], -1, width) for t in lv], 1).permute(0, 2, 1)
-
-    def __missing__(self, key):
-        if key not in self._lazy:
-            raise KeyError(key)
-        self[key] = self._lazy[key]()
-        return dict.__getitem__(self, key)
-
-    def __contains__(self, key):
-        return dict.__contains__(self, key) or key in self._lazy
-
-    def get(self, key, default=None):
-        return self[key] if key in self else default
-
-    def keys(self):
-        return list(dict.keys(self)) + [k for k in self._lazy if not dict.__contains__(self, k)]
 
 
 class SegmentationModel(DetectionModel):

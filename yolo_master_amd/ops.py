@@ -16,6 +16,7 @@ import threading
 
 from . import _lib
 from ._lib import ConvDesc, check
+from .options import OPTIONS
 
 # Element types.  libymk has ONE 16-bit element type per build (include/ymk.h YMK_H16): bfloat16 in libymk.so, IEEE binary16 in
 # libymk_f16.so (the same sources and C-ABI compiled with -DYMK_H16_F16) — the reference's `half=True` mode is fp16.
@@ -105,7 +106,7 @@ def conv_kernel_name(variant: int, dtype, cin: int, cout: int, k: int, kpad: int
     if variant == 1:
         return f"conv1x1_ws_kernel<{t}, {kpad * es // 128}, {'true' if cout % 64 == 0 else 'false'}>"   # whole 64-cout groups: permuted rows
     if variant == 2:
-        prefetch = residual and not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 16)
+        prefetch = residual and OPTIONS.res_prefetch
         return f"conv3x3_tile_kernel<{t}, {cin}, {32 if cout <= 32 else 64}, {'true' if prefetch else 'false'}>"
     return f"conv_igemm_kernel<{t}, {_tile(cout)}, {k}, false>"
 
@@ -262,7 +263,7 @@ def conv2d_stem(x_nchw, w, bias, k: int, stride: int, act: bool, dtype: torch.dt
 def stem_pair_supported(dtype, cin: int, c0: int, c1: int, k0: int, s0: int, k1: int, s1: int) -> bool:
     """YMK_DISABLE bit 2048 switches the fused stem + row-1 kernel off (-> conv2d_stem + conv2d) for A/B runs."""
     return dtype in DT and bool(lib.ymk_stem_pair_supported(DT[dtype], cin, c0, c1, k0, s0, k1, s1)) and \
-        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 2048)
+        OPTIONS.fused_stem_pair
 
 
 def stem_pair(x_nchw, wt0, b0, w1, b1, out=None):
@@ -287,7 +288,7 @@ def stem_pair(x_nchw, wt0, b0, w1, b1, out=None):
 def c3k2_fused_supported(dtype, c1: int, c2: int, c: int, n: int, c3k: bool, shortcut: bool) -> bool:
     """YMK_DISABLE bit 8192 switches the fused C3k2 block off (-> its four convolutions) for A/B runs."""
     return dtype in DT and bool(lib.ymk_c3k2_fused_supported(DT[dtype], c1, c2, c, n, int(bool(c3k)), int(bool(shortcut)))) and \
-        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 8192)
+        OPTIONS.fused_c3k2
 
 
 def c3k2_fused(x, p1, pa, pb, p2, out=None, pool=True):
@@ -310,30 +311,10 @@ def c3k2_fused(x, p1, pa, pb, p2, out=None, pool=True):
     return out
 
 
-def bottleneck_fused_supported(dtype, c1: int, c_mid: int, c2: int) -> bool:
-    """YMK_DISABLE bit 8388608 switches the fused 64-channel Bottleneck off (-> its two 3x3 convolutions) for A/B runs."""
-    return dtype in DT and bool(lib.ymk_bottleneck_fused_supported(DT[dtype], c1, c_mid, c2)) and \
-        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 8388608)
-
-
-def bottleneck_fused(x, w1, b1, w2, b2, add: bool, out=None):
-    """y = [x +] SiLU(cv2(SiLU(cv1 x))), both 3x3 64 -> 64, as one kernel (include/ymk.h ymk_bottleneck_fused).  x / out: [B,H,W,64] views
-    (channel slices of wider buffers are fine; out must not alias x)."""
-    B, H, W, Cc, ldx = _nhwc(x)
-    if out is None:
-        out = new_act(B, H, W, Cc, x.dtype, x.device)
-    ldy = _nhwc(out)[4]
-    e0 = TIMER.begin()
-    check(lib.ymk_bottleneck_fused(DT[x.dtype], _p(x), ldx, B, H, W, _p(w1), w1.shape[1], _p(b1), _p(w2), w2.shape[1], _p(b2), int(bool(add)),
-                                   _p(out), ldy, _stream()), "bottleneck_fused")
-    TIMER.end(e0, "bottleneck_fused", B * H * W * Cc * x.element_size() * 2, 2 * 2 * B * H * W * Cc * Cc * 9, f"{Cc}->{Cc}->{Cc} k3 @{H}x{W}" + (" +res" if add else ""))
-    return out
-
-
 def detect_cls_fused_supported(dtype, cin: int, c3: int, nc: int) -> bool:
     """YMK_DISABLE bit 16384 switches the fused Detect class branch off (-> its five convolutions) for A/B runs."""
     return dtype in DT and bool(lib.ymk_detect_cls_fused_supported(DT[dtype], cin, c3, nc)) and \
-        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 16384)
+        OPTIONS.fused_detect_cls
 
 
 def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None, y=None, nc=0, a_off=0, raw=True):
@@ -371,7 +352,7 @@ def detect_cls_fused(x, d1, p1, d2, p2, w3, out=None, y=None, nc=0, a_off=0, raw
 def detect_box_tail_supported(dtype, cin: int, reg_max: int, nc: int) -> bool:
     """YMK_DISABLE bit 4194304 switches the fused decode of the Detect head off (-> 1x1 convolution, fp32 logits, detect_decode)."""
     return dtype in DT and bool(lib.ymk_detect_box_tail_supported(DT[dtype], cin, reg_max, nc)) and \
-        not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 4194304)
+        OPTIONS.fused_decode
 
 
 def detect_box_tail(x, w_packed, bias, y, stride: float, a_off: int, reg_max: int, raw: bool = False):
@@ -440,8 +421,9 @@ def esmoe_dw(x, dw_w, dw_off, ksizes, kmax: int, top_k: int, sel, csr_off, csr_p
                            _p(csr_off), _p(csr_pair), _p(out), _stream()), "esmoe_dw")
     if e0 is not None:  # algorithmic traffic: every image read once, one plane written per retained (image, expert) pair
         e1 = TIMER.begin()
-        cnt = (csr_off[1:] - csr_off[:-1]).cpu()
-        npairs, k2 = int(cnt.sum()), int((cnt * ksizes.cpu().int() ** 2).sum())
+        live = (sel >= 0).reshape(-1)      # (from the selection of THIS call's images: the layer may be walked in image chunks)
+        npairs = int(live.sum())
+        k2 = int((ksizes.long()[sel.reshape(-1).clamp_min(0).long()] ** 2 * live).sum())
         TIMER.note(("moe_dw", e0, e1, (B + npairs) * H * W * Cc * x.element_size(), 2 * k2 * H * W * Cc), f"C{Cc} @{H}x{W} pairs {npairs}")
     return out
 
@@ -464,46 +446,9 @@ def esmoe_pw(dw_out, B: int, H: int, W: int, pw_w, pw_b, nscale, nshift, top_k: 
     return out
 
 
-def ymk_enabled_bits() -> int:
-    """YMK_ENABLE=<bitmask>: opt-in switches for validated-but-not-default code paths (csrc/ymk_common.h ymk_enabled)."""
-    return int(os.environ.get("YMK_ENABLE", "0"), 0)
-
-
-def esmoe_fused_supported(dtype, C: int, Cout: int, H: int, W: int, kmax: int, E: int, top_k: int) -> bool:
-    """The one-kernel expert body (csrc/esfused.hip) takes this layer.  YMK_DISABLE bit 2097152 switches it off (A/B runs: the
-    two-kernel depthwise + pointwise path computes the same bits)."""
-    if dtype not in H16 or (int(os.environ.get("YMK_DISABLE", "0"), 0) & 2097152):
-        return False
-    use_format(dtype)
-    return bool(lib.ymk_esmoe_fused_supported(DT[dtype], C, Cout, H, W, kmax, E, top_k))
-
-
-def esmoe_fused(x, dw_w, dw_off, ksizes, kmax: int, pw_w, pw_b, nscale, nshift, top_k: int, sel, gate_w, out=None):
-    """ymk_esmoe_fused (include/ymk.h): depthwise stencil -> pointwise grouped GEMM -> gate / accumulate / trailing norm of the retained
-    experts of every image in one kernel; bit-identical to esmoe_dw + esmoe_pw."""
-    B, H, W, Cc, ldx = _nhwc(x)
-    E, Cout, Kp = pw_w.shape
-    if out is None:
-        out = new_act(B, H, W, Cout, x.dtype, x.device)
-    ldy = _nhwc(out)[4]
-    e0 = TIMER.begin()
-    check(lib.ymk_esmoe_fused(DT[x.dtype], _p(x), B, H, W, Cc, ldx, _p(dw_w), _p(dw_off), _p(ksizes), kmax, Cout, Kp,
-                              _p(pw_w), _p(pw_b), _p(nscale), _p(nshift), E, top_k, _p(sel), _p(gate_w), _p(out), ldy, _stream()),
-          "esmoe_fused")
-    if e0 is not None:   # algorithmic traffic: every image in once, out once, the weights; flops of the retained (image, expert) pairs
-        e1 = TIMER.begin()
-        pairs = sel >= 0
-        npairs = int(pairs.sum())
-        k2 = float((ksizes.float()[sel.clamp_min(0).long()] ** 2 * pairs).sum()) / max(npairs, 1)     # mean stencil size of the retained pairs
-        es = x.element_size()
-        TIMER.note(("moe_fused", e0, e1, (B * H * W * (Cc + Cout) + E * Cout * Cc) * es, int(2 * npairs * H * W * Cc * (Cout + k2))),
-                   f"{Cc}->{Cout} @{H}x{W} pairs {npairs}")
-    return out
-
-
 def mlp_fused_supported(dtype, C: int, hidden: int) -> bool:
     """YMK_DISABLE bit 1024 switches the fused ABlock MLP off (-> two 1x1 convolutions) for A/B runs."""
-    return dtype in DT and bool(lib.ymk_mlp_fused_supported(DT[dtype], C, hidden)) and not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 1024)
+    return dtype in DT and bool(lib.ymk_mlp_fused_supported(DT[dtype], C, hidden)) and OPTIONS.fused_mlp
 
 
 def mlp_fused(x, w1, b1, w2, b2, out=None):
@@ -518,6 +463,30 @@ def mlp_fused(x, w1, b1, w2, b2, out=None):
     check(lib.ymk_mlp_fused(_p(x), ldx, _p(w1), w1.shape[1], _p(b1), _p(w2), w2.shape[1], _p(b2), _p(out), ldy, B * H * W, Cc, hidden,
                             _stream()), "mlp_fused")
     TIMER.end(e0, "mlp_fused", (2 * B * H * W * Cc + 2 * Cc * hidden) * x.element_size(), 4 * B * H * W * Cc * hidden, f"{Cc}->{hidden}->{Cc} @{H}x{W}")
+    return out
+
+
+def proj_mlp_fused_supported(dtype, C: int, hidden: int) -> bool:
+    """AAttn's projection + both ABlock skips + the MLP as one kernel (csrc/mlp.hip PROJ; C in {128, 256}).  OPTIONS.fused_proj_mlp off
+    (YMK_DISABLE bit 8388608): projection convolution + ymk_mlp_fused."""
+    return mlp_fused_supported(dtype, C, hidden) and C >= 128 and OPTIONS.fused_proj_mlp
+
+
+def proj_mlp_fused(a, wp, bp, x, w1, b1, w2, b2, out=None):
+    """x1 = x + Wp a + bp;  y = x1 + W2 SiLU(W1 x1 + b1) + b2 per token (include/ymk.h ymk_proj_mlp_fused): a = attention output +
+    positional stencil, x = the ABlock's input; all NHWC 16-bit views of one shape."""
+    B, H, W, Cc, lda = _nhwc(a)
+    ldx = _nhwc(x)[4]
+    assert tuple(x.shape) == tuple(a.shape)
+    hidden = w1.shape[0]
+    if out is None:
+        out = new_act(B, H, W, Cc, x.dtype, x.device)
+    ldy = _nhwc(out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_proj_mlp_fused(_p(a), lda, _p(wp), wp.shape[1], _p(bp), _p(x), ldx, _p(w1), w1.shape[1], _p(b1), _p(w2), w2.shape[1], _p(b2),
+                                 _p(out), ldy, B * H * W, Cc, hidden, _stream()), "proj_mlp_fused")
+    TIMER.end(e0, "proj_mlp_fused", (3 * B * H * W * Cc + Cc * Cc + 2 * Cc * hidden) * x.element_size(), 2 * B * H * W * Cc * (Cc + 2 * hidden),
+              f"{Cc}->{Cc}->{hidden}->{Cc} @{H}x{W}")
     return out
 
 
@@ -630,12 +599,16 @@ def nms_pack_views(pack: torch.Tensor, B: int, max_det: int):
 
 def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, max_det: int, max_nms: int,
                 max_wh: float, cw_sigma: float | None = None, cw_pool: int = 3000, class_keep: torch.Tensor | None = None,
-                pack: torch.Tensor | None = None, nc: int = 0):
+                pack: torch.Tensor | None = None, nc: int = 0, use_best: bool = True):
     """Returns (dets [B,max_det,6], counts [B] int32, idx [B,max_det] int32, status [1] int32).
     class_keep: uint8 [nc] on the GPU (the `classes=` filter, utils/nms.py:63,132) or None.
     pack: optional contiguous float32 [nms_pack_numel(B, max_det)] buffer the three outputs are carved from.
     nc: number of class rows when y carries extra rows behind them (utils/nms.py:76-81: a Segment head's mask coefficients);
-    0 = every row behind the box is a class.  The carried rows of the kept detections: nms_gather_rows."""
+    0 = every row behind the box is a class.  The carried rows of the kept detections: nms_gather_rows.
+    use_best: take the producer's per-anchor best class (`y.best`, attached by Detect) instead of a pass over the class rows when it is
+    valid for y.  CONTRACT ("y.best"): valid means attached to this very tensor and y's autograd version counter unchanged
+    since Detect stamped it — writes that bypass the counter (`y.data`, raw-pointer kernels, graph replays into the same buffer WITHOUT the
+    producer) are invisible to that check; a caller that edits y that way passes use_best=False (or deletes `y.best`)."""
     _need_gpu(y)
     assert y.dtype == torch.float32 and y.is_contiguous()
     B, ch, A = y.shape
@@ -661,7 +634,7 @@ def nms_batched(y, conf: float, iou: float, multi_label: bool, agnostic: bool, m
     # ... and only while y is untouched since (Detect.finish stamps y's version counter: an in-place edit by the caller drops it)
     best = getattr(y, "best", None)
     bc, bi = (None, None)
-    if best is not None and not multi_label and extra == 0 and tuple(best[0].shape) == (B, A) and best[0].device == dev and \
+    if use_best and best is not None and not multi_label and extra == 0 and tuple(best[0].shape) == (B, A) and best[0].device == dev and \
             len(best) == 3 and not y.is_inference() and best[2] == y._version:
         bc, bi = best[0], best[1]
     check(lib.ymk_nms_batched(_p(y), B, nc, extra, A, float(conf), float(iou), int(multi_label), int(agnostic), max_det, max_nms,
@@ -1038,6 +1011,10 @@ def moa_sparse_gate(weights, n: int, threshold: float):
     stats = torch.zeros((2 * n,), dtype=torch.float64, device=dev)          # n sums (fp64) + n maxima (the bits of non-negative floats)
     blend = torch.empty((B, H, W, n), dtype=torch.float32, device=dev)
     active = torch.empty((n,), dtype=torch.int32, device=dev)
+    if torch.cuda.is_available() and weights.is_cuda and torch.cuda.is_current_stream_capturing():
+        # the decision is read on the host (as the reference does, moa/block.py:196-202): not expressible inside a captured HIP graph
+        raise RuntimeError("MoABlock(sparse_inference=True) decides on the host which head groups run: it cannot be captured into a HIP graph "
+                           "(bench.py / serving loops replay graphs) — construct the block with sparse_inference=False for graph replay, or run eagerly")
     check(lib.ymk_moa_sparse_gate(_p(weights), ldw, B * H * W, n, float(threshold), _p(stats), _p(blend), n, _p(active), _stream()),
           "moa_sparse_gate")
     act = [bool(v) for v in active.tolist()]
@@ -1113,7 +1090,7 @@ def expert_conv(x, w_packed, k: int, idx, out=None):
         out = torch.empty((K * B, H, W, Cout), dtype=x.dtype, device=x.device)
     if not out.is_contiguous():
         raise ValueError("expert_conv: dense output")
-    if not (int(os.environ.get("YMK_DISABLE", "0"), 0) & 512) and x.dtype in H16 and Cin % 64 == 0 and Cout % 64 == 0 and Kp == k * k * Cin:
+    if OPTIONS.expert_conv_glds and x.dtype in H16 and Cin % 64 == 0 and Cout % 64 == 0 and Kp == k * k * Cin:
         # true sparse dispatch on the LDS-DMA tiled core (include/ymk_next.h): only the routed filter banks run
         d = ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, B, H, W, Cin, Cout, k, 1, _nhwc(x)[4], Cout, 0, Kp, _lib.ACT_NONE)
         check(lib.ymk_expert_conv_glds(C.byref(d), _p(x), _p(w_packed), _p(idx), K, E, _p(out),

@@ -422,8 +422,11 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         evs = []
+        host_us = []
         for i in range(a.steps):
+            t1 = time.perf_counter()
             evs.append(slots[i % P].run())
+            host_us.append((time.perf_counter() - t1) * 1e6)   # host time to ENQUEUE one step (graph replay, event records, the gather)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -566,6 +569,9 @@ def main():
                                   "p50_batch_ms": round(sync["forward_only"], 4)} if sync else None,
             "p50_inter_completion_ms_per_image": round(p50_ms / a.batch, 5),     # inverse throughput of the pipelined region, not a latency
             "p50_batch_latency_ms": round(p50_latency_ms, 4),                    # launch -> completion of one batch INSIDE the pipelined region
+            # p50 host wall time spent enqueueing one step (graph replay + events + the result gather for N > 1), rank 0: what bounds scaling once
+            # the device work is sharded — 8 ranks each pay this for their own 64 images, in parallel processes
+            "host_us_per_step_launch": round(_p50(host_us), 1),
             "config": {"workload": (f"YOLO-Master-{a.scale.upper()} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, "
                                     f"bs={a.batch}/GPU, ES-MoE top-k=2 ({cfgtag})") if a.cfg is None else
                                    f"{a.cfg} at scale {a.scale} forward+NMS, synthetic {a.imgsz}x{a.imgsz}, bs={a.batch}/GPU (not the headline configuration)",

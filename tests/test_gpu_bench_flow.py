@@ -71,6 +71,17 @@ def test_bench_rccl_code_path_at_world_size_one():
     assert e["config"]["collectives"].startswith("RCCL") and e["value"] > 0
 
 
+def test_bench_rccl_code_path_survives_many_replays():
+    """The same branch over MANY steps (>= 200 timed + the spin-up replays, three slots in flight, one all_gather per step): the process
+    group's watchdog thread passes over the work list hundreds of times while graphs replay and collectives retire — the regime of the
+    driver's 8-GPU run that a 3-step test never reaches.  Warm-up collectives are drained by completion (dist.drain_collectives), not by a
+    sleep; the line must report how much host time a step costs (`host_us_per_step_launch`: 3 graph replays + 1 gather amortised)."""
+    d = _run([sys.executable, "bench.py", "--force-dist", "--steps", "240", "--warmup", "6", "--batch", "8", "--pipeline", "3", "--no-cpu-baseline",
+              "--no-sync-leg"])
+    assert d["steps"] == 240 and d["config"]["collectives"].startswith("RCCL") and "3 batches in flight" in d["config"]["launch"]
+    assert d["value"] > 0 and d["host_us_per_step_launch"] is not None and 0 < d["host_us_per_step_launch"] < 1500
+
+
 def test_bench_config5_flags():
     """BASELINE config 5 as stated — fp16, CW-NMS, dense-scene NMS settings, expert imbalance — at a size the test box runs in seconds."""
     d = _run([sys.executable, "bench.py", "--cfg", "yolo-master-moa-mot.yaml", "--scale", "n", "--imgsz", "320", "--batch", "2", "--dtype", "f16",

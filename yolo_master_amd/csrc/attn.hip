@@ -521,14 +521,11 @@ extern "C" int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* 
     hipStream_t s = (hipStream_t)stream;
     if (!(ymk_disabled() & YMK_OFF_ATTN_RESIDENT) && (int64_t)B * area * heads < (1ll << 31)) {
         if (dtype == YMK_BF16 && Na <= 1024) {
-            // waves per workgroup: the count that leaves the fewest tile-times per workgroup among 4 / 5 / 6 (ties: fewer waves), unless
-            // YMK_ATTN_WAVES forces one (A/B runs)
+            // waves per workgroup: FOUR.  Five or six balance the 25 query tiles of a 400-token area better (5 tile-times per workgroup
+            // instead of 7) but leave two workgroups per CU instead of three at 168 registers: measured 0.54 / 0.51 ms per step against 0.41
+            // (profiles/r05_negative_results.txt).  YMK_ATTN_WAVES=5|6 forces them for A/B runs.
             static const int forced = [] { const char* e = getenv("YMK_ATTN_WAVES"); return e ? atoi(e) : 0; }();
-            const int tiles = (Na + 15) / 16;
-            int nw = 4;
-            for (int w = 5; w <= 6; ++w)
-                if ((tiles + w - 1) / w < (tiles + nw - 1) / nw) nw = w;
-            if (forced >= 4 && forced <= 6) nw = forced;
+            const int nw = (forced >= 4 && forced <= 6) ? forced : 4;
             if (nw == 5) return launch_attn_resident<h16_t, 3, 320>((const h16_t*)qkv, ldq, (h16_t*)out, ldo, B, N, Na, heads, area, scale, s);
             if (nw == 6) return launch_attn_resident<h16_t, 3, 384>((const h16_t*)qkv, ldq, (h16_t*)out, ldo, B, N, Na, heads, area, scale, s);
             return launch_attn_resident<h16_t, 3>((const h16_t*)qkv, ldq, (h16_t*)out, ldo, B, N, Na, heads, area, scale, s);

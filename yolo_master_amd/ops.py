@@ -467,8 +467,8 @@ def mlp_fused(x, w1, b1, w2, b2, out=None):
 
 
 def proj_mlp_fused_supported(dtype, C: int, hidden: int) -> bool:
-    """AAttn's projection + both ABlock skips + the MLP as one kernel (csrc/mlp.hip PROJ; C in {128, 256}).  OPTIONS.fused_proj_mlp off
-    (YMK_DISABLE bit 8388608): projection convolution + ymk_mlp_fused."""
+    """AAttn's projection + both ABlock skips + the MLP as one kernel (csrc/mlp.hip PROJ; C in {128, 256}).  OFF by default (options.py
+    fused_proj_mlp, YMK_ENABLE bit 1024): slower with several batches in flight."""
     return mlp_fused_supported(dtype, C, hidden) and C >= 128 and OPTIONS.fused_proj_mlp
 
 

@@ -181,6 +181,7 @@ static inline hostemu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigne
     return r;
 }
 static inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
+static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }
 static inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }

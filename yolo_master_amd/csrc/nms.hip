@@ -613,14 +613,24 @@ __device__ __forceinline__ float rdlane(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-__global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, float cls_off, int max_det,
-                                                        float* __restrict__ out_dets, int* __restrict__ out_counts,
-                                                        int* __restrict__ out_idx) {
+// NW waves per image (round 5: 16, was 4).  The pass is a chain of chunk steps — 64 candidates against the kept list (phase A, split
+// over the waves), against each other (phase B), an in-order resolve — and with the parity-pinned weights an image hands over a few
+// thousand candidates of which 300 survive: phase A is 64 x kept IoUs per chunk, a dependent VALU chain that ONE wave per SIMD issued at
+// a fraction of the SIMD's rate (270 us of the 320 us NMS step, profiles/r05a_step_dispatch_pmc.txt).  Sixteen waves give every SIMD four
+// chains to interleave and a quarter of the kept list each; the resolve visits only the candidates the kept list left alive.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void nms_greedy_kernel(NmsWs w, float thr, float cls_off, int max_det,
+                                                             float* __restrict__ out_dets, int* __restrict__ out_counts,
+                                                             int* __restrict__ out_idx) {
+    static_assert(64 % NW == 0, "the 64 intra-chunk pivots are dealt evenly to the waves");
+    constexpr int NT = NW * 64, PIV = 64 / NW;
     __shared__ float kx1[NMS_MAXDET_CAP], ky1[NMS_MAXDET_CAP], kx2[NMS_MAXDET_CAP], ky2[NMS_MAXDET_CAP],
         kar[NMS_MAXDET_CAP];
-    __shared__ unsigned long long supw[4];
-    __shared__ unsigned long long part[4][64];
+    __shared__ unsigned long long supw[NW];
+    __shared__ unsigned long long part[NW][64];
+    __shared__ unsigned long long kmask;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
     const int n = w.nsort[b];
     const float* sb = w.sbox + (size_t)b * w.ns * 4;
     const int* sc = w.scls + (size_t)b * w.ns;
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, flo
         }
         const float ai = (x2 - x1) * (y2 - y1);
         // phase A: against this wavefront's share of the kept list
-        const int kq = (kept + 3) >> 2;
+        const int kq = (kept + NW - 1) / NW;
         const int k0 = wave * kq, k1 = min(kept, k0 + kq);
         bool sup = false;
         for (int k = k0; k < k1; ++k) {
@@ -646,12 +656,14 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, flo
             const float iou = inter / ((kar[k] + ai) - inter);
             sup |= !(iou <= thr);
         }
+        // (leaving the loop early once every candidate of the chunk is known to be suppressed — the waves publishing their ballots every
+        // eighth box — changed nothing at sixteen waves and cost the four-wave form 50 %: profiles/r05_negative_results.txt)
         const unsigned long long sw = __ballot(sup);
-        // phase B: 16 intra-chunk columns per wavefront; row = this lane's candidate, earlier box = pivot jj
+        // phase B: PIV intra-chunk columns per wavefront; row = this lane's candidate, earlier box = pivot jj
         unsigned long long bits = 0ull;  // bit jj set: candidate `lane` is suppressed by chunk member jj (jj < lane)
         const int nv = min(64, n - i0);
-        for (int q = 0; q < 16; ++q) {
-            const int jj = wave * 16 + q;
+        for (int q = 0; q < PIV; ++q) {
+            const int jj = wave * PIV + q;
             if (jj >= nv) break;
             const float px1 = rdlane(x1, jj), py1 = rdlane(y1, jj), px2 = rdlane(x2, jj), py2 = rdlane(y2, jj);
             const float pa = rdlane(ai, jj);
@@ -665,41 +677,48 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs w, float thr, flo
         if (lane == 0) supw[wave] = sw;
         part[wave][lane] = bits;
         __syncthreads();
-        unsigned long long cur = supw[0] | supw[1] | supw[2] | supw[3];
-        if (nv < 64) cur |= ~0ull << nv;  // lanes past the end count as suppressed
-        const unsigned long long mine = part[0][lane] | part[1][lane] | part[2][lane] | part[3][lane];
-        // in-order resolve: candidate t survives iff not suppressed by the kept list nor by an earlier survivor
         unsigned long long km = 0ull;
-        for (int t = 0; t < nv; ++t) {
-            const unsigned long long mt = __shfl(mine, t);  // who (earlier in the chunk) suppresses t
-            if (!((cur >> t) & 1ull) && !(mt & km)) km |= 1ull << t;
+        if (wave == 0) {
+            unsigned long long cur = 0ull, mine = 0ull;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) { cur |= supw[q]; mine |= part[q][lane]; }
+            if (nv < 64) cur |= ~0ull << nv;  // lanes past the end count as suppressed
+            // in-order resolve: candidate t survives iff not suppressed by the kept list nor by an earlier survivor.  Only the candidates the
+            // kept list left alive are visited (ascending: the order of the serial loop this replaces — the others never entered km)
+            unsigned long long rem = ~cur;
+            while (rem) {
+                const int t = __builtin_ctzll(rem);
+                rem &= rem - 1ull;
+                const unsigned long long mt = __shfl(mine, t);  // who (earlier in the chunk) suppresses t
+                if (!(mt & km)) km |= 1ull << t;
+            }
+            int cntk = __popcll(km);
+            if (kept + cntk > max_det) {  // keep only the first (max_det - kept) survivors
+                int allow = max_det - kept;
+                unsigned long long m2 = 0ull, tmp = km;
+                while (allow-- > 0) { const unsigned long long low = tmp & (~tmp + 1ull); m2 |= low; tmp ^= low; }
+                km = m2;
+            }
+            if ((km >> lane) & 1ull) {
+                const int pos = kept + __popcll(km & ((1ull << lane) - 1ull));
+                kx1[pos] = x1; ky1[pos] = y1; kx2[pos] = x2; ky2[pos] = y2; kar[pos] = ai;
+                const size_t s = (size_t)b * w.ns + i;
+                float* o = out_dets + ((size_t)b * max_det + pos) * 6;
+                o[0] = w.sbox[s * 4 + 0]; o[1] = w.sbox[s * 4 + 1]; o[2] = w.sbox[s * 4 + 2]; o[3] = w.sbox[s * 4 + 3];
+                o[4] = w.sscore[s]; o[5] = (float)w.scls[s];
+                out_idx[(size_t)b * max_det + pos] = w.sanchor[s];
+                w.keep_pos[(size_t)b * NMS_MAXDET_CAP + pos] = i;
+            }
+            if (lane == 0) kmask = km;
         }
-        int cntk = __popcll(km);
-        if (kept + cntk > max_det) {  // keep only the first (max_det - kept) survivors
-            int allow = max_det - kept;
-            unsigned long long m2 = 0ull, tmp = km;
-            while (allow-- > 0) { const unsigned long long low = tmp & (~tmp + 1ull); m2 |= low; tmp ^= low; }
-            km = m2;
-            cntk = __popcll(km);
-        }
-        if (wave == 0 && ((km >> lane) & 1ull)) {
-            const int pos = kept + __popcll(km & ((1ull << lane) - 1ull));
-            kx1[pos] = x1; ky1[pos] = y1; kx2[pos] = x2; ky2[pos] = y2; kar[pos] = ai;
-            const size_t s = (size_t)b * w.ns + i;
-            float* o = out_dets + ((size_t)b * max_det + pos) * 6;
-            o[0] = w.sbox[s * 4 + 0]; o[1] = w.sbox[s * 4 + 1]; o[2] = w.sbox[s * 4 + 2]; o[3] = w.sbox[s * 4 + 3];
-            o[4] = w.sscore[s]; o[5] = (float)w.scls[s];
-            out_idx[(size_t)b * max_det + pos] = w.sanchor[s];
-            w.keep_pos[(size_t)b * NMS_MAXDET_CAP + pos] = i;
-        }
-        kept += cntk;
         __syncthreads();
+        kept += __popcll(kmask);
     }
     const int nk = kept < max_det ? kept : max_det;
     if (threadIdx.x == 0) out_counts[b] = nk;
     // rows past the count are zero: the caller hands over uninitialised buffers (no fill kernels in the step)
-    for (int i = nk * 6 + threadIdx.x; i < max_det * 6; i += 256) out_dets[(size_t)b * max_det * 6 + i] = 0.f;
-    for (int i = nk + threadIdx.x; i < max_det; i += 256) out_idx[(size_t)b * max_det + i] = 0;
+    for (int i = nk * 6 + threadIdx.x; i < max_det * 6; i += NT) out_dets[(size_t)b * max_det * 6 + i] = 0.f;
+    for (int i = nk + threadIdx.x; i < max_det; i += NT) out_idx[(size_t)b * max_det + i] = 0;
 }
 
 extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t extra, int32_t A, float conf_thres, float iou_thres,
@@ -745,8 +764,14 @@ extern "C" int ymk_nms_batched(const float* y, int32_t B, int32_t nc, int32_t ex
     } else {
         hipLaunchKernelGGL(nms_rank_kernel, dim3((w.capc + 255) / 256, B), dim3(256), 0, s, w, -1);
     }
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det,
-                       out_dets, out_counts, out_idx);
+    // YMK_NMS_GREEDY_WAVES=4: the four-wave form of rounds 1-4 (A/B runs)
+    static const int greedy_waves = [] { const char* e = getenv("YMK_NMS_GREEDY_WAVES"); return e ? atoi(e) : 16; }();
+    if (greedy_waves == 4)
+        hipLaunchKernelGGL(nms_greedy_kernel<4>, dim3(B), dim3(256), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det, out_dets, out_counts, out_idx);
+    else if (greedy_waves == 8)
+        hipLaunchKernelGGL(nms_greedy_kernel<8>, dim3(B), dim3(512), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det, out_dets, out_counts, out_idx);
+    else
+        hipLaunchKernelGGL(nms_greedy_kernel<16>, dim3(B), dim3(1024), 0, s, w, iou_thres, agnostic ? 0.0f : max_wh, max_det, out_dets, out_counts, out_idx);
     return ymk_launch_status();
 }
 

@@ -43,6 +43,7 @@ int ymk_layer_norm(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t l
 #define YMK_ELT_MUL 0
 #define YMK_ELT_SIGMOID_MUL 1
 #define YMK_ELT_LERP 2
+#define YMK_ELT_CLAMP_ADD 3   /* y = clamp(a, -alpha, alpha) + b: UltraOptimizedMoE's `shared + expert_output.clamp_(-1e4, 1e4)` (moe/utils.py:203, moe/modules.py:224) */
 int ymk_eltwise(int32_t op, int32_t dtype, const void* a, int32_t lda, const void* b, int32_t ldb, void* y, int32_t ldy,
                 int64_t npix, int32_t C, float alpha, void* stream);
 
@@ -88,6 +89,13 @@ int ymk_channel_stats(int32_t dtype, const void* x, int32_t ldx, float* out, int
 /* Per-token softmax over n <= 8 fp32 logits scaled by inv_temp; 0 < top_k < n keeps the top_k largest (ties: lower index
  * first), renormalised with the sum clamped at 1e-6 (mot/router.py:243-295, moa/router.py:50-62).
  * w fp32 [npix][ldw]; active int32 [B][n] must be zero on entry (atomicOr 1 where a token selects expert e). */
+/* UltraEfficientRouter's decision tail (moe/routers.py:117-147, eval) + the inference threshold of BatchedExpertComputation (moe/utils.py:166-169):
+ * logits fp32 [B][HW][ldl >= E] of the (pooled) router map -> per pixel softmax(clamp(l, +-30) * inv_temp), mean over the pixels (pooled fp32
+ * [B][E]), top-k (lower index first among equals), w = value / max(sum, 1e-6) with w <= threshold replaced by 0; idx int32 [B][top_k], rows int32
+ * [top_k * B] = idx transposed (the expert of image j * B + b in a slot-major expert batch).  E <= 32, top_k <= 4. */
+int ymk_pooled_softmax_route(const float* logits, int32_t ldl, int32_t B, int32_t HW, int32_t E, float inv_temp, int32_t top_k, float threshold,
+                             float* w, int32_t* idx, int32_t* rows, float* pooled, void* stream);
+
 int ymk_token_softmax(const float* logits, int32_t ldl, const float* bias /*[B][n] or NULL*/, float* w, int32_t ldw, int32_t* active,
                       int32_t B, int32_t HW, int32_t n, float inv_temp, int32_t top_k, void* stream);
 /* bias: added to every token's logits of its image before the temperature — the scene-aware residual of the MoT router

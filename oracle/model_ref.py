@@ -372,6 +372,9 @@ def forward(cfg: dict, sd: dict, x: torch.Tensor, fused: bool = True, taps: dict
             from . import ultimate_ref
             cur = ultimate_ref.ultimate_optimized_moe(sd, p, cur, num_experts=args[1], top_k=args[2], split_ratio=args[3] if len(args) > 3 else 0.5,
                                                       info=moe_info)
+        elif m == "UltraOptimizedMoE":               # v0_1 uomoe / exp v0_2 rows: [c2, num_experts, top_k]
+            from . import uomoe_ref
+            cur = uomoe_ref.ultra_optimized_moe(sd, p, cur, top_k=args[2] if len(args) > 2 else 2, info=moe_info)
         elif m == "ModularRouterExpertMoE":          # v0_1 rows: [c2, num_experts, top_k]
             from . import modular_ref
             cur = modular_ref.modular_router_expert_moe(sd, p, cur, top_k=args[2] if len(args) > 2 else 2, info=moe_info)

@@ -455,6 +455,11 @@ def eltwise_mul(a, b, out=None, act_a=None):
     return _put(_act(a.float(), act_a) * b.float(), out, a.dtype)
 
 
+def clamp_add(a, b, limit, out=None):
+    _count("clamp_add")
+    return _put(a.float().clamp(-float(limit), float(limit)) + b.float(), out, a.dtype)
+
+
 def lerp(a, b, alpha, out=None):
     _count("lerp")
     return _put((1 - alpha) * a.float() + alpha * b.float(), out, a.dtype)
@@ -663,6 +668,20 @@ def gated_route_decide(g_logits, loc_logits, alpha, inv_temp, top_k, cplx_logit,
     return tw.reshape(B, 1, 1, top_k), ti, probs, ti.t().contiguous().reshape(-1)
 
 
+def pooled_softmax_route(logits, E, inv_temp, top_k, threshold):
+    """include/ymk_mixture.h `ymk_pooled_softmax_route`: per-pixel softmax of the clamped logits, mean over the pixels, top-k, renormalise,
+    weights <= threshold zeroed."""
+    _count("pooled_softmax_route")
+    B = logits.shape[0]
+    sm = torch.softmax(logits[..., :E].float().clamp(-30.0, 30.0) * inv_temp, dim=-1)
+    pooled = sm.reshape(B, -1, E).mean(1)
+    tw, ti = torch.topk(pooled, top_k, 1)
+    tw = tw / tw.sum(1, keepdim=True).clamp_min(1e-6)
+    tw = torch.where(tw > threshold, tw, torch.zeros_like(tw))
+    ti = ti.to(torch.int32)
+    return tw.reshape(B, 1, 1, top_k), ti, pooled, ti.t().contiguous().reshape(-1)
+
+
 def expert_conv(x, w_packed, k, idx, out=None):
     _count("expert_conv")
     B, H, W, Cin = x.shape
@@ -721,5 +740,5 @@ EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supp
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",
-            "linear_attention", "deform_attention", "token_softmax", "scene_bias", "moa_sparse_gate", "gated_route_decide", "expert_conv", "expert_dw3", "channel_shuffle_cat",
+            "linear_attention", "deform_attention", "token_softmax", "scene_bias", "moa_sparse_gate", "gated_route_decide", "pooled_softmax_route", "clamp_add", "expert_conv", "expert_dw3", "channel_shuffle_cat",
             "pixel_shuffle2", "tokens_to_rows"]

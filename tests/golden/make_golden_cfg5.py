@@ -40,6 +40,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "v08s":   # v0_8 with SharedExpertMoE (m
     YAML = Path(refboot.REF) / "ultralytics/cfg/models/master/v0_8/det/yolo-master-moe-mot-shared-n.yaml"
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "uomoe":   # v0_1 with UltraOptimizedMoE blocks (moe/modules.py:121-232)
+    TAG = "uomoe"
+    YAML = Path(refboot.REF) / "ultralytics/cfg/models/master/v0_1/det/yolo-master-n-uomoe.yaml"
+
+
 def sample_idx(n, k, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randperm(n, generator=g)[: min(k, n)].sort().values

@@ -291,6 +291,12 @@ def _prep(mod, sd):
     ("v03", "e16", ("UltimateOptimizedMoE", (128, 128, 16, 2, 0.5), {})),
     ("v03", "lowc", ("UltimateOptimizedMoE", (128, 128, 8, 2, 0.5), {})),
     ("v03", "k1", ("UltimateOptimizedMoE", (128, 128, 4, 1, 0.5), {})),
+    # v0_1 uomoe / exp v0_2: UltraOptimizedMoE (moe/modules.py:121-232), tests/golden/make_golden_uomoe.py
+    ("uomoe", "base", ("UltraOptimizedMoE", (64, 64, 4, 2), {})),
+    ("uomoe", "e16", ("UltraOptimizedMoE", (128, 128, 16, 2), {})),
+    ("uomoe", "widen", ("UltraOptimizedMoE", (64, 128, 8, 2), {})),
+    ("uomoe", "small", ("UltraOptimizedMoE", (64, 64, 4, 2), {})),
+    ("uomoe", "thr", ("UltraOptimizedMoE", (64, 64, 4, 2), {})),      # a routed weight below the 0.01 inference threshold: dropped
 ])
 def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
     """fp32 on the GPU against the REAL reference's outputs (the fixtures of tests/test_host_mixture.py)."""
@@ -310,11 +316,12 @@ def test_modules_vs_reference_golden(fam, name, ctor, golden_dir):
     if fam == "mot" and "scene_stats" in z.files:   # the scene statistics themselves (fp64 combines on the device against torch's fp32 reductions)
         st, rs = m.router.last_scene_stats.cpu(), torch.from_numpy(z["scene_stats"])[0]
         assert float(((st - rs).abs() / rs.abs().clamp_min(1e-3)).max()) <= 1e-4, f"scene statistics {st.tolist()} vs {rs.tolist()}"
-    if fam in ("gated", "v01", "v03"):
+    if fam in ("gated", "v01", "v03", "uomoe"):
         B = got.shape[0]
         assert np.array_equal(m.last_route["indices"].cpu().numpy(), z["indices"].reshape(B, -1)), "routed experts differ from the reference"
-    if fam in ("v01", "v03"):
-        assert float(np.abs(m.last_route["weights"].cpu().numpy().reshape(B, -1) - z["weights"]).max()) <= 1e-5, "routing weights"
+    if fam in ("v01", "v03", "uomoe"):
+        zw = z["weights"] if fam != "uomoe" else np.where(z["weights"] > 0.01, z["weights"], 0.0)   # (the library hands back the weights as applied: <= 0.01 dropped)
+        assert float(np.abs(m.last_route["weights"].cpu().numpy().reshape(B, -1) - zw).max()) <= 1e-5, "routing weights"
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -354,7 +361,7 @@ def test_modules_16bit_vs_reference_golden(fam, name, ctor, dtype, golden_dir):
     assert q99 <= tol and mean <= tol / 4, f"{fam}_{name} {dtype}: mean {mean:.3e}, q99 {q99:.3e} > {tol:.3e}"
 
 
-@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06", "v01", "v03", "v08s"])
+@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v06", "v01", "v03", "v08s", "uomoe"])
 def test_config5_model_vs_reference_golden(tag, golden_dir):
     import json
     import warnings

@@ -236,7 +236,7 @@ def test_gated_chain_host_vs_reference(name, golden_dir, emu):
 
 
 MODEL_FIXTURES = {"cfg5": "yolo-master-moa-mot-n.yaml", "v15": "yolo-master-v15-n.yaml",
-                  "v04": None, "v06": None, "v01": None, "v03": None, "v08s": None}    # None: the reference YAML's dict as stored in the fixture (generations v0_4 / v0_6, n scale)
+                  "v04": None, "v06": None, "v01": None, "v03": None, "v08s": None, "uomoe": None}    # None: the reference YAML's dict as stored in the fixture (generations v0_4 / v0_6, n scale)
 
 
 @pytest.mark.parametrize("tag", list(MODEL_FIXTURES))

@@ -59,7 +59,7 @@ def test_kernels_modules_bf16_vs_reference_golden(T, fam, name, ctor, golden_dir
         T.test_modules_16bit_vs_reference_golden(fam, name, ctor, torch.bfloat16, golden_dir)
 
 
-@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v01", "v03", "v08s"])
+@pytest.mark.parametrize("tag", ["cfg5", "v15", "v04", "v01", "v03", "v08s", "uomoe"])
 def test_kernels_config5_model_vs_reference_golden(T, tag, golden_dir):
     T.test_config5_model_vs_reference_golden(tag, golden_dir)
 

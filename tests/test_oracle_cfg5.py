@@ -72,3 +72,34 @@ def test_shared_expert_pool_model_oracle_reproduces_reference(golden_dir):
     with torch.inference_mode():
         model_ref.forward(cfg, sd2, x, fused=False, taps=t2)
     assert not torch.allclose(t2[members[0]], taps[members[0]], rtol=1e-3, atol=1e-3)
+
+
+def test_ultra_optimized_moe_oracle_reproduces_reference(golden_dir):
+    """UltraOptimizedMoE (moe/modules.py:121-232): the five module fixtures of tests/golden/make_golden_uomoe.py (bit-exact there against the real
+    reference, incl. a route dropped by the 0.01 inference threshold) and the whole `v0_1/det/yolo-master-n-uomoe.yaml` detector."""
+    from oracle import model_ref, uomoe_ref
+
+    for name in ("base", "e16", "widen", "small", "thr"):
+        z = np.load(golden_dir / f"uomoe_{name}.npz")
+        sd = {f"m.{k}": torch.from_numpy(z[f"sd::{k}"]) for k in z["keys"].tolist()}
+        info = {}
+        with torch.inference_mode():
+            y = uomoe_ref.ultra_optimized_moe(sd, "m", torch.from_numpy(z["x"]), top_k=int(z["args"][3]), info=info)
+        assert np.array_equal(info["m"]["indices"].numpy().astype(np.int32), z["indices"]), name
+        np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-4, atol=1e-4, err_msg=name)
+        if name == "thr":
+            assert int((info["m"]["weights"] <= 0.01).sum()) > 0
+    z = np.load(golden_dir / "fwd_uomoe.npz")
+    cfg = json.loads(str(z["cfg"]))
+    sd = fill_by_name(json.loads(str(z["spec"])), seed=5, gain=1.0)
+    sd.update({k[len("fixed::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fixed::")})
+    taps, info = {}, {}
+    with torch.inference_mode():
+        y, _, _ = model_ref.forward(cfg, sd, torch.from_numpy(z["x"]), fused=False, taps=taps, moe_info=info)
+    rows = cfg["backbone"] + cfg["head"]
+    assert sum(r[2] == "UltraOptimizedMoE" for r in rows) == 3
+    for k in [f for f in z.files if f.startswith("route::")]:
+        assert np.array_equal(info[k[len("route::"):]]["indices"].numpy().astype(np.int16), z[k]), k
+    for i in range(len(rows) - 1):
+        got = taps[i].reshape(-1)[torch.from_numpy(z[f"layer{i}_idx"].astype(np.int64))].numpy()
+        np.testing.assert_allclose(got, z[f"layer{i}_val"], rtol=1e-4, atol=1e-4, err_msg=f"layer {i} ({rows[i][2]})")

@@ -105,6 +105,7 @@ SYMBOLS_MIXTURE = {
     "ymk_avg_pool": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_channel_stats": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ymk_token_softmax": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "ymk_pooled_softmax_route": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ymk_scene_workspace_bytes": (_sz, [_i32, _i32]),
     "ymk_scene_bias": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),
@@ -136,7 +137,7 @@ SYMBOLS_NEXT = {
     "ymk_letterbox_preprocess": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
 }
 ACT_SIGMOID, ACT_GELU = 2, 3
-ELT_MUL, ELT_SIGMOID_MUL, ELT_LERP = 0, 1, 2
+ELT_MUL, ELT_SIGMOID_MUL, ELT_LERP, ELT_CLAMP_ADD = 0, 1, 2, 3
 
 _lib = None
 _lib_f16 = None

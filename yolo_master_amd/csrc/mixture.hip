@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void eltwise_kernel(int op, int dt, const void
         float r;
         if (op == YMK_ELT_MUL) r = av * bv;
         else if (op == YMK_ELT_SIGMOID_MUL) r = bv / (1.0f + expf(-av));
+        else if (op == YMK_ELT_CLAMP_ADD) r = fminf(fmaxf(av, -alpha), alpha) + bv;
         else r = (1.0f - alpha) * av + alpha * bv;
         stv(y, dt, p * ldy + c, r);
     }
@@ -704,6 +705,7 @@ __global__ __launch_bounds__(256) void eltwise_vec_kernel(int op, const T* a, in
         for (int q = 0; q < VEC; ++q) {
             if (op == YMK_ELT_MUL) av[q] = av[q] * bv[q];
             else if (op == YMK_ELT_SIGMOID_MUL) av[q] = bv[q] / (1.0f + expf(-av[q]));
+            else if (op == YMK_ELT_CLAMP_ADD) av[q] = fminf(fmaxf(av[q], -alpha), alpha) + bv[q];
             else av[q] = (1.0f - alpha) * av[q] + alpha * bv[q];
         }
         store_vec_f32(y + p * ldy + c0, av);
@@ -1033,7 +1035,7 @@ extern "C" int ymk_layer_norm(int32_t dtype, const void* x, int32_t ldx, void* y
 
 extern "C" int ymk_eltwise(int32_t op, int32_t dtype, const void* a, int32_t lda, const void* b, int32_t ldb, void* y, int32_t ldy,
                            int64_t npix, int32_t C, float alpha, void* stream) {
-    if (!a || !b || !y || bad_dt(dtype) || op < YMK_ELT_MUL || op > YMK_ELT_LERP || C < 1 || lda < C || ldb < C || ldy < C)
+    if (!a || !b || !y || bad_dt(dtype) || op < YMK_ELT_MUL || op > YMK_ELT_CLAMP_ADD || C < 1 || lda < C || ldb < C || ldy < C)
         return YMK_E_BADARG;
     if (npix <= 0) return YMK_OK;
     const int V = vecw(dtype);
@@ -1202,6 +1204,79 @@ extern "C" int ymk_token_softmax(const float* logits, int32_t ldl, const float* 
     if ((!logits && !bias) || !w || !active || n < 1 || n > 8 || (logits && ldl < n) || ldw < n || top_k < 0) return YMK_E_BADARG;
     if (B <= 0 || HW <= 0) return YMK_OK;
     LAUNCH(token_softmax_kernel, (int64_t)B * HW, logits, ldl, bias, w, ldw, active, B, HW, n, inv_temp, top_k);
+    return ymk_launch_status();
+}
+
+// ---- UltraEfficientRouter decision tail (moe/routers.py:117-147, eval): per PIXEL of the (pooled) router map softmax(clamp(logits, +-30) *
+// inv_temp) over the E experts, the MEAN of those weights over the pixels, top-k of the pooled weights (lower index first among equals),
+// values / max(sum, 1e-6); routes whose weight is not above `threshold` get weight 0 (the inference-only cut of
+// BatchedExpertComputation, moe/utils.py:166-169: such an expert contributes nothing).  One wave per image: lanes over the pixels,
+// per-expert partial sums reduced across the wave in a fixed order.  E <= 32, top_k <= 4.
+__global__ __launch_bounds__(64) void pooled_softmax_route_kernel(const float* __restrict__ logits, int ldl, int HW, int E, float inv_temp,
+                                                                   int top_k, float threshold, int B, float* __restrict__ w,
+                                                                   int32_t* __restrict__ idx, int32_t* __restrict__ rows,
+                                                                   float* __restrict__ pooled) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float acc[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc[e] = 0.f;
+    for (int p = lane; p < HW; p += 64) {
+        const float* l = logits + ((size_t)b * HW + p) * ldl;
+        float v[32];
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            v[e] = e < E ? fminf(fmaxf(l[e], -30.0f), 30.0f) * inv_temp : -INFINITY;
+            m = fmaxf(m, v[e]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            v[e] = e < E ? expf(v[e] - m) : 0.f;
+            s += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 32; ++e) acc[e] += v[e] / s;
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_xor(acc[e], o);
+        acc[e] = acc[e] / (float)HW;
+    }
+    if (lane != 0) return;
+    unsigned taken = 0u;
+    float vals[4] = {0.f, 0.f, 0.f, 0.f};
+    int sel[4] = {0, 0, 0, 0};
+    float sum = 0.f;
+    for (int j = 0; j < top_k; ++j) {
+        int best = -1;
+        float bv = -1.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+            if (e < E && !((taken >> e) & 1u) && acc[e] > bv) { bv = acc[e]; best = e; }
+        taken |= 1u << best;
+        vals[j] = bv; sel[j] = best;
+        sum += bv;
+    }
+    sum = fmaxf(sum, 1e-6f);
+    for (int j = 0; j < top_k; ++j) {
+        const float wj = vals[j] / sum;
+        w[b * top_k + j] = wj > threshold ? wj : 0.f;
+        idx[b * top_k + j] = sel[j];
+        rows[j * B + b] = sel[j];
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e)
+        if (e < E) pooled[b * E + e] = acc[e];
+}
+
+extern "C" int ymk_pooled_softmax_route(const float* logits, int32_t ldl, int32_t B, int32_t HW, int32_t E, float inv_temp, int32_t top_k,
+                                        float threshold, float* w, int32_t* idx, int32_t* rows, float* pooled, void* stream) {
+    if (!logits || !w || !idx || !rows || !pooled || E < 1 || E > 32 || ldl < E || top_k < 1 || top_k > 4 || top_k > E) return YMK_E_BADARG;
+    if (B <= 0 || HW <= 0) return YMK_OK;
+    hipLaunchKernelGGL(pooled_softmax_route_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ldl, HW, E, inv_temp, top_k, threshold, B, w,
+                       idx, rows, pooled);
     return ymk_launch_status();
 }
 

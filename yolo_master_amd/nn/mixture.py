@@ -1656,6 +1656,93 @@ class ModularRouterExpertMoE(YmkModule):
         return ops.weighted_sum(wk, [f[j * B:(j + 1) * B] for j in range(k)] + [shared], out=out)
 
 
+# ----------------------------------------------------------------------------------------- v0_1 uomoe / exp v0_2: UltraOptimizedMoE
+class UltraEfficientRouter(nn.Module):
+    """Parameter container with the reference's names (moe/routers.py:69-95): router = DW3x3 -> GN(8) -> SiLU -> 1x1 -> GN(4) -> SiLU -> 1x1 (+bias)."""
+
+    def __init__(self, in_channels, num_experts, reduction=16, top_k=2, noise_std=1.0, temperature=1.0, pool_scale=8):
+        super().__init__()
+        self.num_experts, self.top_k, self.noise_std, self.pool_scale = num_experts, top_k, noise_std, pool_scale
+        self.temperature = max(float(temperature), 1e-3)
+        red = max(in_channels // reduction, 4)
+        self.router = nn.Sequential(nn.Conv2d(in_channels, in_channels, 3, padding=1, groups=in_channels, bias=False), _gn(in_channels, 8),
+                                    nn.SiLU(inplace=False), nn.Conv2d(in_channels, red, 1, bias=False), _gn(red, 4), nn.SiLU(inplace=False),
+                                    nn.Conv2d(red, num_experts, 1, bias=True))
+        self.softmax = nn.Softmax(dim=1)
+
+
+class UltraOptimizedMoE(YmkModule):
+    """The MoE block of `v0_1/det/yolo-master-n-uomoe*.yaml` and `exp/yolo-master-v0_2.yaml` (moe/modules.py:121-232; rows `[c2, num_experts,
+    top_k]`: UltraEfficientRouter, OptimizedSimpleExpert — the same 1x1 -> GN -> SiLU -> 1x1 -> GN body as v0_1's SimpleExpert —, the
+    always-on shared expert, no residual).  Eval forward on libymk, true sparse dispatch:
+
+        router   8x8 average pool (fp32) -> DW3x3 -> GN -> SiLU -> 1x1 -> GN -> SiLU -> 1x1 + bias -> per-pixel softmax of the clamped logits,
+                 mean over the pixels, top-k, renormalise, weights <= 0.01 dropped (`ymk_pooled_softmax_route`; moe/routers.py:97-147,
+                 moe/utils.py:166-169)
+        experts  only the routed filter banks run (`ymk_expert_conv_glds`), GroupNorm with the routed expert's affine row, slot-major maps
+        output   SiLU(GN(1x1 x)) + clamp(sum_j w_j expert_j(x), +-1e4)      (moe/utils.py:181-203, moe/modules.py:224)
+    Other expert types of the reference constructor ("ghost", "inverted") are not on the YAML surface and raise."""
+
+    def __init__(self, in_channels, out_channels, num_experts=4, top_k=2, expert_type="simple", router_reduction=16, router_pool_scale=8,
+                 noise_std=1.0, router_temperature=1.0, balance_loss_coeff=1.0, router_z_loss_coeff=1.0, num_groups=8, weight_threshold=0.01):
+        super().__init__()
+        if expert_type != "simple":
+            raise NotImplementedError("ymk UltraOptimizedMoE: the YAML surface uses the default 'simple' experts")
+        if not 1 <= top_k <= 3 or top_k > num_experts or num_experts > 32:
+            raise ValueError("ymk UltraOptimizedMoE: 1 <= top_k <= min(3, num_experts), num_experts <= 32")
+        self.in_channels, self.out_channels, self.num_experts, self.top_k, self.expert_type = in_channels, out_channels, num_experts, top_k, expert_type
+        self.balance_loss_coeff, self.router_z_loss_coeff, self.weight_threshold, self.num_groups = balance_loss_coeff, router_z_loss_coeff, weight_threshold, num_groups
+        self.routing = UltraEfficientRouter(in_channels, num_experts, reduction=router_reduction, top_k=top_k, noise_std=noise_std,
+                                            temperature=router_temperature, pool_scale=router_pool_scale)
+        self.experts = nn.ModuleList(SimpleExpert(in_channels, out_channels, expand_ratio=2, num_groups=num_groups) for _ in range(num_experts))
+        self.shared_expert = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, bias=False), _gn(out_channels, num_groups), nn.SiLU(inplace=True))
+        self.last_route = {}
+
+    def _pack(self, dtype, device):
+        f32 = torch.float32
+        E, r = self.num_experts, self.routing.router
+        red = r[3].out_channels
+        rp, E4 = _ceil(red, 4), _ceil(E, 4)
+        return {
+            "r0": _pack_dw(r[0], f32, device), "r1": _pack_norm(r[1], device),
+            "r3": _pack_conv(r[3], f32, device, pad_cout_to=rp), "r4": _pack_norm(r[4], device), "red": red, "rp": rp,
+            "r6": _pack_conv(r[6], f32, device, pad_cout_to=E4, pad_cin_to=rp),
+            "sh": _pack_conv(self.shared_expert[0], dtype, device), "shn": _pack_norm(self.shared_expert[1], device),
+            "e1": torch.stack([_pack_conv(e.conv[0], dtype, device)[0] for e in self.experts]).contiguous(),          # [E][hid][Kpad]
+            "n1": (torch.stack([e.conv[1].weight.detach().float() for e in self.experts]).to(device).contiguous(),
+                   torch.stack([e.conv[1].bias.detach().float() for e in self.experts]).to(device).contiguous()),
+            "e2": torch.stack([_pack_conv(e.conv[3], dtype, device)[0] for e in self.experts]).contiguous(),          # [E][cout][Kpad]
+            "n2": (torch.stack([e.conv[4].weight.detach().float() for e in self.experts]).to(device).contiguous(),
+                   torch.stack([e.conv[4].bias.detach().float() for e in self.experts]).to(device).contiguous()),
+        }
+
+    def _run(self, x, out=None):
+        """UltraOptimizedMoE.forward, eval (moe/modules.py:212-232)."""
+        B, H, W, C = x.shape
+        pk = self._packed(x.device)
+        E, k, gs, ng = self.num_experts, self.top_k, get_safe_groups, self.num_groups
+        ps = self.routing.pool_scale
+        xin = ops.avg_pool(x, ps if (H > ps and W > ps) else 1, out_dtype=torch.float32)          # the router runs in fp32
+        h = ops.group_norm(ops.dwconv2d(xin, pk["r0"], None, 3, False), gs(C, 8), *pk["r1"], 1e-5, act="silu")
+        h = ops.conv2d(h, *pk["r3"], 1, 1, False)
+        red, rp = pk["red"], pk["rp"]
+        hn = h if red == rp else torch.zeros(h.shape, dtype=h.dtype, device=h.device)             # pad channels must stay zero
+        ops.group_norm(h[..., :red], gs(red, 4), *pk["r4"], 1e-5, act="silu", out=hn[..., :red])
+        logits = ops.conv2d(hn, *pk["r6"], 1, 1, False)
+        w, idx, pooled, rows = ops.pooled_softmax_route(logits, E, 1.0 / self.routing.temperature, k, float(self.weight_threshold))
+        self.last_route = {"weights": w, "indices": idx, "probs": pooled}
+        hid, cout = pk["e1"].shape[1], self.out_channels
+        f = ops.expert_conv(x, pk["e1"], 1, idx)                                                                   # [k * B, H, W, hid], slot-major
+        f = ops.group_norm(f, gs(hid, ng), *pk["n1"], 1e-5, act="silu", affine_rows=rows)
+        f = ops.expert_conv(f, pk["e2"], 1, rows.view(-1, 1).contiguous())                                         # image n of the slot-major batch -> its own expert
+        f = ops.group_norm(f, gs(cout, ng), *pk["n2"], 1e-5, affine_rows=rows)
+        wk = torch.zeros((B, 1, 1, 4), dtype=torch.float32, device=x.device)
+        wk[..., :k].copy_(w)
+        mix = ops.weighted_sum(wk, [f[j * B:(j + 1) * B] for j in range(k)])
+        shared = ops.group_norm(ops.conv2d(x, *pk["sh"], 1, 1, False), gs(cout, ng), *pk["shn"], 1e-5, act="silu")
+        return ops.clamp_add(mix, shared, 1e4, out=out)
+
+
 # ----------------------------------------------------------------------------------------- v0_3: UltimateOptimizedMoE
 class ZeroCostRouter(nn.Module):
     """Parameter container with the reference's names (moe/gated.py:938-961): router = Sequential(Linear(2C -> E, no bias), Softmax)."""
@@ -1757,6 +1844,6 @@ class UltimateOptimizedMoE(YmkModule):
         return ops.group_norm(ops.conv2d(cat, *pk["proj"], 1, 1, False), gs(self.out_channels, ng), *pk["bn"], 1e-5, residual=x, out=out)
 
 
-MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "SharedExpertMoE": SharedExpertMoE, "ModularRouterExpertMoE": ModularRouterExpertMoE, "UltimateOptimizedMoE": UltimateOptimizedMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
+MIXTURE_BOUNDARY_MODULES = {**{c.__name__: c for c in GATED_CHAIN}, "SharedExpertMoE": SharedExpertMoE, "UltraOptimizedMoE": UltraOptimizedMoE, "ModularRouterExpertMoE": ModularRouterExpertMoE, "UltimateOptimizedMoE": UltimateOptimizedMoE, "OptimalHybridGateMoE": OptimalHybridGateMoE, "MultiHeadRouterMoE": MultiHeadRouterMoE, "DiversifiedExpertMoE": DiversifiedExpertMoE,
                             "GatedFusionMoE": GatedFusionMoE, "C2fMoA": C2fMoA, "C2fMoT": C2fMoT}
 MIXTURE_BOUNDARY_REPEAT = {C2fMoA, C2fMoT}

@@ -777,6 +777,11 @@ def eltwise_mul(a, b, out=None, act_a=None):
     return _eltwise(_lib.ELT_SIGMOID_MUL if act_a else _lib.ELT_MUL, a, b, 0.0, out, "eltwise_mul")
 
 
+def clamp_add(a, b, limit: float, out=None):
+    """out = clamp(a, -limit, limit) + b (UltraOptimizedMoE: `shared + expert_output.clamp_(-1e4, 1e4)`, moe/utils.py:203, modules.py:224)."""
+    return _eltwise(_lib.ELT_CLAMP_ADD, a, b, limit, out, "clamp_add")
+
+
 def lerp(a, b, alpha: float, out=None):
     """out = (1 - alpha) * a + alpha * b (exact / linear attention blend, moa/heads.py:366-374)."""
     return _eltwise(_lib.ELT_LERP, a, b, alpha, out, "lerp")
@@ -1044,6 +1049,24 @@ def gated_route_decide(g_logits, loc_logits, alpha: float, inv_temp: float, top_
                                      cplx_logit.stride(0), B, E, float(alpha), float(inv_temp), int(clamp), int(top_k), _p(w), _p(idx), _p(rows),
                                      _p(probs), _stream()), "gated_route_decide")
     return w, idx, probs, rows
+
+
+@_timed("token_router")
+def pooled_softmax_route(logits, E: int, inv_temp: float, top_k: int, threshold: float):
+    """UltraEfficientRouter's decision (moe/routers.py:117-147) + the inference threshold on the routed weights (moe/utils.py:166-169):
+    logits fp32 NHWC [B,h,w,>=E] of the router map -> (w fp32 [B,1,1,top_k] with weights <= threshold zeroed, idx int32 [B,top_k],
+    pooled fp32 [B,E] = the per-pixel softmax averaged over the pixels, rows int32 [top_k*B])."""
+    B, H, W, Cc, ldl = _nhwc(logits)
+    if logits.dtype != torch.float32 or Cc < E:
+        raise ValueError("pooled_softmax_route: fp32 logits with at least E channels")
+    dev = logits.device
+    w = torch.empty((B, 1, 1, top_k), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, top_k), dtype=torch.int32, device=dev)
+    rows = torch.empty((top_k * B,), dtype=torch.int32, device=dev)
+    pooled = torch.empty((B, E), dtype=torch.float32, device=dev)
+    check(lib.ymk_pooled_softmax_route(_p(logits), ldl, B, H * W, E, float(inv_temp), int(top_k), float(threshold), _p(w), _p(idx), _p(rows),
+                                       _p(pooled), _stream()), "pooled_softmax_route")
+    return w, idx, pooled, rows
 
 
 def batch_scale(w, logit, lo: float, hi: float):

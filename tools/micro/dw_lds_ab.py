@@ -29,10 +29,10 @@ def timeit(call, n=10):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-libs = {m: C.CDLL(str(ROOT / "tools" / "micro" / "_dwab" / f"libdw_mode{m}.so")) for m in (0, 1, 2)}
+libs = {m: C.CDLL(str(ROOT / "tools" / "micro" / "_dwab" / f"libdw_mode{m}.so")) for m in (0, 1, 2, 3)}
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
-print(f"# us per call, median of {ROUNDS} interleaved rounds; mode 0 = rounds 1-4 (ds_read2_b64), 1 = un-paired ds_read_b64, 2 = planar ds_read_b128")
+print(f"# us per call, median of {ROUNDS} interleaved rounds; mode 0 = rounds 1-4 (ds_read2_b64), 1 = un-paired ds_read_b64, 2 = planar ds_read_b128, 3 = planar pixel pairs + v_dot2")
 for Cc, HW, pairs in [(128, 160, 107), (256, 80, 98), (256, 40, 105), (512, 20, 92)]:
     B, E, top_k, ks = 64, 4, 2, [3, 5, 7, 9]
     x = torch.randn(B, HW, HW, Cc, device=dev).to(bf)
@@ -59,7 +59,10 @@ for Cc, HW, pairs in [(128, 160, 107), (256, 80, 98), (256, 40, 105), (512, 20, 
         for m in libs:
             ts[m].append(timeit(calls[m]))
     same = all(torch.equal(outs[0], outs[m]) for m in (1, 2))
-    print(f"moe_dw C{Cc} @{HW}x{HW} pairs {int((sel >= 0).sum())}: " + "  ".join(f"mode{m} {med(ts[m]):7.1f}" for m in libs) + f"  bit-identical {same}")
+    live = (sel >= 0).reshape(-1)
+    d3 = (outs[3].float() - outs[0].float())[live]
+    print(f"moe_dw C{Cc} @{HW}x{HW} pairs {int((sel >= 0).sum())}: " + "  ".join(f"mode{m} {med(ts[m]):7.1f}" for m in libs) + f"  modes 0-2 bit-identical {same}; "
+          f"mode 3 vs 0: {float((d3 != 0).float().mean()) * 100:.3f} % of the outputs differ, max |d| {float(d3.abs().max()):.2e}")
 for Cc, HW, k, res in [(128, 40, 7, True), (256, 20, 7, True), (128, 80, 3, False), (256, 40, 3, False)]:
     B = 64
     x = torch.randn(B, HW, HW, Cc, device=dev).to(bf)
@@ -73,4 +76,6 @@ for Cc, HW, k, res in [(128, 40, 7, True), (256, 20, 7, True), (128, 80, 3, Fals
         for m in libs:
             ts[m].append(timeit(calls[m], 20))
     same = all(torch.equal(outs[0], outs[m]) for m in (1, 2))
-    print(f"dwconv C{Cc} k{k} @{HW}x{HW}{' +res' if res else ' +silu'}: " + "  ".join(f"mode{m} {med(ts[m]):7.1f}" for m in libs) + f"  bit-identical {same}")
+    d3 = outs[3].float() - outs[0].float()
+    print(f"dwconv C{Cc} k{k} @{HW}x{HW}{' +res' if res else ' +silu'}: " + "  ".join(f"mode{m} {med(ts[m]):7.1f}" for m in libs) + f"  modes 0-2 bit-identical {same}; "
+          f"mode 3 vs 0: {float((d3 != 0).float().mean()) * 100:.3f} % differ, max |d| {float(d3.abs().max()):.2e}")

@@ -30,8 +30,13 @@
 //   2  PLANAR (default): [row][4-channel group][pixel], a thread's DW_R + K - 1 pixels of its channel group are CONTIGUOUS — (DW_R + K - 1) / 2
 //      16-byte reads per filter row instead of DW_R + K - 1 8-byte ones, plane pitch and row pitch chosen so that every 16-lane
 //      ds_read_b128 group covers the 64 banks exactly once; the filter block is stored [ky][group][kx] the same way.
+//   3  PAIR-DOT (default since the dot2 form was measured): mode 2's planes with the two pixels of a 16-byte slot INTERLEAVED per channel — a
+//      32-bit word = (pixel 2j, pixel 2j + 1) of one channel — and the filter rows stored as tap pairs, so that the arithmetic is
+//      v_dot2_f32_bf16 (two multiply-adds per instruction straight from the 16-bit words) instead of widening shifts / masks +
+//      v_pk_fma_f32: (K + 1) / 2 dot2 per output and channel and filter row, no widening (K = 9: 200 VALU instructions per thread and
+//      row instead of 180 + 108).  Output pixel r even pairs its taps (0,1)(2,3)...; r odd pairs (-,0)(1,2)(3,4)... against the same words.
 #ifndef DW_LDS_MODE
-#define DW_LDS_MODE 2
+#define DW_LDS_MODE 3
 #endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -66,10 +71,11 @@ struct DwTile {
     // lane = group + 4 x strip + 4 x STRIPS x row and strips 80 bytes apart (exhaustive search, tools/micro/dw_planar_pitch.py): in units of
     // 16 bytes the 40-wide tile reads slots 12 x group + {0, 15, RP + 5, RP + 10} / {5, 10, RP, RP + 15} (mod 16) — all sixteen for PL = 28,
     // RP = 112.  Planes hold up to TW + 14 pixels of 8 bytes (k <= 15).
-    static constexpr bool PLANAR = DW_LDS_MODE == 2 && sizeof(T) == 2;
+    static constexpr bool PLANAR = DW_LDS_MODE >= 2 && sizeof(T) == 2;
+    static constexpr bool PAIRDOT = DW_LDS_MODE == 3 && sizeof(T) == 2;
     static constexpr int PL = TW == 40 ? 448 : 288;
     static constexpr size_t wbytes(int K) {    // filter block in LDS (bf16 stays bf16); planar: [ky][group][K + 1 taps] x 4 channels
-        return PLANAR ? (size_t)K * NCG * (K + 1) * 8 : (size_t)K * K * CB * (sizeof(T) == 2 ? 2 : 4);
+        return PAIRDOT ? (size_t)K * NCG * 2 * ((K + 1) / 2) * 16 : PLANAR ? (size_t)K * NCG * (K + 1) * 8 : (size_t)K * K * CB * (sizeof(T) == 2 ? 2 : 4);
     }
     static constexpr int resident_with(int K, int rp) { return (int)(163840 / ((size_t)(TH + K - 1) * rp + wbytes(K))); }
     static constexpr int row_pitch(int K) {    // bytes between staged rows
@@ -317,6 +323,154 @@ __device__ __forceinline__ void dw_run(const T* __restrict__ xb, int H, int W, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// DW_LDS_MODE 3: the 16-bit stencil on v_dot2 (see the header).  Same tiling, thread map (4 channels x DW_R consecutive pixels of one row),
+// planes and pitches as the planar form; one tile per pass, no register prefetch (three workgroups per CU by registers and LDS).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T, int K, int TW>
+__device__ __forceinline__ void dw_run_pairdot(const T* __restrict__ xb, int H, int W, int C, int ldx, const T* __restrict__ w,
+                                               T* __restrict__ ob, int ldy, int cb, int st0, int st1, const DwEpi& ep, const T* __restrict__ rb,
+                                               char* smem) {
+    using D = DwTile<T, TW>;
+    static_assert(sizeof(T) == 2 && (DW_R & 1) == 0, "16-bit elements, an even pixel run");
+    constexpr int TH = D::TH;
+    constexpr int P = K / 2, HT = TH + K - 1, WT = TW + K - 1;
+    static_assert((WT & 1) == 0, "whole pixel pairs per halo row");
+    constexpr int NPR = WT / 2;                       // pixel pairs per halo row
+    constexpr int NW = (K + 1) / 2;                   // tap pairs per filter row
+    constexpr int NPAIR = (DW_R + K - 1) / 2;         // pixel pairs a thread reads per filter row
+    constexpr int NPC = HT * NPR * 2;                 // staged pieces: (pixel pair, 8-channel half)
+    constexpr int NL = (NPC + 255) / 256;
+    constexpr int RP = D::row_pitch(K);
+    const int t = threadIdx.x;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int c0 = cb * D::CB;
+    uint32_t* wsw = reinterpret_cast<uint32_t*>(smem + (size_t)HT * RP);
+
+    // filter block: word ((ky * 4 + group) * 2 + parity) * NW + m, channel ci = (tap lo, tap hi) with the taps (2m, 2m + 1) for even
+    // output pixels and (2m - 1, 2m) for odd ones; taps outside [0, K) and channels past C are zero
+    for (int i = t; i < K * D::NCG * 2 * NW * 4; i += 256) {
+        const int ci = i & 3, m = (i >> 2) % NW, par = ((i >> 2) / NW) & 1, cg = ((i >> 2) / (2 * NW)) % D::NCG, ky = (i >> 2) / (2 * NW * D::NCG);
+        const int c = c0 + cg * 4 + ci, tlo = 2 * m - par, thi = tlo + 1;
+        const uint32_t lo = (tlo >= 0 && tlo < K && c < C) ? w[(size_t)(ky * K + tlo) * C + c] : 0u;
+        const uint32_t hi = (thi >= 0 && thi < K && c < C) ? w[(size_t)(ky * K + thi) * C + c] : 0u;
+        wsw[i] = lo | (hi << 16);
+    }
+    const int cg = t % D::NCG;
+    const int strip = (t / D::NCG) % D::STRIPS;
+    const int y = t / (D::NCG * D::STRIPS);
+    const int x0 = strip * DW_R;
+    const bool chan_ok = c0 + cg * 4 < C;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ep.bias && chan_ok) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(ep.bias + c0 + cg * 4);
+        bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+    }
+    for (int st = st0; st < st1; ++st) {
+        const int ty0 = (st / tiles_x) * TH, tx0 = (st % tiles_x) * TW;
+        // halo staging: a piece = the same 8 channels of the two pixels of a pair (two 16-byte loads, issued back to back for all pieces)
+        u32x4 sa[NL], sb[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int i = t + l * 256;
+            const int pr = i >> 1, q = i & 1;
+            const int hy = pr / NPR, hp = pr - hy * NPR;
+            const int iy = ty0 - P + hy, ix = tx0 - P + 2 * hp;
+            u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+            if (!(DW_ABLATE & 1) && i < NPC && (unsigned)iy < (unsigned)H && c0 + q * 8 < C) {
+                const T* src = xb + ((size_t)iy * W + ix) * ldx + c0 + q * 8;
+                if ((unsigned)ix < (unsigned)W) va = *reinterpret_cast<const u32x4*>(src);
+                if ((unsigned)(ix + 1) < (unsigned)W) vb = *reinterpret_cast<const u32x4*>(src + ldx);
+            }
+            sa[l] = va; sb[l] = vb;
+        }
+        __syncthreads();  // the previous tile's LDS reads are finished (first pass: nothing pending)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int i = t + l * 256;
+            if (!(DW_ABLATE & 2) && i < NPC) {
+                const int pr = i >> 1, q = i & 1;
+                const int hy = pr / NPR, hp = pr - hy * NPR;
+                // per channel (even pixel, odd pixel): channels 0-3 of the piece -> group 2q, channels 4-7 -> group 2q + 1
+                const u32x4 a = sa[l], b = sb[l];
+                const u32x4 g0 = {(a.x & 0xffffu) | (b.x << 16), (a.x >> 16) | (b.x & 0xffff0000u), (a.y & 0xffffu) | (b.y << 16), (a.y >> 16) | (b.y & 0xffff0000u)};
+                const u32x4 g1 = {(a.z & 0xffffu) | (b.z << 16), (a.z >> 16) | (b.z & 0xffff0000u), (a.w & 0xffffu) | (b.w << 16), (a.w >> 16) | (b.w & 0xffff0000u)};
+                char* d = smem + (size_t)hy * RP + hp * 16;
+                constexpr bool SWZ = (2 * D::PL) % 128 == 0;   // planes 0 and 2 on the same banks: the q = 1 lanes store group 3 first (see dw_run)
+                if constexpr (SWZ) {
+                    *reinterpret_cast<u32x4*>(d + (q ? 3 : 0) * D::PL) = q ? g1 : g0;
+                    *reinterpret_cast<u32x4*>(d + (q ? 2 : 1) * D::PL) = q ? g0 : g1;
+                } else {
+                    *reinterpret_cast<u32x4*>(d + (2 * q) * D::PL) = g0;
+                    *reinterpret_cast<u32x4*>(d + (2 * q + 1) * D::PL) = g1;
+                }
+            }
+        }
+        __syncthreads();  // halo (and, first pass, the filter block) visible
+        const int gy = ty0 + y;
+        if (!chan_ok || gy >= H || tx0 + x0 >= W) continue;
+        float acc[DW_R][4];
+#pragma unroll
+        for (int r = 0; r < DW_R; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = 0.f;
+#pragma unroll 1
+        for (int ky = 0; ky < ((DW_ABLATE & 4) ? 1 : K); ++ky) {
+            u32x4 we[NW], wo[NW], pp[NPAIR];
+            const uint32_t* wrow = wsw + (size_t)((ky * D::NCG + cg) * 2) * NW * 4;
+            const char* row = smem + (size_t)(y + ky) * RP + cg * D::PL + x0 * 8;
+#pragma unroll
+            for (int m = 0; m < NW; ++m) {
+                we[m] = *reinterpret_cast<const u32x4*>(wrow + m * 4);
+                wo[m] = *reinterpret_cast<const u32x4*>(wrow + (NW + m) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < NPAIR; ++j) pp[j] = *reinterpret_cast<const u32x4*>(row + (size_t)j * 16);
+#ifndef YMK_HOST_EMU
+            __builtin_amdgcn_sched_barrier(0);     // all reads of the row requested before the first use (see dw_run)
+#endif
+#pragma unroll
+            for (int j = 0; j < NPAIR; ++j)        // pair-major: every word is used while it is hot, by up to 2 x NW outputs
+#pragma unroll
+                for (int r = 0; r < DW_R; ++r) {
+                    const int m = j - (r >> 1);    // compile-time after unrolling
+                    if (m >= 0 && m < NW) {
+                        const u32x4& wv = (r & 1) ? wo[m] : we[m];
+                        acc[r][0] = dot2_h16(pp[j].x, wv.x, acc[r][0]);
+                        acc[r][1] = dot2_h16(pp[j].y, wv.y, acc[r][1]);
+                        acc[r][2] = dot2_h16(pp[j].z, wv.z, acc[r][2]);
+                        acc[r][3] = dot2_h16(pp[j].w, wv.w, acc[r][3]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < DW_R; ++r) {
+            const int gx = tx0 + x0 + r;
+            if (gx >= W) break;
+            const size_t pix = (size_t)gy * W + gx;
+            float v[4] = {acc[r][0] + bv[0], acc[r][1] + bv[1], acc[r][2] + bv[2], acc[r][3] + bv[3]};
+            if (ep.act == YMK_ACT_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
+            }
+            if (rb) {
+                float r0, r1, r2, r3;
+                load4(rb + pix * ep.ldr + c0 + cg * 4, r0, r1, r2, r3);
+                v[0] = r0 + v[0]; v[1] = r1 + v[1]; v[2] = r2 + v[2]; v[3] = r3 + v[3];
+            }
+            if (!(DW_ABLATE & 8) || v[0] == 12345.f) store4(ob + pix * ldy + c0 + cg * 4, v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// the 16-bit stencil of this build: dot2 form where it applies (no register prefetch needed), else dw_run
+template <typename T, int K, int TW>
+__device__ __forceinline__ void dw_tile_run(const T* __restrict__ xb, int H, int W, int C, int ldx, const T* __restrict__ w, T* __restrict__ ob,
+                                            int ldy, int cb, int st0, int st1, const DwEpi& ep, const T* __restrict__ rb, char* smem) {
+    if constexpr (DwTile<T, TW>::PAIRDOT && !DwTile<T, TW>::prefetch(K)) dw_run_pairdot<T, K, TW>(xb, H, W, C, ldx, w, ob, ldy, cb, st0, st1, ep, rb, smem);
+    else dw_run<T, K, TW>(xb, H, W, C, ldx, w, ob, ldy, cb, st0, st1, ep, rb, smem);
+}
+
 // Work decomposition shared by both launchers: blockIdx.x = run * ncb + cb (channel block fastest, XCD-remapped),
 // run = `spt` consecutive spatial tiles.
 struct DwGeom {
@@ -364,7 +518,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
     DwEpi ep{a.bias, a.res, a.ldr, a.act};
     const T* rb = a.res ? reinterpret_cast<const T*>(a.res) + img * a.ldr : nullptr;
     const int cb = lid % a.ncb, st0 = (lid / a.ncb) * a.spt;
-    dw_run<T, K, TW>(reinterpret_cast<const T*>(a.x) + img * a.ldx, a.H, a.W, a.C, a.ldx, reinterpret_cast<const T*>(a.w),
+    dw_tile_run<T, K, TW>(reinterpret_cast<const T*>(a.x) + img * a.ldx, a.H, a.W, a.C, a.ldx, reinterpret_cast<const T*>(a.w),
                      reinterpret_cast<T*>(a.y) + img * a.ldy, a.ldy, cb, st0, min(a.nsp, st0 + a.spt), ep, rb, smem);
 }
 
@@ -453,13 +607,13 @@ __global__ __launch_bounds__(256) void moe_dw_kernel(MoeDwArgs a) {
     const int lid = (int)xcd_remap_dw(blockIdx.x, gridDim.x);
     const int cb = lid % a.ncb, st0 = (lid / a.ncb) * a.spt, st1 = min(a.nsp, st0 + a.spt);
     switch (ks) {
-        case 3: if constexpr (KMAX >= 3) dw_run<T, 3, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
-        case 5: if constexpr (KMAX >= 5) dw_run<T, 5, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
-        case 7: if constexpr (KMAX >= 7) dw_run<T, 7, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
-        case 9: if constexpr (KMAX >= 9) dw_run<T, 9, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
-        case 11: if constexpr (KMAX >= 11) dw_run<T, 11, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
-        case 13: if constexpr (KMAX >= 13) dw_run<T, 13, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
-        case 15: if constexpr (KMAX >= 15) dw_run<T, 15, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 3: if constexpr (KMAX >= 3) dw_tile_run<T, 3, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 5: if constexpr (KMAX >= 5) dw_tile_run<T, 5, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 7: if constexpr (KMAX >= 7) dw_tile_run<T, 7, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 9: if constexpr (KMAX >= 9) dw_tile_run<T, 9, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 11: if constexpr (KMAX >= 11) dw_tile_run<T, 11, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 13: if constexpr (KMAX >= 13) dw_tile_run<T, 13, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
+        case 15: if constexpr (KMAX >= 15) dw_tile_run<T, 15, TW>(xb, a.H, a.W, a.C, a.ldx, w, ob, a.C, cb, st0, st1, ep, nullptr, smem); break;
         default: break;
     }
 }

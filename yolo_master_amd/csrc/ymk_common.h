@@ -67,6 +67,18 @@ __device__ __forceinline__ f32x4 mfma16x16x32_h16(const u32x4& a, const u32x4& b
 }
 #endif
 __device__ __forceinline__ h16_t f32_to_h16(float f) { return (h16_t)(pack_h16x2(f, 0.f) & 0xffffu); }
+// c + a.lo * b.lo + a.hi * b.hi on two packed 16-bit pairs, fp32 accumulate: v_dot2_f32_bf16 / v_dot2_f32_f16 (one VALU instruction for
+// two multiply-adds straight from the 16-bit words: no widening).  The hardware's internal rounding of the two-term sum is its own (not
+// two separately rounded fmaf's); the host emulator restates it as two fmaf's, so kernels built on it are held to a tolerance there.
+__device__ __forceinline__ float dot2_h16(uint32_t a, uint32_t b, float c) {
+#ifdef YMK_HOST_EMU
+    return __builtin_fmaf(h16hi(a), h16hi(b), __builtin_fmaf(h16lo(a), h16lo(b), c));
+#elif defined(YMK_H16_F16)
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(hw_h16x2, a), __builtin_bit_cast(hw_h16x2, b), c, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hw_h16x2, a), __builtin_bit_cast(hw_h16x2, b), c, false);
+#endif
+}
 
 // SiLU exactly as x * sigmoid(x) with sigmoid = 1/(1+exp(-x)) (torch CPU formula)
 // fast form for bf16 outputs: v_exp_f32 + v_rcp_f32 (~1 ulp), 5 instructions instead of an IEEE division

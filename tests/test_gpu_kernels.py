@@ -115,6 +115,47 @@ def test_stem(dtype, shape):
 
 
 # ------------------------------------------------------------------------------- depthwise
+DW_STAGE = [
+    # B, H, W, C, ksizes, sel
+    (4, 40, 60, 64, [3, 5, 7, 9], [[0, 3], [2, 1], [1, -1], [-1, -1]]),     # every (stencil, halo) combination of a pair; 20-wide tiles
+    (3, 80, 80, 128, [3, 5, 7, 9], [[3, 0], [-1, 2], [1, 1]]),              # a leading dropped slot, one expert twice
+    (2, 160, 160, 24, [3, 5, 7, 9], [[2, 3], [0, 1]]),                      # 40-wide tiles; C not a multiple of 16
+    (2, 33, 21, 32, [3, 3, 5, 5], [[0, 1, 2], [3, -1, 0]]),                 # three slots per image
+    (2, 20, 20, 16, [3, 7, 11, 5], [[2, 0], [1, 3]]),                       # an 11-tap expert: the per-pair kernel
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+@pytest.mark.parametrize("case", DW_STAGE, ids=lambda c: f"{c[1]}x{c[2]}x{c[3]}-k{'_'.join(map(str, c[4]))}")
+def test_esmoe_depthwise_stage_vs_per_expert_dwconv(case, dtype):
+    """ymk_esmoe_dw (one workgroup per retained (image, expert) pair and tile, the stencil size read from the selection) against
+    ymk_dwconv run once per retained pair: the same stencil code on the same data.  fp32 identical; 16-bit within 1 ulp on <= 0.1 % of
+    the outputs (the bound a variant that pairs its taps for v_dot2 at the other parity would need; today's kernels agree exactly)."""
+    from tests.test_hostemu_round2 import _dw_stage_inputs
+    from yolo_master_amd import ops
+
+    B, H, W, C, ksizes, sel = case
+    x, dw_w, dw_off, ks, sel_t, csr_off, csr_pair = (t.to(DEV) for t in _dw_stage_inputs(dtype, B, H, W, C, ksizes, sel))
+    top_k = sel_t.shape[1]
+    got = ops.esmoe_dw(x, dw_w, dw_off, ks, max(ksizes), top_k, sel_t, csr_off, csr_pair)
+    zero_b = torch.zeros(C, device=DEV)
+    for b in range(B):
+        for j in range(top_k):
+            e = sel[b][j]
+            if e < 0:
+                continue
+            k = ksizes[e]
+            w = dw_w[int(dw_off[e]): int(dw_off[e]) + k * k * C].reshape(k * k, C).contiguous()
+            ref = ops.dwconv2d(x[b: b + 1], w, zero_b, k, False)
+            g, r = got[b * top_k + j].float(), ref[0].float()
+            if dtype == torch.float32:
+                assert torch.equal(g, r), f"image {b} slot {j} expert {e} (k={k})"
+            else:
+                ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * r.abs().clamp_min(2.0 ** -10)
+                assert bool(((g - r).abs() <= ulp).all()), f"image {b} slot {j} expert {e} (k={k}): {float((g - r).abs().max())}"
+                assert float((g != r).float().mean()) <= 1e-3, f"image {b} slot {j} expert {e} (k={k})"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k", [3, 5, 7, 9, 15])
 def test_dwconv(k, dtype):

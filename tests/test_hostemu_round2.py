@@ -163,3 +163,48 @@ def test_decode_side_outputs_feed_nms(ties, host_ops):
     from tests.helpers import decode_best_then_nms
 
     decode_best_then_nms("cpu", ties=ties, seed=5)
+
+
+def _dw_stage_inputs(dtype, B, H, W, C, ksizes, sel, seed=3):
+    """Packed depthwise filters [sum k*k, C], the CSR of retained (image, slot) pairs per expert and an input with a row pitch."""
+    E, top_k = len(ksizes), len(sel[0])
+    sel = torch.tensor(sel, dtype=torch.int32)
+    xbuf = _rnd(B, H, W, C + 8, seed=seed).to(dtype)
+    x = xbuf[..., :C]                                           # ldx != C
+    offs, parts = [], []
+    for e, k in enumerate(ksizes):
+        offs.append(sum(p.numel() for p in parts))
+        parts.append(_rnd(k * k, C, seed=seed + 10 + e, scale=1.0 / k).to(dtype).reshape(-1))
+    dw_w = torch.cat(parts)
+    csr_off, csr_pair = [0], []
+    for e in range(E):
+        csr_pair += [int(p) for p in torch.nonzero(sel.reshape(-1) == e).reshape(-1)]
+        csr_off.append(len(csr_pair))
+    pad = B * top_k - len(csr_pair)
+    return (x, dw_w, torch.tensor(offs, dtype=torch.int32), torch.tensor(ksizes, dtype=torch.int32), sel,
+            torch.tensor(csr_off, dtype=torch.int32), torch.tensor(csr_pair + [0] * pad, dtype=torch.int32))
+
+
+DW_STAGE_CASES = [
+    # dtype, B, H, W, C, ksizes, sel
+    (torch.bfloat16, 4, 13, 23, 64, [3, 5, 7, 9], [[0, 3], [2, 1], [1, -1], [-1, -1]]),    # every (stencil, halo) combination of a pair; ragged tiles
+    (torch.bfloat16, 3, 9, 44, 24, [3, 5, 7, 9], [[3, 0], [-1, 2], [1, 1]]),               # wide tiles; C not a multiple of 16; a leading dropped slot
+    (torch.bfloat16, 2, 8, 21, 32, [3, 3, 5, 5], [[0, 1, 2], [3, -1, 0]]),                 # three slots per image, equal stencil sizes
+    (torch.float32, 2, 10, 20, 16, [3, 5, 7, 9], [[0, 3], [2, -1]]),                       # fp32: the per-pair kernel
+    (torch.bfloat16, 2, 10, 20, 16, [3, 7, 11, 5], [[2, 0], [1, 3]]),                      # an 11-tap expert: the per-pair kernel
+]
+
+
+@pytest.mark.parametrize("case", DW_STAGE_CASES, ids=lambda c: f"{str(c[0])[6:]}-{c[2]}x{c[3]}x{c[4]}-k{'_'.join(map(str, c[5]))}")
+def test_esmoe_depthwise_stage(case, host_ops):
+    """The depthwise stage of the retained (image, expert) pairs: since round 5 one workgroup stages an image tile's halo once (for the
+    largest stencil among the image's retained experts) and runs every retained expert on it.  Planes of dropped slots stay untouched."""
+    dtype, B, H, W, C, ksizes, sel = case
+    x, dw_w, dw_off, ks, sel_t, csr_off, csr_pair = _dw_stage_inputs(dtype, B, H, W, C, ksizes, sel)
+    top_k = sel_t.shape[1]
+    ref = emu_ops.esmoe_dw(x, dw_w, dw_off, ks, max(ksizes), top_k, sel_t, csr_off, csr_pair)
+    got = host_ops.esmoe_dw(x, dw_w, dw_off, ks, max(ksizes), top_k, sel_t, csr_off, csr_pair)
+    live = (sel_t.reshape(-1) >= 0)
+    tol = 2e-2 if dtype != torch.float32 else 2e-5
+    err = float((got[live].float() - ref[live].float()).abs().max())
+    assert err <= tol * max(1.0, float(ref[live].float().abs().max())), err

@@ -5,7 +5,7 @@ run() { python bench.py --steps 40 --warmup 10 --no-cpu-baseline "$@" 2>/dev/nul
 import json,sys; r=json.loads(sys.stdin.read()); print('$*', '->', r['value'], r['value_sync'], r['ms_per_step'], r['p50_batch_ms_sync'])"; }
 for rep in 1 2; do
 run --pipeline 3 --split 1 --sync-split 2
-run --pipeline 3 --split 1 --sync-split 3
+run --pipeline 5 --split 1 --sync-split 2
 run --pipeline 4 --split 1 --sync-split 4
 run --pipeline 2 --split 2 --sync-split 1
 run --pipeline 3 --split 2 --sync-split 2

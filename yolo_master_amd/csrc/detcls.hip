@@ -80,31 +80,87 @@ struct DetClsArgs {
     int nc, A, a_off;
 };
 
-// 3x3 depthwise stencil + bias + SiLU for this thread's 4 channels: output pixels s, s + 16, ... < npix of an (orow x ocol) map read
-// from an input tile of row length icol whose origin is one pixel up / left of the output map's
-template <int CTOT>
-__device__ __forceinline__ void dc_dw3(const char* in, int icol, char* out, int npix, int ocol, const h16_t* w, int coff, const float* bias,
+// Stencil inputs (round 5) live in LDS as PIXEL PAIRS: a 32-bit word = (pixel 2p, pixel 2p + 1) of ONE channel, a pair's 128 channels =
+// 512 bytes, pairs DC_PP bytes apart, rows of the map an even number of pixels long (20 / 18), so horizontally adjacent pixels share their
+// words.  The 3x3 stencil is then v_dot2 straight from the 16-bit words (csrc/dwconv.hip dw_run_pairdot has the idea): a thread computes the
+// TWO outputs of a pair from the pairs (v, v + 1) and (v + 2, v + 3) of three rows — the even output pairs its taps (0, 1)(2, -), the odd
+// one (-, 0)(1, 2): 48 v_dot2 and six 16-byte LDS reads per output pair and 4 channels, where the form before read nine 8-byte pixels per
+// OUTPUT and spent 36 widening shifts / masks beside 36 FMAs on them.  (The instruction rounds its two-term sum once: an output may differ
+// from the FMA chain in its last bf16 place.)  Outputs go to `out` in the [pixel][channel] layout the pointwise stages read as MFMA B rows.
+#define DC_PP 576   // bytes between pixel pairs: 512 + 64 (the pointwise epilogue's 8-byte stores of eight pairs then spread over the banks)
+
+// the 8-channel chunk q of pixels (2 pr, 2 pr + 1) -> words of channels 8q .. 8q + 7 of pair pr
+__device__ __forceinline__ void dc_store_pair(char* base, int pr, int q, const u32x4& a, const u32x4& b) {
+    const u32x4 g0 = {(a.x & 0xffffu) | (b.x << 16), (a.x >> 16) | (b.x & 0xffff0000u), (a.y & 0xffffu) | (b.y << 16), (a.y >> 16) | (b.y & 0xffff0000u)};
+    const u32x4 g1 = {(a.z & 0xffffu) | (b.z << 16), (a.z >> 16) | (b.z & 0xffff0000u), (a.w & 0xffffu) | (b.w << 16), (a.w >> 16) | (b.w & 0xffff0000u)};
+    *reinterpret_cast<u32x4*>(base + pr * DC_PP + q * 32) = g0;
+    *reinterpret_cast<u32x4*>(base + pr * DC_PP + q * 32 + 16) = g1;
+}
+
+// 3x3 depthwise stencil + bias + SiLU for this thread's 4 channels: output pairs s, s + 16, ... < npair of a map `oprow` pairs wide, read
+// from a pair-layout input tile `iprow` pairs wide whose origin is one pixel up / left of the output map's
+// LEAN (the first stencil of the 256-channel levels, which runs with the first pointwise stage's twelve accumulators live): the odd output's
+// (-, 0) tap words are shifted out of the even output's (0, 1) words instead of being held, and the pairs are read row by row: 28 registers less
+template <int CTOT, bool LEAN>
+__device__ __forceinline__ void dc_dw3(const char* in, int iprow, char* out, int npair, int oprow, const h16_t* w, int coff, const float* bias,
                                        int cg, int s) {
-    float wt[9][4];
+    u32x4 we0[3], we1[3], wo0[LEAN ? 1 : 3], wo1[3];   // per filter row: tap pairs (0,1) (2,-) for the even output, (-,0) (1,2) for the odd one; .xyzw = channels
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const u32x2 q = *reinterpret_cast<const u32x2*>(w + (size_t)tap * CTOT + coff + cg * 4);
-        wt[tap][0] = h16lo(q.x); wt[tap][1] = h16hi(q.x); wt[tap][2] = h16lo(q.y); wt[tap][3] = h16hi(q.y);
+    for (int ky = 0; ky < 3; ++ky) {
+        const u32x2 t0 = *reinterpret_cast<const u32x2*>(w + (size_t)(ky * 3 + 0) * CTOT + coff + cg * 4);
+        const u32x2 t1 = *reinterpret_cast<const u32x2*>(w + (size_t)(ky * 3 + 1) * CTOT + coff + cg * 4);
+        const u32x2 t2 = *reinterpret_cast<const u32x2*>(w + (size_t)(ky * 3 + 2) * CTOT + coff + cg * 4);
+        const uint32_t a0[4] = {t0.x & 0xffffu, t0.x >> 16, t0.y & 0xffffu, t0.y >> 16};
+        const uint32_t a1[4] = {t1.x & 0xffffu, t1.x >> 16, t1.y & 0xffffu, t1.y >> 16};
+        const uint32_t a2[4] = {t2.x & 0xffffu, t2.x >> 16, t2.y & 0xffffu, t2.y >> 16};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            we0[ky][c] = a0[c] | (a1[c] << 16);
+            we1[ky][c] = a2[c];
+            if (!LEAN) wo0[ky][c] = a0[c] << 16;
+            wo1[ky][c] = a1[c] | (a2[c] << 16);
+        }
     }
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + coff + cg * 4);
-    for (int p = s; p < npix; p += DC_NT / 32) {
-        const int u = p / ocol, v = p - u * ocol;
-        f32x4 acc = bv;
+    const int ocol = 2 * oprow;
+    for (int p = s; p < npair; p += DC_NT / 32) {
+        const int u = p / oprow, vp = p - u * oprow;
+        f32x4 ae = bv, ao = bv;
+        if constexpr (LEAN) {
 #pragma unroll
-        for (int tap = 0; tap < ((DC_ABLATE & 2) ? 1 : 9); ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const u32x2 q = *reinterpret_cast<const u32x2*>(in + ((u + ky) * icol + v + kx) * DC_PITCH + cg * 8);
-            acc.x = __builtin_fmaf(h16lo(q.x), wt[tap][0], acc.x);
-            acc.y = __builtin_fmaf(h16hi(q.x), wt[tap][1], acc.y);
-            acc.z = __builtin_fmaf(h16lo(q.y), wt[tap][2], acc.z);
-            acc.w = __builtin_fmaf(h16hi(q.y), wt[tap][3], acc.w);
+            for (int ky = 0; ky < ((DC_ABLATE & 2) ? 1 : 3); ++ky) {
+                const char* r = in + ((u + ky) * iprow + vp) * DC_PP + cg * 16;
+                const u32x4 pa = *reinterpret_cast<const u32x4*>(r), pb = *reinterpret_cast<const u32x4*>(r + DC_PP);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ae[c] = dot2_h16(pa[c], we0[ky][c], ae[c]);
+                    ae[c] = dot2_h16(pb[c], we1[ky][c], ae[c]);
+                    ao[c] = dot2_h16(pa[c], we0[ky][c] << 16, ao[c]);
+                    ao[c] = dot2_h16(pb[c], wo1[ky][c], ao[c]);
+                }
+            }
+        } else {
+            u32x4 pa[3], pb[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const char* r = in + ((u + ky) * iprow + vp) * DC_PP + cg * 16;
+                pa[ky] = *reinterpret_cast<const u32x4*>(r);
+                pb[ky] = *reinterpret_cast<const u32x4*>(r + DC_PP);
+            }
+            DC_SCHED_BARRIER();
+#pragma unroll
+            for (int ky = 0; ky < ((DC_ABLATE & 2) ? 1 : 3); ++ky)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ae[c] = dot2_h16(pa[ky][c], we0[ky][c], ae[c]);
+                    ae[c] = dot2_h16(pb[ky][c], we1[ky][c], ae[c]);
+                    ao[c] = dot2_h16(pa[ky][c], wo0[ky][c], ao[c]);
+                    ao[c] = dot2_h16(pb[ky][c], wo1[ky][c], ao[c]);
+                }
         }
-        *reinterpret_cast<u32x2*>(out + p * DC_PITCH + cg * 8) = dc_pack_silu(acc);
+        char* o = out + (u * ocol + 2 * vp) * DC_PITCH + cg * 8;
+        *reinterpret_cast<u32x2*>(o) = dc_pack_silu(ae);
+        *reinterpret_cast<u32x2*>(o + DC_PITCH) = dc_pack_silu(ao);
     }
 }
 
@@ -150,27 +206,32 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
         for (int ch = 0; ch < NCH; ++ch) {   // (unrolled: the fragment array is indexed by ch)
             // ---- stage: x chunk on the tile + 2 -> region A -----------------------------------------------------------------------------
             {
-                constexpr int NL = (DC_NX * 16 + DC_NT - 1) / DC_NT;   // 16-byte pieces per thread (8)
-                u32x4 v[NL];
+                constexpr int NPR = DC_NX / 2;                          // 120 pixel pairs (rows of DC_XC = 20 pixels)
+                constexpr int NL = (NPR * 16 + DC_NT - 1) / DC_NT;      // (pair, 8-channel chunk) pieces per thread (4)
+                u32x4 va[NL], vb[NL];
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const int i = t + l * DC_NT;
-                    const int px = i >> 4, q = i & 15;
-                    const int u = px / DC_XC, w = px - u * DC_XC;
+                    const int pr = i >> 4, q = i & 15;
+                    const int u = pr / (DC_XC / 2), w = 2 * (pr - u * (DC_XC / 2));
                     const int iy = oy0 - 2 + u, ix = ox0 - 2 + w;
-                    v[l] = u32x4{0u, 0u, 0u, 0u};
-                    if (!(DC_ABLATE & 1) && px < DC_NX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                        v[l] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.ldx + ch * 128 + q * 8);
+                    va[l] = u32x4{0u, 0u, 0u, 0u};
+                    vb[l] = u32x4{0u, 0u, 0u, 0u};
+                    if (!(DC_ABLATE & 1) && pr < NPR && (unsigned)iy < (unsigned)a.H) {
+                        const h16_t* src = xb + ((size_t)iy * a.W + ix) * a.ldx + ch * 128 + q * 8;
+                        if ((unsigned)ix < (unsigned)a.W) va[l] = *reinterpret_cast<const u32x4*>(src);
+                        if ((unsigned)(ix + 1) < (unsigned)a.W) vb[l] = *reinterpret_cast<const u32x4*>(src + a.ldx);
+                    }
                 }
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const int i = t + l * DC_NT;
-                    if ((i >> 4) < DC_NX) *reinterpret_cast<u32x4*>(sA + (i >> 4) * DC_PITCH + (i & 15) * 16) = v[l];
+                    if ((i >> 4) < NPR) dc_store_pair(sA, i >> 4, i & 15, va[l], vb[l]);
                 }
             }
             __syncthreads();
             // ---- dw1: region A -> region B (tile + 1) -------------------------------------------------------------------------------------
-            dc_dw3<CIN>(sA, DC_XC, sB, DC_NMID, DC_MC, a.dw1, ch * 128, a.bd1, cg, sl);
+            dc_dw3<CIN, (CIN > 128)>(sA, DC_XC / 2, sB, DC_NMID / 2, DC_MC / 2, a.dw1, ch * 128, a.bd1, cg, sl);
             __syncthreads();
             // ---- pw1: K chunk ch ----------------------------------------------------------------------------------------------------------
             // k-step outermost: the MFMAs that follow one another then belong to DIFFERENT accumulators (with the pixel fragment outermost
@@ -194,20 +255,26 @@ __global__ __launch_bounds__(DC_NT) void detect_cls_kernel(DetClsArgs a) {
                 }
             if (ch + 1 < NCH) __syncthreads();   // region A / B are restaged for the next chunk
         }
-        // pw1 epilogue -> region A (the x chunk is dead: every wave is past its dw1)
+        // pw1 epilogue -> region A in the stencil's pair layout (the x chunk is dead: every wave is past its dw1).  Lanes fr and fr ^ 1 hold the
+        // two pixels of a pair (DC_MC is even) for the same four channels: the even lane hands over channels 2, 3 and assembles the words
+        // of channels 0, 1, the odd lane the other way round — one 8-byte store per lane and fragment as before.
 #pragma unroll
         for (int j = 0; j < NF1; ++j) {
             const int px = j * 16 + fr;
-            if (px < DC_NMID) {
-                const int u = px / DC_MC, v = px - u * DC_MC;
-                const int my = oy0 - 1 + u, mx = ox0 - 1 + v;
-                const bool inside = (unsigned)my < (unsigned)a.H && (unsigned)mx < (unsigned)a.W;
-                *reinterpret_cast<u32x2*>(sA + px * DC_PITCH + (wave * 16 + fc * 4) * 2) = inside ? dc_pack_silu(acc1[j]) : u32x2{0u, 0u};
-            }
+            const int u = px / DC_MC, v = px - u * DC_MC;
+            const int my = oy0 - 1 + u, mx = ox0 - 1 + v;
+            const bool inside = px < DC_NMID && (unsigned)my < (unsigned)a.H && (unsigned)mx < (unsigned)a.W;
+            const u32x2 mine = inside ? dc_pack_silu(acc1[j]) : u32x2{0u, 0u};     // (c0 | c1 << 16, c2 | c3 << 16) of this lane's pixel
+            const bool odd = fr & 1;
+            const uint32_t give = odd ? mine.x : mine.y, keep = odd ? mine.y : mine.x;
+            const uint32_t got = (uint32_t)__shfl_xor((int)give, 1);               // the partner pixel's half this lane assembles
+            const uint32_t ev = odd ? got : keep, od = odd ? keep : got;           // (even pixel, odd pixel) of this lane's two channels
+            const u32x2 wds = {(ev & 0xffffu) | (od << 16), (ev >> 16) | (od & 0xffff0000u)};
+            if (px < DC_NMID) *reinterpret_cast<u32x2*>(sA + (px >> 1) * DC_PP + (wave * 4 + fc) * 16 + (odd ? 8 : 0)) = wds;
         }
         __syncthreads();
         // ---- dw2: region A (tile + 1) -> region B (tile) -------------------------------------------------------------------------------------
-        dc_dw3<128>(sA, DC_MC, sB, DC_NP, DC_TW, a.dw2, 0, a.bd2, cg, sl);
+        dc_dw3<128, false>(sA, DC_MC / 2, sB, DC_NP / 2, DC_TW / 2, a.dw2, 0, a.bd2, cg, sl);
         __syncthreads();
         // ---- pw2: region B -> region A ----------------------------------------------------------------------------------------------------------
         {

@@ -29,7 +29,10 @@ def _yaml(scale="n", task="det"):
     return f"{refboot.REF}/ultralytics/cfg/models/master/v0/{task}/{name}"
 
 
-def _yolo(scale="n", task="det", seed=0):
+def _yolo(scale="n", task="det", seed=0, mask_gain=None):
+    """mask_gain (segment): the last 1x1 of the mask-coefficient branch (`Segment.cv4[i][2]`, head.py) times this factor.  With the plain seeded
+    weights every mask logit lies within 0.03 of zero, so the predictor's empty-mask filter (`masks.amax > 0`) and the mask pixels themselves
+    are decided by the last bits of whichever convolution algorithm ran; x 1000 puts 99 % of the logits beyond 0.4 (median 14)."""
     refboot.boot()
     refboot.stub_torchvision()
     from ultralytics import YOLO
@@ -37,7 +40,12 @@ def _yolo(scale="n", task="det", seed=0):
     from yolo_master_amd.weights import synth_state_dict
 
     m = YOLO(_yaml(scale, task), verbose=False)
-    m.model.load_state_dict(synth_state_dict(m.model.state_dict(), seed=seed))
+    sd = synth_state_dict(m.model.state_dict(), seed=seed)
+    if mask_gain:
+        for k in sd:
+            if ".cv4." in k and k.endswith(".2.weight"):
+                sd[k] = sd[k] * mask_gain
+    m.model.load_state_dict(sd)
     return m
 
 
@@ -47,15 +55,18 @@ def _iou(a, b):
     return inter / ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
 
 
-def _match(gb, rb, box_tol, score_tol):
+def _match(gb, rb, box_tol, score_tol, allow_extra=False):
     """Row j of the reference's detections -> the row of the hooked run that is the same detection (same class, score within
     score_tol, box within box_tol).  Position-wise comparison is not enough: detections with EQUAL scores (saturated logits of the
     seeded random weights) come out of the reference's unstable argsort in an order of its own.  And with thousands of candidates above a
     conf of 0.002 two overlapping candidates of one class can carry scores that differ in the 9th digit (the synthetic network is nearly
     translation-equivariant: the same box one stride further): which of the two NMS keeps is decided by arithmetic the two runs do not
-    share (the reference's own convolution algorithms differ between boxes).  Such a pair — same class, scores within 1e-6, IoU above the NMS
-    threshold — counts as a tie flip, not as a mismatch; the callers bound their number.  Returns (perm, flipped)."""
-    assert gb.shape == rb.shape and gb.shape[0] > 0, (gb.shape, rb.shape)
+    share (the reference's eager path lets MIOpen pick its convolution algorithms per box).  Such a pair — same class, scores within 1e-6,
+    IoU above the NMS threshold — counts as a tie flip, not as a mismatch; the callers bound their number.
+    allow_extra: gb may hold rows rb has no counterpart for (segment: see _same_detections).  Returns (perm, flipped)."""
+    if not allow_extra:
+        assert gb.shape == rb.shape, (gb.shape, rb.shape)
+    assert gb.shape[0] >= rb.shape[0] > 0, (gb.shape, rb.shape)
     used = torch.zeros(gb.shape[0], dtype=torch.bool)
     perm, flipped = [], []
     for j in range(rb.shape[0]):
@@ -77,18 +88,34 @@ def _match(gb, rb, box_tol, score_tol):
     return torch.tensor(perm), torch.tensor(flipped)
 
 
-def _same_detections(got, ref, box_tol=1e-2, score_tol=1e-4):
+def _same_detections(got, ref, box_tol=1e-2, score_tol=1e-4, masks_filtered=False):
+    """masks_filtered (segment): the predictor drops every detection whose mask has no positive pixel (`masks.amax((-2, -1)) > 0`,
+    models/yolo/segment/predict.py:107-109), so WHICH detections survive depends on the sign of the largest mask logit inside each box — with
+    ill-conditioned masks on arithmetic the two runs do not share (seen with the plain seeded weights: 203 hooked against 203 or 137
+    un-hooked on two boxes; the test now conditions the mask branch, `_yolo(mask_gain=...)`).  The smaller list is matched into the larger
+    one; every unmatched detection of the larger list must be a borderline of that filter — at most 0.2 % of its mask pixels set in the
+    run that kept it — and there may be at most max(2, 3 %) of them.  Returns (n, perms)."""
     assert len(got) == len(ref)
-    n, perms, flips = 0, [], []
+    n, perms, flips, swaps = 0, [], [], []
     for g, r in zip(got, ref):
         gb, rb = g.boxes.data.float().cpu(), r.boxes.data.float().cpu()
-        perm, flipped = _match(gb, rb, box_tol, score_tol)
-        perms.append(perm); flips.append(flipped)
+        swap = masks_filtered and rb.shape[0] > gb.shape[0]
+        big, small, bigres = (rb, gb, r) if swap else (gb, rb, g)
+        perm, flipped = _match(big, small, box_tol, score_tol, allow_extra=masks_filtered)
+        if big.shape[0] > small.shape[0]:
+            extra = torch.ones(big.shape[0], dtype=torch.bool)
+            extra[perm] = False
+            area = bigres.masks.data.bool().cpu()[extra].flatten(1).float().mean(1)
+            assert int(extra.sum()) <= max(2, (3 * big.shape[0]) // 100), f"{int(extra.sum())} of {big.shape[0]} detections were kept by one run only"
+            assert float(area.max()) <= 2e-3, (f"{int(extra.sum())} detections only one run kept, and one of them has {float(area.max()):.2%} "
+                                               f"of its mask pixels set: not a borderline of the empty-mask filter")
+            print(f"  ({int(extra.sum())} detections kept by one run only: masks within rounding of empty, <= {float(area.max()):.3%} of the pixels)")
+        perms.append(perm); flips.append(flipped); swaps.append(swap)
         assert g.orig_shape == r.orig_shape and g.names == r.names
-        n += gb.shape[0]
+        n += small.shape[0]
     nflip = int(sum(int(f.sum()) for f in flips))
     assert nflip <= max(2, n // 50), f"{nflip} of {n} detections are score-tie flips"
-    _same_detections.flips = flips
+    _same_detections.flips, _same_detections.swaps = flips, swaps
     return n, perms
 
 
@@ -256,19 +283,20 @@ def test_segment_predict_on_the_gpu_through_the_hooks():
         pytest.skip("no v0 segmentation YAML in this reference checkout")
     x = synth_input(2, 256, 256, seed=44)
     kw = dict(conf=0.002, iou=0.7, verbose=False, device=0)
-    ref = _yolo(task="seg").predict(x, **kw)
-    m = _yolo(task="seg")
+    ref = _yolo(task="seg", mask_gain=1000.0).predict(x, **kw)
+    m = _yolo(task="seg", mask_gain=1000.0)
     yolo_master_amd.enable(m)
     try:
         got = m.predict(x, **kw)
         st = dropin.stats(m)
         assert st["calls"] >= 1 and st["nms_calls"] >= 1 and not dropin._PATCHED.get("_nms_fallbacks"), (st, dropin._PATCHED.get("_nms_fallbacks"))
-        n, perms = _same_detections(got, ref, box_tol=2e-2)
-        for g, r, perm, fl in zip(got, ref, perms, _same_detections.flips):
-            if r.masks is None:
-                assert g.masks is None
+        n, perms = _same_detections(got, ref, box_tol=2e-2, masks_filtered=True)
+        for g, r, perm, fl, swap in zip(got, ref, perms, _same_detections.flips, _same_detections.swaps):
+            if r.masks is None or g.masks is None:
+                assert g.masks is None and r.masks is None
                 continue
-            gm, rm = g.masks.data.bool().cpu()[perm], r.masks.data.bool().cpu()
+            big, small = (r, g) if swap else (g, r)          # perm: rows of the smaller list -> rows of the larger one
+            gm, rm = big.masks.data.bool().cpu()[perm], small.masks.data.bool().cpu()
             assert gm.shape == rm.shape
             gm, rm = gm[~fl], rm[~fl]          # (a tie flip kept the neighbouring candidate: its mask is that candidate's)
             assert float((gm != rm).float().mean()) <= 2e-3, "mask pixels differ beyond boundary flips"

@@ -18,7 +18,7 @@ fi
 tail -4 $O/r05_closures.log
 python - <<'PY'
 import json
-r = json.loads(open("gpurun_out/r05_bench_force_dist.json").read().strip().splitlines()[-1])
+r = json.loads([l for l in open("gpurun_out/r05_bench_force_dist.json") if l.startswith("{")][0])   # (RCCL prints its version banner after the line)
 print("force-dist", r["value"], r.get("value_sync"), r["ms_per_step"], r.get("host_us_per_step_launch"), r["config"].get("collectives"))
 PY
 tail -2 $O/r05_reference_timing.log | head -c 3000

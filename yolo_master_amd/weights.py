@@ -10,6 +10,7 @@ the 0.4 threshold see both outcomes), and a Detect class bias high enough that N
 """
 from __future__ import annotations
 
+import re
 import zlib
 from pathlib import Path
 
@@ -23,6 +24,9 @@ def _gen(seed: int, name: str) -> torch.Generator:
     g = torch.Generator(device="cpu")
     g.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2**63 - 1))
     return g
+
+
+_DETECT_TAIL_BIAS = re.compile(r"\.(one2one_)?cv[23]\.\d+\.2\.bias$")
 
 
 def synth_state_dict(template: dict, seed: int = 0, router_scale: float = 4.0, cls_bias_shift: float = 6.0,
@@ -63,10 +67,15 @@ def synth_state_dict(template: dict, seed: int = 0, router_scale: float = 4.0, c
                 if name.endswith((".cv2.0.2.weight", ".cv2.1.2.weight", ".cv2.2.2.weight", ".cv3.0.2.weight",
                                   ".cv3.1.2.weight", ".cv3.2.2.weight")):
                     v = v * tail_gain  # Detect tail 1x1: spread the box/cls logits (std ~1-2)
-        elif name.endswith("bias"):  # Detect tail convs: keep the reference's bias_init value (template) + jitter
+        elif name.endswith("bias") and _DETECT_TAIL_BIAS.search(name):
+            # Detect tail convs: keep the reference's bias_init value (the template's: deterministic, head.py bias_init) + jitter
             v = t.detach().clone().float() + torch.randn(shp, generator=g) * 0.1
             if ".cv3." in name:
                 v = v + cls_bias_shift
+        elif name.endswith("bias"):
+            # any other plain convolution bias (Segment's mask-coefficient tail, Proto's transposed convolution ...): the template holds
+            # torch's RANDOM initialisation there — two models built in one process would get different values — so it is never read
+            v = torch.randn(shp, generator=g) * 0.1
         elif name.endswith("gamma"):
             v = torch.full(shp, 0.01) + torch.randn(shp, generator=g) * 0.001
         else:

@@ -142,6 +142,16 @@ int ymk_c3k2_fused_pooled(const void* x, int32_t ldx, int32_t B, int32_t H, int3
                           const void* wa, int32_t kapad, const float* ba, const void* wb, int32_t kbpad, const float* bb, const void* w2,
                           int32_t k2pad, const float* b2, void* y, int32_t ldy, float* gap_part, int32_t* flags, void* stream);
 
+/* Streaming 1x1 convolution that ALSO leaves the per-tile channel sums of its output (round 5): the layer that produces an ES-MoE
+ * layer's input (a C3k2's last 1x1: block.py:293-351 -> moe/routers.py:458-527) hands the router its global average pool.  Arguments as
+ * ymk_conv2d + pool_part fp32 [B][ymk_conv1x1_pool_chunks(d)][Cout]: sums over the 128-pixel tiles of each image of the values AS STORED
+ * (rounded to the 16-bit type), in a fixed order — feed it to ymk_esmoe_route_pooled.  ymk_conv1x1_pool_chunks returns 0 for a shape the
+ * pooled kernel does not take (then ymk_conv1x1_pooled returns YMK_E_BADARG): 16-bit in and out, 1x1 stride 1, SiLU or no activation,
+ * Cout a multiple of 64 and > 64, H * W a multiple of 128, Kpad <= 256, at least the streaming kernel's minimum of pixel tiles. */
+int32_t ymk_conv1x1_pool_chunks(const ymk_conv_desc* d);
+int ymk_conv1x1_pooled(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                       float* pool_part, void* stream);
+
 /* Detect class branch of one pyramid level as ONE kernel (bf16 in, fp32 logits out): DWConv3x3 -> Conv1x1 -> DWConv3x3 -> Conv1x1 ->
  * Conv2d 1x1 (+bias) (head.py:111-118, non-legacy `cv3[i]`), c3 = 128, cin = 128 or 256.  The four intermediate maps stay in LDS
  * (csrc/detcls.hip).  dw1 [9][cin] / dw2 [9][128] packed as for ymk_dwconv2d, pw1 [128][k1pad] / pw2 [128][k2pad] / w3 [ncpad][k3pad]

@@ -76,8 +76,8 @@ def _rules(x, cout=None, out=None, residual=None):
         assert _ld(residual) % 4 == 0
 
 
-def conv2d(x, w_packed, bias, k, stride, act, out=None, residual=None, out_dtype=None):
-    _count("conv2d")
+def conv2d(x, w_packed, bias, k, stride, act, out=None, residual=None, out_dtype=None, pool=False):
+    _count("conv2d")   # (pool: the library may leave `out.gap_part`; the emulated router always pools the map itself)
     assert w_packed.dtype == x.dtype and bias.dtype == torch.float32
     assert k in (1, 3) and stride in (1, 2)
     _rules(x, w_packed.shape[0], out, residual)

@@ -669,7 +669,33 @@ def test_esmoe_route_from_the_producers_pooled_sums():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 80, 80, 192, 256), (16, 160, 160, 96, 128), (32, 80, 64, 256, 384)], ids=lambda c: "x".join(map(str, c)))
+def test_streaming_1x1_pooled_sums_feed_the_router(shape):
+    """ops.conv2d(pool=True) -> ymk_conv1x1_pooled (round 5): the C3k2 tail that produces an ES-MoE layer's input leaves the router's pooled
+    sums.  Same stored values as the plain convolution; sums = the stored values summed per 128-pixel tile; the router on the sums retains the
+    experts the router on the map retains."""
+    from yolo_master_amd import ops
 
+    B, H, W, Cin, Cout = shape
+    x = rnd(B, H, W, Cin, seed=21).to(torch.bfloat16).to(DEV)
+    wp = ops.pack_conv_weight(rnd(Cout, Cin, 1, 1, seed=22, scale=Cin ** -0.5), torch.bfloat16).to(DEV)
+    bias = rnd(Cout, seed=23, scale=0.2).to(DEV)
+    plain = ops.conv2d(x, wp, bias, 1, 1, True)
+    y = ops.conv2d(x, wp, bias, 1, 1, True, pool=True)
+    assert torch.equal(y, plain)
+    part = y.gap_part
+    assert part.shape == (B, H * W // 128, Cout)
+    ref = y.float().reshape(B, H * W // 128, 128, Cout).sum(2)
+    assert torch.allclose(part, ref, rtol=1e-5, atol=1e-3), float((part - ref).abs().max())
+    g = torch.Generator().manual_seed(2)
+    w1, b1 = (torch.randn(32, Cout, generator=g) * 0.5).to(DEV), (torch.randn(32, generator=g) * 0.1).to(DEV)
+    w2, b2 = (torch.randn(4, 32, generator=g) * 0.8).to(DEV), (torch.randn(4, generator=g) * 0.1).to(DEV)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    pooled = ops.esmoe_route(y, w1, b1, w2, b2, 2, 0.3, flags)
+    byread = ops.esmoe_route(plain, w1, b1, w2, b2, 2, 0.3, flags)
+    torch.cuda.synchronize()
+    assert int(flags.item()) == 0
+    assert float((pooled[0] - byread[0]).abs().max()) <= 1e-5 and torch.equal(pooled[2], byread[2])
 
 
 @pytest.mark.gpu

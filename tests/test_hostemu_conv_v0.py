@@ -57,6 +57,39 @@ def test_conv2d_kernels(case, host_ops, hostlib):
         assert torch.all(ybuf[..., Cout:] == 7.0), "wrote past the channel range"
 
 
+POOL_CASES = [
+    # B, H, W, Cin, Cout, act, residual
+    (2, 16, 16, 128, 128, True, False),     # two 128-pixel tiles per image, one cout tile
+    (3, 16, 24, 96, 192, True, True),       # three tiles per image, two cout tiles (the second half empty), K padded to 128, residual
+    (1, 32, 16, 192, 256, False, False),    # three K groups, two full cout tiles, no activation
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: f"{c[3]}to{c[4]}-{c[0]}x{c[1]}x{c[2]}")
+def test_streaming_1x1_leaves_the_routers_pooled_sums(case, host_ops, hostlib):
+    """ops.conv2d(pool=True) -> ymk_conv1x1_pooled: the same output as the plain convolution, bit for bit, plus `out.gap_part` = the sums
+    of the STORED values over the 128-pixel tiles of each image (what ymk_esmoe_route_pooled consumes instead of the map)."""
+    B, H, W, Cin, Cout, act, use_res = case
+    dtype = torch.bfloat16
+    x = _rnd(B, H, W, Cin, seed=11).to(dtype)
+    wp = host_ops.pack_conv_weight(_rnd(Cout, Cin, 1, 1, seed=12, scale=Cin ** -0.5), dtype)
+    bias = _rnd(Cout, seed=13, scale=0.2)
+    res = _rnd(B, H, W, Cout, seed=14).to(dtype) if use_res else None
+    plain = host_ops.conv2d(x, wp, bias, 1, 1, act, residual=res)
+    assert getattr(plain, "gap_part", None) is None
+    got = host_ops.conv2d(x, wp, bias, 1, 1, act, residual=res, pool=True)
+    assert (hostlib.ymk_conv2d_last_variant() & 0xff) == 1
+    assert torch.equal(got, plain), "the pooled variant stores other values"
+    part = got.gap_part
+    chunks = H * W // 128
+    assert part.shape == (B, chunks, Cout) and part.dtype == torch.float32
+    ref = got.float().reshape(B, chunks, 128, Cout).sum(2)
+    assert torch.allclose(part, ref, rtol=1e-5, atol=1e-4), float((part - ref).abs().max())
+    # shapes the pooled kernel does not take fall back to the plain convolution, silently and without sums
+    odd = host_ops.conv2d(x[:, :, :15].contiguous(), wp, bias, 1, 1, act, pool=True)   # H x 15 pixels: not a multiple of 128
+    assert getattr(odd, "gap_part", None) is None
+
+
 DW_CASES = [
     # dtype, B, H, W, C, k, bias, act, residual
     (torch.bfloat16, 2, 20, 23, 32, 3, True, True, False),     # 40-wide tiles, two channel blocks

@@ -15,6 +15,8 @@ struct ConvArgs {
     int ablate; // tools/micro ablation switch (always 0 in the library build)
     int ncot;   // cout tiles (fast block index: workgroups sharing a pixel tile run back to back => L2 reuse)
     int64_t M;  // B*Ho*Wo
+    float* pool;      // streaming 1x1 only: fp32 [B][pool_chunks][Cout] per-tile channel sums of the STORED values, or null
+    int pool_chunks;  // 128-pixel tiles per image (H * W a multiple of 128: no tile straddles two images)
 };
 
 static int ymk_use_ws = 1;          // tools/micro can switch the streaming 1x1 kernel off for A/B runs
@@ -166,7 +168,23 @@ __device__ __forceinline__ void ws_store8(float* p, const float (&v)[8]) {
     store4(p + 4, v[4], v[5], v[6], v[7]);
 }
 
-template <typename T, int KG, bool PERM>
+// sum over the 16 lanes of a DPP row (lanes 16 i .. 16 i + 15), left in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+#ifndef YMK_HOST_EMU
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+#else
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+#endif
+    return v;
+}
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<h16_t>(float v) { return h16_to_f32(f32_to_h16(v)); }
+
+template <typename T, int KG, bool PERM, bool POOL = false>
 __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int BK = 8 * VEC;            // elements per 128-byte K group
@@ -178,6 +196,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
     constexpr bool PRECISE = sizeof(T) == 4;
     __shared__ u32x4 sW[128 * RS];
     __shared__ u32x4 sA[128 * RS];
+    __shared__ float sPool[POOL ? 256 : 1];   // [2 pixel halves][128 couts]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wco = wave >> 1, wpx = wave & 1;
     const int srow = t >> 3, cq = t & 7;
@@ -270,6 +289,11 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
             }
+        float psum[2][8];   // pooled variant: this lane's sums over its four pixel groups, couts cout_of(2h) .. + 7
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) psum[h][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t m = tile * 128 + (wpx * 4 + j) * 16 + fr;
@@ -291,6 +315,10 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
                         v[q * 4 + 0] += r0; v[q * 4 + 1] += r1; v[q * 4 + 2] += r2; v[q * 4 + 3] += r3;
                     }
                 }
+                if (POOL) {   // sums of the values AS STORED (rounded to the activation type): what a global average pool of y would read
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) psum[h][r] += round_to<T>(v[r]);
+                }
                 T* yo = reinterpret_cast<T*>(a.y) + m * a.ldy;
                 if (wide) {
                     if (cout_of(2 * h) < a.Cout) ws_store8(yo + cout_of(2 * h), v);   // whole 64-cout groups: the lane's eight couts are in or out together
@@ -298,6 +326,26 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
                     if (cout_of(2 * h) < a.Cout) store4(yo + cout_of(2 * h), v[0], v[1], v[2], v[3]);
                     if (cout_of(2 * h + 1) < a.Cout) store4(yo + cout_of(2 * h + 1), v[4], v[5], v[6], v[7]);
                 }
+            }
+        }
+        if (POOL) {
+            // Fixed order: a lane's four pixel groups (above), the sixteen lanes of a cout group (row rotations by 8, 4, 2, 1: DPP operands of
+            // the adds, no LDS round trip — __shfl_xor is a ds_bpermute each and made this epilogue 23 % longer), then the two pixel halves of
+            // the tile (waves wpx = 0, 1) through 1 KB of LDS.
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) psum[h][r] = row16_sum(psum[h][r]);
+            if (fr == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) sPool[wpx * 128 + wco * 64 + h * 32 + fc * 8 + r] = psum[h][r];
+            }
+            __syncthreads();   // (the next tile writes sPool only behind the two barriers at the top of the loop)
+            if (t < 128 && co0 + t < a.Cout) {
+                const int64_t b = tile / a.pool_chunks, ch = tile - b * a.pool_chunks;
+                a.pool[((size_t)b * a.pool_chunks + ch) * a.Cout + co0 + t] = sPool[t] + sPool[128 + t];
             }
         }
     }
@@ -317,6 +365,15 @@ static bool launch_conv1x1_ws(ConvArgs a, hipStream_t s) {
     if (nblk_px < 1) nblk_px = 1;
     if (nblk_px > ntiles) nblk_px = (int)ntiles;
     dim3 grid(nblk_px * a.ncot), blk(256);
+    if (a.pool) {   // (ymk_conv1x1_pooled checked: 16-bit type, Cout % 64 == 0, H * W % 128 == 0)
+        switch (kg) {
+            case 1: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 1, true, true>), grid, blk, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 2, true, true>), grid, blk, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 3, true, true>), grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 4, true, true>), grid, blk, 0, s, a); break;
+        }
+        return true;
+    }
     if (a.Cout % 64 == 0) {   // whole 64-cout groups: weight rows permuted for 16-byte stores
         switch (kg) {
             case 1: hipLaunchKernelGGL((conv1x1_ws_kernel<T, 1, true>), grid, blk, 0, s, a); break;
@@ -641,7 +698,7 @@ static int conv2d_dispatch(const ymk_conv_desc* d, const ymk_conv_desc* dglds, c
     if (d->out_dtype != d->dtype && d->out_dtype != YMK_F32) return YMK_E_BADARG;
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
-    a.x2 = nullptr; a.ldx2 = 0; a.C1 = 0; a.up1 = 0; a.H1 = 0; a.W1 = 0;
+    a.x2 = nullptr; a.ldx2 = 0; a.C1 = 0; a.up1 = 0; a.H1 = 0; a.W1 = 0; a.pool = nullptr; a.pool_chunks = 0;
     a.B = d->B; a.H = d->H; a.W = d->W;
     const int pad = d->ksize / 2;
     a.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
@@ -1107,5 +1164,41 @@ extern "C" int ymk_conv2d_stem_nchw(const float* x, const float* w, const float*
                            B, Cin, H, W, Ho, Wo, Cout, ksize, stride, ldy, act);
     else
         return YMK_E_BADARG;
+    return ymk_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Streaming 1x1 convolution that also leaves the per-tile channel sums of its output (round 5): the producer of an ES-MoE layer's input
+// hands the router its global average pool (moe/routers.py:458-527) instead of the router re-reading the map (210 MB at 64 x 80 x 80 x 256).
+// pool_part fp32 [B][ymk_conv1x1_pool_chunks(...)][Cout]: sums over the 128-pixel tiles of each image of the values AS STORED, fixed order;
+// feed it to ymk_esmoe_route_pooled.  Shapes: 16-bit types, 1x1 stride 1, Cout % 64 == 0, H * W % 128 == 0, and what conv1x1_ws_kernel takes
+// (Cin <= 256 ..., enough tiles) — ymk_conv1x1_pool_chunks returns 0 otherwise and ymk_conv1x1_pooled YMK_E_BADARG.
+// ---------------------------------------------------------------------------------------------------------------------------------
+static bool conv1x1_pool_ok(const ymk_conv_desc* d) {
+    if (!d || d->dtype != YMK_BF16 || d->out_dtype != YMK_BF16 || d->ksize != 1 || d->stride != 1) return false;
+    if (d->Cout % 64 || d->Cout <= 64 || ((int64_t)d->H * d->W) % 128 || d->Cin % 8 || d->ldx % 8 || d->ldy % 4 || d->Kpad % 64) return false;
+    if (d->act != YMK_ACT_NONE && d->act != YMK_ACT_SILU) return false;
+    const int kg = d->Kpad / 64;
+    const int64_t ntiles = (int64_t)d->B * d->H * d->W / 128;
+    if (kg < 1 || kg > 4 || d->Kpad < d->Cin || ntiles < (kg <= 2 ? ymk_ws_min_tiles / 2 : ymk_ws_min_tiles)) return false;
+    return ymk_use_ws && !(ymk_disabled() & YMK_OFF_CONV_STREAM);
+}
+extern "C" int32_t ymk_conv1x1_pool_chunks(const ymk_conv_desc* d) { return conv1x1_pool_ok(d) ? (int32_t)((int64_t)d->H * d->W / 128) : 0; }
+extern "C" int ymk_conv1x1_pooled(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                                  float* pool_part, void* stream) {
+    if (!d || !x || !w || !bias || !y || !pool_part || !conv1x1_pool_ok(d) || (residual && d->ldr % 4)) return YMK_E_BADARG;
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+    a.x2 = nullptr; a.ldx2 = 0; a.C1 = 0; a.up1 = 0; a.H1 = 0; a.W1 = 0;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W;
+    a.Cin = d->Cin; a.Cout = d->Cout; a.stride = 1;
+    a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.Kpad = d->Kpad; a.act = d->act; a.out_f32 = 0;
+    a.M = (int64_t)d->B * d->H * d->W;
+    if (a.M <= 0) return YMK_OK;
+    if (a.M >= (1ll << 31) || (2ll * d->H * d->W + 4096) * d->ldx >= (1ll << 31)) return YMK_E_BADARG;
+    a.pool = pool_part;
+    a.pool_chunks = (int)((int64_t)d->H * d->W / 128);
+    if (!launch_conv1x1_ws<h16_t>(a, (hipStream_t)stream)) return YMK_E_BADARG;
+    ymk_last_variant = YMK_CONV_STREAM_1X1;
     return ymk_launch_status();
 }

@@ -154,6 +154,8 @@ class Conv(YmkModule):
     # multiple of the 16-byte channel vector; padded outputs are SiLU(0) = 0 and meet zero weight columns downstream)
     pad_cout_to = None
     pad_cin_to = None
+    # set by the model builder on the convolution whose output IS the input of an ES-MoE layer: ask the kernel for the router's pooled sums
+    pool_out = False
 
     def _pack(self, dtype, device):
         k, s, dw = self._geometry()
@@ -183,7 +185,7 @@ class Conv(YmkModule):
             raise RuntimeError("stem Conv (Cin<=4) consumes the NCHW network input: use _run_stem")
         if pk["dw"]:
             return ops.dwconv2d(x, pk["w"], pk["b"], pk["k"], act, out=out, residual=residual)
-        return ops.conv2d(x, pk["w"], pk["b"], pk["k"], pk["s"], act, out=out, residual=residual, out_dtype=out_dtype)
+        return ops.conv2d(x, pk["w"], pk["b"], pk["k"], pk["s"], act, out=out, residual=residual, out_dtype=out_dtype, pool=self.pool_out)
 
     def _run_stem(self, x_nchw, out=None):
         pk = self._packed(x_nchw.device)

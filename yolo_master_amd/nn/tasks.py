@@ -147,7 +147,21 @@ def parse_model(d, ch, verbose=False):
             ch = []
         ch.append(c2)
     SharedExpertMoE.reset_shared_pools()      # (nn/tasks.py:2272)
+    mark_pooled_producers(layers)
     return nn.Sequential(*layers), sorted(save)
+
+
+def mark_pooled_producers(layers):
+    """An ES-MoE layer starts with a global average pool of its input (moe/routers.py:458-527).  Where that input is the previous YAML row's
+    output and the row ends in a 1x1 convolution (C2f / C3k2 / A2C2f `cv2`, a plain Conv), the convolution is asked to leave the per-tile channel
+    sums of what it stores (Conv.pool_out -> ops.conv2d(pool=True) -> ymk_conv1x1_pooled where the shape is taken): the router then reads
+    B x chunks x C floats instead of the whole map."""
+    for i, m in enumerate(layers):
+        if isinstance(m, ES_MOE) and m.f == -1 and i > 0:
+            prev = layers[i - 1]
+            tail = prev if isinstance(prev, Conv) else getattr(prev, "cv2", None)
+            if isinstance(tail, Conv) and tail.conv.kernel_size == (1, 1) and tail.conv.groups == 1:
+                tail.pool_out = True
 
 
 class DetectionModel(nn.Module):

@@ -191,8 +191,10 @@ def fold_bn(w: torch.Tensor, bn_w, bn_b, bn_mean, bn_var, eps: float, conv_bias=
 
 
 # ----------------------------------------------------------------------------- conv
-def conv2d(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None, out_dtype=None):
-    """ymk_conv2d (include/ymk.h): y = act(conv(x) + bias) (+ residual).  act: False / True (SiLU), or "gelu" / "sigmoid" (no residual)."""
+def conv2d(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None, out_dtype=None, pool=False):
+    """ymk_conv2d (include/ymk.h): y = act(conv(x) + bias) (+ residual).  act: False / True (SiLU), or "gelu" / "sigmoid" (no residual).
+    pool: the caller's output feeds an ES-MoE router — where the pooled streaming 1x1 takes the shape (ymk_conv1x1_pool_chunks) the per-tile
+    channel sums of the output are left in `out.gap_part` (fp32 [B, chunks, Cout]) and the router pools those instead of re-reading the map."""
     B, H, W, Cin, ldx = _nhwc(x)
     Cout, Kp = w_packed.shape
     pad = k // 2
@@ -210,8 +212,14 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None,
     # act: False / True (SiLU) or "gelu" / "sigmoid" (ymk.h YMK_ACT_*: fused in the LDS-DMA core's epilogue, one in-place pass after the others)
     d = ConvDesc(DT[x.dtype], DT[out.dtype], B, H, W, Cin, Cout, k, stride, ldx, ldy, ldr, Kp,
                  _ACT[act] if isinstance(act, str) else (_lib.ACT_SILU if act else _lib.ACT_NONE))
+    chunks = int(lib.ymk_conv1x1_pool_chunks(C.byref(d))) if (pool and OPTIONS.pooled_producers and not isinstance(act, str)) else 0
     e0 = TIMER.begin()
-    check(lib.ymk_conv2d(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), _stream()), "conv2d")
+    if chunks > 0:
+        part = torch.empty((B, chunks, Cout), dtype=torch.float32, device=x.device)
+        check(lib.ymk_conv1x1_pooled(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), _p(part), _stream()), "conv1x1_pooled")
+        out.gap_part = part
+    else:
+        check(lib.ymk_conv2d(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(residual), _p(out), _stream()), "conv2d")
     if e0 is not None:
         es = x.element_size()
         nbytes = (B * H * W * Cin + Cout * k * k * Cin + (B * Ho * Wo * Cout if residual is not None else 0)) * es \

@@ -151,6 +151,10 @@ int ymk_c3k2_fused_pooled(const void* x, int32_t ldx, int32_t B, int32_t H, int3
 int32_t ymk_conv1x1_pool_chunks(const ymk_conv_desc* d);
 int ymk_conv1x1_pooled(const ymk_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                        float* pool_part, void* stream);
+/* The same sums, in the same order (bit-identical), from a map y [B][HW][ldy] that is already in memory — for producers the pooled kernel
+ * does not take (a small batch has too few tiles for the streaming kernel): a router's decision must not depend on which kernel wrote
+ * its input.  HW a multiple of 128; pool_part fp32 [B][HW / 128][C]. */
+int ymk_pool_tiles128(int32_t dtype, const void* y, int32_t ldy, int32_t B, int32_t HW, int32_t C, float* pool_part, void* stream);
 
 /* Detect class branch of one pyramid level as ONE kernel (bf16 in, fp32 logits out): DWConv3x3 -> Conv1x1 -> DWConv3x3 -> Conv1x1 ->
  * Conv2d 1x1 (+bias) (head.py:111-118, non-legacy `cv3[i]`), c3 = 128, cin = 128 or 256.  The four intermediate maps stay in LDS

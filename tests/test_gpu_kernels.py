@@ -687,6 +687,9 @@ def test_streaming_1x1_pooled_sums_feed_the_router(shape):
     assert part.shape == (B, H * W // 128, Cout)
     ref = y.float().reshape(B, H * W // 128, 128, Cout).sum(2)
     assert torch.allclose(part, ref, rtol=1e-5, atol=1e-3), float((part - ref).abs().max())
+    # a batch too small for the streaming kernel: plain convolution + ymk_pool_tiles128 — the SAME sums, bit for bit, for the same images
+    ys = ops.conv2d(x[:2].contiguous(), wp, bias, 1, 1, True, pool=True)
+    assert torch.equal(ys, y[:2]) and torch.equal(ys.gap_part, part[:2]), "tile sums depend on the kernel that produced the map"
     g = torch.Generator().manual_seed(2)
     w1, b1 = (torch.randn(32, Cout, generator=g) * 0.5).to(DEV), (torch.randn(32, generator=g) * 0.1).to(DEV)
     w2, b2 = (torch.randn(4, 32, generator=g) * 0.8).to(DEV), (torch.randn(4, generator=g) * 0.1).to(DEV)

@@ -85,8 +85,13 @@ def test_streaming_1x1_leaves_the_routers_pooled_sums(case, host_ops, hostlib):
     assert part.shape == (B, chunks, Cout) and part.dtype == torch.float32
     ref = got.float().reshape(B, chunks, 128, Cout).sum(2)
     assert torch.allclose(part, ref, rtol=1e-5, atol=1e-4), float((part - ref).abs().max())
-    # shapes the pooled kernel does not take fall back to the plain convolution, silently and without sums
-    odd = host_ops.conv2d(x[:, :, :15].contiguous(), wp, bias, 1, 1, act, pool=True)   # H x 15 pixels: not a multiple of 128
+    # the same sums, bit for bit, from the stand-alone kernel (what a batch too small for the streaming kernel gets)
+    import ctypes as C
+    alone = torch.empty_like(part)
+    assert hostlib.ymk_pool_tiles128(1, C.c_void_p(got.data_ptr()), Cout, B, H * W, Cout, C.c_void_p(alone.data_ptr()), None) == 0
+    assert torch.equal(alone, part), float((alone - part).abs().max())
+    # a map that is not a whole number of 128-pixel tiles gets no sums (the router reads it)
+    odd = host_ops.conv2d(x[:, :, :15].contiguous(), wp, bias, 1, 1, act, pool=True)   # H x 15 pixels
     assert getattr(odd, "gap_part", None) is None
 
 

@@ -65,6 +65,7 @@ SYMBOLS = {
     "ymk_c3k2_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "ymk_conv1x1_pool_chunks": (_i32, [_vp]),
     "ymk_conv1x1_pooled": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ymk_pool_tiles128": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ymk_c3k2_fused_pool_chunks": (_i32, [_i32, _i32]),
     "ymk_c3k2_fused_pooled": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "ymk_esmoe_route_pooled": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

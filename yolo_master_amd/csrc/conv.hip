@@ -168,21 +168,29 @@ __device__ __forceinline__ void ws_store8(float* p, const float (&v)[8]) {
     store4(p + 4, v[4], v[5], v[6], v[7]);
 }
 
-// sum over the 16 lanes of a DPP row (lanes 16 i .. 16 i + 15), left in every lane of the row
+// Sum over the 16 lanes of a DPP row (lanes 16 i .. 16 i + 15), left in every lane of the row.  Every step pairs lanes by an INVOLUTION
+// (mirror of the row, mirror of its halves, neighbours, neighbours' neighbours), so both partners compute the same sum and the
+// association order is a property of the lane index alone: pool_tiles128_kernel below restates it with plain loops, bit for bit.
+__device__ __forceinline__ int row16_partner(int i, int step) {   // i = lane & 15
+    return step == 0 ? 15 - i : step == 1 ? (i < 8 ? 7 - i : 23 - i) : step == 2 ? (i ^ 1) : (i ^ 2);
+}
 __device__ __forceinline__ float row16_sum(float v) {
 #ifndef YMK_HOST_EMU
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
 #else
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int lane = (int)(threadIdx.x & 63);
+    for (int step = 0; step < 4; ++step) v += __shfl(v, (lane & ~15) | row16_partner(lane & 15, step));
 #endif
     return v;
 }
 template <typename T> __device__ __forceinline__ float round_to(float v);
 template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_to<h16_t>(float v) { return h16_to_f32(f32_to_h16(v)); }
+__device__ __forceinline__ float to_f32_elem(float v) { return v; }
+__device__ __forceinline__ float to_f32_elem(h16_t v) { return h16_to_f32(v); }
 
 template <typename T, int KG, bool PERM, bool POOL = false>
 __global__ __launch_bounds__(256) void conv1x1_ws_kernel(ConvArgs a) {
@@ -1200,5 +1208,50 @@ extern "C" int ymk_conv1x1_pooled(const ymk_conv_desc* d, const void* x, const v
     a.pool_chunks = (int)((int64_t)d->H * d->W / 128);
     if (!launch_conv1x1_ws<h16_t>(a, (hipStream_t)stream)) return YMK_E_BADARG;
     ymk_last_variant = YMK_CONV_STREAM_1X1;
+    return ymk_launch_status();
+}
+
+// The same sums from a map that is already in memory (a producer the pooled kernel does not take — too few tiles at a small batch, another
+// kernel family): one workgroup per (image, 128-pixel tile), a thread per channel, the summation order of conv1x1_ws_kernel<..., POOL>
+// restated — so a router's decision does not depend on which kernel produced its input (tests: batch-independence at the full size).
+template <typename T>
+__global__ __launch_bounds__(128) void pool_tiles128_kernel(const T* __restrict__ y, int ldy, int HW, int C, float* __restrict__ part) {
+    const int chunks = HW / 128;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int c = blockIdx.y * 128 + threadIdx.x;
+    if (c >= C) return;
+    const T* base = y + ((size_t)b * HW + (size_t)ch * 128) * ldy + c;
+    float half[2];
+    for (int wpx = 0; wpx < 2; ++wpx) {
+        float sfr[16];
+#pragma unroll
+        for (int fr = 0; fr < 16; ++fr) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += to_f32_elem(base[(size_t)((wpx * 4 + j) * 16 + fr) * ldy]);
+            sfr[fr] = acc;
+        }
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            float nx[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nx[i] = sfr[i] + sfr[row16_partner(i, step)];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sfr[i] = nx[i];
+        }
+        half[wpx] = sfr[0];
+    }
+    part[((size_t)b * chunks + ch) * C + c] = half[0] + half[1];
+}
+
+extern "C" int ymk_pool_tiles128(int32_t dtype, const void* y, int32_t ldy, int32_t B, int32_t HW, int32_t C, float* pool_part, void* stream) {
+    if (!y || !pool_part || HW <= 0 || HW % 128 || C < 1 || ldy < C || (dtype != YMK_BF16 && dtype != YMK_F32)) return YMK_E_BADARG;
+    if (B <= 0) return YMK_OK;
+    const int64_t nb = (int64_t)B * (HW / 128);
+    if (nb >= (1ll << 31)) return YMK_E_BADARG;
+    dim3 grid((unsigned)nb, (unsigned)((C + 127) / 128));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == YMK_F32) hipLaunchKernelGGL(pool_tiles128_kernel<float>, grid, dim3(128), 0, s, (const float*)y, ldy, HW, C, pool_part);
+    else hipLaunchKernelGGL(pool_tiles128_kernel<h16_t>, grid, dim3(128), 0, s, (const h16_t*)y, ldy, HW, C, pool_part);
     return ymk_launch_status();
 }

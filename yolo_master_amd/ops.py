@@ -212,7 +212,11 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None,
     # act: False / True (SiLU) or "gelu" / "sigmoid" (ymk.h YMK_ACT_*: fused in the LDS-DMA core's epilogue, one in-place pass after the others)
     d = ConvDesc(DT[x.dtype], DT[out.dtype], B, H, W, Cin, Cout, k, stride, ldx, ldy, ldr, Kp,
                  _ACT[act] if isinstance(act, str) else (_lib.ACT_SILU if act else _lib.ACT_NONE))
-    chunks = int(lib.ymk_conv1x1_pool_chunks(C.byref(d))) if (pool and OPTIONS.pooled_producers and not isinstance(act, str)) else 0
+    # pooled sums for an ES-MoE router: whenever the map is a whole number of 128-pixel tiles — from the convolution's own epilogue where the
+    # streaming kernel takes the shape, else by ymk_pool_tiles128 in the SAME summation order (a routing decision must not depend on the batch size)
+    want_pool = pool and OPTIONS.pooled_producers and not isinstance(act, str) and k == 1 and stride == 1 and (Ho * Wo) % 128 == 0 \
+        and x.dtype in H16 and out.dtype == x.dtype
+    chunks = int(lib.ymk_conv1x1_pool_chunks(C.byref(d))) if want_pool else 0
     e0 = TIMER.begin()
     if chunks > 0:
         part = torch.empty((B, chunks, Cout), dtype=torch.float32, device=x.device)
@@ -227,6 +231,12 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None,
         name = conv_kernel_name(lib.ymk_conv2d_last_variant(), x.dtype, Cin, Cout, k, Kp, residual is not None)
         TIMER.end(e0, name, nbytes, 2 * B * Ho * Wo * Cout * k * k * Cin,
                   f"{Cin}->{Cout} k{k} s{stride} @{Ho}x{Wo}{' +res' if residual is not None else ''}")
+    if want_pool and chunks == 0:
+        part = torch.empty((B, Ho * Wo // 128, Cout), dtype=torch.float32, device=x.device)
+        e0 = TIMER.begin()
+        check(lib.ymk_pool_tiles128(DT[out.dtype], _p(out), ldy, B, Ho * Wo, Cout, _p(part), _stream()), "pool_tiles128")
+        TIMER.end(e0, "moe_route", B * Ho * Wo * Cout * out.element_size(), B * Ho * Wo * Cout, f"C{Cout} @{Ho}x{Wo} tile sums")
+        out.gap_part = part
     return out
 
 

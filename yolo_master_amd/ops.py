@@ -237,6 +237,8 @@ def conv2d(x, w_packed, bias, k: int, stride: int, act, out=None, residual=None,
         check(lib.ymk_pool_tiles128(DT[out.dtype], _p(out), ldy, B, Ho * Wo, Cout, _p(part), _stream()), "pool_tiles128")
         TIMER.end(e0, "moe_route", B * Ho * Wo * Cout * out.element_size(), B * Ho * Wo * Cout, f"C{Cout} @{Ho}x{Wo} tile sums")
         out.gap_part = part
+    elif not want_pool and getattr(out, "gap_part", None) is not None:
+        out.gap_part = None   # a caller-owned output tensor written before by a pooling producer: its sums describe the OLD contents
     return out
 
 
@@ -326,6 +328,8 @@ def c3k2_fused(x, p1, pa, pb, p2, out=None, pool=True):
     TIMER.end(e0, "c3k2_fused", B * H * W * (Cin + Cout) * 2, 2 * B * H * W * (64 * 64 + 288 * 16 + 144 * 32 + 96 * 128), f"{Cin}->{Cout} @{H}x{W}")
     if pool:
         out.gap_part = part
+    elif getattr(out, "gap_part", None) is not None:
+        out.gap_part = None   # (see conv2d)
     return out
 
 

@@ -169,6 +169,15 @@ def _p50(v):
     return v[len(v) // 2]
 
 
+def _flush_c_stdio():
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # (no libc handle: nothing buffered there that we could reach)
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +217,11 @@ def main():
                     "thread-local graph capture, one packed all_gather per step on the launching stream) at WORLD_SIZE = 1: the multi-GPU path's "
                     "smoke test on a 1-GPU box")
     a = ap.parse_args()
+    # stdout carries ONE line, the JSON at the end: whatever a library prints through file descriptor 1 in between (RCCL's version banner,
+    # MIOpen / hipBLASLt chatter) goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     from yolo_master_amd import ops
     from yolo_master_amd.dist import broadcast_state_dict, gather_packed, init_from_env
@@ -608,9 +622,20 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(a.scale)
             except Exception as e:  # never lose the measured line to the host-side baseline
                 print(f"[bench] cpu_baseline failed ({type(e).__name__}: {e})", file=sys.stderr)
-        print(json.dumps(res))
+        line = json.dumps(res)
+    # The JSON line is the ONLY thing the job writes to stdout.  RCCL prints a five-line version banner through C stdio when a communicator is
+    # created; with stdout a pipe it sits in the C buffer until the process exits — i.e. it used to land AFTER the line (seen with --force-dist),
+    # once per rank.  main() therefore points file descriptor 1 at stderr for the whole run; here every rank flushes its C stdio (to stderr), the
+    # ranks meet, the process group goes away, and rank 0 prints the line on the real stdout.
+    _flush_c_stdio()
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    if rank == 0:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

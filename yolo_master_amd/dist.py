@@ -93,6 +93,8 @@ def gather_packed(pack: torch.Tensor, out: torch.Tensor | None = None) -> torch.
     if dist.get_backend() == "nccl":      # RCCL over xGMI: 0.54 MB per rank at 64 images x 300 detections — latency-bound
         w = dist.all_gather_into_tensor(out, pack, async_op=True)
         w.wait()                          # stream-level: the current stream waits for the collective (what async_op=False does), the host does not
+        while _PENDING and _PENDING[0].is_completed():   # a serving loop that never drains does not accumulate retired handles
+            _PENDING.popleft()
         _PENDING.append(w)                # kept (bounded) so that drain_collectives can wait for completion instead of sleeping
         return out
     src = pack.cpu()                      # gloo (CPU tests / single-GPU functional runs)

@@ -1729,7 +1729,7 @@ class UltraOptimizedMoE(YmkModule):
         hn = h if red == rp else torch.zeros(h.shape, dtype=h.dtype, device=h.device)             # pad channels must stay zero
         ops.group_norm(h[..., :red], gs(red, 4), *pk["r4"], 1e-5, act="silu", out=hn[..., :red])
         logits = ops.conv2d(hn, *pk["r6"], 1, 1, False)
-        w, idx, pooled, rows = ops.pooled_softmax_route(logits, E, 1.0 / self.routing.temperature, k, float(self.weight_threshold))
+        w, idx, pooled, rows = ops.pooled_softmax_route(logits, E, 1.0 / self.routing.temperature, k, 0.01)   # eval threshold: the constant of moe/utils.py:172 (the module attribute is not consulted there)
         self.last_route = {"weights": w, "indices": idx, "probs": pooled}
         hid, cout = pk["e1"].shape[1], self.out_channels
         f = ops.expert_conv(x, pk["e1"], 1, idx)                                                                   # [k * B, H, W, hid], slot-major

@@ -21,6 +21,25 @@ import torch.nn as nn
 
 from .. import ops
 from ..options import OPTIONS
+
+
+class _Opt:
+    """A module attribute that follows `options.OPTIONS.<name>` at CALL time (setting OPTIONS after import takes effect)
+    unless the instance has been given its own value (`m.chunk_mb = 2.0` in a test)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __set_name__(self, owner, attr):
+        self.slot = "_opt_" + attr
+
+    def __get__(self, obj, typ=None):
+        if obj is not None and self.slot in obj.__dict__:
+            return obj.__dict__[self.slot]
+        return getattr(OPTIONS, self.name)
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.slot] = value
 from ..errors import MoERouterError, ShapeMismatchError
 
 __all__ = [
@@ -628,7 +647,7 @@ class Detect(YmkModule):
 
     # levels 1.. on side HIP streams (fork / join, also valid under graph capture): measured slower in round 1 (10.8 vs 10.1 ms/step,
     # contention) -> off; options.OPTIONS.detect_level_streams (YMK_ENABLE bit 16) switches it on for A/B runs
-    level_streams = OPTIONS.detect_level_streams
+    level_streams = _Opt("detect_level_streams")
 
     def _side_streams(self, device, n, main=None):
         """Side streams of the walk that runs on stream `main` (two concurrent walks of one model — bench.py --split — must not share them)."""
@@ -665,7 +684,7 @@ class Detect(YmkModule):
     # events: parallel branches of the captured graph).  `begin` allocates y, `start_level` forks, `finish` runs what is left and joins.
     # Measured (round 3, profiles/r03_negative_results.txt): +0.3 % on the one-stream step (6.049 -> 6.032 ms) — the levels' kernels and the
     # neck's do not overlap enough to matter — and nothing on top of bench.py's two concurrent sub-batches: OFF; options.OPTIONS.detect_early_levels (YMK_ENABLE bit 32) for A/B runs.
-    early_levels = OPTIONS.detect_early_levels
+    early_levels = _Opt("detect_early_levels")
 
     def begin(self, B, level_hw, device):
         """level_hw: [(H_l, W_l)] of every pyramid level.  Returns the run state (y, anchor offsets, raw slots)."""
@@ -688,7 +707,7 @@ class Detect(YmkModule):
     # on the predict / val path reads it, so DetectPreds recomputes the logits on first access (raw_logits) from the head's inputs.
     # options.OPTIONS.fused_decode off (YMK_DISABLE bit 4194304): the unfused path; .detect_keep_raw (YMK_ENABLE bit 256): fused, logits materialised too.
     fuse_decode = True          # (ops.detect_box_tail_supported consults OPTIONS.fused_decode)
-    keep_raw = OPTIONS.detect_keep_raw
+    keep_raw = _Opt("detect_keep_raw")
 
     def _cls_weights(self, i, device):
         s0, s1 = self.cv3[i][0], self.cv3[i][1]
@@ -1090,7 +1109,7 @@ class ES_MOE(YmkModule):
         return y
 
     # depthwise planes kept in flight between the two expert stages (MB); 0 = the whole batch in one pass (yolo_master_amd/options.py)
-    chunk_mb = OPTIONS.moe_chunk_mb
+    chunk_mb = _Opt("moe_chunk_mb")
 
     def _chunk_images(self, B, H, W, C, top_k, es):
         if self.chunk_mb <= 0:

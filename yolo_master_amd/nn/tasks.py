@@ -159,7 +159,17 @@ def mark_pooled_producers(layers):
     for i, m in enumerate(layers):
         if isinstance(m, ES_MOE) and m.f == -1 and i > 0:
             prev = layers[i - 1]
-            tail = prev if isinstance(prev, Conv) else getattr(prev, "cv2", None)
+            # the row's TAIL 1x1: cv3 for C3 / C3k (their cv2 is the parallel branch that fills half of the concat), cv2 for C2f / C3k2 /
+            # A2C2f / SPPF / C2PSA; an A2C2f with a residual scale (gamma) multiplies its output into a new tensor afterwards, so the
+            # sums of what cv2 stored would describe a tensor nobody reads — skipped
+            if isinstance(prev, Conv):
+                tail = prev
+            elif type(prev).__name__ in ("C3", "C3k"):
+                tail = getattr(prev, "cv3", None)
+            elif type(prev).__name__ == "A2C2f" and getattr(prev, "gamma", None) is not None:
+                tail = None
+            else:
+                tail = getattr(prev, "cv2", None)
             if isinstance(tail, Conv) and tail.conv.kernel_size == (1, 1) and tail.conv.groups == 1:
                 tail.pool_out = True
 

@@ -30,6 +30,13 @@ below marked (C) are read there as well, from the same variables.
 
     moe_chunk_mb            0         YMK_MOE_CHUNK_MB     ES-MoE expert stages walked in image chunks whose depthwise planes total at most this many MB
                                                            (0: the whole batch per stage)
+
+C-side, read by libymk itself at first use (A/B switches of one kernel's launch shape; every value computes the same result):
+    YMK_NMS_GREEDY_WAVES    16        waves per image in the greedy NMS pass (4 = the rounds 1-4 form)            csrc/nms.hip
+    YMK_ATTN_WAVES          0         5 | 6 forces five- / six-wave workgroups in the resident area attention      csrc/attn.hip
+    YMK_WS_MIN_TILES, YMK_GLDS_MIN_TILES, YMK_GLDS_MIN_K, YMK_GLDS_BIG_MIN_TILES, YMK_GLDS_SMALL_BELOW, YMK_GLDS_TILE, YMK_GLDS_TAP_OUTER,
+    YMK_GLDS_THREE_STAGE    —         kernel-selection thresholds of the convolution cores                         csrc/conv.hip, conv_glds.hip
+    YMK_DW_WG_TARGET        0         tiles per workgroup of the depthwise stencil                                 csrc/dwconv.hip
 """
 from __future__ import annotations
 

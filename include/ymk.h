@@ -259,6 +259,16 @@ int ymk_esmoe_pw(int32_t dtype, const void* dw_out, int32_t B, int32_t H, int32_
 int ymk_area_attn(int32_t dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, int32_t B,
                   int32_t N /*tokens = H*W*/, int32_t heads, int32_t area, void* stream);
 
+/* The same attention with the qkv projection INSIDE the kernel (16-bit, C = heads * 32 in {64, 128}, H*W / area <= 448: the
+ * detector's 40x40 A2C2f row): x is the ABlock's input [B][H*W][C] (pixel stride ldx), w the folded qkv 1x1 convolution + BatchNorm
+ * (block.py:1687,1708) packed [3C][Kpad] with rows ordered [Q | K | V], each [heads][32] (nn/modules.py AAttn.qkv.cout_perm), bias
+ * fp32 [3C].  K and V^T of a head are produced in LDS and never stored; written: out = the attention output [B][H*W][C] (stride
+ * ldo; the kernel also parks q there before overwriting it) and v [B][H*W][C] (stride ldv), the input of AAttn.pe.  Same results as
+ * ymk_conv2d + ymk_area_attn up to the rounding of the 16-bit q / k / v.  YMK_E_BADARG outside ymk_area_attn_qkv_supported. */
+int ymk_area_attn_qkv_supported(int32_t dtype, int32_t C, int32_t heads, int32_t N /*tokens = H*W*/, int32_t area);
+int ymk_area_attn_qkv(int32_t dtype, const void* x, int32_t ldx, const void* w, int32_t Kpad, const float* bias, void* out,
+                      int32_t ldo, void* v, int32_t ldv, int32_t B, int32_t N, int32_t C, int32_t heads, int32_t area, void* stream);
+
 /* nearest 2x upsample (nn.Upsample(None, 2, "nearest"), yaml head) into a channel slice */
 int ymk_upsample2x(int32_t dtype, const void* x, void* y, int32_t B, int32_t H, int32_t W,
                    int32_t C, int32_t ldx, int32_t ldy, void* stream);

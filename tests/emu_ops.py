@@ -312,6 +312,27 @@ def area_attn(qkv, heads, area, out=None):
     return out
 
 
+def area_attn_qkv_supported(dtype, C, heads, N, area):
+    return dtype in (torch.bfloat16, torch.float16) and C == heads * 32 and C in (64, 128) and N % area == 0 and 16 <= N // area <= 448
+
+
+def area_attn_qkv(x, w, b, heads, area, out=None, v_out=None):
+    """`ymk_area_attn_qkv`: qkv = w x + b rounded to the 16-bit type (what the unfused convolution stores), then area_attn; returns (out, v)."""
+    _count("area_attn_qkv")
+    B, H, W, C = x.shape
+    qkv = (x.float().reshape(-1, C) @ w[:, :C].float().t() + b.float()).to(x.dtype).reshape(B, H, W, 3 * C)
+    o = area_attn(qkv, heads, area)
+    CALLS["area_attn"] -= 1
+    v = qkv[..., 2 * C:].contiguous()
+    if out is not None:
+        out.copy_(o)
+        o = out
+    if v_out is not None:
+        v_out.copy_(v)
+        v = v_out
+    return o, v
+
+
 def upsample2x(x, out=None):
     _count("upsample2x")
     y = x.repeat_interleave(2, 1).repeat_interleave(2, 2)
@@ -736,7 +757,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
 
 
 EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "proj_mlp_fused_supported", "proj_mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "esmoe_route", "esmoe_dw",
-            "esmoe_pw", "area_attn", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
+            "esmoe_pw", "area_attn", "area_attn_qkv_supported", "area_attn_qkv", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",
             "mean_upsampled", "adaptive_avg_pool", "avg_pool", "channel_stats", "attention", "window_attention",

@@ -195,6 +195,19 @@ def test_proj_mlp_fused(case):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("case", __import__("tests.test_hostemu_round2", fromlist=["QKV_ATTN_CASES"]).QKV_ATTN_CASES
+                         + [(16, 40, 40, 4, 4, 0, 0), (3, 20, 40, 4, 2, 128, 0), (4, 16, 28, 2, 1, 0, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_area_attn_qkv_fused(case, dtype):
+    """The qkv projection inside the attention kernel (csrc/attn.hip area_attn_qkv_kernel) through the C-ABI against the 1x1 convolution +
+    attention composition in fp32 on the same 16-bit operands (incl. the detector's 40x40 / area 4 / 128-channel shape and a 448-token area)."""
+    from tests.test_hostemu_round2 import run_qkv_attn_case
+    from yolo_master_amd import ops
+
+    run_qkv_attn_case(ops, case, dev=DEV, dtype=dtype)
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------- layout kernels
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_kernels(dtype):

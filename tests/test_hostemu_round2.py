@@ -79,6 +79,51 @@ def test_area_attention(case, host_ops):
     assert torch.allclose(got.float(), ref.float(), atol=tol, rtol=tol), float((got.float() - ref.float()).abs().max())
 
 
+QKV_ATTN_CASES = [
+    # B, H, W, heads, area, x pad, out pad
+    (1, 20, 20, 4, 1, 0, 0),      # the detector's 400-token area at C = 128: 25 tiles over four waves (7 / 6 / 6 / 6), two chunks of key-tile pairs
+    (2, 6, 12, 2, 2, 64, 64),     # C = 64 (two k-steps), 36 tokens per area: ragged last token tile AND ragged key-tile pair, strided views
+    (1, 4, 8, 4, 1, 0, 128),      # a single key-tile pair, fewer token tiles than waves
+]
+
+
+def run_qkv_attn_case(ops, case, dev="cpu", dtype=torch.bfloat16):
+    """ymk_area_attn_qkv against the composition it replaces (1x1 convolution storing 16-bit qkv, then ymk_area_attn's arithmetic restated
+    in fp32) on the same 16-bit operands.  Shared with tests/test_gpu_kernels.py."""
+    from tests import emu_ops
+
+    B, H, W, heads, area, xpad, opad = case
+    C = heads * 32
+    x = _rnd(B, H, W, C, seed=5 + H, scale=1.0).to(dtype)
+    w = _rnd(3 * C, C, seed=6, scale=1.5 * C ** -0.5).to(dtype)          # rows already in [Q | K | V] order
+    b = _rnd(3 * C, seed=7, scale=0.3)
+    ref_o, ref_v = emu_ops.area_attn_qkv(x, w, b, heads, area)
+    xb = torch.full((B, H, W, C + xpad), 3.0, dtype=dtype)
+    xb[..., xpad // 2: xpad // 2 + C] = x
+    xd = xb.to(dev)[..., xpad // 2: xpad // 2 + C]
+    ob = torch.full((B, H, W, C + opad), 7.0, dtype=dtype, device=dev)
+    vb = torch.full((B, H, W, C + opad), 9.0, dtype=dtype, device=dev)
+    o, v = ob[..., opad // 2: opad // 2 + C], vb[..., opad // 2: opad // 2 + C]
+    assert ops.area_attn_qkv_supported(dtype, C, heads, H * W, area)
+    got_o, got_v = ops.area_attn_qkv(xd, w.to(dev), b.to(dev), heads, area, out=o, v_out=v)
+    assert got_o.data_ptr() == o.data_ptr() and got_v.data_ptr() == v.data_ptr()
+    # v: one rounding of the same fp32 sums (summation order may differ in the last bit of the 16-bit value)
+    ev = (got_v.float().cpu() - ref_v.float()).abs()
+    assert float(ev.max()) <= 2.0 ** -6 * max(1.0, float(ref_v.float().abs().max())), f"{case}: v max err {float(ev.max()):.3e}"
+    assert float((ev > 0).float().mean()) <= 0.02, f"{case}: {float((ev > 0).float().mean()):.4f} of v differ"
+    eo = (got_o.float().cpu() - ref_o.float()).abs()
+    assert float(eo.max()) <= 3e-2 * max(1.0, float(ref_o.float().abs().max())), f"{case}: attention max err {float(eo.max()):.3e}"
+    assert float(eo.mean()) <= 2e-3, f"{case}: attention mean err {float(eo.mean()):.3e}"
+    if opad:
+        for buf, fill in ((ob, 7.0), (vb, 9.0)):
+            assert bool((buf[..., : opad // 2].float().cpu() == fill).all()) and bool((buf[..., opad // 2 + C:].float().cpu() == fill).all()), "wrote outside the view"
+
+
+@pytest.mark.parametrize("case", QKV_ATTN_CASES, ids=lambda c: f"{c[1]}x{c[2]}-h{c[3]}-a{c[4]}")
+def test_area_attention_with_the_projection_inside(case, host_ops):
+    run_qkv_attn_case(host_ops, case)
+
+
 @pytest.mark.parametrize("ties", [False, True])
 def test_nms_radix_ordering(ties, host_ops):
     """More than 1024 candidates per image -> the radix index sort; kept anchors and detections bit-exact against the oracle,

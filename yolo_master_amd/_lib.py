@@ -78,6 +78,8 @@ SYMBOLS = {
     "ymk_mlp_fused": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ymk_proj_mlp_fused": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ymk_area_attn_qkv_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "ymk_area_attn_qkv": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_upsample2x": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_copy_channels": (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "ymk_scale_residual": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _i32, _vp]),

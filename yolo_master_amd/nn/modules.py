@@ -437,8 +437,14 @@ class AAttn(YmkModule):
         B, H, W, _ = x.shape
         if (H * W) % self.area:
             raise ValueError(f"AAttn: {H}x{W} tokens not divisible by area={self.area}")
-        qkv = self.qkv._run(x)
         c = self.all_head_dim
+        if (x.shape[-1] == c and self.qkv.conv.kernel_size == (1, 1) and not _is_silu(self.qkv.act)
+                and ops.area_attn_qkv_supported(x.dtype, c, self.num_heads, H * W, self.area)):
+            # the projection inside the attention kernel: K / V^T never leave the CU, only v (pe's input) and the result are stored
+            pk = self.qkv._packed(x.device)
+            att, v = ops.area_attn_qkv(x, pk["w"], pk["b"], self.num_heads, self.area)
+            return self.pe._run(v, residual=att)
+        qkv = self.qkv._run(x)
         att = ops.area_attn(qkv, self.num_heads, self.area)
         return self.pe._run(qkv[..., 2 * c:], residual=att)  # x + pe(v)
 

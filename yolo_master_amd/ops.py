@@ -527,6 +527,30 @@ def area_attn(qkv, heads: int, area: int, out=None):
     return out
 
 
+def area_attn_qkv_supported(dtype, C: int, heads: int, N: int, area: int) -> bool:
+    """The qkv projection inside the attention kernel (csrc/attn.hip area_attn_qkv_kernel): 16-bit, C = heads * 32 in {64, 128}, at most
+    512 tokens per area.  OPTIONS.fused_qkv_attn / YMK_DISABLE bit 2097152 switch it off (-> 1x1 convolution + area_attn)."""
+    return dtype in DT and OPTIONS.fused_qkv_attn and bool(lib.ymk_area_attn_qkv_supported(DT[dtype], C, heads, N, area))
+
+
+def area_attn_qkv(x, w, b, heads: int, area: int, out=None, v_out=None):
+    """attention(q, k, v) with qkv = w x + b computed inside the kernel (include/ymk.h ymk_area_attn_qkv): x NHWC [B, H, W, C], w the packed
+    [3C][Kpad] weights with rows [Q | K | V]; returns (attention output, v), both [B, H, W, C]."""
+    B, H, W, Cc, ldx = _nhwc(x)
+    if out is None:
+        out = new_act(B, H, W, Cc, x.dtype, x.device)
+    if v_out is None:
+        v_out = new_act(B, H, W, Cc, x.dtype, x.device)
+    ldo, ldv = _nhwc(out)[4], _nhwc(v_out)[4]
+    e0 = TIMER.begin()
+    check(lib.ymk_area_attn_qkv(DT[x.dtype], _p(x), ldx, _p(w), w.shape[1], _p(b), _p(out), ldo, _p(v_out), ldv, B, H * W, Cc, heads, area,
+                                _stream()), "area_attn_qkv")
+    es = x.element_size()
+    TIMER.end(e0, "area_attn_qkv", 3 * B * H * W * Cc * es + w.numel() * es, 2 * B * H * W * Cc * 3 * Cc + 4 * B * H * W * (H * W // area) * Cc,
+              f"C{Cc} heads {heads} area {area} @{H}x{W}")
+    return out, v_out
+
+
 # ----------------------------------------------------------------------------- layout
 def upsample2x(x, out=None):
     B, H, W, Cc, ldx = _nhwc(x)

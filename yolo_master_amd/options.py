@@ -16,6 +16,8 @@ below marked (C) are read there as well, from the same variables.
     fused_c3k2              on        8192                 YAML row 2 as one kernel (csrc/c3k2f.hip) (-> its four convolutions)
     fused_detect_cls        on        16384                Detect class branch of a level as one kernel (csrc/detcls.hip) (-> five convolutions)
     fused_decode            on        4194304              DFL decode / sigmoid in the producers' epilogues (-> fp32 logits + detect_decode kernel)
+    fused_qkv_attn          on        2097152 (C)          AAttn's qkv 1x1 + attention as ONE kernel where C = heads * 32 <= 128 (csrc/attn.hip area_attn_qkv_kernel): K / V^T are
+                                                           produced in LDS, only v and the attention output are stored (-> 1x1 convolution + ymk_area_attn)
     pooled_producers        on        1048576              the streaming 1x1 that produces an ES-MoE layer's input also leaves its per-tile channel sums
                                                            (ymk_conv1x1_pooled): the router pools those instead of re-reading the map (-> plain convolution)
 
@@ -61,6 +63,7 @@ class Options:
     fused_detect_cls: bool = True
     fused_decode: bool = True
     pooled_producers: bool = True
+    fused_qkv_attn: bool = True
     fused_proj_mlp: bool = False
     detect_level_streams: bool = False
     detect_early_levels: bool = False
@@ -77,7 +80,7 @@ class Options:
         except ValueError:
             chunk = 0.0
         return cls(res_prefetch=not d & 16, expert_conv_glds=not d & 512, fused_mlp=not d & 1024, fused_stem_pair=not d & 2048,
-                   fused_c3k2=not d & 8192, fused_detect_cls=not d & 16384, fused_decode=not d & 4194304, pooled_producers=not d & 1048576,
+                   fused_c3k2=not d & 8192, fused_detect_cls=not d & 16384, fused_decode=not d & 4194304, pooled_producers=not d & 1048576, fused_qkv_attn=not d & 2097152,
                    fused_proj_mlp=bool(e & 1024),
                    detect_level_streams=bool(e & 16), detect_early_levels=bool(e & 32), detect_keep_raw=bool(e & 256),
                    moe_chunk_mb=chunk, disable_mask=d, enable_mask=e)

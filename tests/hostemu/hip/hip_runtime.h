@@ -290,6 +290,8 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v,
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 template <typename K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 static inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }

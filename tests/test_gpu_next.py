@@ -8,7 +8,7 @@ import sys
 import pytest
 import torch
 
-from tests.test_hostemu_conv import CASES, CAT2_CASES, EPILOGUE_CASES, EXPERT_CASES, run_case, run_cat2_case, run_expert_case
+from tests.test_hostemu_conv import BIG_TILE_CASES, CASES, CAT2_CASES, EPILOGUE_CASES, EXPERT_CASES, run_case, run_cat2_case, run_expert_case, tile_flags
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +18,18 @@ BIG = [(4, 80, 80, 128, 128, 3, 2, True, False, False, 0, 0, 0), (4, 40, 40, 256
 
 @pytest.mark.parametrize("case", CASES + BIG)
 def test_conv2d_glds_direct(case):
+    from yolo_master_amd import _lib
+
+    run_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", [c[:-1] + (tile_flags(*t),) for c, t in BIG_TILE_CASES] + [
+    (8, 80, 80, 256, 256, 3, 2, True, False, False, 0, 0, tile_flags(256, 208)),      # the detector's 256 -> 256 stride-2 row: 62 tiles, ragged last
+    (16, 40, 40, 384, 256, 1, 1, True, False, False, 0, 0, tile_flags(256, 208)),     # a C3k2 tail at 40^2
+    (16, 20, 20, 768, 512, 1, 1, True, True, False, 0, 0, tile_flags(256, 208))])     # two cout tiles per pixel tile + residual
+def test_conv2d_glds_forced_big_tiles(case):
+    """The one-workgroup-per-CU tiles (128 x 512, 256 x 256, 128 x 256 and round 6's 256 x 208) forced through the entry point's flags."""
     from yolo_master_amd import _lib
 
     run_case(_lib.load(), case, dev="cuda:0", stream=torch.cuda.current_stream().cuda_stream)

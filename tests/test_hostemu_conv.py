@@ -114,6 +114,11 @@ BIG_TILE_CASES = [
     ((1, 18, 17, 128, 256, 1, 1, False, True, True, 0, 0, 1), (256, 256)),
     ((1, 30, 20, 64, 128, 1, 1, True, False, False, 0, 0, 1), (128, 512)),
     ((1, 12, 12, 64, 128, 3, 1, True, True, False, 0, 0, 1), (128, 256)),
+    # round 6: 256 couts x 208 pixels (13 pixel fragments as 7 + 6 over the two wave rows; the last transfer instruction of a k-step only in the
+    # waves whose rows exist): two tiles + a ragged third, stride 2 with residual; 1x1 with fp32 output; two cout tiles
+    ((2, 21, 19, 64, 256, 3, 2, True, True, False, 64, 0, 1), (256, 208)),
+    ((1, 25, 18, 128, 256, 1, 1, False, False, True, 0, 0, 1), (256, 208)),
+    ((1, 16, 13, 64, 512, 3, 1, True, False, False, 0, 128, 1), (256, 208)),
 ]
 
 
@@ -130,7 +135,7 @@ def test_conv2d_glds_rejects_impossible_tiles(hostlib):
     b, y = torch.zeros(128), torch.zeros(1, 8, 8, 128, dtype=torch.bfloat16)
     d = _lib.ConvDesc(_lib.YMK_BF16, _lib.YMK_BF16, 1, 8, 8, 64, 128, 1, 1, 64, 128, 0, 64, 0)
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
-    for bn, bm, two in ((256, 512, 1), (128, 512, 0), (192, 128, 1), (256, 128, 1)):   # 3-stage big tiles do not fit the LDS
+    for bn, bm, two in ((256, 512, 1), (128, 512, 0), (192, 128, 1), (256, 128, 1), (128, 208, 1), (256, 208, 0)):   # 3-stage big tiles do not fit the LDS
         assert hostlib.ymk_conv2d_glds(C.byref(d), p(x), p(w), p(b), None, p(y), tile_flags(bn, bm, two), None) == -1
 
 

@@ -10,6 +10,7 @@
 // transfer latency (one k-step in flight per workgroup, ~1.7 us per k-step at two 128 x 128 workgroups per CU = 38 GB/s per CU), so
 // at a fixed LDS budget the FLOPs per in-flight byte decide: 2 x (128 x 128) -> 128 x 512 or 256 x 256 doubles them.
 #include <stdio.h>
+#include <type_traits>
 
 #include "ymk_common.h"
 #include "glds.h"
@@ -51,16 +52,23 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
     constexpr int CPR = BK / 8;               // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;             // rows per wave-instruction
     constexpr int STAGE_U4 = ROWS * CPR;      // 16-byte slots per stage
-    constexpr int G = ROWS / (8 * RPI);       // buffer_load ... lds instructions per wave per k-step (6 or 5)
+    constexpr int G = (ROWS + 8 * RPI - 1) / (8 * RPI);   // buffer_load ... lds instructions per wave per k-step (6 or 5)
+    constexpr bool GRAG = ROWS % (8 * RPI) != 0;          // ... the last of them only in the waves whose rows exist (BM = 208)
     constexpr int GW = BN / (8 * RPI);        // of which weight rows
     constexpr int WN = BN / 64;               // waves along couts (64 couts per wave)
     constexpr int WM = 8 / WN;                // waves along pixels
-    constexpr int TP = BM / WM / 16;          // 16-pixel fragments per wave (4 or 2; 2 or 1 with 128-pixel tiles)
+    constexpr int FRAGS = BM / 16;            // 16-pixel fragments of the tile
+    constexpr int TP = (FRAGS + WM - 1) / WM; // ... per wave (4 or 2; 2 or 1 with 128-pixel tiles); UNEVEN: the last wave row holds fewer (208 pixels = 7 + 6)
+    constexpr bool UNEVEN = FRAGS % WM != 0;
     static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
+    static_assert(!(GRAG || UNEVEN) || STAGES == 2, "ragged tiles: two-stage loop only (the three-stage loop counts G transfers per wave)");
+    static_assert(BM % 16 == 0 && ROWS % RPI == 0, "tile");
     extern __shared__ u32x4 smem[];           // STAGES * STAGE_U4
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fc = lane >> 4;
+    const int tp_mine = UNEVEN ? min(TP, FRAGS - (wave / (BN / 64)) * TP) : TP;   // pixel fragments of this wave (wave-uniform)
+    const bool glast = !GRAG || ((G - 1) * 8 + wave) * RPI < ROWS;                // this wave takes part in the last transfer instruction of a k-step
     const int M = a.B * a.Ho * a.Wo;
     const int nt = a.Cout / BN;
     // bijective XCD remap: workgroup b runs on XCD b % 8, so consecutive LOGICAL tiles (same pixels, next couts; then the
@@ -114,7 +122,7 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
         } else {
             const int p = m0 + r - BN;
             unsigned mask = 0, off = 0, off2 = 0x80000000u;
-            if (p < Mlim) {
+            if (p < Mlim && (!GRAG || r < ROWS)) {
                 const int ox = p % a.Wo, oy = (p / a.Wo) % a.Ho, b = b_img >= 0 ? b_img : p / (a.Wo * a.Ho);
                 const int iy0 = oy * a.stride - pad, ix0 = ox * a.stride - pad;
                 off = (unsigned)((((b * a.H + oy * a.stride) * a.W + ox * a.stride) * a.ldx + sc) * 2);   // = tap (0, 0) from the shifted base
@@ -157,12 +165,13 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
         if (second) {
             const unsigned x2offB = (unsigned)((it_k - k1) * BK * 2);
 #pragma unroll
-            for (int j = GW; j < G; ++j) GLDS_BUFFER_LOAD_LDS(rs_x2, dst0 + j * 512, pvoff2[j - GW], x2offB);
+            for (int j = GW; j < G; ++j)
+                if (j < G - 1 || glast) GLDS_BUFFER_LOAD_LDS(rs_x2, dst0 + j * 512, pvoff2[j - GW], x2offB);
         } else {
 #pragma unroll
             for (int j = GW; j < G; ++j) {
                 const int m = ((int)(pbad[j - GW] << (31 - it_tap_bit))) >> 31;   // -1: this tap is outside the image
-                GLDS_BUFFER_LOAD_LDS(rs_x, dst0 + j * 512, pvoff[j - GW] | ((unsigned)m & 0x80000000u), tapoffB);
+                if (j < G - 1 || glast) GLDS_BUFFER_LOAD_LDS(rs_x, dst0 + j * 512, pvoff[j - GW] | ((unsigned)m & 0x80000000u), tapoffB);
             }
         }
         ++it_k;
@@ -190,7 +199,10 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
     // All fragment reads of a k-step (TP <= 4: both 32-channel halves, 24-48 registers) or of one half (the 256-pixel-per-wave tiles) are
     // ISSUED before the first MFMA: left to itself the compiler interleaves reads and MFMAs in the smallest register footprint
     // (4 reads, wait, 2 MFMAs, wait, 2 MFMAs, 2 reads, wait ...: eight exposed LDS round trips per k-step beside 16 MFMAs).
-    auto compute = [&](int stage) {
+    // tpw: the wave's pixel-fragment count as a compile-time constant (uneven tiles: the two wave rows run two straight-line copies of the
+    // k-step — a per-fragment predicate instead broke the read / MFMA clusters: 208-pixel tiles at 90 us per tile against 75 for 256)
+    auto compute = [&](int stage, auto tpw) {
+        constexpr int TPW = decltype(tpw)::value;
         if (GLDS_ABLATE & 1) return;
         const u32x4* sW = smem + stage * STAGE_U4;
         const u32x4* sX = sW + BN * CPR;
@@ -207,7 +219,7 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
                     af[kk][i] = sW[r * CPR + (((k0 + kk) * 4 + fc) ^ swz(r))];
                 }
 #pragma unroll
-                for (int j = 0; j < TP; ++j) {
+                for (int j = 0; j < TPW; ++j) {
                     const int r = ((wave / WN) * TP + j) * 16 + fr;   // BN % 8 == 0: swz(BN + r) == swz(r)
                     bfr[kk][j] = sX[r * CPR + (((k0 + kk) * 4 + fc) ^ swz(r))];
                 }
@@ -223,7 +235,7 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < TP; ++j)
+                    for (int j = 0; j < TPW; ++j)
                         if (GLDS_ABLATE & 8) acc[i][j].x += __uint_as_float(af[kk][i].x ^ bfr[kk][j].y); else
                         acc[i][j] = mfma16x16x32_h16(af[kk][i], bfr[kk][j], acc[i][j]);
 #ifndef YMK_HOST_EMU
@@ -245,7 +257,8 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
             if (!(GLDS_ABLATE & 4)) __builtin_amdgcn_s_barrier();   // everyone's pieces landed: stage kt&1 complete, the other one free
             GLDS_COMPILER_FENCE();
             if (kt + 1 < nk && !(GLDS_ABLATE & 2)) issue((kt + 1) & 1);
-            compute(kt & 1);
+            if (UNEVEN && tp_mine != TP) compute(kt & 1, std::integral_constant<int, UNEVEN ? FRAGS - (WM - 1) * TP : TP>{});
+            else compute(kt & 1, std::integral_constant<int, TP>{});
         }
     } else {
         // STAGES - 1 k-steps of DMA in flight: k-step kt + STAGES - 1 is issued right after the barrier of k-step kt, into the stage that
@@ -263,7 +276,7 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
             if (!(GLDS_ABLATE & 4)) __builtin_amdgcn_s_barrier();       // everyone's pieces landed, everyone's reads done
             GLDS_COMPILER_FENCE();
             if (kt + STAGES - 1 < nk && !(GLDS_ABLATE & 2)) issue(nxt);
-            compute(cur);
+            compute(cur, std::integral_constant<int, TP>{});
             cur = cur == STAGES - 1 ? 0 : cur + 1;
             nxt = nxt == STAGES - 1 ? 0 : nxt + 1;
         }
@@ -294,6 +307,7 @@ __device__ __forceinline__ void conv_glds_body(const GldsArgs& a) {
         const int co = cout_of(2 * h);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
+            if (UNEVEN && j >= tp_mine) continue;
             const int p = m0 + ((wave / WN) * TP + j) * 16 + fr;
             float v[8];
 #pragma unroll
@@ -375,6 +389,19 @@ static int glds_big_min_tiles() {   // YMK_GLDS_BIG_MIN_TILES=<n>: the 256 x 256
     return v;
 }
 
+static int glds_tile208() {   // YMK_GLDS_TILE208=1: the 256 x 208 tile where it fills the CU rounds better (A/B runs; off: see glds_launch_any)
+    static const int v = [] { const char* e = getenv("YMK_GLDS_TILE208"); return e ? atoi(e) : 0; }();
+    return v;
+}
+static int glds_cu_count() {
+    static const int v = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return v;
+}
+
 static int glds_tap_outer() {   // YMK_GLDS_TAP_OUTER=1: the rounds 2-3 k-step order (A/B runs)
     static const int v = [] { const char* e = getenv("YMK_GLDS_TAP_OUTER"); return e ? atoi(e) : 0; }();
     return v;
@@ -402,8 +429,8 @@ static int glds_launch_any(const GldsArgs& a, hipStream_t s, int flags) {
     auto tiles = [&](int bn, int bm) { return groups * ((M + bm - 1) / bm) * (a.Cout / bn); };
     int bn = ((flags >> 8) & 15) * 64, bm = (flags >> 12) & 1023;
     if (!bn) glds_forced_tile(bn, bm);
-    if (bn && !((bn == 64 || bn == 128 || (bn == 256 && STAGES == 2)) && (bm == 128 || bm == 256 || (bm == 512 && STAGES == 2 && bn == 128)) &&
-                !(bn == 256 && bm != 256)))
+    if (bn && !((bn == 64 || bn == 128 || (bn == 256 && STAGES == 2)) && (bm == 128 || bm == 256 || (bm == 512 && STAGES == 2 && bn == 128) || (bm == 208 && bn == 256)) &&
+                !(bn == 256 && bm != 256 && bm != 208)))
         return YMK_E_BADARG;
     if (!bn || a.Cout % bn) {
         const bool c128 = a.Cout % 128 == 0;
@@ -420,12 +447,26 @@ static int glds_launch_any(const GldsArgs& a, hipStream_t s, int flags) {
         // k-step) wins 5-10 % where there are at least ~3/4 of a round of them and the reduction is long (256 -> 256 s2 at 80^2: 149 -> 138
         // us, 256 -> 512 s2 at 40^2: 80 -> 72, 768 -> 256 1x1 at 40^2: 66 -> 62), loses on short reductions / few tiles (256 -> 768 1x1 at
         // 20^2: 26 -> 33).  The 128 x 512 tile never won (reachable through the flags only).
-        if (STAGES == 2 && a.Cout % 256 == 0 && a.Kpad >= 384 && tiles(256, 256) >= glds_big_min_tiles()) { bn = 256; bm = 256; }
+        if (STAGES == 2 && a.Cout % 256 == 0 && a.Kpad >= 384 && tiles(256, 256) >= glds_big_min_tiles()) {
+            bn = 256; bm = 256;
+            // round 6 (measured, OFF): ONE 256 x 256 workgroup fits a CU, and the detector's maps give 400 tiles (64 images x 40^2:
+            // 1.56 rounds of 256 CUs) or 200 (20^2 x 512 couts: 0.78) — 78 % of the CU-rounds paid for.  A 208-pixel tile (13 fragments: seven in the
+            // first wave row, six in the second, each row its own straight-line copy of the k-step) makes that 493 / 248 tiles: two rounds / one at 96 %,
+            // each tile 13/16 of the MFMAs.  Measured: 256 -> 256 s2 at 40^2 151.8 -> 143.0 us, 256 -> 512 s2 at 20^2 79.0 -> 75.1, the six 1x1 shapes
+            // +-2 %; value 12 940 -> 12 804, value_sync 11 252 -> 11 113 (inside the noise).  A tile's time does not follow its MFMA count: the k-step is
+            // paced by the transfer round trip + barrier of the ONE workgroup a CU holds, so a shorter tile is not a faster tile and the "half-empty
+            // second round" costs what it costs.  Reachable through the flags / YMK_GLDS_TILE208=1; profiles/r06_negative_results.txt item 3.
+            const int64_t cus = glds_cu_count();
+            const int64_t t256 = tiles(256, 256), t208 = tiles(256, 208);
+            const int64_t c256 = ((t256 + cus - 1) / cus) * 256 * 100, c208 = ((t208 + cus - 1) / cus) * 208 * 104;   // (4 % for the tile's poorer staging / MFMA ratio)
+            if (glds_tile208() && c208 < c256) bm = 208;
+        }
     }
     glds_last_tile = bm;
     glds_last_bn = bn;
     if (STAGES == 2) {
         if (bn == 256 && bm == 256) return glds_launch_bm<256, 2, 256>(a, s);
+        if (bn == 256 && bm == 208) return glds_launch_bm<256, 2, 208>(a, s);
         if (bn == 128 && bm == 512) return glds_launch_bm<128, 2, 512>(a, s);
     }
     if (bn == 128) return bm == 256 ? glds_launch_bm<128, STAGES, 256>(a, s) : glds_launch_bm<128, STAGES, 128>(a, s);

@@ -291,13 +291,7 @@ int ymk_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t B, int3
 int ymk_mlp_fused_supported(int32_t dtype, int32_t C, int32_t hidden);
 int ymk_mlp_fused(const void* x, int32_t ldx, const void* w1, int32_t k1pad, const float* b1, const void* w2, int32_t k2pad,
                   const float* b2, void* y, int32_t ldy, int64_t M, int32_t C, int32_t hidden, void* stream);
-/* The same with AAttn's output projection and the ABlock's first skip in front (one kernel per ABlock tail):
- *   x1 = x + Wp a + bp,  y = x1 + W2 SiLU(W1 x1 + b1) + b2   — `self.proj(x + pp)` (nn/modules/block.py:1727-1732) inside
- * `x = x + self.attn(x); x = x + self.mlp(x)` (ABlock.forward, :1787-1797).  a [M][lda] = attention output + positional stencil, wp
- * packed [C][kppad], bp fp32 [C]; x1 is rounded to the 16-bit type where the unfused projection stores it.  C in {128, 256}. */
-int ymk_proj_mlp_fused(const void* a, int32_t lda, const void* wp, int32_t kppad, const float* bp, const void* x, int32_t ldx,
-                       const void* w1, int32_t k1pad, const float* b1, const void* w2, int32_t k2pad, const float* b2, void* y,
-                       int32_t ldy, int64_t M, int32_t C, int32_t hidden, void* stream);
+
 
 /* ------------------------------------------------------------------------
  * Detect decode: DFL softmax-expectation + dist2bbox(xywh) * stride + sigmoid

@@ -67,7 +67,7 @@ def emu(monkeypatch):
 
 
 
-V0_OPS = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "proj_mlp_fused_supported", "proj_mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "esmoe_route", "esmoe_dw",
+V0_OPS = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "esmoe_route", "esmoe_dw",
           "esmoe_pw", "area_attn", "area_attn_qkv_supported", "area_attn_qkv", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32", "detect_decode",
           "nms_batched"]
 
@@ -103,7 +103,7 @@ def hostlib():
     import os
     os.environ.setdefault("YMK_WS_MIN_TILES", "2")   # read when the library is loaded: lets the tiny emulator shapes reach the streaming 1x1 kernel
     h = C.CDLL(str(path))
-    dw = {k: v for k, v in _lib.SYMBOLS.items() if k in ("ymk_mlp_fused_supported", "ymk_mlp_fused", "ymk_proj_mlp_fused", "ymk_stem_pair_supported", "ymk_stem_pair", "ymk_c3k2_fused_supported", "ymk_c3k2_fused", "ymk_c3k2_fused_pool_chunks", "ymk_c3k2_fused_pooled", "ymk_detect_cls_fused_supported", "ymk_detect_cls_fused", "ymk_detect_box_tail_supported", "ymk_detect_box_tail", 
+    dw = {k: v for k, v in _lib.SYMBOLS.items() if k in ("ymk_mlp_fused_supported", "ymk_mlp_fused", "ymk_stem_pair_supported", "ymk_stem_pair", "ymk_c3k2_fused_supported", "ymk_c3k2_fused", "ymk_c3k2_fused_pool_chunks", "ymk_c3k2_fused_pooled", "ymk_detect_cls_fused_supported", "ymk_detect_cls_fused", "ymk_detect_box_tail_supported", "ymk_detect_box_tail", 
                                                          "ymk_esmoe_pw", "ymk_area_attn", "ymk_area_attn_qkv_supported", "ymk_area_attn_qkv", "ymk_nms_workspace_bytes", "ymk_nms_batched",
                                                          "ymk_conv2d", "ymk_conv2d_last_variant", "ymk_dwconv2d")}   # csrc/mlp.hip, stem2.hip, ..., esmoe.hip, attn.hip, nms.hip
     for name, (res, args) in {**_lib.SYMBOLS_MIXTURE, **_lib.SYMBOLS_NEXT, **dw}.items():   # SYMBOLS_NEXT includes csrc/preproc.hip

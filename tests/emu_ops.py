@@ -197,17 +197,6 @@ def mlp_fused(x, w1, b1, w2, b2, out=None):
     return conv2d(h, w2, b2, 1, 1, False, out=out, residual=x)
 
 
-def proj_mlp_fused_supported(dtype, C, hidden):
-    return mlp_fused_supported(dtype, C, hidden) and C >= 128
-
-
-def proj_mlp_fused(a, wp, bp, x, w1, b1, w2, b2, out=None):
-    """include/ymk.h `ymk_proj_mlp_fused`: x1 = x + Wp a + bp (rounded to the activation type), then ymk_mlp_fused on x1."""
-    _count("proj_mlp_fused")
-    x1 = conv2d(a, wp, bp, 1, 1, False, residual=x)
-    return mlp_fused(x1, w1, b1, w2, b2, out=out)
-
-
 # ------------------------------------------------------------------------------------------------- ES-MoE
 def esmoe_route(x, w1, b1, w2, b2, top_k, thr, flags):
     """include/ymk.h `ymk_esmoe_route`: GAP -> MLP -> clamped softmax -> hard top-k -> retained set + CSR."""
@@ -756,7 +745,7 @@ def tokens_to_rows(x, y, a_off, row_off=0):
     return y
 
 
-EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "proj_mlp_fused_supported", "proj_mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "esmoe_route", "esmoe_dw",
+EMULATED = ["conv2d", "conv1x1_cat2", "conv2d_stem", "dwconv2d", "mlp_fused_supported", "mlp_fused", "stem_pair_supported", "stem_pair", "c3k2_fused_supported", "c3k2_fused", "detect_cls_fused_supported", "detect_cls_fused", "detect_box_tail_supported", "detect_box_tail", "esmoe_route", "esmoe_dw",
             "esmoe_pw", "area_attn", "area_attn_qkv_supported", "area_attn_qkv", "upsample2x", "copy_channels", "scale_residual", "nhwc_to_nchw_f32",
             "detect_decode", "nms_batched", "nms_gather_rows",
             "conv2d_act", "group_norm", "layer_norm", "eltwise_mul", "lerp", "fma_gate", "channel_gate", "batch_scale", "weighted_sum",

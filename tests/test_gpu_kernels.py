@@ -184,17 +184,6 @@ def test_mlp_fused(case):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("case", __import__("tests.test_hostemu_mlp", fromlist=["PROJ_CASES"]).PROJ_CASES + [(128, 256, 102400, 0, 0), (256, 512, 25600, 0, 0)])
-def test_proj_mlp_fused(case):
-    """AAttn projection + both ABlock skips + MLP as one kernel (csrc/mlp.hip PROJ) through the C-ABI against the composition in fp32
-    (incl. the detector's sizes)."""
-    from tests.test_hostemu_mlp import run_proj_case
-    from yolo_master_amd import _lib
-
-    run_proj_case(_lib.load(), case, dev=DEV, stream=torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-
-
 @pytest.mark.parametrize("case", __import__("tests.test_hostemu_round2", fromlist=["QKV_ATTN_CASES"]).QKV_ATTN_CASES
                          + [(16, 40, 40, 4, 4, 0, 0), (3, 20, 40, 4, 2, 128, 0), (4, 16, 28, 2, 1, 0, 64)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -60,3 +60,19 @@ def test_specialised_kernels_match_generic_fallbacks(tmp_path, dtype):
         assert same.mean() >= 0.75, "bf16 routing differs between kernel variants on more than a quarter of the images"
         bs = box[same]
         assert np.median(bs) <= 4.0 and np.median(cls[same]) <= 1e-1, (np.median(bs), np.median(cls[same]))
+
+
+def test_qkv_inside_the_attention_kernel_matches_the_two_launch_form(tmp_path):
+    """Round 6: AAttn's qkv 1x1 convolution inside the area-attention kernel (ymk_area_attn_qkv; YMK_DISABLE bit 2097152 = the 1x1
+    convolution + ymk_area_attn).  q, k, v are rounded to bf16 in both forms and every other kernel is the same, so whole-model outputs
+    may differ only through the last bit of a 16-bit q / k / v value (summation order of the projection): routing identical on (nearly)
+    every image, boxes and scores far inside the spread between any two kernel variants above."""
+    a = _run(tmp_path, 0, "bf16")
+    b = _run(tmp_path, 2097152, "bf16")
+    B = a["y"].shape[0]
+    same = (a["routes"] == b["routes"]).reshape(4, B, -1).all(2).all(0)
+    box = np.abs(a["y"][:, :4] - b["y"][:, :4]).reshape(B, -1).max(1)
+    cls = np.abs(a["y"][:, 4:] - b["y"][:, 4:]).reshape(B, -1).max(1)
+    print(f"qkv fused vs unfused: same routing {int(same.sum())}/{B}; boxes median {np.median(box):.3e} max {box.max():.3e}; scores median {np.median(cls):.3e} max {cls.max():.3e}")
+    assert same.mean() >= 0.95
+    assert np.median(box[same]) <= 0.5 and np.median(cls[same]) <= 2e-2, (np.median(box[same]), np.median(cls[same]))

@@ -76,7 +76,6 @@ SYMBOLS = {
     "ymk_detect_box_tail": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
     "ymk_mlp_fused_supported": (C.c_int, [_i32, _i32, _i32]),
     "ymk_mlp_fused": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
-    "ymk_proj_mlp_fused": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ymk_area_attn": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ymk_area_attn_qkv_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "ymk_area_attn_qkv": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -481,12 +481,6 @@ class ABlock(YmkModule):
 
     def _run(self, x, out=None):
         m0, m1 = self.mlp[0], self.mlp[1]
-        pj = self.attn.proj
-        if (ops.proj_mlp_fused_supported(x.dtype, x.shape[-1], m0.conv.out_channels) and _is_silu(m0.act) and not _is_silu(m1.act)
-                and not _is_silu(pj.act) and pj.conv.kernel_size == (1, 1) and pj.cout_perm is None and self.attn.all_head_dim == x.shape[-1]):
-            # the block's tail as ONE kernel: x1 = x + proj(attn(x) + pe(v)) stays in LDS and feeds x1 + mlp(x1) (csrc/mlp.hip PROJ)
-            pp, p0, p1 = pj._packed(x.device), m0._packed(x.device), m1._packed(x.device)
-            return ops.proj_mlp_fused(self.attn._pre_proj(x), pp["w"], pp["b"], x, p0["w"], p0["b"], p1["w"], p1["b"], out=out)
         x1 = self.attn._run(x, residual=x)              # x + attn(x)
         if ops.mlp_fused_supported(x1.dtype, x1.shape[-1], m0.conv.out_channels) and _is_silu(m0.act) and not _is_silu(m1.act):
             p0, p1 = m0._packed(x1.device), m1._packed(x1.device)   # x + mlp(x) as one kernel: the hidden tensor never leaves the CU

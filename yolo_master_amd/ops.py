@@ -488,30 +488,6 @@ def mlp_fused(x, w1, b1, w2, b2, out=None):
     return out
 
 
-def proj_mlp_fused_supported(dtype, C: int, hidden: int) -> bool:
-    """AAttn's projection + both ABlock skips + the MLP as one kernel (csrc/mlp.hip PROJ; C in {128, 256}).  OFF by default (options.py
-    fused_proj_mlp, YMK_ENABLE bit 1024): slower with several batches in flight."""
-    return mlp_fused_supported(dtype, C, hidden) and C >= 128 and OPTIONS.fused_proj_mlp
-
-
-def proj_mlp_fused(a, wp, bp, x, w1, b1, w2, b2, out=None):
-    """x1 = x + Wp a + bp;  y = x1 + W2 SiLU(W1 x1 + b1) + b2 per token (include/ymk.h ymk_proj_mlp_fused): a = attention output +
-    positional stencil, x = the ABlock's input; all NHWC 16-bit views of one shape."""
-    B, H, W, Cc, lda = _nhwc(a)
-    ldx = _nhwc(x)[4]
-    assert tuple(x.shape) == tuple(a.shape)
-    hidden = w1.shape[0]
-    if out is None:
-        out = new_act(B, H, W, Cc, x.dtype, x.device)
-    ldy = _nhwc(out)[4]
-    e0 = TIMER.begin()
-    check(lib.ymk_proj_mlp_fused(_p(a), lda, _p(wp), wp.shape[1], _p(bp), _p(x), ldx, _p(w1), w1.shape[1], _p(b1), _p(w2), w2.shape[1], _p(b2),
-                                 _p(out), ldy, B * H * W, Cc, hidden, _stream()), "proj_mlp_fused")
-    TIMER.end(e0, "proj_mlp_fused", (3 * B * H * W * Cc + Cc * Cc + 2 * Cc * hidden) * x.element_size(), 2 * B * H * W * Cc * (Cc + 2 * hidden),
-              f"{Cc}->{Cc}->{hidden}->{Cc} @{H}x{W}")
-    return out
-
-
 # ----------------------------------------------------------------------------- attention
 def area_attn(qkv, heads: int, area: int, out=None):
     B, H, W, C3, ldq = _nhwc(qkv)

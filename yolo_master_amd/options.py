@@ -22,10 +22,6 @@ below marked (C) are read there as well, from the same variables.
                                                            (ymk_conv1x1_pooled): the router pools those instead of re-reading the map (-> plain convolution)
 
     field                   default   YMK_ENABLE bit       what it selects
-    fused_proj_mlp          off       1024                 AAttn's projection + both ABlock skips + MLP as ONE kernel (csrc/mlp.hip PROJ): 8 launches and
-                                                           0.05 ms of eager kernel time less per step, +0.5 % on the one-batch-at-a-time rate, but -1.8 % on the
-                                                           three-batches-in-flight rate (six interleaved rounds, profiles/r05_negative_results.txt): a persistent
-                                                           one-wave-per-SIMD workgroup holds its CU longer than the two kernels it replaces
     detect_level_streams    off       16                   a side HIP stream per Detect level (measured slower: profiles/r03_negative_results.txt)
     detect_early_levels     off       32                   Detect levels launched as soon as their input map exists (no gain on top of the batch pipeline)
     detect_keep_raw         off       256                  fused decode that ALSO materialises the fp32 logits (`preds["raw"]` without recomputation)
@@ -64,7 +60,6 @@ class Options:
     fused_decode: bool = True
     pooled_producers: bool = True
     fused_qkv_attn: bool = True
-    fused_proj_mlp: bool = False
     detect_level_streams: bool = False
     detect_early_levels: bool = False
     detect_keep_raw: bool = False
@@ -81,7 +76,6 @@ class Options:
             chunk = 0.0
         return cls(res_prefetch=not d & 16, expert_conv_glds=not d & 512, fused_mlp=not d & 1024, fused_stem_pair=not d & 2048,
                    fused_c3k2=not d & 8192, fused_detect_cls=not d & 16384, fused_decode=not d & 4194304, pooled_producers=not d & 1048576, fused_qkv_attn=not d & 2097152,
-                   fused_proj_mlp=bool(e & 1024),
                    detect_level_streams=bool(e & 16), detect_early_levels=bool(e & 32), detect_keep_raw=bool(e & 256),
                    moe_chunk_mb=chunk, disable_mask=d, enable_mask=e)
 

@@ -38,6 +38,12 @@
 #ifndef DW_LDS_MODE
 #define DW_LDS_MODE 3
 #endif
+#ifndef DW_EARLY_HALO
+#define DW_EARLY_HALO 0   // 1: the first tile's halo loads are issued before the filter block is staged (A/B builds)
+#endif
+#ifndef DW_PAIRDOT_PF
+#define DW_PAIRDOT_PF 0   // 1: the dot2 stencil walks runs of tiles with the next halo prefetched into registers (A/B builds)
+#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -342,20 +348,12 @@ __device__ __forceinline__ void dw_run_pairdot(const T* __restrict__ xb, int H, 
     constexpr int NPC = HT * NPR * 2;                 // staged pieces: (pixel pair, 8-channel half)
     constexpr int NL = (NPC + 255) / 256;
     constexpr int RP = D::row_pitch(K);
+    constexpr bool PF = DW_PAIRDOT_PF != 0;
     const int t = threadIdx.x;
     const int tiles_x = (W + TW - 1) / TW;
     const int c0 = cb * D::CB;
     uint32_t* wsw = reinterpret_cast<uint32_t*>(smem + (size_t)HT * RP);
 
-    // filter block: word ((ky * 4 + group) * 2 + parity) * NW + m, channel ci = (tap lo, tap hi) with the taps (2m, 2m + 1) for even
-    // output pixels and (2m - 1, 2m) for odd ones; taps outside [0, K) and channels past C are zero
-    for (int i = t; i < K * D::NCG * 2 * NW * 4; i += 256) {
-        const int ci = i & 3, m = (i >> 2) % NW, par = ((i >> 2) / NW) & 1, cg = ((i >> 2) / (2 * NW)) % D::NCG, ky = (i >> 2) / (2 * NW * D::NCG);
-        const int c = c0 + cg * 4 + ci, tlo = 2 * m - par, thi = tlo + 1;
-        const uint32_t lo = (tlo >= 0 && tlo < K && c < C) ? w[(size_t)(ky * K + tlo) * C + c] : 0u;
-        const uint32_t hi = (thi >= 0 && thi < K && c < C) ? w[(size_t)(ky * K + thi) * C + c] : 0u;
-        wsw[i] = lo | (hi << 16);
-    }
     const int cg = t % D::NCG;
     const int strip = (t / D::NCG) % D::STRIPS;
     const int y = t / (D::NCG * D::STRIPS);
@@ -366,10 +364,10 @@ __device__ __forceinline__ void dw_run_pairdot(const T* __restrict__ xb, int H, 
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(ep.bias + c0 + cg * 4);
         bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
     }
-    for (int st = st0; st < st1; ++st) {
+    // halo staging: a piece = the same 8 channels of the two pixels of a pair (two 16-byte loads, issued back to back for all pieces)
+    u32x4 sa[NL], sb[NL];
+    auto gload = [&](int st) {
         const int ty0 = (st / tiles_x) * TH, tx0 = (st % tiles_x) * TW;
-        // halo staging: a piece = the same 8 channels of the two pixels of a pair (two 16-byte loads, issued back to back for all pieces)
-        u32x4 sa[NL], sb[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const int i = t + l * 256;
@@ -384,6 +382,24 @@ __device__ __forceinline__ void dw_run_pairdot(const T* __restrict__ xb, int H, 
             }
             sa[l] = va; sb[l] = vb;
         }
+    };
+    // PF (DW_PAIRDOT_PF builds): the workgroup walks a RUN of tiles and the next tile's halo is requested right after the current one has been
+    // written to LDS — in flight under the stencil and the output stores — instead of at the top of its own pass
+    // EARLY: the first halo is requested BEFORE the filter block is staged (two dependent-free round trips in flight together instead of one after the other)
+    constexpr bool EARLY = PF || DW_EARLY_HALO != 0;
+    if (EARLY && st0 < st1) gload(st0);
+    // filter block: word ((ky * 4 + group) * 2 + parity) * NW + m, channel ci = (tap lo, tap hi) with the taps (2m, 2m + 1) for even
+    // output pixels and (2m - 1, 2m) for odd ones; taps outside [0, K) and channels past C are zero
+    for (int i = t; i < K * D::NCG * 2 * NW * 4; i += 256) {
+        const int ci = i & 3, m = (i >> 2) % NW, par = ((i >> 2) / NW) & 1, cg = ((i >> 2) / (2 * NW)) % D::NCG, ky = (i >> 2) / (2 * NW * D::NCG);
+        const int c = c0 + cg * 4 + ci, tlo = 2 * m - par, thi = tlo + 1;
+        const uint32_t lo = (tlo >= 0 && tlo < K && c < C) ? w[(size_t)(ky * K + tlo) * C + c] : 0u;
+        const uint32_t hi = (thi >= 0 && thi < K && c < C) ? w[(size_t)(ky * K + thi) * C + c] : 0u;
+        wsw[i] = lo | (hi << 16);
+    }
+    for (int st = st0; st < st1; ++st) {
+        const int ty0 = (st / tiles_x) * TH, tx0 = (st % tiles_x) * TW;
+        if (!PF && !(EARLY && st == st0)) gload(st);
         __syncthreads();  // the previous tile's LDS reads are finished (first pass: nothing pending)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -407,6 +423,7 @@ __device__ __forceinline__ void dw_run_pairdot(const T* __restrict__ xb, int H, 
             }
         }
         __syncthreads();  // halo (and, first pass, the filter block) visible
+        if (PF && st + 1 < st1) gload(st + 1);
         const int gy = ty0 + y;
         if (!chan_ok || gy >= H || tx0 + x0 >= W) continue;
         float acc[DW_R][4];
@@ -537,7 +554,7 @@ static void launch_dw_k(const DwArgs& a, int nrun, hipStream_t s) {
 template <typename T, int TW>
 static int launch_dw_tw(DwArgs a, int k, hipStream_t s) {
     const bool prefetch = k <= 15 && DwTile<T, TW>::prefetch(k);
-    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, a.B, prefetch);
+    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, a.B, prefetch || (DW_PAIRDOT_PF && sizeof(T) == 2));
     a.ncb = g.ncb; a.nsp = g.nsp; a.spt = g.spt;
     switch (k) {
         case 1: launch_dw_k<T, 1, TW>(a, g.nrun, s); break;
@@ -629,7 +646,7 @@ static int launch_moe_dw_k(MoeDwArgs a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_once.done();
     }
-    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, (int64_t)a.B * a.top_k, DwTile<T, TW>::prefetch(KMAX));
+    const DwGeom g = dw_geom<T>(a.H, a.W, a.C, TW, (int64_t)a.B * a.top_k, DwTile<T, TW>::prefetch(KMAX) || (DW_PAIRDOT_PF && sizeof(T) == 2));
     a.ncb = g.ncb; a.nsp = g.nsp; a.spt = g.spt;
     hipLaunchKernelGGL((moe_dw_kernel<T, TW, KMAX>), dim3(g.nrun * g.ncb, a.B * a.top_k), dim3(256), shm, s, a);
     return ymk_launch_status();

@@ -32,7 +32,7 @@ TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float3
 
 # op family (yolo_master_amd.ops TIMER) -> kernel-name prefix in the rocprofv3 output; single-kernel families only
 FAMILY_KERNEL = {
-    "moe_pw": "moe_pw_", "moe_dw": "moe_dw_kernel<", "dwconv": "dwconv_kernel<", "area_attn": "area_attn_kernel<",
+    "moe_pw": "moe_pw_", "moe_dw": "moe_dw_kernel<", "dwconv": "dwconv_kernel<", "area_attn": "area_attn_re", "area_attn_qkv": "area_attn_qkv_kernel<",
     "detect_decode": "detect_decode_kernel", "stem": "stem_",
 }
 

@@ -733,3 +733,12 @@ def test_detect_cls_fused(case):
     d = (y - got).abs()
     scale = max(1.0, float(y.abs().max()))
     assert float(d.max()) <= 4e-2 * scale and float(d.mean()) <= 3e-4 * scale, f"max {float(d.max()):.3e} mean {float(d.mean()):.3e}"
+
+
+def test_nms_iou_threshold_ties():
+    """IoU thresholds exactly on / one ulp off a pair's float32 IoU: the greedy pass decides as the reference's `inter / union > thr` does —
+    kept sets bit-exact against the oracle."""
+    from tests.test_hostemu_round2 import run_nms_threshold_ties
+    from yolo_master_amd.nms import non_max_suppression
+
+    run_nms_threshold_ties(lambda y, c, t, **kw: non_max_suppression(y.to(DEV), c, t, **kw))

@@ -253,3 +253,49 @@ def test_esmoe_depthwise_stage(case, host_ops):
     tol = 2e-2 if dtype != torch.float32 else 2e-5
     err = float((got[live].float() - ref[live].float()).abs().max())
     assert err <= tol * max(1.0, float(ref[live].float().abs().max())), err
+
+
+def run_nms_threshold_ties(nms_fn):
+    """IoU thresholds that sit EXACTLY on, one ulp below and one ulp above the float32 IoU of a pair of the scene — and, in the same
+    image, hundreds of pairs at random overlaps — must give the oracle's kept set (the reference's `inter / union > thr`, utils/nms.py).  Shared
+    with tests/test_gpu_kernels.py."""
+    from oracle import nms_ref
+
+    g = torch.Generator().manual_seed(77)
+    npair = 260
+    cx = (torch.arange(npair) % 20).float() * 30 + 20 + torch.rand(npair, generator=g)
+    cy = (torch.arange(npair) // 20).float() * 40 + 20 + torch.rand(npair, generator=g)
+    w0, h0 = torch.rand(npair, generator=g) * 8 + 12, torch.rand(npair, generator=g) * 8 + 12
+    dx, dy = (torch.rand(npair, generator=g) - 0.5) * 14, (torch.rand(npair, generator=g) - 0.5) * 14      # second box of the pair: shifted, own size
+    w1, h1 = torch.rand(npair, generator=g) * 8 + 12, torch.rand(npair, generator=g) * 8 + 12
+    xywh = torch.stack([torch.cat([cx, cx + dx]), torch.cat([cy, cy + dy]), torch.cat([w0, w1]), torch.cat([h0, h1])])       # [4, 2 npair]
+    score = torch.cat([torch.rand(npair, generator=g) * 0.3 + 0.6, torch.rand(npair, generator=g) * 0.3 + 0.3])           # the first box of a pair ranks higher
+    y = torch.cat([xywh, score[None]], 0)[None].contiguous()                                                                  # [1, 5, A], one class
+    # float32 IoU of pair 0, computed the reference's way
+    b = nms_ref.xywh2xyxy(y[0, :4].t().numpy()) if hasattr(nms_ref, "xywh2xyxy") else None
+    if b is None:
+        c = y[0, :4].t().numpy().astype(np.float32)
+        b = np.stack([c[:, 0] - c[:, 2] / np.float32(2), c[:, 1] - c[:, 3] / np.float32(2), c[:, 0] + c[:, 2] / np.float32(2), c[:, 1] + c[:, 3] / np.float32(2)], 1)
+    ious = []
+    for p in (0, 1, 2, 3):
+        a0, a1 = b[p], b[npair + p]
+        iw = max(np.float32(0), min(a0[2], a1[2]) - max(a0[0], a1[0])); ih = max(np.float32(0), min(a0[3], a1[3]) - max(a0[1], a1[1]))
+        inter = np.float32(iw * ih)
+        ar0, ar1 = np.float32((a0[2] - a0[0]) * (a0[3] - a0[1])), np.float32((a1[2] - a1[0]) * (a1[3] - a1[1]))
+        ious.append(np.float32(inter / np.float32(np.float32(ar0 + ar1) - inter)))
+    thrs = []
+    for v in ious:
+        if 0.05 < v < 0.95:
+            thrs += [float(v), float(np.nextafter(v, np.float32(0))), float(np.nextafter(v, np.float32(1)))]
+    assert len(thrs) >= 3, ious
+    for thr in thrs + [0.45, 0.7]:
+        ref, ref_idx = nms_ref.non_max_suppression(y.numpy(), 0.25, thr, return_idxs=True, max_det=600)
+        got, got_idx = nms_fn(y, 0.25, thr, return_idxs=True, max_det=600)
+        assert np.array_equal(np.asarray(got_idx[0].cpu()), ref_idx[0]), f"iou threshold {thr!r}: kept anchors differ"
+        assert np.array_equal(np.asarray(got[0].cpu()), ref[0]), f"iou threshold {thr!r}: detections differ"
+
+
+def test_nms_iou_threshold_ties(host_ops):
+    from yolo_master_amd.nms import non_max_suppression
+
+    run_nms_threshold_ties(non_max_suppression)

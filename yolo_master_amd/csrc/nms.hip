@@ -635,13 +635,28 @@ __global__ __launch_bounds__(NW * 64) void nms_greedy_kernel(NmsWs w, float thr,
     const float* sb = w.sbox + (size_t)b * w.ns * 4;
     const int* sc = w.scls + (size_t)b * w.ns;
     int kept = 0;
+    // the NEXT chunk's candidates are requested while this chunk is resolved: every chunk used to start with its own exposed global round trip
+    // (a few thousand candidates = ~50 chunks per image: a third of the pass was that wait)
+    f32x4 nbx = {0.f, 0.f, 0.f, 0.f};
+    int ncl = 0, nan_ = 0;      // wave 0 (the one that emits the kept rows) also carries the candidates' scores and anchor ids: no load inside the resolve
+    float nsc = 0.f;
+    if (lane < n) {
+        nbx = *reinterpret_cast<const f32x4*>(sb + (size_t)lane * 4); ncl = sc[lane];
+        if (wave == 0) { nsc = w.sscore[(size_t)b * w.ns + lane]; nan_ = w.sanchor[(size_t)b * w.ns + lane]; }
+    }
     for (int i0 = 0; i0 < n && kept < max_det; i0 += 64) {
         const int i = i0 + lane;
         float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+        const f32x4 rbx = nbx;
+        const int rcl = ncl, ran = nan_;
+        const float rsc = nsc;
         if (i < n) {
-            const f32x4 bx = *reinterpret_cast<const f32x4*>(sb + (size_t)i * 4);
-            const float c = (float)sc[i] * cls_off;
-            x1 = bx.x + c; y1 = bx.y + c; x2 = bx.z + c; y2 = bx.w + c;
+            const float c = (float)rcl * cls_off;
+            x1 = rbx.x + c; y1 = rbx.y + c; x2 = rbx.z + c; y2 = rbx.w + c;
+        }
+        if (i + 64 < n) {
+            nbx = *reinterpret_cast<const f32x4*>(sb + (size_t)(i + 64) * 4); ncl = sc[i + 64];
+            if (wave == 0) { nsc = w.sscore[(size_t)b * w.ns + i + 64]; nan_ = w.sanchor[(size_t)b * w.ns + i + 64]; }
         }
         const float ai = (x2 - x1) * (y2 - y1);
         // phase A: against this wavefront's share of the kept list
@@ -653,7 +668,7 @@ __global__ __launch_bounds__(NW * 64) void nms_greedy_kernel(NmsWs w, float thr,
             const float xx2 = fminf(kx2[k], x2), yy2 = fminf(ky2[k], y2);
             const float ww = fmaxf(xx2 - xx1, 0.f), hh = fmaxf(yy2 - yy1, 0.f);
             const float inter = ww * hh;
-            const float iou = inter / ((kar[k] + ai) - inter);
+            const float iou = inter / ((kar[k] + ai) - inter);   // (deciding from inter against thr * union with the division only in a 2^-21 band: 209 vs 184 us — the branches cost more than the division)
             sup |= !(iou <= thr);
         }
         // (leaving the loop early once every candidate of the chunk is known to be suppressed — the waves publishing their ballots every
@@ -689,7 +704,10 @@ __global__ __launch_bounds__(NW * 64) void nms_greedy_kernel(NmsWs w, float thr,
             while (rem) {
                 const int t = __builtin_ctzll(rem);
                 rem &= rem - 1ull;
-                const unsigned long long mt = __shfl(mine, t);  // who (earlier in the chunk) suppresses t
+                // who (earlier in the chunk) suppresses t: t is wave-uniform, so this is two v_readlane_b32 — a __shfl here was a ds_bpermute
+                // round trip through the LDS crossbar per visited candidate, in the one serial section of the pass
+                const unsigned long long mt = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), t) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffull), t);
                 if (!(mt & km)) km |= 1ull << t;
             }
             int cntk = __popcll(km);
@@ -702,11 +720,10 @@ __global__ __launch_bounds__(NW * 64) void nms_greedy_kernel(NmsWs w, float thr,
             if ((km >> lane) & 1ull) {
                 const int pos = kept + __popcll(km & ((1ull << lane) - 1ull));
                 kx1[pos] = x1; ky1[pos] = y1; kx2[pos] = x2; ky2[pos] = y2; kar[pos] = ai;
-                const size_t s = (size_t)b * w.ns + i;
                 float* o = out_dets + ((size_t)b * max_det + pos) * 6;
-                o[0] = w.sbox[s * 4 + 0]; o[1] = w.sbox[s * 4 + 1]; o[2] = w.sbox[s * 4 + 2]; o[3] = w.sbox[s * 4 + 3];
-                o[4] = w.sscore[s]; o[5] = (float)w.scls[s];
-                out_idx[(size_t)b * max_det + pos] = w.sanchor[s];
+                o[0] = rbx.x; o[1] = rbx.y; o[2] = rbx.z; o[3] = rbx.w;
+                o[4] = rsc; o[5] = (float)rcl;
+                out_idx[(size_t)b * max_det + pos] = ran;
                 w.keep_pos[(size_t)b * NMS_MAXDET_CAP + pos] = i;
             }
             if (lane == 0) kmask = km;

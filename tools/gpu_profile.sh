@@ -10,7 +10,7 @@ python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --split 1 -
 set +e
 BENCH="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --split 1 --pipeline 1 --no-sync-leg"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_trace -- $BENCH > $R/gpurun_out/${TAG}_trace.log 2>&1
-python $R/tools/prof_summary.py $(ls $R/gpurun_out/${TAG}_trace/*/*.db | head -1) 13 > $R/gpurun_out/${TAG}_kernel_stats.txt 2>&1
+python $R/tools/prof_summary.py $(ls $R/gpurun_out/${TAG}_trace/*/*.db | head -1) 15 > $R/gpurun_out/${TAG}_kernel_stats.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 240 rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/${TAG}_pmc_$C -- $BENCH > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
   python $R/tools/pmc_summary.py $(ls $R/gpurun_out/${TAG}_pmc_$C/*/*.db | head -1) > $R/gpurun_out/${TAG}_pmc_$C.json 2>&1

@@ -88,7 +88,7 @@ def _match(gb, rb, box_tol, score_tol, allow_extra=False):
     return torch.tensor(perm), torch.tensor(flipped)
 
 
-def _same_detections(got, ref, box_tol=1e-2, score_tol=1e-4, masks_filtered=False):
+def _same_detections(got, ref, box_tol=1e-2, score_tol=1e-4, masks_filtered=False, strict=False):
     """masks_filtered (segment): the predictor drops every detection whose mask has no positive pixel (`masks.amax((-2, -1)) > 0`,
     models/yolo/segment/predict.py:107-109), so WHICH detections survive depends on the sign of the largest mask logit inside each box — with
     ill-conditioned masks on arithmetic the two runs do not share (seen with the plain seeded weights: 203 hooked against 203 or 137
@@ -114,7 +114,7 @@ def _same_detections(got, ref, box_tol=1e-2, score_tol=1e-4, masks_filtered=Fals
         assert g.orig_shape == r.orig_shape and g.names == r.names
         n += small.shape[0]
     nflip = int(sum(int(f.sum()) for f in flips))
-    assert nflip <= max(2, n // 50), f"{nflip} of {n} detections are score-tie flips"
+    assert nflip <= (0 if strict else max(2, n // 50)), f"{nflip} of {n} detections are score-tie flips" + (" (strict: none allowed)" if strict else "")
     _same_detections.flips, _same_detections.swaps = flips, swaps
     return n, perms
 
@@ -138,6 +138,16 @@ def test_reference_predict_on_the_gpu_through_the_hooks():
         assert st["calls"] >= 1 and st["nms_calls"] >= 1, st
         n, _ = _same_detections(got, ref)
         print(f"reference predict(device=0) through the libymk hooks: {n} detections identical in class, <= 1e-4 in score, <= 1e-2 px; hook stats {st}")
+        # beside the relaxed high-recall configuration, a STRICT one — the default confidence (far fewer candidates, no crowds of
+        # near-identical scores): every reference detection must have its counterpart position for position in box and score, no tie flip allowed
+        kw_strict = dict(kw, conf=0.25)
+        ref_s = _yolo().predict(x, **kw_strict)
+        got_s = m.predict(x, **kw_strict)
+        if all(r.boxes.data.shape[0] > 0 for r in ref_s):
+            ns, _ = _same_detections(got_s, ref_s, strict=True)
+            print(f"  strict configuration (conf 0.25): {ns} detections, no tie flips")
+        else:
+            assert [g.boxes.data.shape[0] for g in got_s] == [r.boxes.data.shape[0] for r in ref_s]
         core = m.model
         before = dropin.stats(m)["fallbacks"]
         core._predict_once(x.to(DEV), profile=False, visualize=False, embed=[1])     # an embed call is the reference's business

@@ -57,6 +57,14 @@ def test_bench_reports_the_synchronised_convention_beside_the_pipelined_rate():
     assert d["p50_batch_latency_ms"] >= d["ms_per_step"] * 0.9 and "p50_ms_per_image" not in d
     assert d["op_calls_per_step"] > 50 and len(d["retained_pairs"]) == 4 and all(8 <= v <= 16 for v in d["retained_pairs"].values())
     assert "sub-batches" in d["config"]["sync_launch"] and d["config"]["nms"].startswith("NMS conf 0.25")
+    # round 6: the driver's record keeps `config` and `roofline` and drops unknown top-level keys — the convention numbers live there too
+    c, r = d["config"], d["roofline"]
+    assert c["value_sync"] == d["value_sync"] and c["p50_batch_ms_sync"] == d["p50_batch_ms_sync"] and c["pipeline_depth"] == 3
+    assert c["forward_only_sync"] == d["forward_only_sync"] and r["value_sync"] == d["value_sync"]
+    # roofline.frac = achieved / peak of the SCOPE it names (the dominant kernel's layer group where there is one), kernel_frac = the kernel alone
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 2e-4 and abs(r["kernel_frac"] - r["kernel_achieved"] / r["kernel_peak"]) <= 2e-4
+    assert r["scope"] and 0 < r["frac"] <= 1 and 0 < r["kernel_frac"] <= 1
+    assert set(r["step"]) >= {"hbm_frac", "mfma_frac", "hbm_frac_sync", "mfma_frac_sync"}
 
 
 def test_bench_rccl_code_path_at_world_size_one():

@@ -620,8 +620,9 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                      pack_h16x2(a1.x + b1.x, a1.y + b1.y), pack_h16x2(a1.z + b1.z, a1.w + b1.w)};
     };
     // EVERY x tile of the wave is requested at once and stays in registers through the three passes (AT_QKV_MAXT x KS x 4 registers: the
-    // attention phase's registers are not live yet): one exposed round trip for x instead of one per tile and pass — a first form that
-    // streamed the tiles two or three deep through each pass spent ~22 us per launch in this phase, all of it waiting
+    // attention phase's registers are not live yet): one exposed round trip for x instead of one per tile and pass.  Measured against the forms
+    // that streamed the tiles two / three deep through two passes: 85.9 us per launch against 85.5 / 91.6 — the phase costs ~22 us either way
+    // (44 us run alone: profiles/r06_negative_results.txt item 1); this form reads x once
     // (pass order V, Q, K — the storing passes first, their stores retiring under the later ones — measured 90.5 us against 85.9: nine more spilled registers)
     u32x4 w[2][KS];
     wload(0, w);

@@ -11,7 +11,7 @@ bash tools/gpu_pmc.sh $TAG "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS
 cd /tmp && export TMPDIR=/tmp
 CFG5="--cfg yolo-master-moa-mot.yaml --scale l --imgsz 1280 --batch 16 --dtype f16 --cluster --sigma 0.1 --dense --imbalance 8,3"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_cfg5_trace -- python $R/bench.py $CFG5 --steps 3 --warmup 1 --no-cpu-baseline --no-graph --split 1 --pipeline 1 --no-sync-leg > $R/gpurun_out/${TAG}_cfg5_trace.log 2>&1
-python $R/tools/prof_summary.py $(ls $R/gpurun_out/${TAG}_cfg5_trace/*/*.db | head -1) 7 > $R/gpurun_out/${TAG}_cfg5_kernel_stats.txt 2>&1
+python $R/tools/prof_summary.py $(ls $R/gpurun_out/${TAG}_cfg5_trace/*/*.db | head -1) 9 > $R/gpurun_out/${TAG}_cfg5_kernel_stats.txt 2>&1
 rm -rf $R/gpurun_out/${TAG}_cfg5_trace
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_gtrace -- python $R/bench.py --steps 200 --warmup 6 --no-cpu-baseline --no-sync-leg > $R/gpurun_out/${TAG}_gtrace.log 2>&1
 ( echo "# rocprofv3 --kernel-trace of bench.py --steps 200 --warmup 6 --no-sync-leg (hipGraph replays, three batches in flight);"

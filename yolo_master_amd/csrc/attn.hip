@@ -215,6 +215,9 @@ __device__ __forceinline__ float at_rowgroup_sum(float v) {
 #ifndef AT_QKV_ABLATE
 #define AT_QKV_ABLATE 0   // tools/micro stage ablation of the projection phase (bits): 1 no x loads, 2 one weight load for all passes, 4 no q / v stores, 16 no attention phase
 #endif
+#ifndef AT_QKV_WLDS
+#define AT_QKV_WLDS 1   // the K / V weight rows of area_attn_qkv_kernel staged through LDS at kernel start (0: fetched per pass by every wave)
+#endif
 #define AT_QKV_MAXT 7   // token tiles per wave in the projection phase of area_attn_qkv_kernel (all resident in registers): Na <= 16 * 4 * 7
 #ifndef AT_NQ2_NP
 #define AT_NQ2_NP 3   // key-tile pairs per chunk when two query tiles walk together (4: 61 spilled registers at three waves per SIMD, 3: 18)
@@ -638,6 +641,29 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             else xf[i][ks] = *reinterpret_cast<const u32x4*>(xb + (size_t)tok * ldx + ks * 32 + g * 8);
         }
     }
+#if AT_QKV_WLDS
+    // The K and V weight rows of the head travel through LDS (the V^T region: not written before pass V) instead of being fetched by every wave at
+    // the top of its pass: requested here, together with x and W_q, they cost no round trip of their own.  Image: [part][row block mt][lane fi] rows of
+    // 64 KS + 16 bytes (consecutive fragment rows 68 dwords apart: the sixteen rows of a ds_read_b128 lane group cover the 64 banks once).
+    constexpr int WPITCH = 64 * KS + 16;
+    char* sWst = reinterpret_cast<char*>(sVt);
+    {
+        constexpr int CPRW = 4 * KS;                   // 16-byte chunks per weight row
+        for (int i = t; i < 2 * 32 * CPRW; i += AT_NT) {
+            const int part = i / (32 * CPRW), r = (i / CPRW) % 32, c = i % CPRW;     // r = mt * 16 + fi
+            const int row = 8 * ((r & 15) >> 2) + ((r & 15) & 3) + 4 * (r >> 4);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wqkv + (size_t)((1 + part) * C + h * 32 + row) * Kpad + c * 8);
+            *reinterpret_cast<u32x4*>(sWst + (size_t)(part * 32 + r) * WPITCH + c * 16) = v;
+        }
+    }
+    auto wlds = [&](int part, u32x4 (&wf)[2][KS]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                wf[mt][ks] = *reinterpret_cast<const u32x4*>(sWst + (size_t)(part * 32 + mt * 16 + fi) * WPITCH + ks * 64 + g * 16);
+    };
+#endif
     {   // ---- pass Q: parked in `out` --------------------------------------------------------------------------------------------
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + h * 32 + 8 * g), b1 = *reinterpret_cast<const f32x4*>(bias + h * 32 + 8 * g + 4);
 #pragma unroll
@@ -658,7 +684,12 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 #ifndef YMK_HOST_EMU
         __builtin_amdgcn_sched_barrier(0);   // the next pass's weight loads stay BEHIND this pass (hoisted, three weight sets beside the resident x tiles spill)
 #endif
+#if AT_QKV_WLDS
+        __syncthreads();                       // the staged weight rows are complete (their loads had pass Q to arrive)
+        wlds(0, w);
+#else
         if (!(AT_QKV_ABLATE & 2)) wload(1, w);
+#endif
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + C + h * 32 + 8 * g), b1 = *reinterpret_cast<const f32x4*>(bias + C + h * 32 + 8 * g + 4);
 #pragma unroll
         for (int i = 0; i < AT_QKV_MAXT; ++i) {
@@ -678,7 +709,12 @@ __global__ __launch_bounds__(AT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 #ifndef YMK_HOST_EMU
         __builtin_amdgcn_sched_barrier(0);   // the next pass's weight loads stay BEHIND this pass (hoisted, three weight sets beside the resident x tiles spill)
 #endif
+#if AT_QKV_WLDS
+        wlds(1, w);
+        __syncthreads();                       // every wave holds its W_v fragments and is done with the staged rows: V^T may be written over them
+#else
         if (!(AT_QKV_ABLATE & 2)) wload(2, w);
+#endif
 
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 2 * C + h * 32 + 8 * g), b1 = *reinterpret_cast<const f32x4*>(bias + 2 * C + h * 32 + 8 * g + 4);
         const float bt0 = bias[2 * C + h * 32 + wrow], bt1 = bias[2 * C + h * 32 + wrow + 4];   // the channel of this lane in the transposed product
@@ -746,7 +782,13 @@ extern "C" int ymk_area_attn_qkv(int32_t dtype, const void* x, int32_t ldx, cons
     if (B <= 0) return YMK_OK;
     if ((int64_t)B * area * heads >= (1ll << 31)) return YMK_E_BADARG;
     const int Na = N / area, Nk = (Na + 31) & ~31, Nr = (Na + 15) & ~15;
-    const size_t shm = ((size_t)Nr * 32 + (size_t)32 * (Nk + 4)) * sizeof(h16_t);
+    size_t shm = ((size_t)Nr * 32 + (size_t)32 * (Nk + 4)) * sizeof(h16_t);
+#if AT_QKV_WLDS
+    {   // short areas: the staged K / V weight rows (behind K) outgrow the V^T region they borrow
+        const size_t wst = (size_t)Nr * 32 * sizeof(h16_t) + (size_t)2 * 32 * (64 * (C / 32) + 16);
+        shm = shm > wst ? shm : wst;
+    }
+#endif
     const float scale = 0.17677669529663687f;  // 32^-0.5
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((size_t)B * area * heads));

@@ -222,6 +222,14 @@ __device__ __forceinline__ float at_rowgroup_sum(float v) {
 #ifndef AT_NQ2_NP
 #define AT_NQ2_NP 3   // key-tile pairs per chunk when two query tiles walk together (4: 61 spilled registers at three waves per SIMD, 3: 18)
 #endif
+#ifndef AT_SETPRIO
+#define AT_SETPRIO 1   // the two MFMA clusters of a chunk at raised wave priority (cdna_hip_programming.md T5): 63.8 -> 62.5 / 37.7 -> 36.9 / 84.0 -> 82.7 us, three interleaved runs
+#endif
+#if AT_SETPRIO && !defined(YMK_HOST_EMU)
+#define AT_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define AT_PRIO(p) ((void)0)
+#endif
 #ifndef AT_ABLATE
 #define AT_ABLATE 0   // tools/micro stage ablation (bits): 1 K fragments not read, 2 V fragments not read, 4 no exp2, 8 no score MFMAs, 16 no P V MFMAs
 #endif
@@ -247,6 +255,7 @@ __device__ __forceinline__ void at_chunk(const T* __restrict__ sK, const T* __re
             if (AT_ABLATE & 1) kf[tk][f] = u32x4{(unsigned)tk, (unsigned)fi, 0u, 0u};
             else kf[tk][f] = *reinterpret_cast<const u32x4*>(&sK[(c0 + tk * 16 + fi) * 32 + f * 16 + (sizeof(T) == 2 ? (g ^ ((0 - (fi >> 2)) & 3)) : g) * VEC]);
         }
+    AT_PRIO(1);
 #pragma unroll
     for (int tk = 0; tk < NTILE; ++tk)
 #pragma unroll
@@ -260,6 +269,7 @@ __device__ __forceinline__ void at_chunk(const T* __restrict__ sK, const T* __re
             if (PRECISE) acc *= scale;
             sacc[q][tk] = acc;
         }
+    AT_PRIO(0);
     u32x4 va[sizeof(T) == 2 ? NP : 1][2];
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -313,6 +323,7 @@ __device__ __forceinline__ void at_chunk(const T* __restrict__ sK, const T* __re
         lrun[q] = lrun[q] * resc + lsum;
     }
     if constexpr (sizeof(T) == 2) {
+        AT_PRIO(1);
 #pragma unroll
         for (int u = 0; u < NP; ++u)
 #pragma unroll
@@ -326,6 +337,7 @@ __device__ __forceinline__ void at_chunk(const T* __restrict__ sK, const T* __re
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) mma16<T>(o[q][dt], va[u][dt], pb);
             }
+        AT_PRIO(0);
     } else {
 #pragma unroll
         for (int tk = 0; tk < NTILE; ++tk)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6, call E: the dot2 depthwise stencil with the next tile's halo prefetched into registers (DW_PAIRDOT_PF) at several run lengths
+# round 6, call E (record): the dot2 depthwise stencil with the next tile's halo prefetched into registers (DW_PAIRDOT_PF; the source with that path is
+# parked: tools/micro/parked/dwconv_pairdot_pf.hip.txt) at several run lengths
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
 cp yolo_master_amd/libymk.so /tmp/libymk_tree.so
 one() {  # name lib target

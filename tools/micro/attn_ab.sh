@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round-6 record; the YMK_ATTN_NQ=2 lines need the parked two-query-tile form: tools/micro/parked/attn_nq2.hip.txt)
 # GPU box: resident area attention — two query tiles per pass (YMK_ATTN_NQ=2) and the stage ablation of the kernel (tools/micro/_dwab/libymk_at*.so,
 # built by `bash tools/micro/attn_ab.sh build` on the build host: AT_ABLATE bits 1 K reads, 2 V reads, 4 exp2, 8 score MFMAs, 16 P V MFMAs)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R

@@ -657,6 +657,13 @@ def main():
                 if res["roofline_step"] else None
             res["roofline"]["value_sync"] = res["value_sync"]
             res["roofline"]["p50_batch_ms_sync"] = res["p50_batch_ms_sync"]
+            # (the driver's record keeps `roofline` whole and drops unknown top-level keys: what a reader of that record needs is repeated here)
+            res["roofline"]["op_calls_per_step"] = res["op_calls_per_step"]
+            res["roofline"]["layers"] = None if not res["roofline_layers"] else {
+                k: {q: v[q] for q in ("ms_per_step_eager", "hbm_frac", "mfma_frac")} for k, v in res["roofline_layers"].items()}
+            res["roofline"]["counter_gb_per_step"] = None if not (res["roofline_step"] and res["roofline_step"]["counter"]) else round(
+                res["roofline_step"]["counter"]["fetch_gb"] + res["roofline_step"]["counter"]["write_gb"], 2)
+            res["roofline"]["layer_fused_gb_per_step"] = None if not res["roofline_step"] else round(res["roofline_step"]["layer_fused_bytes"] / 1e9, 3)
         if world == 1 and not a.no_cpu_baseline and a.cfg is None:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.scale)

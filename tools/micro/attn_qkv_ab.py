@@ -15,7 +15,7 @@ from yolo_master_amd import ops  # noqa: E402
 
 tag = sys.argv[2] if len(sys.argv) > 2 else "tree"
 dev = torch.device("cuda")
-B, H, heads, area = 64, 40, 4, 4
+B, H, heads, area = (64, 40, 4, 4) if os.environ.get("QKV_SHAPE", "40") == "40" else (64, 20, 8, 1)
 C = heads * 32
 g = torch.Generator().manual_seed(1)
 x = torch.randn(B, H, H, C, generator=g).to(torch.bfloat16).to(dev)
@@ -53,7 +53,7 @@ unfused()
 ref_o, ref_v = o.clone(), qkv[..., 2 * C:].clone()
 fused()
 torch.cuda.synchronize()
-print(f"{tag:20s} conv 128->384 + area_attn {timeit(unfused):7.1f} us   area_attn_qkv {timeit(fused):7.1f} us   "
+print(f"{tag:20s} [{H}^2 C{C}] conv + area_attn {timeit(unfused):7.1f} us   area_attn_qkv {timeit(fused):7.1f} us   "
       f"max |o - o'| {float((o.float() - ref_o.float()).abs().max()):.2e}  v differs in {float((v != ref_v).float().mean()):.4f}", flush=True)
 if len(sys.argv) > 1:
     shutil.copy("/tmp/libymk_keep.so", here)
